@@ -1,0 +1,35 @@
+"""Builds libadmm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["csrc/admm_hip.hip", "csrc/host_setup.cpp"]
+HEADERS = ["csrc/kernels.hpp", "csrc/device_math.hpp", "csrc/host_setup.hpp", "../include/admm_hip.h"]
+OUT = os.path.join(HERE, "libadmm_hip.so")
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> admm-elastic_amd/libadmm_hip.so.  Returns the path."""
+    if not force and not needs_build():
+        return OUT
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-result"] + [os.path.join(HERE, s) for s in SOURCES] + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT

@@ -1,0 +1,158 @@
+"""ctypes binding of include/admm_hip.h (the C ABI of libadmm_hip.so).
+
+This is the stub a maintainer of the reference would add to drive the GPU hot path from Python; the
+C++ mirror of the reference classes (host/) binds the same symbols.  There is NO CPU fallback: if
+the shared library is missing or no HIP device is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(HERE, "libadmm_hip.so")
+
+
+class AdmmHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("admm_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int32)
+
+
+class Desc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32),
+        ("n_verts", C.c_int32), ("masses", c_double_p), ("dt", C.c_double),
+        ("n_tets", C.c_int32), ("tet_idx", c_int_p), ("tet_Binv", c_double_p), ("tet_weight", c_double_p),
+        ("tet_kind", c_int_p), ("tet_mu", c_double_p), ("tet_lambda", c_double_p), ("tet_k", c_double_p),
+        ("n_tris", C.c_int32), ("tri_idx", c_int_p), ("tri_rest", c_double_p), ("tri_weight", c_double_p),
+        ("tri_limit_min", c_double_p), ("tri_limit_max", c_double_p),
+        ("n_pins", C.c_int32), ("pin_vert", c_int_p), ("pin_xyz", c_double_p), ("pin_active", c_int_p),
+        ("pin_weight", C.c_double),
+        ("linsolver", C.c_int32), ("constraint_w", C.c_double),
+        ("pcg_max_iters", C.c_int32), ("pcg_tol", C.c_double),
+        ("gs_max_iters", C.c_int32), ("gs_tol", C.c_double), ("gs_omega", C.c_double),
+        ("uzawa_max_iters", C.c_int32), ("uzawa_tol", C.c_double),
+        ("n_obstacles", C.c_int32), ("obstacle_kind", c_int_p), ("obstacle_params", c_double_p),
+        ("gs_colors", c_int_p),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("global_ms", C.c_double), ("local_ms", C.c_double), ("collision_ms", C.c_double),
+        ("inner_iters", C.c_int32), ("admm_iters", C.c_int32), ("step_ms", C.c_double),
+        ("last_solve_converged", C.c_int32), ("n_constraints", C.c_int32),
+    ]
+
+
+# every symbol include/admm_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("admm_hip_last_error", C.c_char_p, []),
+    ("admm_hip_device_count", C.c_int, []),
+    ("admm_hip_create", C.c_int, [C.POINTER(Desc), C.POINTER(C.c_void_p)]),
+    ("admm_hip_destroy", None, [C.c_void_p]),
+    ("admm_hip_set_state", C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    ("admm_hip_get_state", C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    ("admm_hip_set_pins", C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_double_p]),
+    ("admm_hip_step", C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(Stats)]),
+    ("admm_hip_local_step", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
+    ("admm_hip_global_solve", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int_p]),
+    ("admm_hip_num_rows", C.c_int, [C.c_void_p]),
+    ("admm_hip_get_matrix", C.c_int, [C.c_void_p, c_int_p, c_int_p, c_double_p, c_int_p]),
+    ("admm_hip_get_colors", C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    ("admm_hip_comm_unique_id", C.c_int, [C.c_char_p]),
+    ("admm_hip_comm_init", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    ("admm_host_assemble_matrix", C.c_int, [C.POINTER(Desc), c_int_p, c_int_p, c_double_p, c_int_p]),
+    ("admm_host_partition", None, [C.c_int32, C.c_int, C.c_int, c_int_p, c_int_p]),
+    ("admm_host_tet_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
+    ("admm_host_tri_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
+    ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
+    ("admm_host_greedy_coloring", C.c_int, [C.c_int32, c_int_p, c_int_p, c_int_p]),
+]
+
+_lib = None
+
+
+def lib():
+    """Loads libadmm_hip.so (built by build.py / __graft_entry__.build()).  Fails loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path):
+            raise AdmmHipError(-2, "libadmm_hip.so is not built (%s); run `python __graft_entry__.py build`. "
+                                   "There is no CPU fallback for the ADMM hot path." % lib_path)
+        L = C.CDLL(lib_path)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AdmmHipError(rc, lib().admm_hip_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return lib().admm_hip_device_count()
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(c_int_p)
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a if shape is None else a.reshape(shape)
+
+
+def i32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a if shape is None else a.reshape(shape)
+
+
+# ---- host-only helpers (no GPU) ----
+def tet_rest(verts, tets):
+    verts = f64(verts, (-1, 3)); tets = i32(tets, (-1, 4))
+    n = tets.shape[0]
+    Binv = np.empty((n, 9)); vol = np.empty(n)
+    check(lib().admm_host_tet_rest(n, iptr(tets), dptr(verts), dptr(Binv), dptr(vol)))
+    return Binv, vol
+
+
+def tri_rest(verts, tris):
+    verts = f64(verts, (-1, 3)); tris = i32(tris, (-1, 3))
+    n = tris.shape[0]
+    rest = np.empty((n, 4)); area = np.empty(n)
+    check(lib().admm_host_tri_rest(n, iptr(tris), dptr(verts), dptr(rest), dptr(area)))
+    return rest, area
+
+
+def lame(youngs, poisson):
+    mu, la, k = C.c_double(), C.c_double(), C.c_double()
+    lib().admm_host_lame(youngs, poisson, C.byref(mu), C.byref(la), C.byref(k))
+    return mu.value, la.value, k.value
+
+
+def greedy_coloring(rowptr, col):
+    rowptr = i32(rowptr); col = i32(col)
+    n = rowptr.shape[0] - 1
+    color = np.empty(n, dtype=np.int32)
+    nc = lib().admm_host_greedy_coloring(n, iptr(rowptr), iptr(col), iptr(color))
+    return color, nc
+
+
+def partition(n_items, world_size, rank):
+    b, e = C.c_int32(), C.c_int32()
+    lib().admm_host_partition(n_items, world_size, rank, C.byref(b), C.byref(e))
+    return b.value, e.value

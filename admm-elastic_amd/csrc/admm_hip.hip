@@ -1,0 +1,732 @@
+// admm_hip.hip -- context, launch sequencing and the C ABI (include/admm_hip.h) of the MI355X-native
+// ADMM elastic hot path.  gfx950 only.  Reference call stack being replaced: Solver::initialize
+// (src/Solver.cpp:167-261) -> admm_hip_create, Solver::step (src/Solver.cpp:35-110) -> admm_hip_step.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/admm_hip.h"
+#include "host_setup.hpp"
+#include "kernels.hpp"
+
+using namespace admm_k;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(ADMM_HIP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        if (count == 0) { p = nullptr; return hipSuccess; }
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &h) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    hipError_t zero() { return n ? hipMemset(p, 0, n * sizeof(T)) : hipSuccess; }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct SellDev {
+    DevBuf<int> ptr, w, idx;
+    DevBuf<double> val;
+    int n_rows = 0, n_slices = 0;
+    hipError_t upload(const admm_host::Sell &S) {
+        n_rows = S.n_rows; n_slices = S.n_slices;
+        hipError_t e;
+        if ((e = ptr.upload(S.slice_ptr)) != hipSuccess) return e;
+        if ((e = w.upload(S.slice_width)) != hipSuccess) return e;
+        if ((e = idx.upload(S.idx)) != hipSuccess) return e;
+        if (!S.val.empty() && (e = val.upload(S.val)) != hipSuccess) return e;
+        return hipSuccess;
+    }
+    void release() { ptr.release(); w.release(); idx.release(); val.release(); }
+};
+
+} // namespace
+
+struct admm_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_step0 = nullptr, ev_step1 = nullptr;
+    std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration when stats are requested
+
+    int nv = 0, n3 = 0;
+    double dt = 1.0 / 24.0;
+    int linsolver = 0;
+    double constraint_w = 1.0;
+    int pcg_max_iters = 500; double pcg_tol = 1e-10;
+    int gs_max_iters = 30; double gs_tol = 1e-10, gs_omega = 1.9;
+    int uz_max_iters = 20; double uz_tol = 1e-10;
+    bool state_set = false;
+    int rank = 0, world = 1;
+
+    // node vectors
+    DevBuf<double> x, v, m, Mxbar, curr, b, dinv;
+    // tets (sorted by constitutive model; perm[new] = caller's index)
+    int nt = 0, ldt = 0;
+    int kind_begin[4] = {0, 0, 0, 0}; // [linear | NH (+spline) | StVK | end]
+    std::vector<int> tet_perm;
+    DevBuf<int4> t_idx;
+    DevBuf<double> t_Binv, t_u, t_z, t_sc, t_cf;
+    DevBuf<int> t_mat;
+    DevBuf<Mat> mats;
+    SellDev t_inc;
+    // tris
+    int ntri = 0, ldr = 0;
+    DevBuf<int4> r_idx;
+    DevBuf<double> r_rest, r_u, r_z, r_sc, r_cf, r_lmin, r_lmax;
+    SellDev r_inc;
+    // pins
+    int npin_terms = 0;      // SpringPin energy terms (linsolver 0/2)
+    std::vector<int> pin_vert_h; // creation-time pin vertices (terms), in term order
+    DevBuf<int> vert_pin, pin_active;
+    DevBuf<double> pin_xyz, pin_u, pin_z;
+    double pin_weight = 0.0;
+    // in-sweep pins (linsolver 1)
+    DevBuf<int> gs_pin_flag;
+    DevBuf<double> gs_pin_xyz;
+    bool gs_has_pins = false;
+    // system matrix
+    admm_host::Csr Ahat;
+    SellDev A;
+    DevBuf<int> csr_rowptr, csr_col;
+    DevBuf<double> csr_val;
+    // PCG work
+    int NB = 1;
+    DevBuf<double> cg_r, cg_u, cg_w, cg_p, cg_s, part, part_b;
+    DevBuf<CgScal> cg_scal;
+    DevBuf<int> counters; // [0] total inner iterations of the step, [1] gs done flag, [2] gs sweeps
+    // GS
+    std::vector<int> color_h; int n_colors = 0;
+    std::vector<int> color_ptr_h;
+    DevBuf<int> color_nodes;
+    Obstacles obst{};
+
+    ~admm_hip_ctx() {
+        (void)hipSetDevice(device);
+        x.release(); v.release(); m.release(); Mxbar.release(); curr.release(); b.release(); dinv.release();
+        t_idx.release(); t_Binv.release(); t_u.release(); t_z.release(); t_sc.release(); t_cf.release();
+        t_mat.release(); mats.release(); t_inc.release();
+        r_idx.release(); r_rest.release(); r_u.release(); r_z.release(); r_sc.release(); r_cf.release();
+        r_lmin.release(); r_lmax.release(); r_inc.release();
+        vert_pin.release(); pin_active.release(); pin_xyz.release(); pin_u.release(); pin_z.release();
+        gs_pin_flag.release(); gs_pin_xyz.release();
+        A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
+        cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
+        cg_scal.release(); counters.release(); color_nodes.release();
+        for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
+        if (ev_step0) (void)hipEventDestroy(ev_step0);
+        if (ev_step1) (void)hipEventDestroy(ev_step1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+inline int blocks_for(int n) { return (n + 255) / 256; }
+
+SellA sell_arg(const SellDev &S) { return SellA{S.n_rows, S.n_slices, S.ptr.p, S.w.p, S.idx.p, S.val.p}; }
+
+// ---- launch helpers (all on ctx->stream) -------------------------------------------------------------
+template <bool WRITE_Z>
+void launch_local(admm_hip_ctx *c) {
+    hipStream_t st = c->stream;
+    if (c->nt > 0) {
+        const int b0 = c->kind_begin[0], b1 = c->kind_begin[1], b2 = c->kind_begin[2], b3 = c->kind_begin[3];
+        if (b1 > b0)
+            hipLaunchKernelGGL((k_local_tets<0, WRITE_Z>), dim3(blocks_for(b1 - b0)), dim3(256), 0, st, b0, b1, c->ldt,
+                               c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p);
+        if (b2 > b1)
+            hipLaunchKernelGGL((k_local_tets<1, WRITE_Z>), dim3(blocks_for(b2 - b1)), dim3(256), 0, st, b1, b2, c->ldt,
+                               c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p);
+        if (b3 > b2)
+            hipLaunchKernelGGL((k_local_tets<2, WRITE_Z>), dim3(blocks_for(b3 - b2)), dim3(256), 0, st, b2, b3, c->ldt,
+                               c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p);
+    }
+    if (c->ntri > 0)
+        hipLaunchKernelGGL((k_local_tris<WRITE_Z>), dim3(blocks_for(c->ntri)), dim3(256), 0, st, c->ntri, c->ldr, c->r_idx.p,
+                           c->r_rest.p, c->r_u.p, c->r_z.p, c->r_sc.p, c->r_lmin.p, c->r_lmax.p, c->curr.p, c->r_cf.p);
+}
+
+void launch_gather(admm_hip_ctx *c) {
+    GatherArgs a{};
+    a.nv = c->nv; a.n_slices = (c->nv + 63) / 64;
+    if (c->nt > 0) { a.t_ptr = c->t_inc.ptr.p; a.t_w = c->t_inc.w.p; a.t_inc = c->t_inc.idx.p; a.t_cf = c->t_cf.p; a.t_ld = c->ldt; }
+    if (c->ntri > 0) { a.r_ptr = c->r_inc.ptr.p; a.r_w = c->r_inc.w.p; a.r_inc = c->r_inc.idx.p; a.r_cf = c->r_cf.p; a.r_ld = c->ldr; }
+    if (c->npin_terms > 0) {
+        a.vert_pin = c->vert_pin.p; a.pin_xyz = c->pin_xyz.p; a.pin_active = c->pin_active.p;
+        a.pin_u = c->pin_u.p; a.pin_z = c->pin_z.p; a.pin_sc = c->dt * c->dt * c->pin_weight * c->pin_weight;
+    }
+    a.x = c->curr.p; a.Mxbar = c->Mxbar.p; a.b = c->b.p; a.add_mxbar = (c->rank == 0) ? 1 : 0;
+    const int grid = std::max(1, std::min((a.n_slices + 3) / 4, 2048));
+    hipLaunchKernelGGL(k_gather_rhs, dim3(grid), dim3(256), 0, c->stream, a);
+}
+
+// PCG solve of A x = b, x = curr (warm start).  Blind launch of max_iters iterations with device-side
+// early exit (no host synchronisation inside a step).
+void launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
+    hipStream_t st = c->stream;
+    const SellA A = sell_arg(c->A);
+    const int NB = c->NB;
+    const double tol2 = c->pcg_tol * c->pcg_tol;
+    hipLaunchKernelGGL(k_cg_resid, dim3(NB), dim3(256), 0, st, A, c->m.p, c->dinv.p, b, x, c->cg_r.p, c->cg_u.p, c->part_b.p, NB,
+                       c->cg_scal.p);
+    for (int it = 0; it < max_iters; ++it) {
+        const CgScal *prev = c->cg_scal.p + (it & 1);
+        CgScal *next = c->cg_scal.p + ((it + 1) & 1);
+        hipLaunchKernelGGL(k_cg_spmv, dim3(NB), dim3(256), 0, st, A, c->m.p, c->cg_u.p, c->cg_r.p, c->cg_w.p, c->part.p, NB, prev);
+        hipLaunchKernelGGL(k_cg_vec, dim3(NB), dim3(256), 0, st, it, c->n3, NB, c->part.p, c->part_b.p, prev, next, tol2,
+                           c->counters.p, c->dinv.p, c->cg_p.p, c->cg_s.p, x, c->cg_r.p, c->cg_u.p, c->cg_w.p);
+    }
+}
+
+void launch_gs(admm_hip_ctx *c, const double *b, double *x) {
+    hipStream_t st = c->stream;
+    (void)hipMemsetAsync(c->counters.p + 1, 0, 2 * sizeof(int), st);
+    GsArgs a{};
+    a.rowptr = c->csr_rowptr.p; a.col = c->csr_col.p; a.val = c->csr_val.p; a.m = c->m.p; a.b = b; a.x = x;
+    a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p;
+    a.omega = c->gs_omega; a.done = c->counters.p + 1;
+    const SellA A = sell_arg(c->A);
+    const int check = c->gs_tol > 0.0 ? 1 : 0;
+    for (int it = 0; it < c->gs_max_iters; ++it) {
+        for (int col = 0; col < c->n_colors; ++col) {
+            const int beg = c->color_ptr_h[col], cnt = c->color_ptr_h[col + 1] - beg;
+            if (cnt == 0) continue;
+            hipLaunchKernelGGL(k_gs_color, dim3(blocks_for(cnt)), dim3(256), 0, st, a, c->color_nodes.p + beg, cnt, c->obst);
+        }
+        if (check)
+            hipLaunchKernelGGL(k_gs_resid, dim3(c->NB), dim3(256), 0, st, A, c->m.p, b, x, c->part.p, c->NB, c->counters.p + 1);
+        hipLaunchKernelGGL(k_gs_check, dim3(1), dim3(256), 0, st, c->part.p, c->NB, c->gs_tol * c->gs_tol, c->counters.p + 1,
+                           c->counters.p + 2, c->counters.p, check);
+    }
+}
+
+int validate(const admm_hip_desc *d) {
+    if (!d) return fail(ADMM_HIP_ERR_ARG, "desc is NULL");
+    if (d->struct_size != (int32_t)sizeof(admm_hip_desc)) return fail(ADMM_HIP_ERR_ARG, "desc.struct_size mismatch");
+    if (d->n_verts < 1 || !d->masses) return fail(ADMM_HIP_ERR_ARG, "Problem with node data (Solver.cpp:180-183)");
+    if (d->n_tets < 0 || d->n_tris < 0 || d->n_pins < 0) return fail(ADMM_HIP_ERR_ARG, "negative count");
+    if (d->n_tets && (!d->tet_idx || !d->tet_Binv || !d->tet_weight || !d->tet_kind || !d->tet_mu || !d->tet_lambda || !d->tet_k))
+        return fail(ADMM_HIP_ERR_ARG, "tet arrays missing");
+    if (d->n_tris && (!d->tri_idx || !d->tri_rest || !d->tri_weight || !d->tri_limit_min || !d->tri_limit_max))
+        return fail(ADMM_HIP_ERR_ARG, "tri arrays missing");
+    if (d->n_pins && (!d->pin_vert || !d->pin_xyz)) return fail(ADMM_HIP_ERR_ARG, "pin arrays missing");
+    if (d->linsolver < 0 || d->linsolver > 2) return fail(ADMM_HIP_ERR_ARG, "linsolver must be 0, 1 or 2");
+    if (d->n_obstacles < 0 || d->n_obstacles > kMaxObst) return fail(ADMM_HIP_ERR_ARG, "too many obstacles (max 8)");
+    if (d->n_obstacles && d->linsolver == 0)
+        return fail(ADMM_HIP_ERR_ARG, "No collisions with LDLT solver (Solver.cpp:249-254)");
+    for (int i = 0; i < 3 * d->n_verts; ++i)
+        if (!(d->masses[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "non-positive mass");
+    for (int64_t i = 0; i < (int64_t)4 * d->n_tets; ++i)
+        if (d->tet_idx[i] < 0 || d->tet_idx[i] >= d->n_verts) return fail(ADMM_HIP_ERR_ARG, "tet index out of range");
+    for (int64_t i = 0; i < (int64_t)3 * d->n_tris; ++i)
+        if (d->tri_idx[i] < 0 || d->tri_idx[i] >= d->n_verts) return fail(ADMM_HIP_ERR_ARG, "tri index out of range");
+    for (int i = 0; i < d->n_tets; ++i) {
+        if (!(d->tet_weight[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "Some weight leq 0 (EnergyTerm.hpp:124-126)");
+        if (d->tet_kind[i] < 0 || d->tet_kind[i] > 3) return fail(ADMM_HIP_ERR_ARG, "unknown tet kind");
+    }
+    for (int i = 0; i < d->n_tris; ++i) {
+        if (!(d->tri_weight[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "Some weight leq 0 (EnergyTerm.hpp:124-126)");
+        if (d->tri_limit_min[i] > 1.0) return fail(ADMM_HIP_ERR_ARG, "Strain limit min should be -inf to 1 (TriEnergyTerm.cpp:32)");
+        if (d->tri_limit_max[i] < 1.0) return fail(ADMM_HIP_ERR_ARG, "Strain limit max should be 1 to inf (TriEnergyTerm.cpp:33)");
+    }
+    for (int i = 0; i < d->n_pins; ++i)
+        if (d->pin_vert[i] < 0 || d->pin_vert[i] >= d->n_verts) return fail(ADMM_HIP_ERR_ARG, "pin index out of range");
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *admm_hip_last_error(void) { return g_last_error.c_str(); }
+
+int admm_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
+    if (!out) return fail(ADMM_HIP_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int rc = validate(d);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(ADMM_HIP_ERR_DEVICE, "no HIP device available: the ADMM hot path has no CPU fallback");
+    if (d->device < 0 || d->device >= ndev) return fail(ADMM_HIP_ERR_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(d->device));
+
+    admm_hip_ctx *c = new admm_hip_ctx();
+    std::unique_ptr<admm_hip_ctx> guard(c);
+    c->device = d->device;
+    c->nv = d->n_verts; c->n3 = 3 * d->n_verts;
+    c->dt = d->dt > 0.0 ? d->dt : 1.0 / 24.0;
+    c->linsolver = d->linsolver;
+    c->pcg_max_iters = d->pcg_max_iters > 0 ? d->pcg_max_iters : 500;
+    c->pcg_tol = d->pcg_tol > 0 ? d->pcg_tol : 1e-10;
+    c->gs_max_iters = d->gs_max_iters > 0 ? d->gs_max_iters : 30;
+    c->gs_tol = d->gs_tol >= 0 ? d->gs_tol : 1e-10;
+    c->gs_omega = d->gs_omega > 0 ? d->gs_omega : 1.9;
+    c->uz_max_iters = d->uzawa_max_iters > 0 ? d->uzawa_max_iters : 20;
+    c->uz_tol = d->uzawa_tol > 0 ? d->uzawa_tol : 1e-10;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->ev_step0));
+    HIP_TRY(hipEventCreate(&c->ev_step1));
+
+    const double dt2 = c->dt * c->dt;
+    const int nv = c->nv;
+
+    // ---- tets: sort by constitutive model (wave-uniform code paths), build the material table ----
+    c->nt = d->n_tets; c->ldt = d->n_tets + 1;
+    if (c->nt > 0) {
+        const int nt = c->nt, ld = c->ldt;
+        auto grp = [&](int k) { return k == ADMM_TET_LINEAR ? 0 : (k == ADMM_TET_STVK ? 2 : 1); };
+        c->tet_perm.resize(nt);
+        std::iota(c->tet_perm.begin(), c->tet_perm.end(), 0);
+        std::stable_sort(c->tet_perm.begin(), c->tet_perm.end(), [&](int a, int b) { return grp(d->tet_kind[a]) < grp(d->tet_kind[b]); });
+        int cnt[3] = {0, 0, 0};
+        for (int t = 0; t < nt; ++t) cnt[grp(d->tet_kind[t])]++;
+        c->kind_begin[0] = 0; c->kind_begin[1] = cnt[0]; c->kind_begin[2] = cnt[0] + cnt[1]; c->kind_begin[3] = nt;
+        std::map<std::tuple<double, double, double>, int> mat_map;
+        std::vector<Mat> mats;
+        std::vector<int4> idx(nt);
+        std::vector<double> Binv((size_t)9 * ld, 0.0), sc(ld, 0.0);
+        std::vector<int> mat(nt);
+        for (int n = 0; n < nt; ++n) {
+            const int o = c->tet_perm[n];
+            idx[n] = make_int4(d->tet_idx[4 * o], d->tet_idx[4 * o + 1], d->tet_idx[4 * o + 2], d->tet_idx[4 * o + 3]);
+            for (int k = 0; k < 9; ++k) Binv[(size_t)k * ld + n] = d->tet_Binv[9 * (size_t)o + k];
+            sc[n] = dt2 * d->tet_weight[o] * d->tet_weight[o];
+            auto key = std::make_tuple(d->tet_mu[o], d->tet_lambda[o], d->tet_k[o]);
+            auto it = mat_map.find(key);
+            if (it == mat_map.end()) { it = mat_map.emplace(key, (int)mats.size()).first; mats.push_back(Mat{d->tet_mu[o], d->tet_lambda[o], d->tet_k[o]}); }
+            mat[n] = it->second;
+        }
+        HIP_TRY(c->t_idx.upload(idx)); HIP_TRY(c->t_Binv.upload(Binv)); HIP_TRY(c->t_sc.upload(sc));
+        HIP_TRY(c->t_mat.upload(mat)); HIP_TRY(c->mats.upload(mats));
+        HIP_TRY(c->t_u.alloc((size_t)9 * ld)); HIP_TRY(c->t_u.zero());
+        HIP_TRY(c->t_z.alloc((size_t)9 * ld)); HIP_TRY(c->t_z.zero());
+        HIP_TRY(c->t_cf.alloc((size_t)12 * ld)); HIP_TRY(c->t_cf.zero());
+        // incidence on the permuted numbering
+        std::vector<int32_t> pidx((size_t)4 * nt);
+        for (int n = 0; n < nt; ++n) { pidx[4 * n] = idx[n].x; pidx[4 * n + 1] = idx[n].y; pidx[4 * n + 2] = idx[n].z; pidx[4 * n + 3] = idx[n].w; }
+        HIP_TRY(c->t_inc.upload(admm_host::incidence_sell(nv, nt, 4, pidx.data(), nt * 4)));
+    }
+    // ---- tris ----
+    c->ntri = d->n_tris; c->ldr = d->n_tris + 1;
+    if (c->ntri > 0) {
+        const int n = c->ntri, ld = c->ldr;
+        std::vector<int4> idx(n);
+        std::vector<double> rest((size_t)4 * ld, 0.0), sc(ld, 0.0), lmin(ld, -100.0), lmax(ld, 100.0);
+        for (int t = 0; t < n; ++t) {
+            idx[t] = make_int4(d->tri_idx[3 * t], d->tri_idx[3 * t + 1], d->tri_idx[3 * t + 2], 0);
+            for (int k = 0; k < 4; ++k) rest[(size_t)k * ld + t] = d->tri_rest[4 * (size_t)t + k];
+            sc[t] = dt2 * d->tri_weight[t] * d->tri_weight[t];
+            lmin[t] = d->tri_limit_min[t]; lmax[t] = d->tri_limit_max[t];
+        }
+        HIP_TRY(c->r_idx.upload(idx)); HIP_TRY(c->r_rest.upload(rest)); HIP_TRY(c->r_sc.upload(sc));
+        HIP_TRY(c->r_lmin.upload(lmin)); HIP_TRY(c->r_lmax.upload(lmax));
+        HIP_TRY(c->r_u.alloc((size_t)6 * ld)); HIP_TRY(c->r_u.zero());
+        HIP_TRY(c->r_z.alloc((size_t)6 * ld)); HIP_TRY(c->r_z.zero());
+        HIP_TRY(c->r_cf.alloc((size_t)9 * ld)); HIP_TRY(c->r_cf.zero());
+        HIP_TRY(c->r_inc.upload(admm_host::incidence_sell(nv, n, 3, d->tri_idx, n * 4)));
+    }
+    // ---- pins ----
+    double max_w = 0.0;
+    for (int t = 0; t < d->n_tets; ++t) max_w = std::max(max_w, d->tet_weight[t]);
+    for (int t = 0; t < d->n_tris; ++t) max_w = std::max(max_w, d->tri_weight[t]);
+    {
+        double mu, la, k;
+        admm_host::lame(10000000.0, 0.499, &mu, &la, &k); // Lame::rubber(), SpringEnergyTerm.hpp:50-51
+        c->pin_weight = d->pin_weight > 0 ? d->pin_weight : std::sqrt(k * 2.0);
+    }
+    const bool pins_as_terms = (d->linsolver == 0 || d->linsolver == 2); // Solver.cpp:190-196
+    if (pins_as_terms && d->n_pins > 0) {
+        c->npin_terms = d->n_pins;
+        max_w = std::max(max_w, c->pin_weight);
+        std::vector<int> vp(nv, -1), act(d->n_pins, 1);
+        std::vector<double> xyz(d->pin_xyz, d->pin_xyz + 3 * (size_t)d->n_pins);
+        for (int p = 0; p < d->n_pins; ++p) {
+            if (vp[d->pin_vert[p]] >= 0) return fail(ADMM_HIP_ERR_ARG, "duplicate pin vertex");
+            vp[d->pin_vert[p]] = p;
+            if (d->pin_active) act[p] = d->pin_active[p] ? 1 : 0;
+        }
+        c->pin_vert_h.assign(d->pin_vert, d->pin_vert + d->n_pins);
+        HIP_TRY(c->vert_pin.upload(vp)); HIP_TRY(c->pin_active.upload(act)); HIP_TRY(c->pin_xyz.upload(xyz));
+        HIP_TRY(c->pin_u.alloc(3 * (size_t)d->n_pins)); HIP_TRY(c->pin_u.zero());
+        HIP_TRY(c->pin_z.alloc(3 * (size_t)d->n_pins)); HIP_TRY(c->pin_z.zero());
+    }
+    if (d->linsolver == 1) {
+        std::vector<int> flag(nv, 0);
+        std::vector<double> xyz((size_t)3 * nv, 0.0);
+        for (int p = 0; p < d->n_pins; ++p) {
+            if (d->pin_active && !d->pin_active[p]) continue;
+            flag[d->pin_vert[p]] = 1;
+            for (int j = 0; j < 3; ++j) xyz[3 * (size_t)d->pin_vert[p] + j] = d->pin_xyz[3 * (size_t)p + j];
+            c->gs_has_pins = true;
+        }
+        HIP_TRY(c->gs_pin_flag.upload(flag)); HIP_TRY(c->gs_pin_xyz.upload(xyz));
+    }
+    // constraint weight: Solver.cpp:235 (GS: 3 max W), :239 (Uzawa: 1), :245 (override)
+    c->constraint_w = (d->linsolver == 1) ? 3.0 * max_w : 1.0;
+    if (d->constraint_w > 0.0) c->constraint_w = d->constraint_w;
+    c->obst.n = d->n_obstacles;
+    for (int j = 0; j < d->n_obstacles; ++j) {
+        c->obst.kind[j] = d->obstacle_kind[j];
+        for (int k = 0; k < 4; ++k) c->obst.par[j][k] = d->obstacle_params[4 * j + k];
+    }
+
+    // ---- system matrix ----
+    c->Ahat = admm_host::assemble_Ahat(nv, c->dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris, d->tri_idx,
+                                       d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, c->pin_weight);
+    HIP_TRY(c->A.upload(admm_host::csr_to_sell(c->Ahat)));
+    {
+        std::vector<double> mass(d->masses, d->masses + c->n3), dinv(c->n3);
+        for (int vtx = 0; vtx < nv; ++vtx) {
+            double diag = 0.0;
+            for (int k = c->Ahat.rowptr[vtx]; k < c->Ahat.rowptr[vtx + 1]; ++k)
+                if (c->Ahat.col[k] == vtx) diag = c->Ahat.val[k];
+            for (int j = 0; j < 3; ++j) dinv[3 * (size_t)vtx + j] = 1.0 / (mass[3 * (size_t)vtx + j] + diag);
+        }
+        HIP_TRY(c->m.upload(mass)); HIP_TRY(c->dinv.upload(dinv));
+    }
+    HIP_TRY(c->x.alloc(c->n3)); HIP_TRY(c->x.zero());
+    HIP_TRY(c->v.alloc(c->n3)); HIP_TRY(c->v.zero());
+    HIP_TRY(c->Mxbar.alloc(c->n3)); HIP_TRY(c->Mxbar.zero());
+    HIP_TRY(c->curr.alloc(c->n3)); HIP_TRY(c->curr.zero());
+    HIP_TRY(c->b.alloc(c->n3)); HIP_TRY(c->b.zero());
+    c->NB = std::max(1, std::min((c->A.n_slices + 3) / 4, 512));
+    HIP_TRY(c->cg_r.alloc(c->n3)); HIP_TRY(c->cg_u.alloc(c->n3)); HIP_TRY(c->cg_w.alloc(c->n3));
+    HIP_TRY(c->cg_p.alloc(c->n3)); HIP_TRY(c->cg_s.alloc(c->n3));
+    HIP_TRY(c->cg_p.zero()); HIP_TRY(c->cg_s.zero());
+    HIP_TRY(c->part.alloc(6 * (size_t)c->NB)); HIP_TRY(c->part_b.alloc(3 * (size_t)c->NB));
+    HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
+    HIP_TRY(c->counters.alloc(4)); HIP_TRY(c->counters.zero());
+
+    if (d->linsolver == 1) {
+        c->color_h.resize(nv);
+        if (d->gs_colors) {
+            c->n_colors = 0;
+            for (int i = 0; i < nv; ++i) {
+                if (d->gs_colors[i] < 0) return fail(ADMM_HIP_ERR_ARG, "negative colour");
+                c->color_h[i] = d->gs_colors[i];
+                c->n_colors = std::max(c->n_colors, d->gs_colors[i] + 1);
+            }
+            for (int i = 0; i < nv; ++i)
+                for (int k = c->Ahat.rowptr[i]; k < c->Ahat.rowptr[i + 1]; ++k)
+                    if (c->Ahat.col[k] != i && c->color_h[c->Ahat.col[k]] == c->color_h[i])
+                        return fail(ADMM_HIP_ERR_ARG, "gs_colors is not a valid colouring of A");
+        } else {
+            c->n_colors = admm_host::greedy_coloring(nv, c->Ahat.rowptr.data(), c->Ahat.col.data(), c->color_h.data());
+        }
+        c->color_ptr_h.assign(c->n_colors + 1, 0);
+        for (int i = 0; i < nv; ++i) c->color_ptr_h[c->color_h[i] + 1]++;
+        for (int k = 0; k < c->n_colors; ++k) c->color_ptr_h[k + 1] += c->color_ptr_h[k];
+        std::vector<int> nodes(nv), pos(c->color_ptr_h.begin(), c->color_ptr_h.end() - 1);
+        for (int i = 0; i < nv; ++i) nodes[pos[c->color_h[i]]++] = i;
+        HIP_TRY(c->color_nodes.upload(nodes));
+        HIP_TRY(c->csr_rowptr.upload(c->Ahat.rowptr)); HIP_TRY(c->csr_col.upload(c->Ahat.col)); HIP_TRY(c->csr_val.upload(c->Ahat.val));
+    }
+    if (d->linsolver == 2 && d->n_obstacles > 0)
+        return fail(ADMM_HIP_ERR_ARG, "UzawaCG with obstacles is not available in this build yet");
+    HIP_TRY(hipDeviceSynchronize());
+    *out = guard.release();
+    return ADMM_HIP_OK;
+}
+
+void admm_hip_destroy(admm_hip_ctx *ctx) { delete ctx; }
+
+int admm_hip_num_rows(const admm_hip_ctx *c) { return c ? 9 * c->nt + 6 * c->ntri + 6 * c->npin_terms : 0; }
+
+int admm_hip_set_state(admm_hip_ctx *c, const double *x, const double *v) {
+    if (!c || !x) return fail(ADMM_HIP_ERR_ARG, "set_state: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->x.p, x, c->n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (v) HIP_TRY(hipMemcpyAsync(c->v.p, v, c->n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    else HIP_TRY(hipMemsetAsync(c->v.p, 0, c->n3 * sizeof(double), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->state_set = true;
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_get_state(admm_hip_ctx *c, double *x, double *v) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "get_state: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    if (x) HIP_TRY(hipMemcpyAsync(x, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (v) HIP_TRY(hipMemcpyAsync(v, c->v.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const double *xyz) {
+    if (!c || n < 0 || (n > 0 && (!vert || !xyz))) return fail(ADMM_HIP_ERR_ARG, "set_pins: Bad input (Solver.cpp:118-120)");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->linsolver == 1) {
+        std::vector<int> flag(c->nv, 0);
+        std::vector<double> p((size_t)c->n3, 0.0);
+        for (int i = 0; i < n; ++i) {
+            if (vert[i] < 0 || vert[i] >= c->nv) return fail(ADMM_HIP_ERR_ARG, "set_pins: index out of range");
+            flag[vert[i]] = 1;
+            for (int j = 0; j < 3; ++j) p[3 * (size_t)vert[i] + j] = xyz[3 * (size_t)i + j];
+        }
+        c->gs_has_pins = n > 0;
+        HIP_TRY(hipMemcpy(c->gs_pin_flag.p, flag.data(), flag.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->gs_pin_xyz.p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));
+        return ADMM_HIP_OK;
+    }
+    // energy-based pins: locations may move, the set may only be (de)activated (Solver.cpp:126-156)
+    std::vector<int> act(c->npin_terms, 0);
+    std::vector<double> p(3 * (size_t)c->npin_terms);
+    if (c->npin_terms) HIP_TRY(hipMemcpy(p.data(), c->pin_xyz.p, p.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::map<int, int> term_of;
+    for (int i = 0; i < c->npin_terms; ++i) term_of[c->pin_vert_h[i]] = i;
+    for (int i = 0; i < n; ++i) {
+        auto it = term_of.find(vert[i]);
+        if (it == term_of.end())
+            return fail(ADMM_HIP_ERR_ARG, "Solver::set_pins Error: Constraint for " + std::to_string(vert[i]) + " not found.");
+        act[it->second] = 1;
+        for (int j = 0; j < 3; ++j) p[3 * (size_t)it->second + j] = xyz[3 * (size_t)i + j];
+    }
+    if (c->npin_terms) {
+        HIP_TRY(hipMemcpy(c->pin_active.p, act.data(), act.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->pin_xyz.p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return ADMM_HIP_OK;
+}
+
+static void launch_global(admm_hip_ctx *c, const double *b, double *x) {
+    if (c->linsolver == 1) launch_gs(c, b, x);
+    else launch_pcg(c, b, x, c->pcg_max_iters);
+}
+
+int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_stats *stats) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "step: NULL context");
+    if (!c->state_set) return fail(ADMM_HIP_ERR_STATE, "step: call admm_hip_set_state first");
+    if (admm_iters < 0) return fail(ADMM_HIP_ERR_ARG, "step: admm_iters < 0");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const bool timed = stats != nullptr;
+    if (timed) {
+        while ((int)c->ev_phase.size() < 3 * admm_iters + 1) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            c->ev_phase.push_back(e);
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev_step0, st));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(int), st));
+    hipLaunchKernelGGL(k_predict, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, c->dt, gravity, c->x.p, c->v.p, c->m.p,
+                       c->Mxbar.p, c->curr.p);
+    // curr_u = 0 (Solver.cpp:71); curr_z = D x is a dead store in the reference (:70)
+    if (c->nt) HIP_TRY(hipMemsetAsync(c->t_u.p, 0, c->t_u.n * sizeof(double), st));
+    if (c->ntri) HIP_TRY(hipMemsetAsync(c->r_u.p, 0, c->r_u.n * sizeof(double), st));
+    if (c->npin_terms) HIP_TRY(hipMemsetAsync(c->pin_u.p, 0, c->pin_u.n * sizeof(double), st));
+    for (int s = 0; s < admm_iters; ++s) {
+        if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s], st));
+        launch_local<false>(c);
+        launch_gather(c);
+        if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 1], st));
+        // collision detection against passive objects happens inside the GS sweeps (linsolver 1)
+        if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 2], st));
+        launch_global(c, c->b.p, c->curr.p);
+    }
+    if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * admm_iters], st));
+    hipLaunchKernelGGL(k_finish, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, 1.0 / c->dt, c->x.p, c->v.p, c->curr.p);
+    HIP_TRY(hipEventRecord(c->ev_step1, st));
+    HIP_TRY(hipGetLastError());
+    if (timed) {
+        HIP_TRY(hipEventSynchronize(c->ev_step1));
+        std::memset(stats, 0, sizeof(*stats));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_step0, c->ev_step1));
+        stats->step_ms = ms;
+        for (int s = 0; s < admm_iters; ++s) {
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s], c->ev_phase[3 * s + 1])); stats->local_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 2])); stats->collision_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 2], c->ev_phase[3 * s + 3])); stats->global_ms += ms;
+        }
+        int h[4];
+        HIP_TRY(hipMemcpy(h, c->counters.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+        CgScal sc[2];
+        HIP_TRY(hipMemcpy(sc, c->cg_scal.p, sizeof(sc), hipMemcpyDeviceToHost));
+        stats->admm_iters = admm_iters;
+        if (c->linsolver == 1) { stats->inner_iters = h[0]; stats->last_solve_converged = h[1]; }
+        else {
+            stats->inner_iters = h[0];
+            stats->last_solve_converged = sc[c->pcg_max_iters & 1].converged;
+        }
+    }
+    return ADMM_HIP_OK;
+}
+
+// z/u between the reference row layout (AoS, caller's term order) and the device SoA (sorted tets)
+static void rows_to_dev(const admm_hip_ctx *c, const double *rows, std::vector<double> &tu, std::vector<double> &ru, std::vector<double> &pu) {
+    tu.assign((size_t)9 * c->ldt, 0.0); ru.assign((size_t)6 * c->ldr, 0.0); pu.assign(3 * (size_t)c->npin_terms, 0.0);
+    for (int n = 0; n < c->nt; ++n)
+        for (int k = 0; k < 9; ++k) tu[(size_t)k * c->ldt + n] = rows[9 * (size_t)c->tet_perm[n] + k];
+    const double *r = rows + 9 * (size_t)c->nt;
+    for (int t = 0; t < c->ntri; ++t)
+        for (int k = 0; k < 6; ++k) ru[(size_t)k * c->ldr + t] = r[6 * (size_t)t + k];
+    r += 6 * (size_t)c->ntri;
+    for (int p = 0; p < c->npin_terms; ++p)
+        for (int k = 0; k < 3; ++k) pu[3 * (size_t)p + k] = r[6 * (size_t)p + k];
+}
+static void dev_to_rows(const admm_hip_ctx *c, const std::vector<double> &tu, const std::vector<double> &ru, const std::vector<double> &pu, double *rows) {
+    for (int n = 0; n < c->nt; ++n)
+        for (int k = 0; k < 9; ++k) rows[9 * (size_t)c->tet_perm[n] + k] = tu[(size_t)k * c->ldt + n];
+    double *r = rows + 9 * (size_t)c->nt;
+    for (int t = 0; t < c->ntri; ++t)
+        for (int k = 0; k < 6; ++k) r[6 * (size_t)t + k] = ru[(size_t)k * c->ldr + t];
+    r += 6 * (size_t)c->ntri;
+    for (int p = 0; p < c->npin_terms; ++p) {
+        for (int k = 0; k < 3; ++k) r[6 * (size_t)p + k] = pu[3 * (size_t)p + k];
+        for (int k = 3; k < 6; ++k) r[6 * (size_t)p + k] = 0.0; // rows 3..5 of a SpringPin are never populated
+    }
+}
+
+int admm_hip_local_step(admm_hip_ctx *c, const double *x, double *u_inout, double *z_out, const double *Mxbar, double *b_out) {
+    if (!c || !x || !u_inout || !z_out) return fail(ADMM_HIP_ERR_ARG, "local_step: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    std::vector<double> tu, ru, pu;
+    rows_to_dev(c, u_inout, tu, ru, pu);
+    HIP_TRY(hipMemcpyAsync(c->curr.p, x, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
+    if (c->nt) HIP_TRY(hipMemcpyAsync(c->t_u.p, tu.data(), tu.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    if (c->ntri) HIP_TRY(hipMemcpyAsync(c->r_u.p, ru.data(), ru.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    if (c->npin_terms) HIP_TRY(hipMemcpyAsync(c->pin_u.p, pu.data(), pu.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    if (Mxbar) HIP_TRY(hipMemcpyAsync(c->Mxbar.p, Mxbar, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
+    else HIP_TRY(hipMemsetAsync(c->Mxbar.p, 0, c->n3 * sizeof(double), st));
+    launch_local<true>(c);
+    launch_gather(c);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> tz((size_t)9 * c->ldt), rz((size_t)6 * c->ldr), pz(3 * (size_t)c->npin_terms);
+    if (c->nt) {
+        HIP_TRY(hipMemcpyAsync(tu.data(), c->t_u.p, tu.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(tz.data(), c->t_z.p, tz.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (c->ntri) {
+        HIP_TRY(hipMemcpyAsync(ru.data(), c->r_u.p, ru.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(rz.data(), c->r_z.p, rz.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (c->npin_terms) {
+        HIP_TRY(hipMemcpyAsync(pu.data(), c->pin_u.p, pu.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(pz.data(), c->pin_z.p, pz.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (b_out) HIP_TRY(hipMemcpyAsync(b_out, c->b.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    dev_to_rows(c, tu, ru, pu, u_inout);
+    dev_to_rows(c, tz, rz, pz, z_out);
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int32_t *iters) {
+    if (!c || !b || !x_inout) return fail(ADMM_HIP_ERR_ARG, "global_solve: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->b.p, b, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(c->curr.p, x_inout, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(int), st));
+    launch_global(c, c->b.p, c->curr.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(x_inout, c->curr.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, st));
+    int h[4];
+    HIP_TRY(hipMemcpyAsync(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (iters) *iters = (c->linsolver == 1) ? h[2] : h[0];
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_get_matrix(const admm_hip_ctx *c, int32_t *rowptr, int32_t *col, double *val, int32_t *nnz) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "get_matrix: NULL context");
+    if (nnz) *nnz = (int32_t)c->Ahat.col.size();
+    if (rowptr) std::copy(c->Ahat.rowptr.begin(), c->Ahat.rowptr.end(), rowptr);
+    if (col) std::copy(c->Ahat.col.begin(), c->Ahat.col.end(), col);
+    if (val) std::copy(c->Ahat.val.begin(), c->Ahat.val.end(), val);
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_get_colors(const admm_hip_ctx *c, int32_t *color, int32_t *n_colors) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "get_colors: NULL context");
+    if (c->linsolver != 1) return fail(ADMM_HIP_ERR_STATE, "get_colors: context was not created with linsolver 1");
+    if (n_colors) *n_colors = c->n_colors;
+    if (color) std::copy(c->color_h.begin(), c->color_h.end(), color);
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_comm_unique_id(char *id128) {
+    (void)id128;
+    return fail(ADMM_HIP_ERR_COMM, "multi-GPU path not built yet");
+}
+int admm_hip_comm_init(admm_hip_ctx *ctx, const char *id128, int rank, int world_size) {
+    (void)ctx; (void)id128; (void)rank; (void)world_size;
+    return fail(ADMM_HIP_ERR_COMM, "multi-GPU path not built yet");
+}
+
+// ---- host-only entry points ----
+int admm_host_assemble_matrix(const admm_hip_desc *d, int32_t *rowptr, int32_t *col, double *val, int32_t *nnz) {
+    int rc = validate(d);
+    if (rc) return rc;
+    const double dt = d->dt > 0.0 ? d->dt : 1.0 / 24.0;
+    double mu, la, k;
+    admm_host::lame(10000000.0, 0.499, &mu, &la, &k);
+    const double pw = d->pin_weight > 0 ? d->pin_weight : std::sqrt(k * 2.0);
+    const bool pins_as_terms = (d->linsolver == 0 || d->linsolver == 2);
+    admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
+                                                d->tri_idx, d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, pw);
+    if (nnz) *nnz = (int32_t)A.col.size();
+    if (rowptr) std::copy(A.rowptr.begin(), A.rowptr.end(), rowptr);
+    if (col) std::copy(A.col.begin(), A.col.end(), col);
+    if (val) std::copy(A.val.begin(), A.val.end(), val);
+    return ADMM_HIP_OK;
+}
+void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end) {
+    admm_host::partition(n_items, world_size, rank, begin, end);
+}
+int admm_host_tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol) {
+    int r = admm_host::tet_rest(n, idx, verts, Binv, vol);
+    if (r) return fail(ADMM_HIP_ERR_GEOMETRY, "TetEnergyTerm Error: Inverted initial tet " + std::to_string(-r - 1));
+    return ADMM_HIP_OK;
+}
+int admm_host_tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area) {
+    int r = admm_host::tri_rest(n, idx, verts, rest, area);
+    if (r) return fail(ADMM_HIP_ERR_GEOMETRY, "TriEnergyTerm Error: Inverted initial pose " + std::to_string(-r - 1));
+    return ADMM_HIP_OK;
+}
+void admm_host_lame(double youngs, double poisson, double *mu, double *lambda, double *bulk) {
+    admm_host::lame(youngs, poisson, mu, lambda, bulk);
+}
+int admm_host_greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color) {
+    return admm_host::greedy_coloring(n, rowptr, col, color);
+}
+
+} // extern "C"

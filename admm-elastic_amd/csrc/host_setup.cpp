@@ -1,0 +1,235 @@
+// host_setup.cpp -- host-side set-up arithmetic of Solver::initialize (reference src/Solver.cpp:167-261)
+// re-designed for the GPU data layout.  No GPU calls.
+#include "host_setup.hpp"
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace admm_host {
+
+namespace {
+struct Entry { int32_t col; double val; };
+} // namespace
+
+// A = M + dt^2 D^T W^2 D (src/Solver.cpp:225-226).  Every term writes the same scalar on the x, y and
+// z rows (src/TetEnergyTerm.cpp:66-68, src/TriEnergyTerm.cpp:65-68, src/SpringEnergyTerm.hpp:56-58),
+// so A = M + Ahat (x) I3 and only the scalar n_verts x n_verts Ahat is assembled.
+Csr assemble_Ahat(int32_t n_verts, double dt,
+                  int32_t n_tets, const int32_t *tet_idx, const double *tet_Binv, const double *tet_w,
+                  int32_t n_tris, const int32_t *tri_idx, const double *tri_rest, const double *tri_w,
+                  int32_t n_pins, const int32_t *pin_vert, double pin_w) {
+    const double dt2 = dt * dt;
+    // pass 1: count entries per row
+    std::vector<int64_t> cnt(n_verts + 1, 0);
+    for (int32_t t = 0; t < n_tets; ++t)
+        for (int a = 0; a < 4; ++a) cnt[tet_idx[4 * t + a] + 1] += 4;
+    for (int32_t t = 0; t < n_tris; ++t)
+        for (int a = 0; a < 3; ++a) cnt[tri_idx[3 * t + a] + 1] += 3;
+    for (int32_t p = 0; p < n_pins; ++p) cnt[pin_vert[p] + 1] += 1;
+    for (int32_t i = 0; i < n_verts; ++i) cnt[i + 1] += cnt[i];
+    std::vector<Entry> ent(cnt[n_verts]);
+    std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+
+    for (int32_t t = 0; t < n_tets; ++t) {
+        const int32_t *id = tet_idx + 4 * t;
+        const double *Bi = tet_Binv + 9 * t; // column-major: Bi[c*3+m] = Binv(m,c)
+        const double w2 = tet_w[t] * tet_w[t] * dt2;
+        double d[3][4]; // d[r][corner]
+        for (int r = 0; r < 3; ++r) {
+            d[r][0] = -(Bi[r * 3 + 0] + Bi[r * 3 + 1] + Bi[r * 3 + 2]);
+            d[r][1] = Bi[r * 3 + 0]; d[r][2] = Bi[r * 3 + 1]; d[r][3] = Bi[r * 3 + 2];
+        }
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                double v = 0.0;
+                for (int r = 0; r < 3; ++r) v += d[r][a] * d[r][b];
+                ent[pos[id[a]]++] = {id[b], w2 * v};
+            }
+    }
+    for (int32_t t = 0; t < n_tris; ++t) {
+        const int32_t *id = tri_idx + 3 * t;
+        const double *R = tri_rest + 4 * t; // column-major 2x2: R[c*2+m] = rest(m,c)
+        const double w2 = tri_w[t] * tri_w[t] * dt2;
+        double d[2][3];
+        for (int c = 0; c < 2; ++c) {
+            d[c][0] = -(R[c * 2 + 0] + R[c * 2 + 1]);
+            d[c][1] = R[c * 2 + 0]; d[c][2] = R[c * 2 + 1];
+        }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                ent[pos[id[a]]++] = {id[b], w2 * (d[0][a] * d[0][b] + d[1][a] * d[1][b])};
+    }
+    for (int32_t p = 0; p < n_pins; ++p) ent[pos[pin_vert[p]]++] = {pin_vert[p], pin_w * pin_w * dt2};
+
+    Csr A;
+    A.n = n_verts;
+    A.rowptr.assign(n_verts + 1, 0);
+    A.col.reserve(ent.size() / 3);
+    A.val.reserve(ent.size() / 3);
+    for (int32_t i = 0; i < n_verts; ++i) {
+        Entry *b = ent.data() + cnt[i], *e = ent.data() + cnt[i + 1];
+        std::stable_sort(b, e, [](const Entry &x, const Entry &y) { return x.col < y.col; });
+        bool has_diag = false;
+        for (Entry *q = b; q < e;) {
+            int32_t c = q->col;
+            double s = 0.0;
+            for (; q < e && q->col == c; ++q) s += q->val;
+            if (c == i) has_diag = true;
+            A.col.push_back(c);
+            A.val.push_back(s);
+        }
+        if (!has_diag) { // isolated vertex: keep an explicit (zero) diagonal so every row has one
+            // insert keeping columns sorted
+            size_t start = A.rowptr[i], end = A.col.size();
+            size_t ins = start;
+            while (ins < end && A.col[ins] < i) ++ins;
+            A.col.insert(A.col.begin() + ins, i);
+            A.val.insert(A.val.begin() + ins, 0.0);
+        }
+        A.rowptr[i + 1] = (int32_t)A.col.size();
+    }
+    return A;
+}
+
+Sell csr_to_sell(const Csr &A) {
+    Sell S;
+    S.n_rows = A.n;
+    S.n_slices = (A.n + 63) / 64;
+    S.slice_ptr.assign(S.n_slices + 1, 0);
+    S.slice_width.assign(S.n_slices, 0);
+    for (int32_t s = 0; s < S.n_slices; ++s) {
+        int32_t w = 0;
+        for (int32_t r = 64 * s; r < std::min(A.n, 64 * s + 64); ++r) w = std::max(w, A.rowptr[r + 1] - A.rowptr[r]);
+        S.slice_width[s] = w;
+        S.slice_ptr[s + 1] = S.slice_ptr[s] + 64 * w;
+    }
+    S.idx.assign(S.slice_ptr[S.n_slices], 0);
+    S.val.assign(S.slice_ptr[S.n_slices], 0.0);
+    for (int32_t s = 0; s < S.n_slices; ++s)
+        for (int32_t l = 0; l < 64; ++l) {
+            const int32_t r = 64 * s + l;
+            const int32_t rr = std::min(r, A.n - 1);
+            const int32_t len = (r < A.n) ? A.rowptr[r + 1] - A.rowptr[r] : 0;
+            for (int32_t k = 0; k < S.slice_width[s]; ++k) {
+                const size_t o = (size_t)S.slice_ptr[s] + 64 * k + l;
+                if (k < len) { S.idx[o] = A.col[A.rowptr[r] + k]; S.val[o] = A.val[A.rowptr[r] + k]; }
+                else { S.idx[o] = rr; S.val[o] = 0.0; } // padding: harmless self reference, zero value
+            }
+        }
+    return S;
+}
+
+Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t pad_code) {
+    std::vector<int32_t> cnt(n_verts + 1, 0);
+    for (int64_t i = 0; i < (int64_t)n_elems * corners; ++i) cnt[idx[i] + 1]++;
+    for (int32_t i = 0; i < n_verts; ++i) cnt[i + 1] += cnt[i];
+    std::vector<int32_t> lst(cnt[n_verts]);
+    std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
+    for (int32_t e = 0; e < n_elems; ++e)
+        for (int32_t c = 0; c < corners; ++c) lst[pos[idx[(int64_t)e * corners + c]]++] = e * 4 + c;
+    Sell S;
+    S.n_rows = n_verts;
+    S.n_slices = (n_verts + 63) / 64;
+    S.slice_ptr.assign(S.n_slices + 1, 0);
+    S.slice_width.assign(S.n_slices, 0);
+    for (int32_t s = 0; s < S.n_slices; ++s) {
+        int32_t w = 0;
+        for (int32_t r = 64 * s; r < std::min(n_verts, 64 * s + 64); ++r) w = std::max(w, cnt[r + 1] - cnt[r]);
+        S.slice_width[s] = w;
+        S.slice_ptr[s + 1] = S.slice_ptr[s] + 64 * w;
+    }
+    S.idx.assign(S.slice_ptr[S.n_slices], pad_code);
+    for (int32_t r = 0; r < n_verts; ++r) {
+        const int32_t s = r / 64, l = r % 64;
+        for (int32_t k = 0; k < cnt[r + 1] - cnt[r]; ++k) S.idx[(size_t)S.slice_ptr[s] + 64 * k + l] = lst[cnt[r] + k];
+    }
+    return S;
+}
+
+// Sequential greedy colouring in node-index order: node i takes the smallest colour not used by an
+// already-coloured neighbour.  (The reference delegates to mcl::graphcolor::color_matrix, which is
+// absent; any valid colouring yields a correct multi-colour Gauss-Seidel, only the sweep order differs.)
+int greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color) {
+    int ncol = 0;
+    std::vector<int32_t> mark;
+    for (int32_t i = 0; i < n; ++i) color[i] = -1;
+    for (int32_t i = 0; i < n; ++i) {
+        mark.assign(ncol + 1, 0);
+        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            const int32_t j = col[k];
+            if (j != i && color[j] >= 0) mark[color[j]] = 1;
+        }
+        int c = 0;
+        while (c < ncol && mark[c]) ++c;
+        color[i] = c;
+        if (c == ncol) ++ncol;
+    }
+    return ncol;
+}
+
+// src/TetEnergyTerm.cpp:31-48
+int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol) {
+    for (int32_t t = 0; t < n; ++t) {
+        const double *v0 = verts + 3 * idx[4 * t], *v1 = verts + 3 * idx[4 * t + 1];
+        const double *v2 = verts + 3 * idx[4 * t + 2], *v3 = verts + 3 * idx[4 * t + 3];
+        double B[3][3]; // B[r][c]
+        for (int r = 0; r < 3; ++r) { B[r][0] = v1[r] - v0[r]; B[r][1] = v2[r] - v0[r]; B[r][2] = v3[r] - v0[r]; }
+        const double det = B[0][0] * (B[1][1] * B[2][2] - B[1][2] * B[2][1])
+                         - B[0][1] * (B[1][0] * B[2][2] - B[1][2] * B[2][0])
+                         + B[0][2] * (B[1][0] * B[2][1] - B[1][1] * B[2][0]);
+        vol[t] = det / 6.0;
+        if (vol[t] < 0) return -(t + 1);
+        const double id = 1.0 / det;
+        double *o = Binv + 9 * t; // column-major o[c*3+r]
+        o[0 * 3 + 0] =  (B[1][1] * B[2][2] - B[1][2] * B[2][1]) * id;
+        o[1 * 3 + 0] = -(B[0][1] * B[2][2] - B[0][2] * B[2][1]) * id;
+        o[2 * 3 + 0] =  (B[0][1] * B[1][2] - B[0][2] * B[1][1]) * id;
+        o[0 * 3 + 1] = -(B[1][0] * B[2][2] - B[1][2] * B[2][0]) * id;
+        o[1 * 3 + 1] =  (B[0][0] * B[2][2] - B[0][2] * B[2][0]) * id;
+        o[2 * 3 + 1] = -(B[0][0] * B[1][2] - B[0][2] * B[1][0]) * id;
+        o[0 * 3 + 2] =  (B[1][0] * B[2][1] - B[1][1] * B[2][0]) * id;
+        o[1 * 3 + 2] = -(B[0][0] * B[2][1] - B[0][1] * B[2][0]) * id;
+        o[2 * 3 + 2] =  (B[0][0] * B[1][1] - B[0][1] * B[1][0]) * id;
+    }
+    return 0;
+}
+
+// src/TriEnergyTerm.cpp:29-52
+int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area) {
+    for (int32_t t = 0; t < n; ++t) {
+        const double *v0 = verts + 3 * idx[3 * t], *v1 = verts + 3 * idx[3 * t + 1], *v2 = verts + 3 * idx[3 * t + 2];
+        double e12[3], e13[3], n1[3], n2[3];
+        for (int r = 0; r < 3; ++r) { e12[r] = v1[r] - v0[r]; e13[r] = v2[r] - v0[r]; }
+        double l = std::sqrt(e12[0] * e12[0] + e12[1] * e12[1] + e12[2] * e12[2]);
+        for (int r = 0; r < 3; ++r) n1[r] = e12[r] / l;
+        const double dp = e13[0] * n1[0] + e13[1] * n1[1] + e13[2] * n1[2];
+        for (int r = 0; r < 3; ++r) n2[r] = e13[r] - dp * n1[r];
+        l = std::sqrt(n2[0] * n2[0] + n2[1] * n2[1] + n2[2] * n2[2]);
+        for (int r = 0; r < 3; ++r) n2[r] /= l;
+        const double m00 = n1[0] * e12[0] + n1[1] * e12[1] + n1[2] * e12[2];
+        const double m01 = n1[0] * e13[0] + n1[1] * e13[1] + n1[2] * e13[2];
+        const double m10 = n2[0] * e12[0] + n2[1] * e12[1] + n2[2] * e12[2];
+        const double m11 = n2[0] * e13[0] + n2[1] * e13[1] + n2[2] * e13[2];
+        const double det = m00 * m11 - m01 * m10;
+        area[t] = det / 2.0;
+        if (area[t] < 0) return -(t + 1);
+        double *o = rest + 4 * t; // column-major 2x2
+        o[0] = m11 / det; o[1] = -m10 / det; o[2] = -m01 / det; o[3] = m00 / det;
+    }
+    return 0;
+}
+
+// src/EnergyTerm.hpp:34-59
+void lame(double youngs, double poisson, double *mu, double *lambda, double *bulk) {
+    *mu = youngs / (2.0 * (1.0 + poisson));
+    *lambda = youngs * poisson / ((1.0 + poisson) * (1.0 - 2.0 * poisson));
+    *bulk = *lambda + (2.0 / 3.0) * (*mu);
+}
+
+void partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end) {
+    const int64_t n = n_items;
+    *begin = (int32_t)(n * rank / world_size);
+    *end = (int32_t)(n * (rank + 1) / world_size);
+}
+
+} // namespace admm_host

@@ -1,0 +1,50 @@
+// host_setup.hpp -- host-side set-up structures shared by the C ABI (no GPU code here).
+#pragma once
+#include <cstdint>
+#include <vector>
+#include <string>
+
+namespace admm_host {
+
+struct Csr {
+    int32_t n = 0;
+    std::vector<int32_t> rowptr, col;
+    std::vector<double> val;
+};
+
+// Sliced ELL with slice height 64 (= one gfx950 wavefront): slice s holds rows [64 s, 64 s + 64),
+// all padded to the slice's widest row; element (row 64 s + l, k) lives at slice_ptr[s] + 64 k + l,
+// so a wave reads 64 consecutive entries per k (coalesced).
+struct Sell {
+    int32_t n_rows = 0, n_slices = 0;
+    std::vector<int32_t> slice_ptr;   // [n_slices + 1], element offsets
+    std::vector<int32_t> slice_width; // [n_slices]
+    std::vector<int32_t> idx;         // column index / incidence code
+    std::vector<double> val;          // empty for pure index lists
+};
+
+// One scalar reduction row of D-hat: coefficient `c` on vertex `v` (TetEnergyTerm.cpp:52-70 etc.)
+struct TermRows {
+    // For every energy term: its weight^2 and its rows as (vertex, coefficient) lists.
+    // Assembled directly into Ahat = dt^2 sum_terms w^2 sum_rows d d^T  (Solver.cpp:225-226).
+};
+
+// Ahat (n_verts x n_verts, scalar; the mass diagonal is NOT included) from the flattened terms.
+Csr assemble_Ahat(int32_t n_verts, double dt,
+                  int32_t n_tets, const int32_t *tet_idx, const double *tet_Binv, const double *tet_w,
+                  int32_t n_tris, const int32_t *tri_idx, const double *tri_rest, const double *tri_w,
+                  int32_t n_pins, const int32_t *pin_vert, double pin_w);
+
+Sell csr_to_sell(const Csr &A);
+
+// vertex -> list of (element, corner) codes, code = elem * stride + corner; padding = pad_code
+Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t pad_code);
+
+int greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color);
+
+int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
+int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
+void lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);
+void partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end);
+
+} // namespace admm_host

@@ -1,0 +1,542 @@
+// kernels.hpp -- gfx950 kernels of the ADMM hot path (included once by admm_hip.hip).
+//
+// Data layout in HBM (FP64, int32 indices):
+//   node vectors  x, v, m, Mxbar, curr, b, r, p, ...   [n_verts][3] interleaved (the API's layout)
+//   per-tet       idx  int4[nt]            one 16-B load per lane, coalesced
+//                 Binv [9][ld], u [9][ld], z [9][ld], cf [12][ld]   SoA, ld = nt + 1: lane t reads
+//                 component c at c*ld + t -> every load/store of a wave is one contiguous 512-B run
+//                 sc [ld] = dt^2 w^2, mat int[nt] -> Mat table {mu, lambda, k}
+//   per-tri       idx int4[n], rest [4][ld], u/z [6][ld], cf [9][ld], sc, limits
+//   Ahat / vertex->corner incidence: SELL-64 (slice = one wavefront, see host_setup.hpp)
+// One lane owns one element (local step) or one vertex row (gather, SpMV): the SoA layout makes all
+// streaming traffic fully coalesced 8-B-per-lane accesses, and the only irregular accesses are the
+// 24-B position gathers, which hit L2 for any locality-preserving mesh order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_math.hpp"
+
+namespace admm_k {
+
+using namespace admm_dev;
+
+struct Mat { double mu, la, k; };
+
+constexpr int kMaxObst = 8;
+struct Obstacles {
+    int n;
+    int kind[kMaxObst];
+    double par[kMaxObst][4];
+};
+
+// scalars of one PCG solve, double-buffered by iteration parity
+struct CgScal {
+    double gamma[3];
+    double alpha[3];
+    double gamma_b[3];
+    int converged;
+    int iters;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// block-wide sum of NQ quantities (256 threads = 4 waves); result valid in all threads
+template <int NQ>
+__device__ __forceinline__ void block_sum(double *q, double *lds /* [4*NQ] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const double s = wave_sum(q[i]);
+        if (lane == 0) lds[wv * NQ + i] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) q[i] = lds[i] + lds[NQ + i] + lds[2 * NQ + i] + lds[3 * NQ + i];
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Solver::step prologue (src/Solver.cpp:57-72): gravity, x_bar, M x_bar, curr_x = x_bar
+__global__ __launch_bounds__(256) void k_predict(int n3, double dt, double gravity, const double *__restrict__ x,
+                                                 double *__restrict__ v, const double *__restrict__ m,
+                                                 double *__restrict__ Mxbar, double *__restrict__ curr) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    double vi = v[i];
+    if (i % 3 == 1) { vi += dt * gravity; v[i] = vi; }
+    const double xb = x[i] + dt * vi;
+    Mxbar[i] = m[i] * xb;
+    curr[i] = xb;
+}
+
+// Solver::step epilogue (src/Solver.cpp:105-106)
+__global__ __launch_bounds__(256) void k_finish(int n3, double inv_dt, double *__restrict__ x, double *__restrict__ v,
+                                                const double *__restrict__ curr) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    const double c = curr[i];
+    v[i] = (c - x[i]) * inv_dt;
+    x[i] = c;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LOCAL STEP, tets: EnergyTerm::update (src/EnergyTerm.hpp:130-140) for every tet of one constitutive
+// model, fused with the element's contribution to dt^2 D^T W^2 (z - u) (src/Solver.cpp:98), written as
+// 4 corner force vectors cf[12][ld] that k_gather_rhs sums per vertex (no atomics, deterministic).
+//   F = [x1-x0, x2-x0, x3-x0] Binv  ==  D_i x   (D-block of src/TetEnergyTerm.cpp:50-71)
+template <int KIND, bool WRITE_Z>
+__global__ __launch_bounds__(256) void k_local_tets(int t0, int t1, int ld, const int4 *__restrict__ idx,
+                                                    const double *__restrict__ Binv, double *__restrict__ u,
+                                                    double *__restrict__ z, const double *__restrict__ sc,
+                                                    const int *__restrict__ mat_id, const Mat *__restrict__ mats,
+                                                    const double *__restrict__ x, double *__restrict__ cf) {
+    const int t = t0 + blockIdx.x * 256 + threadIdx.x;
+    if (t >= t1) return;
+    const int4 id = idx[t];
+    double Bi[9], ui[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { Bi[c] = Binv[(size_t)c * ld + t]; ui[c] = u[(size_t)c * ld + t]; }
+    const double *p0 = x + 3 * (size_t)id.x, *p1 = x + 3 * (size_t)id.y, *p2 = x + 3 * (size_t)id.z, *p3 = x + 3 * (size_t)id.w;
+    double Ds[9];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double a = p0[j];
+        Ds[0 + j] = p1[j] - a; Ds[3 + j] = p2[j] - a; Ds[6 + j] = p3[j] - a;
+    }
+    double F[9], q[9], zi[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double f = fma(Ds[j], Bi[r * 3 + 0], fma(Ds[3 + j], Bi[r * 3 + 1], Ds[6 + j] * Bi[r * 3 + 2]));
+            F[r * 3 + j] = f;
+            q[r * 3 + j] = f + ui[r * 3 + j];
+        }
+    if (KIND == 0) {
+        prox_tet_linear(q, zi);
+    } else {
+        const Mat mt = mats[mat_id[t]];
+        if (KIND == 1) prox_tet_hyper<1>(mt.mu, mt.la, mt.k, q, zi);
+        else prox_tet_hyper<2>(mt.mu, mt.la, mt.k, q, zi);
+    }
+    const double s = sc[t];
+    double G[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) {
+        const double un = ui[c] + (F[c] - zi[c]);         // EnergyTerm.hpp:137
+        u[(size_t)c * ld + t] = un;
+        if (WRITE_Z) z[(size_t)c * ld + t] = zi[c];
+        G[c] = s * (zi[c] - un);
+    }
+    // corner forces: H(j,m) = sum_r G(j,r) Binv(m,r); corner m+1 gets H(:,m), corner 0 gets -sum_m H(:,m)
+    double f0[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double h = fma(G[j], Bi[m], fma(G[3 + j], Bi[3 + m], G[6 + j] * Bi[6 + m]));
+            cf[(size_t)(3 * (m + 1) + j) * ld + t] = h;
+            f0[j] -= h;
+        }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) cf[(size_t)j * ld + t] = f0[j];
+}
+
+// LOCAL STEP, triangles (src/TriEnergyTerm.cpp:54-101): F (3x2) = [x1-x0, x2-x0] rest
+template <bool WRITE_Z>
+__global__ __launch_bounds__(256) void k_local_tris(int n, int ld, const int4 *__restrict__ idx,
+                                                    const double *__restrict__ rest, double *__restrict__ u,
+                                                    double *__restrict__ z, const double *__restrict__ sc,
+                                                    const double *__restrict__ lmin, const double *__restrict__ lmax,
+                                                    const double *__restrict__ x, double *__restrict__ cf) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int4 id = idx[t];
+    double R[4], ui[6];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) R[c] = rest[(size_t)c * ld + t];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) ui[c] = u[(size_t)c * ld + t];
+    const double *p0 = x + 3 * (size_t)id.x, *p1 = x + 3 * (size_t)id.y, *p2 = x + 3 * (size_t)id.z;
+    double F[6], q[6], zi[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double a = p0[j], e1 = p1[j] - a, e2 = p2[j] - a;
+        F[j] = fma(e1, R[0], e2 * R[1]);
+        F[3 + j] = fma(e1, R[2], e2 * R[3]);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) q[c] = F[c] + ui[c];
+    prox_tri(q, lmin[t], lmax[t], zi);
+    const double s = sc[t];
+    double G[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const double un = ui[c] + (F[c] - zi[c]);
+        u[(size_t)c * ld + t] = un;
+        if (WRITE_Z) z[(size_t)c * ld + t] = zi[c];
+        G[c] = s * (zi[c] - un);
+    }
+    // D = S rest: corner1 coefficient (R0 for col0, R2 for col1), corner2 (R1, R3), corner0 = -(sum)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double h1 = fma(G[j], R[0], G[3 + j] * R[2]);
+        const double h2 = fma(G[j], R[1], G[3 + j] * R[3]);
+        cf[(size_t)(0 + j) * ld + t] = -(h1 + h2);
+        cf[(size_t)(3 + j) * ld + t] = h1;
+        cf[(size_t)(6 + j) * ld + t] = h2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RHS: b = [M x_bar] + dt^2 D^T W^2 (z - u)  (src/Solver.cpp:98), gathered per vertex from the corner
+// forces, plus the SpringPin terms (src/SpringEnergyTerm.hpp:54-61), whose local step is done here.
+struct GatherArgs {
+    int nv, n_slices;
+    const int *t_ptr, *t_w, *t_inc; const double *t_cf; int t_ld;  // tets (t_inc == nullptr -> none)
+    const int *r_ptr, *r_w, *r_inc; const double *r_cf; int r_ld;  // tris
+    const int *vert_pin;       // [nv] pin term index or -1 (nullptr -> no pin terms)
+    const double *pin_xyz; const int *pin_active; double *pin_u, *pin_z; double pin_sc; // dt^2 w_pin^2
+    const double *x;           // curr_x (for the pin terms)
+    const double *Mxbar;       // added when add_mxbar
+    double *b;
+    int add_mxbar;             // 1 on a single GPU / on rank 0
+};
+
+__global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    for (int s = wave; s < a.n_slices; s += nwaves) {
+        const int v = s * 64 + lane;
+        double acc[3] = {0.0, 0.0, 0.0};
+        if (a.t_inc) {
+            const int w = a.t_w[s];
+            const int *inc = a.t_inc + a.t_ptr[s] + lane;
+            for (int k = 0; k < w; ++k) {
+                const int e = inc[64 * k];
+                const int t = e >> 2, c = e & 3;
+                const double *p = a.t_cf + (size_t)(3 * c) * a.t_ld + t;
+                acc[0] += p[0]; acc[1] += p[a.t_ld]; acc[2] += p[2 * (size_t)a.t_ld];
+            }
+        }
+        if (a.r_inc) {
+            const int w = a.r_w[s];
+            const int *inc = a.r_inc + a.r_ptr[s] + lane;
+            for (int k = 0; k < w; ++k) {
+                const int e = inc[64 * k];
+                const int t = e >> 2, c = e & 3;
+                const double *p = a.r_cf + (size_t)(3 * c) * a.r_ld + t;
+                acc[0] += p[0]; acc[1] += p[a.r_ld]; acc[2] += p[2 * (size_t)a.r_ld];
+            }
+        }
+        if (v < a.nv) {
+            if (a.vert_pin) {
+                const int pi = a.vert_pin[v];
+                if (pi >= 0) {
+                    const bool act = a.pin_active[pi] != 0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double Dix = a.x[3 * (size_t)v + j];
+                        const double uo = a.pin_u[3 * (size_t)pi + j];
+                        const double zi = act ? a.pin_xyz[3 * (size_t)pi + j] : (Dix + uo);
+                        const double un = uo + (Dix - zi);
+                        a.pin_u[3 * (size_t)pi + j] = un;
+                        a.pin_z[3 * (size_t)pi + j] = zi;
+                        if (a.add_mxbar) acc[j] += a.pin_sc * (zi - un);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double r = acc[j];
+                if (a.add_mxbar) r += a.Mxbar[3 * (size_t)v + j];
+                a.b[3 * (size_t)v + j] = r;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GLOBAL STEP (ADMM_LS_LDLT_AS_PCG): Jacobi-preconditioned CG in the Chronopoulos-Gear form (one
+// reduction point per iteration -> two kernels per iteration) on A = diag(m) + Ahat (x) I3, the three
+// axes carried as three independent systems sharing Ahat (own alpha/beta per axis).
+// Replaces the prefactored LDLT solve of src/LinearSolver.hpp:87-90.
+struct SellA { int n_rows, n_slices; const int *ptr, *w, *col; const double *val; };
+
+// y_row = m_row * in_row + sum_k Ahat(row,k) in_col   for the 3 axes of one row
+__device__ __forceinline__ void sell_row(const SellA &A, int s, int lane, const double *__restrict__ in, double *acc) {
+    const int w = A.w[s];
+    const int base = A.ptr[s] + lane;
+    acc[0] = acc[1] = acc[2] = 0.0;
+    for (int k = 0; k < w; ++k) {
+        const int c = A.col[base + 64 * k];
+        const double a = A.val[base + 64 * k];
+        const double *p = in + 3 * (size_t)c;
+        acc[0] = fma(a, p[0], acc[0]); acc[1] = fma(a, p[1], acc[1]); acc[2] = fma(a, p[2], acc[2]);
+    }
+}
+
+// r = b - A x ; u = dinv r ; partial_b[3][NB] = sum b * dinv * b
+__global__ __launch_bounds__(256) void k_cg_resid(SellA A, const double *__restrict__ m, const double *__restrict__ dinv,
+                                                  const double *__restrict__ b, const double *__restrict__ x,
+                                                  double *__restrict__ r, double *__restrict__ u,
+                                                  double *__restrict__ part_b, int NB, CgScal *__restrict__ sc0) {
+    __shared__ double lds[12];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc0->converged = 0; sc0->iters = 0; }
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    double q[3] = {0.0, 0.0, 0.0};
+    for (int s = wave; s < A.n_slices; s += nwaves) {
+        const int row = s * 64 + lane;
+        double acc[3];
+        sell_row(A, s, lane, x, acc);
+        if (row < A.n_rows) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const size_t i = 3 * (size_t)row + j;
+                const double bi = b[i], di = dinv[i];
+                const double ri = bi - fma(m[i], x[i], acc[j]);
+                r[i] = ri; u[i] = di * ri;
+                q[j] = fma(bi * di, bi, q[j]);
+            }
+        }
+    }
+    block_sum<3>(q, lds);
+    if (threadIdx.x == 0) { part_b[blockIdx.x] = q[0]; part_b[NB + blockIdx.x] = q[1]; part_b[2 * NB + blockIdx.x] = q[2]; }
+}
+
+// w = A u ; partials gamma = r.u, delta = w.u   (skipped when the solve has converged)
+__global__ __launch_bounds__(256) void k_cg_spmv(SellA A, const double *__restrict__ m, const double *__restrict__ u,
+                                                 const double *__restrict__ r, double *__restrict__ w,
+                                                 double *__restrict__ part, int NB, const CgScal *__restrict__ sc) {
+    __shared__ double lds[24];
+    if (sc->converged) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int s = wave; s < A.n_slices; s += nwaves) {
+        const int row = s * 64 + lane;
+        double acc[3];
+        sell_row(A, s, lane, u, acc);
+        if (row < A.n_rows) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const size_t i = 3 * (size_t)row + j;
+                const double ui = u[i];
+                const double wi = fma(m[i], ui, acc[j]);
+                w[i] = wi;
+                q[j] = fma(r[i], ui, q[j]);
+                q[3 + j] = fma(wi, ui, q[3 + j]);
+            }
+        }
+    }
+    block_sum<6>(q, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) part[i * NB + blockIdx.x] = q[i];
+    }
+}
+
+// reduce the partials, derive alpha/beta, update p, s, x, r, u
+__global__ __launch_bounds__(256) void k_cg_vec(int it, int n3, int NB, const double *__restrict__ part,
+                                                const double *__restrict__ part_b, const CgScal *__restrict__ prev,
+                                                CgScal *__restrict__ next, double tol2, int *__restrict__ total_iters,
+                                                const double *__restrict__ dinv, double *__restrict__ p,
+                                                double *__restrict__ s, double *__restrict__ x, double *__restrict__ r,
+                                                double *__restrict__ u, const double *__restrict__ w) {
+    __shared__ double lds[36];
+    const CgScal pv = *prev;
+    if (it > 0 && pv.converged) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *next = pv;
+        return;
+    }
+    double q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < NB; i += 256) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q[k] += part[k * NB + i];
+        if (it == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q[6 + k] += part_b[k * NB + i];
+        }
+    }
+    block_sum<9>(q, lds);
+    double gb[3], alpha[3], beta[3];
+    bool conv = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        gb[a] = (it == 0) ? q[6 + a] : pv.gamma_b[a];
+        conv = conv && (q[a] <= tol2 * gb[a] + 1e-300);
+    }
+    if (conv) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            CgScal o = pv;
+            if (it == 0) { o.iters = 0; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { o.gamma[a] = q[a]; o.gamma_b[a] = gb[a]; o.alpha[a] = 0.0; }
+            o.converged = 1;
+            *next = o;
+        }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double g = q[a], d = q[3 + a];
+        if (it == 0) { beta[a] = 0.0; alpha[a] = (d > 0.0) ? g / d : 0.0; }
+        else {
+            beta[a] = (pv.gamma[a] > 0.0) ? g / pv.gamma[a] : 0.0;
+            const double den = (pv.alpha[a] != 0.0) ? d - beta[a] * g / pv.alpha[a] : d;
+            alpha[a] = (den > 0.0) ? g / den : 0.0;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CgScal o;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { o.gamma[a] = q[a]; o.alpha[a] = alpha[a]; o.gamma_b[a] = gb[a]; }
+        o.converged = 0;
+        o.iters = (it == 0 ? 0 : pv.iters) + 1;
+        *next = o;
+        atomicAdd(total_iters, 1);
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n3; i += gridDim.x * 256) {
+        const int a = i % 3;
+        const double be = beta[a], al = alpha[a];
+        const double pi = (it == 0) ? u[i] : fma(be, p[i], u[i]);
+        const double si = (it == 0) ? w[i] : fma(be, s[i], w[i]);
+        p[i] = pi; s[i] = si;
+        x[i] = fma(al, pi, x[i]);
+        const double ri = fma(-al, si, r[i]);
+        r[i] = ri;
+        u[i] = dinv[i] * ri;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GLOBAL STEP (ADMM_LS_NCMCGS): nodal multi-colour SOR, src/NodalMultiColorGS.hpp:60-146,180-262.
+__device__ __forceinline__ bool passive_hit(const Obstacles &ob, const double *x, double *n, double *p) {
+    double best = 1.7976931348623157e308; // Payload ctor (src/Collider.hpp:73)
+    for (int j = 0; j < ob.n; ++j) {
+        if (ob.kind[j] == 0) { // Floor, src/PassiveObject.hpp:32-45
+            const double dx = x[1] - ob.par[j][0];
+            if (!(dx > best)) { best = dx; p[0] = x[0]; p[1] = ob.par[j][0]; p[2] = x[2]; n[0] = 0.0; n[1] = 1.0; n[2] = 0.0; }
+        } else {               // Sphere, src/PassiveObject.hpp:48-64
+            double d[3] = {x[0] - ob.par[j][0], x[1] - ob.par[j][1], x[2] - ob.par[j][2]};
+            const double l = sqrt(dot3(d, d)), dx = l - ob.par[j][3];
+            if (!(dx > best)) {
+                best = dx;
+                const double il = 1.0 / l;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { d[c] *= il; p[c] = ob.par[j][c] + d[c] * ob.par[j][3]; n[c] = d[c]; }
+            }
+        }
+        if (best < 0.0) return true; // src/Collider.hpp:143-148: first object with dx < 0 wins
+    }
+    return false;
+}
+
+struct GsArgs {
+    const int *rowptr, *col; const double *val; // Ahat CSR
+    const double *m;        // [3 nv]
+    const double *b; double *x;
+    const int *pin_flag; const double *pin_xyz; // per node (nullptr -> no pins)
+    double omega;
+    const int *done;        // set once the residual test passed
+};
+
+__global__ __launch_bounds__(256) void k_gs_color(GsArgs a, const int *__restrict__ nodes, int count, Obstacles ob) {
+    if (*a.done) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int v = nodes[i];
+    if (a.pin_flag && a.pin_flag[v]) { // :111-117
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a.x[3 * (size_t)v + s] = a.pin_xyz[3 * (size_t)v + s];
+        return;
+    }
+    double LUx[3] = {0.0, 0.0, 0.0}, ad = 0.0;
+    for (int k = a.rowptr[v]; k < a.rowptr[v + 1]; ++k) {
+        const double val = a.val[k];
+        if (fabs(val) <= 0.0) continue; // :194
+        const int c = a.col[k];
+        if (c == v) { ad = val; continue; }
+        const double *p = a.x + 3 * (size_t)c;
+        LUx[0] += val * p[0]; LUx[1] += val * p[1]; LUx[2] += val * p[2];
+    }
+    double jac[3], nx[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const double aii = ad + a.m[3 * (size_t)v + s];
+        const double cx = a.x[3 * (size_t)v + s];
+        jac[s] = (a.b[3 * (size_t)v + s] - LUx[s]) / aii;
+        nx[s] = (1.0 - a.omega) * cx + a.omega * jac[s]; // :210
+    }
+    double n[3], p[3];
+    if (ob.n > 0 && passive_hit(ob, nx, n, p)) { // constrained_segment_update :218-262
+        double dx[3] = {jac[0] - p[0], jac[1] - p[1], jac[2] - p[2]};
+        double nn[3] = {0.0, 0.0, 0.0}, uu[3], vv[3];
+        if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0; // orthoG :171-177
+        cross3(nn, n, uu);
+        double il = 1.0 / sqrt(dot3(uu, uu));
+#pragma unroll
+        for (int s = 0; s < 3; ++s) uu[s] *= il;
+        cross3(n, uu, vv);
+        il = 1.0 / sqrt(dot3(vv, vv));
+#pragma unroll
+        for (int s = 0; s < 3; ++s) vv[s] *= il;
+        const double t0 = dot3(uu, dx), t1 = dot3(vv, dx);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) nx[s] = uu[s] * t0 + vv[s] * t1 + p[s];
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a.x[3 * (size_t)v + s] = nx[s];
+}
+
+// residual test of one sweep (:136-140): partial sums of |b - A x|^2 and |b|^2
+__global__ __launch_bounds__(256) void k_gs_resid(SellA A, const double *__restrict__ m, const double *__restrict__ b,
+                                                  const double *__restrict__ x, double *__restrict__ part, int NB,
+                                                  const int *__restrict__ done) {
+    __shared__ double lds[8];
+    if (*done) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    double q[2] = {0.0, 0.0};
+    for (int s = wave; s < A.n_slices; s += nwaves) {
+        const int row = s * 64 + lane;
+        double acc[3];
+        sell_row(A, s, lane, x, acc);
+        if (row < A.n_rows) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const size_t i = 3 * (size_t)row + j;
+                const double bi = b[i];
+                const double ri = bi - fma(m[i], x[i], acc[j]);
+                q[0] = fma(ri, ri, q[0]);
+                q[1] = fma(bi, bi, q[1]);
+            }
+        }
+    }
+    block_sum<2>(q, lds);
+    if (threadIdx.x == 0) { part[blockIdx.x] = q[0]; part[NB + blockIdx.x] = q[1]; }
+}
+
+// one block: finish the reduction, count the sweep like the reference's `iter`, raise `done`
+__global__ __launch_bounds__(256) void k_gs_check(const double *__restrict__ part, int NB, double tol2, int *done,
+                                                  int *sweeps, int *total, int check) {
+    __shared__ double lds[8];
+    if (*done) return;
+    bool conv = false;
+    if (check) {
+        double q[2] = {0.0, 0.0};
+        for (int i = threadIdx.x; i < NB; i += 256) { q[0] += part[i]; q[1] += part[NB + i]; }
+        block_sum<2>(q, lds);
+        conv = (q[0] / q[1] < tol2);
+    }
+    if (threadIdx.x == 0) {
+        if (conv) *done = 1; else { atomicAdd(sweeps, 1); atomicAdd(total, 1); }
+    }
+}
+
+} // namespace admm_k

@@ -1,0 +1,99 @@
+"""Synthetic mesh generators for the BASELINE configs and lumped masses.
+
+The reference's generators (mcl::factory::make_tet_blocks / make_plane, TetMesh::weighted_masses)
+live in the absent mclscene submodule; these are written from their described behaviour.
+"""
+import itertools
+
+import numpy as np
+
+
+def tet_blocks(nx, ny, nz, size=None, origin=(0.0, 0.0, 0.0)):
+    """Kuhn triangulation: 6 tets per cell of an nx x ny x nz grid, all positively oriented
+    (the reference throws on negative rest volume, src/TetEnergyTerm.cpp:42-44).
+    Returns verts [nv,3] float64, tets [nt,4] int32.  size: (sx,sy,sz) extents (default = cell counts)."""
+    gx, gy, gz = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), np.arange(nz + 1), indexing="ij")
+    verts = np.stack([gx, gy, gz], axis=-1).reshape(-1, 3).astype(np.float64)
+
+    def vid(i, j, k):
+        return (i * (ny + 1) + j) * (nz + 1) + k
+
+    ci, cj, ck = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    ci, cj, ck = ci.ravel(), cj.ravel(), ck.ravel()
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        p = [np.stack([ci, cj, ck], axis=1)]
+        for ax in perm:
+            q = p[-1].copy()
+            q[:, ax] += 1
+            p.append(q)
+        ids = [vid(a[:, 0], a[:, 1], a[:, 2]) for a in p]
+        # orientation of (v1-v0, v2-v0, v3-v0) is the parity of the permutation
+        e = np.zeros((3, 3))
+        cum = np.zeros(3)
+        for c, ax in enumerate(perm):
+            cum = cum.copy(); cum[ax] += 1
+            e[:, c] = cum
+        if np.linalg.det(e) < 0:
+            ids[2], ids[3] = ids[3], ids[2]
+        tets.append(np.stack(ids, axis=1))
+    # interleave so the 6 tets of a cell are contiguous (cell-major order = good locality)
+    tets = np.stack(tets, axis=1).reshape(-1, 4).astype(np.int32)
+    if size is not None:
+        verts = verts * (np.asarray(size, dtype=np.float64) / np.array([nx, ny, nz], dtype=np.float64))
+    verts = verts + np.asarray(origin, dtype=np.float64)
+    return verts, tets
+
+
+def kuhn_cube(n, size=1.0):
+    """Unit cube, n cells per edge: nt = 6 n^3, nv = (n+1)^3 (n=26 -> 105 456 tets, n=55 -> 998 250)."""
+    return tet_blocks(n, n, n, size=(size, size, size))
+
+
+def cloth_grid(m, size=1.0, y=0.0):
+    """m x m cells in the xz-plane at height y, two triangles (a,b,c),(a,c,d) per cell."""
+    g = np.arange(m + 1)
+    gx, gz = np.meshgrid(g, g, indexing="ij")
+    verts = np.stack([gx * (size / m), np.full_like(gx, y, dtype=np.float64), gz * (size / m)], axis=-1).reshape(-1, 3)
+    verts = verts.astype(np.float64)
+    ci, ck = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    ci, ck = ci.ravel(), ck.ravel()
+    a = ci * (m + 1) + ck; b = (ci + 1) * (m + 1) + ck; c = (ci + 1) * (m + 1) + ck + 1; d = ci * (m + 1) + ck + 1
+    tris = np.stack([np.stack([a, b, c], 1), np.stack([a, c, d], 1)], axis=1).reshape(-1, 3).astype(np.int32)
+    return verts, tris
+
+
+def tet_volumes(verts, tets):
+    v0, v1, v2, v3 = (verts[tets[:, i]] for i in range(4))
+    return np.einsum("ij,ij->i", np.cross(v1 - v0, v2 - v0), v3 - v0) / 6.0
+
+
+def lumped_masses_tets(verts, tets, density=1522.0):
+    """rho * vol / 4 to every corner (AddMeshes.hpp:113-122 uses density 1522 for tets). Returns [nv]."""
+    vol = tet_volumes(verts, tets)
+    m = np.zeros(verts.shape[0])
+    np.add.at(m, tets.ravel(), np.repeat(density * vol / 4.0, 4))
+    return m
+
+
+def lumped_masses_tris(verts, tris, density=1.0):
+    v0, v1, v2 = (verts[tris[:, i]] for i in range(3))
+    area = 0.5 * np.linalg.norm(np.cross(v1 - v0, v2 - v0), axis=1)
+    m = np.zeros(verts.shape[0])
+    np.add.at(m, tris.ravel(), np.repeat(density * area / 3.0, 3))
+    return m
+
+
+def load_tetgen(node_path, ele_path):
+    """TetGen .node/.ele reader (the reference's samples/data format, 0- or 1-indexed)."""
+    with open(node_path) as f:
+        rows = [ln.split() for ln in f if ln.strip() and not ln.lstrip().startswith("#")]
+    nv = int(rows[0][0])
+    body = rows[1:1 + nv]
+    first = int(body[0][0])
+    verts = np.array([[float(r[1]), float(r[2]), float(r[3])] for r in body])
+    with open(ele_path) as f:
+        rows = [ln.split() for ln in f if ln.strip() and not ln.lstrip().startswith("#")]
+    nt = int(rows[0][0])
+    tets = np.array([[int(r[1]), int(r[2]), int(r[3]), int(r[4])] for r in rows[1:1 + nt]], dtype=np.int32) - first
+    return verts, tets

@@ -1,0 +1,334 @@
+"""Python mirror of the reference's Solver / EnergyTerm / Lame interface for the ADMM hot path.
+
+Same names, argument meaning and error behaviour as the reference classes (file:line cited per
+method), sitting on the C ABI in include/admm_hip.h.  All per-iteration work runs in the HIP kernels
+of libadmm_hip.so; this file only flattens the scene description, like Solver::initialize does.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import AdmmHipError, Desc, Stats, check, dptr, f64, i32, iptr, lib
+
+TET_LINEAR, TET_NEOHOOKEAN, TET_STVK, TET_SPLINE_NH = 0, 1, 2, 3
+LS_LDLT, LS_NCMCGS, LS_UZAWACG = 0, 1, 2
+
+
+class Lame:
+    """src/EnergyTerm.hpp:34-59."""
+
+    def __init__(self, youngs=None, poisson=None, mu=None, lambda_=None):
+        if youngs is not None:
+            self.mu = youngs / (2.0 * (1.0 + poisson))
+            self.lambda_ = youngs * poisson / ((1.0 + poisson) * (1.0 - 2.0 * poisson))
+        else:
+            self.mu, self.lambda_ = mu, lambda_
+        self.limit_min, self.limit_max = -100.0, 100.0
+
+    def bulk_modulus(self):
+        return self.lambda_ + (2.0 / 3.0) * self.mu
+
+    @staticmethod
+    def rubber():
+        return Lame(10000000.0, 0.499)
+
+    @staticmethod
+    def soft_rubber():
+        return Lame(10000000.0, 0.399)
+
+    @staticmethod
+    def very_soft_rubber():
+        return Lame(1000000.0, 0.299)
+
+
+class Settings:
+    """Solver::Settings, src/Solver.hpp:39-50 (+ the GPU inner-solver knobs)."""
+
+    def __init__(self, **kw):
+        self.timestep_s = 1.0 / 24.0
+        self.verbose = 0
+        self.admm_iters = 10
+        self.gravity = -9.8
+        self.linsolver = 0
+        self.constraint_w = -1.0
+        self.pcg_max_iters = 0
+        self.pcg_tol = 0.0
+        self.gs_max_iters = 0
+        self.gs_tol = -1.0
+        self.gs_omega = 0.0
+        self.uzawa_max_iters = 0
+        self.uzawa_tol = 0.0
+        self.device = 0
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError("unknown setting " + k)
+            setattr(self, k, v)
+
+
+class RuntimeData:
+    """Solver::RuntimeData, src/Solver.hpp:54-61."""
+
+    def __init__(self):
+        self.global_ms = 0.0
+        self.local_ms = 0.0
+        self.collision_ms = 0.0
+        self.inner_iters = 0
+        self.step_ms = 0.0
+        self.last_solve_converged = 0
+
+
+class Floor:
+    """src/PassiveObject.hpp:32-45."""
+
+    def __init__(self, y):
+        self.kind, self.params = 0, [float(y), 0.0, 0.0, 0.0]
+
+
+class Sphere:
+    """src/PassiveObject.hpp:48-64."""
+
+    def __init__(self, center, radius):
+        self.kind, self.params = 1, [float(center[0]), float(center[1]), float(center[2]), float(radius)]
+
+
+class Solver:
+    """admm::Solver (src/Solver.hpp:32-124) on the MI355X hot path."""
+
+    def __init__(self):
+        self.m_x = np.zeros(0)
+        self.m_v = np.zeros(0)
+        self.m_masses = np.zeros(0)
+        self._tets = []   # (idx[n,4], Binv[n,9], weight[n], kind[n], mu[n], la[n], k[n])
+        self._tris = []   # (idx[n,3], rest[n,4], weight[n], lmin[n], lmax[n])
+        self._pins = {}   # vertex -> xyz   (ConstraintSet::pins)
+        self._obstacles = []
+        self._ctx = None
+        self._settings = Settings()
+        self._runtime = RuntimeData()
+        self.initialized = False
+        self._gs_colors = None
+        self._rank, self._world = 0, 1
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            lib().admm_hip_destroy(self._ctx)
+            self._ctx = None
+
+    # ---- scene construction -------------------------------------------------------------------
+    def add_nodes(self, x, m):
+        """Solver::add_nodes (src/Solver.hpp:127-141): x, m are [n,3] / [3n] (masses x3). Returns node count."""
+        x = f64(x).ravel(); m = f64(m).ravel()
+        if x.size != m.size or x.size % 3:
+            raise ValueError("add_nodes: x and m must both hold 3 values per node")
+        self.m_x = np.concatenate([self.m_x, x])
+        self.m_v = np.concatenate([self.m_v, np.zeros_like(x)])
+        self.m_masses = np.concatenate([self.m_masses, m])
+        return self.m_x.size // 3
+
+    def add_tets(self, verts, inds, lame, kind=TET_LINEAR, vertex_offset=0):
+        """create_tets_from_mesh<IN_SCALAR,TYPE> (src/TetEnergyTerm.hpp:35-51) + the TetEnergyTerm ctor
+        (src/TetEnergyTerm.cpp:31-48).  verts are the REST positions the indices refer to; kind selects
+        TetEnergyTerm / NeoHookeanTet / StVKTet / SplineTet.  Raises on an inverted rest tet."""
+        inds = i32(inds, (-1, 4))
+        Binv, vol = capi.tet_rest(verts, inds)
+        k = lame.bulk_modulus()
+        n = inds.shape[0]
+        w = np.sqrt(k * vol)
+        self._tets.append((inds + vertex_offset, Binv, w, np.full(n, kind, np.int32), np.full(n, lame.mu),
+                           np.full(n, lame.lambda_), np.full(n, k)))
+        return n
+
+    def add_tris(self, verts, inds, lame, vertex_offset=0):
+        """create_tris_from_mesh (src/TriEnergyTerm.hpp:31-46) + TriEnergyTerm ctor (src/TriEnergyTerm.cpp:29-52)."""
+        if lame.limit_min > 1.0:
+            raise AdmmHipError(-1, "**TriEnergyTerm Error: Strain limit min should be -inf to 1")
+        if lame.limit_max < 1.0:
+            raise AdmmHipError(-1, "**TriEnergyTerm Error: Strain limit max should be 1 to inf")
+        inds = i32(inds, (-1, 3))
+        rest, area = capi.tri_rest(verts, inds)
+        n = inds.shape[0]
+        w = np.sqrt(lame.bulk_modulus() * area)
+        self._tris.append((inds + vertex_offset, rest, w, np.full(n, lame.limit_min), np.full(n, lame.limit_max)))
+        return n
+
+    def set_pins(self, inds, points=None):
+        """Solver::set_pins (src/Solver.cpp:113-157)."""
+        inds = [int(i) for i in inds]
+        n = len(inds)
+        pin_in_place = points is None or len(points) != n
+        if (self.m_x.size == 0 and pin_in_place) or (pin_in_place and points is not None and len(points) > 0):
+            raise AdmmHipError(-1, "**Solver::set_pins Error: Bad input.")
+        self._pins = {}
+        for i, idx in enumerate(inds):
+            self._pins[idx] = self.m_x[3 * idx:3 * idx + 3].copy() if pin_in_place else f64(points[i]).copy()
+        if self.initialized:
+            v = i32(list(self._pins.keys()))
+            p = f64(np.array(list(self._pins.values())).reshape(-1, 3)) if n else np.zeros((0, 3))
+            check(lib().admm_hip_set_pins(self._ctx, len(v), iptr(v), dptr(p)))
+
+    def add_obstacle(self, obj):
+        """Solver::add_obstacle (src/Solver.cpp:159-161)."""
+        self._obstacles.append(obj)
+
+    def set_gs_colors(self, colors):
+        self._gs_colors = i32(colors)
+
+    # ---- Solver::initialize (src/Solver.cpp:167-261) ----------------------------------------------
+    def flatten(self):
+        """Flat arrays of every energy term, in the order tets, tris (pins are appended by the library)."""
+        def cat(lst, k, shape, dt):
+            return np.concatenate([t[k] for t in lst]).astype(dt) if lst else np.zeros(shape, dt)
+        T, R = self._tets, self._tris
+        out = dict(
+            tet_idx=cat(T, 0, (0, 4), np.int32), tet_Binv=cat(T, 1, (0, 9), np.float64), tet_weight=cat(T, 2, (0,), np.float64),
+            tet_kind=cat(T, 3, (0,), np.int32), tet_mu=cat(T, 4, (0,), np.float64), tet_lambda=cat(T, 5, (0,), np.float64),
+            tet_k=cat(T, 6, (0,), np.float64),
+            tri_idx=cat(R, 0, (0, 3), np.int32), tri_rest=cat(R, 1, (0, 4), np.float64), tri_weight=cat(R, 2, (0,), np.float64),
+            tri_limit_min=cat(R, 3, (0,), np.float64), tri_limit_max=cat(R, 4, (0,), np.float64),
+            pin_vert=i32(list(self._pins.keys())),
+            pin_xyz=f64(np.array(list(self._pins.values())).reshape(-1, 3)) if self._pins else np.zeros((0, 3)),
+        )
+        return out
+
+    def make_desc(self, s):
+        dof = self.m_x.size
+        f = self.flatten()
+        self._flat = f  # keep the arrays alive while the descriptor points at them
+        d = Desc()
+        d.struct_size = C.sizeof(Desc)
+        d.device = s.device
+        d.n_verts = dof // 3
+        self._masses_c = f64(self.m_masses)
+        d.masses = dptr(self._masses_c)
+        d.dt = s.timestep_s
+        d.n_tets = f["tet_idx"].shape[0]
+        d.tet_idx, d.tet_Binv, d.tet_weight = iptr(f["tet_idx"]), dptr(f["tet_Binv"]), dptr(f["tet_weight"])
+        d.tet_kind, d.tet_mu, d.tet_lambda, d.tet_k = iptr(f["tet_kind"]), dptr(f["tet_mu"]), dptr(f["tet_lambda"]), dptr(f["tet_k"])
+        d.n_tris = f["tri_idx"].shape[0]
+        d.tri_idx, d.tri_rest, d.tri_weight = iptr(f["tri_idx"]), dptr(f["tri_rest"]), dptr(f["tri_weight"])
+        d.tri_limit_min, d.tri_limit_max = dptr(f["tri_limit_min"]), dptr(f["tri_limit_max"])
+        d.n_pins = f["pin_vert"].shape[0]
+        d.pin_vert, d.pin_xyz, d.pin_active, d.pin_weight = iptr(f["pin_vert"]), dptr(f["pin_xyz"]), None, 0.0
+        d.linsolver, d.constraint_w = s.linsolver, s.constraint_w
+        d.pcg_max_iters, d.pcg_tol = s.pcg_max_iters, s.pcg_tol
+        d.gs_max_iters, d.gs_tol, d.gs_omega = s.gs_max_iters, s.gs_tol, s.gs_omega
+        d.uzawa_max_iters, d.uzawa_tol = s.uzawa_max_iters, s.uzawa_tol
+        self._obst_kind = i32([o.kind for o in self._obstacles])
+        self._obst_par = f64([o.params for o in self._obstacles]).reshape(-1, 4) if self._obstacles else np.zeros((0, 4))
+        d.n_obstacles = len(self._obstacles)
+        d.obstacle_kind, d.obstacle_params = iptr(self._obst_kind), dptr(self._obst_par)
+        d.gs_colors = iptr(self._gs_colors) if self._gs_colors is not None else None
+        return d
+
+    def host_matrix(self, settings=None):
+        """Ahat for this scene from the host-only assembly path (no GPU): (rowptr, col, val)."""
+        d = self.make_desc(settings if settings is not None else self._settings)
+        nnz = C.c_int32(0)
+        check(lib().admm_host_assemble_matrix(C.byref(d), None, None, None, C.byref(nnz)))
+        nv = self.m_x.size // 3
+        rp = np.zeros(nv + 1, np.int32); ci = np.zeros(nnz.value, np.int32); va = np.zeros(nnz.value)
+        check(lib().admm_host_assemble_matrix(C.byref(d), iptr(rp), iptr(ci), dptr(va), C.byref(nnz)))
+        return rp, ci, va
+
+    def initialize(self, settings=None):
+        s = settings if settings is not None else Settings()
+        self._settings = s
+        dof = self.m_x.size
+        if s.timestep_s <= 0.0:
+            s.timestep_s = 1.0 / 24.0
+        if not (self.m_masses.size == dof and dof >= 3):
+            return False  # "Problem with node data!" (Solver.cpp:180-183)
+        self.m_v = np.zeros(dof)
+        self.close()
+        d = self.make_desc(s)
+        ctx = C.c_void_p()
+        check(lib().admm_hip_create(C.byref(d), C.byref(ctx)))
+        self._ctx = ctx
+        self.initialized = True
+        return True
+
+    # ---- Solver::step (src/Solver.cpp:35-110) ------------------------------------------------------
+    def step(self):
+        """One time step on the host-visible state m_x/m_v (uploaded, stepped on the GPU, downloaded)."""
+        self.upload()
+        self.step_device(stats=True)
+        self.download()
+
+    def upload(self):
+        self._need_ctx()
+        self.m_x = f64(self.m_x); self.m_v = f64(self.m_v)
+        check(lib().admm_hip_set_state(self._ctx, dptr(self.m_x), dptr(self.m_v)))
+
+    def download(self):
+        self._need_ctx()
+        check(lib().admm_hip_get_state(self._ctx, dptr(self.m_x), dptr(self.m_v)))
+
+    def step_device(self, stats=False, admm_iters=None):
+        """admm_hip_step on the device-resident state (no host<->device copies)."""
+        self._need_ctx()
+        s = self._settings
+        it = s.admm_iters if admm_iters is None else admm_iters
+        if stats:
+            st = Stats()
+            check(lib().admm_hip_step(self._ctx, it, s.gravity, C.byref(st)))
+            r = self._runtime = RuntimeData()
+            r.global_ms, r.local_ms, r.collision_ms = st.global_ms, st.local_ms, st.collision_ms
+            r.inner_iters, r.step_ms, r.last_solve_converged = st.inner_iters, st.step_ms, st.last_solve_converged
+        else:
+            check(lib().admm_hip_step(self._ctx, it, s.gravity, None))
+
+    def runtime_data(self):
+        return self._runtime
+
+    def settings(self):
+        return self._settings
+
+    # ---- kernel-level entry points (parity tests) -------------------------------------------------
+    def num_rows(self):
+        self._need_ctx()
+        return lib().admm_hip_num_rows(self._ctx)
+
+    def local_step(self, x, u, Mxbar=None):
+        """EnergyTerm::update over all terms. Returns (z, u_new[, b])."""
+        self._need_ctx()
+        R = self.num_rows()
+        x = f64(x).ravel().copy(); u = f64(u).ravel().copy()
+        assert u.size == R
+        z = np.zeros(R)
+        b = np.zeros(x.size) if Mxbar is not None else None
+        mx = f64(Mxbar).ravel().copy() if Mxbar is not None else None
+        check(lib().admm_hip_local_step(self._ctx, dptr(x), dptr(u), dptr(z), dptr(mx), dptr(b)))
+        return (z, u, b) if Mxbar is not None else (z, u)
+
+    def global_solve(self, b, x0):
+        """LinearSolver::solve: returns (x, inner_iters)."""
+        self._need_ctx()
+        b = f64(b).ravel().copy(); x = f64(x0).ravel().copy()
+        it = C.c_int32(0)
+        check(lib().admm_hip_global_solve(self._ctx, dptr(b), dptr(x), C.byref(it)))
+        return x, it.value
+
+    def system_matrix(self):
+        """Ahat as (rowptr, col, val): A = diag(m) + Ahat (x) I3."""
+        self._need_ctx()
+        nnz = C.c_int32(0)
+        check(lib().admm_hip_get_matrix(self._ctx, None, None, None, C.byref(nnz)))
+        nv = self.m_x.size // 3
+        rp = np.zeros(nv + 1, np.int32); ci = np.zeros(nnz.value, np.int32); va = np.zeros(nnz.value)
+        check(lib().admm_hip_get_matrix(self._ctx, iptr(rp), iptr(ci), dptr(va), C.byref(nnz)))
+        return rp, ci, va
+
+    def gs_colors(self):
+        self._need_ctx()
+        nv = self.m_x.size // 3
+        col = np.zeros(nv, np.int32); nc = C.c_int32(0)
+        check(lib().admm_hip_get_colors(self._ctx, iptr(col), C.byref(nc)))
+        return col, nc.value
+
+    def _need_ctx(self):
+        if not self._ctx:
+            raise AdmmHipError(-4, "Solver is not initialized")

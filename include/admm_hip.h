@@ -1,0 +1,192 @@
+/*
+ * admm_hip.h -- C ABI of the MI355X-native ADMM elastic hot path (libadmm_hip.so).
+ *
+ * The reference (mattoverby/admm-elastic) has no FFI of its own: its extension points are the C++
+ * classes admm::Solver / EnergyTerm / LinearSolver.  This header is the boundary those classes'
+ * MI355X-native re-implementation (admm-elastic_amd/host/) sits on, and the only thing the Python
+ * harness binds (ctypes).  Plain pointers and sizes, no C++/torch types.  Each entry point cites the
+ * reference interface it replaces (file:line relative to the reference repo root).
+ *
+ * Conventions
+ *   - all floating point data is FP64, all indices int32
+ *   - node vectors (x, v, b, masses) are [3*n_verts], interleaved xyz, exactly like Solver::m_x
+ *     (src/Solver.hpp:66-68)
+ *   - 3x3 / 2x2 matrices are column-major (Eigen default)
+ *   - energy-term order inside a context is: tets (given order), then tris, then pins; the ADMM
+ *     vectors z,u use the reference's row layout (9 rows per tet, 6 per tri, 6 per pin:
+ *     src/TetEnergyTerm.hpp:68, src/TriEnergyTerm.hpp:66, src/SpringEnergyTerm.hpp:42)
+ *   - every function returns 0 on success or a negative admm_hip_status; the message of the last
+ *     failure on the calling thread is available from admm_hip_last_error()
+ *   - a context is bound to one HIP device, owns all of its device memory, is not thread-safe
+ *   - functions named admm_host_* do not touch the GPU (set-up arithmetic shared by every caller)
+ */
+#ifndef ADMM_HIP_H
+#define ADMM_HIP_H 1
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ADMM_HIP_OK = 0,
+    ADMM_HIP_ERR_ARG = -1,      /* bad argument / inconsistent description  (reference: std::runtime_error) */
+    ADMM_HIP_ERR_DEVICE = -2,   /* no usable HIP device, or a HIP runtime call failed */
+    ADMM_HIP_ERR_GEOMETRY = -3, /* inverted rest element (src/TetEnergyTerm.cpp:42-44, TriEnergyTerm.cpp:45-47) */
+    ADMM_HIP_ERR_STATE = -4,    /* call out of order (e.g. step before set_state) */
+    ADMM_HIP_ERR_COMM = -5      /* RCCL failure */
+} admm_hip_status;
+
+/* tet constitutive models -- src/TetEnergyTerm.hpp:57 (linear), :116 (NeoHookean), :142 (StVK),
+ * :176 (SplineTet with its default xu::NeoHookean spline, which is algebraically the NH model) */
+enum { ADMM_TET_LINEAR = 0, ADMM_TET_NEOHOOKEAN = 1, ADMM_TET_STVK = 2, ADMM_TET_SPLINE_NH = 3 };
+
+/* global solvers -- Solver::Settings::linsolver, src/Solver.hpp:46 ("0=LDLT, 1=NCMCGS, 2=UzawaCG").
+ * 0: the prefactored LDLT (src/LinearSolver.hpp:59-92) is replaced by a Jacobi-preconditioned CG on
+ *    the GPU iterated to pcg_tol; 1: nodal multi-colour SOR (src/NodalMultiColorGS.hpp); 2: Schur-
+ *    complement CG (src/UzawaCG.hpp) whose inner LDLT solves are the same GPU PCG. */
+enum { ADMM_LS_LDLT_AS_PCG = 0, ADMM_LS_NCMCGS = 1, ADMM_LS_UZAWACG = 2 };
+
+/* passive obstacles -- src/PassiveObject.hpp:32-45 (Floor: params[0]=y), :48-64 (Sphere: cx,cy,cz,r) */
+enum { ADMM_OBJ_FLOOR = 0, ADMM_OBJ_SPHERE = 1 };
+
+typedef struct admm_hip_ctx admm_hip_ctx;
+
+/* Everything Solver::initialize (src/Solver.cpp:167-261) consumes, flattened to arrays. */
+typedef struct {
+    int32_t struct_size;          /* = sizeof(admm_hip_desc), for forward compatibility */
+    int32_t device;               /* HIP device ordinal */
+
+    int32_t n_verts;
+    const double *masses;         /* [3*n_verts]  Solver::m_masses (src/Solver.hpp:68) */
+    double dt;                    /* Settings::timestep_s (src/Solver.hpp:42); <=0 -> 1/24 like Solver.cpp:175-179 */
+
+    /* TetEnergyTerm family (src/TetEnergyTerm.cpp:31-71) */
+    int32_t n_tets;
+    const int32_t *tet_idx;       /* [4*n_tets] */
+    const double *tet_Binv;       /* [9*n_tets] edges_inv, column-major */
+    const double *tet_weight;     /* [n_tets]   w = sqrt(k*vol) */
+    const int32_t *tet_kind;      /* [n_tets]   ADMM_TET_* */
+    const double *tet_mu;         /* [n_tets]   Lame::mu */
+    const double *tet_lambda;     /* [n_tets]   Lame::lambda */
+    const double *tet_k;          /* [n_tets]   Lame::bulk_modulus() */
+
+    /* TriEnergyTerm (src/TriEnergyTerm.cpp:29-101) */
+    int32_t n_tris;
+    const int32_t *tri_idx;       /* [3*n_tris] */
+    const double *tri_rest;       /* [4*n_tris] rest_pose (2x2, column-major) */
+    const double *tri_weight;     /* [n_tris] */
+    const double *tri_limit_min;  /* [n_tris] Lame::limit_min */
+    const double *tri_limit_max;  /* [n_tris] Lame::limit_max */
+
+    /* Pins.  linsolver 0/2: every pin becomes a SpringPin energy term (src/Solver.cpp:190-196,
+     * src/SpringEnergyTerm.hpp:31-73) with weight pin_weight (<=0 -> sqrt(2*k_rubber)).
+     * linsolver 1: pins are applied inside the GS sweeps (src/NodalMultiColorGS.hpp:111-117). */
+    int32_t n_pins;
+    const int32_t *pin_vert;      /* [n_pins] */
+    const double *pin_xyz;        /* [3*n_pins] */
+    const int32_t *pin_active;    /* [n_pins] or NULL (= all active) */
+    double pin_weight;
+
+    int32_t linsolver;            /* ADMM_LS_* */
+    double constraint_w;          /* Settings::constraint_w; <=0 -> auto (src/Solver.cpp:235,239,245) */
+
+    int32_t pcg_max_iters;        /* <=0 -> 500 */
+    double pcg_tol;               /* relative residual of the (Jacobi-scaled) system; <=0 -> 1e-10 */
+    int32_t gs_max_iters;         /* <=0 -> 30   (NodalMultiColorGS::max_iters, NodalMultiColorGS.hpp:45-46) */
+    double gs_tol;                /* <0 -> 1e-10 (m_tol); 0 disables the residual test like the reference */
+    double gs_omega;              /* <=0 -> 1.9  (m_omega) */
+    int32_t uzawa_max_iters;      /* <=0 -> 20   (UzawaCG::max_iters, UzawaCG.hpp:44-45) */
+    double uzawa_tol;             /* <=0 -> 1e-10 */
+
+    int32_t n_obstacles;          /* Solver::add_obstacle (src/Solver.cpp:159-161); needs linsolver 1 or 2 */
+    const int32_t *obstacle_kind; /* [n_obstacles] ADMM_OBJ_* */
+    const double *obstacle_params;/* [4*n_obstacles] */
+
+    const int32_t *gs_colors;     /* optional [n_verts] colour per node; NULL -> greedy (admm_host_greedy_coloring) */
+} admm_hip_desc;
+
+/* Maps 1:1 onto Solver::RuntimeData (src/Solver.hpp:54-61) plus GPU-side extras. */
+typedef struct {
+    double global_ms;
+    double local_ms;
+    double collision_ms;
+    int32_t inner_iters;
+    int32_t admm_iters;
+    double step_ms;               /* whole step, HIP events */
+    int32_t last_solve_converged; /* PCG: residual test met within pcg_max_iters in the last ADMM iteration */
+    int32_t n_constraints;        /* rows of C in the last ADMM iteration (UzawaCG) */
+} admm_hip_stats;
+
+const char *admm_hip_last_error(void);
+
+/* Number of visible HIP devices (0 when there is no GPU / no driver). Never fails. */
+int admm_hip_device_count(void);
+
+/* Solver::initialize (src/Solver.cpp:167-261): validates, uploads, assembles D / W / A on the host,
+ * builds the SpMV / gather structures, colours the graph (linsolver 1). */
+int admm_hip_create(const admm_hip_desc *desc, admm_hip_ctx **out);
+void admm_hip_destroy(admm_hip_ctx *ctx);
+
+/* Solver::m_x / m_v access (src/Solver.hpp:66-67).  Host <-> device copies. */
+int admm_hip_set_state(admm_hip_ctx *ctx, const double *x, const double *v);
+int admm_hip_get_state(admm_hip_ctx *ctx, double *x, double *v);
+
+/* Solver::set_pins after initialize (src/Solver.cpp:113-157): move / activate / deactivate pins.
+ * linsolver 0/2: idx must be among the pins given at create (else ADMM_HIP_ERR_ARG, like the throw
+ * at Solver.cpp:147-151); all other pins become inactive.  linsolver 1: the set is replaced freely. */
+int admm_hip_set_pins(admm_hip_ctx *ctx, int32_t n, const int32_t *vert, const double *xyz);
+
+/* Solver::step (src/Solver.cpp:35-110) on the device-resident state: gravity, x_bar, admm_iters x
+ * {local step, collision detection, RHS, global solve}, velocity update.  No host<->device traffic
+ * besides the launch stream; stats may be NULL. */
+int admm_hip_step(admm_hip_ctx *ctx, int32_t admm_iters, double gravity, admm_hip_stats *stats);
+
+/* Kernel-level entry points (parity tests).
+ * local step = the OpenMP loop at src/Solver.cpp:84-87 over EnergyTerm::update
+ * (src/EnergyTerm.hpp:130-140): given x and u (in/out) produce z, u in the reference row layout.
+ * If Mxbar and b_out are non-NULL also returns b = Mxbar + dt^2 D^T W^2 (z-u) (src/Solver.cpp:98). */
+int admm_hip_local_step(admm_hip_ctx *ctx, const double *x, double *u_inout, double *z_out,
+                        const double *Mxbar, double *b_out);
+/* LinearSolver::solve (src/LinearSolver.hpp:46): x is in/out (warm start), returns inner iterations
+ * through *iters.  Uses the context's linsolver, pins and obstacles. */
+int admm_hip_global_solve(admm_hip_ctx *ctx, const double *b, double *x_inout, int32_t *iters);
+
+/* Sizes: R = rows of D (9*n_tets + 6*n_tris + 6*n_pin_terms). */
+int admm_hip_num_rows(const admm_hip_ctx *ctx);
+
+/* The assembled scalar system matrix Ahat (A = M + Ahat (x) I3, src/Solver.cpp:225-226 with the
+ * x/y/z replication of src/TetEnergyTerm.cpp:66-68 factored out), CSR with sorted columns.
+ * Pass NULL pointers to query nnz only. */
+int admm_hip_get_matrix(const admm_hip_ctx *ctx, int32_t *rowptr, int32_t *col, double *val, int32_t *nnz);
+/* colour per node used by linsolver 1 */
+int admm_hip_get_colors(const admm_hip_ctx *ctx, int32_t *color, int32_t *n_colors);
+
+/* ---- multi-GPU (one context per rank; new work, no reference counterpart -- SURVEY.md 8e) ----
+ * Element-block partition: rank r owns the contiguous block of tets/tris admm_host_partition gives
+ * it; every rank holds all vertices and replicates the global solve; the only exchange is one RCCL
+ * sum all-reduce of the [3*n_verts] partial right-hand side per ADMM iteration. */
+int admm_hip_comm_unique_id(char *id128);                                   /* ncclGetUniqueId */
+int admm_hip_comm_init(admm_hip_ctx *ctx, const char *id128, int rank, int world_size);
+void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end);
+
+/* ---- host-side set-up arithmetic (no GPU) ---- */
+/* The matrix admm_hip_create would assemble for this description (same code path), without a GPU:
+ * Ahat in CSR (see admm_hip_get_matrix).  Pass NULL arrays to query nnz. */
+int admm_host_assemble_matrix(const admm_hip_desc *desc, int32_t *rowptr, int32_t *col, double *val, int32_t *nnz);
+/* TetEnergyTerm ctor (src/TetEnergyTerm.cpp:31-48): Binv [9*n], vol [n]; ADMM_HIP_ERR_GEOMETRY if a
+ * rest volume is negative.  verts [3*nv], idx [4*n]. */
+int admm_host_tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
+/* TriEnergyTerm ctor (src/TriEnergyTerm.cpp:29-52): rest [4*n], area [n]. */
+int admm_host_tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
+/* Lame (src/EnergyTerm.hpp:34-59) */
+void admm_host_lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);
+/* Greedy nodal colouring in index order on a CSR pattern (stands in for the absent
+ * mcl::graphcolor::color_matrix, src/NodalMultiColorGS.hpp:57); returns the number of colours. */
+int admm_host_greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADMM_HIP_H */

@@ -1,0 +1,627 @@
+/*
+ * admm_oracle.c -- CPU restatement of the ADMM hot path of mattoverby/admm-elastic.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped product (admm-elastic_amd/, include/)
+ * may link, import or execute this file.  It is used by tests/, __graft_entry__.smoke()
+ * and the cpu_baseline leg of bench.py as the checker / reported CPU baseline.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) whose
+ * arithmetic it restates.  Nothing here is copied from the reference; the SVD is a
+ * one-sided (Hestenes) Jacobi instead of Eigen's two-sided Jacobi (any convergent SVD is
+ * equivalent: prox outputs depend on U,V only through U f(S) V^T).
+ *
+ * PINNING STATUS (see oracle/README.md):
+ *   - linear tet + exact solve + step loop : pinned by the reference's own known answers
+ *     (samples/tests/test_lineartet.cpp), restated in tests/test_known_answers.py
+ *   - signed SVD, triangle term, pin term, EnergyTerm::update, ConstraintSet::make_matrix:
+ *     pinned against the real reference sources compiled into oracle/_ref (oracle/ref_driver.cpp)
+ *   - Neo-Hookean / StVK / spline prox: objective, gradient and stop rule are the reference's
+ *     (src/TetEnergyTerm.cpp:173-265); the minimiser (mcl::optlib::LBFGS, mattoverby/mcloptlib,
+ *     un-vendored submodule, no pinned SHA recoverable) is ABSENT => "parity unpinned" at the
+ *     iterate level.  Restated here from the published L-BFGS algorithm (Nocedal 1980 two-loop
+ *     recursion + backtracking Armijo line search).
+ *   - NodalMultiColorGS: sweeps restated; the colouring library (mclscene) is ABSENT =>
+ *     "parity unpinned" for the colour order; colours are an input here.
+ *
+ * Layout conventions: 3x3 matrices are column-major (Eigen default), index c*3+r.
+ */
+#include <math.h>
+#include <float.h>
+#include <string.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+#define M3(A, r, c) ((A)[(c) * 3 + (r)])
+
+static double det3(const double *A) {
+    return M3(A,0,0) * (M3(A,1,1) * M3(A,2,2) - M3(A,1,2) * M3(A,2,1))
+         - M3(A,0,1) * (M3(A,1,0) * M3(A,2,2) - M3(A,1,2) * M3(A,2,0))
+         + M3(A,0,2) * (M3(A,1,0) * M3(A,2,1) - M3(A,1,1) * M3(A,2,0));
+}
+
+static void cross3(const double *a, const double *b, double *c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+static double norm3(const double *a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
+/* any unit vector orthogonal to unit vector a */
+static void any_orthogonal(const double *a, double *o) {
+    double e[3] = {0, 0, 0};
+    int k = 0;
+    if (fabs(a[1]) < fabs(a[k])) k = 1;
+    if (fabs(a[2]) < fabs(a[k])) k = 2;
+    e[k] = 1.0;
+    cross3(a, e, o);
+    double n = norm3(o);
+    o[0] /= n; o[1] /= n; o[2] /= n;
+}
+
+/*
+ * One-sided Jacobi SVD of a 3 x n column-major matrix (n = 2 or 3).
+ * Out: U 3x3 (full, orthonormal), S[n] sorted descending >= 0, V n x n (col-major, ld n).
+ * Stands in for Eigen::JacobiSVD<..>(F, ComputeFullU|ComputeFullV) as used at
+ * src/FastSVD.hpp:47, src/TetEnergyTerm.cpp:76, src/TriEnergyTerm.cpp:78.
+ */
+void orc_svd3xn(int n, const double *A, double *U, double *S, double *V) {
+    double G[9], Vw[9];
+    memcpy(G, A, sizeof(double) * 3 * n);
+    for (int i = 0; i < n * n; ++i) Vw[i] = 0.0;
+    for (int i = 0; i < n; ++i) Vw[i * n + i] = 1.0;
+
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < n - 1; ++p) {
+            for (int q = p + 1; q < n; ++q) {
+                double *gp = G + 3 * p, *gq = G + 3 * q;
+                double al = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
+                double be = gq[0] * gq[0] + gq[1] * gq[1] + gq[2] * gq[2];
+                double ga = gp[0] * gq[0] + gp[1] * gq[1] + gp[2] * gq[2];
+                if (fabs(ga) <= 1e-17 * sqrt(al * be) || ga == 0.0) continue;
+                rotated = 1;
+                double zeta = (be - al) / (2.0 * ga);
+                double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int r = 0; r < 3; ++r) {
+                    double a = gp[r], b = gq[r];
+                    gp[r] = c * a - s * b;
+                    gq[r] = s * a + c * b;
+                }
+                for (int r = 0; r < n; ++r) {
+                    double a = Vw[p * n + r], b = Vw[q * n + r];
+                    Vw[p * n + r] = c * a - s * b;
+                    Vw[q * n + r] = s * a + c * b;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    /* singular values = column norms; sort descending (Eigen sorts too, JacobiSVD.h step 4) */
+    double sig[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < n; ++j) sig[j] = norm3(G + 3 * j);
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j)
+            if (sig[ord[j]] > sig[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    double smax = sig[ord[0]];
+    int rank = 0, open_rank = 1;
+    for (int j = 0; j < n; ++j) {
+        int o = ord[j];
+        S[j] = sig[o];
+        for (int r = 0; r < n; ++r) V[j * n + r] = Vw[o * n + r];
+        if (open_rank && sig[o] > 1e-300 && sig[o] > 1e-15 * smax) {
+            for (int r = 0; r < 3; ++r) U[3 * j + r] = G[3 * o + r] / sig[o];
+            rank = j + 1;
+        } else {
+            open_rank = 0; /* remaining U columns are completed below */
+        }
+    }
+    /* complete U to a full orthonormal basis */
+    if (rank == 0) { memset(U, 0, sizeof(double) * 9); U[0] = U[4] = U[8] = 1.0; }
+    else if (rank == 1) { any_orthogonal(U, U + 3); cross3(U, U + 3, U + 6); }
+    else if (rank == 2) { cross3(U, U + 3, U + 6); }
+}
+
+/* src/FastSVD.hpp:43-68 -- SVD with U,V in SO(3); S[2] carries the sign of det F. */
+void orc_signed_svd3(const double *F, double *S, double *U, double *V) {
+    orc_svd3xn(3, F, U, S, V);
+    if (det3(U) < 0.0) { /* FastSVD.hpp:55-58 */
+        for (int r = 0; r < 3; ++r) M3(U, r, 2) = -M3(U, r, 2);
+        S[2] = -S[2];
+    }
+    if (det3(V) < 0.0) { /* FastSVD.hpp:61-66 */
+        for (int r = 0; r < 3; ++r) M3(V, r, 2) = -M3(V, r, 2);
+        S[2] = -S[2];
+    }
+}
+
+static void usvt(const double *U, const double *S, const double *V, double *out) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double a = 0.0;
+            for (int k = 0; k < 3; ++k) a += M3(U, r, k) * S[k] * M3(V, c, k);
+            M3(out, r, c) = a;
+        }
+}
+
+/* src/TetEnergyTerm.cpp:73-92 -- linear ("ARAP-like") tet prox: z <- (P + z)/2 */
+void orc_prox_tet_linear(double *z) {
+    double U[9], S[3], V[9], P[9];
+    orc_svd3xn(3, z, U, S, V);
+    double one[3] = {1.0, 1.0, 1.0};
+    if (det3(z) < 0.0) one[2] = -1.0; /* :80 */
+    usvt(U, one, V, P);               /* :82 */
+    for (int i = 0; i < 9; ++i) z[i] = 0.5 * (P[i] + z[i]); /* :86 */
+}
+
+/* src/TetEnergyTerm.cpp:94-100 -- linear tet energy = k/2 vol |sigma - 1|^2 */
+double orc_energy_tet_linear(const double *F, double k, double vol) {
+    double U[9], S[3], V[9];
+    orc_svd3xn(3, F, U, S, V);
+    double e = 0.0;
+    for (int i = 0; i < 3; ++i) e += (S[i] - 1.0) * (S[i] - 1.0);
+    return 0.5 * k * vol * e;
+}
+
+/* ---- principal-stretch objectives: kind 1 = NeoHookean, 2 = StVK, 3 = Spline(NH default) ---- */
+typedef struct { int kind; double mu, lambda, k; double x0[3]; } prox_problem;
+
+#define ORC_FLT_MAX 3.40282346638528859812e+38 /* std::numeric_limits<float>::max() */
+
+/* Xu spline NeoHookean (src/XuSpline.hpp:48-62), kappa = 0 as constructed at TetEnergyTerm.hpp:194 */
+static double xu_nh_f(double mu, double x) { return 0.5 * mu * (x * x - 1.0); }
+static double xu_nh_h(double mu, double la, double x) { double l = log(x); return -mu * l + 0.5 * la * l * l; }
+static double xu_nh_df(double mu, double x) { return mu * x; }
+static double xu_nh_dh(double mu, double la, double x) { return -mu / x + la * log(x) / x; }
+
+static double energy_density(const prox_problem *p, const double *x) {
+    if (p->kind == 1) { /* TetEnergyTerm.cpp:173-182 */
+        double J = x[0] * x[1] * x[2];
+        double I1 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+        double logI3 = log(J * J);
+        return 0.5 * p->mu * (I1 - logI3 - 3.0) + 0.125 * p->lambda * logI3 * logI3;
+    } else if (p->kind == 2) { /* TetEnergyTerm.cpp:220-226 */
+        double st[3], tr = 0.0, dd = 0.0;
+        for (int i = 0; i < 3; ++i) { st[i] = 0.5 * (x[i] * x[i] - 1.0); tr += st[i]; dd += st[i] * st[i]; }
+        return p->mu * dd + p->lambda * 0.5 * tr * tr;
+    } else { /* TetEnergyTerm.cpp:243-247 with xu::NeoHookean (g == 0) */
+        return xu_nh_f(p->mu, x[0]) + xu_nh_f(p->mu, x[1]) + xu_nh_f(p->mu, x[2])
+             + xu_nh_h(p->mu, p->lambda, x[0] * x[1] * x[2]);
+    }
+}
+
+/* ::value  -- TetEnergyTerm.cpp:184-192, :210-218, :249-257 */
+static double prox_value(const prox_problem *p, const double *x) {
+    if (x[0] < 0.0 || x[1] < 0.0 || x[2] < 0.0) return ORC_FLT_MAX;
+    double q = 0.0;
+    for (int i = 0; i < 3; ++i) q += (x[i] - p->x0[i]) * (x[i] - p->x0[i]);
+    return energy_density(p, x) + 0.5 * p->k * q;
+}
+
+/* ::gradient -- TetEnergyTerm.cpp:195-204, :228-237, :259-265.  Returns value.  The reference throws
+ * for NH when J <= 0; callers here never evaluate the gradient at an infeasible point. */
+static double prox_gradient(const prox_problem *p, const double *x, double *g) {
+    if (p->kind == 1) {
+        double J = x[0] * x[1] * x[2], lJ = log(J);
+        for (int i = 0; i < 3; ++i) {
+            double xi = 1.0 / x[i];
+            g[i] = (p->mu * (x[i] - xi) + p->lambda * lJ * xi) + p->k * (x[i] - p->x0[i]);
+        }
+    } else if (p->kind == 2) {
+        double xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+        for (int i = 0; i < 3; ++i)
+            g[i] = p->mu * x[i] * (x[i] * x[i] - 1.0) + 0.5 * p->lambda * (xx - 3.0) * x[i]
+                 + p->k * (x[i] - p->x0[i]);
+    } else {
+        double hp = xu_nh_dh(p->mu, p->lambda, x[0] * x[1] * x[2]);
+        g[0] = xu_nh_df(p->mu, x[0]) + hp * x[1] * x[2] + p->k * (x[0] - p->x0[0]);
+        g[1] = xu_nh_df(p->mu, x[1]) + hp * x[2] * x[0] + p->k * (x[1] - p->x0[1]);
+        g[2] = xu_nh_df(p->mu, x[2]) + hp * x[0] * x[1] + p->k * (x[2] - p->x0[2]);
+    }
+    return prox_value(p, x);
+}
+
+/* Hessian of value() -- derived, used only for the "tight" Newton polish */
+static void prox_hessian(const prox_problem *p, const double *x, double *H) {
+    memset(H, 0, 9 * sizeof(double));
+    if (p->kind == 1 || p->kind == 3) {
+        double lJ = log(x[0] * x[1] * x[2]);
+        double xi[3] = {1.0 / x[0], 1.0 / x[1], 1.0 / x[2]};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M3(H, i, j) = p->lambda * xi[i] * xi[j];
+        for (int i = 0; i < 3; ++i)
+            M3(H, i, i) += p->mu * (1.0 + xi[i] * xi[i]) - p->lambda * lJ * xi[i] * xi[i] + p->k;
+    } else {
+        double xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M3(H, i, j) = p->lambda * x[i] * x[j];
+        for (int i = 0; i < 3; ++i)
+            M3(H, i, i) += p->mu * (3.0 * x[i] * x[i] - 1.0) + 0.5 * p->lambda * (xx - 3.0) + p->k;
+    }
+}
+
+static int feasible(const prox_problem *p, const double *x) {
+    (void)p;
+    return x[0] > 0.0 && x[1] > 0.0 && x[2] > 0.0;
+}
+
+/*
+ * L-BFGS minimiser standing in for mcl::optlib::LBFGS<double,3>::minimize (ABSENT dependency;
+ * call site src/TetEnergyTerm.cpp:133, interface src/TetEnergyTerm.hpp:90-97).
+ * Published algorithm: Nocedal (1980) two-loop recursion, history M, backtracking Armijo line
+ * search (c1 = 1e-4, halve), first step scaled by 1/|g|.  Stop rule = the reference's
+ * HyperElasticTet::Prox::converged (TetEnergyTerm.hpp:93-95): |g| < 1e-6 or |x0-x1| < 1e-6.
+ * Returns iterations used.
+ */
+#define LB_M 6
+static int lbfgs3(const prox_problem *p, double *x, int max_iters) {
+    double sh[LB_M][3], yh[LB_M][3], rho[LB_M];
+    int hist = 0, head = 0;
+    double g[3];
+    double f = prox_gradient(p, x, g);
+    int it = 0;
+    for (; it < max_iters; ++it) {
+        double d[3] = {-g[0], -g[1], -g[2]}, alpha[LB_M];
+        for (int h = 0; h < hist; ++h) {
+            int i = (head - 1 - h + LB_M) % LB_M;
+            alpha[i] = rho[i] * (sh[i][0] * d[0] + sh[i][1] * d[1] + sh[i][2] * d[2]);
+            for (int c = 0; c < 3; ++c) d[c] -= alpha[i] * yh[i][c];
+        }
+        if (hist > 0) {
+            int i = (head - 1 + LB_M) % LB_M;
+            double sy = sh[i][0] * yh[i][0] + sh[i][1] * yh[i][1] + sh[i][2] * yh[i][2];
+            double yy = yh[i][0] * yh[i][0] + yh[i][1] * yh[i][1] + yh[i][2] * yh[i][2];
+            double sc = sy / yy;
+            for (int c = 0; c < 3; ++c) d[c] *= sc;
+        }
+        for (int h = hist - 1; h >= 0; --h) {
+            int i = (head - 1 - h + LB_M) % LB_M;
+            double b = rho[i] * (yh[i][0] * d[0] + yh[i][1] * d[1] + yh[i][2] * d[2]);
+            for (int c = 0; c < 3; ++c) d[c] += (alpha[i] - b) * sh[i][c];
+        }
+        double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+        if (!(gd < 0.0)) { /* not a descent direction: reset to steepest descent */
+            for (int c = 0; c < 3; ++c) d[c] = -g[c];
+            gd = -(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+            hist = 0;
+        }
+        double gnorm = sqrt(g[0]*g[0] + g[1]*g[1] + g[2]*g[2]);
+        double t = (hist == 0 && gnorm > 1.0) ? 1.0 / gnorm : 1.0;
+        double xn[3], fn = 0.0;
+        int ok = 0;
+        for (int ls = 0; ls < 60; ++ls) {
+            for (int c = 0; c < 3; ++c) xn[c] = x[c] + t * d[c];
+            if (feasible(p, xn)) {
+                fn = prox_value(p, xn);
+                if (fn <= f + 1e-4 * t * gd) { ok = 1; break; }
+            }
+            t *= 0.5;
+        }
+        if (!ok) break;
+        double gn[3];
+        fn = prox_gradient(p, xn, gn);
+        double s[3], y[3], sy = 0.0, gg = 0.0, ss = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            s[c] = xn[c] - x[c]; y[c] = gn[c] - g[c];
+            sy += s[c] * y[c]; gg += gn[c] * gn[c]; ss += s[c] * s[c];
+        }
+        if (sy > 1e-300) {
+            for (int c = 0; c < 3; ++c) { sh[head][c] = s[c]; yh[head][c] = y[c]; }
+            rho[head] = 1.0 / sy;
+            head = (head + 1) % LB_M;
+            if (hist < LB_M) hist++;
+        }
+        for (int c = 0; c < 3; ++c) { x[c] = xn[c]; g[c] = gn[c]; }
+        f = fn;
+        if (sqrt(gg) < 1e-6 || sqrt(ss) < 1e-6) { ++it; break; } /* TetEnergyTerm.hpp:93-95 */
+    }
+    return it;
+}
+
+/* damped Newton polish to the exact minimiser ("tight" oracle mode) */
+static int newton3(const prox_problem *p, double *x, int max_iters) {
+    int it = 0;
+    for (; it < max_iters; ++it) {
+        double g[3], H[9];
+        double f = prox_gradient(p, x, g);
+        prox_hessian(p, x, H);
+        /* solve H d = -g by Cramer; shift the diagonal until H is positive definite */
+        double d[3] = {-g[0], -g[1], -g[2]};
+        double shift = 0.0, tr = fabs(M3(H,0,0)) + fabs(M3(H,1,1)) + fabs(M3(H,2,2));
+        for (int tries = 0; tries < 60; ++tries) {
+            double Hs[9];
+            memcpy(Hs, H, sizeof(Hs));
+            for (int c = 0; c < 3; ++c) M3(Hs, c, c) += shift;
+            double D = det3(Hs);
+            int pd = M3(Hs,0,0) > 0 && (M3(Hs,0,0)*M3(Hs,1,1) - M3(Hs,0,1)*M3(Hs,1,0)) > 0 && D > 0;
+            if (pd) {
+                double Hc[9];
+                for (int c = 0; c < 3; ++c) {
+                    memcpy(Hc, Hs, sizeof(Hc));
+                    for (int r = 0; r < 3; ++r) M3(Hc, r, c) = -g[r];
+                    d[c] = det3(Hc) / D;
+                }
+                break;
+            }
+            shift = (shift == 0.0) ? 1e-3 * tr + 1e-300 : 10.0 * shift;
+        }
+        double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+        double t = 1.0, xn[3];
+        int ok = 0;
+        for (int ls = 0; ls < 60; ++ls) {
+            for (int c = 0; c < 3; ++c) xn[c] = x[c] + t * d[c];
+            if (feasible(p, xn) && prox_value(p, xn) <= f + 1e-4 * t * gd + 1e-14 * fabs(f)) { ok = 1; break; }
+            t *= 0.5;
+        }
+        if (!ok) break;
+        double ss = 0.0;
+        for (int c = 0; c < 3; ++c) { ss += (xn[c] - x[c]) * (xn[c] - x[c]); x[c] = xn[c]; }
+        if (sqrt(ss) < 1e-14 * (1.0 + norm3(x))) { ++it; break; }
+    }
+    return it;
+}
+
+/*
+ * src/TetEnergyTerm.cpp:114-136 -- HyperElasticTet::prox.
+ * kind 1 NH, 2 StVK, 3 Spline(NH).  mode 0 = reference stop rule only (L-BFGS), mode 1 = "tight"
+ * (L-BFGS then Newton polish to the exact minimiser).  Returns minimiser iterations.
+ */
+int orc_prox_tet_hyper(int kind, double mu, double lambda, double k, double *z, int mode) {
+    double U[9], S[3], V[9];
+    orc_signed_svd3(z, S, U, V);
+    prox_problem p;
+    p.kind = kind; p.mu = mu; p.lambda = lambda; p.k = k;
+    p.x0[0] = S[0]; p.x0[1] = S[1]; p.x0[2] = S[2];           /* :124 set_x0 BEFORE the fix-ups */
+    const double eps = 1e-6;
+    if (fabs(S[0]) < eps && fabs(S[1]) < eps && fabs(S[2]) < eps) { S[0] = S[1] = S[2] = eps; } /* :128-131 */
+    if (S[2] < 0.0) S[2] = -S[2];                               /* :133 */
+    if (S[2] == 0.0) S[2] = 1e-12; /* reference would take log(0); keep the start strictly feasible */
+    int it = lbfgs3(&p, S, 200);                                /* :135 */
+    if (mode == 1) it += newton3(&p, S, 100);
+    usvt(U, S, V, z);                                           /* :136-137 */
+    return it;
+}
+
+double orc_prox_value(int kind, double mu, double lambda, double k, const double *x0, const double *x) {
+    prox_problem p; p.kind = kind; p.mu = mu; p.lambda = lambda; p.k = k;
+    memcpy(p.x0, x0, sizeof(p.x0));
+    return prox_value(&p, x);
+}
+void orc_prox_gradient(int kind, double mu, double lambda, double k, const double *x0, const double *x, double *g) {
+    prox_problem p; p.kind = kind; p.mu = mu; p.lambda = lambda; p.k = k;
+    memcpy(p.x0, x0, sizeof(p.x0));
+    prox_gradient(&p, x, g);
+}
+
+/* src/TriEnergyTerm.cpp:73-101 -- triangle prox on the 3x2 F (col-major, 6 doubles) + strain limit */
+void orc_prox_tri(double *z, double limit_min, double limit_max) {
+    double U[9], S[2], V[4], P[6];
+    orc_svd3xn(2, z, U, S, V);
+    /* P = U [I2;0] V^T  (:79-81) */
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 2; ++c)
+            P[c * 3 + r] = U[0 * 3 + r] * V[0 * 2 + c] + U[1 * 3 + r] * V[1 * 2 + c];
+    for (int i = 0; i < 6; ++i) z[i] = 0.5 * (P[i] + z[i]); /* :83 */
+    int check = limit_min > 0.0 || limit_max < 99.0;          /* :91 */
+    if (check) {
+        double l0 = norm3(z), l1 = norm3(z + 3);
+        if (l0 < limit_min) for (int i = 0; i < 3; ++i) z[i] *= (limit_min / l0);
+        if (l1 < limit_min) for (int i = 0; i < 3; ++i) z[3 + i] *= (limit_min / l1);
+        if (l0 > limit_max) for (int i = 0; i < 3; ++i) z[i] *= (limit_max / l0);
+        if (l1 > limit_max) for (int i = 0; i < 3; ++i) z[3 + i] *= (limit_max / l1);
+    }
+}
+
+/* ---- element set-up ------------------------------------------------------------------------ */
+
+/* src/TetEnergyTerm.cpp:31-48 -- Binv (col-major), volume; returns -1 on an inverted rest tet */
+int orc_tet_rest(const double *v0, const double *v1, const double *v2, const double *v3,
+                 double *Binv, double *vol) {
+    double B[9];
+    for (int r = 0; r < 3; ++r) { M3(B, r, 0) = v1[r] - v0[r]; M3(B, r, 1) = v2[r] - v0[r]; M3(B, r, 2) = v3[r] - v0[r]; }
+    double d = det3(B);
+    *vol = d / 6.0;
+    if (*vol < 0) return -1;
+    double id = 1.0 / d;
+    M3(Binv,0,0) =  (M3(B,1,1)*M3(B,2,2) - M3(B,1,2)*M3(B,2,1)) * id;
+    M3(Binv,0,1) = -(M3(B,0,1)*M3(B,2,2) - M3(B,0,2)*M3(B,2,1)) * id;
+    M3(Binv,0,2) =  (M3(B,0,1)*M3(B,1,2) - M3(B,0,2)*M3(B,1,1)) * id;
+    M3(Binv,1,0) = -(M3(B,1,0)*M3(B,2,2) - M3(B,1,2)*M3(B,2,0)) * id;
+    M3(Binv,1,1) =  (M3(B,0,0)*M3(B,2,2) - M3(B,0,2)*M3(B,2,0)) * id;
+    M3(Binv,1,2) = -(M3(B,0,0)*M3(B,1,2) - M3(B,0,2)*M3(B,1,0)) * id;
+    M3(Binv,2,0) =  (M3(B,1,0)*M3(B,2,1) - M3(B,1,1)*M3(B,2,0)) * id;
+    M3(Binv,2,1) = -(M3(B,0,0)*M3(B,2,1) - M3(B,0,1)*M3(B,2,0)) * id;
+    M3(Binv,2,2) =  (M3(B,0,0)*M3(B,1,1) - M3(B,0,1)*M3(B,1,0)) * id;
+    return 0;
+}
+
+/* src/TriEnergyTerm.cpp:29-52 -- rest_pose (2x2 col-major), area; -1 on negative area */
+int orc_tri_rest(const double *v0, const double *v1, const double *v2, double *rest, double *area) {
+    double e12[3], e13[3], n1[3], n2[3];
+    for (int r = 0; r < 3; ++r) { e12[r] = v1[r] - v0[r]; e13[r] = v2[r] - v0[r]; }
+    double l = norm3(e12);
+    for (int r = 0; r < 3; ++r) n1[r] = e12[r] / l;
+    double dp = e13[0] * n1[0] + e13[1] * n1[1] + e13[2] * n1[2];
+    for (int r = 0; r < 3; ++r) n2[r] = e13[r] - dp * n1[r];
+    l = norm3(n2);
+    for (int r = 0; r < 3; ++r) n2[r] /= l;
+    /* M = basis^T * edges (2x2): M(i,j) = n_i . e_j */
+    double m00 = n1[0]*e12[0] + n1[1]*e12[1] + n1[2]*e12[2];
+    double m01 = n1[0]*e13[0] + n1[1]*e13[1] + n1[2]*e13[2];
+    double m10 = n2[0]*e12[0] + n2[1]*e12[1] + n2[2]*e12[2];
+    double m11 = n2[0]*e13[0] + n2[1]*e13[1] + n2[2]*e13[2];
+    double d = m00 * m11 - m01 * m10;
+    *area = d / 2.0;
+    if (*area < 0) return -1;
+    rest[0] = m11 / d;  /* (0,0) */
+    rest[1] = -m10 / d; /* (1,0) */
+    rest[2] = -m01 / d; /* (0,1) */
+    rest[3] = m00 / d;  /* (1,1) */
+    return 0;
+}
+
+/* ---- local step (src/EnergyTerm.hpp:130-140 applied to every term, Solver.cpp:84-87) ------- */
+
+/* tets: F = [x1-x0,x2-x0,x3-x0] * Binv, equal to D_i x with the D-block of TetEnergyTerm.cpp:50-71.
+ * z,u: AoS [nt][9] in the reference's row order (row 3r+j <-> F(j,r)).  x: [nv][3]. */
+void orc_local_tets(int nt, const int32_t *idx, const double *Binv, const int32_t *kind,
+                    const double *mu, const double *lambda, const double *k,
+                    const double *x, double *z, double *u, int mode) {
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < nt; ++t) {
+        const int32_t *id = idx + 4 * t;
+        const double *Bi = Binv + 9 * t;
+        double Ds[9], Dix[9], zi[9];
+        for (int m = 0; m < 3; ++m)
+            for (int j = 0; j < 3; ++j) M3(Ds, j, m) = x[3 * id[m + 1] + j] - x[3 * id[0] + j];
+        for (int j = 0; j < 3; ++j)
+            for (int r = 0; r < 3; ++r) {
+                double a = 0.0;
+                for (int m = 0; m < 3; ++m) a += M3(Ds, j, m) * M3(Bi, m, r);
+                M3(Dix, j, r) = a;
+            }
+        double *ui = u + 9 * t;
+        for (int i = 0; i < 9; ++i) zi[i] = Dix[i] + ui[i];            /* EnergyTerm.hpp:135 */
+        if (kind[t] == 0) orc_prox_tet_linear(zi);
+        else orc_prox_tet_hyper(kind[t], mu[t], lambda[t], k[t], zi, mode);
+        for (int i = 0; i < 9; ++i) { ui[i] += Dix[i] - zi[i]; z[9 * t + i] = zi[i]; } /* :137-139 */
+    }
+}
+
+/* tris: rows i and 3+i <-> columns of the 3x2 F = [x1-x0,x2-x0] * rest (TriEnergyTerm.cpp:54-69) */
+void orc_local_tris(int n, const int32_t *idx, const double *rest, const double *lmin, const double *lmax,
+                    const double *x, double *z, double *u) {
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < n; ++t) {
+        const int32_t *id = idx + 3 * t;
+        const double *R = rest + 4 * t; /* col-major 2x2 */
+        double Dix[6], zi[6];
+        for (int c = 0; c < 2; ++c)
+            for (int j = 0; j < 3; ++j) {
+                double e1 = x[3 * id[1] + j] - x[3 * id[0] + j];
+                double e2 = x[3 * id[2] + j] - x[3 * id[0] + j];
+                Dix[c * 3 + j] = e1 * R[c * 2 + 0] + e2 * R[c * 2 + 1];
+            }
+        double *ui = u + 6 * t;
+        for (int i = 0; i < 6; ++i) zi[i] = Dix[i] + ui[i];
+        orc_prox_tri(zi, lmin[t], lmax[t]);
+        for (int i = 0; i < 6; ++i) { ui[i] += Dix[i] - zi[i]; z[6 * t + i] = zi[i]; }
+    }
+}
+
+/* pins: SpringPin (src/SpringEnergyTerm.hpp:31-73): dim 6, rows 0-2 = the vertex, rows 3-5 are
+ * never populated (restated as zero). prox: z = pin if active else identity. */
+void orc_local_pins(int n, const int32_t *vidx, const double *pin, const int32_t *active,
+                    const double *x, double *z, double *u) {
+    for (int t = 0; t < n; ++t) {
+        double *ui = u + 6 * t, *zo = z + 6 * t;
+        for (int j = 0; j < 3; ++j) {
+            double Dix = x[3 * vidx[t] + j];
+            double zi = Dix + ui[j];
+            if (active[t]) zi = pin[3 * t + j];
+            ui[j] += Dix - zi;
+            zo[j] = zi;
+        }
+        for (int j = 3; j < 6; ++j) { ui[j] = 0.0; zo[j] = 0.0; }
+    }
+}
+
+/* ---- global step pieces ----------------------------------------------------------------------- */
+
+/* y = A x for a CSR matrix */
+void orc_csr_matvec(int n, const int32_t *rp, const int32_t *ci, const double *v, const double *x, double *y) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        double a = 0.0;
+        for (int k = rp[i]; k < rp[i + 1]; ++k) a += v[k] * x[ci[k]];
+        y[i] = a;
+    }
+}
+
+/*
+ * src/NodalMultiColorGS.hpp:60-146,180-262 -- multi-colour nodal SOR on A = Ahat (x) I3.
+ * Ahat in CSR (nv x nv).  colours: concatenated node lists, cptr[ncolors+1].
+ * pin_flag[v] != 0 -> x_v = pin_xyz[v] (:111-117).  Passive objects: array of (kind, 4 params):
+ * kind 0 = Floor(y0) (PassiveObject.hpp:32-45), kind 1 = Sphere(cx,cy,cz,r) (:48-64); first object
+ * with dx<0 wins (Collider.hpp:137-150).  Returns the sweep count like the reference (iter at break).
+ */
+static int passive_hit(int nobj, const int32_t *okind, const double *opar, const double *x, double *n, double *p) {
+    double best = DBL_MAX; /* Payload ctor: dx = max (Collider.hpp:73) */
+    for (int j = 0; j < nobj; ++j) {
+        const double *q = opar + 4 * j;
+        if (okind[j] == 0) {
+            double dx = x[1] - q[0];
+            if (!(dx > best)) { best = dx; p[0] = x[0]; p[1] = q[0]; p[2] = x[2]; n[0] = 0; n[1] = 1; n[2] = 0; }
+        } else {
+            double dir[3] = {x[0] - q[0], x[1] - q[1], x[2] - q[2]};
+            double l = norm3(dir), dx = l - q[3];
+            if (!(dx > best)) {
+                best = dx;
+                for (int c = 0; c < 3; ++c) { dir[c] /= l; p[c] = q[c] + dir[c] * q[3]; n[c] = dir[c]; }
+            }
+        }
+        if (best < 0) return 1; /* detect_passive returns at the first object with dx<0 */
+    }
+    return 0;
+}
+
+int orc_gs_solve(int nv, const int32_t *rp, const int32_t *ci, const double *val,
+                 const double *b, double *x,
+                 int ncolors, const int32_t *cptr, const int32_t *cnodes,
+                 const int32_t *pin_flag, const double *pin_xyz,
+                 int nobj, const int32_t *okind, const double *opar,
+                 double omega, int max_iters, double tol) {
+    double bnorm = 1.0, tol2 = tol * tol;
+    if (tol > 0) { bnorm = 0.0; for (int i = 0; i < 3 * nv; ++i) bnorm += b[i] * b[i]; }
+    int iter = 0;
+    for (; iter < max_iters; ++iter) {
+        for (int c = 0; c < ncolors; ++c) {
+            int beg = cptr[c], end = cptr[c + 1];
+#pragma omp parallel for schedule(static) if (end - beg > 31)
+            for (int ii = beg; ii < end; ++ii) {
+                int v = cnodes[ii];
+                if (pin_flag && pin_flag[v]) { for (int s = 0; s < 3; ++s) x[3 * v + s] = pin_xyz[3 * v + s]; continue; }
+                double LUx[3] = {0, 0, 0}, aii = 0.0;
+                for (int k = rp[v]; k < rp[v + 1]; ++k) {
+                    if (fabs(val[k]) <= 0.0) continue;              /* :194 */
+                    int col = ci[k];
+                    if (col == v) { aii = val[k]; continue; }
+                    for (int s = 0; s < 3; ++s) LUx[s] += val[k] * x[3 * col + s];
+                }
+                double cx[3], nx[3];
+                for (int s = 0; s < 3; ++s) {
+                    cx[s] = x[3 * v + s];
+                    double xn = (b[3 * v + s] - LUx[s]) / aii;
+                    nx[s] = (1.0 - omega) * cx[s] + omega * xn;     /* :210 */
+                }
+                double n[3], p[3];
+                if (nobj > 0 && passive_hit(nobj, okind, opar, nx, n, p)) {
+                    /* constrained_segment_update :218-262, orthoG :171-177 */
+                    double dx[3], nn[3] = {0, 0, 0}, uu[3], vv[3];
+                    for (int s = 0; s < 3; ++s) dx[s] = (b[3 * v + s] - LUx[s]) / aii - p[s];
+                    if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0;
+                    cross3(nn, n, uu); double l = norm3(uu); for (int s = 0; s < 3; ++s) uu[s] /= l;
+                    cross3(n, uu, vv); l = norm3(vv); for (int s = 0; s < 3; ++s) vv[s] /= l;
+                    double t0 = uu[0] * dx[0] + uu[1] * dx[1] + uu[2] * dx[2];
+                    double t1 = vv[0] * dx[0] + vv[1] * dx[1] + vv[2] * dx[2];
+                    for (int s = 0; s < 3; ++s) nx[s] = uu[s] * t0 + vv[s] * t1 + p[s];
+                }
+                for (int s = 0; s < 3; ++s) x[3 * v + s] = nx[s];
+            }
+        }
+        if (tol > 0) { /* :136-140 */
+            double err = 0.0;
+#pragma omp parallel for schedule(static) reduction(+:err)
+            for (int v = 0; v < nv; ++v) {
+                double a[3] = {0, 0, 0};
+                for (int k = rp[v]; k < rp[v + 1]; ++k)
+                    for (int s = 0; s < 3; ++s) a[s] += val[k] * x[3 * ci[k] + s];
+                for (int s = 0; s < 3; ++s) { double r = b[3 * v + s] - a[s]; err += r * r; }
+            }
+            if (err / bnorm < tol2) break;
+        }
+    }
+    return iter;
+}

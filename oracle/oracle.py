@@ -1,0 +1,447 @@
+"""CPU oracle driver: the reference's Solver::initialize / Solver::step restated in numpy/scipy on top
+of the C restatement (admm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product (admm-elastic_amd/) never imports this module.
+
+Reference lines restated (relative to the reference repo root):
+  initialize : src/Solver.cpp:167-261 (D, W, A = M + dt^2 D^T W^2 D, pins -> SpringPin terms)
+  step       : src/Solver.cpp:35-110
+  reductions : src/TetEnergyTerm.cpp:50-71, src/TriEnergyTerm.cpp:54-69, src/SpringEnergyTerm.hpp:54-59
+  LDLT       : src/LinearSolver.hpp:79-90 (scipy SuperLU direct solve stands in for Eigen SimplicialLDLT;
+               tests/test_oracle_vs_ref.py checks it against the real SimplicialLDLT in oracle/_ref)
+  UzawaCG    : src/UzawaCG.hpp:57-125
+  GS         : src/NodalMultiColorGS.hpp:60-146 (C), colours supplied by the caller
+  collisions : src/Collider.hpp:152-212, src/ConstraintSet.hpp:59-116, src/PassiveObject.hpp:32-64
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(HERE, "_build", "liboracle.so")
+_REF = os.path.join(HERE, "_ref", "libadmm_ref.so")
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+
+
+def build(force=False):
+    """gcc the C restatement (and, when /root/reference exists, the real-reference driver)."""
+    src = os.path.join(HERE, "admm_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src) or \
+            (os.path.exists("/root/reference/src/TriEnergyTerm.cpp") and not os.path.exists(_REF)):
+        subprocess.run(["make", "-C", HERE, "-s"], check=True)
+    return _LIB
+
+
+_lib = None
+
+
+def _p(a):
+    return a.ctypes.data_as(dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(ip)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.orc_svd3xn.argtypes = [C.c_int, dp, dp, dp, dp]
+        L.orc_signed_svd3.argtypes = [dp, dp, dp, dp]
+        L.orc_prox_tet_linear.argtypes = [dp]
+        L.orc_energy_tet_linear.argtypes = [dp, C.c_double, C.c_double]
+        L.orc_energy_tet_linear.restype = C.c_double
+        L.orc_prox_tet_hyper.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, dp, C.c_int]
+        L.orc_prox_tet_hyper.restype = C.c_int
+        L.orc_prox_value.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, dp, dp]
+        L.orc_prox_value.restype = C.c_double
+        L.orc_prox_gradient.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, dp, dp, dp]
+        L.orc_prox_tri.argtypes = [dp, C.c_double, C.c_double]
+        L.orc_tet_rest.argtypes = [dp, dp, dp, dp, dp, dp]
+        L.orc_tet_rest.restype = C.c_int
+        L.orc_tri_rest.argtypes = [dp, dp, dp, dp, dp]
+        L.orc_tri_rest.restype = C.c_int
+        L.orc_local_tets.argtypes = [C.c_int, ip, dp, ip, dp, dp, dp, dp, dp, dp, C.c_int]
+        L.orc_local_tris.argtypes = [C.c_int, ip, dp, dp, dp, dp, dp, dp]
+        L.orc_local_pins.argtypes = [C.c_int, ip, dp, ip, dp, dp, dp]
+        L.orc_csr_matvec.argtypes = [C.c_int, ip, ip, dp, dp, dp]
+        L.orc_gs_solve.argtypes = [C.c_int, ip, ip, dp, dp, dp, C.c_int, ip, ip, ip, dp, C.c_int, ip, dp,
+                                   C.c_double, C.c_int, C.c_double]
+        L.orc_gs_solve.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def ref_lib():
+    """The real-reference pieces (oracle/_ref/libadmm_ref.so) or None when not built."""
+    if not os.path.exists(_REF):
+        try:
+            build()
+        except Exception:
+            pass
+    if not os.path.exists(_REF):
+        return None
+    L = C.CDLL(_REF)
+    L.ref_signed_svd.argtypes = [dp, dp, dp, dp]
+    L.ref_jacobi_svd3.argtypes = [dp, dp, dp, dp]
+    L.ref_lame.argtypes = [C.c_double, C.c_double, dp, dp, dp]
+    L.ref_tri_local_step.argtypes = [C.c_int, ip, C.c_int, dp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                     dp, dp, dp, dp, ip, ip, dp]
+    L.ref_tri_local_step.restype = C.c_int
+    L.ref_pin_local_step.argtypes = [C.c_int, ip, dp, ip, C.c_int, dp, dp, dp]
+    L.ref_pin_local_step.restype = C.c_double
+    L.ref_floor_constraints.argtypes = [C.c_int, dp, C.c_double, C.c_double, C.c_int, ip, dp, dp]
+    L.ref_floor_constraints.restype = C.c_int
+    L.ref_ldlt_solve.argtypes = [C.c_int, ip, ip, dp, C.c_int, dp, dp]
+    L.ref_ldlt_solve.restype = C.c_int
+    L.ref_xu_spline.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp]
+    return L
+
+
+# ---- small wrappers -------------------------------------------------------------------------------
+def lame(youngs, poisson):
+    """src/EnergyTerm.hpp:48-52 -> (mu, lambda, bulk)."""
+    mu = youngs / (2.0 * (1.0 + poisson))
+    la = youngs * poisson / ((1.0 + poisson) * (1.0 - 2.0 * poisson))
+    return mu, la, la + (2.0 / 3.0) * mu
+
+
+def svd3(F):
+    F = np.asfortranarray(np.asarray(F, dtype=np.float64).reshape(3, 3))
+    a = np.ascontiguousarray(F.T).copy()  # column-major flat
+    U = np.zeros(9); S = np.zeros(3); V = np.zeros(9)
+    lib().orc_svd3xn(3, _p(a), _p(U), _p(S), _p(V))
+    return U.reshape(3, 3).T, S, V.reshape(3, 3).T
+
+
+def signed_svd3(F):
+    a = np.ascontiguousarray(np.asarray(F, dtype=np.float64).reshape(3, 3).T).copy()
+    U = np.zeros(9); S = np.zeros(3); V = np.zeros(9)
+    lib().orc_signed_svd3(_p(a), _p(S), _p(U), _p(V))
+    return U.reshape(3, 3).T, S, V.reshape(3, 3).T
+
+
+def tet_rest(verts, tets):
+    verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+    n = len(tets)
+    Binv = np.zeros((n, 9)); vol = np.zeros(n)
+    v = C.c_double()
+    for t in range(n):
+        q = [np.ascontiguousarray(verts[tets[t][i]]) for i in range(4)]
+        b = np.zeros(9)
+        rc = lib().orc_tet_rest(_p(q[0]), _p(q[1]), _p(q[2]), _p(q[3]), _p(b), C.byref(v))
+        if rc:
+            raise RuntimeError("**TetEnergyTerm Error: Inverted initial tet")
+        Binv[t] = b; vol[t] = v.value
+    return Binv, vol
+
+
+def tet_rest_fast(verts, tets):
+    """Vectorised numpy version of tet_rest (same arithmetic) for large meshes."""
+    verts = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+    v0 = verts[tets[:, 0]]
+    B = np.stack([verts[tets[:, 1]] - v0, verts[tets[:, 2]] - v0, verts[tets[:, 3]] - v0], axis=2)  # [n,3,3], B[:,:,c]
+    det = np.linalg.det(B)
+    if np.any(det < 0):
+        raise RuntimeError("**TetEnergyTerm Error: Inverted initial tet")
+    Bi = np.linalg.inv(B)
+    return np.ascontiguousarray(Bi.transpose(0, 2, 1).reshape(-1, 9)), det / 6.0  # column-major flat
+
+
+def tri_rest(verts, tris):
+    verts = np.ascontiguousarray(verts, dtype=np.float64).reshape(-1, 3)
+    n = len(tris)
+    rest = np.zeros((n, 4)); area = np.zeros(n)
+    a = C.c_double()
+    for t in range(n):
+        q = [np.ascontiguousarray(verts[tris[t][i]]) for i in range(3)]
+        r = np.zeros(4)
+        if lib().orc_tri_rest(_p(q[0]), _p(q[1]), _p(q[2]), _p(r), C.byref(a)):
+            raise RuntimeError("**TriEnergyTerm Error: Inverted initial pose")
+        rest[t] = r; area[t] = a.value
+    return rest, area
+
+
+PIN_WEIGHT = np.sqrt(lame(10000000.0, 0.499)[2] * 2.0)  # src/SpringEnergyTerm.hpp:47-52
+
+
+class OracleSolver:
+    """Restatement of admm::Solver for tets / tris / pins / Floor / Sphere."""
+
+    def __init__(self, x, masses, dt=1.0 / 24.0, gravity=-9.8, admm_iters=10, linsolver=0, constraint_w=-1.0,
+                 tets=None, tris=None, pins=None, obstacles=(), mode=1, gs_colors=None,
+                 gs_max_iters=30, gs_tol=1e-10, gs_omega=1.9, uzawa_max_iters=20, uzawa_tol=1e-10, big=False):
+        """tets = dict(idx[n,4], verts(rest), kind[n], mu[n], la[n]); tris = dict(idx[n,3], verts, mu, la,
+        limit_min, limit_max); pins = {vertex: xyz}; obstacles = [(kind, [4 params])];
+        masses [3*nv]; mode 0 = reference stop rule, 1 = tight minimiser."""
+        self.x = np.ascontiguousarray(x, dtype=np.float64).ravel().copy()
+        self.dof = self.x.size
+        self.nv = self.dof // 3
+        self.v = np.zeros(self.dof)
+        self.m = np.ascontiguousarray(masses, dtype=np.float64).ravel().copy()
+        self.dt, self.gravity, self.admm_iters, self.linsolver, self.mode = dt, gravity, admm_iters, linsolver, mode
+        self.gs_max_iters, self.gs_tol, self.gs_omega = gs_max_iters, gs_tol, gs_omega
+        self.uz_max_iters, self.uz_tol = uzawa_max_iters, uzawa_tol
+        self.obstacles = list(obstacles)
+        self.pins = dict(pins or {})
+        if self.obstacles and linsolver == 0:
+            raise RuntimeError("**Solver::add_obstacle Error: No collisions with LDLT solver")
+        self.inner_iters = 0
+        L = lib()
+
+        trip_r, trip_c, trip_v, weights = [], [], [], []
+        row = 0
+        self.nt = 0
+        if tets is not None and len(tets["idx"]):
+            idx = np.ascontiguousarray(tets["idx"], dtype=np.int32).reshape(-1, 4)
+            self.nt = idx.shape[0]
+            Binv, vol = (tet_rest_fast if big else tet_rest)(tets["verts"], idx)
+            self.t_idx, self.t_Binv, self.t_vol = idx, np.ascontiguousarray(Binv), vol
+            self.t_kind = np.ascontiguousarray(np.broadcast_to(tets["kind"], (self.nt,)), dtype=np.int32)
+            self.t_mu = np.ascontiguousarray(np.broadcast_to(tets["mu"], (self.nt,)), dtype=np.float64)
+            self.t_la = np.ascontiguousarray(np.broadcast_to(tets["la"], (self.nt,)), dtype=np.float64)
+            self.t_k = self.t_la + (2.0 / 3.0) * self.t_mu
+            self.t_w = np.sqrt(self.t_k * vol)                    # TetEnergyTerm.cpp:46-47
+            if np.any(self.t_w <= 0):
+                raise RuntimeError("**EnergyTerm::get_reduction Error: Some weight leq 0")
+            # D-block (TetEnergyTerm.cpp:50-71): Dt(r,c) = (S Binv)^T ; rows {0,3,6}+j, cols 3 tet[c] + j
+            Bm = Binv.reshape(-1, 3, 3).transpose(0, 2, 1)        # Bm[t, m, r] = Binv(m, r)
+            Dm = np.concatenate([-Bm.sum(axis=1, keepdims=True), Bm], axis=1)  # [t, 4, 3] = S * Binv
+            for r in range(3):
+                for c in range(4):
+                    for j in range(3):
+                        trip_r.append(row + 9 * np.arange(self.nt) + 3 * r + j)
+                        trip_c.append(3 * idx[:, c] + j)
+                        trip_v.append(Dm[:, c, r])
+            weights.append(np.repeat(self.t_w, 9))
+            row += 9 * self.nt
+        self.ntri = 0
+        if tris is not None and len(tris["idx"]):
+            idx = np.ascontiguousarray(tris["idx"], dtype=np.int32).reshape(-1, 3)
+            self.ntri = idx.shape[0]
+            rest, area = tri_rest(tris["verts"], idx)
+            self.r_idx, self.r_rest = idx, np.ascontiguousarray(rest)
+            mu = np.broadcast_to(tris["mu"], (self.ntri,)).astype(np.float64)
+            la = np.broadcast_to(tris["la"], (self.ntri,)).astype(np.float64)
+            self.r_lmin = np.ascontiguousarray(np.broadcast_to(tris.get("limit_min", -100.0), (self.ntri,)), dtype=np.float64)
+            self.r_lmax = np.ascontiguousarray(np.broadcast_to(tris.get("limit_max", 100.0), (self.ntri,)), dtype=np.float64)
+            self.r_w = np.sqrt((la + (2.0 / 3.0) * mu) * area)    # TriEnergyTerm.cpp:50-51
+            Rm = rest.reshape(-1, 2, 2).transpose(0, 2, 1)        # Rm[t, m, c] = rest(m, c)
+            Dm = np.concatenate([-Rm.sum(axis=1, keepdims=True), Rm], axis=1)  # [t, 3, 2] = S * rest
+            for i in range(3):
+                for j in range(3):
+                    trip_r.append(row + 6 * np.arange(self.ntri) + i); trip_c.append(3 * idx[:, j] + i); trip_v.append(Dm[:, j, 0])
+                    trip_r.append(row + 6 * np.arange(self.ntri) + 3 + i); trip_c.append(3 * idx[:, j] + i); trip_v.append(Dm[:, j, 1])
+            weights.append(np.repeat(self.r_w, 6))
+            row += 6 * self.ntri
+        # pins become SpringPin terms for LDLT / Uzawa (Solver.cpp:190-196)
+        self.npin = 0
+        if linsolver in (0, 2) and self.pins:
+            self.p_vert = np.array(list(self.pins.keys()), dtype=np.int32)
+            self.p_xyz = np.ascontiguousarray(np.array(list(self.pins.values()), dtype=np.float64).reshape(-1, 3))
+            self.p_active = np.ones(len(self.p_vert), dtype=np.int32)
+            self.npin = len(self.p_vert)
+            for j in range(3):
+                trip_r.append(row + 6 * np.arange(self.npin) + j); trip_c.append(3 * self.p_vert + j); trip_v.append(np.ones(self.npin))
+            weights.append(np.full(6 * self.npin, PIN_WEIGHT))
+            row += 6 * self.npin
+        self.R = row
+        self.W = np.concatenate(weights) if weights else np.zeros(0)
+        rr = np.concatenate(trip_r) if trip_r else np.zeros(0, int)
+        cc = np.concatenate(trip_c) if trip_c else np.zeros(0, int)
+        vv = np.concatenate(trip_v) if trip_v else np.zeros(0)
+        self.D = sp.csr_matrix((vv, (rr, cc)), shape=(self.R, self.dof))
+        dt2 = dt * dt
+        self.DtWtW = (dt2 * self.D.T @ sp.diags(self.W * self.W)).tocsr()   # Solver.cpp:225
+        self.A = (sp.diags(self.m) + self.DtWtW @ self.D).tocsr()            # Solver.cpp:226
+        self.A.sum_duplicates()
+        # constraint weight (Solver.cpp:235, 239, 245)
+        wmax = self.W.max() if self.W.size else 0.0
+        self.constraint_w = 3.0 * wmax if linsolver == 1 else 1.0
+        if constraint_w > 0:
+            self.constraint_w = constraint_w
+        self._lu = None
+        if linsolver in (0, 2):
+            self._lu = spla.splu(self.A.tocsc())
+        if linsolver == 1:
+            Ah = self.A[0::3, :][:, 0::3].tocsr()
+            Ah.sort_indices()
+            self.Ah = Ah
+            self.gs_colors = np.asarray(gs_colors, dtype=np.int32) if gs_colors is not None else None
+        self.y = np.zeros(0)  # Uzawa multipliers (warm start, UzawaCG.hpp:74)
+        # ADMM state
+        self.z = np.zeros(self.R); self.u = np.zeros(self.R)
+
+    # -- local step (Solver.cpp:84-87 + EnergyTerm.hpp:130-140) on the AoS z/u in reference row order
+    def local_step(self, curr_x, z, u):
+        L = lib()
+        curr_x = np.ascontiguousarray(curr_x)
+        o = 0
+        if self.nt:
+            zz = np.ascontiguousarray(z[o:o + 9 * self.nt]); uu = np.ascontiguousarray(u[o:o + 9 * self.nt])
+            L.orc_local_tets(self.nt, _i(self.t_idx), _p(self.t_Binv), _i(self.t_kind), _p(self.t_mu), _p(self.t_la),
+                             _p(self.t_k), _p(curr_x), _p(zz), _p(uu), self.mode)
+            z[o:o + 9 * self.nt] = zz; u[o:o + 9 * self.nt] = uu
+            o += 9 * self.nt
+        if self.ntri:
+            zz = np.ascontiguousarray(z[o:o + 6 * self.ntri]); uu = np.ascontiguousarray(u[o:o + 6 * self.ntri])
+            L.orc_local_tris(self.ntri, _i(self.r_idx), _p(self.r_rest), _p(self.r_lmin), _p(self.r_lmax), _p(curr_x), _p(zz), _p(uu))
+            z[o:o + 6 * self.ntri] = zz; u[o:o + 6 * self.ntri] = uu
+            o += 6 * self.ntri
+        if self.npin:
+            zz = np.ascontiguousarray(z[o:o + 6 * self.npin]); uu = np.ascontiguousarray(u[o:o + 6 * self.npin])
+            L.orc_local_pins(self.npin, _i(self.p_vert), _p(self.p_xyz), _i(self.p_active), _p(curr_x), _p(zz), _p(uu))
+            z[o:o + 6 * self.npin] = zz; u[o:o + 6 * self.npin] = uu
+
+    # -- Collider::detect with passive objects (Collider.hpp:152-212); hits in vertex order
+    def detect_passive(self, x):
+        if not self.obstacles:
+            return []
+        X = x.reshape(-1, 3)
+        best = np.full(self.nv, np.finfo(np.float64).max)
+        point = np.zeros((self.nv, 3)); normal = np.zeros((self.nv, 3))
+        for kind, par in self.obstacles:
+            if kind == 0:   # Floor, PassiveObject.hpp:37-43
+                dx = X[:, 1] - par[0]
+                upd = ~(dx > best)
+                p = X.copy(); p[:, 1] = par[0]
+                n = np.zeros_like(X); n[:, 1] = 1.0
+            else:           # Sphere, PassiveObject.hpp:55-62
+                d = X - np.asarray(par[:3])
+                l = np.linalg.norm(d, axis=1)
+                dx = l - par[3]
+                upd = ~(dx > best)
+                n = d / l[:, None]
+                p = np.asarray(par[:3]) + n * par[3]
+            best = np.where(upd, dx, best)
+            point[upd] = p[upd]; normal[upd] = n[upd]
+        hit = np.nonzero(best < 0)[0]
+        return [(int(i), best[i], point[i].copy(), normal[i].copy()) for i in hit]
+
+    # -- ConstraintSet::make_matrix (ConstraintSet.hpp:59-116), passive hits only
+    def make_matrix(self, hits):
+        ck = np.sqrt(max(0.0, self.constraint_w))
+        rows, cols, vals = [], [], []
+        c = np.zeros(len(hits))
+        for i, (vi, dx, p, n) in enumerate(hits):
+            c[i] = ck * n.dot(p)
+            for j in range(3):
+                rows.append(i); cols.append(3 * vi + j); vals.append(ck * n[j])
+        Cm = sp.csr_matrix((vals, (rows, cols)), shape=(len(hits), self.dof))
+        return Cm, c
+
+    # -- global solvers
+    def solve_ldlt(self, b):
+        return self._lu.solve(b)
+
+    def solve_uzawa(self, x, b, hits):
+        """UzawaCG::solve (UzawaCG.hpp:57-125); returns (x, iters)."""
+        Cm, c = self.make_matrix(hits)
+        if self.y.shape[0] != Cm.shape[0]:
+            self.y = np.zeros(Cm.shape[0])
+        if Cm.nnz == 0:
+            return self._lu.solve(b), 1
+        Ct = Cm.T.tocsr()
+        x = self._lu.solve(b - Ct @ self.y)
+        r = Cm @ x - c
+        d = r.copy()
+        tol2 = self.uz_tol * self.uz_tol
+        tiny = np.finfo(np.float64).tiny
+        it = 0
+        while it < self.uz_max_iters:
+            q2 = self._lu.solve(Ct @ d)
+            q3 = Cm @ q2
+            denom = d.dot(q3)
+            if abs(denom) < tiny:
+                break
+            alpha = d.dot(r) / denom
+            x = x - alpha * q2
+            self.y = self.y + alpha * d
+            r = r - alpha * q3
+            if r.dot(r) < tol2:
+                break
+            beta = r.dot(q3) / denom
+            d = r - beta * d
+            it += 1
+        return x, it
+
+    def solve_gs(self, x, b):
+        L = lib()
+        if self.gs_colors is None:
+            raise RuntimeError("oracle GS needs colours (the reference's colouring library is absent)")
+        nc = int(self.gs_colors.max()) + 1
+        order = np.argsort(self.gs_colors, kind="stable").astype(np.int32)
+        cptr = np.zeros(nc + 1, dtype=np.int32)
+        np.cumsum(np.bincount(self.gs_colors, minlength=nc), out=cptr[1:])
+        pin_flag = np.zeros(self.nv, dtype=np.int32); pin_xyz = np.zeros((self.nv, 3))
+        for k, p in self.pins.items():
+            pin_flag[k] = 1; pin_xyz[k] = p
+        okind = np.array([o[0] for o in self.obstacles], dtype=np.int32)
+        opar = np.ascontiguousarray(np.array([o[1] for o in self.obstacles], dtype=np.float64).reshape(-1, 4))
+        x = np.ascontiguousarray(x).copy()
+        b = np.ascontiguousarray(b)
+        rp = np.ascontiguousarray(self.Ah.indptr, dtype=np.int32); ci = np.ascontiguousarray(self.Ah.indices, dtype=np.int32)
+        va = np.ascontiguousarray(self.Ah.data)
+        it = L.orc_gs_solve(self.nv, _i(rp), _i(ci), _p(va), _p(b), _p(x), nc, _i(cptr), _i(order),
+                            _i(pin_flag) if self.pins else None, _p(pin_xyz), len(self.obstacles),
+                            _i(okind) if len(okind) else None, _p(opar) if len(okind) else None,
+                            self.gs_omega, self.gs_max_iters, self.gs_tol)
+        return x, it
+
+    def rhs(self, Mxbar, z, u):
+        return Mxbar + self.DtWtW @ (z - u)          # Solver.cpp:98
+
+    def global_solve(self, x, b):
+        if self.linsolver == 1:
+            return self.solve_gs(x, b)
+        if self.linsolver == 2:
+            return self.solve_uzawa(x, b, self._hits)
+        return self.solve_ldlt(b), 1
+
+    def step(self, trace=None):
+        """Solver::step (Solver.cpp:35-110). trace: optional list receiving (z,u,b,x) per ADMM iteration."""
+        dt = self.dt
+        if abs(self.gravity) > 0:
+            self.v[1::3] += dt * self.gravity                     # :57-59
+        x_bar = self.x + dt * self.v                              # :65
+        Mxbar = self.m * x_bar
+        curr = x_bar.copy()
+        z = np.zeros(self.R); u = np.zeros(self.R)                # :70-71 (z = D x is a dead store)
+        self.inner_iters = 0
+        for _ in range(self.admm_iters):
+            self.local_step(curr, z, u)                           # :84-87
+            self._hits = self.detect_passive(curr) if self.linsolver != 1 else []   # :92-93
+            b = self.rhs(Mxbar, z, u)                             # :98
+            curr, it = self.global_solve(curr, b)                 # :99
+            self.inner_iters += it
+            if trace is not None:
+                trace.append((z.copy(), u.copy(), b.copy(), curr.copy()))
+        self.v = (curr - self.x) / dt                             # :105
+        self.x = curr                                             # :106
+        self.z, self.u = z, u
+
+    def set_pins(self, pins):
+        """Solver::set_pins after initialize (Solver.cpp:113-157)."""
+        self.pins = dict(pins)
+        if self.linsolver in (0, 2) and self.npin:
+            self.p_active[:] = 0
+            where = {int(v): i for i, v in enumerate(self.p_vert)}
+            for k, p in self.pins.items():
+                if k not in where:
+                    raise RuntimeError("**Solver::set_pins Error: Constraint for %d not found." % k)
+                self.p_active[where[k]] = 1
+                self.p_xyz[where[k]] = p
+
+    # TetEnergyTerm::energy for one linear tet (TetEnergyTerm.cpp:94-100) given its 9 D-rows times x
+    def tet_energy_linear(self, t, x):
+        F = (self.D[9 * t:9 * t + 9] @ x)
+        return lib().orc_energy_tet_linear(_p(np.ascontiguousarray(F)), self.t_k[t], self.t_vol[t])

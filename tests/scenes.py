@@ -1,0 +1,138 @@
+"""Scene builders shared by the tests: the same description goes to the product Solver
+(admm_elastic_amd, HIP) and to the CPU oracle (oracle/oracle.py)."""
+import numpy as np
+
+import admm_elastic_amd as pkg
+from admm_elastic_amd import meshes
+from admm_elastic_amd.solver import Floor, Lame, Settings, Solver, Sphere
+from oracle import oracle as orc
+
+
+class Scene:
+    def __init__(self):
+        self.x = np.zeros((0, 3)); self.m = np.zeros(0)
+        self.tets = []   # (verts_rest, idx, lame, kind)
+        self.tris = []   # (verts_rest, idx, lame)
+        self.pins = {}
+        self.obstacles = []  # (kind, params)
+        self.settings = dict(timestep_s=1.0 / 24.0, admm_iters=10, gravity=-9.8, linsolver=0, constraint_w=-1.0)
+
+    def add_tet_mesh(self, verts, tets, lame, kind, density=1522.0):
+        off = self.x.shape[0]
+        self.x = np.concatenate([self.x, verts])
+        self.m = np.concatenate([self.m, meshes.lumped_masses_tets(verts, tets, density)])
+        self.tets.append((verts, tets, lame, kind, off))
+        return off
+
+    def add_tri_mesh(self, verts, tris, lame, density=1.0):
+        off = self.x.shape[0]
+        self.x = np.concatenate([self.x, verts])
+        self.m = np.concatenate([self.m, meshes.lumped_masses_tris(verts, tris, density)])
+        self.tris.append((verts, tris, lame, off))
+        return off
+
+    def masses3(self):
+        return np.repeat(self.m, 3)
+
+    # ---- product ----
+    def make_solver(self, init=True, **gpu_kw):
+        s = Solver()
+        s.add_nodes(self.x, self.masses3())
+        for verts, tets, lame, kind, off in self.tets:
+            s.add_tets(verts, tets, lame, kind, vertex_offset=off)
+        for verts, tris, lame, off in self.tris:
+            s.add_tris(verts, tris, lame, vertex_offset=off)
+        if self.pins:
+            s.set_pins(list(self.pins.keys()), [self.pins[k] for k in self.pins])
+        for kind, par in self.obstacles:
+            s.add_obstacle(Floor(par[0]) if kind == 0 else Sphere(par[:3], par[3]))
+        st = Settings(**self.settings)
+        for k, v in gpu_kw.items():
+            setattr(st, k, v)
+        self.product_settings = st
+        if init:
+            assert s.initialize(st)
+        else:
+            s._settings = st
+        return s
+
+    # ---- oracle ----
+    def make_oracle(self, mode=1, gs_colors=None, big=False, **kw):
+        tets = tris = None
+        if self.tets:
+            idx = np.concatenate([t[1] + t[4] for t in self.tets]).astype(np.int32)
+            kind = np.concatenate([np.full(len(t[1]), t[3], np.int32) for t in self.tets])
+            mu = np.concatenate([np.full(len(t[1]), t[2].mu) for t in self.tets])
+            la = np.concatenate([np.full(len(t[1]), t[2].lambda_) for t in self.tets])
+            tets = dict(idx=idx, verts=self.x, kind=kind, mu=mu, la=la)
+        if self.tris:
+            idx = np.concatenate([t[1] + t[3] for t in self.tris]).astype(np.int32)
+            mu = np.concatenate([np.full(len(t[1]), t[2].mu) for t in self.tris])
+            la = np.concatenate([np.full(len(t[1]), t[2].lambda_) for t in self.tris])
+            lmin = np.concatenate([np.full(len(t[1]), t[2].limit_min) for t in self.tris])
+            lmax = np.concatenate([np.full(len(t[1]), t[2].limit_max) for t in self.tris])
+            tris = dict(idx=idx, verts=self.x, mu=mu, la=la, limit_min=lmin, limit_max=lmax)
+        st = self.settings
+        return orc.OracleSolver(self.x, self.masses3(), dt=st["timestep_s"], gravity=st["gravity"],
+                                admm_iters=st["admm_iters"], linsolver=st["linsolver"], constraint_w=st["constraint_w"],
+                                tets=tets, tris=tris, pins=self.pins, obstacles=self.obstacles, mode=mode,
+                                gs_colors=gs_colors, big=big, **kw)
+
+
+def cube_scene(n, kind, lame=None, pin_face=True, size=1.0, **settings):
+    """Kuhn cube, x=0 face pinned (SURVEY 8d config 2/3 shape)."""
+    sc = Scene()
+    verts, tets = meshes.kuhn_cube(n, size)
+    sc.add_tet_mesh(verts, tets, lame or Lame.soft_rubber(), kind)
+    if pin_face:
+        for i in np.nonzero(verts[:, 0] < 1e-9)[0]:
+            sc.pins[int(i)] = verts[i].copy()
+    sc.settings.update(settings)
+    return sc
+
+
+def mixed_cube_scene(n, **settings):
+    """StVK / Neo-Hookean alternating by z-slab + a linear slab (config 3 shape)."""
+    sc = Scene()
+    verts, tets = meshes.kuhn_cube(n)
+    cz = verts[tets].mean(axis=1)[:, 2]
+    slab = np.minimum((cz * 3).astype(int), 2)
+    sc.x = verts; sc.m = meshes.lumped_masses_tets(verts, tets)
+    lame = Lame.soft_rubber()
+    for s, kind in ((0, pkg.TET_NEOHOOKEAN), (1, pkg.TET_STVK), (2, pkg.TET_LINEAR)):
+        sel = tets[slab == s]
+        if len(sel):
+            sc.tets.append((verts, sel, lame, kind, 0))
+    for i in np.nonzero(verts[:, 0] < 1e-9)[0]:
+        sc.pins[int(i)] = verts[i].copy()
+    sc.settings.update(settings)
+    return sc
+
+
+def cloth_scene(m, limits=(0.95, 1.05), floor=None, **settings):
+    """config 5 shape: m x m cloth, Lame(100, 0.1) with strain limits, two corner pins."""
+    sc = Scene()
+    verts, tris = meshes.cloth_grid(m, size=1.0, y=0.5)
+    lame = Lame(100.0, 0.1)
+    if limits:
+        lame.limit_min, lame.limit_max = limits
+    sc.add_tri_mesh(verts, tris, lame)
+    for i in (0, m):  # two corners of the x=0 edge
+        sc.pins[int(i)] = verts[i].copy()
+    if floor is not None:
+        sc.obstacles.append((0, [floor, 0.0, 0.0, 0.0]))
+    sc.settings.update(settings)
+    return sc
+
+
+def perturb(x, amp, seed=0):
+    rng = np.random.default_rng(seed)
+    return x + amp * rng.standard_normal(x.shape)
+
+
+def rel_err(a, b, x_ref=None):
+    """max_v |a_v - b_v| / bbox_diag (SURVEY 8d parity metric)."""
+    a = np.asarray(a).reshape(-1, 3); b = np.asarray(b).reshape(-1, 3)
+    ref = b if x_ref is None else np.asarray(x_ref).reshape(-1, 3)
+    diag = np.linalg.norm(ref.max(axis=0) - ref.min(axis=0))
+    return np.linalg.norm(a - b, axis=1).max() / max(diag, 1e-300)

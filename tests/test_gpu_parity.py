@@ -1,0 +1,234 @@
+"""Parity of the HIP hot path (through the C ABI) against the CPU oracle on identical seeded inputs.
+Tolerances: FP64 everywhere; kernel-level quantities agree to ~1e-10 absolute (values are O(1)
+deformation gradients), whole-step positions to <= 1e-5 of the bounding-box diagonal -- the
+tolerance BASELINE.json's north_star states -- and in practice ~1e-8."""
+import os
+
+import numpy as np
+import pytest
+
+import admm_elastic_amd as pkg
+from admm_elastic_amd import meshes
+from admm_elastic_amd.solver import Lame
+from oracle import oracle as orc
+import scenes
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.npz")
+KINDS = {"linear": pkg.TET_LINEAR, "neohookean": pkg.TET_NEOHOOKEAN, "stvk": pkg.TET_STVK, "spline": pkg.TET_SPLINE_NH}
+
+
+def deformed(sc, amp, seed):
+    rng = np.random.default_rng(seed)
+    x = sc.x.copy()
+    x = x @ np.array([[1.15, 0.1, 0.0], [0.0, 0.9, 0.05], [0.02, 0.0, 1.05]]).T  # global shear/stretch
+    return (x + amp * rng.standard_normal(x.shape)).ravel()
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("amp", [0.0, 0.01, 0.12])   # 0.12 on a 1/4 grid inverts a few tets
+def test_local_step_tets(kind, amp):
+    sc = scenes.cube_scene(4, KINDS[kind], pin_face=False)
+    s = sc.make_solver()
+    o = sc.make_oracle(mode=1)
+    x = deformed(sc, amp, 11)
+    R = o.R
+    u0 = 0.05 * np.random.default_rng(12).standard_normal(R)
+    z, u = s.local_step(x, u0)
+    zo = np.zeros(R); uo = u0.copy()
+    o.local_step(x, zo, uo)
+    tol = 1e-11 if kind == "linear" else 2e-8
+    assert np.abs(z - zo).max() < tol, np.abs(z - zo).max()
+    assert np.abs(u - uo).max() < tol
+    if amp == 0.12:
+        F = (uo - u0 + zo).reshape(-1, 3, 3)
+        assert (np.linalg.det(F) < 0).any(), "case meant to contain inverted elements"
+
+
+def test_local_step_mixed_materials_and_rhs():
+    sc = scenes.mixed_cube_scene(4)
+    s = sc.make_solver()
+    o = sc.make_oracle(mode=1)
+    x = deformed(sc, 0.02, 21)
+    u0 = 0.02 * np.random.default_rng(22).standard_normal(o.R)
+    Mxbar = np.random.default_rng(23).standard_normal(x.size)
+    z, u, b = s.local_step(x, u0, Mxbar)
+    zo = np.zeros(o.R); uo = u0.copy()
+    o.local_step(x, zo, uo)
+    assert np.abs(z - zo).max() < 2e-8 and np.abs(u - uo).max() < 2e-8
+    bo = o.rhs(Mxbar, zo, uo)
+    assert np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+
+
+def test_local_step_tris_pins_and_golden():
+    import test_oracle_vs_ref as T
+    verts, tris, x, u0, mu, la, limits = T.tri_case()
+    sc = scenes.Scene()
+    lame = Lame(100.0, 0.1); lame.limit_min, lame.limit_max = limits
+    sc.add_tri_mesh(verts, tris, lame)
+    sc.pins = {0: np.array([0.1, 0.2, 0.3]), 5: verts[5].copy()}
+    s = sc.make_solver()
+    o = sc.make_oracle()
+    uu = np.concatenate([u0, np.zeros(12)])
+    z, u = s.local_step(x.ravel(), uu)
+    zo = np.zeros(o.R); uo = uu.copy()
+    o.local_step(x.ravel(), zo, uo)
+    assert np.abs(z - zo).max() < 1e-11 and np.abs(u - uo).max() < 1e-11
+    g = np.load(GOLD)   # what the real reference TriEnergyTerm returned for this input
+    n = 6 * len(tris)
+    assert np.abs(z[:n] - g["tri_z"]).max() < 1e-11 and np.abs(u[:n] - g["tri_u"]).max() < 1e-11
+
+
+def test_global_solve_pcg_matches_exact():
+    sc = scenes.cube_scene(5, pkg.TET_NEOHOOKEAN)
+    s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+    o = sc.make_oracle()
+    rng = np.random.default_rng(31)
+    b = o.A @ rng.standard_normal(o.dof)
+    x, it = s.global_solve(b, np.zeros(o.dof))
+    xo = o.solve_ldlt(b)
+    assert 0 < it < 400
+    assert np.linalg.norm(x - xo) <= 1e-8 * np.linalg.norm(xo)
+    x2, it2 = s.global_solve(b, xo)       # warm start at the solution: converged immediately
+    assert it2 <= 1 and np.linalg.norm(x2 - xo) <= 1e-8 * np.linalg.norm(xo)
+
+
+@pytest.mark.parametrize("floor", [None, 0.3])
+def test_global_solve_gs_sweep_for_sweep(floor):
+    sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, linsolver=1)
+    if floor is not None:
+        sc.obstacles.append((0, [floor, 0.0, 0.0, 0.0]))
+    s = sc.make_solver()
+    colors, nc = s.gs_colors()
+    o = sc.make_oracle(gs_colors=colors)
+    rng = np.random.default_rng(41)
+    xt = sc.x.ravel() + 0.01 * rng.standard_normal(o.dof)
+    b = o.A @ xt
+    x, it = s.global_solve(b, sc.x.ravel())
+    xo, ito = o.solve_gs(sc.x.ravel(), b)
+    assert it == ito == 30
+    assert np.abs(x - xo).max() < 1e-10
+    if floor is not None:
+        y = x.reshape(-1, 3)[:, 1]
+        assert y[[k for k in range(len(y)) if k not in sc.pins]].min() >= floor - 1e-12
+
+
+def run_both(sc, frames, mode=1, gs=False, **gpu_kw):
+    s = sc.make_solver(**gpu_kw)
+    o = sc.make_oracle(mode=mode, gs_colors=s.gs_colors()[0] if gs else None)
+    for _ in range(frames):
+        s.step(); o.step()
+    return s, o
+
+
+@pytest.mark.parametrize("kind", ["linear", "neohookean", "stvk"])
+def test_step_parity_cube_ldlt(kind):
+    """config-1/2-like: pinned cube under gravity, exact global solve vs PCG(1e-10)."""
+    sc = scenes.cube_scene(5, KINDS[kind], admm_iters=10, linsolver=0)
+    s, o = run_both(sc, 5, pcg_tol=1e-11, pcg_max_iters=300)
+    err = scenes.rel_err(s.m_x, o.x)
+    assert err < 1e-5, err
+    assert err < 1e-7, err          # what we actually expect
+    assert np.abs(s.m_v - o.v).max() <= 1e-5 * max(1.0, np.abs(o.v).max())
+    assert np.abs(o.x - sc.x.ravel()).max() > 1e-3   # the scene actually moved
+    assert s.runtime_data().inner_iters > 0 and s.runtime_data().last_solve_converged == 1
+
+
+def test_step_parity_mixed_materials():
+    sc = scenes.mixed_cube_scene(6, admm_iters=20, linsolver=0)
+    s, o = run_both(sc, 3, pcg_tol=1e-11, pcg_max_iters=300)
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7
+
+
+def test_step_parity_reference_stop_rule_gap():
+    """Oracle with the reference's loose L-BFGS stop rule vs the exact minimiser the GPU computes:
+    the irreducible uncertainty about the absent mcloptlib (SURVEY 7 'hard parts') stays << 1e-5."""
+    sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, admm_iters=10, linsolver=0)
+    s, o = run_both(sc, 5, mode=0, pcg_tol=1e-11, pcg_max_iters=300)
+    assert scenes.rel_err(s.m_x, o.x) < 1e-5
+
+
+def test_step_parity_gs():
+    """config-2-like: multi-colour GS global step, compared sweep for sweep with the shared colouring."""
+    sc = scenes.cube_scene(5, pkg.TET_NEOHOOKEAN, admm_iters=20, linsolver=1)
+    s, o = run_both(sc, 3, gs=True)
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7
+    assert s.runtime_data().inner_iters == o.inner_iters == 20 * 30
+
+
+def test_step_parity_cloth_ldlt_and_moving_pins():
+    sc = scenes.cloth_scene(8, admm_iters=10, linsolver=0)
+    s = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=300)
+    o = sc.make_oracle()
+    keys = list(sc.pins.keys())
+    for f in range(4):
+        pts = {k: sc.pins[k] + np.array([0.0, 0.01 * (f + 1), 0.0]) for k in keys}
+        s.set_pins(keys, [pts[k] for k in keys]); o.set_pins(pts)
+        s.step(); o.step()
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7
+    with pytest.raises(pkg.AdmmHipError):     # Solver.cpp:147-151: unknown pin after initialize
+        s.set_pins([3], [np.zeros(3)])
+
+
+def test_step_parity_cloth_floor_gs():
+    """config-5-like: strain-limited cloth falling on a floor, GS with in-sweep pins + plane projection."""
+    sc = scenes.cloth_scene(10, floor=0.45, admm_iters=10, linsolver=1)
+    s, o = run_both(sc, 6, gs=True)
+    assert scenes.rel_err(s.m_x, o.x) < 1e-6
+    y = s.m_x.reshape(-1, 3)[:, 1]
+    assert abs(y.min() - 0.45) < 1e-9      # came to rest exactly on the floor
+
+
+# ---- BASELINE-size properties (size-independent invariants at 1M tets) ----------------------------
+@pytest.fixture(scope="module")
+def big():
+    n = int(os.environ.get("ADMM_TEST_BIG_N", "55"))
+    verts, tets = meshes.kuhn_cube(n)
+    sc = scenes.Scene()
+    cz = verts[tets].mean(axis=1)[:, 2]
+    slab = (cz * 8).astype(int) % 2
+    sc.x = verts; sc.m = meshes.lumped_masses_tets(verts, tets)
+    lame = Lame.soft_rubber()
+    sc.tets.append((verts, tets[slab == 0], lame, pkg.TET_NEOHOOKEAN, 0))
+    sc.tets.append((verts, tets[slab == 1], lame, pkg.TET_STVK, 0))
+    sc.settings.update(admm_iters=3, linsolver=0, gravity=0.0)
+    s = sc.make_solver(pcg_tol=1e-10, pcg_max_iters=60)
+    return sc, s
+
+
+def test_big_rotation_is_a_fixed_point_of_the_prox(big):
+    """F = R for every tet => z = R, u stays 0, and the assembled RHS equals M x_bar exactly (up to
+    round-off): checks SVD, prox and gather on ~1M tets without needing the oracle at that size."""
+    sc, s = big
+    Rm = np.linalg.qr(np.random.default_rng(5).standard_normal((3, 3)))[0]
+    if np.linalg.det(Rm) < 0:
+        Rm[:, 2] *= -1
+    x = (sc.x @ Rm.T + np.array([0.3, -0.2, 0.1])).ravel()
+    R = s.num_rows()
+    Mx = np.random.default_rng(6).standard_normal(x.size)
+    z, u, b = s.local_step(x, np.zeros(R), Mx)
+    Z = z.reshape(-1, 3, 3).transpose(0, 2, 1)
+    assert np.abs(Z - Rm).max() < 1e-9
+    assert np.abs(u).max() < 1e-9
+    scale = np.abs(s.flatten()["tet_weight"]).max() ** 2 * (1.0 / 24.0) ** 2
+    assert np.abs(b - Mx).max() < 1e-7 * max(1.0, scale)
+
+
+def test_big_rest_state_is_stationary(big):
+    sc, s = big
+    s.m_x = sc.x.ravel().copy(); s.m_v = np.zeros_like(s.m_x)
+    s.step()
+    assert scenes.rel_err(s.m_x, sc.x) < 1e-9
+    assert np.abs(s.m_v).max() < 1e-6
+
+
+def test_big_translation_equivariance(big):
+    sc, s = big
+    rng = np.random.default_rng(8)
+    x0 = (sc.x * np.array([1.05, 0.97, 1.0])).ravel()     # mildly stretched start, no pins
+    s.m_x = x0.copy(); s.m_v = np.zeros_like(x0); s.step()
+    xa = s.m_x.copy()
+    t = np.tile(rng.standard_normal(3), len(sc.x))
+    s.m_x = x0 + t; s.m_v = np.zeros_like(x0); s.step()
+    assert np.abs((s.m_x - t) - xa).max() < 1e-7
+    assert np.abs(xa - x0).max() > 1e-4

@@ -1,0 +1,109 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol
+include/admm_hip.h declares, the set-up arithmetic (rest poses, Lame, A assembly, colouring,
+partition) matches the oracle, and the hot path fails loudly when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import admm_elastic_amd as pkg
+from admm_elastic_amd import capi, meshes
+from admm_elastic_amd.solver import Lame, Settings, Solver
+from oracle import oracle as orc
+import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "admm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(admm_(?:hip|host)_[a-z_0-9]+)\s*\(", hdr))
+    bound = {s[0] for s in capi.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    L = C.CDLL(capi.lib_path)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert C.sizeof(capi.Desc) > 0 and capi.lib().admm_hip_device_count() >= 0
+
+
+def test_no_gpu_means_loud_failure():
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    sc = scenes.cube_scene(2, pkg.TET_LINEAR)
+    s = sc.make_solver(init=False)
+    with pytest.raises(pkg.AdmmHipError) as e:
+        s.initialize(sc.product_settings)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_rest_pose_and_lame_match_oracle():
+    verts, tets = meshes.kuhn_cube(3, 0.7)
+    verts = scenes.perturb(verts, 0.01, 1)
+    B, vol = capi.tet_rest(verts, tets)
+    Bo, volo = orc.tet_rest(verts, tets)
+    assert np.allclose(B, Bo, rtol=1e-12, atol=1e-12) and np.allclose(vol, volo, rtol=1e-13)
+    assert np.all(vol > 0)
+    v2, tris = meshes.cloth_grid(4)
+    v2 = scenes.perturb(v2, 0.01, 2)
+    R, area = capi.tri_rest(v2, tris)
+    Ro, areao = orc.tri_rest(v2, tris)
+    assert np.allclose(R, Ro, rtol=1e-12, atol=1e-12) and np.allclose(area, areao, rtol=1e-13)
+    assert np.allclose(capi.lame(1e7, 0.399), orc.lame(1e7, 0.399), rtol=1e-15)
+    bad = tets.copy(); bad[0, [2, 3]] = bad[0, [3, 2]]
+    with pytest.raises(pkg.AdmmHipError) as e:
+        capi.tet_rest(verts, bad)
+    assert e.value.code == -3 and "Inverted initial tet" in str(e.value)
+
+
+@pytest.mark.parametrize("ls", [0, 1])
+def test_assembled_matrix_matches_oracle(ls):
+    sc = scenes.mixed_cube_scene(3, linsolver=ls)
+    v2, tris = meshes.cloth_grid(3, 1.0, 1.5)
+    sc.add_tri_mesh(v2, tris, Lame(100.0, 0.1))
+    s = sc.make_solver(init=False)
+    rp, ci, va = s.host_matrix(sc.product_settings)
+    nv = sc.x.shape[0]
+    Ah = sp.csr_matrix((va, ci, rp), shape=(nv, nv))
+    o = sc.make_oracle()
+    A = (sp.kron(Ah, sp.identity(3)) + sp.diags(sc.masses3())).tocsr()
+    assert abs(A - o.A).max() <= 1e-12 * abs(o.A).max()
+    assert o.R == 9 * o.nt + 6 * o.ntri + 6 * o.npin
+    assert o.D.nnz == 36 * o.nt + 18 * o.ntri + 3 * o.npin
+    assert np.all(np.diff(ci.reshape(-1)[rp[0]:rp[1]]) > 0)     # sorted columns
+
+
+def test_greedy_coloring_is_valid():
+    sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, linsolver=1)
+    s = sc.make_solver(init=False)
+    rp, ci, va = s.host_matrix(sc.product_settings)
+    col, nc = capi.greedy_coloring(rp, ci)
+    assert col.min() == 0 and col.max() == nc - 1
+    for i in range(len(rp) - 1):
+        nb = ci[rp[i]:rp[i + 1]]
+        assert np.all(col[nb[nb != i]] != col[i])
+
+
+def test_partition_covers_everything():
+    for n in (1, 7, 1000, 998250):
+        for w in (1, 2, 4, 8):
+            spans = [capi.partition(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def test_bad_descriptions_are_rejected():
+    sc = scenes.cube_scene(2, pkg.TET_LINEAR)
+    sc.obstacles.append((0, [0.0, 0, 0, 0]))
+    s = sc.make_solver(init=False)
+    with pytest.raises(pkg.AdmmHipError) as e:      # Solver.cpp:249-254
+        s.host_matrix(sc.product_settings)
+    assert "No collisions with LDLT solver" in str(e.value)
+    lame = Lame(100.0, 0.1); lame.limit_min = 1.5
+    with pytest.raises(pkg.AdmmHipError):            # TriEnergyTerm.cpp:32
+        Solver().add_tris(*meshes.cloth_grid(2), lame)
+    assert Solver().initialize(Settings()) is False  # Solver.cpp:180-183
