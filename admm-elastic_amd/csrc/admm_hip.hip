@@ -75,7 +75,7 @@ struct admm_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_step0 = nullptr, ev_step1 = nullptr;
-    std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration when stats are requested
+    std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration (+1) when stats are requested
 
     int nv = 0, n3 = 0;
     double dt = 1.0 / 24.0;
@@ -553,12 +553,12 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
     if (c->npin_terms) HIP_TRY(hipMemsetAsync(c->pin_u.p, 0, c->pin_u.n * sizeof(double), st));
     for (int s = 0; s < admm_iters; ++s) {
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s], st));
-        launch_local<false>(c);
-        launch_gather(c);
+        launch_local<false>(c);                 // Solver.cpp:84-87
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 1], st));
-        // collision detection against passive objects happens inside the GS sweeps (linsolver 1)
+        // passive collisions are resolved inside the GS sweeps (linsolver 1, Solver.cpp:76)
+        launch_gather(c);                       // Solver.cpp:98
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 2], st));
-        launch_global(c, c->b.p, c->curr.p);
+        launch_global(c, c->b.p, c->curr.p);    // Solver.cpp:99
     }
     if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * admm_iters], st));
     hipLaunchKernelGGL(k_finish, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, 1.0 / c->dt, c->x.p, c->v.p, c->curr.p);
@@ -571,9 +571,10 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_step0, c->ev_step1));
         stats->step_ms = ms;
         for (int s = 0; s < admm_iters; ++s) {
+            // local_ms = the prox kernels (the reference's local loop); global_ms = RHS + solve, as in Solver.cpp:97-100
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s], c->ev_phase[3 * s + 1])); stats->local_ms += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 2])); stats->collision_ms += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 2], c->ev_phase[3 * s + 3])); stats->global_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 2])); stats->rhs_ms += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 3])); stats->global_ms += ms;
         }
         int h[4];
         HIP_TRY(hipMemcpy(h, c->counters.p, 4 * sizeof(int), hipMemcpyDeviceToHost));

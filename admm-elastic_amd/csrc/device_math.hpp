@@ -207,6 +207,10 @@ struct StretchModel {
 };
 
 // argmin_s Psi(s) + k/2 |s - x0|^2 by safeguarded Newton, started from s (in/out). Returns iterations.
+// NH: the log barrier keeps the iterates strictly positive.  StVK: the feasible set is s >= 0 (value()
+// is FLT_MAX only for s < 0) and for inverted elements the minimiser sits ON that boundary, so the
+// iteration is a projected Newton: components at the bound whose gradient points outward are frozen,
+// the rest take the reduced Newton step, and trial points are projected back onto s >= 0.
 template <int KIND>
 __device__ __forceinline__ int minimize_stretch(const StretchModel<KIND> &m, double *s) {
     double g[3], D[3], w[3];
@@ -220,7 +224,8 @@ __device__ __forceinline__ int minimize_stretch(const StretchModel<KIND> &m, dou
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double Di = fmax(fabs(D[i]), floorD);
-            a[i] = 1.0 / Di;
+            const bool active = (KIND == 2) && (s[i] <= 0.0) && (g[i] > 0.0);
+            a[i] = active ? 0.0 : 1.0 / Di;
             y[i] = g[i] * a[i];
             wDg = fma(w[i], y[i], wDg);
             wDw = fma(w[i] * w[i], a[i], wDw);
@@ -237,16 +242,21 @@ __device__ __forceinline__ int minimize_stretch(const StretchModel<KIND> &m, dou
             gd = 0.0;
 #pragma unroll
             for (int i = 0; i < 3; ++i) { d[i] = -y[i]; gd = fma(g[i], d[i], gd); }
-            if (!(gd < 0.0)) break; // zero gradient
+            if (!(gd < 0.0)) break; // zero (reduced) gradient
         }
         double t = 1.0, sn[3], fn = f;
         bool ok = false;
         for (int ls = 0; ls < 50; ++ls) {
+            double gs = 0.0; // g . (sn - s) along the projected path
 #pragma unroll
-            for (int i = 0; i < 3; ++i) sn[i] = fma(t, d[i], s[i]);
+            for (int i = 0; i < 3; ++i) {
+                sn[i] = fma(t, d[i], s[i]);
+                if (KIND == 2) sn[i] = fmax(sn[i], 0.0);
+                gs = fma(g[i], sn[i] - s[i], gs);
+            }
             if (m.feasible(sn)) {
                 fn = m.value(sn);
-                if (fn <= f + 1e-4 * t * gd + 1e-15 * fabs(f)) { ok = true; break; }
+                if (fn <= f + 1e-4 * gs + 1e-15 * fabs(f)) { ok = true; break; }
             }
             t *= 0.5;
         }

@@ -76,6 +76,7 @@ class RuntimeData:
         self.inner_iters = 0
         self.step_ms = 0.0
         self.last_solve_converged = 0
+        self.rhs_ms = 0.0
 
 
 class Floor:
@@ -278,6 +279,7 @@ class Solver:
             r = self._runtime = RuntimeData()
             r.global_ms, r.local_ms, r.collision_ms = st.global_ms, st.local_ms, st.collision_ms
             r.inner_iters, r.step_ms, r.last_solve_converged = st.inner_iters, st.step_ms, st.last_solve_converged
+            r.rhs_ms = st.rhs_ms
         else:
             check(lib().admm_hip_step(self._ctx, it, s.gravity, None))
 

@@ -1,0 +1,188 @@
+"""bench.py -- ADMM iterations/sec of the MI355X-native hot path (Solver::step) on synthetic tet meshes.
+
+A "step" = one Solver::step() (one frame) = `admm_iters` ADMM iterations {local step, RHS gather,
+global solve} on a device-resident state (no host<->device traffic inside the timed region).
+
+  python bench.py --gpus 1 --steps K --warmup W [--workload cube1m_mix|cube1m_nh|cube100k_gs]
+
+Workloads (BASELINE.json `configs`):
+  cube1m_mix   configs[2]: n=55 Kuhn cube (998 250 tets), StVK / Neo-Hookean by z-slab, soft rubber,
+               x=0 face pinned, g=-9.8, dt=1/24, 20 ADMM iters/step, global solve = GPU PCG (the
+               "UzawaCG" config has no active constraints, so its solve IS the prefactored solve)
+  cube1m_nh    same mesh, all Neo-Hookean (the north-star's target mesh)
+  cube100k_gs  configs[1]: n=26 (105 456 tets), Neo-Hookean, multi-colour GS global step
+
+Prints ONE JSON line (rank 0).  value = ADMM iterations/sec over the whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    "cube1m_mix": dict(n=55, kinds="mix", linsolver=0, admm_iters=20),
+    "cube1m_nh": dict(n=55, kinds="nh", linsolver=0, admm_iters=20),
+    "cube100k_gs": dict(n=26, kinds="nh", linsolver=1, admm_iters=20),
+}
+
+
+def build_scene(w, n_override=None):
+    import admm_elastic_amd as pkg
+    from admm_elastic_amd import meshes
+    from admm_elastic_amd.solver import Lame
+    import scenes
+    n = n_override or w["n"]
+    verts, tets = meshes.kuhn_cube(n)
+    sc = scenes.Scene()
+    sc.x = verts
+    sc.m = meshes.lumped_masses_tets(verts, tets)
+    lame = Lame.soft_rubber()
+    if w["kinds"] == "mix":
+        cz = verts[tets].mean(axis=1)[:, 2]
+        slab = (cz * 8).astype(int) % 2
+        sc.tets.append((verts, tets[slab == 0], lame, pkg.TET_NEOHOOKEAN, 0))
+        sc.tets.append((verts, tets[slab == 1], lame, pkg.TET_STVK, 0))
+    else:
+        sc.tets.append((verts, tets, lame, pkg.TET_NEOHOOKEAN, 0))
+    for i in np.nonzero(verts[:, 0] < 1e-9)[0]:
+        sc.pins[int(i)] = verts[i].copy()
+    sc.settings.update(admm_iters=w["admm_iters"], linsolver=w["linsolver"], gravity=-9.8, timestep_s=1.0 / 24.0)
+    return sc, len(tets), len(verts)
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """The oracle (CPU restatement, OpenMP local step + exact sparse solve / GS) timed on this box's
+    host cores on a bounded sample: the same scene shape at reduced size, a few ADMM iterations."""
+    from oracle import oracle as orc
+    import scenes  # noqa: F401
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    n_s = min(w["n"], 20)  # 48 000 tets: the sample
+    sc, nt, nv = build_scene(w, n_override=n_s)
+    sc.settings["admm_iters"] = 5
+    colors = None
+    if w["linsolver"] == 1:
+        import admm_elastic_amd as pkg
+        from admm_elastic_amd import capi
+        s = sc.make_solver(init=False)
+        rp, ci, _ = s.host_matrix(sc.product_settings)
+        colors, _ = capi.greedy_coloring(rp, ci)
+    o = sc.make_oracle(mode=0, gs_colors=colors, big=True)
+    o.step()  # warm-up
+    t0 = time.perf_counter(); iters = 0
+    while time.perf_counter() - t0 < budget_s and iters < 40:
+        o.step(); iters += o.admm_iters
+    dt = time.perf_counter() - t0
+    its = iters / dt
+    return dict(value=its * nt / 1e6, unit="M tet-ADMM-iterations/s", admm_iters_per_s_at_sample=its, cores=threads,
+                kind="port", sample="%d-tet Kuhn cube (n=%d), same materials/solver family, %d ADMM iterations in %.1f s; "
+                "oracle = OpenMP local step (L-BFGS, reference stop rule) + %s" %
+                (nt, n_s, iters, dt, "30 multi-colour SOR sweeps" if w["linsolver"] == 1 else "SuperLU direct solve (prefactored)"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cube1m_mix", choices=list(WORKLOADS))
+    ap.add_argument("--n", type=int, default=0, help="override cells per edge (testing only)")
+    ap.add_argument("--pcg-tol", type=float, default=1e-8)
+    ap.add_argument("--pcg-max-iters", type=int, default=120)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import admm_elastic_amd as pkg
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    pkg.build_library()
+    w = WORKLOADS[args.workload]
+    sc, nt, nv = build_scene(w, args.n or None)
+    iters = w["admm_iters"]
+    s = sc.make_solver(device=local_rank, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters)
+    if world > 1:
+        s.comm_init(dist, rank, world)
+    s.upload()
+
+    def sync():
+        torch.cuda.synchronize(local_rank)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(local_rank)
+
+    for _ in range(args.warmup):
+        s.step_device(stats=True)
+    sync()
+    # Timed region.  Every step also records HIP events (on the context's own stream) around its
+    # prox kernels; reading them back costs one stream sync per frame, which is inside the timing.
+    local_ms = rhs_ms = global_ms = 0.0
+    inner = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s.step_device(stats=True)
+        rd = s.runtime_data()
+        local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms; inner += rd.inner_iters
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    value = iters * args.steps / elapsed
+
+    rd = s.runtime_data()
+    s.download()
+    finite = bool(np.isfinite(s.m_x).all())
+
+    out = {
+        "metric": "ADMM iterations/sec", "value": value, "unit": "ADMM it/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload + (" (n=%d override)" % args.n if args.n else ""), "tets": nt, "verts": nv,
+                   "admm_iters_per_step": iters, "global_solver": "multicolor-GS(30 sweeps)" if w["linsolver"] == 1 else
+                   "Jacobi-PCG tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters),
+                   "parallelism": "element-block x%d" % world if world > 1 else "single-gpu"},
+        "ms_per_frame": ms_per_step,
+        "split_ms_per_admm_iter": {"local": local_ms / (iters * args.steps), "rhs": rhs_ms / (iters * args.steps),
+                                   "global": global_ms / (iters * args.steps)},
+        "inner_iters_per_admm_iter": inner / (iters * args.steps), "last_solve_converged": rd.last_solve_converged,
+        "finite": finite,
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            # dominant single kernel = the per-tet prox kernel (local step).  ALGORITHMIC bytes per tet per
+            # ADMM iteration: 16 idx + 72 Binv + 72 u read + 72 u write + 72 z write + 24 nv/nt.
+            launches = iters * args.steps
+            bytes_per_launch = (304.0 + 24.0 * nv / nt) * nt
+            avg_s = 1e-3 * local_ms / launches
+            achieved = bytes_per_launch / avg_s / 1e9
+            out["roofline"] = {"kernel": "k_local_tets (all constitutive models of one ADMM iteration)", "bound": "hbm",
+                               "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                               "traffic": None, "avg_launch_us": 1e6 * avg_s, "algorithmic_bytes_per_launch": bytes_per_launch}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -110,13 +110,14 @@ typedef struct {
 /* Maps 1:1 onto Solver::RuntimeData (src/Solver.hpp:54-61) plus GPU-side extras. */
 typedef struct {
     double global_ms;
-    double local_ms;
+    double local_ms;              /* the per-element prox kernels only (HIP events on the context's stream) */
     double collision_ms;
     int32_t inner_iters;
     int32_t admm_iters;
     double step_ms;               /* whole step, HIP events */
     int32_t last_solve_converged; /* PCG: residual test met within pcg_max_iters in the last ADMM iteration */
     int32_t n_constraints;        /* rows of C in the last ADMM iteration (UzawaCG) */
+    double rhs_ms;                /* part of global_ms spent assembling b = M x_bar + dt^2 D^T W^2 (z-u) */
 } admm_hip_stats;
 
 const char *admm_hip_last_error(void);

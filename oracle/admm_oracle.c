@@ -320,15 +320,25 @@ static int lbfgs3(const prox_problem *p, double *x, int max_iters) {
     return it;
 }
 
-/* damped Newton polish to the exact minimiser ("tight" oracle mode) */
+/* Damped (projected) Newton polish to the exact minimiser ("tight" oracle mode).
+ * StVK's feasible set is x >= 0 (value() is FLT_MAX only for x < 0); for inverted elements the
+ * minimiser lies on that boundary, so components at the bound with an outward-pointing gradient are
+ * frozen and trial points are projected back onto x >= 0. */
 static int newton3(const prox_problem *p, double *x, int max_iters) {
     int it = 0;
+    const int proj = (p->kind == 2);
     for (; it < max_iters; ++it) {
         double g[3], H[9];
         double f = prox_gradient(p, x, g);
         prox_hessian(p, x, H);
+        double gr[3] = {g[0], g[1], g[2]};
+        for (int i = 0; i < 3; ++i)
+            if (proj && x[i] <= 0.0 && g[i] > 0.0) { /* active bound: remove from the Newton system */
+                for (int j = 0; j < 3; ++j) { M3(H, i, j) = 0.0; M3(H, j, i) = 0.0; }
+                M3(H, i, i) = 1.0; gr[i] = 0.0;
+            }
         /* solve H d = -g by Cramer; shift the diagonal until H is positive definite */
-        double d[3] = {-g[0], -g[1], -g[2]};
+        double d[3] = {-gr[0], -gr[1], -gr[2]};
         double shift = 0.0, tr = fabs(M3(H,0,0)) + fabs(M3(H,1,1)) + fabs(M3(H,2,2));
         for (int tries = 0; tries < 60; ++tries) {
             double Hs[9];
@@ -340,19 +350,24 @@ static int newton3(const prox_problem *p, double *x, int max_iters) {
                 double Hc[9];
                 for (int c = 0; c < 3; ++c) {
                     memcpy(Hc, Hs, sizeof(Hc));
-                    for (int r = 0; r < 3; ++r) M3(Hc, r, c) = -g[r];
+                    for (int r = 0; r < 3; ++r) M3(Hc, r, c) = -gr[r];
                     d[c] = det3(Hc) / D;
                 }
                 break;
             }
             shift = (shift == 0.0) ? 1e-3 * tr + 1e-300 : 10.0 * shift;
         }
-        double gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
         double t = 1.0, xn[3];
         int ok = 0;
         for (int ls = 0; ls < 60; ++ls) {
-            for (int c = 0; c < 3; ++c) xn[c] = x[c] + t * d[c];
-            if (feasible(p, xn) && prox_value(p, xn) <= f + 1e-4 * t * gd + 1e-14 * fabs(f)) { ok = 1; break; }
+            double gs = 0.0;
+            for (int c = 0; c < 3; ++c) {
+                xn[c] = x[c] + t * d[c];
+                if (proj && xn[c] < 0.0) xn[c] = 0.0;
+                gs += g[c] * (xn[c] - x[c]);
+            }
+            int feas = proj ? 1 : feasible(p, xn);
+            if (feas && prox_value(p, xn) <= f + 1e-4 * gs + 1e-14 * fabs(f)) { ok = 1; break; }
             t *= 0.5;
         }
         if (!ok) break;
