@@ -119,10 +119,20 @@ struct admm_hip_ctx {
     DevBuf<int> csr_rowptr, csr_col;
     DevBuf<double> csr_val;
     // PCG work
-    int NB = 1;
+    int NB = 1, NBV = 1;
     DevBuf<double> cg_r, cg_u, cg_w, cg_p, cg_s, part, part_b;
     DevBuf<CgScal> cg_scal;
-    DevBuf<int> counters; // [0] total inner iterations of the step, [1] gs done flag, [2] gs sweeps
+    DevBuf<int> counters; // [0] total inner iterations of the step, [1] gs done flag, [2] gs sweeps,
+                          // [3] max PCG iterations of one solve, [4] PCG solves that converged
+    // PCG launch control.  Iterations are launched in chunks of kChunk, one chunk speculatively ahead
+    // of the GPU; the vec kernel signals convergence (sig[0] = solve sequence number) and progress
+    // (sig[1] = number of closed chunks) through pinned, device-mapped host memory, so the host stops
+    // launching as soon as a solve has converged -- without ever synchronising the stream.
+    int *h_sig = nullptr;         // pinned + mapped: [0] seq of the last converged solve, [1] closed chunks
+    int *d_sig = nullptr;         // device alias of h_sig
+    int solve_seq = 0;
+    int marks_expected = 0;       // chunks closed so far (host count)
+    int last_launched_iters = 0;
     // GS
     std::vector<int> color_h; int n_colors = 0;
     std::vector<int> color_ptr_h;
@@ -142,6 +152,7 @@ struct admm_hip_ctx {
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
+        if (h_sig) (void)hipHostFree(h_sig);
         if (ev_step0) (void)hipEventDestroy(ev_step0);
         if (ev_step1) (void)hipEventDestroy(ev_step1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -185,26 +196,48 @@ void launch_gather(admm_hip_ctx *c) {
         a.pin_u = c->pin_u.p; a.pin_z = c->pin_z.p; a.pin_sc = c->dt * c->dt * c->pin_weight * c->pin_weight;
     }
     a.x = c->curr.p; a.Mxbar = c->Mxbar.p; a.b = c->b.p; a.add_mxbar = (c->rank == 0) ? 1 : 0;
-    const int grid = std::max(1, std::min((a.n_slices + 3) / 4, 2048));
+    const int grid = std::max(1, (a.n_slices + 3) / 4);
     hipLaunchKernelGGL(k_gather_rhs, dim3(grid), dim3(256), 0, c->stream, a);
 }
 
-// PCG solve of A x = b, x = curr (warm start).  Blind launch of max_iters iterations with device-side
-// early exit (no host synchronisation inside a step).
-void launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
+// PCG solve of A x = b, x = curr (warm start).  See the launch-control comment in admm_hip_ctx.
+constexpr int kChunk = 32;
+
+int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
     hipStream_t st = c->stream;
     const SellA A = sell_arg(c->A);
     const int NB = c->NB;
     const double tol2 = c->pcg_tol * c->pcg_tol;
+    const int seq = ++c->solve_seq;
     hipLaunchKernelGGL(k_cg_resid, dim3(NB), dim3(256), 0, st, A, c->m.p, c->dinv.p, b, x, c->cg_r.p, c->cg_u.p, c->part_b.p, NB,
-                       c->cg_scal.p);
-    for (int it = 0; it < max_iters; ++it) {
-        const CgScal *prev = c->cg_scal.p + (it & 1);
-        CgScal *next = c->cg_scal.p + ((it + 1) & 1);
-        hipLaunchKernelGGL(k_cg_spmv, dim3(NB), dim3(256), 0, st, A, c->m.p, c->cg_u.p, c->cg_r.p, c->cg_w.p, c->part.p, NB, prev);
-        hipLaunchKernelGGL(k_cg_vec, dim3(NB), dim3(256), 0, st, it, c->n3, NB, c->part.p, c->part_b.p, prev, next, tol2,
-                           c->counters.p, c->dinv.p, c->cg_p.p, c->cg_s.p, x, c->cg_r.p, c->cg_u.p, c->cg_w.p);
+                       c->cg_scal.p, seq);
+    volatile int *sig = c->h_sig;
+    int launched = 0, chunks = 0;
+    while (launched < max_iters) {
+        const int n = std::min(kChunk, max_iters - launched);
+        for (int it = launched; it < launched + n; ++it) {
+            const CgScal *prev = c->cg_scal.p + (it & 1);
+            CgScal *next = c->cg_scal.p + ((it + 1) & 1);
+            hipLaunchKernelGGL(k_cg_spmv, dim3(NB), dim3(256), 0, st, A, c->m.p, c->cg_u.p, c->cg_r.p, c->cg_w.p, c->part.p, NB, prev);
+            hipLaunchKernelGGL(k_cg_vec, dim3(c->NBV), dim3(256), 0, st, it, c->n3, NB, c->part.p, c->part_b.p, prev, next, tol2,
+                               c->counters.p, c->dinv.p, c->cg_p.p, c->cg_s.p, x, c->cg_r.p, c->cg_u.p, c->cg_w.p, c->d_sig,
+                               (it == launched + n - 1) ? 1 : 0);
+        }
+        launched += n;
+        ++chunks;
+        ++c->marks_expected;
+        if (chunks >= 2 && launched < max_iters) {
+            // wait until the chunk BEFORE the one just launched has drained, then look at the flag
+            const int need = c->marks_expected - 1;
+            long spins = 0;
+            while (sig[1] < need) {
+                if (++spins > 2000000000L) return -1; // the GPU stopped making progress
+            }
+            if (sig[0] == seq) break;
+        }
     }
+    c->last_launched_iters = launched;
+    return 0;
 }
 
 void launch_gs(admm_hip_ctx *c, const double *b, double *x) {
@@ -302,6 +335,9 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev_step0));
     HIP_TRY(hipEventCreate(&c->ev_step1));
+    HIP_TRY(hipHostMalloc((void **)&c->h_sig, 4 * sizeof(int), hipHostMallocMapped));
+    c->h_sig[0] = c->h_sig[1] = c->h_sig[2] = c->h_sig[3] = 0;
+    HIP_TRY(hipHostGetDevicePointer((void **)&c->d_sig, c->h_sig, 0));
 
     const double dt2 = c->dt * c->dt;
     const int nv = c->nv;
@@ -425,13 +461,14 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->Mxbar.alloc(c->n3)); HIP_TRY(c->Mxbar.zero());
     HIP_TRY(c->curr.alloc(c->n3)); HIP_TRY(c->curr.zero());
     HIP_TRY(c->b.alloc(c->n3)); HIP_TRY(c->b.zero());
-    c->NB = std::max(1, std::min((c->A.n_slices + 3) / 4, 512));
+    c->NB = std::max(1, (c->A.n_slices + 3) / 4);              // SpMV-type kernels: one SELL slice per wave
+    c->NBV = std::max(1, std::min((c->n3 + 255) / 256, 512));   // streaming vector kernels
     HIP_TRY(c->cg_r.alloc(c->n3)); HIP_TRY(c->cg_u.alloc(c->n3)); HIP_TRY(c->cg_w.alloc(c->n3));
     HIP_TRY(c->cg_p.alloc(c->n3)); HIP_TRY(c->cg_s.alloc(c->n3));
     HIP_TRY(c->cg_p.zero()); HIP_TRY(c->cg_s.zero());
     HIP_TRY(c->part.alloc(6 * (size_t)c->NB)); HIP_TRY(c->part_b.alloc(3 * (size_t)c->NB));
     HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
-    HIP_TRY(c->counters.alloc(4)); HIP_TRY(c->counters.zero());
+    HIP_TRY(c->counters.alloc(8)); HIP_TRY(c->counters.zero());
 
     if (d->linsolver == 1) {
         c->color_h.resize(nv);
@@ -524,9 +561,9 @@ int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const dou
     return ADMM_HIP_OK;
 }
 
-static void launch_global(admm_hip_ctx *c, const double *b, double *x) {
-    if (c->linsolver == 1) launch_gs(c, b, x);
-    else launch_pcg(c, b, x, c->pcg_max_iters);
+static int launch_global(admm_hip_ctx *c, const double *b, double *x) {
+    if (c->linsolver == 1) { launch_gs(c, b, x); return 0; }
+    return launch_pcg(c, b, x, c->pcg_max_iters);
 }
 
 int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_stats *stats) {
@@ -544,7 +581,8 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
         }
     }
     HIP_TRY(hipEventRecord(c->ev_step0, st));
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(int), st));
+    // counters[5] (closed chunks) must stay monotone across steps: only [0..4] are reset
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
     hipLaunchKernelGGL(k_predict, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, c->dt, gravity, c->x.p, c->v.p, c->m.p,
                        c->Mxbar.p, c->curr.p);
     // curr_u = 0 (Solver.cpp:71); curr_z = D x is a dead store in the reference (:70)
@@ -558,7 +596,8 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
         // passive collisions are resolved inside the GS sweeps (linsolver 1, Solver.cpp:76)
         launch_gather(c);                       // Solver.cpp:98
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 2], st));
-        launch_global(c, c->b.p, c->curr.p);    // Solver.cpp:99
+        if (launch_global(c, c->b.p, c->curr.p))   // Solver.cpp:99
+            return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     }
     if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * admm_iters], st));
     hipLaunchKernelGGL(k_finish, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, 1.0 / c->dt, c->x.p, c->v.p, c->curr.p);
@@ -576,15 +615,17 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 2])); stats->rhs_ms += ms;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 3])); stats->global_ms += ms;
         }
-        int h[4];
-        HIP_TRY(hipMemcpy(h, c->counters.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+        int h[8];
+        HIP_TRY(hipMemcpy(h, c->counters.p, 8 * sizeof(int), hipMemcpyDeviceToHost));
         CgScal sc[2];
         HIP_TRY(hipMemcpy(sc, c->cg_scal.p, sizeof(sc), hipMemcpyDeviceToHost));
         stats->admm_iters = admm_iters;
         if (c->linsolver == 1) { stats->inner_iters = h[0]; stats->last_solve_converged = h[1]; }
         else {
             stats->inner_iters = h[0];
-            stats->last_solve_converged = sc[c->pcg_max_iters & 1].converged;
+            stats->last_solve_converged = sc[c->last_launched_iters & 1].converged;
+            stats->unconverged_solves = admm_iters - h[4];
+            stats->pcg_launched_iters = c->last_launched_iters;
         }
     }
     return ADMM_HIP_OK;
@@ -656,11 +697,11 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->b.p, b, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->curr.p, x_inout, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 4 * sizeof(int), st));
-    launch_global(c, c->b.p, c->curr.p);
+    HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
+    if (launch_global(c, c->b.p, c->curr.p)) return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(x_inout, c->curr.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, st));
-    int h[4];
+    int h[8];
     HIP_TRY(hipMemcpyAsync(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (iters) *iters = (c->linsolver == 1) ? h[2] : h[0];

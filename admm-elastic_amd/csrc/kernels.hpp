@@ -35,6 +35,8 @@ struct CgScal {
     double gamma_b[3];
     int converged;
     int iters;
+    int seq;      // sequence number of the solve these scalars belong to
+    int pad_;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -56,6 +58,11 @@ __device__ __forceinline__ void block_sum(double *q, double *lds /* [4*NQ] */) {
 #pragma unroll
     for (int i = 0; i < NQ; ++i) q[i] = lds[i] + lds[NQ + i] + lds[2 * NQ + i] + lds[3 * NQ + i];
     __syncthreads();
+}
+
+// wave-uniform slice index of this wave (one wave = one SELL slice)
+__device__ __forceinline__ int wave_slice() {
+    return __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -206,33 +213,44 @@ struct GatherArgs {
     int add_mxbar;             // 1 on a single GPU / on rank 0
 };
 
+// sum of the corner forces incident to this lane's vertex (widths are multiples of 4; padding points
+// at the all-zero dummy element ld-1)
+__device__ __forceinline__ void gather_corners(const int *__restrict__ inc, int w, const double *__restrict__ cf, int ld, double *acc) {
+    int e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = inc[64 * i];
+    for (int k = 4; k < w; k += 4) {
+        int en[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) en[i] = inc[64 * (k + i)];
+        double g[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double *p = cf + (size_t)(3 * (e[i] & 3)) * ld + (e[i] >> 2);
+            g[3 * i] = p[0]; g[3 * i + 1] = p[ld]; g[3 * i + 2] = p[2 * (size_t)ld];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[0] += g[3 * i]; acc[1] += g[3 * i + 1]; acc[2] += g[3 * i + 2]; e[i] = en[i]; }
+    }
+    double g[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double *p = cf + (size_t)(3 * (e[i] & 3)) * ld + (e[i] >> 2);
+        g[3 * i] = p[0]; g[3 * i + 1] = p[ld]; g[3 * i + 2] = p[2 * (size_t)ld];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[0] += g[3 * i]; acc[1] += g[3 * i + 1]; acc[2] += g[3 * i + 2]; }
+}
+
 __global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
-    for (int s = wave; s < a.n_slices; s += nwaves) {
+    const int s = wave_slice();
+    if (s >= a.n_slices) return;
+    {
         const int v = s * 64 + lane;
         double acc[3] = {0.0, 0.0, 0.0};
-        if (a.t_inc) {
-            const int w = a.t_w[s];
-            const int *inc = a.t_inc + a.t_ptr[s] + lane;
-            for (int k = 0; k < w; ++k) {
-                const int e = inc[64 * k];
-                const int t = e >> 2, c = e & 3;
-                const double *p = a.t_cf + (size_t)(3 * c) * a.t_ld + t;
-                acc[0] += p[0]; acc[1] += p[a.t_ld]; acc[2] += p[2 * (size_t)a.t_ld];
-            }
-        }
-        if (a.r_inc) {
-            const int w = a.r_w[s];
-            const int *inc = a.r_inc + a.r_ptr[s] + lane;
-            for (int k = 0; k < w; ++k) {
-                const int e = inc[64 * k];
-                const int t = e >> 2, c = e & 3;
-                const double *p = a.r_cf + (size_t)(3 * c) * a.r_ld + t;
-                acc[0] += p[0]; acc[1] += p[a.r_ld]; acc[2] += p[2 * (size_t)a.r_ld];
-            }
-        }
+        if (a.t_inc) gather_corners(a.t_inc + a.t_ptr[s] + lane, a.t_w[s], a.t_cf, a.t_ld, acc);
+        if (a.r_inc) gather_corners(a.r_inc + a.r_ptr[s] + lane, a.r_w[s], a.r_cf, a.r_ld, acc);
         if (v < a.nv) {
             if (a.vert_pin) {
                 const int pi = a.vert_pin[v];
@@ -267,16 +285,36 @@ __global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
 // Replaces the prefactored LDLT solve of src/LinearSolver.hpp:87-90.
 struct SellA { int n_rows, n_slices; const int *ptr, *w, *col; const double *val; };
 
-// y_row = m_row * in_row + sum_k Ahat(row,k) in_col   for the 3 axes of one row
+// acc = sum_k Ahat(row,k) in_col for the 3 axes of one row of slice s (slice widths are multiples of 4).
+// Software-pipelined: the column/value loads of round k+1 are in flight while round k gathers, so a
+// wave keeps 4 index loads + 12 gathers outstanding instead of one dependent chain per non-zero.
 __device__ __forceinline__ void sell_row(const SellA &A, int s, int lane, const double *__restrict__ in, double *acc) {
     const int w = A.w[s];
-    const int base = A.ptr[s] + lane;
+    const int *__restrict__ cp = A.col + A.ptr[s] + lane;
+    const double *__restrict__ vp = A.val + A.ptr[s] + lane;
     acc[0] = acc[1] = acc[2] = 0.0;
-    for (int k = 0; k < w; ++k) {
-        const int c = A.col[base + 64 * k];
-        const double a = A.val[base + 64 * k];
-        const double *p = in + 3 * (size_t)c;
-        acc[0] = fma(a, p[0], acc[0]); acc[1] = fma(a, p[1], acc[1]); acc[2] = fma(a, p[2], acc[2]);
+    int c[4]; double a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c[i] = cp[64 * i]; a[i] = vp[64 * i]; }
+    for (int k = 4; k < w; k += 4) {
+        int cn[4]; double an[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { cn[i] = cp[64 * (k + i)]; an[i] = vp[64 * (k + i)]; }
+        double g[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const double *p = in + 3 * (size_t)c[i]; g[3 * i] = p[0]; g[3 * i + 1] = p[1]; g[3 * i + 2] = p[2]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = fma(a[i], g[3 * i], acc[0]); acc[1] = fma(a[i], g[3 * i + 1], acc[1]); acc[2] = fma(a[i], g[3 * i + 2], acc[2]);
+            c[i] = cn[i]; a[i] = an[i];
+        }
+    }
+    double g[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const double *p = in + 3 * (size_t)c[i]; g[3 * i] = p[0]; g[3 * i + 1] = p[1]; g[3 * i + 2] = p[2]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        acc[0] = fma(a[i], g[3 * i], acc[0]); acc[1] = fma(a[i], g[3 * i + 1], acc[1]); acc[2] = fma(a[i], g[3 * i + 2], acc[2]);
     }
 }
 
@@ -284,13 +322,13 @@ __device__ __forceinline__ void sell_row(const SellA &A, int s, int lane, const 
 __global__ __launch_bounds__(256) void k_cg_resid(SellA A, const double *__restrict__ m, const double *__restrict__ dinv,
                                                   const double *__restrict__ b, const double *__restrict__ x,
                                                   double *__restrict__ r, double *__restrict__ u,
-                                                  double *__restrict__ part_b, int NB, CgScal *__restrict__ sc0) {
+                                                  double *__restrict__ part_b, int NB, CgScal *__restrict__ sc0, int seq) {
     __shared__ double lds[12];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { sc0->converged = 0; sc0->iters = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc0->converged = 0; sc0->iters = 0; sc0->seq = seq; }
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int s = wave_slice();
     double q[3] = {0.0, 0.0, 0.0};
-    for (int s = wave; s < A.n_slices; s += nwaves) {
+    if (s < A.n_slices) {
         const int row = s * 64 + lane;
         double acc[3];
         sell_row(A, s, lane, x, acc);
@@ -316,9 +354,9 @@ __global__ __launch_bounds__(256) void k_cg_spmv(SellA A, const double *__restri
     __shared__ double lds[24];
     if (sc->converged) return;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int s = wave_slice();
     double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int s = wave; s < A.n_slices; s += nwaves) {
+    if (s < A.n_slices) {
         const int row = s * 64 + lane;
         double acc[3];
         sell_row(A, s, lane, u, acc);
@@ -347,9 +385,15 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int n3, int NB, const do
                                                 CgScal *__restrict__ next, double tol2, int *__restrict__ total_iters,
                                                 const double *__restrict__ dinv, double *__restrict__ p,
                                                 double *__restrict__ s, double *__restrict__ x, double *__restrict__ r,
-                                                double *__restrict__ u, const double *__restrict__ w) {
+                                                double *__restrict__ u, const double *__restrict__ w,
+                                                int *__restrict__ sig, int mark_here) {
     __shared__ double lds[36];
     const CgScal pv = *prev;
+    // progress mark for the host (pinned memory): the chunk this kernel closes has (almost) drained
+    if (mark_here && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int m = atomicAdd(total_iters + 5, 1) + 1;
+        __hip_atomic_store(sig + 1, m, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (it > 0 && pv.converged) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *next = pv;
         return;
@@ -379,6 +423,9 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int n3, int NB, const do
             for (int a = 0; a < 3; ++a) { o.gamma[a] = q[a]; o.gamma_b[a] = gb[a]; o.alpha[a] = 0.0; }
             o.converged = 1;
             *next = o;
+            atomicAdd(total_iters + 4, 1);        // solves that met the residual test
+            atomicMax(total_iters + 3, o.iters);  // most iterations any solve of this step needed
+            __hip_atomic_store(sig, pv.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // tell the host
         }
         return;
     }
@@ -398,6 +445,7 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int n3, int NB, const do
         for (int a = 0; a < 3; ++a) { o.gamma[a] = q[a]; o.alpha[a] = alpha[a]; o.gamma_b[a] = gb[a]; }
         o.converged = 0;
         o.iters = (it == 0 ? 0 : pv.iters) + 1;
+        o.seq = pv.seq; o.pad_ = 0;
         *next = o;
         atomicAdd(total_iters, 1);
     }
@@ -501,9 +549,9 @@ __global__ __launch_bounds__(256) void k_gs_resid(SellA A, const double *__restr
     __shared__ double lds[8];
     if (*done) return;
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const int s = wave_slice();
     double q[2] = {0.0, 0.0};
-    for (int s = wave; s < A.n_slices; s += nwaves) {
+    if (s < A.n_slices) {
         const int row = s * 64 + lane;
         double acc[3];
         sell_row(A, s, lane, x, acc);

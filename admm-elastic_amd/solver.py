@@ -77,6 +77,8 @@ class RuntimeData:
         self.step_ms = 0.0
         self.last_solve_converged = 0
         self.rhs_ms = 0.0
+        self.unconverged_solves = 0
+        self.pcg_launched_iters = 0
 
 
 class Floor:
@@ -279,7 +281,7 @@ class Solver:
             r = self._runtime = RuntimeData()
             r.global_ms, r.local_ms, r.collision_ms = st.global_ms, st.local_ms, st.collision_ms
             r.inner_iters, r.step_ms, r.last_solve_converged = st.inner_iters, st.step_ms, st.last_solve_converged
-            r.rhs_ms = st.rhs_ms
+            r.rhs_ms, r.unconverged_solves, r.pcg_launched_iters = st.rhs_ms, st.unconverged_solves, st.pcg_launched_iters
         else:
             check(lib().admm_hip_step(self._ctx, it, s.gravity, None))
 

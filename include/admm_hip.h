@@ -92,7 +92,8 @@ typedef struct {
     int32_t linsolver;            /* ADMM_LS_* */
     double constraint_w;          /* Settings::constraint_w; <=0 -> auto (src/Solver.cpp:235,239,245) */
 
-    int32_t pcg_max_iters;        /* <=0 -> 500 */
+    int32_t pcg_max_iters;        /* <=0 -> 500.  Iterations are launched in chunks, one chunk ahead of the GPU,
+                                   * and stop as soon as the device signals convergence (no stream sync). */
     double pcg_tol;               /* relative residual of the (Jacobi-scaled) system; <=0 -> 1e-10 */
     int32_t gs_max_iters;         /* <=0 -> 30   (NodalMultiColorGS::max_iters, NodalMultiColorGS.hpp:45-46) */
     double gs_tol;                /* <0 -> 1e-10 (m_tol); 0 disables the residual test like the reference */
@@ -118,6 +119,8 @@ typedef struct {
     int32_t last_solve_converged; /* PCG: residual test met within pcg_max_iters in the last ADMM iteration */
     int32_t n_constraints;        /* rows of C in the last ADMM iteration (UzawaCG) */
     double rhs_ms;                /* part of global_ms spent assembling b = M x_bar + dt^2 D^T W^2 (z-u) */
+    int32_t unconverged_solves;   /* PCG solves of this step that did not meet pcg_tol (0 = every solve converged) */
+    int32_t pcg_launched_iters;   /* PCG iterations launched for the last solve (converged ones exit early on the device) */
 } admm_hip_stats;
 
 const char *admm_hip_last_error(void);
