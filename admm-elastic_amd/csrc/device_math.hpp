@@ -30,15 +30,32 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
     c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
+// ---- fast FP64 reciprocal / rsqrt: hardware seed + two Newton steps (no IEEE div/sqrt sequences) ----
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0); r = fma(r, e, r);
+    e = fma(-x, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    double e = fma(-h * y, y, 0.5); y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5); y = fma(y, e, y);
+    return y;
+}
+
 // One Jacobi rotation annihilating a_pq of a symmetric 3x3; r is the third index.
-// vp, vq: the two affected eigenvector columns.
+// vp, vq: the two affected eigenvector columns.  t = sgn(a) b / (|a| + sqrt(a^2 + b^2)), a = aqq-app, b = 2 apq.
 __device__ __forceinline__ bool jacobi_rotate(double &app, double &aqq, double &apq, double &arp, double &arq,
                                               double *vp, double *vq) {
     const double scale = fabs(app) + fabs(aqq);
     if (!(fabs(apq) > 1e-17 * scale)) { return false; }
-    const double theta = (aqq - app) / (2.0 * apq);
-    const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-    const double c = rsqrt(fma(t, t, 1.0));
+    const double a = aqq - app, b = 2.0 * apq;
+    const double h2 = fma(a, a, b * b);
+    const double h = h2 * fast_rsqrt(h2);
+    const double t = copysign(1.0, a) * b * fast_rcp(fabs(a) + h);
+    const double c = fast_rsqrt(fma(t, t, 1.0));
     const double s = t * c;
     app = fma(-t, apq, app);
     aqq = fma(t, apq, aqq);
@@ -48,20 +65,84 @@ __device__ __forceinline__ bool jacobi_rotate(double &app, double &aqq, double &
     arq = s * rp + c * rq;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double a = vp[i], b = vq[i];
-        vp[i] = c * a - s * b;
-        vq[i] = s * a + c * b;
+        const double x = vp[i], y = vq[i];
+        vp[i] = c * x - s * y;
+        vq[i] = s * x + c * y;
     }
     return true;
 }
 
+// FP32 version used only to SEED the eigenvectors (quarter-rate hardware rcp/sqrt/rsq, 2-cycle VALU)
+__device__ __forceinline__ void jacobi_rotate_f32(float &app, float &aqq, float &apq, float &arp, float &arq,
+                                                  float *vp, float *vq) {
+    const float a = aqq - app, b = 2.0f * apq;
+    const float h2 = fmaf(a, a, b * b);
+    if (!(h2 > 1e-30f) || !(fabsf(b) > 1e-9f * (fabsf(app) + fabsf(aqq)))) return;
+    const float h = __builtin_amdgcn_sqrtf(h2);
+    const float t = copysignf(1.0f, a) * b * __builtin_amdgcn_rcpf(fabsf(a) + h);
+    const float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
+    const float s = t * c;
+    app = fmaf(-t, apq, app);
+    aqq = fmaf(t, apq, aqq);
+    apq = 0.0f;
+    const float rp = arp, rq = arq;
+    arp = c * rp - s * rq;
+    arq = s * rp + c * rq;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float x = vp[i], y = vq[i];
+        vp[i] = c * x - s * y;
+        vq[i] = s * x + c * y;
+    }
+}
+
 // Signed SVD  F = U diag(S) V^T,  U,V in SO(3),  S[0] >= S[1] >= |S[2]|, sign(S[2]) = sign(det F).
 // F, U, V column-major.
+// Mixed precision, full FP64 accuracy: (1) 4 cyclic Jacobi sweeps on F^T F in FP32 give V to ~1e-7;
+// (2) V is re-orthonormalised in FP64 and C' = V^T C V formed in FP64 (off-diagonals ~1e-7 |C|);
+// (3) FP64 Jacobi sweeps finish the job -- Jacobi converges quadratically, so one sweep (rarely two)
+// reaches round-off; the loop still runs to convergence, so the result does not depend on step (1).
 __device__ __forceinline__ void signed_svd3(const double *F, double *U, double *S, double *V) {
     // C = F^T F
     double c00 = dot3(F + 0, F + 0), c01 = dot3(F + 0, F + 3), c02 = dot3(F + 0, F + 6);
     double c11 = dot3(F + 3, F + 3), c12 = dot3(F + 3, F + 6), c22 = dot3(F + 6, F + 6);
     double v0[3] = {1, 0, 0}, v1[3] = {0, 1, 0}, v2[3] = {0, 0, 1};
+    const double tr = c00 + c11 + c22;
+    if (tr > 1e-280) {
+        // (1) FP32 seed on the trace-normalised matrix
+        const double itr = fast_rcp(tr);
+        float a00 = (float)(c00 * itr), a01 = (float)(c01 * itr), a02 = (float)(c02 * itr);
+        float a11 = (float)(c11 * itr), a12 = (float)(c12 * itr), a22 = (float)(c22 * itr);
+        float w0[3] = {1.f, 0.f, 0.f}, w1[3] = {0.f, 1.f, 0.f}, w2[3] = {0.f, 0.f, 1.f};
+#pragma unroll 1
+        for (int sweep = 0; sweep < 4; ++sweep) {
+            jacobi_rotate_f32(a00, a11, a01, a02, a12, w0, w1);
+            jacobi_rotate_f32(a00, a22, a02, a01, a12, w0, w2);
+            jacobi_rotate_f32(a11, a22, a12, a01, a02, w1, w2);
+        }
+        // (2) orthonormalise in FP64 (Gram-Schmidt; v2 = v0 x v1) and rotate C into that basis
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v0[i] = (double)w0[i]; v1[i] = (double)w1[i]; }
+        double n = fast_rsqrt(dot3(v0, v0));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v0[i] *= n;
+        const double pr01 = dot3(v0, v1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v1[i] = fma(-pr01, v0[i], v1[i]);
+        n = fast_rsqrt(dot3(v1, v1));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) v1[i] *= n;
+        cross3(v0, v1, v2);
+        // W = C V (columns), then C' = V^T W (symmetric)
+        double x0[3], x1[3], x2[3];
+        x0[0] = fma(c00, v0[0], fma(c01, v0[1], c02 * v0[2])); x0[1] = fma(c01, v0[0], fma(c11, v0[1], c12 * v0[2])); x0[2] = fma(c02, v0[0], fma(c12, v0[1], c22 * v0[2]));
+        x1[0] = fma(c00, v1[0], fma(c01, v1[1], c02 * v1[2])); x1[1] = fma(c01, v1[0], fma(c11, v1[1], c12 * v1[2])); x1[2] = fma(c02, v1[0], fma(c12, v1[1], c22 * v1[2]));
+        x2[0] = fma(c00, v2[0], fma(c01, v2[1], c02 * v2[2])); x2[1] = fma(c01, v2[0], fma(c11, v2[1], c12 * v2[2])); x2[2] = fma(c02, v2[0], fma(c12, v2[1], c22 * v2[2]));
+        c00 = dot3(v0, x0); c01 = dot3(v0, x1); c02 = dot3(v0, x2);
+        c11 = dot3(v1, x1); c12 = dot3(v1, x2); c22 = dot3(v2, x2);
+    }
+    // (3) FP64 sweeps to convergence
+#pragma unroll 1
     for (int sweep = 0; sweep < 12; ++sweep) {
         bool any = false;
         any |= jacobi_rotate(c00, c11, c01, c02, c12, v0, v1);
@@ -93,9 +174,10 @@ __device__ __forceinline__ void signed_svd3(const double *F, double *U, double *
     }
     // U by Gram-Schmidt on b0, b1; u2 = u0 x u1
     double u0[3], u1[3], u2[3];
-    const double s0 = sqrt(n0);
-    if (s0 > 1e-300) {
-        const double inv = 1.0 / s0;
+    double s0 = 0.0;
+    if (n0 > 1e-300) {
+        const double inv = fast_rsqrt(n0);
+        s0 = n0 * inv;
 #pragma unroll
         for (int i = 0; i < 3; ++i) u0[i] = b0[i] * inv;
     } else { u0[0] = 1.0; u0[1] = 0.0; u0[2] = 0.0; }
@@ -111,7 +193,7 @@ __device__ __forceinline__ void signed_svd3(const double *F, double *U, double *
         wn = dot3(w, w);
     }
     {
-        const double inv = rsqrt(wn);
+        const double inv = fast_rsqrt(wn);
 #pragma unroll
         for (int i = 0; i < 3; ++i) u1[i] = w[i] * inv;
     }
@@ -139,171 +221,192 @@ __device__ __forceinline__ void usvt(const double *U, const double *s, const dou
 // KIND 1: Neo-Hookean  Psi = mu/2 (I1 - ln I3 - 3) + lambda/8 ln^2 I3     (TetEnergyTerm.cpp:173-182)
 // KIND 2: StVK         Psi = mu |E|^2 + lambda/2 tr(E)^2, E_i=(s_i^2-1)/2  (TetEnergyTerm.cpp:220-226)
 // objective = Psi(s) + k/2 |s - x0|^2                                      (:184-192, :210-218)
-template <int KIND>
+// The model is templated on the scalar type: the same Newton runs first in FP32 (cheap iterations that
+// get within ~1e-6 of the minimiser) and then in FP64 (one or two polishing iterations).  Newton is
+// self-correcting, so the FP64 result does not depend on the FP32 phase beyond its starting point.
+__device__ __forceinline__ float t_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double t_rcp(double x) { return fast_rcp(x); }
+__device__ __forceinline__ float t_log(float x) { return __logf(x); }
+__device__ __forceinline__ double t_log(double x) { return log(x); }
+__device__ __forceinline__ float t_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double t_fma(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ float t_abs(float a) { return fabsf(a); }
+__device__ __forceinline__ double t_abs(double a) { return fabs(a); }
+__device__ __forceinline__ float t_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double t_max(double a, double b) { return fmax(a, b); }
+
+template <int KIND, typename T>
 struct StretchModel {
-    double mu, la, k;
-    double x0[3];
+    T mu, la, k;
+    T x0[3];
 
     // value, gradient and the Hessian split H = diag(D) + la * w w^T
-    __device__ __forceinline__ double eval(const double *s, double *g, double *D, double *w) const {
+    __device__ __forceinline__ T eval(const T *s, T *g, T *D, T *w) const {
         if (KIND == 1) {
-            const double J = s[0] * s[1] * s[2];
-            const double lJ = log(J);
-            double f = 0.0, q = 0.0;
+            const T J = s[0] * s[1] * s[2];
+            const T lJ = t_log(J);
+            T f = T(0), q = T(0);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const double si = 1.0 / s[i];
-                const double d = s[i] - x0[i];
+                const T si = t_rcp(s[i]);
+                const T d = s[i] - x0[i];
                 w[i] = si;
-                g[i] = fma(mu, s[i] - si, fma(la * lJ, si, k * d));
-                D[i] = fma(mu, fma(si, si, 1.0), fma(-la * lJ, si * si, k));
-                f = fma(s[i], s[i], f);
-                q = fma(d, d, q);
+                g[i] = t_fma(mu, s[i] - si, t_fma(la * lJ, si, k * d));
+                D[i] = t_fma(mu, t_fma(si, si, T(1)), t_fma(-la * lJ, si * si, k));
+                f = t_fma(s[i], s[i], f);
+                q = t_fma(d, d, q);
             }
-            return 0.5 * mu * (f - 3.0) - mu * lJ + 0.5 * la * lJ * lJ + 0.5 * k * q;
+            return T(0.5) * mu * (f - T(3)) - mu * lJ + T(0.5) * la * lJ * lJ + T(0.5) * k * q;
         } else {
-            const double ss = s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
-            const double trE = 0.5 * (ss - 3.0);
-            double ee = 0.0, q = 0.0;
+            const T ss = s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+            const T trE = T(0.5) * (ss - T(3));
+            T ee = T(0), q = T(0);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const double E = 0.5 * (s[i] * s[i] - 1.0);
-                const double d = s[i] - x0[i];
+                const T E = T(0.5) * (s[i] * s[i] - T(1));
+                const T d = s[i] - x0[i];
                 w[i] = s[i];
-                g[i] = fma(mu * s[i], s[i] * s[i] - 1.0, fma(la * trE, s[i], k * d));
-                D[i] = fma(mu, 3.0 * s[i] * s[i] - 1.0, fma(la, trE, k));
-                ee = fma(E, E, ee);
-                q = fma(d, d, q);
+                g[i] = t_fma(mu * s[i], s[i] * s[i] - T(1), t_fma(la * trE, s[i], k * d));
+                D[i] = t_fma(mu, T(3) * s[i] * s[i] - T(1), t_fma(la, trE, k));
+                ee = t_fma(E, E, ee);
+                q = t_fma(d, d, q);
             }
-            return mu * ee + 0.5 * la * trE * trE + 0.5 * k * q;
-        }
-    }
-    __device__ __forceinline__ double value(const double *s) const {
-        if (KIND == 1) {
-            const double lJ = log(s[0] * s[1] * s[2]);
-            double f = 0.0, q = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { const double d = s[i] - x0[i]; f = fma(s[i], s[i], f); q = fma(d, d, q); }
-            return 0.5 * mu * (f - 3.0) - mu * lJ + 0.5 * la * lJ * lJ + 0.5 * k * q;
-        } else {
-            const double ss = s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
-            const double trE = 0.5 * (ss - 3.0);
-            double ee = 0.0, q = 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const double E = 0.5 * (s[i] * s[i] - 1.0);
-                const double d = s[i] - x0[i];
-                ee = fma(E, E, ee);
-                q = fma(d, d, q);
-            }
-            return mu * ee + 0.5 * la * trE * trE + 0.5 * k * q;
+            return mu * ee + T(0.5) * la * trE * trE + T(0.5) * k * q;
         }
     }
     // NH needs s > 0 (log barrier); StVK accepts s >= 0 (value() returns FLT_MAX only for s < 0)
-    __device__ __forceinline__ bool feasible(const double *s) const {
-        if (KIND == 1) return s[0] > 0.0 && s[1] > 0.0 && s[2] > 0.0;
-        return s[0] >= 0.0 && s[1] >= 0.0 && s[2] >= 0.0;
+    __device__ __forceinline__ bool feasible(const T *s) const {
+        if (KIND == 1) return s[0] > T(0) && s[1] > T(0) && s[2] > T(0);
+        return s[0] >= T(0) && s[1] >= T(0) && s[2] >= T(0);
     }
 };
 
-// argmin_s Psi(s) + k/2 |s - x0|^2 by safeguarded Newton, started from s (in/out). Returns iterations.
-// NH: the log barrier keeps the iterates strictly positive.  StVK: the feasible set is s >= 0 (value()
-// is FLT_MAX only for s < 0) and for inverted elements the minimiser sits ON that boundary, so the
-// iteration is a projected Newton: components at the bound whose gradient points outward are frozen,
-// the rest take the reduced Newton step, and trial points are projected back onto s >= 0.
-template <int KIND>
-__device__ __forceinline__ int minimize_stretch(const StretchModel<KIND> &m, double *s) {
-    double g[3], D[3], w[3];
-    double f = m.eval(s, g, D, w);
+// Safeguarded Newton for argmin_s Psi(s) + k/2 |s - x0|^2, started from s (in/out); returns iterations.
+//  - Hessian = diag(D) + la w w^T  -> Sherman-Morrison solve, |D| floored to stay positive definite
+//  - NH: the log barrier keeps iterates strictly positive.  StVK: the feasible set is s >= 0 and for
+//    inverted elements the minimiser sits ON that boundary -> projected Newton (components at the bound
+//    with an outward gradient are frozen, trial points are projected back)
+//  - Armijo backtracking on the objective, evaluated once per trial point (value+gradient+Hessian)
+//  - a predicted step below tol_final is applied without re-evaluation and ends the iteration
+//    (quadratic convergence: the remaining error is ~ step^2)
+template <int KIND, typename T>
+__device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T *s, int max_it, T tol_final, T noise, int max_ls) {
+    T g[3], D[3], w[3];
+    T f = m.eval(s, g, D, w);
+    const T fscale = T(4) * (t_abs(m.mu) + t_abs(m.la) + t_abs(m.k));
     int it = 0;
-    for (; it < 60; ++it) {
-        // modified Hessian: keep the diagonal part safely positive
-        const double floorD = 1e-8 * (fabs(m.k) + fabs(m.mu)) + 1e-300;
-        double a[3], y[3];
-        double wDg = 0.0, wDw = 0.0;
+#pragma unroll 1
+    for (; it < max_it; ++it) {
+        const T floorD = T(1e-8) * (t_abs(m.k) + t_abs(m.mu)) + T(1e-30);
+        T a[3], y[3];
+        T wDg = T(0), wDw = T(0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const double Di = fmax(fabs(D[i]), floorD);
-            const bool active = (KIND == 2) && (s[i] <= 0.0) && (g[i] > 0.0);
-            a[i] = active ? 0.0 : 1.0 / Di;
+            const T Di = t_max(t_abs(D[i]), floorD);
+            const bool active = (KIND == 2) && (s[i] <= T(0)) && (g[i] > T(0));
+            a[i] = active ? T(0) : t_rcp(Di);
             y[i] = g[i] * a[i];
-            wDg = fma(w[i], y[i], wDg);
-            wDw = fma(w[i] * w[i], a[i], wDw);
+            wDg = t_fma(w[i], y[i], wDg);
+            wDw = t_fma(w[i] * w[i], a[i], wDw);
         }
-        const double den = fma(m.la, wDw, 1.0);
-        const double coef = (den > 1e-12) ? m.la * wDg / den : 0.0;
-        double d[3], gd = 0.0;
+        const T den = t_fma(m.la, wDw, T(1));
+        const T coef = (den > T(1e-6)) ? m.la * wDg * t_rcp(den) : T(0);
+        T d[3], gd = T(0), dmax = T(0), mag = T(1);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             d[i] = -(y[i] - coef * w[i] * a[i]);
-            gd = fma(g[i], d[i], gd);
+            gd = t_fma(g[i], d[i], gd);
         }
-        if (!(gd < 0.0)) { // not a descent direction (indefinite rank-one part): scaled steepest descent
-            gd = 0.0;
+        if (!(gd < T(0))) { // not a descent direction (indefinite rank-one part): scaled steepest descent
+            gd = T(0);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { d[i] = -y[i]; gd = fma(g[i], d[i], gd); }
-            if (!(gd < 0.0)) break; // zero (reduced) gradient
+            for (int i = 0; i < 3; ++i) { d[i] = -y[i]; gd = t_fma(g[i], d[i], gd); }
+            if (!(gd < T(0))) break; // zero (reduced) gradient
         }
-        double t = 1.0, sn[3], fn = f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { dmax = t_max(dmax, t_abs(d[i])); mag = t_max(mag, t_abs(s[i])); }
+        if (dmax <= tol_final * mag) { // final correction: apply and stop
+            T sn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (KIND == 2) sn[i] = t_max(sn[i], T(0)); }
+            if (m.feasible(sn)) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) s[i] = sn[i];
+            }
+            ++it;
+            break;
+        }
+        T t = T(1), sn[3], gn[3], Dn[3], wn[3], fn = f;
         bool ok = false;
-        for (int ls = 0; ls < 50; ++ls) {
-            double gs = 0.0; // g . (sn - s) along the projected path
+#pragma unroll 1
+        for (int ls = 0; ls < max_ls; ++ls) {
+            T gs = T(0); // g . (sn - s) along the projected path
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                sn[i] = fma(t, d[i], s[i]);
-                if (KIND == 2) sn[i] = fmax(sn[i], 0.0);
-                gs = fma(g[i], sn[i] - s[i], gs);
+                sn[i] = t_fma(t, d[i], s[i]);
+                if (KIND == 2) sn[i] = t_max(sn[i], T(0));
+                gs = t_fma(g[i], sn[i] - s[i], gs);
             }
             if (m.feasible(sn)) {
-                fn = m.value(sn);
-                if (fn <= f + 1e-4 * gs + 1e-15 * fabs(f)) { ok = true; break; }
+                fn = m.eval(sn, gn, Dn, wn);
+                // round-off in f is absolute (O(1) terms cancel to O(strain^2)): scale the allowance by the
+                // magnitude of the terms, not by |f|
+                if (fn <= f + T(1e-4) * gs + noise * (t_abs(f) + fscale)) { ok = true; break; }
             }
-            t *= 0.5;
+            t *= T(0.5);
         }
         if (!ok) break;
-        double step = 0.0, mag = 1.0;
+        f = fn;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            step = fmax(step, fabs(sn[i] - s[i]));
-            mag = fmax(mag, fabs(sn[i]));
-            s[i] = sn[i];
-        }
-        f = m.eval(s, g, D, w);
-        if (step <= 1e-10 * mag) { ++it; break; }
+        for (int i = 0; i < 3; ++i) { s[i] = sn[i]; g[i] = gn[i]; D[i] = Dn[i]; w[i] = wn[i]; }
     }
     return it;
 }
 
-// src/TetEnergyTerm.cpp:73-92.  q (col-major 3x3) -> z
-__device__ __forceinline__ void prox_tet_linear(const double *q, double *z) {
-    double U[9], S[3], V[9];
-    signed_svd3(q, U, S, V);
-    // P = U diag(1,1,sign det F) V^T with Eigen's unsigned factors == U V^T with the signed ones
+// mixed-precision driver: FP32 iterations, then FP64 polish.  Parameters are normalised by k so the
+// FP32 phase works with O(1) coefficients.
+template <int KIND>
+__device__ __forceinline__ int minimize_stretch(double mu, double la, double k, const double *x0, double *s) {
+    const double ik = fast_rcp(k);
+    StretchModel<KIND, float> mf;
+    mf.mu = (float)(mu * ik); mf.la = (float)(la * ik); mf.k = 1.0f;
+    float sf[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int i = 0; i < 3; ++i) { mf.x0[i] = (float)x0[i]; sf[i] = (float)s[i]; }
+    if (KIND == 1) { sf[0] = fmaxf(sf[0], 1e-12f); sf[1] = fmaxf(sf[1], 1e-12f); sf[2] = fmaxf(sf[2], 1e-12f); }
+    int it = newton_stretch<KIND, float>(mf, sf, 10, 3e-5f, 1e-6f, 12);
+    StretchModel<KIND, double> md;
+    md.mu = mu * ik; md.la = la * ik; md.k = 1.0;
+    bool fin = true;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double p = fma(U[r], V[c], fma(U[3 + r], V[3 + c], U[6 + r] * V[6 + c]));
-            ADMM_M3(z, r, c) = 0.5 * (p + ADMM_M3(q, r, c));
-        }
+    for (int i = 0; i < 3; ++i) { md.x0[i] = x0[i]; fin = fin && (sf[i] == sf[i]) && (fabsf(sf[i]) < 1e30f); }
+    if (fin && mf.feasible(sf)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s[i] = (double)sf[i];
+    }
+    it += newton_stretch<KIND, double>(md, s, 60, 1e-9, 4e-16, 50);
+    return it;
 }
 
-// src/TetEnergyTerm.cpp:114-136
+// Prox in principal stretches.  S (in) = signed stretches of q = D_i x + u_i; S (out) = stretches of z.
+// KIND 0, linear tet (src/TetEnergyTerm.cpp:73-92): z = (P + q)/2 with P = U V^T (signed factors)
+//         == U diag((1 + S)/2) V^T.
+// KIND 1/2, hyperelastic (src/TetEnergyTerm.cpp:114-136): minimise over the stretches.
 template <int KIND>
-__device__ __forceinline__ void prox_tet_hyper(double mu, double la, double k, const double *q, double *z) {
-    double U[9], S[3], V[9];
-    signed_svd3(q, U, S, V);
-    StretchModel<KIND> m;
-    m.mu = mu; m.la = la; m.k = k;
-    m.x0[0] = S[0]; m.x0[1] = S[1]; m.x0[2] = S[2];       // :124 (before the fix-ups)
+__device__ __forceinline__ void prox_stretches(double mu, double la, double k, double *S) {
+    if (KIND == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) S[i] = 0.5 * (1.0 + S[i]);
+        return;
+    }
+    double x0[3] = {S[0], S[1], S[2]};                      // :124 set_x0 (before the fix-ups)
     const double eps = 1e-6;
     if (fabs(S[0]) < eps && fabs(S[1]) < eps && fabs(S[2]) < eps) { S[0] = eps; S[1] = eps; S[2] = eps; } // :128-131
     if (S[2] < 0.0) S[2] = -S[2];                           // :133
     if (KIND == 1) { // keep the start strictly inside the log barrier
         S[0] = fmax(S[0], 1e-12); S[1] = fmax(S[1], 1e-12); S[2] = fmax(S[2], 1e-12);
     }
-    minimize_stretch<KIND>(m, S);
-    usvt(U, S, V, z);
+    minimize_stretch<(KIND == 0 ? 1 : KIND)>(mu, la, k, x0, S);
 }
 
 // src/TriEnergyTerm.cpp:73-101.  q = 3x2 column-major (6 doubles) -> z
@@ -312,9 +415,10 @@ __device__ __forceinline__ void prox_tri(const double *q, double lmin, double lm
     double c00 = dot3(q, q), c01 = dot3(q, q + 3), c11 = dot3(q + 3, q + 3);
     double cs = 1.0, sn = 0.0;
     if (fabs(c01) > 1e-17 * (c00 + c11)) {
-        const double theta = (c11 - c00) / (2.0 * c01);
-        const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
-        cs = rsqrt(fma(t, t, 1.0));
+        const double a = c11 - c00, b = 2.0 * c01;
+        const double h2 = fma(a, a, b * b);
+        const double t = copysign(1.0, a) * b * fast_rcp(fabs(a) + h2 * fast_rsqrt(h2));
+        cs = fast_rsqrt(fma(t, t, 1.0));
         sn = t * cs;
     }
     // v0 = (cs, -sn), v1 = (sn, cs);  b_j = F v_j
@@ -335,7 +439,7 @@ __device__ __forceinline__ void prox_tri(const double *q, double lmin, double lm
         double t = n0; n0 = n1; n1 = t;
     }
     if (n0 > 1e-300) {
-        const double inv = rsqrt(n0);
+        const double inv = fast_rsqrt(n0);
 #pragma unroll
         for (int r = 0; r < 3; ++r) u0[r] = b0[r] * inv;
     } else { u0[0] = 1.0; u0[1] = 0.0; u0[2] = 0.0; }
@@ -350,7 +454,7 @@ __device__ __forceinline__ void prox_tri(const double *q, double lmin, double lm
         wn = dot3(w, w);
     }
     {
-        const double inv = rsqrt(wn);
+        const double inv = fast_rsqrt(wn);
 #pragma unroll
         for (int r = 0; r < 3; ++r) u1[r] = w[r] * inv;
     }

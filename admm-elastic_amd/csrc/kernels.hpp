@@ -103,51 +103,70 @@ __global__ __launch_bounds__(256) void k_local_tets(int t0, int t1, int ld, cons
     const int t = t0 + blockIdx.x * 256 + threadIdx.x;
     if (t >= t1) return;
     const int4 id = idx[t];
-    double Bi[9], ui[9];
+    double U[9], V[9], S0[3], S1[3];
+    {
+        double q[9];
+        {
+            double Bi[9], ui[9];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) { Bi[c] = Binv[(size_t)c * ld + t]; ui[c] = u[(size_t)c * ld + t]; }
-    const double *p0 = x + 3 * (size_t)id.x, *p1 = x + 3 * (size_t)id.y, *p2 = x + 3 * (size_t)id.z, *p3 = x + 3 * (size_t)id.w;
-    double Ds[9];
+            for (int c = 0; c < 9; ++c) { Bi[c] = Binv[(size_t)c * ld + t]; ui[c] = u[(size_t)c * ld + t]; }
+            const double *p0 = x + 3 * (size_t)id.x, *p1 = x + 3 * (size_t)id.y, *p2 = x + 3 * (size_t)id.z, *p3 = x + 3 * (size_t)id.w;
+            double Ds[9];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const double a = p0[j];
-        Ds[0 + j] = p1[j] - a; Ds[3 + j] = p2[j] - a; Ds[6 + j] = p3[j] - a;
-    }
-    double F[9], q[9], zi[9];
+            for (int j = 0; j < 3; ++j) {
+                const double a = p0[j];
+                Ds[0 + j] = p1[j] - a; Ds[3 + j] = p2[j] - a; Ds[6 + j] = p3[j] - a;
+            }
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const double f = fma(Ds[j], Bi[r * 3 + 0], fma(Ds[3 + j], Bi[r * 3 + 1], Ds[6 + j] * Bi[r * 3 + 2]));
-            F[r * 3 + j] = f;
-            q[r * 3 + j] = f + ui[r * 3 + j];
+                for (int j = 0; j < 3; ++j)   // EnergyTerm.hpp:133-135  zi = D_i x + u_i
+                    q[r * 3 + j] = fma(Ds[j], Bi[r * 3 + 0], fma(Ds[3 + j], Bi[r * 3 + 1], fma(Ds[6 + j], Bi[r * 3 + 2], ui[r * 3 + j])));
         }
+        signed_svd3(q, U, S0, V);   // q = U diag(S0) V^T to round-off: q itself is not needed any more
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) S1[i] = S0[i];
     if (KIND == 0) {
-        prox_tet_linear(q, zi);
+        prox_stretches<0>(0.0, 0.0, 0.0, S1);
     } else {
         const Mat mt = mats[mat_id[t]];
-        if (KIND == 1) prox_tet_hyper<1>(mt.mu, mt.la, mt.k, q, zi);
-        else prox_tet_hyper<2>(mt.mu, mt.la, mt.k, q, zi);
+        prox_stretches<KIND>(mt.mu, mt.la, mt.k, S1);
     }
+    // z = U diag(S1) V^T ; u_new = u + D_i x - z = q - z = U diag(S0 - S1) V^T   (EnergyTerm.hpp:137)
+    // G = dt^2 w^2 (z - u_new) = s U diag(2 S1 - S0) V^T
     const double s = sc[t];
     double G[9];
+    {
+        double du[3], dg[3];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) {
-        const double un = ui[c] + (F[c] - zi[c]);         // EnergyTerm.hpp:137
-        u[(size_t)c * ld + t] = un;
-        if (WRITE_Z) z[(size_t)c * ld + t] = zi[c];
-        G[c] = s * (zi[c] - un);
+        for (int i = 0; i < 3; ++i) { du[i] = S0[i] - S1[i]; dg[i] = s * (2.0 * S1[i] - S0[i]); }
+        double un[9];
+        usvt(U, du, V, un);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) u[(size_t)c * ld + t] = un[c];
+        if (WRITE_Z) {
+            double zi[9];
+            usvt(U, S1, V, zi);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) z[(size_t)c * ld + t] = zi[c];
+        }
+        usvt(U, dg, V, G);
     }
-    // corner forces: H(j,m) = sum_r G(j,r) Binv(m,r); corner m+1 gets H(:,m), corner 0 gets -sum_m H(:,m)
+    // corner forces: H(j,m) = sum_r G(j,r) Binv(m,r); corner m+1 gets H(:,m), corner 0 gets -sum_m H(:,m).
+    // Binv is re-read here (L2-resident: the block read it microseconds ago) instead of being held in
+    // 18 VGPRs across the whole prox.
     double f0[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 3; ++m) {
+        const double b0 = Binv[(size_t)(0 + m) * ld + t], b1 = Binv[(size_t)(3 + m) * ld + t], b2 = Binv[(size_t)(6 + m) * ld + t];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double h = fma(G[j], Bi[m], fma(G[3 + j], Bi[3 + m], G[6 + j] * Bi[6 + m]));
+            const double h = fma(G[j], b0, fma(G[3 + j], b1, G[6 + j] * b2));
             cf[(size_t)(3 * (m + 1) + j) * ld + t] = h;
             f0[j] -= h;
         }
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) cf[(size_t)j * ld + t] = f0[j];
 }

@@ -30,6 +30,8 @@ WORKLOADS = {
     "cube1m_mix": dict(n=55, kinds="mix", linsolver=0, admm_iters=20),
     "cube1m_nh": dict(n=55, kinds="nh", linsolver=0, admm_iters=20),
     "cube100k_gs": dict(n=26, kinds="nh", linsolver=1, admm_iters=20),
+    "cube1m_linear": dict(n=55, kinds="linear", linsolver=0, admm_iters=20),   # diagnostic: cheapest prox
+    "cube1m_stvk": dict(n=55, kinds="stvk", linsolver=0, admm_iters=20),
 }
 
 
@@ -50,7 +52,8 @@ def build_scene(w, n_override=None):
         sc.tets.append((verts, tets[slab == 0], lame, pkg.TET_NEOHOOKEAN, 0))
         sc.tets.append((verts, tets[slab == 1], lame, pkg.TET_STVK, 0))
     else:
-        sc.tets.append((verts, tets, lame, pkg.TET_NEOHOOKEAN, 0))
+        kind = {"nh": pkg.TET_NEOHOOKEAN, "linear": pkg.TET_LINEAR, "stvk": pkg.TET_STVK}[w["kinds"]]
+        sc.tets.append((verts, tets, lame, kind, 0))
     for i in np.nonzero(verts[:, 0] < 1e-9)[0]:
         sc.pins[int(i)] = verts[i].copy()
     sc.settings.update(admm_iters=w["admm_iters"], linsolver=w["linsolver"], gravity=-9.8, timestep_s=1.0 / 24.0)
