@@ -39,6 +39,7 @@ class Desc(C.Structure):
         ("uzawa_max_iters", C.c_int32), ("uzawa_tol", C.c_double),
         ("n_obstacles", C.c_int32), ("obstacle_kind", c_int_p), ("obstacle_params", c_double_p),
         ("gs_colors", c_int_p),
+        ("rank", C.c_int32), ("world_size", C.c_int32),
     ]
 
 

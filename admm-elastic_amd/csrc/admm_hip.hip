@@ -2,6 +2,8 @@
 // ADMM elastic hot path.  gfx950 only.  Reference call stack being replaced: Solver::initialize
 // (src/Solver.cpp:167-261) -> admm_hip_create, Solver::step (src/Solver.cpp:35-110) -> admm_hip_step.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -69,6 +71,31 @@ struct SellDev {
     void release() { ptr.release(); w.release(); idx.release(); val.release(); }
 };
 
+// RCCL is bound lazily (dlopen) so single-GPU use never loads it.
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load() {
+        if (h) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return false;
+        GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        return GetUniqueId && CommInitRank && CommDestroy && AllReduce && GetErrorString;
+    }
+};
+RcclApi g_rccl;
+
 } // namespace
 
 struct admm_hip_ctx {
@@ -86,6 +113,11 @@ struct admm_hip_ctx {
     int uz_max_iters = 20; double uz_tol = 1e-10;
     bool state_set = false;
     int rank = 0, world = 1;
+
+    // multi-GPU (element-block partition, replicated global solve, RCCL all-reduce of the partial RHS)
+    ncclComm_t comm = nullptr;
+    int nt_total = 0, ntri_total = 0; // element counts of the whole scene (row layout of z/u)
+    int tri_begin = 0;                // first triangle owned by this rank
 
     // node vectors
     DevBuf<double> x, v, m, Mxbar, curr, b, dinv;
@@ -141,6 +173,7 @@ struct admm_hip_ctx {
 
     ~admm_hip_ctx() {
         (void)hipSetDevice(device);
+        if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
         x.release(); v.release(); m.release(); Mxbar.release(); curr.release(); b.release(); dinv.release();
         t_idx.release(); t_Binv.release(); t_u.release(); t_z.release(); t_sc.release(); t_cf.release();
         t_mat.release(); mats.release(); t_inc.release();
@@ -198,6 +231,18 @@ void launch_gather(admm_hip_ctx *c) {
     a.x = c->curr.p; a.Mxbar = c->Mxbar.p; a.b = c->b.p; a.add_mxbar = (c->rank == 0) ? 1 : 0;
     const int grid = std::max(1, (a.n_slices + 3) / 4);
     hipLaunchKernelGGL(k_gather_rhs, dim3(grid), dim3(256), 0, c->stream, a);
+}
+
+// b = M x_bar + dt^2 D^T W^2 (z - u): per-rank gather over the owned elements, then (multi-GPU) one
+// in-place RCCL sum all-reduce over xGMI; rank 0 contributed M x_bar and the pin terms.
+int launch_rhs(admm_hip_ctx *c) {
+    launch_gather(c);
+    if (c->world > 1) {
+        if (!c->comm) return -2;
+        ncclResult_t r = g_rccl.AllReduce(c->b.p, c->b.p, (size_t)c->n3, ncclDouble, ncclSum, c->comm, c->stream);
+        if (r != ncclSuccess) return -3;
+    }
+    return 0;
 }
 
 // PCG solve of A x = b, x = curr (warm start).  See the launch-control comment in admm_hip_ctx.
@@ -276,6 +321,7 @@ int validate(const admm_hip_desc *d) {
     if (d->n_obstacles < 0 || d->n_obstacles > kMaxObst) return fail(ADMM_HIP_ERR_ARG, "too many obstacles (max 8)");
     if (d->n_obstacles && d->linsolver == 0)
         return fail(ADMM_HIP_ERR_ARG, "No collisions with LDLT solver (Solver.cpp:249-254)");
+    if (d->world_size > 1 && (d->rank < 0 || d->rank >= d->world_size)) return fail(ADMM_HIP_ERR_ARG, "rank out of range");
     for (int i = 0; i < 3 * d->n_verts; ++i)
         if (!(d->masses[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "non-positive mass");
     for (int64_t i = 0; i < (int64_t)4 * d->n_tets; ++i)
@@ -342,16 +388,25 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     const double dt2 = c->dt * c->dt;
     const int nv = c->nv;
 
+    // ---- element-block partition (multi-GPU): contiguous blocks of the caller's element order ----
+    c->world = d->world_size > 1 ? d->world_size : 1;
+    c->rank = d->world_size > 1 ? d->rank : 0;
+    int32_t tb = 0, te = d->n_tets, rb = 0, re = d->n_tris;
+    if (c->world > 1) {
+        admm_host::partition(d->n_tets, c->world, c->rank, &tb, &te);
+        admm_host::partition(d->n_tris, c->world, c->rank, &rb, &re);
+    }
+    c->nt_total = d->n_tets; c->ntri_total = d->n_tris; c->tri_begin = rb;
     // ---- tets: sort by constitutive model (wave-uniform code paths), build the material table ----
-    c->nt = d->n_tets; c->ldt = d->n_tets + 1;
+    c->nt = te - tb; c->ldt = c->nt + 1;
     if (c->nt > 0) {
         const int nt = c->nt, ld = c->ldt;
         auto grp = [&](int k) { return k == ADMM_TET_LINEAR ? 0 : (k == ADMM_TET_STVK ? 2 : 1); };
         c->tet_perm.resize(nt);
-        std::iota(c->tet_perm.begin(), c->tet_perm.end(), 0);
+        std::iota(c->tet_perm.begin(), c->tet_perm.end(), tb);
         std::stable_sort(c->tet_perm.begin(), c->tet_perm.end(), [&](int a, int b) { return grp(d->tet_kind[a]) < grp(d->tet_kind[b]); });
         int cnt[3] = {0, 0, 0};
-        for (int t = 0; t < nt; ++t) cnt[grp(d->tet_kind[t])]++;
+        for (int t = tb; t < te; ++t) cnt[grp(d->tet_kind[t])]++;
         c->kind_begin[0] = 0; c->kind_begin[1] = cnt[0]; c->kind_begin[2] = cnt[0] + cnt[1]; c->kind_begin[3] = nt;
         std::map<std::tuple<double, double, double>, int> mat_map;
         std::vector<Mat> mats;
@@ -379,23 +434,24 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->t_inc.upload(admm_host::incidence_sell(nv, nt, 4, pidx.data(), nt * 4)));
     }
     // ---- tris ----
-    c->ntri = d->n_tris; c->ldr = d->n_tris + 1;
+    c->ntri = re - rb; c->ldr = c->ntri + 1;
     if (c->ntri > 0) {
         const int n = c->ntri, ld = c->ldr;
         std::vector<int4> idx(n);
         std::vector<double> rest((size_t)4 * ld, 0.0), sc(ld, 0.0), lmin(ld, -100.0), lmax(ld, 100.0);
         for (int t = 0; t < n; ++t) {
-            idx[t] = make_int4(d->tri_idx[3 * t], d->tri_idx[3 * t + 1], d->tri_idx[3 * t + 2], 0);
-            for (int k = 0; k < 4; ++k) rest[(size_t)k * ld + t] = d->tri_rest[4 * (size_t)t + k];
-            sc[t] = dt2 * d->tri_weight[t] * d->tri_weight[t];
-            lmin[t] = d->tri_limit_min[t]; lmax[t] = d->tri_limit_max[t];
+            const int o = rb + t;
+            idx[t] = make_int4(d->tri_idx[3 * o], d->tri_idx[3 * o + 1], d->tri_idx[3 * o + 2], 0);
+            for (int k = 0; k < 4; ++k) rest[(size_t)k * ld + t] = d->tri_rest[4 * (size_t)o + k];
+            sc[t] = dt2 * d->tri_weight[o] * d->tri_weight[o];
+            lmin[t] = d->tri_limit_min[o]; lmax[t] = d->tri_limit_max[o];
         }
         HIP_TRY(c->r_idx.upload(idx)); HIP_TRY(c->r_rest.upload(rest)); HIP_TRY(c->r_sc.upload(sc));
         HIP_TRY(c->r_lmin.upload(lmin)); HIP_TRY(c->r_lmax.upload(lmax));
         HIP_TRY(c->r_u.alloc((size_t)6 * ld)); HIP_TRY(c->r_u.zero());
         HIP_TRY(c->r_z.alloc((size_t)6 * ld)); HIP_TRY(c->r_z.zero());
         HIP_TRY(c->r_cf.alloc((size_t)9 * ld)); HIP_TRY(c->r_cf.zero());
-        HIP_TRY(c->r_inc.upload(admm_host::incidence_sell(nv, n, 3, d->tri_idx, n * 4)));
+        HIP_TRY(c->r_inc.upload(admm_host::incidence_sell(nv, n, 3, d->tri_idx + 3 * (size_t)rb, n * 4)));
     }
     // ---- pins ----
     double max_w = 0.0;
@@ -503,7 +559,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
 
 void admm_hip_destroy(admm_hip_ctx *ctx) { delete ctx; }
 
-int admm_hip_num_rows(const admm_hip_ctx *c) { return c ? 9 * c->nt + 6 * c->ntri + 6 * c->npin_terms : 0; }
+int admm_hip_num_rows(const admm_hip_ctx *c) { return c ? 9 * c->nt_total + 6 * c->ntri_total + 6 * c->npin_terms : 0; }
 
 int admm_hip_set_state(admm_hip_ctx *c, const double *x, const double *v) {
     if (!c || !x) return fail(ADMM_HIP_ERR_ARG, "set_state: NULL argument");
@@ -594,7 +650,8 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
         launch_local<false>(c);                 // Solver.cpp:84-87
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 1], st));
         // passive collisions are resolved inside the GS sweeps (linsolver 1, Solver.cpp:76)
-        launch_gather(c);                       // Solver.cpp:98
+        if (int rr = launch_rhs(c))             // Solver.cpp:98
+            return fail(rr == -2 ? ADMM_HIP_ERR_STATE : ADMM_HIP_ERR_COMM, rr == -2 ? "step: world_size > 1 but admm_hip_comm_init was not called" : "ncclAllReduce failed");
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 2], st));
         if (launch_global(c, c->b.p, c->curr.p))   // Solver.cpp:99
             return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
@@ -636,20 +693,20 @@ static void rows_to_dev(const admm_hip_ctx *c, const double *rows, std::vector<d
     tu.assign((size_t)9 * c->ldt, 0.0); ru.assign((size_t)6 * c->ldr, 0.0); pu.assign(3 * (size_t)c->npin_terms, 0.0);
     for (int n = 0; n < c->nt; ++n)
         for (int k = 0; k < 9; ++k) tu[(size_t)k * c->ldt + n] = rows[9 * (size_t)c->tet_perm[n] + k];
-    const double *r = rows + 9 * (size_t)c->nt;
+    const double *r = rows + 9 * (size_t)c->nt_total;
     for (int t = 0; t < c->ntri; ++t)
-        for (int k = 0; k < 6; ++k) ru[(size_t)k * c->ldr + t] = r[6 * (size_t)t + k];
-    r += 6 * (size_t)c->ntri;
+        for (int k = 0; k < 6; ++k) ru[(size_t)k * c->ldr + t] = r[6 * (size_t)(c->tri_begin + t) + k];
+    r += 6 * (size_t)c->ntri_total;
     for (int p = 0; p < c->npin_terms; ++p)
         for (int k = 0; k < 3; ++k) pu[3 * (size_t)p + k] = r[6 * (size_t)p + k];
 }
 static void dev_to_rows(const admm_hip_ctx *c, const std::vector<double> &tu, const std::vector<double> &ru, const std::vector<double> &pu, double *rows) {
     for (int n = 0; n < c->nt; ++n)
         for (int k = 0; k < 9; ++k) rows[9 * (size_t)c->tet_perm[n] + k] = tu[(size_t)k * c->ldt + n];
-    double *r = rows + 9 * (size_t)c->nt;
+    double *r = rows + 9 * (size_t)c->nt_total;
     for (int t = 0; t < c->ntri; ++t)
-        for (int k = 0; k < 6; ++k) r[6 * (size_t)t + k] = ru[(size_t)k * c->ldr + t];
-    r += 6 * (size_t)c->ntri;
+        for (int k = 0; k < 6; ++k) r[6 * (size_t)(c->tri_begin + t) + k] = ru[(size_t)k * c->ldr + t];
+    r += 6 * (size_t)c->ntri_total;
     for (int p = 0; p < c->npin_terms; ++p) {
         for (int k = 0; k < 3; ++k) r[6 * (size_t)p + k] = pu[3 * (size_t)p + k];
         for (int k = 3; k < 6; ++k) r[6 * (size_t)p + k] = 0.0; // rows 3..5 of a SpringPin are never populated
@@ -669,7 +726,9 @@ int admm_hip_local_step(admm_hip_ctx *c, const double *x, double *u_inout, doubl
     if (Mxbar) HIP_TRY(hipMemcpyAsync(c->Mxbar.p, Mxbar, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
     else HIP_TRY(hipMemsetAsync(c->Mxbar.p, 0, c->n3 * sizeof(double), st));
     launch_local<true>(c);
-    launch_gather(c);
+    // multi-GPU contexts without a communicator return their PARTIAL right-hand side (parity tests sum them)
+    if (c->world > 1 && !c->comm) launch_gather(c);
+    else if (launch_rhs(c)) return fail(ADMM_HIP_ERR_COMM, "local_step: ncclAllReduce failed");
     HIP_TRY(hipGetLastError());
     std::vector<double> tz((size_t)9 * c->ldt), rz((size_t)6 * c->ldr), pz(3 * (size_t)c->npin_terms);
     if (c->nt) {
@@ -726,12 +785,28 @@ int admm_hip_get_colors(const admm_hip_ctx *c, int32_t *color, int32_t *n_colors
 }
 
 int admm_hip_comm_unique_id(char *id128) {
-    (void)id128;
-    return fail(ADMM_HIP_ERR_COMM, "multi-GPU path not built yet");
+    if (!id128) return fail(ADMM_HIP_ERR_ARG, "comm_unique_id: NULL buffer");
+    if (!g_rccl.load()) return fail(ADMM_HIP_ERR_COMM, "cannot load librccl");
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(ADMM_HIP_ERR_COMM, std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return ADMM_HIP_OK;
 }
-int admm_hip_comm_init(admm_hip_ctx *ctx, const char *id128, int rank, int world_size) {
-    (void)ctx; (void)id128; (void)rank; (void)world_size;
-    return fail(ADMM_HIP_ERR_COMM, "multi-GPU path not built yet");
+
+int admm_hip_comm_init(admm_hip_ctx *c, const char *id128, int rank, int world_size) {
+    if (!c || !id128) return fail(ADMM_HIP_ERR_ARG, "comm_init: NULL argument");
+    if (rank != c->rank || world_size != c->world)
+        return fail(ADMM_HIP_ERR_ARG, "comm_init: rank/world_size differ from the ones the context was created with");
+    if (c->world <= 1) return ADMM_HIP_OK;
+    if (!g_rccl.load()) return fail(ADMM_HIP_ERR_COMM, "cannot load librccl");
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world_size, id, rank);
+    if (r != ncclSuccess) return fail(ADMM_HIP_ERR_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    return ADMM_HIP_OK;
 }
 
 // ---- host-only entry points ----

@@ -60,6 +60,8 @@ class Settings:
         self.uzawa_max_iters = 0
         self.uzawa_tol = 0.0
         self.device = 0
+        self.rank = 0
+        self.world_size = 1
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown setting " + k)
@@ -225,6 +227,7 @@ class Solver:
         d.n_obstacles = len(self._obstacles)
         d.obstacle_kind, d.obstacle_params = iptr(self._obst_kind), dptr(self._obst_par)
         d.gs_colors = iptr(self._gs_colors) if self._gs_colors is not None else None
+        d.rank, d.world_size = s.rank, s.world_size
         return d
 
     def host_matrix(self, settings=None):
@@ -284,6 +287,18 @@ class Solver:
             r.rhs_ms, r.unconverged_solves, r.pcg_launched_iters = st.rhs_ms, st.unconverged_solves, st.pcg_launched_iters
         else:
             check(lib().admm_hip_step(self._ctx, it, s.gravity, None))
+
+    def comm_init(self, dist):
+        """Multi-GPU: build the RCCL communicator of this rank's context.  `dist` is an initialised
+        torch.distributed (any backend) used only to broadcast the 128-byte RCCL unique id."""
+        self._need_ctx()
+        s = self._settings
+        buf = C.create_string_buffer(128)
+        if s.rank == 0:
+            check(lib().admm_hip_comm_unique_id(buf))
+        obj = [bytes(buf.raw)]
+        dist.broadcast_object_list(obj, src=0)
+        check(lib().admm_hip_comm_init(self._ctx, obj[0], s.rank, s.world_size))
 
     def runtime_data(self):
         return self._runtime

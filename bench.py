@@ -119,9 +119,9 @@ def main():
     w = WORKLOADS[args.workload]
     sc, nt, nv = build_scene(w, args.n or None)
     iters = w["admm_iters"]
-    s = sc.make_solver(device=local_rank, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters)
+    s = sc.make_solver(device=local_rank, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters, rank=rank, world_size=world)
     if world > 1:
-        s.comm_init(dist, rank, world)
+        s.comm_init(dist)
     s.upload()
 
     def sync():

@@ -106,6 +106,12 @@ typedef struct {
     const double *obstacle_params;/* [4*n_obstacles] */
 
     const int32_t *gs_colors;     /* optional [n_verts] colour per node; NULL -> greedy (admm_host_greedy_coloring) */
+
+    /* multi-GPU: this context is rank `rank` of `world_size` (0 or 1 = single GPU).  Every rank is
+     * given the FULL description; the library keeps the element block admm_host_partition assigns to
+     * the rank (tets and tris separately), assembles the full matrix, and replicates the global solve. */
+    int32_t rank;
+    int32_t world_size;
 } admm_hip_desc;
 
 /* Maps 1:1 onto Solver::RuntimeData (src/Solver.hpp:54-61) plus GPU-side extras. */
@@ -150,7 +156,9 @@ int admm_hip_step(admm_hip_ctx *ctx, int32_t admm_iters, double gravity, admm_hi
 /* Kernel-level entry points (parity tests).
  * local step = the OpenMP loop at src/Solver.cpp:84-87 over EnergyTerm::update
  * (src/EnergyTerm.hpp:130-140): given x and u (in/out) produce z, u in the reference row layout.
- * If Mxbar and b_out are non-NULL also returns b = Mxbar + dt^2 D^T W^2 (z-u) (src/Solver.cpp:98). */
+ * If Mxbar and b_out are non-NULL also returns b = Mxbar + dt^2 D^T W^2 (z-u) (src/Solver.cpp:98).
+ * Multi-GPU contexts fill only the rows of their own element block; before admm_hip_comm_init they
+ * return their partial b (rank 0 carries Mxbar and the pin terms), afterwards the all-reduced one. */
 int admm_hip_local_step(admm_hip_ctx *ctx, const double *x, double *u_inout, double *z_out,
                         const double *Mxbar, double *b_out);
 /* LinearSolver::solve (src/LinearSolver.hpp:46): x is in/out (warm start), returns inner iterations
