@@ -165,6 +165,10 @@ struct admm_hip_ctx {
     int solve_seq = 0;
     int marks_expected = 0;       // chunks closed so far (host count)
     int last_launched_iters = 0;
+    // UzawaCG (per-vertex constraint rows)
+    DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part;
+    DevBuf<UzScal> uz_scal;
+    int uz_prev_hits = -1, uz_last_hits = 0, NBU = 1, uz_iters_step = 0;
     // GS
     std::vector<int> color_h; int n_colors = 0;
     std::vector<int> color_ptr_h;
@@ -184,6 +188,8 @@ struct admm_hip_ctx {
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release();
+        uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
+        uz_q2.release(); uz_part.release(); uz_scal.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
         if (h_sig) (void)hipHostFree(h_sig);
         if (ev_step0) (void)hipEventDestroy(ev_step0);
@@ -282,6 +288,52 @@ int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
         }
     }
     c->last_launched_iters = launched;
+    return 0;
+}
+
+// UzawaCG::solve (src/UzawaCG.hpp:57-125).  Host-driven outer loop (one stream sync per Schur-CG
+// iteration, negligible next to the inner solves); returns the reference's iteration count via *iters.
+int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
+    hipStream_t st = c->stream;
+    const int nv = c->nv, gv = blocks_for(nv);
+    *iters = 1;
+    int nh = 0;
+    if (c->obst.n > 0) {
+        // Collider::detect at the current iterate + ConstraintSet::make_matrix (ck = sqrt(constraint_w))
+        if (hipMemsetAsync(c->counters.p + 6, 0, sizeof(int), st) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_uz_detect, dim3(gv), dim3(256), 0, st, nv, x, c->obst, std::sqrt(std::max(0.0, c->constraint_w)),
+                           c->uz_cn.p, c->uz_cc.p, c->counters.p + 6);
+        if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    }
+    c->uz_last_hits = nh;
+    if (nh != c->uz_prev_hits) { // multipliers are kept only while the number of rows is unchanged (UzawaCG.hpp:74)
+        if (hipMemsetAsync(c->uz_y.p, 0, nv * sizeof(double), st) != hipSuccess) return -1;
+        c->uz_prev_hits = nh;
+    }
+    if (nh == 0) return launch_pcg(c, b, x, c->pcg_max_iters); // no constraints: one prefactored solve (:78-81)
+    hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 0, b, c->uz_cn.p, c->uz_y.p, c->uz_q1.p);       // q1 = b - C^T y
+    if (launch_pcg(c, c->uz_q1.p, x, c->pcg_max_iters)) return -1;                                               // x = A^-1 q1
+    hipLaunchKernelGGL(k_uz_resid, dim3(gv), dim3(256), 0, st, nv, x, c->uz_cn.p, c->uz_cc.p, c->uz_r.p, c->uz_d.p);
+    if (hipMemsetAsync(c->uz_scal.p, 0, sizeof(UzScal), st) != hipSuccess) return -1;
+    const double tol2 = c->uz_tol * c->uz_tol;
+    UzScal h{};
+    for (int it = 0; it < c->uz_max_iters; ++it) {
+        hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 1, b, c->uz_cn.p, c->uz_d.p, c->uz_q1.p);   // q1 = C^T d
+        if (hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) return -1;
+        if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, c->pcg_max_iters)) return -1;                                  // q2 = A^-1 q1
+        hipLaunchKernelGGL(k_uz_dots, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_q2.p, c->uz_cn.p, c->uz_d.p, c->uz_r.p, c->uz_q3.p,
+                           c->uz_part.p, c->NBU);
+        hipLaunchKernelGGL(k_uz_alpha, dim3(1), dim3(256), 0, st, c->uz_part.p, c->NBU, c->uz_scal.p);
+        hipLaunchKernelGGL(k_uz_step, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_scal.p, x, c->uz_q2.p, c->uz_y.p, c->uz_d.p, c->uz_r.p,
+                           c->uz_q3.p, c->uz_part.p, c->NBU);
+        hipLaunchKernelGGL(k_uz_beta, dim3(1), dim3(256), 0, st, c->uz_part.p, c->NBU, tol2, c->uz_scal.p);
+        hipLaunchKernelGGL(k_uz_dir, dim3(gv), dim3(256), 0, st, nv, c->uz_scal.p, c->uz_r.p, c->uz_d.p);
+        if (hipMemcpyAsync(&h, c->uz_scal.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (h.stop) break;
+    }
+    *iters = h.iters;
     return 0;
 }
 
@@ -550,8 +602,14 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->color_nodes.upload(nodes));
         HIP_TRY(c->csr_rowptr.upload(c->Ahat.rowptr)); HIP_TRY(c->csr_col.upload(c->Ahat.col)); HIP_TRY(c->csr_val.upload(c->Ahat.val));
     }
-    if (d->linsolver == 2 && d->n_obstacles > 0)
-        return fail(ADMM_HIP_ERR_ARG, "UzawaCG with obstacles is not available in this build yet");
+    if (d->linsolver == 2) {
+        c->NBU = std::max(1, std::min((nv + 255) / 256, 256));
+        HIP_TRY(c->uz_cn.alloc(c->n3)); HIP_TRY(c->uz_cn.zero());
+        HIP_TRY(c->uz_q1.alloc(c->n3)); HIP_TRY(c->uz_q2.alloc(c->n3)); HIP_TRY(c->uz_q2.zero());
+        HIP_TRY(c->uz_cc.alloc(nv)); HIP_TRY(c->uz_y.alloc(nv)); HIP_TRY(c->uz_y.zero());
+        HIP_TRY(c->uz_r.alloc(nv)); HIP_TRY(c->uz_d.alloc(nv)); HIP_TRY(c->uz_q3.alloc(nv));
+        HIP_TRY(c->uz_part.alloc(2 * (size_t)c->NBU)); HIP_TRY(c->uz_scal.alloc(1)); HIP_TRY(c->uz_scal.zero());
+    }
     HIP_TRY(hipDeviceSynchronize());
     *out = guard.release();
     return ADMM_HIP_OK;
@@ -619,6 +677,12 @@ int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const dou
 
 static int launch_global(admm_hip_ctx *c, const double *b, double *x) {
     if (c->linsolver == 1) { launch_gs(c, b, x); return 0; }
+    if (c->linsolver == 2) {
+        int it = 1;
+        const int rc = launch_uzawa(c, b, x, &it);
+        c->uz_iters_step += it;
+        return rc;
+    }
     return launch_pcg(c, b, x, c->pcg_max_iters);
 }
 
@@ -638,6 +702,7 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
     }
     HIP_TRY(hipEventRecord(c->ev_step0, st));
     // counters[5] (closed chunks) must stay monotone across steps: only [0..4] are reset
+    c->uz_iters_step = 0;
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
     hipLaunchKernelGGL(k_predict, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, c->dt, gravity, c->x.p, c->v.p, c->m.p,
                        c->Mxbar.p, c->curr.p);
@@ -678,6 +743,12 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
         HIP_TRY(hipMemcpy(sc, c->cg_scal.p, sizeof(sc), hipMemcpyDeviceToHost));
         stats->admm_iters = admm_iters;
         if (c->linsolver == 1) { stats->inner_iters = h[0]; stats->last_solve_converged = h[1]; }
+        else if (c->linsolver == 2) {
+            stats->inner_iters = c->uz_iters_step; // the reference counts Schur-CG iterations (UzawaCG.hpp:124)
+            stats->n_constraints = c->uz_last_hits;
+            stats->last_solve_converged = sc[c->last_launched_iters & 1].converged;
+            stats->pcg_launched_iters = c->last_launched_iters;
+        }
         else {
             stats->inner_iters = h[0];
             stats->last_solve_converged = sc[c->last_launched_iters & 1].converged;
@@ -756,6 +827,7 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->b.p, b, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->curr.p, x_inout, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
+    c->uz_iters_step = 0;
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
     if (launch_global(c, c->b.p, c->curr.p)) return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     HIP_TRY(hipGetLastError());
@@ -763,7 +835,7 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     int h[8];
     HIP_TRY(hipMemcpyAsync(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (iters) *iters = (c->linsolver == 1) ? h[2] : h[0];
+    if (iters) *iters = (c->linsolver == 1) ? h[2] : (c->linsolver == 2 ? c->uz_iters_step : h[0]);
     return ADMM_HIP_OK;
 }
 

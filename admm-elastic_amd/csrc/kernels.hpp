@@ -606,4 +606,139 @@ __global__ __launch_bounds__(256) void k_gs_check(const double *__restrict__ par
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// GLOBAL STEP (ADMM_LS_UZAWACG): Schur-complement CG for [A C^T; C 0] (src/UzawaCG.hpp:57-125) with the
+// constraint rows of ConstraintSet::make_matrix (src/ConstraintSet.hpp:59-116) for passive hits found by
+// Collider::detect (src/Collider.hpp:152-212).  A passive hit constrains ONE vertex (row = ck n^T at the
+// vertex, rhs = ck n.p), so C is stored per vertex: cn[nv][3] = ck n (0 when not hit), cc[nv] = ck n.p.
+// The inner A^-1 applications are the GPU PCG above.
+struct UzScal { double denom, alpha, beta, rr; int stop; int iters; int nhits; int pad_; };
+
+// Collider::detect for every vertex against the passive objects; builds the per-vertex constraint rows
+__global__ __launch_bounds__(256) void k_uz_detect(int nv, const double *__restrict__ x, Obstacles ob, double ck,
+                                                   double *__restrict__ cn, double *__restrict__ cc, int *__restrict__ nhits) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    const double xv[3] = {x[3 * (size_t)v], x[3 * (size_t)v + 1], x[3 * (size_t)v + 2]};
+    // Collider::detect: every object updates the payload when its distance is lower (no early exit)
+    double best = 1.7976931348623157e308, n[3] = {0, 0, 0}, p[3] = {0, 0, 0};
+    for (int j = 0; j < ob.n; ++j) {
+        if (ob.kind[j] == 0) {
+            const double dx = xv[1] - ob.par[j][0];
+            if (!(dx > best)) { best = dx; p[0] = xv[0]; p[1] = ob.par[j][0]; p[2] = xv[2]; n[0] = 0.0; n[1] = 1.0; n[2] = 0.0; }
+        } else {
+            double d[3] = {xv[0] - ob.par[j][0], xv[1] - ob.par[j][1], xv[2] - ob.par[j][2]};
+            const double l = sqrt(dot3(d, d)), dx = l - ob.par[j][3];
+            if (!(dx > best)) {
+                best = dx;
+                const double il = 1.0 / l;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { d[c] *= il; p[c] = ob.par[j][c] + d[c] * ob.par[j][3]; n[c] = d[c]; }
+            }
+        }
+    }
+    const bool hit = best < 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cn[3 * (size_t)v + c] = hit ? ck * n[c] : 0.0;
+    cc[v] = hit ? ck * dot3(n, p) : 0.0;
+    if (hit) atomicAdd(nhits, 1);
+}
+
+// out = base - C^T y  (mode 0)   or   out = C^T y (mode 1)
+__global__ __launch_bounds__(256) void k_uz_ct(int nv, int mode, const double *__restrict__ base, const double *__restrict__ cn,
+                                               const double *__restrict__ y, double *__restrict__ out) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    const double yv = y[v];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const size_t i = 3 * (size_t)v + c;
+        out[i] = (mode == 0) ? base[i] - cn[i] * yv : cn[i] * yv;
+    }
+}
+
+// r = C x - c ; d = r ; also clears y when the number of hits changed (UzawaCG.hpp:74)
+__global__ __launch_bounds__(256) void k_uz_resid(int nv, const double *__restrict__ x, const double *__restrict__ cn,
+                                                  const double *__restrict__ cc, double *__restrict__ r, double *__restrict__ d) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    const double rv = cn[3 * (size_t)v] * x[3 * (size_t)v] + cn[3 * (size_t)v + 1] * x[3 * (size_t)v + 1] +
+                      cn[3 * (size_t)v + 2] * x[3 * (size_t)v + 2] - cc[v];
+    r[v] = rv; d[v] = rv;
+}
+
+// q3 = C q2 ; partial sums of d.q3 and d.r
+__global__ __launch_bounds__(256) void k_uz_dots(int nv, const double *__restrict__ q2, const double *__restrict__ cn,
+                                                 const double *__restrict__ d, const double *__restrict__ r,
+                                                 double *__restrict__ q3, double *__restrict__ part, int NBp) {
+    __shared__ double lds[8];
+    double q[2] = {0.0, 0.0};
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
+        const double t = cn[3 * (size_t)v] * q2[3 * (size_t)v] + cn[3 * (size_t)v + 1] * q2[3 * (size_t)v + 1] +
+                         cn[3 * (size_t)v + 2] * q2[3 * (size_t)v + 2];
+        q3[v] = t;
+        q[0] = fma(d[v], t, q[0]);
+        q[1] = fma(d[v], r[v], q[1]);
+    }
+    block_sum<2>(q, lds);
+    if (threadIdx.x == 0) { part[blockIdx.x] = q[0]; part[NBp + blockIdx.x] = q[1]; }
+}
+
+// alpha = d.r / d.q3 (stop when the denominator vanishes, UzawaCG.hpp:103-105)
+__global__ __launch_bounds__(256) void k_uz_alpha(const double *__restrict__ part, int NBp, UzScal *sc) {
+    __shared__ double lds[8];
+    double q[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < NBp; i += 256) { q[0] += part[i]; q[1] += part[NBp + i]; }
+    block_sum<2>(q, lds);
+    if (threadIdx.x == 0) {
+        sc->denom = q[0];
+        if (fabs(q[0]) < 2.2250738585072014e-308) { sc->stop = 1; sc->alpha = 0.0; }
+        else sc->alpha = q[1] / q[0];
+    }
+}
+
+// x -= alpha q2 ; y += alpha d ; r -= alpha q3 ; partial sums of r.r and r.q3
+__global__ __launch_bounds__(256) void k_uz_step(int nv, const UzScal *__restrict__ sc, double *__restrict__ x,
+                                                 const double *__restrict__ q2, double *__restrict__ y,
+                                                 const double *__restrict__ d, double *__restrict__ r,
+                                                 const double *__restrict__ q3, double *__restrict__ part, int NBp) {
+    __shared__ double lds[8];
+    if (sc->stop) return;
+    const double al = sc->alpha;
+    double q[2] = {0.0, 0.0};
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[3 * (size_t)v + c] -= al * q2[3 * (size_t)v + c];
+        y[v] += al * d[v];
+        const double rv = r[v] - al * q3[v];
+        r[v] = rv;
+        q[0] = fma(rv, rv, q[0]);
+        q[1] = fma(rv, q3[v], q[1]);
+    }
+    block_sum<2>(q, lds);
+    if (threadIdx.x == 0) { part[blockIdx.x] = q[0]; part[NBp + blockIdx.x] = q[1]; }
+}
+
+// residual test (UzawaCG.hpp:112-113), beta (UzawaCG.hpp:115-118); counts the iteration like the reference
+__global__ __launch_bounds__(256) void k_uz_beta(const double *__restrict__ part, int NBp, double tol2, UzScal *sc) {
+    __shared__ double lds[8];
+    if (sc->stop) return;
+    double q[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < NBp; i += 256) { q[0] += part[i]; q[1] += part[NBp + i]; }
+    block_sum<2>(q, lds);
+    if (threadIdx.x == 0) {
+        sc->rr = q[0];
+        if (q[0] < tol2) { sc->stop = 1; return; }
+        sc->beta = q[1] / sc->denom;
+        sc->iters += 1;
+    }
+}
+
+// d = r - beta d
+__global__ __launch_bounds__(256) void k_uz_dir(int nv, const UzScal *__restrict__ sc, const double *__restrict__ r, double *__restrict__ d) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv || sc->stop) return;
+    d[v] = r[v] - sc->beta * d[v];
+}
+
 } // namespace admm_k

@@ -179,6 +179,62 @@ def test_step_parity_cloth_floor_gs():
     assert abs(y.min() - 0.45) < 1e-9      # came to rest exactly on the floor
 
 
+def test_step_parity_uzawa_no_constraints():
+    """linsolver 2 without active constraints is one prefactored solve (UzawaCG.hpp:78-81)."""
+    sc = scenes.cube_scene(4, pkg.TET_STVK, admm_iters=8, linsolver=2)
+    s, o = run_both(sc, 3, pcg_tol=1e-11, pcg_max_iters=300)
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7
+    assert s.runtime_data().inner_iters == o.inner_iters == 8
+
+
+@pytest.mark.parametrize("what", ["cloth_floor", "cube_floor", "cube_sphere"])
+def test_global_solve_uzawa_collisions(what):
+    """UzawaCG::solve with passive collisions at the SOLVE level: Collider::detect ->
+    ConstraintSet::make_matrix -> Schur CG, against the oracle's restatement on the same (b, x)."""
+    if what == "cloth_floor":
+        sc = scenes.cloth_scene(8, floor=0.46, admm_iters=8, linsolver=2)
+    else:
+        sc = scenes.cube_scene(3, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=8, linsolver=2, size=0.5)
+        sc.obstacles.append((0, [0.03, 0.0, 0.0, 0.0]) if what == "cube_floor" else (1, [0.25, -0.45, 0.25, 0.55]))
+    s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+    o = sc.make_oracle(mode=1)
+    rng = np.random.default_rng(1)
+    x = sc.x.copy(); x[:, 1] -= 0.02 + 0.03 * rng.random(len(x)); x = x.ravel()
+    b = o.A @ (x + 0.001 * rng.standard_normal(x.size))
+    hits = o.detect_passive(x)
+    assert 3 < len(hits) < len(sc.x)
+    for rep in range(2):          # second call exercises the multiplier warm start (UzawaCG.hpp:74)
+        xo, ito = o.solve_uzawa(x, b, hits)
+        xg, itg = s.global_solve(b, x)
+        assert np.abs(xg - xo).max() < 1e-7, (rep, np.abs(xg - xo).max())
+        assert abs(itg - ito) <= 3      # the residual hovers around the 1e-10 tolerance
+    # the constrained vertices ended on the obstacle surface
+    X = xg.reshape(-1, 3)
+    hv = [h[0] for h in hits]
+    if what == "cube_sphere":
+        d = np.linalg.norm(X[hv] - np.array([0.25, -0.45, 0.25]), axis=1) - 0.55
+        assert np.abs(np.einsum("ij,ij->i", np.array([h[3] for h in hits]), X[hv] - np.array([h[2] for h in hits]))).max() < 1e-6
+    else:
+        assert np.abs(X[hv, 1] - sc.obstacles[0][1][0]).max() < 1e-6
+
+
+def test_step_uzawa_collisions_loose():
+    """Whole steps with contact.  The reference's active set is chaotic by construction: a vertex resting
+    on the floor at y0 +- 1e-10 is or is not a hit in the next ADMM iteration (dx < 0, Collider.hpp:181),
+    and the reference's own hit order is thread-dependent, so trajectories are only comparable loosely."""
+    sc = scenes.cloth_scene(8, floor=0.46, admm_iters=8, linsolver=2)
+    s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+    o = sc.make_oracle(mode=1)
+    hit_frames = 0
+    for _ in range(8):
+        s.step(); o.step()
+        hit_frames += 1 if len(o._hits) else 0
+    assert hit_frames >= 2, "scene meant to collide"
+    assert scenes.rel_err(s.m_x, o.x) < 2e-2
+    assert s.m_x.reshape(-1, 3)[:, 1].min() > 0.46 - 5e-3
+    assert s.runtime_data().inner_iters > 8
+
+
 # ---- BASELINE-size properties (size-independent invariants at 1M tets) ----------------------------
 @pytest.fixture(scope="module")
 def big():
