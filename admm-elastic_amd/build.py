@@ -33,3 +33,23 @@ def build_library(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
     return OUT
+
+
+OUT_HOST = os.path.join(HERE, "libadmm_elastic.so")
+HOST_SOURCES = ["host/src/Solver.cpp"]
+
+
+def build_host_library(force=False, verbose=False):
+    """g++ -> admm-elastic_amd/libadmm_elastic.so: the C++ mirror of the reference's class API
+    (admm::Solver, EnergyTerm, ...) on top of libadmm_hip.so."""
+    build_library(force=force, verbose=verbose)
+    import glob
+    deps = [os.path.join(HERE, f) for f in HOST_SOURCES] + glob.glob(os.path.join(HERE, "host", "include", "*.hpp")) + [OUT]
+    if not force and os.path.exists(OUT_HOST) and all(os.path.getmtime(d) <= os.path.getmtime(OUT_HOST) for d in deps):
+        return OUT_HOST
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + os.path.join(HERE, "host", "include")] + \
+          [os.path.join(HERE, f) for f in HOST_SOURCES] + ["-L" + HERE, "-ladmm_hip", "-Wl,-rpath,$ORIGIN", "-o", OUT_HOST]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT_HOST

@@ -1,0 +1,421 @@
+// Solver.cpp -- host side of the MI355X-native admm::Solver: flattens the scene, drives the C ABI.
+// Reference call stack replaced: Solver::initialize (src/Solver.cpp:167-261), Solver::step (:35-110),
+// Solver::set_pins (:113-157).
+#include "Solver.hpp"
+#include "TetEnergyTerm.hpp"
+#include "TriEnergyTerm.hpp"
+#include "../../../include/admm_hip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+namespace admm {
+
+namespace {
+void check(int rc, const char *what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + admm_hip_last_error());
+}
+
+// gathers flat arrays for admm_hip_desc
+struct Flat {
+    std::vector<int32_t> tet_idx, tet_kind, tri_idx, pin_vert, pin_active;
+    std::vector<double> tet_Binv, tet_w, tet_mu, tet_la, tet_k, tri_rest, tri_w, tri_lmin, tri_lmax, pin_xyz;
+    double pin_weight = 0.0;
+    void add(const FlatTerm &t) {
+        if (t.type == FlatTerm::TET) {
+            for (int i = 0; i < 4; ++i) tet_idx.push_back(t.idx[i]);
+            for (int i = 0; i < 9; ++i) tet_Binv.push_back(t.mat[i]);
+            tet_w.push_back(t.weight); tet_kind.push_back(t.kind); tet_mu.push_back(t.mu); tet_la.push_back(t.lambda); tet_k.push_back(t.k);
+        } else if (t.type == FlatTerm::TRI) {
+            for (int i = 0; i < 3; ++i) tri_idx.push_back(t.idx[i]);
+            for (int i = 0; i < 4; ++i) tri_rest.push_back(t.mat[i]);
+            tri_w.push_back(t.weight); tri_lmin.push_back(t.limit_min); tri_lmax.push_back(t.limit_max);
+        } else {
+            pin_vert.push_back(t.idx[0]);
+            for (int i = 0; i < 3; ++i) pin_xyz.push_back(t.pin[i]);
+            pin_active.push_back(t.active); pin_weight = t.weight;
+        }
+    }
+    void fill(admm_hip_desc &d) const {
+        d.n_tets = (int32_t)tet_w.size();
+        d.tet_idx = tet_idx.data(); d.tet_Binv = tet_Binv.data(); d.tet_weight = tet_w.data(); d.tet_kind = tet_kind.data();
+        d.tet_mu = tet_mu.data(); d.tet_lambda = tet_la.data(); d.tet_k = tet_k.data();
+        d.n_tris = (int32_t)tri_w.size();
+        d.tri_idx = tri_idx.data(); d.tri_rest = tri_rest.data(); d.tri_weight = tri_w.data();
+        d.tri_limit_min = tri_lmin.data(); d.tri_limit_max = tri_lmax.data();
+        d.n_pins = (int32_t)pin_vert.size();
+        d.pin_vert = pin_vert.data(); d.pin_xyz = pin_xyz.data(); d.pin_active = pin_active.data(); d.pin_weight = pin_weight;
+    }
+};
+
+double det3(const double *B) { // column-major
+    return B[0] * (B[4] * B[8] - B[7] * B[5]) - B[3] * (B[1] * B[8] - B[7] * B[2]) + B[6] * (B[1] * B[5] - B[4] * B[2]);
+}
+} // namespace
+
+// ---------------------------------------------------------------- EnergyTerm -----------------------
+EnergyTerm::~EnergyTerm() {
+    if (one_ctx_) admm_hip_destroy((admm_hip_ctx *)one_ctx_);
+}
+
+void EnergyTerm::get_reduction(std::vector<Triplet> &triplets, std::vector<double> &weights) {
+    std::vector<Triplet> tmp;
+    get_reduction(tmp);
+    g_index = (int)weights.size();
+    for (const Triplet &t : tmp) triplets.emplace_back(t.row() + g_index, t.col(), t.value());
+    const double w = get_weight();
+    if (w <= 0.0) throw std::runtime_error("**EnergyTerm::get_reduction Error: Some weight leq 0");
+    for (int i = 0; i < get_dim(); ++i) weights.emplace_back(w);
+}
+
+void EnergyTerm::update(const SparseMat &D, const VecX &x, VecX &z, VecX &u) {
+    (void)D; // the kernel recomputes D_i x from the term's own rest data
+    FlatTerm ft;
+    std::memset(&ft, 0, sizeof(ft));
+    if (!flatten(ft)) throw std::runtime_error("EnergyTerm::update: this term type has no GPU kernel");
+    const int nv = x.rows() / 3, dim = get_dim();
+    if (!one_ctx_) {
+        Flat f; f.add(ft);
+        std::vector<double> masses(x.rows(), 1.0);
+        admm_hip_desc d;
+        std::memset(&d, 0, sizeof(d));
+        d.struct_size = sizeof(d); d.n_verts = nv; d.masses = masses.data(); d.dt = 1.0; d.linsolver = 0; d.gs_tol = -1.0;
+        f.fill(d);
+        admm_hip_ctx *ctx = nullptr;
+        check(admm_hip_create(&d, &ctx), "EnergyTerm::update");
+        one_ctx_ = ctx;
+    }
+    std::vector<double> ui(dim, 0.0), zi(dim, 0.0);
+    for (int i = 0; i < dim; ++i) ui[i] = u[g_index + i];
+    if (ft.type == FlatTerm::PIN) { // pins may move between calls
+        int32_t v = ft.idx[0];
+        if (ft.active) check(admm_hip_set_pins((admm_hip_ctx *)one_ctx_, 1, &v, ft.pin), "EnergyTerm::update");
+        else check(admm_hip_set_pins((admm_hip_ctx *)one_ctx_, 0, nullptr, nullptr), "EnergyTerm::update");
+    }
+    check(admm_hip_local_step((admm_hip_ctx *)one_ctx_, x.data(), ui.data(), zi.data(), nullptr, nullptr), "EnergyTerm::update");
+    for (int i = 0; i < dim; ++i) { u[g_index + i] = ui[i]; z[g_index + i] = zi[i]; }
+}
+
+double EnergyTerm::energy(const SparseMat &D, const VecX &x) {
+    const int dim = get_dim();
+    VecX Dx = D * x, F(dim);
+    for (int i = 0; i < dim; ++i) F[i] = Dx[g_index + i];
+    return energy(F);
+}
+
+double EnergyTerm::gradient(const SparseMat &D, const VecX &x, VecX &grad) {
+    const int dim = get_dim();
+    VecX Dx = D * x, F(dim);
+    for (int i = 0; i < dim; ++i) F[i] = Dx[g_index + i];
+    return gradient(F, grad);
+}
+
+// One-sided Jacobi on the host -- debugging aid for energy(); not on the hot path.
+void host_signed_svd3(const double *F, double *U, double *S, double *V) {
+    double G[9], W[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(G, F, sizeof(G));
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rot = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double al = 0, be = 0, ga = 0;
+                for (int r = 0; r < 3; ++r) { al += G[3 * p + r] * G[3 * p + r]; be += G[3 * q + r] * G[3 * q + r]; ga += G[3 * p + r] * G[3 * q + r]; }
+                if (ga == 0.0 || std::fabs(ga) <= 1e-17 * std::sqrt(al * be)) continue;
+                rot = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                for (int r = 0; r < 3; ++r) {
+                    double a = G[3 * p + r], b = G[3 * q + r]; G[3 * p + r] = c * a - s * b; G[3 * q + r] = s * a + c * b;
+                    a = W[3 * p + r]; b = W[3 * q + r]; W[3 * p + r] = c * a - s * b; W[3 * q + r] = s * a + c * b;
+                }
+            }
+        if (!rot) break;
+    }
+    int ord[3] = {0, 1, 2};
+    double sig[3];
+    for (int j = 0; j < 3; ++j) sig[j] = std::sqrt(G[3 * j] * G[3 * j] + G[3 * j + 1] * G[3 * j + 1] + G[3 * j + 2] * G[3 * j + 2]);
+    for (int i = 0; i < 3; ++i) for (int j = i + 1; j < 3; ++j) if (sig[ord[j]] > sig[ord[i]]) std::swap(ord[i], ord[j]);
+    for (int j = 0; j < 3; ++j) {
+        S[j] = sig[ord[j]];
+        for (int r = 0; r < 3; ++r) { V[3 * j + r] = W[3 * ord[j] + r]; U[3 * j + r] = sig[ord[j]] > 0 ? G[3 * ord[j] + r] / sig[ord[j]] : (r == j ? 1.0 : 0.0); }
+    }
+    if (det3(U) < 0) { for (int r = 0; r < 3; ++r) U[6 + r] = -U[6 + r]; S[2] = -S[2]; }
+    if (det3(V) < 0) { for (int r = 0; r < 3; ++r) V[6 + r] = -V[6 + r]; S[2] = -S[2]; }
+}
+
+// ---------------------------------------------------------------- tets ------------------------------
+TetEnergyTerm::TetEnergyTerm(const Vec4i &tet_, const std::vector<Vec3> &verts, const Lame &lame_)
+    : tet(tet_), lame(lame_), volume(0.0), weight(0.0) {
+    const int32_t idx[4] = {0, 1, 2, 3};
+    double vv[12];
+    for (int c = 0; c < 4; ++c) for (int j = 0; j < 3; ++j) vv[3 * c + j] = verts[c][j];
+    if (admm_host_tet_rest(1, idx, vv, edges_inv, &volume) != 0)
+        throw std::runtime_error("**TetEnergyTerm Error: Inverted initial tet"); // src/TetEnergyTerm.cpp:42-44
+    weight = std::sqrt(lame.bulk_modulus() * volume);                           // :46-47
+}
+
+void TetEnergyTerm::get_reduction(std::vector<Triplet> &triplets) { // src/TetEnergyTerm.cpp:50-71
+    for (int r = 0; r < 3; ++r) {
+        const double d[4] = {-(edges_inv[3 * r] + edges_inv[3 * r + 1] + edges_inv[3 * r + 2]), edges_inv[3 * r], edges_inv[3 * r + 1], edges_inv[3 * r + 2]};
+        for (int c = 0; c < 4; ++c)
+            for (int j = 0; j < 3; ++j) triplets.emplace_back(3 * r + j, 3 * tet[c] + j, d[c]);
+    }
+}
+
+bool TetEnergyTerm::flatten(FlatTerm &o) const {
+    o.type = FlatTerm::TET;
+    for (int i = 0; i < 4; ++i) o.idx[i] = tet[i];
+    for (int i = 0; i < 9; ++i) o.mat[i] = edges_inv[i];
+    o.weight = weight; o.kind = kind(); o.mu = lame.mu; o.lambda = lame.lambda; o.k = lame.bulk_modulus();
+    return true;
+}
+
+double TetEnergyTerm::energy(const VecX &F) { // src/TetEnergyTerm.cpp:94-100
+    double U[9], S[3], V[9];
+    host_signed_svd3(F.data(), U, S, V);
+    double e = 0;
+    for (int i = 0; i < 3; ++i) e += (std::fabs(S[i]) - 1.0) * (std::fabs(S[i]) - 1.0);
+    return 0.5 * lame.bulk_modulus() * volume * e;
+}
+double TetEnergyTerm::gradient(const VecX &, VecX &) { throw std::runtime_error("**TetEnergyTerm TODO: gradient function"); }
+
+double NeoHookeanTet::energy(const VecX &F) { // src/TetEnergyTerm.cpp:138-150, :173-182
+    double U[9], S[3], V[9];
+    host_signed_svd3(F.data(), U, S, V);
+    if (S[2] < 0) S[2] = -S[2];
+    const double J = S[0] * S[1] * S[2], I1 = S[0] * S[0] + S[1] * S[1] + S[2] * S[2], l = std::log(J * J);
+    return (0.5 * lame.mu * (I1 - l - 3.0) + 0.125 * lame.lambda * l * l) * volume;
+}
+double StVKTet::energy(const VecX &F) { // src/TetEnergyTerm.cpp:220-226
+    double U[9], S[3], V[9];
+    host_signed_svd3(F.data(), U, S, V);
+    double tr = 0, dd = 0;
+    for (int i = 0; i < 3; ++i) { const double st = 0.5 * (S[i] * S[i] - 1.0); tr += st; dd += st * st; }
+    return (lame.mu * dd + 0.5 * lame.lambda * tr * tr) * volume;
+}
+
+// ---------------------------------------------------------------- tris / pins -----------------------
+TriEnergyTerm::TriEnergyTerm(const Vec3i &tri_, const std::vector<Vec3> &verts, const Lame &lame_)
+    : tri(tri_), lame(lame_), area(0.0), weight(0.0) {
+    if (lame.limit_min > 1.0) throw std::runtime_error("**TriEnergyTerm Error: Strain limit min should be -inf to 1");
+    if (lame.limit_max < 1.0) throw std::runtime_error("**TriEnergyTerm Error: Strain limit max should be 1 to inf");
+    const int32_t idx[3] = {0, 1, 2};
+    double vv[9];
+    for (int c = 0; c < 3; ++c) for (int j = 0; j < 3; ++j) vv[3 * c + j] = verts[c][j];
+    if (admm_host_tri_rest(1, idx, vv, rest_pose, &area) != 0)
+        throw std::runtime_error("**TriEnergyTerm Error: Inverted initial pose");
+    weight = std::sqrt(lame.bulk_modulus() * area);
+}
+void TriEnergyTerm::get_reduction(std::vector<Triplet> &triplets) {
+    const double D[3][2] = {{-(rest_pose[0] + rest_pose[1]), -(rest_pose[2] + rest_pose[3])}, {rest_pose[0], rest_pose[2]}, {rest_pose[1], rest_pose[3]}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            triplets.emplace_back(i, 3 * tri[j] + i, D[j][0]);
+            triplets.emplace_back(3 + i, 3 * tri[j] + i, D[j][1]);
+        }
+}
+bool TriEnergyTerm::flatten(FlatTerm &o) const {
+    o.type = FlatTerm::TRI;
+    for (int i = 0; i < 3; ++i) o.idx[i] = tri[i];
+    for (int i = 0; i < 4; ++i) o.mat[i] = rest_pose[i];
+    o.weight = weight; o.limit_min = lame.limit_min; o.limit_max = lame.limit_max;
+    return true;
+}
+double TriEnergyTerm::energy(const VecX &) { throw std::runtime_error("TriEnergyTerm::energy: debugging aid not provided in the MI355X build"); }
+double TriEnergyTerm::gradient(const VecX &, VecX &) { throw std::runtime_error("**TriEnergyTerm TODO: gradient function"); }
+
+bool SpringPin::flatten(FlatTerm &o) const {
+    o.type = FlatTerm::PIN; o.idx[0] = idx; o.weight = weight; o.active = active ? 1 : 0;
+    for (int i = 0; i < 3; ++i) o.pin[i] = pin[i];
+    return true;
+}
+
+// ---------------------------------------------------------------- LinearSolver ----------------------
+int LinearSolver::solve(VecX &x, const VecX &b) {
+    if (!ctx_) throw std::runtime_error("LinearSolver::solve: not attached to an initialized Solver");
+    int32_t it = 0;
+    check(admm_hip_global_solve((admm_hip_ctx *)ctx_, b.data(), x.data(), &it), "LinearSolver::solve");
+    return it;
+}
+
+// ---------------------------------------------------------------- Solver ----------------------------
+Solver::Solver() : device(0), initialized(false), m_constraints(std::make_shared<ConstraintSet>()), m_ctx(nullptr) {}
+Solver::~Solver() { release(); }
+void Solver::release() { if (m_ctx) { admm_hip_destroy((admm_hip_ctx *)m_ctx); m_ctx = nullptr; } }
+
+void Solver::set_pins(const std::vector<int> &inds, const std::vector<Vec3> &points) { // src/Solver.cpp:113-157
+    const int n_pins = (int)inds.size();
+    const bool pin_in_place = (int)points.size() != n_pins;
+    if ((m_x.rows() == 0 && pin_in_place) || (pin_in_place && points.size() > 0))
+        throw std::runtime_error("**Solver::set_pins Error: Bad input.");
+    m_constraints->pins.clear();
+    for (int i = 0; i < n_pins; ++i)
+        m_constraints->pins[inds[i]] = pin_in_place ? Vec3(m_x.segment<3>(inds[i] * 3)) : points[i];
+    if (!initialized) return;
+    std::vector<int32_t> v; std::vector<double> p;
+    if (m_settings.linsolver == 0 || m_settings.linsolver == 2) {
+        for (auto &pe : m_pin_energies) pe.second->set_active(false);
+        for (int i = 0; i < n_pins; ++i) {
+            auto it = m_pin_energies.find(inds[i]);
+            if (it == m_pin_energies.end()) {
+                std::stringstream err;
+                err << "**Solver::set_pins Error: Constraint for " << inds[i] << " not found.\n";
+                throw std::runtime_error(err.str());
+            }
+            it->second->set_active(true);
+            it->second->set_pin(m_constraints->pins[inds[i]]);
+        }
+    }
+    for (auto &kv : m_constraints->pins) { v.push_back(kv.first); for (int j = 0; j < 3; ++j) p.push_back(kv.second[j]); }
+    check(admm_hip_set_pins((admm_hip_ctx *)m_ctx, (int32_t)v.size(), v.data(), p.data()), "Solver::set_pins");
+}
+
+void Solver::add_obstacle(std::shared_ptr<PassiveCollision> obj) { m_constraints->collider->add_passive_obj(obj); }
+void Solver::add_dynamic_collider(std::shared_ptr<DynamicCollision> obj) { m_constraints->collider->add_dynamic_obj(obj); }
+
+bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
+    m_settings = settings_;
+    const int dof = m_x.rows();
+    if (m_settings.verbose > 0) std::cout << "Solver::initialize: " << std::endl;
+    if (m_settings.timestep_s <= 0.0) {
+        std::cerr << "\n**Solver Error: timestep set to " << m_settings.timestep_s << "s, changing to 1/24s." << std::endl;
+        m_settings.timestep_s = 1.0 / 24.0;
+    }
+    if (!(m_masses.rows() == dof && dof >= 3)) {
+        std::cerr << "\n**Solver Error: Problem with node data!" << std::endl;
+        return false;
+    }
+    if (m_v.rows() != dof) m_v.resize(dof);
+    m_v.setZero();
+    release();
+
+    // energy-based hard constraints (src/Solver.cpp:190-196)
+    if (m_settings.linsolver == 0 || m_settings.linsolver == 2)
+        for (auto &pin : m_constraints->pins) {
+            m_pin_energies[pin.first] = std::make_shared<SpringPin>(pin.first, pin.second);
+            energyterms.emplace_back(m_pin_energies[pin.first]);
+        }
+    // the reference sizes D here (and assigns every term its first row); we keep that side effect
+    std::vector<Triplet> triplets; std::vector<double> weights;
+    Flat flat;
+    for (auto &term : energyterms) {
+        term->get_reduction(triplets, weights);
+        FlatTerm ft;
+        std::memset(&ft, 0, sizeof(ft));
+        if (!term->flatten(ft))
+            throw std::runtime_error("Solver::initialize: an EnergyTerm subclass without a GPU kernel was added "
+                                     "(the MI355X hot path has no CPU fallback)");
+        flat.add(ft);
+    }
+    switch (m_settings.linsolver) {
+        default: if (!std::dynamic_pointer_cast<LDLTSolver>(m_linsolver)) m_linsolver = std::make_shared<LDLTSolver>(); break;
+        case 1: if (!std::dynamic_pointer_cast<NodalMultiColorGS>(m_linsolver)) m_linsolver = std::make_shared<NodalMultiColorGS>(m_constraints); break;
+        case 2: if (!std::dynamic_pointer_cast<UzawaCG>(m_linsolver)) m_linsolver = std::make_shared<UzawaCG>(m_constraints); break;
+    }
+    if (m_settings.linsolver == 0 && (m_constraints->collider->passive_objs.size() > 0 || m_constraints->collider->dynamic_objs.size() > 0))
+        throw std::runtime_error("**Solver::add_obstacle Error: No collisions with LDLT solver"); // :249-254
+    if (m_constraints->collider->dynamic_objs.size() > 0)
+        throw std::runtime_error("Solver::initialize: dynamic (self-)collision objects are out of scope of the MI355X hot path");
+
+    admm_hip_desc d;
+    std::memset(&d, 0, sizeof(d));
+    d.struct_size = sizeof(d); d.device = device;
+    d.n_verts = dof / 3; d.masses = m_masses.data(); d.dt = m_settings.timestep_s;
+    flat.fill(d);
+    // pins that are not energy terms (linsolver 1) go through the in-sweep pin list
+    std::vector<int32_t> gs_v; std::vector<double> gs_p;
+    if (m_settings.linsolver == 1) {
+        for (auto &kv : m_constraints->pins) { gs_v.push_back(kv.first); for (int j = 0; j < 3; ++j) gs_p.push_back(kv.second[j]); }
+        d.n_pins = (int32_t)gs_v.size(); d.pin_vert = gs_v.data(); d.pin_xyz = gs_p.data(); d.pin_active = nullptr;
+    }
+    d.linsolver = m_settings.linsolver; d.constraint_w = m_settings.constraint_w;
+    d.gs_tol = -1.0;
+    if (auto s0 = std::dynamic_pointer_cast<LDLTSolver>(m_linsolver)) { d.pcg_max_iters = s0->pcg_max_iters; d.pcg_tol = s0->pcg_tol; }
+    if (auto s1 = std::dynamic_pointer_cast<NodalMultiColorGS>(m_linsolver)) { d.gs_max_iters = s1->max_iters; d.gs_tol = s1->m_tol; d.gs_omega = s1->m_omega; }
+    if (auto s2 = std::dynamic_pointer_cast<UzawaCG>(m_linsolver)) { d.uzawa_max_iters = s2->max_iters; d.uzawa_tol = s2->m_tol; d.pcg_max_iters = s2->pcg_max_iters; d.pcg_tol = s2->pcg_tol; }
+    std::vector<int32_t> okind; std::vector<double> opar;
+    for (auto &obj : m_constraints->collider->passive_objs) {
+        int k; double q[4];
+        if (!obj->flatten(k, q)) throw std::runtime_error("Solver::initialize: only Floor and Sphere obstacles have GPU kernels");
+        okind.push_back(k); for (int i = 0; i < 4; ++i) opar.push_back(q[i]);
+    }
+    d.n_obstacles = (int32_t)okind.size(); d.obstacle_kind = okind.data(); d.obstacle_params = opar.data();
+
+    admm_hip_ctx *ctx = nullptr;
+    check(admm_hip_create(&d, &ctx), "Solver::initialize");
+    m_ctx = ctx;
+    m_linsolver->attach(ctx);
+    // keep the assembled matrix host-side (save_matrix, LinearSolver::matrix)
+    int32_t nnz = 0;
+    check(admm_hip_get_matrix(ctx, nullptr, nullptr, nullptr, &nnz), "Solver::initialize");
+    std::vector<int32_t> rp(d.n_verts + 1), ci(nnz); std::vector<double> va(nnz);
+    check(admm_hip_get_matrix(ctx, rp.data(), ci.data(), va.data(), &nnz), "Solver::initialize");
+    solver_termA.setCsr(d.n_verts, std::vector<int>(rp.begin(), rp.end()), std::vector<int>(ci.begin(), ci.end()), va);
+    m_linsolver->update_system(solver_termA);
+    if (m_settings.verbose >= 1) printf("%d nodes, %d energy terms\n", (int)m_x.size() / 3, (int)energyterms.size());
+    initialized = true;
+    return true;
+}
+
+void Solver::step() { // src/Solver.cpp:35-110
+    if (!initialized) throw std::runtime_error("Solver::step: initialize() first");
+    if (m_settings.verbose > 0) std::cout << "\nSimulating with dt: " << m_settings.timestep_s << "s..." << std::flush;
+    const double dt = m_settings.timestep_s;
+    for (auto &f : ext_forces) f->project(dt, m_x, m_v, m_masses); // :54 (host, pre-loop)
+    admm_hip_ctx *ctx = (admm_hip_ctx *)m_ctx;
+    check(admm_hip_set_state(ctx, m_x.data(), m_v.data()), "Solver::step");
+    admm_hip_stats st;
+    check(admm_hip_step(ctx, m_settings.admm_iters, m_settings.gravity, &st), "Solver::step");
+    check(admm_hip_get_state(ctx, m_x.data(), m_v.data()), "Solver::step");
+    m_runtime = RuntimeData();
+    m_runtime.global_ms = st.global_ms; m_runtime.local_ms = st.local_ms; m_runtime.collision_ms = st.collision_ms;
+    m_runtime.inner_iters = st.inner_iters;
+    if (m_settings.verbose > 0) m_runtime.print(m_settings);
+}
+
+void Solver::save_matrix(const std::string &filename) { // src/Solver.cpp:264-269 (Ahat; A = diag(m) + Ahat (x) I3)
+    std::cout << "Saving matrix (" << solver_termA.rows() << "x" << solver_termA.cols() << ") to " << filename << std::endl;
+    std::ofstream out(filename.c_str());
+    for (int i = 0; i < solver_termA.rows(); ++i)
+        for (int k = solver_termA.rowptr()[i]; k < solver_termA.rowptr()[i + 1]; ++k)
+            out << i << " " << solver_termA.colind()[k] << " " << solver_termA.values()[k] << "\n";
+}
+
+bool Solver::Settings::parse_args(int argc, char **argv) { // src/Solver.cpp:273-294
+    for (int i = 1; i < argc - 1; ++i) {
+        std::string arg(argv[i]);
+        std::stringstream val(argv[i + 1]);
+        if (arg == "-help" || arg == "--help" || arg == "-h") { help(); return true; }
+        else if (arg == "-dt") val >> timestep_s;
+        else if (arg == "-v") val >> verbose;
+        else if (arg == "-it") val >> admm_iters;
+        else if (arg == "-g") val >> gravity;
+        else if (arg == "-ls") val >> linsolver;
+        else if (arg == "-ck") val >> constraint_w;
+    }
+    if (argc > 0) {
+        std::string arg(argv[argc - 1]);
+        if (arg == "-help" || arg == "--help" || arg == "-h") { help(); return true; }
+    }
+    return false;
+}
+
+void Solver::Settings::help() {
+    printf("\n==========================================\nArgs:\n\t-dt: time step (s)\n\t-v: verbosity (higher -> show more)\n"
+           "\t-it: # admm iters\n\t-g: gravity (m/s^2)\n\t-ls: linear solver (0=LDLT as GPU PCG, 1=NCMCGS, 2=UzawaCG) \n"
+           "\t-ck: constraint weights (-1 = auto) \n==========================================\n");
+}
+
+void Solver::RuntimeData::print(const Settings &settings) { // src/Solver.cpp:309-319
+    const double n = double(settings.admm_iters);
+    std::cout << "\nTotal global step: " << global_ms << "ms\nTotal local step: " << local_ms << "ms\nTotal collision update: " << collision_ms
+              << "ms\nAvg global step: " << global_ms / n << "ms\nAvg local step: " << local_ms / n << "ms\nAvg collision update: "
+              << collision_ms / n << "ms\nADMM Iters: " << settings.admm_iters << "\nAvg Inner Iters: " << float(inner_iters) / float(settings.admm_iters)
+              << std::endl;
+}
+
+} // namespace admm
