@@ -155,6 +155,14 @@ def main():
     rd = s.runtime_data()
     s.download()
     finite = bool(np.isfinite(s.m_x).all())
+    # PCIe-inclusive rate (never `value`): the reference-style Solver::step() with m_x/m_v on the host,
+    # i.e. upload + step + download per frame.
+    pcie_value = None
+    if world == 1:
+        t1 = time.perf_counter()
+        for _ in range(2):
+            s.step()
+        pcie_value = iters * 2 / (time.perf_counter() - t1)
 
     out = {
         "metric": "ADMM iterations/sec", "value": value, "unit": "ADMM it/s", "n_gpus": world, "steps": args.steps,
@@ -168,7 +176,7 @@ def main():
         "split_ms_per_admm_iter": {"local": local_ms / (iters * args.steps), "rhs": rhs_ms / (iters * args.steps),
                                    "global": global_ms / (iters * args.steps)},
         "inner_iters_per_admm_iter": inner / (iters * args.steps), "unconverged_solves_in_timed_region": unconv, "pcg_launched_iters": rd.pcg_launched_iters,
-        "finite": finite,
+        "finite": finite, "pcie_inclusive_admm_it_per_s": pcie_value,
     }
     if rank == 0:
         if not args.no_roofline:
