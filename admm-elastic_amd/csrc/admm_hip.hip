@@ -502,7 +502,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->r_lmin.upload(lmin)); HIP_TRY(c->r_lmax.upload(lmax));
         HIP_TRY(c->r_u.alloc((size_t)6 * ld)); HIP_TRY(c->r_u.zero());
         HIP_TRY(c->r_z.alloc((size_t)6 * ld)); HIP_TRY(c->r_z.zero());
-        HIP_TRY(c->r_cf.alloc((size_t)9 * ld)); HIP_TRY(c->r_cf.zero());
+        HIP_TRY(c->r_cf.alloc((size_t)12 * ld)); HIP_TRY(c->r_cf.zero());
         HIP_TRY(c->r_inc.upload(admm_host::incidence_sell(nv, n, 3, d->tri_idx + 3 * (size_t)rb, n * 4)));
     }
     // ---- pins ----

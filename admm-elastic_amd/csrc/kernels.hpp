@@ -60,9 +60,19 @@ __device__ __forceinline__ void block_sum(double *q, double *lds /* [4*NQ] */) {
     __syncthreads();
 }
 
+// XCD-aware block remap (MI355X: block b runs on XCD b % 8, each XCD has its own 4 MB L2).  Blocks that
+// land on the same XCD are given a CONTIGUOUS range of work, so neighbouring rows / elements -- which
+// share gathered cache lines -- hit the same L2 instead of re-fetching through the fabric.  Bijective on
+// [0, nb); only a speed-up, never needed for correctness.
+__device__ __forceinline__ int xcd_block() {
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    const int per = nb >> 3, rem = nb & 7, x = b & 7, i = b >> 3;
+    return x * per + (x < rem ? x : rem) + i;
+}
+
 // wave-uniform slice index of this wave (one wave = one SELL slice)
 __device__ __forceinline__ int wave_slice() {
-    return __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    return __builtin_amdgcn_readfirstlane(xcd_block() * 4 + (int)(threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -95,14 +105,19 @@ __global__ __launch_bounds__(256) void k_finish(int n3, double inv_dt, double *_
 // 4 corner force vectors cf[12][ld] that k_gather_rhs sums per vertex (no atomics, deterministic).
 //   F = [x1-x0, x2-x0, x3-x0] Binv  ==  D_i x   (D-block of src/TetEnergyTerm.cpp:50-71)
 template <int KIND, bool WRITE_Z>
-__global__ __launch_bounds__(256) void k_local_tets(int t0, int t1, int ld, const int4 *__restrict__ idx,
+__global__ __launch_bounds__(256, (KIND == 1 ? 3 : 4)) void k_local_tets(int t0, int t1, int ld, const int4 *__restrict__ idx,
                                                     const double *__restrict__ Binv, double *__restrict__ u,
                                                     double *__restrict__ z, const double *__restrict__ sc,
                                                     const int *__restrict__ mat_id, const Mat *__restrict__ mats,
                                                     const double *__restrict__ x, double *__restrict__ cf) {
-    const int t = t0 + blockIdx.x * 256 + threadIdx.x;
+    const int t = t0 + xcd_block() * 256 + threadIdx.x;
     if (t >= t1) return;
     const int4 id = idx[t];
+    // Binv is needed twice (F = Ds Binv before the prox, corner forces after it).  It is parked in LDS in
+    // between: thread-private slots, [c][tid] layout (bank-conflict-free 8-B accesses), no VGPRs held
+    // across the prox and no second trip to HBM (rocprof FETCH_SIZE showed the re-read going to fabric).
+    __shared__ double sBi[9][256];
+    __shared__ double sV[9][256];   // V is parked here across the stretch minimisation (hyperelastic models)
     double U[9], V[9], S0[3], S1[3];
     {
         double q[9];
@@ -122,6 +137,8 @@ __global__ __launch_bounds__(256) void k_local_tets(int t0, int t1, int ld, cons
 #pragma unroll
                 for (int j = 0; j < 3; ++j)   // EnergyTerm.hpp:133-135  zi = D_i x + u_i
                     q[r * 3 + j] = fma(Ds[j], Bi[r * 3 + 0], fma(Ds[3 + j], Bi[r * 3 + 1], fma(Ds[6 + j], Bi[r * 3 + 2], ui[r * 3 + j])));
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sBi[c][threadIdx.x] = Bi[c];
         }
         signed_svd3(q, U, S0, V);   // q = U diag(S0) V^T to round-off: q itself is not needed any more
     }
@@ -130,8 +147,19 @@ __global__ __launch_bounds__(256) void k_local_tets(int t0, int t1, int ld, cons
     if (KIND == 0) {
         prox_stretches<0>(0.0, 0.0, 0.0, S1);
     } else {
+        // StVK fits 4 waves/SIMD (128 VGPRs) only with V out of the way; NH needs 3 waves/SIMD either way
+        // (measured: forcing 128 VGPRs spills and is slower), so it keeps V in registers.
+        constexpr bool kParkV = (KIND == 2);
+        if (kParkV) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) sV[c][threadIdx.x] = V[c];
+        }
         const Mat mt = mats[mat_id[t]];
         prox_stretches<KIND>(mt.mu, mt.la, mt.k, S1);
+        if (kParkV) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) V[c] = sV[c][threadIdx.x];
+        }
     }
     // z = U diag(S1) V^T ; u_new = u + D_i x - z = q - z = U diag(S0 - S1) V^T   (EnergyTerm.hpp:137)
     // G = dt^2 w^2 (z - u_new) = s U diag(2 S1 - S0) V^T
@@ -154,12 +182,12 @@ __global__ __launch_bounds__(256) void k_local_tets(int t0, int t1, int ld, cons
         usvt(U, dg, V, G);
     }
     // corner forces: H(j,m) = sum_r G(j,r) Binv(m,r); corner m+1 gets H(:,m), corner 0 gets -sum_m H(:,m).
-    // Binv is re-read here (L2-resident: the block read it microseconds ago) instead of being held in
-    // 18 VGPRs across the whole prox.
+    // SoA cf[12][ld] (an AoS-per-tet layout was measured slower for both this kernel and the gather: with a
+    // locality-preserving element order the SoA accesses coalesce across lanes).
     double f0[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        const double b0 = Binv[(size_t)(0 + m) * ld + t], b1 = Binv[(size_t)(3 + m) * ld + t], b2 = Binv[(size_t)(6 + m) * ld + t];
+        const double b0 = sBi[0 + m][threadIdx.x], b1 = sBi[3 + m][threadIdx.x], b2 = sBi[6 + m][threadIdx.x];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const double h = fma(G[j], b0, fma(G[3 + j], b1, G[6 + j] * b2));
@@ -178,7 +206,7 @@ __global__ __launch_bounds__(256) void k_local_tris(int n, int ld, const int4 *_
                                                     double *__restrict__ z, const double *__restrict__ sc,
                                                     const double *__restrict__ lmin, const double *__restrict__ lmax,
                                                     const double *__restrict__ x, double *__restrict__ cf) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = xcd_block() * 256 + threadIdx.x;
     if (t >= n) return;
     const int4 id = idx[t];
     double R[4], ui[6];
