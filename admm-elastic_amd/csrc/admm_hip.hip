@@ -169,7 +169,10 @@ struct admm_hip_ctx {
     DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part;
     DevBuf<UzScal> uz_scal;
     int uz_prev_hits = -1, uz_last_hits = 0, NBU = 1, uz_iters_step = 0;
-    // GS
+    // GS: the whole solve (colours x sweeps + residual tests, ~500 tiny launches) is captured once into a
+    // hipGraph and replayed -- the per-colour kernels are far below the host launch rate
+    hipGraphExec_t gs_exec = nullptr;
+    const double *gs_graph_b = nullptr; double *gs_graph_x = nullptr;
     std::vector<int> color_h; int n_colors = 0;
     std::vector<int> color_ptr_h;
     DevBuf<int> color_nodes;
@@ -191,6 +194,7 @@ struct admm_hip_ctx {
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
+        if (gs_exec) (void)hipGraphExecDestroy(gs_exec);
         if (h_sig) (void)hipHostFree(h_sig);
         if (ev_step0) (void)hipEventDestroy(ev_step0);
         if (ev_step1) (void)hipEventDestroy(ev_step1);
@@ -260,7 +264,7 @@ int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
     const int NB = c->NB;
     const double tol2 = c->pcg_tol * c->pcg_tol;
     const int seq = ++c->solve_seq;
-    hipLaunchKernelGGL(k_cg_resid, dim3(NB), dim3(256), 0, st, A, c->m.p, c->dinv.p, b, x, c->cg_r.p, c->cg_u.p, c->part_b.p, NB,
+    hipLaunchKernelGGL(k_cg_resid, dim3(NB), dim3(256), 0, st, A, c->m.p, c->dinv.p, b, x, c->cg_u.p, c->part_b.p, NB,
                        c->cg_scal.p, seq);
     volatile int *sig = c->h_sig;
     int launched = 0, chunks = 0;
@@ -269,9 +273,9 @@ int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
         for (int it = launched; it < launched + n; ++it) {
             const CgScal *prev = c->cg_scal.p + (it & 1);
             CgScal *next = c->cg_scal.p + ((it + 1) & 1);
-            hipLaunchKernelGGL(k_cg_spmv, dim3(NB), dim3(256), 0, st, A, c->m.p, c->cg_u.p, c->cg_r.p, c->cg_w.p, c->part.p, NB, prev);
-            hipLaunchKernelGGL(k_cg_vec, dim3(c->NBV), dim3(256), 0, st, it, c->n3, NB, c->part.p, c->part_b.p, prev, next, tol2,
-                               c->counters.p, c->dinv.p, c->cg_p.p, c->cg_s.p, x, c->cg_r.p, c->cg_u.p, c->cg_w.p, c->d_sig,
+            hipLaunchKernelGGL(k_cg_spmv, dim3(NB), dim3(256), 0, st, A, c->m.p, c->cg_u.p, c->dinv.p, c->cg_w.p, c->part.p, NB, prev);
+            hipLaunchKernelGGL(k_cg_vec, dim3(c->NBV), dim3(256), 0, st, it, c->nv, NB, c->part.p, c->part_b.p, prev, next, tol2,
+                               c->counters.p, c->dinv.p, c->cg_p.p, c->cg_s.p, x, c->cg_u.p, c->cg_w.p, c->d_sig,
                                (it == launched + n - 1) ? 1 : 0);
         }
         launched += n;
@@ -337,7 +341,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     return 0;
 }
 
-void launch_gs(admm_hip_ctx *c, const double *b, double *x) {
+void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
     hipStream_t st = c->stream;
     (void)hipMemsetAsync(c->counters.p + 1, 0, 2 * sizeof(int), st);
     GsArgs a{};
@@ -357,6 +361,26 @@ void launch_gs(admm_hip_ctx *c, const double *b, double *x) {
         hipLaunchKernelGGL(k_gs_check, dim3(1), dim3(256), 0, st, c->part.p, c->NB, c->gs_tol * c->gs_tol, c->counters.p + 1,
                            c->counters.p + 2, c->counters.p, check);
     }
+}
+
+void launch_gs(admm_hip_ctx *c, const double *b, double *x) {
+    if (c->gs_exec && (c->gs_graph_b != b || c->gs_graph_x != x)) { (void)hipGraphExecDestroy(c->gs_exec); c->gs_exec = nullptr; }
+    if (!c->gs_exec) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            enqueue_gs(c, b, x);
+            if (hipStreamEndCapture(c->stream, &g) == hipSuccess && g &&
+                hipGraphInstantiate(&c->gs_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                c->gs_graph_b = b; c->gs_graph_x = x;
+            } else {
+                c->gs_exec = nullptr;
+            }
+            if (g) (void)hipGraphDestroy(g);
+        }
+        (void)hipGetLastError();
+    }
+    if (c->gs_exec && hipGraphLaunch(c->gs_exec, c->stream) == hipSuccess) return;
+    enqueue_gs(c, b, x); // capture unavailable: plain launches
 }
 
 int validate(const admm_hip_desc *d) {
@@ -570,7 +594,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->curr.alloc(c->n3)); HIP_TRY(c->curr.zero());
     HIP_TRY(c->b.alloc(c->n3)); HIP_TRY(c->b.zero());
     c->NB = std::max(1, (c->A.n_slices + 3) / 4);              // SpMV-type kernels: one SELL slice per wave
-    c->NBV = std::max(1, std::min((c->n3 + 255) / 256, 512));   // streaming vector kernels
+    c->NBV = std::max(1, (c->nv + 255) / 256);                  // vector-update kernel: one vertex per thread
     HIP_TRY(c->cg_r.alloc(c->n3)); HIP_TRY(c->cg_u.alloc(c->n3)); HIP_TRY(c->cg_w.alloc(c->n3));
     HIP_TRY(c->cg_p.alloc(c->n3)); HIP_TRY(c->cg_s.alloc(c->n3));
     HIP_TRY(c->cg_p.zero()); HIP_TRY(c->cg_s.zero());
@@ -589,10 +613,19 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
             }
             for (int i = 0; i < nv; ++i)
                 for (int k = c->Ahat.rowptr[i]; k < c->Ahat.rowptr[i + 1]; ++k)
-                    if (c->Ahat.col[k] != i && c->color_h[c->Ahat.col[k]] == c->color_h[i])
+                    if (c->Ahat.col[k] != i && c->Ahat.val[k] != 0.0 && c->color_h[c->Ahat.col[k]] == c->color_h[i])
                         return fail(ADMM_HIP_ERR_ARG, "gs_colors is not a valid colouring of A");
         } else {
-            c->n_colors = admm_host::greedy_coloring(nv, c->Ahat.rowptr.data(), c->Ahat.col.data(), c->color_h.data());
+            // colour the graph of NON-ZERO couplings: exact zeros do not couple nodes (the sweep skips them,
+            // NodalMultiColorGS.hpp:194) and on structured meshes they would only multiply the colour count
+            std::vector<int32_t> rp(nv + 1, 0), ci;
+            ci.reserve(c->Ahat.col.size());
+            for (int i = 0; i < nv; ++i) {
+                for (int k = c->Ahat.rowptr[i]; k < c->Ahat.rowptr[i + 1]; ++k)
+                    if (c->Ahat.val[k] != 0.0 || c->Ahat.col[k] == i) ci.push_back(c->Ahat.col[k]);
+                rp[i + 1] = (int32_t)ci.size();
+            }
+            c->n_colors = admm_host::greedy_coloring(nv, rp.data(), ci.data(), c->color_h.data());
         }
         c->color_ptr_h.assign(c->n_colors + 1, 0);
         for (int i = 0; i < nv; ++i) c->color_ptr_h[c->color_h[i] + 1]++;
@@ -600,7 +633,15 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         std::vector<int> nodes(nv), pos(c->color_ptr_h.begin(), c->color_ptr_h.end() - 1);
         for (int i = 0; i < nv; ++i) nodes[pos[c->color_h[i]]++] = i;
         HIP_TRY(c->color_nodes.upload(nodes));
-        HIP_TRY(c->csr_rowptr.upload(c->Ahat.rowptr)); HIP_TRY(c->csr_col.upload(c->Ahat.col)); HIP_TRY(c->csr_val.upload(c->Ahat.val));
+        {   // the sweep kernel reads a CSR without the exact zeros (the reference skips them at run time)
+            std::vector<int32_t> rp(nv + 1, 0), ci; std::vector<double> va;
+            for (int i = 0; i < nv; ++i) {
+                for (int k = c->Ahat.rowptr[i]; k < c->Ahat.rowptr[i + 1]; ++k)
+                    if (c->Ahat.val[k] != 0.0 || c->Ahat.col[k] == i) { ci.push_back(c->Ahat.col[k]); va.push_back(c->Ahat.val[k]); }
+                rp[i + 1] = (int32_t)ci.size();
+            }
+            HIP_TRY(c->csr_rowptr.upload(rp)); HIP_TRY(c->csr_col.upload(ci)); HIP_TRY(c->csr_val.upload(va));
+        }
     }
     if (d->linsolver == 2) {
         c->NBU = std::max(1, std::min((nv + 255) / 256, 256));
@@ -651,6 +692,7 @@ int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const dou
             for (int j = 0; j < 3; ++j) p[3 * (size_t)vert[i] + j] = xyz[3 * (size_t)i + j];
         }
         c->gs_has_pins = n > 0;
+        if (c->gs_exec) { (void)hipGraphExecDestroy(c->gs_exec); c->gs_exec = nullptr; } // pin pointer is baked into the graph
         HIP_TRY(hipMemcpy(c->gs_pin_flag.p, flag.data(), flag.size() * sizeof(int), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->gs_pin_xyz.p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));
         return ADMM_HIP_OK;

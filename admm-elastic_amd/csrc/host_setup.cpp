@@ -91,15 +91,21 @@ Csr assemble_Ahat(int32_t n_verts, double dt,
     return A;
 }
 
+// Entries that are exactly 0.0 (structural cancellation, e.g. the face/body diagonals of a Kuhn
+// triangulation: 8 of 15 entries per row) are not stored; the diagonal always is.
 Sell csr_to_sell(const Csr &A) {
     Sell S;
     S.n_rows = A.n;
     S.n_slices = (A.n + 63) / 64;
     S.slice_ptr.assign(S.n_slices + 1, 0);
     S.slice_width.assign(S.n_slices, 0);
+    auto keep = [&](int32_t r, int32_t k) { return A.val[k] != 0.0 || A.col[k] == r; };
+    std::vector<int32_t> len(A.n, 0);
+    for (int32_t r = 0; r < A.n; ++r)
+        for (int32_t k = A.rowptr[r]; k < A.rowptr[r + 1]; ++k) len[r] += keep(r, k) ? 1 : 0;
     for (int32_t s = 0; s < S.n_slices; ++s) {
         int32_t w = 0;
-        for (int32_t r = 64 * s; r < std::min(A.n, 64 * s + 64); ++r) w = std::max(w, A.rowptr[r + 1] - A.rowptr[r]);
+        for (int32_t r = 64 * s; r < std::min(A.n, 64 * s + 64); ++r) w = std::max(w, len[r]);
         w = std::max(4, (w + 3) / 4 * 4); // kernels consume 4 entries per software-pipelined round
         S.slice_width[s] = w;
         S.slice_ptr[s + 1] = S.slice_ptr[s] + 64 * w;
@@ -110,11 +116,17 @@ Sell csr_to_sell(const Csr &A) {
         for (int32_t l = 0; l < 64; ++l) {
             const int32_t r = 64 * s + l;
             const int32_t rr = std::min(r, A.n - 1);
-            const int32_t len = (r < A.n) ? A.rowptr[r + 1] - A.rowptr[r] : 0;
-            for (int32_t k = 0; k < S.slice_width[s]; ++k) {
+            int32_t k = 0;
+            if (r < A.n)
+                for (int32_t q = A.rowptr[r]; q < A.rowptr[r + 1]; ++q) {
+                    if (!keep(r, q)) continue;
+                    const size_t o = (size_t)S.slice_ptr[s] + 64 * k + l;
+                    S.idx[o] = A.col[q]; S.val[o] = A.val[q];
+                    ++k;
+                }
+            for (; k < S.slice_width[s]; ++k) { // padding: harmless self reference, zero value
                 const size_t o = (size_t)S.slice_ptr[s] + 64 * k + l;
-                if (k < len) { S.idx[o] = A.col[A.rowptr[r] + k]; S.val[o] = A.val[A.rowptr[r] + k]; }
-                else { S.idx[o] = rr; S.val[o] = 0.0; } // padding: harmless self reference, zero value
+                S.idx[o] = rr; S.val[o] = 0.0;
             }
         }
     return S;

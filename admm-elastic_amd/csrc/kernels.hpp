@@ -365,10 +365,11 @@ __device__ __forceinline__ void sell_row(const SellA &A, int s, int lane, const 
     }
 }
 
-// r = b - A x ; u = dinv r ; partial_b[3][NB] = sum b * dinv * b
+// u = dinv (b - A x) ; partial_b[3][NB] = sum b * dinv * b.   The residual r itself is never stored: the
+// iteration carries only u = M^-1 r (r = u / dinv), which saves two vector passes per iteration.
 __global__ __launch_bounds__(256) void k_cg_resid(SellA A, const double *__restrict__ m, const double *__restrict__ dinv,
                                                   const double *__restrict__ b, const double *__restrict__ x,
-                                                  double *__restrict__ r, double *__restrict__ u,
+                                                  double *__restrict__ u,
                                                   double *__restrict__ part_b, int NB, CgScal *__restrict__ sc0, int seq) {
     __shared__ double lds[12];
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc0->converged = 0; sc0->iters = 0; sc0->seq = seq; }
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void k_cg_resid(SellA A, const double *__restr
                 const size_t i = 3 * (size_t)row + j;
                 const double bi = b[i], di = dinv[i];
                 const double ri = bi - fma(m[i], x[i], acc[j]);
-                r[i] = ri; u[i] = di * ri;
+                u[i] = di * ri;
                 q[j] = fma(bi * di, bi, q[j]);
             }
         }
@@ -394,9 +395,9 @@ __global__ __launch_bounds__(256) void k_cg_resid(SellA A, const double *__restr
     if (threadIdx.x == 0) { part_b[blockIdx.x] = q[0]; part_b[NB + blockIdx.x] = q[1]; part_b[2 * NB + blockIdx.x] = q[2]; }
 }
 
-// w = A u ; partials gamma = r.u, delta = w.u   (skipped when the solve has converged)
+// w = A u ; partials gamma = r.u = sum u^2 / dinv, delta = w.u   (skipped when the solve has converged)
 __global__ __launch_bounds__(256) void k_cg_spmv(SellA A, const double *__restrict__ m, const double *__restrict__ u,
-                                                 const double *__restrict__ r, double *__restrict__ w,
+                                                 const double *__restrict__ dinv, double *__restrict__ w,
                                                  double *__restrict__ part, int NB, const CgScal *__restrict__ sc) {
     __shared__ double lds[24];
     if (sc->converged) return;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(256) void k_cg_spmv(SellA A, const double *__restri
                 const double ui = u[i];
                 const double wi = fma(m[i], ui, acc[j]);
                 w[i] = wi;
-                q[j] = fma(r[i], ui, q[j]);
+                q[j] = fma(ui * ui, fast_rcp(dinv[i]), q[j]);
                 q[3 + j] = fma(wi, ui, q[3 + j]);
             }
         }
@@ -426,12 +427,14 @@ __global__ __launch_bounds__(256) void k_cg_spmv(SellA A, const double *__restri
     }
 }
 
-// reduce the partials, derive alpha/beta, update p, s, x, r, u
-__global__ __launch_bounds__(256) void k_cg_vec(int it, int n3, int NB, const double *__restrict__ part,
+// reduce the partials, derive alpha/beta, update p, s, x, u.   One vertex (3 dofs) per thread; the
+// thread's own vector entries are loaded BEFORE the partial-sum reduction so that the reduction's latency
+// (every block re-reduces the <= ~700 SpMV partials; deterministic, no atomics) hides behind those loads.
+__global__ __launch_bounds__(256) void k_cg_vec(int it, int nv, int NB, const double *__restrict__ part,
                                                 const double *__restrict__ part_b, const CgScal *__restrict__ prev,
                                                 CgScal *__restrict__ next, double tol2, int *__restrict__ total_iters,
                                                 const double *__restrict__ dinv, double *__restrict__ p,
-                                                double *__restrict__ s, double *__restrict__ x, double *__restrict__ r,
+                                                double *__restrict__ s, double *__restrict__ x,
                                                 double *__restrict__ u, const double *__restrict__ w,
                                                 int *__restrict__ sig, int mark_here) {
     __shared__ double lds[36];
@@ -445,13 +448,23 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int n3, int NB, const do
         if (blockIdx.x == 0 && threadIdx.x == 0) *next = pv;
         return;
     }
+    const int v = xcd_block() * 256 + threadIdx.x;   // same XCD <-> row-range affinity as the SpMV
+    const bool live = v < nv;
+    const size_t i0 = 3 * (size_t)(live ? v : 0);
+    double ru[3], rw[3], rp[3], rs[3], rx[3], rd[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ru[a] = u[i0 + a]; rw[a] = w[i0 + a]; rx[a] = x[i0 + a]; rd[a] = dinv[i0 + a];
+        rp[a] = (it == 0) ? 0.0 : p[i0 + a];
+        rs[a] = (it == 0) ? 0.0 : s[i0 + a];
+    }
     double q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < NB; i += 256) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) q[k] += part[k * NB + i];
+        for (int kk = 0; kk < 6; ++kk) q[kk] += part[kk * NB + i];
         if (it == 0) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) q[6 + k] += part_b[k * NB + i];
+            for (int kk = 0; kk < 3; ++kk) q[6 + kk] += part_b[kk * NB + i];
         }
     }
     block_sum<9>(q, lds);
@@ -496,16 +509,14 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int n3, int NB, const do
         *next = o;
         atomicAdd(total_iters, 1);
     }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n3; i += gridDim.x * 256) {
-        const int a = i % 3;
-        const double be = beta[a], al = alpha[a];
-        const double pi = (it == 0) ? u[i] : fma(be, p[i], u[i]);
-        const double si = (it == 0) ? w[i] : fma(be, s[i], w[i]);
-        p[i] = pi; s[i] = si;
-        x[i] = fma(al, pi, x[i]);
-        const double ri = fma(-al, si, r[i]);
-        r[i] = ri;
-        u[i] = dinv[i] * ri;
+    if (!live) return;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double pi = fma(beta[a], rp[a], ru[a]);
+        const double si = fma(beta[a], rs[a], rw[a]);
+        p[i0 + a] = pi; s[i0 + a] = si;
+        x[i0 + a] = fma(alpha[a], pi, rx[a]);
+        u[i0 + a] = fma(-alpha[a] * rd[a], si, ru[a]);     // u = M^-1 (r - alpha s)
     }
 }
 
