@@ -30,6 +30,9 @@ WORKLOADS = {
     "cube1m_mix": dict(n=55, kinds="mix", linsolver=0, admm_iters=20),
     "cube1m_nh": dict(n=55, kinds="nh", linsolver=0, admm_iters=20),
     "cube100k_gs": dict(n=26, kinds="nh", linsolver=1, admm_iters=20),
+    # configs[4]: 316 x 316-cell cloth (199 712 tris), Lame(100, 0.1) with strain limits 0.95/1.05, two corner
+    # pins, Floor, multi-colour GS with in-sweep pins and plane projection, 10 ADMM iters/step
+    "cloth200k_gs_floor": dict(n=316, kinds="cloth", linsolver=1, admm_iters=10),
     "cube1m_linear": dict(n=55, kinds="linear", linsolver=0, admm_iters=20),   # diagnostic: cheapest prox
     "cube1m_stvk": dict(n=55, kinds="stvk", linsolver=0, admm_iters=20),
 }
@@ -41,6 +44,9 @@ def build_scene(w, n_override=None):
     from admm_elastic_amd.solver import Lame
     import scenes
     n = n_override or w["n"]
+    if w["kinds"] == "cloth":
+        sc = scenes.cloth_scene(n, limits=(0.95, 1.05), floor=0.3, admm_iters=w["admm_iters"], linsolver=w["linsolver"])
+        return sc, len(sc.tris[0][1]), len(sc.x)
     verts, tets = meshes.kuhn_cube(n)
     sc = scenes.Scene()
     sc.x = verts
@@ -68,7 +74,7 @@ def cpu_baseline(w, budget_s=12.0):
     from oracle import oracle as orc
     import scenes  # noqa: F401
     cores = os.cpu_count() or 1
-    n_s = min(w["n"], 20)  # 48 000 tets: the sample
+    n_s = min(w["n"], 20 if w["kinds"] != "cloth" else 100)  # the sample: 48 000 tets / 20 000 tris
     sc, nt, nv = build_scene(w, n_override=n_s)
     sc.settings["admm_iters"] = 5
     colors = None
@@ -200,7 +206,7 @@ def main():
         "metric": "ADMM iterations/sec", "value": value, "unit": "ADMM it/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": args.workload + (" (n=%d override)" % args.n if args.n else ""), "tets": nt, "verts": nv,
+        "config": {"workload": args.workload + (" (n=%d override)" % args.n if args.n else ""), "elements": nt, "verts": nv,
                    "admm_iters_per_step": iters, "global_solver": "multicolor-GS(30 sweeps)" if w["linsolver"] == 1 else
                    "Jacobi-PCG tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters),
                    "parallelism": "element-block x%d" % world if world > 1 else "single-gpu"},
@@ -215,10 +221,10 @@ def main():
             # dominant single kernel = the per-tet prox kernel (local step).  ALGORITHMIC bytes per tet per
             # ADMM iteration: 16 idx + 72 Binv + 72 u read + 72 u write + 72 z write + 24 nv/nt.
             launches = iters * args.steps
-            bytes_per_launch = (304.0 + 24.0 * nv / nt) * nt
+            bytes_per_launch = ((188.0 if w["kinds"] == "cloth" else 304.0) + 24.0 * nv / nt) * nt
             avg_s = 1e-3 * local_ms / launches
             achieved = bytes_per_launch / avg_s / 1e9
-            out["roofline"] = {"kernel": "k_local_tets (all constitutive models of one ADMM iteration)", "bound": "hbm",
+            out["roofline"] = {"kernel": "k_local_tris" if w["kinds"] == "cloth" else "k_local_tets (all constitutive models of one ADMM iteration)", "bound": "hbm",
                                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": pmc_traffic(args.workload), "avg_launch_us": 1e6 * avg_s,
                                "algorithmic_bytes_per_launch": bytes_per_launch}

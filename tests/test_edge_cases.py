@@ -1,0 +1,112 @@
+"""Edge cases the reference guards (or would crash on): empty / minimal scenes, ragged term mixes,
+degenerate elements, error paths.  GPU-marked where a context is needed."""
+import numpy as np
+import pytest
+
+import admm_elastic_amd as pkg
+from admm_elastic_amd import capi, meshes
+from admm_elastic_amd.solver import Lame, Settings, Solver
+from oracle import oracle as orc
+import scenes
+
+
+def test_oracle_prox_degenerate_elements():
+    """collapsed-to-a-point and flat deformation gradients go through the reference's fix-ups
+    (TetEnergyTerm.cpp:128-133) without NaNs"""
+    mu, la, k = orc.lame(1e6, 0.3)
+    for F in (np.zeros((3, 3)), np.diag([1.0, 1.0, 0.0]), np.diag([1.0, 1e-9, -1e-9]), 1e-9 * np.ones((3, 3))):
+        for kind in (1, 2, 3):
+            z = np.ascontiguousarray(F.T).ravel().copy()
+            orc.lib().orc_prox_tet_hyper(kind, mu, la, k, orc._p(z), 1)
+            assert np.isfinite(z).all()
+        z = np.ascontiguousarray(F.T).ravel().copy()
+        orc.lib().orc_prox_tet_linear(orc._p(z))
+        assert np.isfinite(z).all()
+
+
+def test_host_helpers_accept_empty_inputs():
+    B, v = capi.tet_rest(np.zeros((4, 3)), np.zeros((0, 4), np.int32))
+    assert B.shape == (0, 9) and v.shape == (0,)
+    R, a = capi.tri_rest(np.zeros((3, 3)), np.zeros((0, 3), np.int32))
+    assert R.shape == (0, 4)
+    assert capi.partition(0, 4, 2) == (0, 0)
+
+
+@pytest.mark.gpu
+def test_scene_without_energy_terms_is_free_fall():
+    """no terms: A = M, every solve returns x_bar (the reference would do the same with an empty D)"""
+    s = Solver()
+    x = np.random.default_rng(0).standard_normal((5, 3))
+    s.add_nodes(x, np.ones(15))
+    assert s.initialize(Settings(gravity=-9.8, admm_iters=3, linsolver=0))
+    s.step()
+    dt = 1.0 / 24.0
+    assert np.allclose(s.m_x.reshape(-1, 3)[:, 1], x[:, 1] + dt * dt * -9.8, atol=1e-12)
+    assert np.allclose(s.m_x.reshape(-1, 3)[:, [0, 2]], x[:, [0, 2]], atol=1e-12)
+    assert s.num_rows() == 0
+
+
+@pytest.mark.gpu
+def test_single_element_scenes_and_zero_iterations():
+    for kind in (pkg.TET_LINEAR, pkg.TET_NEOHOOKEAN, pkg.TET_STVK, pkg.TET_SPLINE_NH):
+        s = Solver()
+        verts = np.array([[0, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 0]], float)
+        s.add_nodes(verts, np.ones(12))
+        s.add_tets(verts, [[0, 1, 2, 3]], Lame.soft_rubber(), kind)
+        assert s.initialize(Settings(gravity=0.0, admm_iters=0))
+        s.step()                       # zero ADMM iterations: x = x_bar = x
+        assert np.allclose(s.m_x, verts.ravel())
+        s.close()
+
+
+@pytest.mark.gpu
+def test_ragged_mix_of_all_term_types():
+    """tets of every model + triangles + pins + unused vertices in one scene (ragged SELL slices,
+    isolated rows) against the oracle"""
+    sc = scenes.mixed_cube_scene(3, admm_iters=6, linsolver=0)
+    v2, tris = meshes.cloth_grid(3, 0.7, 1.4)
+    sc.add_tri_mesh(v2, tris, Lame(100.0, 0.1))
+    sc.x = np.concatenate([sc.x, np.array([[5.0, 5.0, 5.0], [6.0, 5.0, 5.0]])])   # two isolated nodes
+    sc.m = np.concatenate([sc.m, [0.3, 0.4]])
+    s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=300)
+    o = sc.make_oracle()
+    for _ in range(3):
+        s.step(); o.step()
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7
+
+
+@pytest.mark.gpu
+def test_degenerate_deformations_through_the_kernel():
+    """collapsed / flat / inverted inputs: finite outputs that match the oracle where the problem is
+    well-posed (linear + NH), finite everywhere"""
+    sc = scenes.cube_scene(2, pkg.TET_NEOHOOKEAN, pin_face=False)
+    s = sc.make_solver()
+    o = sc.make_oracle(mode=1)
+    R = o.R
+    x = sc.x.copy()
+    x[:, 2] = 0.0                       # flatten the whole mesh into a plane
+    z, u = s.local_step(x.ravel(), np.zeros(R))
+    assert np.isfinite(z).all() and np.isfinite(u).all()
+    x = np.zeros_like(sc.x)             # collapse to a point
+    z, u = s.local_step(x.ravel(), np.zeros(R))
+    assert np.isfinite(z).all() and np.isfinite(u).all()
+    x = -sc.x                           # point reflection: every tet inverted
+    z, u = s.local_step(x.ravel(), np.zeros(R))
+    zo = np.zeros(R); uo = np.zeros(R)
+    o.local_step(x.ravel(), zo, uo)
+    assert np.abs(z - zo).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_error_paths_keep_the_reference_messages():
+    sc = scenes.cube_scene(2, pkg.TET_LINEAR)
+    s = sc.make_solver()
+    with pytest.raises(pkg.AdmmHipError, match="Constraint for"):
+        s.set_pins([26], [np.zeros(3)])       # vertex 26 (x = 1 face) was never a pin: Solver.cpp:147-151
+    s2 = Solver()
+    with pytest.raises(pkg.AdmmHipError, match="not initialized"):
+        s2.step_device()
+    bad = scenes.cube_scene(2, pkg.TET_LINEAR)
+    bad.m[:] = 0.0
+    with pytest.raises(pkg.AdmmHipError, match="mass"):
+        bad.make_solver()
