@@ -165,6 +165,15 @@ struct admm_hip_ctx {
     int solve_seq = 0;
     int marks_expected = 0;       // chunks closed so far (host count)
     int last_launched_iters = 0;
+    // recycled warm start (k_rc_*): ring of kRc (correction, initial residual) pairs
+    // Pairs are kept per (frame parity, ADMM iteration index) -- 2 x kRcSlots x 2 vectors, sized for 288 GB
+    // of HBM rather than for a cache; the projection basis of solve s is the last kRc pairs of the frame.
+    static constexpr int kRcSlots = 64;
+    DevBuf<double> rc_buf, rc_r0, rc_xs, rc_part, rc_coef;
+    int rc_iter = 0, rc_frame = 0, rc_prev_valid = 0, NBR = 1; // pairs of the previous frame valid for s < rc_prev_valid
+    bool rc_enabled = true;
+    double *rc_E(int parity, int s) { return rc_buf.p + ((size_t)(parity * kRcSlots + s) * 2 + 0) * (size_t)n3; }
+    double *rc_R(int parity, int s) { return rc_buf.p + ((size_t)(parity * kRcSlots + s) * 2 + 1) * (size_t)n3; }
     // UzawaCG (per-vertex constraint rows)
     DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part;
     DevBuf<UzScal> uz_scal;
@@ -191,6 +200,7 @@ struct admm_hip_ctx {
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release();
+        rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
@@ -295,6 +305,29 @@ int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
     return 0;
 }
 
+// The ADMM global solve with the recycled (Galerkin) warm start around the PCG.
+int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
+    const int s = c->rc_iter;
+    if (!c->rc_enabled || s >= admm_hip_ctx::kRcSlots) return launch_pcg(c, b, x, c->pcg_max_iters);
+    hipStream_t st = c->stream;
+    const int par = c->rc_frame & 1;
+    RcBasis B{};
+    // basis: the (up to) kRc most recent pairs of THIS frame.  (Adding the previous frame's pair at the same
+    // index was measured: it does not help the first solves of a frame.)
+    for (int j = 1; j <= kRc && s - j >= 0; ++j) { B.E[B.cnt] = c->rc_E(par, s - j); B.R[B.cnt] = c->rc_R(par, s - j); ++B.cnt; }
+    hipLaunchKernelGGL(k_rc_resid, dim3(c->NB), dim3(256), 0, st, sell_arg(c->A), c->m.p, b, x, c->rc_r0.p, c->rc_xs.p);
+    if (B.cnt > 0) {
+        hipLaunchKernelGGL(k_rc_dots, dim3(c->NBR), dim3(256), 0, st, c->nv, B, c->rc_r0.p, b, c->dinv.p, c->rc_part.p, c->NBR);
+        hipLaunchKernelGGL(k_rc_solve, dim3(1), dim3(128), 0, st, B.cnt, c->rc_part.p, c->NBR, c->pcg_tol * c->pcg_tol, c->rc_coef.p);
+        hipLaunchKernelGGL(k_rc_apply, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, B, c->rc_coef.p, x);
+    }
+    const int rc = launch_pcg(c, b, x, c->pcg_max_iters);
+    hipLaunchKernelGGL(k_rc_record, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, x, c->rc_xs.p, c->rc_r0.p, c->cg_u.p, c->dinv.p,
+                       c->rc_E(par, s), c->rc_R(par, s));
+    c->rc_iter = s + 1;
+    return rc;
+}
+
 // UzawaCG::solve (src/UzawaCG.hpp:57-125).  Host-driven outer loop (one stream sync per Schur-CG
 // iteration, negligible next to the inner solves); returns the reference's iteration count via *iters.
 int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
@@ -315,7 +348,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
         if (hipMemsetAsync(c->uz_y.p, 0, nv * sizeof(double), st) != hipSuccess) return -1;
         c->uz_prev_hits = nh;
     }
-    if (nh == 0) return launch_pcg(c, b, x, c->pcg_max_iters); // no constraints: one prefactored solve (:78-81)
+    if (nh == 0) return launch_pcg_recycled(c, b, x); // no constraints: one prefactored solve (:78-81)
     hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 0, b, c->uz_cn.p, c->uz_y.p, c->uz_q1.p);       // q1 = b - C^T y
     if (launch_pcg(c, c->uz_q1.p, x, c->pcg_max_iters)) return -1;                                               // x = A^-1 q1
     hipLaunchKernelGGL(k_uz_resid, dim3(gv), dim3(256), 0, st, nv, x, c->uz_cn.p, c->uz_cc.p, c->uz_r.p, c->uz_d.p);
@@ -600,7 +633,15 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->cg_p.zero()); HIP_TRY(c->cg_s.zero());
     HIP_TRY(c->part.alloc(6 * (size_t)c->NB)); HIP_TRY(c->part_b.alloc(3 * (size_t)c->NB));
     HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
-    HIP_TRY(c->counters.alloc(8)); HIP_TRY(c->counters.zero());
+    HIP_TRY(c->counters.alloc(8 + 64)); HIP_TRY(c->counters.zero());
+    if (d->linsolver != 1) {
+        const char *env = getenv("ADMM_HIP_NO_RECYCLE");
+        c->rc_enabled = !(env && env[0] == '1');
+        c->NBR = std::max(1, std::min((nv + 255) / 256, 256));
+        HIP_TRY(c->rc_buf.alloc((size_t)2 * admm_hip_ctx::kRcSlots * 2 * c->n3));
+        HIP_TRY(c->rc_r0.alloc(c->n3)); HIP_TRY(c->rc_xs.alloc(c->n3));
+        HIP_TRY(c->rc_part.alloc((size_t)3 * kRcQ * c->NBR)); HIP_TRY(c->rc_coef.alloc(3 * kRc)); HIP_TRY(c->rc_coef.zero());
+    }
 
     if (d->linsolver == 1) {
         c->color_h.resize(nv);
@@ -725,7 +766,7 @@ static int launch_global(admm_hip_ctx *c, const double *b, double *x) {
         c->uz_iters_step += it;
         return rc;
     }
-    return launch_pcg(c, b, x, c->pcg_max_iters);
+    return launch_pcg_recycled(c, b, x);
 }
 
 int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_stats *stats) {
@@ -745,6 +786,7 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
     HIP_TRY(hipEventRecord(c->ev_step0, st));
     // counters[5] (closed chunks) must stay monotone across steps: only [0..4] are reset
     c->uz_iters_step = 0;
+    c->rc_prev_valid = c->rc_iter; c->rc_frame += 1; c->rc_iter = 0;   // this frame's pairs become "previous frame"
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
     hipLaunchKernelGGL(k_predict, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, c->dt, gravity, c->x.p, c->v.p, c->m.p,
                        c->Mxbar.p, c->curr.p);
@@ -795,6 +837,12 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
             stats->inner_iters = h[0];
             stats->last_solve_converged = sc[c->last_launched_iters & 1].converged;
             stats->unconverged_solves = admm_iters - h[4];
+            {   // iterations of the last (up to 64) solves of this step, oldest first
+                int ring[64];
+                HIP_TRY(hipMemcpy(ring, c->counters.p + 8, sizeof(ring), hipMemcpyDeviceToHost));
+                const int n = std::min(admm_iters, 64);
+                for (int i = 0; i < n; ++i) stats->pcg_iters_per_solve[i] = ring[(c->solve_seq - n + 1 + i) & 63];
+            }
             stats->pcg_launched_iters = c->last_launched_iters;
         }
     }
@@ -870,6 +918,7 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     HIP_TRY(hipMemcpyAsync(c->b.p, b, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->curr.p, x_inout, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
     c->uz_iters_step = 0;
+    c->rc_prev_valid = 0; c->rc_frame += 1; c->rc_iter = 0;   // stand-alone solve: nothing to recycle
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
     if (launch_global(c, c->b.p, c->curr.p)) return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     HIP_TRY(hipGetLastError());

@@ -485,6 +485,7 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int nv, int NB, const do
             *next = o;
             atomicAdd(total_iters + 4, 1);        // solves that met the residual test
             atomicMax(total_iters + 3, o.iters);  // most iterations any solve of this step needed
+            total_iters[8 + (pv.seq & 63)] = o.iters; // per-solve log (ring of 64)
             __hip_atomic_store(sig, pv.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); // tell the host
         }
         return;
@@ -518,6 +519,156 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int nv, int NB, const do
         x[i0 + a] = fma(alpha[a], pi, rx[a]);
         u[i0 + a] = fma(-alpha[a] * rd[a], si, ru[a]);     // u = M^-1 (r - alpha s)
     }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RECYCLED WARM START.  ADMM converges linearly, so the correction e_s = x_{s+1} - x_s of one global solve
+// is almost a combination of the previous ones.  With A e_j = r0_j known for free (r0_j = the initial
+// residual of solve j), the A-orthogonal (Galerkin) projection of the new error onto span{e_j} is
+//     x <- x + sum_j c_j e_j,   (E^T R) c = E^T r0,   G_ij = e_i . r0_j  (= e_i^T A e_j),
+// done per axis (the three axes are independent systems).  It cuts the initial PCG residual by 2-3 decades
+// in the later ADMM iterations of a frame.  Purely an initial guess: the PCG still iterates to pcg_tol.
+constexpr int kRc = 4; // recycled pairs in one projection
+struct RcBasis { const double *E[kRc]; const double *R[kRc]; int cnt; };
+
+// r0 = b - A x ; xs = x
+__global__ __launch_bounds__(256) void k_rc_resid(SellA A, const double *__restrict__ m, const double *__restrict__ b,
+                                                  const double *__restrict__ x, double *__restrict__ r0, double *__restrict__ xs) {
+    const int lane = threadIdx.x & 63;
+    const int s = wave_slice();
+    if (s >= A.n_slices) return;
+    const int row = s * 64 + lane;
+    double acc[3];
+    sell_row(A, s, lane, x, acc);
+    if (row < A.n_rows) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const size_t i = 3 * (size_t)row + j;
+            const double xi = x[i];
+            r0[i] = b[i] - fma(m[i], xi, acc[j]);
+            xs[i] = xi;
+        }
+    }
+}
+
+// partial sums (per axis) of G_ij = E_i . R_j and g_i = E_i . r0 for the `cnt` stored pairs
+// (+ the preconditioned norms of r0 and b, so that the projection can be skipped when r0 already meets pcg_tol)
+constexpr int kRcQ = kRc * kRc + kRc + 2;
+__global__ __launch_bounds__(256) void k_rc_dots(int nv, RcBasis B, const double *__restrict__ r0, const double *__restrict__ b,
+                                                 const double *__restrict__ dinv, double *__restrict__ part, int NBr) {
+    const int cnt = B.cnt;
+    __shared__ double lds[4 * kRcQ];
+    double q[3][kRcQ];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int i = 0; i < kRcQ; ++i) q[a][i] = 0.0;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const size_t i = 3 * (size_t)v + a;
+            double e[kRc], r[kRc];
+#pragma unroll
+            for (int j = 0; j < kRc; ++j) { e[j] = (j < cnt) ? B.E[j][i] : 0.0; r[j] = (j < cnt) ? B.R[j][i] : 0.0; }
+            const double rr = r0[i], bb = b[i], di = dinv[i];
+            q[a][20] = fma(rr * di, rr, q[a][20]);
+            q[a][21] = fma(bb * di, bb, q[a][21]);
+#pragma unroll
+            for (int ii = 0; ii < kRc; ++ii) {
+#pragma unroll
+                for (int jj = 0; jj < kRc; ++jj) q[a][ii * kRc + jj] = fma(e[ii], r[jj], q[a][ii * kRc + jj]);
+                q[a][16 + ii] = fma(e[ii], rr, q[a][16 + ii]);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        block_sum<kRcQ>(q[a], lds);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < kRcQ; ++i) part[(size_t)(a * kRcQ + i) * NBr + blockIdx.x] = q[a][i];
+        }
+    }
+}
+
+// one block: finish the sums, solve the three cnt x cnt systems (symmetrised Cholesky that SKIPS numerically
+// null or dependent directions).  If r0 already meets pcg_tol on every axis the coefficients are exactly
+// zero: in a stationary state the stored pairs are round-off and must not perturb the iterate.
+__global__ __launch_bounds__(128) void k_rc_solve(int cnt, const double *__restrict__ part, int NBr, double tol2, double *__restrict__ coef) {
+    __shared__ double sums[3 * kRcQ];
+    __shared__ int skip;
+    const int t = threadIdx.x;
+    if (t < 3 * kRcQ) {
+        double s = 0.0;
+        for (int i = 0; i < NBr; ++i) s += part[(size_t)t * NBr + i];
+        sums[t] = s;
+    }
+    __syncthreads();
+    if (t == 0) {
+        bool conv = true;
+        for (int a = 0; a < 3; ++a) conv = conv && (sums[a * kRcQ + 20] <= tol2 * sums[a * kRcQ + 21] + 1e-300);
+        skip = conv ? 1 : 0;
+    }
+    __syncthreads();
+    if (t < 3) {
+        const double *S = sums + kRcQ * t;
+        double G[kRc][kRc], g[kRc], c[kRc] = {0, 0, 0, 0};
+        double gmax = 0.0;
+        for (int i = 0; i < cnt; ++i) {
+            g[i] = S[16 + i];
+            for (int j = 0; j < cnt; ++j) G[i][j] = 0.5 * (S[i * kRc + j] + S[j * kRc + i]);
+            gmax = fmax(gmax, G[i][i]);
+        }
+        // Cholesky over the usable directions only (a skipped direction gets a zero coefficient)
+        double L[kRc][kRc];
+        int use[kRc], n = 0; // indices of accepted directions
+        if (!skip && gmax > 0.0) {
+            for (int i = 0; i < cnt; ++i) {
+                if (!(G[i][i] > 1e-12 * gmax)) continue;        // numerically null pair
+                double row[kRc];
+                double d = G[i][i];
+                for (int k2 = 0; k2 < n; ++k2) {
+                    double v = G[i][use[k2]];
+                    for (int k3 = 0; k3 < k2; ++k3) v -= row[k3] * L[k2][k3];
+                    row[k2] = v / L[k2][k2];
+                    d -= row[k2] * row[k2];
+                }
+                if (!(d > 1e-10 * G[i][i])) continue;           // dependent on the accepted ones
+                for (int k2 = 0; k2 < n; ++k2) L[n][k2] = row[k2];
+                L[n][n] = sqrt(d);
+                use[n++] = i;
+            }
+        }
+        double y[kRc], cc[kRc];
+        for (int i = 0; i < n; ++i) { double v = g[use[i]]; for (int k2 = 0; k2 < i; ++k2) v -= L[i][k2] * y[k2]; y[i] = v / L[i][i]; }
+        for (int i = n - 1; i >= 0; --i) { double v = y[i]; for (int k2 = i + 1; k2 < n; ++k2) v -= L[k2][i] * cc[k2]; cc[i] = v / L[i][i]; }
+        for (int i = 0; i < n; ++i) c[use[i]] = (cc[i] == cc[i]) ? cc[i] : 0.0;
+        for (int i = 0; i < kRc; ++i) coef[t * kRc + i] = c[i];
+    }
+}
+
+// x += sum_j c_j E_j
+__global__ __launch_bounds__(256) void k_rc_apply(int n3, RcBasis B, const double *__restrict__ coef, double *__restrict__ x) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    const int a = i % 3;
+    double acc = x[i];
+#pragma unroll
+    for (int j = 0; j < kRc; ++j)
+        if (j < B.cnt) acc = fma(coef[a * kRc + j], B.E[j][i], acc);
+    x[i] = acc;
+}
+
+// after the solve: store the pair (e = x - xs, A e) in a ring slot.  A e = r0 - r_final exactly, and the PCG
+// carries r_final = u / dinv, so the pair is exact (up to round-off) even though the solve stopped at pcg_tol.
+__global__ __launch_bounds__(256) void k_rc_record(int n3, const double *__restrict__ x, const double *__restrict__ xs,
+                                                   const double *__restrict__ r0, const double *__restrict__ u,
+                                                   const double *__restrict__ dinv, double *__restrict__ Eslot,
+                                                   double *__restrict__ Rslot) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    Eslot[i] = x[i] - xs[i];
+    Rslot[i] = r0[i] - u[i] * fast_rcp(dinv[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------

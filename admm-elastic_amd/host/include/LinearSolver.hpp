@@ -30,7 +30,7 @@ protected:
 class LDLTSolver : public LinearSolver {
 public:
     int pcg_max_iters; double pcg_tol;
-    LDLTSolver() : pcg_max_iters(500), pcg_tol(1e-10) {}
+    LDLTSolver() : pcg_max_iters(500), pcg_tol(1e-12) {} // stands for an exact factorisation: converge tightly
     int kind() const { return 0; }
 };
 

@@ -81,6 +81,7 @@ class RuntimeData:
         self.rhs_ms = 0.0
         self.unconverged_solves = 0
         self.pcg_launched_iters = 0
+        self.pcg_iters_per_solve = []
 
 
 class Floor:
@@ -285,6 +286,7 @@ class Solver:
             r.global_ms, r.local_ms, r.collision_ms = st.global_ms, st.local_ms, st.collision_ms
             r.inner_iters, r.step_ms, r.last_solve_converged = st.inner_iters, st.step_ms, st.last_solve_converged
             r.rhs_ms, r.unconverged_solves, r.pcg_launched_iters = st.rhs_ms, st.unconverged_solves, st.pcg_launched_iters
+            r.pcg_iters_per_solve = list(st.pcg_iters_per_solve)[:min(it, 64)]
         else:
             check(lib().admm_hip_step(self._ctx, it, s.gravity, None))
 

@@ -127,6 +127,7 @@ typedef struct {
     double rhs_ms;                /* part of global_ms spent assembling b = M x_bar + dt^2 D^T W^2 (z-u) */
     int32_t unconverged_solves;   /* PCG solves of this step that did not meet pcg_tol (0 = every solve converged) */
     int32_t pcg_launched_iters;   /* PCG iterations launched for the last solve (converged ones exit early on the device) */
+    int32_t pcg_iters_per_solve[64]; /* linsolver 0: PCG iterations of each ADMM iteration's solve (first 64) */
 } admm_hip_stats;
 
 const char *admm_hip_last_error(void);
