@@ -594,14 +594,18 @@ __global__ __launch_bounds__(256) void k_rc_dots(int nv, RcBasis B, const double
 // one block: finish the sums, solve the three cnt x cnt systems (symmetrised Cholesky that SKIPS numerically
 // null or dependent directions).  If r0 already meets pcg_tol on every axis the coefficients are exactly
 // zero: in a stationary state the stored pairs are round-off and must not perturb the iterate.
-__global__ __launch_bounds__(128) void k_rc_solve(int cnt, const double *__restrict__ part, int NBr, double tol2, double *__restrict__ coef) {
+__global__ __launch_bounds__(256) void k_rc_solve(int cnt, const double *__restrict__ part, int NBr, double tol2, double *__restrict__ coef) {
     __shared__ double sums[3 * kRcQ];
     __shared__ int skip;
     const int t = threadIdx.x;
-    if (t < 3 * kRcQ) {
-        double s = 0.0;
-        for (int i = 0; i < NBr; ++i) s += part[(size_t)t * NBr + i];
-        sums[t] = s;
+    {   // each wave reduces a strided subset of the 3 * kRcQ partial-sum rows
+        const int lane = t & 63, wv = t >> 6;
+        for (int qi = wv; qi < 3 * kRcQ; qi += 4) {
+            double s = 0.0;
+            for (int i = lane; i < NBr; i += 64) s += part[(size_t)qi * NBr + i];
+            s = wave_sum(s);
+            if (lane == 0) sums[qi] = s;
+        }
     }
     __syncthreads();
     if (t == 0) {

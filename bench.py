@@ -221,7 +221,8 @@ def main():
             # dominant single kernel = the per-tet prox kernel (local step).  ALGORITHMIC bytes per tet per
             # ADMM iteration: 16 idx + 72 Binv + 72 u read + 72 u write + 72 z write + 24 nv/nt.
             launches = iters * args.steps
-            bytes_per_launch = ((188.0 if w["kinds"] == "cloth" else 304.0) + 24.0 * nv / nt) * nt
+            # (with N ranks, rank 0 times its own element block: nt / N elements per launch)
+            bytes_per_launch = ((188.0 if w["kinds"] == "cloth" else 304.0) + 24.0 * nv / nt) * nt / world
             avg_s = 1e-3 * local_ms / launches
             achieved = bytes_per_launch / avg_s / 1e9
             out["roofline"] = {"kernel": "k_local_tris" if w["kinds"] == "cloth" else "k_local_tets (all constitutive models of one ADMM iteration)", "bound": "hbm",
