@@ -235,6 +235,39 @@ def test_step_uzawa_collisions_loose():
     assert s.runtime_data().inner_iters > 8
 
 
+def test_step_parity_beams_config1():
+    """BASELINE configs[0] / samples/sca2016/beams.cpp: three 12x3x3-cell beams (1 944 tets), linear / NH /
+    StVK, soft rubber, scaled to 1 m height and spread along y (beams.cpp:43-90), pins = all vertices within
+    1e-2 of min-x / max-x, moved -/+ dt (1,0,0) per frame (:107-132), 10 ADMM iterations, exact solve."""
+    sc = scenes.Scene()
+    dt = 1.0 / 24.0
+    left, right = [], []
+    for i, (kind, yoff) in enumerate(((pkg.TET_LINEAR, 1.75), (pkg.TET_NEOHOOKEAN, 0.0), (pkg.TET_STVK, -1.75))):
+        verts, tets = meshes.tet_blocks(12, 3, 3, size=(4.0, 1.0, 1.0))
+        verts = verts - verts.mean(axis=0) + np.array([0.0, yoff, 0.0])
+        off = sc.add_tet_mesh(verts, tets, Lame(10000000.0, 0.399), kind)
+        left += [off + int(j) for j in np.nonzero(verts[:, 0] < verts[:, 0].min() + 1e-2)[0]]
+        right += [off + int(j) for j in np.nonzero(verts[:, 0] > verts[:, 0].max() - 1e-2)[0]]
+    assert sum(len(t[1]) for t in sc.tets) == 1944 and len(left) == len(right) == 48
+    for v in left + right:
+        sc.pins[v] = sc.x[v].copy()
+    sc.settings.update(admm_iters=10, linsolver=0, gravity=-9.8, timestep_s=dt)
+    s = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=400)
+    o = sc.make_oracle(mode=1)
+    pts = {v: sc.x[v].copy() for v in left + right}
+    for frame in range(6):
+        for v in left:
+            pts[v] = pts[v] - np.array([dt, 0.0, 0.0])
+        for v in right:
+            pts[v] = pts[v] + np.array([dt, 0.0, 0.0])
+        keys = list(pts.keys())
+        s.set_pins(keys, [pts[k] for k in keys]); o.set_pins(pts)
+        s.step(); o.step()
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7
+    assert np.abs(s.m_x.reshape(-1, 3)[left, 0] - np.array([pts[v][0] for v in left])).max() < 1e-4   # pins hold
+    assert s.runtime_data().unconverged_solves == 0
+
+
 # ---- BASELINE-size properties (size-independent invariants at 1M tets) ----------------------------
 @pytest.fixture(scope="module")
 def big():
