@@ -224,15 +224,18 @@ void launch_local(admm_hip_ctx *c) {
     hipStream_t st = c->stream;
     if (c->nt > 0) {
         const int b0 = c->kind_begin[0], b1 = c->kind_begin[1], b2 = c->kind_begin[2], b3 = c->kind_begin[3];
-        if (b1 > b0)
-            hipLaunchKernelGGL((k_local_tets<0, WRITE_Z>), dim3(blocks_for(b1 - b0)), dim3(256), 0, st, b0, b1, c->ldt,
-                               c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p);
-        if (b2 > b1)
-            hipLaunchKernelGGL((k_local_tets<1, WRITE_Z>), dim3(blocks_for(b2 - b1)), dim3(256), 0, st, b1, b2, c->ldt,
-                               c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p);
-        if (b3 > b2)
-            hipLaunchKernelGGL((k_local_tets<2, WRITE_Z>), dim3(blocks_for(b3 - b2)), dim3(256), 0, st, b2, b3, c->ldt,
-                               c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p);
+        const TetArgs a{c->ldt, c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p};
+        const int kinds = (b1 > b0) + (b2 > b1) + (b3 > b2);
+        if (kinds >= 2) { // mixed scene: one launch over all models
+            const int n0 = blocks_for(b1 - b0), n1 = blocks_for(b2 - b1), n2 = blocks_for(b3 - b2);
+            hipLaunchKernelGGL((k_local_tets_fused<WRITE_Z>), dim3(n0 + n1 + n2), dim3(256), 0, st, b0, b1, b2, b3, n0, n0 + n1, a);
+        } else if (b1 > b0) {
+            hipLaunchKernelGGL((k_local_tets<0, WRITE_Z>), dim3(blocks_for(b1 - b0)), dim3(256), 0, st, b0, b1, a);
+        } else if (b2 > b1) {
+            hipLaunchKernelGGL((k_local_tets<1, WRITE_Z>), dim3(blocks_for(b2 - b1)), dim3(256), 0, st, b1, b2, a);
+        } else if (b3 > b2) {
+            hipLaunchKernelGGL((k_local_tets<2, WRITE_Z>), dim3(blocks_for(b3 - b2)), dim3(256), 0, st, b2, b3, a);
+        }
     }
     if (c->ntri > 0)
         hipLaunchKernelGGL((k_local_tris<WRITE_Z>), dim3(blocks_for(c->ntri)), dim3(256), 0, st, c->ntri, c->ldr, c->r_idx.p,

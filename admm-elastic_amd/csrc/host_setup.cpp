@@ -148,7 +148,7 @@ Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int
     for (int32_t s = 0; s < S.n_slices; ++s) {
         int32_t w = 0;
         for (int32_t r = 64 * s; r < std::min(n_verts, 64 * s + 64); ++r) w = std::max(w, cnt[r + 1] - cnt[r]);
-        w = std::max(4, (w + 3) / 4 * 4);
+        w = std::max(8, (w + 7) / 8 * 8); // the gather kernel consumes 8 incidences per pipelined round
         S.slice_width[s] = w;
         S.slice_ptr[s + 1] = S.slice_ptr[s] + 64 * w;
     }

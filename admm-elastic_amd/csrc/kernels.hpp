@@ -104,20 +104,23 @@ __global__ __launch_bounds__(256) void k_finish(int n3, double inv_dt, double *_
 // model, fused with the element's contribution to dt^2 D^T W^2 (z - u) (src/Solver.cpp:98), written as
 // 4 corner force vectors cf[12][ld] that k_gather_rhs sums per vertex (no atomics, deterministic).
 //   F = [x1-x0, x2-x0, x3-x0] Binv  ==  D_i x   (D-block of src/TetEnergyTerm.cpp:50-71)
+struct TetArgs {
+    int ld;
+    const int4 *idx; const double *Binv; double *u; double *z; const double *sc; const int *mat_id; const Mat *mats;
+    const double *x; double *cf;
+};
+
 template <int KIND, bool WRITE_Z>
-__global__ __launch_bounds__(256, (KIND == 1 ? 3 : 4)) void k_local_tets(int t0, int t1, int ld, const int4 *__restrict__ idx,
-                                                    const double *__restrict__ Binv, double *__restrict__ u,
-                                                    double *__restrict__ z, const double *__restrict__ sc,
-                                                    const int *__restrict__ mat_id, const Mat *__restrict__ mats,
-                                                    const double *__restrict__ x, double *__restrict__ cf) {
-    const int t = t0 + xcd_block() * 256 + threadIdx.x;
-    if (t >= t1) return;
+__device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (*sBi)[256], double (*sV)[256]) {
+    const int ld = a.ld;
+    const int4 *__restrict__ idx = a.idx; const double *__restrict__ Binv = a.Binv; double *__restrict__ u = a.u;
+    double *__restrict__ z = a.z; const double *__restrict__ sc = a.sc; const int *__restrict__ mat_id = a.mat_id;
+    const Mat *__restrict__ mats = a.mats; const double *__restrict__ x = a.x; double *__restrict__ cf = a.cf;
     const int4 id = idx[t];
-    // Binv is needed twice (F = Ds Binv before the prox, corner forces after it).  It is parked in LDS in
+    // Binv is needed twice (F = Ds Binv before the prox, corner forces after it).  It is parked in LDS (sBi) in
     // between: thread-private slots, [c][tid] layout (bank-conflict-free 8-B accesses), no VGPRs held
     // across the prox and no second trip to HBM (rocprof FETCH_SIZE showed the re-read going to fabric).
-    __shared__ double sBi[9][256];
-    __shared__ double sV[9][256];   // V is parked here across the stretch minimisation (hyperelastic models)
+    // sV: V is parked there across the stretch minimisation (StVK).
     double U[9], V[9], S0[3], S1[3];
     {
         double q[9];
@@ -199,6 +202,35 @@ __global__ __launch_bounds__(256, (KIND == 1 ? 3 : 4)) void k_local_tets(int t0,
     for (int j = 0; j < 3; ++j) cf[(size_t)j * ld + t] = f0[j];
 }
 
+// one constitutive model per launch (used when a scene has a single model, and by the parity entry point)
+template <int KIND, bool WRITE_Z>
+__global__ __launch_bounds__(256, (KIND == 1 ? 3 : 4)) void k_local_tets(int t0, int t1, TetArgs a) {
+    __shared__ double sBi[9][256];
+    __shared__ double sV[KIND == 2 ? 9 : 1][256];
+    const int t = t0 + xcd_block() * 256 + threadIdx.x;
+    if (t >= t1) return;
+    local_tet_body<KIND, WRITE_Z>(a, t, sBi, sV);
+}
+
+// all models in ONE launch: block ranges [0,nb0) linear, [nb0,nb1) NH, [nb1,nb2) StVK (wave-uniform branch).
+// Avoids the ramp-down / ramp-up between per-model launches of a mixed scene.
+template <bool WRITE_Z>
+__global__ __launch_bounds__(256, 3) void k_local_tets_fused(int b0, int b1, int b2, int b3, int nb0, int nb1, TetArgs a) {
+    __shared__ double sBi[9][256];
+    __shared__ double sV[9][256];
+    const int blk = xcd_block();
+    if (blk < nb0) {
+        const int t = b0 + blk * 256 + threadIdx.x;
+        if (t < b1) local_tet_body<0, WRITE_Z>(a, t, sBi, sV);
+    } else if (blk < nb1) {
+        const int t = b1 + (blk - nb0) * 256 + threadIdx.x;
+        if (t < b2) local_tet_body<1, WRITE_Z>(a, t, sBi, sV);
+    } else {
+        const int t = b2 + (blk - nb1) * 256 + threadIdx.x;
+        if (t < b3) local_tet_body<2, WRITE_Z>(a, t, sBi, sV);
+    }
+}
+
 // LOCAL STEP, triangles (src/TriEnergyTerm.cpp:54-101): F (3x2) = [x1-x0, x2-x0] rest
 template <bool WRITE_Z>
 __global__ __launch_bounds__(256) void k_local_tris(int n, int ld, const int4 *__restrict__ idx,
@@ -260,33 +292,34 @@ struct GatherArgs {
     int add_mxbar;             // 1 on a single GPU / on rank 0
 };
 
-// sum of the corner forces incident to this lane's vertex (widths are multiples of 4; padding points
-// at the all-zero dummy element ld-1)
+// sum of the corner forces incident to this lane's vertex (incidence widths are multiples of 8; padding
+// points at the all-zero dummy element ld-1).  Software-pipelined, 8 incidences (24 gathers) per round.
 __device__ __forceinline__ void gather_corners(const int *__restrict__ inc, int w, const double *__restrict__ cf, int ld, double *acc) {
-    int e[4];
+    constexpr int R = 8;
+    int e[R];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = inc[64 * i];
-    for (int k = 4; k < w; k += 4) {
-        int en[4];
+    for (int i = 0; i < R; ++i) e[i] = inc[64 * i];
+    for (int k = R; k < w; k += R) {
+        int en[R];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) en[i] = inc[64 * (k + i)];
-        double g[12];
+        for (int i = 0; i < R; ++i) en[i] = inc[64 * (k + i)];
+        double g[3 * R];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < R; ++i) {
             const double *p = cf + (size_t)(3 * (e[i] & 3)) * ld + (e[i] >> 2);
             g[3 * i] = p[0]; g[3 * i + 1] = p[ld]; g[3 * i + 2] = p[2 * (size_t)ld];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[0] += g[3 * i]; acc[1] += g[3 * i + 1]; acc[2] += g[3 * i + 2]; e[i] = en[i]; }
+        for (int i = 0; i < R; ++i) { acc[0] += g[3 * i]; acc[1] += g[3 * i + 1]; acc[2] += g[3 * i + 2]; e[i] = en[i]; }
     }
-    double g[12];
+    double g[3 * R];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < R; ++i) {
         const double *p = cf + (size_t)(3 * (e[i] & 3)) * ld + (e[i] >> 2);
         g[3 * i] = p[0]; g[3 * i + 1] = p[ld]; g[3 * i + 2] = p[2 * (size_t)ld];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[0] += g[3 * i]; acc[1] += g[3 * i + 1]; acc[2] += g[3 * i + 2]; }
+    for (int i = 0; i < R; ++i) { acc[0] += g[3 * i]; acc[1] += g[3 * i + 1]; acc[2] += g[3 * i + 2]; }
 }
 
 __global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
