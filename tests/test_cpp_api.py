@@ -12,15 +12,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "_build", "test_lineartet")
 
 
-def _build_exe():
+def _build_exe(name="test_lineartet"):
     build.build_host_library()
-    os.makedirs(os.path.dirname(EXE), exist_ok=True)
-    src = os.path.join(ROOT, "tests", "cpp", "test_lineartet.cpp")
+    exe = os.path.join(os.path.dirname(EXE), name)
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cpp")
     pk = os.path.join(ROOT, "admm-elastic_amd")
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(build.OUT_HOST)):
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(build.OUT_HOST)):
         subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(pk, "host", "include"), src, "-L" + pk, "-ladmm_elastic",
-                        "-ladmm_hip", "-Wl,-rpath," + pk, "-o", EXE], check=True)
-    return EXE
+                        "-ladmm_hip", "-Wl,-rpath," + pk, "-o", exe], check=True)
+    return exe
 
 
 def test_cpp_api_builds_and_fails_loudly_without_gpu():
@@ -36,3 +37,44 @@ def test_cpp_lineartet_known_answers():
     exe = _build_exe()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SUCCESS" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_scene_builds():
+    _build_exe("test_scene")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ls", [0, 1, 2])
+def test_cpp_scene_matches_python_binding(ls):
+    """The same scene through the C++ class mirror and through the Python binding: both flatten to the same
+    admm_hip_desc, so the trajectories must agree to round-off (pins as energy terms / in-sweep pins,
+    Floor obstacle with GS and with UzawaCG, moving pins)."""
+    import numpy as np
+    import scenes
+    from admm_elastic_amd import meshes
+    from admm_elastic_amd.solver import Lame
+    exe = _build_exe("test_scene")
+    frames = 3
+    r = subprocess.run([exe, str(ls), str(frames)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]
+    lines = r.stdout.strip().split("\n")
+    x_cpp = np.array([float(v) for v in lines[1:]])
+    n = 3
+    verts, tets = meshes.kuhn_cube(n, 0.5)
+    verts = verts + np.array([0.0, 0.02, 0.0])
+    sc = scenes.Scene()
+    sc.add_tet_mesh(verts, tets, Lame.soft_rubber(), pkg.TET_NEOHOOKEAN)
+    sc.settings.update(admm_iters=8, linsolver=ls)
+    pins = [int(i) for i in np.nonzero(verts[:, 0] < 1e-9)[0]]
+    if ls == 0:
+        for v in pins:
+            sc.pins[v] = verts[v].copy()
+    else:
+        sc.obstacles.append((0, [0.0, 0.0, 0.0, 0.0]))
+    s = sc.make_solver(pcg_tol=1e-12 if ls == 0 else 1e-10, pcg_max_iters=500)
+    for f in range(frames):
+        if ls == 0:
+            s.set_pins(pins, [verts[v] + np.array([0.0, 0.01 * (f + 1), 0.0]) for v in pins])
+        s.step()
+    tol = 1e-9 if ls != 2 else 5e-3   # UzawaCG contact is chaotic by construction (see test_gpu_parity)
+    assert scenes.rel_err(x_cpp, s.m_x) < tol, scenes.rel_err(x_cpp, s.m_x)
