@@ -648,38 +648,53 @@ __global__ __launch_bounds__(256) void k_rc_solve(int cnt, const double *__restr
     }
     __syncthreads();
     if (t < 3) {
+        // fully unrolled 4x4 masked Cholesky (static indices only: everything stays in registers).  A direction is
+        // dropped (zero coefficient) when it is absent, numerically null, or dependent on the accepted ones.
         const double *S = sums + kRcQ * t;
-        double G[kRc][kRc], g[kRc], c[kRc] = {0, 0, 0, 0};
+        double G[kRc][kRc], g[kRc], L[kRc][kRc], y[kRc], c[kRc];
+        bool ok[kRc];
         double gmax = 0.0;
-        for (int i = 0; i < cnt; ++i) {
+#pragma unroll
+        for (int i = 0; i < kRc; ++i) {
             g[i] = S[16 + i];
-            for (int j = 0; j < cnt; ++j) G[i][j] = 0.5 * (S[i * kRc + j] + S[j * kRc + i]);
-            gmax = fmax(gmax, G[i][i]);
+#pragma unroll
+            for (int j = 0; j < kRc; ++j) { G[i][j] = 0.5 * (S[i * kRc + j] + S[j * kRc + i]); L[i][j] = 0.0; }
+            gmax = fmax(gmax, (i < cnt) ? G[i][i] : 0.0);
         }
-        // Cholesky over the usable directions only (a skipped direction gets a zero coefficient)
-        double L[kRc][kRc];
-        int use[kRc], n = 0; // indices of accepted directions
-        if (!skip && gmax > 0.0) {
-            for (int i = 0; i < cnt; ++i) {
-                if (!(G[i][i] > 1e-12 * gmax)) continue;        // numerically null pair
-                double row[kRc];
-                double d = G[i][i];
-                for (int k2 = 0; k2 < n; ++k2) {
-                    double v = G[i][use[k2]];
-                    for (int k3 = 0; k3 < k2; ++k3) v -= row[k3] * L[k2][k3];
-                    row[k2] = v / L[k2][k2];
-                    d -= row[k2] * row[k2];
-                }
-                if (!(d > 1e-10 * G[i][i])) continue;           // dependent on the accepted ones
-                for (int k2 = 0; k2 < n; ++k2) L[n][k2] = row[k2];
-                L[n][n] = sqrt(d);
-                use[n++] = i;
+#pragma unroll
+        for (int i = 0; i < kRc; ++i) {
+            double d = G[i][i];
+#pragma unroll
+            for (int k2 = 0; k2 < i; ++k2) d -= L[i][k2] * L[i][k2];
+            ok[i] = !skip && (i < cnt) && (G[i][i] > 1e-12 * gmax) && (d > 1e-10 * G[i][i]) && (d > 0.0);
+            const double piv = ok[i] ? sqrt(d) : 1.0;
+            L[i][i] = piv;
+#pragma unroll
+            for (int k2 = 0; k2 < i; ++k2) L[i][k2] = ok[i] ? L[i][k2] : 0.0;
+#pragma unroll
+            for (int j = i + 1; j < kRc; ++j) {
+                double v = G[j][i];
+#pragma unroll
+                for (int k2 = 0; k2 < i; ++k2) v -= L[j][k2] * L[i][k2];
+                L[j][i] = ok[i] ? v / piv : 0.0;
             }
         }
-        double y[kRc], cc[kRc];
-        for (int i = 0; i < n; ++i) { double v = g[use[i]]; for (int k2 = 0; k2 < i; ++k2) v -= L[i][k2] * y[k2]; y[i] = v / L[i][i]; }
-        for (int i = n - 1; i >= 0; --i) { double v = y[i]; for (int k2 = i + 1; k2 < n; ++k2) v -= L[k2][i] * cc[k2]; cc[i] = v / L[i][i]; }
-        for (int i = 0; i < n; ++i) c[use[i]] = (cc[i] == cc[i]) ? cc[i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < kRc; ++i) {
+            double v = g[i];
+#pragma unroll
+            for (int k2 = 0; k2 < i; ++k2) v -= L[i][k2] * y[k2];
+            y[i] = ok[i] ? v / L[i][i] : 0.0;
+        }
+#pragma unroll
+        for (int i = kRc - 1; i >= 0; --i) {
+            double v = y[i];
+#pragma unroll
+            for (int k2 = i + 1; k2 < kRc; ++k2) v -= L[k2][i] * c[k2];
+            c[i] = ok[i] ? v / L[i][i] : 0.0;
+            if (!(c[i] == c[i])) c[i] = 0.0;
+        }
+#pragma unroll
         for (int i = 0; i < kRc; ++i) coef[t * kRc + i] = c[i];
     }
 }
