@@ -185,6 +185,7 @@ struct admm_hip_ctx {
     std::vector<int> color_h; int n_colors = 0;
     std::vector<int> color_ptr_h;
     DevBuf<int> color_nodes;
+    SellDev gs_sell; DevBuf<int> gs_slot_node; DevBuf<double> gs_diag; std::vector<int> gs_color_slice;
     Obstacles obst{};
 
     ~admm_hip_ctx() {
@@ -199,7 +200,7 @@ struct admm_hip_ctx {
         gs_pin_flag.release(); gs_pin_xyz.release();
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
-        cg_scal.release(); counters.release(); color_nodes.release();
+        cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -381,16 +382,16 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
     hipStream_t st = c->stream;
     (void)hipMemsetAsync(c->counters.p + 1, 0, 2 * sizeof(int), st);
     GsArgs a{};
-    a.rowptr = c->csr_rowptr.p; a.col = c->csr_col.p; a.val = c->csr_val.p; a.m = c->m.p; a.b = b; a.x = x;
+    a.S = sell_arg(c->gs_sell); a.slot_node = c->gs_slot_node.p; a.diag = c->gs_diag.p; a.m = c->m.p; a.b = b; a.x = x;
     a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p;
     a.omega = c->gs_omega; a.done = c->counters.p + 1;
     const SellA A = sell_arg(c->A);
     const int check = c->gs_tol > 0.0 ? 1 : 0;
     for (int it = 0; it < c->gs_max_iters; ++it) {
         for (int col = 0; col < c->n_colors; ++col) {
-            const int beg = c->color_ptr_h[col], cnt = c->color_ptr_h[col + 1] - beg;
-            if (cnt == 0) continue;
-            hipLaunchKernelGGL(k_gs_color, dim3(blocks_for(cnt)), dim3(256), 0, st, a, c->color_nodes.p + beg, cnt, c->obst);
+            const int s0 = c->gs_color_slice[col], ns = c->gs_color_slice[col + 1] - s0;
+            if (ns == 0) continue;
+            hipLaunchKernelGGL(k_gs_color, dim3((ns + 3) / 4), dim3(256), 0, st, a, s0, ns, c->obst);
         }
         if (check)
             hipLaunchKernelGGL(k_gs_resid, dim3(c->NB), dim3(256), 0, st, A, c->m.p, b, x, c->part.p, c->NB, c->counters.p + 1);
@@ -677,14 +678,12 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         std::vector<int> nodes(nv), pos(c->color_ptr_h.begin(), c->color_ptr_h.end() - 1);
         for (int i = 0; i < nv; ++i) nodes[pos[c->color_h[i]]++] = i;
         HIP_TRY(c->color_nodes.upload(nodes));
-        {   // the sweep kernel reads a CSR without the exact zeros (the reference skips them at run time)
-            std::vector<int32_t> rp(nv + 1, 0), ci; std::vector<double> va;
-            for (int i = 0; i < nv; ++i) {
-                for (int k = c->Ahat.rowptr[i]; k < c->Ahat.rowptr[i + 1]; ++k)
-                    if (c->Ahat.val[k] != 0.0 || c->Ahat.col[k] == i) { ci.push_back(c->Ahat.col[k]); va.push_back(c->Ahat.val[k]); }
-                rp[i + 1] = (int32_t)ci.size();
-            }
-            HIP_TRY(c->csr_rowptr.upload(rp)); HIP_TRY(c->csr_col.upload(ci)); HIP_TRY(c->csr_val.upload(va));
+        {   // colour-ordered SELL of the off-diagonal non-zeros for the sweep kernel
+            std::vector<int32_t> col32(c->color_h.begin(), c->color_h.end());
+            admm_host::GsSell g = admm_host::build_gs_sell(c->Ahat, c->n_colors, col32);
+            HIP_TRY(c->gs_sell.upload(g.sell));
+            HIP_TRY(c->gs_slot_node.upload(g.slot_node)); HIP_TRY(c->gs_diag.upload(g.diag));
+            c->gs_color_slice.assign(g.color_slice.begin(), g.color_slice.end());
         }
     }
     if (d->linsolver == 2) {

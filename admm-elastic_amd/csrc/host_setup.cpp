@@ -181,6 +181,57 @@ int greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_
     return ncol;
 }
 
+GsSell build_gs_sell(const Csr &A, int n_colors, const std::vector<int32_t> &color) {
+    GsSell g;
+    std::vector<std::vector<int32_t> > by_color(n_colors);
+    for (int32_t i = 0; i < A.n; ++i) by_color[color[i]].push_back(i);
+    g.color_slice.assign(n_colors + 1, 0);
+    for (int c = 0; c < n_colors; ++c) {
+        const int32_t nsl = ((int32_t)by_color[c].size() + 63) / 64;
+        g.color_slice[c + 1] = g.color_slice[c] + nsl;
+        for (int32_t k = 0; k < nsl * 64; ++k) g.slot_node.push_back(k < (int32_t)by_color[c].size() ? by_color[c][k] : -1);
+    }
+    const int32_t n_slices = g.color_slice[n_colors];
+    Sell &S = g.sell;
+    S.n_rows = 64 * n_slices; S.n_slices = n_slices;
+    S.slice_ptr.assign(n_slices + 1, 0); S.slice_width.assign(n_slices, 0);
+    g.diag.assign((size_t)64 * n_slices, 1.0);
+    auto keep = [&](int32_t r, int32_t k) { return A.val[k] != 0.0 && A.col[k] != r; }; // off-diagonal non-zeros
+    for (int32_t s = 0; s < n_slices; ++s) {
+        int32_t w = 0;
+        for (int32_t l = 0; l < 64; ++l) {
+            const int32_t r = g.slot_node[(size_t)64 * s + l];
+            if (r < 0) continue;
+            int32_t len = 0;
+            for (int32_t k = A.rowptr[r]; k < A.rowptr[r + 1]; ++k) len += keep(r, k) ? 1 : 0;
+            w = std::max(w, len);
+        }
+        w = std::max(4, (w + 3) / 4 * 4);
+        S.slice_width[s] = w;
+        S.slice_ptr[s + 1] = S.slice_ptr[s] + 64 * w;
+    }
+    S.idx.assign(S.slice_ptr[n_slices], 0);
+    S.val.assign(S.slice_ptr[n_slices], 0.0);
+    for (int32_t s = 0; s < n_slices; ++s)
+        for (int32_t l = 0; l < 64; ++l) {
+            const int32_t r = g.slot_node[(size_t)64 * s + l];
+            int32_t k = 0;
+            if (r >= 0)
+                for (int32_t q = A.rowptr[r]; q < A.rowptr[r + 1]; ++q) {
+                    if (A.col[q] == r) { g.diag[(size_t)64 * s + l] = A.val[q]; continue; }
+                    if (!keep(r, q)) continue;
+                    const size_t o = (size_t)S.slice_ptr[s] + 64 * k + l;
+                    S.idx[o] = A.col[q]; S.val[o] = A.val[q];
+                    ++k;
+                }
+            for (; k < S.slice_width[s]; ++k) { // padding: any valid column, zero value
+                const size_t o = (size_t)S.slice_ptr[s] + 64 * k + l;
+                S.idx[o] = r >= 0 ? r : 0; S.val[o] = 0.0;
+            }
+        }
+    return g;
+}
+
 // src/TetEnergyTerm.cpp:31-48
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol) {
     for (int32_t t = 0; t < n; ++t) {

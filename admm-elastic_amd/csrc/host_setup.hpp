@@ -42,6 +42,17 @@ Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int
 
 int greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color);
 
+// Colour-ordered SELL for the multi-colour Gauss-Seidel sweeps: every colour's node list is padded to whole
+// 64-lane slices (slot_node = -1 for padding lanes); the SELL holds the OFF-diagonal non-zeros of each node's
+// row in column order, the diagonal goes to `diag`.  Colour c owns slices [color_slice[c], color_slice[c+1]).
+struct GsSell {
+    Sell sell;
+    std::vector<int32_t> slot_node;   // [64 * n_slices]
+    std::vector<double> diag;         // [64 * n_slices]
+    std::vector<int32_t> color_slice; // [n_colors + 1]
+};
+GsSell build_gs_sell(const Csr &A, int n_colors, const std::vector<int32_t> &color);
+
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
 int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
 void lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);

@@ -747,40 +747,42 @@ __device__ __forceinline__ bool passive_hit(const Obstacles &ob, const double *x
 }
 
 struct GsArgs {
-    const int *rowptr, *col; const double *val; // Ahat CSR
-    const double *m;        // [3 nv]
+    SellA S;                    // colour-ordered SELL of the off-diagonal non-zeros (host_setup.hpp: GsSell)
+    const int *slot_node;       // node of every SELL lane, -1 = padding
+    const double *diag;         // Ahat(v,v) per lane
+    const double *m;            // [3 nv]
     const double *b; double *x;
     const int *pin_flag; const double *pin_xyz; // per node (nullptr -> no pins)
     double omega;
-    const int *done;        // set once the residual test passed
+    const int *done;            // set once the residual test passed
 };
 
-__global__ __launch_bounds__(256) void k_gs_color(GsArgs a, const int *__restrict__ nodes, int count, Obstacles ob) {
+// one colour of one sweep: wave = one 64-node slice of that colour, lane = node.  The off-diagonal row sum is
+// the same software-pipelined SELL loop as the SpMV (exact zeros are not stored: the reference skips them at
+// run time, NodalMultiColorGS.hpp:194; the summation order is the row's column order, like the reference).
+__global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nslices, Obstacles ob) {
     if (*a.done) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    const int v = nodes[i];
+    const int lane = threadIdx.x & 63;
+    const int ws = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (ws >= nslices) return;
+    const int s = slice0 + ws;
+    const int v = a.slot_node[(size_t)64 * s + lane];
+    double LUx[3];
+    sell_row(a.S, s, lane, a.x, LUx);
+    if (v < 0) return;
     if (a.pin_flag && a.pin_flag[v]) { // :111-117
 #pragma unroll
-        for (int s = 0; s < 3; ++s) a.x[3 * (size_t)v + s] = a.pin_xyz[3 * (size_t)v + s];
+        for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = a.pin_xyz[3 * (size_t)v + q];
         return;
     }
-    double LUx[3] = {0.0, 0.0, 0.0}, ad = 0.0;
-    for (int k = a.rowptr[v]; k < a.rowptr[v + 1]; ++k) {
-        const double val = a.val[k];
-        if (fabs(val) <= 0.0) continue; // :194
-        const int c = a.col[k];
-        if (c == v) { ad = val; continue; }
-        const double *p = a.x + 3 * (size_t)c;
-        LUx[0] += val * p[0]; LUx[1] += val * p[1]; LUx[2] += val * p[2];
-    }
+    const double ad = a.diag[(size_t)64 * s + lane];
     double jac[3], nx[3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const double aii = ad + a.m[3 * (size_t)v + s];
-        const double cx = a.x[3 * (size_t)v + s];
-        jac[s] = (a.b[3 * (size_t)v + s] - LUx[s]) / aii;
-        nx[s] = (1.0 - a.omega) * cx + a.omega * jac[s]; // :210
+    for (int q = 0; q < 3; ++q) {
+        const double aii = ad + a.m[3 * (size_t)v + q];
+        const double cx = a.x[3 * (size_t)v + q];
+        jac[q] = (a.b[3 * (size_t)v + q] - LUx[q]) / aii;
+        nx[q] = (1.0 - a.omega) * cx + a.omega * jac[q]; // :210
     }
     double n[3], p[3];
     if (ob.n > 0 && passive_hit(ob, nx, n, p)) { // constrained_segment_update :218-262
@@ -790,17 +792,17 @@ __global__ __launch_bounds__(256) void k_gs_color(GsArgs a, const int *__restric
         cross3(nn, n, uu);
         double il = 1.0 / sqrt(dot3(uu, uu));
 #pragma unroll
-        for (int s = 0; s < 3; ++s) uu[s] *= il;
+        for (int q = 0; q < 3; ++q) uu[q] *= il;
         cross3(n, uu, vv);
         il = 1.0 / sqrt(dot3(vv, vv));
 #pragma unroll
-        for (int s = 0; s < 3; ++s) vv[s] *= il;
+        for (int q = 0; q < 3; ++q) vv[q] *= il;
         const double t0 = dot3(uu, dx), t1 = dot3(vv, dx);
 #pragma unroll
-        for (int s = 0; s < 3; ++s) nx[s] = uu[s] * t0 + vv[s] * t1 + p[s];
+        for (int q = 0; q < 3; ++q) nx[q] = uu[q] * t0 + vv[q] * t1 + p[q];
     }
 #pragma unroll
-    for (int s = 0; s < 3; ++s) a.x[3 * (size_t)v + s] = nx[s];
+    for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
 }
 
 // residual test of one sweep (:136-140): partial sums of |b - A x|^2 and |b|^2
