@@ -385,19 +385,25 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
     a.S = sell_arg(c->gs_sell); a.slot_node = c->gs_slot_node.p; a.diag = c->gs_diag.p; a.m = c->m.p; a.b = b; a.x = x;
     a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p;
     a.omega = c->gs_omega; a.done = c->counters.p + 1;
+    a.part = c->part.p; a.NBp = c->NB; a.tol2 = c->gs_tol * c->gs_tol; a.sweeps = c->counters.p + 2; a.total = c->counters.p;
     const SellA A = sell_arg(c->A);
     const int check = c->gs_tol > 0.0 ? 1 : 0;
     for (int it = 0; it < c->gs_max_iters; ++it) {
+        bool first = true;
         for (int col = 0; col < c->n_colors; ++col) {
             const int s0 = c->gs_color_slice[col], ns = c->gs_color_slice[col + 1] - s0;
             if (ns == 0) continue;
-            hipLaunchKernelGGL(k_gs_color, dim3((ns + 3) / 4), dim3(256), 0, st, a, s0, ns, c->obst);
+            // the first colour kernel of sweep it >= 1 settles the residual test / sweep count of sweep it-1
+            const int decide = (first && it > 0) ? (check ? 2 : 1) : 0;
+            hipLaunchKernelGGL(k_gs_color, dim3((ns + 3) / 4), dim3(256), 0, st, a, s0, ns, c->obst, decide);
+            first = false;
         }
         if (check)
             hipLaunchKernelGGL(k_gs_resid, dim3(c->NB), dim3(256), 0, st, A, c->m.p, b, x, c->part.p, c->NB, c->counters.p + 1);
-        hipLaunchKernelGGL(k_gs_check, dim3(1), dim3(256), 0, st, c->part.p, c->NB, c->gs_tol * c->gs_tol, c->counters.p + 1,
-                           c->counters.p + 2, c->counters.p, check);
     }
+    // the last sweep is settled by a dedicated one-block kernel
+    hipLaunchKernelGGL(k_gs_check, dim3(1), dim3(256), 0, st, c->part.p, c->NB, c->gs_tol * c->gs_tol, c->counters.p + 1,
+                       c->counters.p + 2, c->counters.p, check);
 }
 
 void launch_gs(admm_hip_ctx *c, const double *b, double *x) {

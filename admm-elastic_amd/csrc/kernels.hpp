@@ -754,14 +754,28 @@ struct GsArgs {
     const double *b; double *x;
     const int *pin_flag; const double *pin_xyz; // per node (nullptr -> no pins)
     double omega;
-    const int *done;            // set once the residual test passed
+    int *done;                  // set once the residual test passed
+    // residual test of the PREVIOUS sweep, decided here by every block of the first colour kernel of a sweep
+    // (deterministic re-reduction of the k_gs_resid partials; saves one launch per sweep)
+    const double *part; int NBp; double tol2; int *sweeps; int *total;
 };
 
 // one colour of one sweep: wave = one 64-node slice of that colour, lane = node.  The off-diagonal row sum is
 // the same software-pipelined SELL loop as the SpMV (exact zeros are not stored: the reference skips them at
 // run time, NodalMultiColorGS.hpp:194; the summation order is the row's column order, like the reference).
-__global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nslices, Obstacles ob) {
+__global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nslices, Obstacles ob, int decide) {
+    __shared__ double lds[8];
     if (*a.done) return;
+    if (decide) { // first colour of sweep i+1: was sweep i converged?  (NodalMultiColorGS.hpp:136-140)
+        double q[2] = {0.0, 0.0};
+        for (int i = threadIdx.x; i < a.NBp; i += 256) { q[0] += a.part[i]; q[1] += a.part[a.NBp + i]; }
+        block_sum<2>(q, lds);
+        const bool conv = decide == 2 && (q[0] / q[1] < a.tol2);   // decide == 1: count the sweep only (tol <= 0)
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (conv) *a.done = 1; else { atomicAdd(a.sweeps, 1); atomicAdd(a.total, 1); }
+        }
+        if (conv) return;
+    }
     const int lane = threadIdx.x & 63;
     const int ws = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (ws >= nslices) return;
