@@ -18,6 +18,7 @@
 #include "../../include/admm_hip.h"
 #include "host_setup.hpp"
 #include "kernels.hpp"
+#include "pcg_onchip.hpp"
 
 using namespace admm_k;
 
@@ -148,6 +149,7 @@ struct admm_hip_ctx {
     // system matrix
     admm_host::Csr Ahat;
     SellDev A;
+    int A_wmax = 4;
     DevBuf<int> csr_rowptr, csr_col;
     DevBuf<double> csr_val;
     // PCG work
@@ -162,6 +164,12 @@ struct admm_hip_ctx {
     // launching as soon as a solve has converged -- without ever synchronising the stream.
     int *h_sig = nullptr;         // pinned + mapped: [0] seq of the last converged solve, [1] closed chunks
     int *d_sig = nullptr;         // device alias of h_sig
+    // on-chip PCG (pcg_onchip.hpp): one persistent launch per solve when the system fits the chip
+    bool oc_enabled = false;
+    int oc_G = 0, oc_spb = 0, oc_T = 0, oc_wl = 0; size_t oc_lds = 0;
+    DevBuf<double> oc_ubuf, oc_part, oc_part_b;
+    DevBuf<unsigned> oc_bar;
+    DevBuf<unsigned long long> oc_prof;
     int solve_seq = 0;
     int marks_expected = 0;       // chunks closed so far (host count)
     int last_launched_iters = 0;
@@ -201,6 +209,7 @@ struct admm_hip_ctx {
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release();
+        oc_ubuf.release(); oc_part.release(); oc_part_b.release(); oc_bar.release(); oc_prof.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -272,7 +281,77 @@ int launch_rhs(admm_hip_ctx *c) {
 // PCG solve of A x = b, x = curr (warm start).  See the launch-control comment in admm_hip_ctx.
 constexpr int kChunk = 32;
 
+int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
+    hipStream_t st = c->stream;
+    if (hipMemsetAsync(c->oc_bar.p, 0, c->oc_bar.n * sizeof(unsigned), st) != hipSuccess) return -1;
+    OcArgs a{};
+    a.n_rows = c->A.n_rows; a.n_slices = c->A.n_slices;
+    a.ptr = c->A.ptr.p; a.w = c->A.w.p; a.col = c->A.idx.p; a.val = c->A.val.p;
+    a.m = c->m.p; a.dinv = c->dinv.p; a.b = b; a.x = x; a.u_out = c->cg_u.p;
+    a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.part_b = c->oc_part_b.p; a.bar = c->oc_bar.p;
+    a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
+    a.spb = c->oc_spb; a.wl = c->oc_wl; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
+    a.tol2 = c->pcg_tol * c->pcg_tol;
+    a.prof = c->oc_prof.p;
+    if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    else hipLaunchKernelGGL((k_pcg_onchip<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    c->last_launched_iters = 0; // the verdict of the solve is written to cg_scal[0]
+    if (c->oc_prof.p) { // diagnosis only: per-phase time of block 0, mean over iterations 1..62
+        std::vector<unsigned long long> h(64 * 8);
+        if (hipMemcpyAsync(h.data(), c->oc_prof.p, h.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        double d[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
+        for (int it = 1; it + 1 < 64 && h[(it + 1) * 8] > h[it * 8 + 5] && h[it * 8 + 5] > h[it * 8]; ++it, ++n) {
+            for (int k = 0; k < 5; ++k) d[k] += (double)(h[it * 8 + k + 1] - h[it * 8 + k]);
+            d[5] += (double)(h[(it + 1) * 8] - h[it * 8]);
+        }
+        if (n) fprintf(stderr, "[oc_prof] n=%d  barrier1 %.2f  spmv+partials %.2f  barrier2 %.2f  reduce %.2f  update+publish %.2f  | iteration %.2f us (100 MHz ticks)\n",
+                       n, d[0] / n / 100, d[1] / n / 100, d[2] / n / 100, d[3] / n / 100, d[4] / n / 100, d[5] / n / 100);
+        (void)hipMemsetAsync(c->oc_prof.p, 0, h.size() * 8, st);
+    }
+    return 0;
+}
+
+// Decide whether the system fits the chip: one SELL slice per wave, <= 16 waves per block, one block per CU.
+hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
+    c->oc_enabled = false;
+    const char *env = getenv("ADMM_HIP_PCG_LAUNCHES");
+    if (env && env[0] == '1') return hipSuccess;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, c->device);
+    if (e != hipSuccess) return e;
+    const int cus = prop.multiProcessorCount, ns = c->A.n_slices;
+    if (ns <= 0 || cus <= 0) return hipSuccess;
+    int G = std::min(cus, ns);
+    const int spb = (ns + G - 1) / G;
+    if (spb > 16) return hipSuccess;
+    G = (ns + spb - 1) / spb;
+    const int T = 64 * spb;
+    const int wmax = c->A_wmax;
+    const size_t lds_max = std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
+    if (lds_max < (size_t)kOcScratch + (size_t)T * 4 * 12) return hipSuccess;
+    int wl = (int)((lds_max - kOcScratch) / ((size_t)T * 12)) & ~3;
+    wl = std::min(wl, wmax);
+    const size_t lds = (size_t)kOcScratch + (size_t)T * wl * 12;
+    const void *fn = T <= 768 ? (const void *)k_pcg_onchip<768> : (const void *)k_pcg_onchip<1024>;
+    if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    int per_cu = 0;
+    if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<1024>, T, lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1 || G > cus) return hipSuccess; // one block per CU keeps every block resident whatever the LDS split
+    c->oc_G = G; c->oc_spb = spb; c->oc_T = T; c->oc_wl = wl; c->oc_lds = lds;
+    if ((e = c->oc_ubuf.alloc((size_t)ns * 64 * 4)) != hipSuccess) return e;
+    if ((e = c->oc_part.alloc((size_t)G * 8)) != hipSuccess) return e;
+    if ((e = c->oc_part_b.alloc((size_t)G * 4)) != hipSuccess) return e;
+    if ((e = c->oc_bar.alloc(32 * 16)) != hipSuccess) return e;
+    if ((e = hipMemset(c->oc_ubuf.p, 0, c->oc_ubuf.n * sizeof(double))) != hipSuccess) return e;
+    { const char *pe = getenv("ADMM_HIP_OC_PROF"); if (pe && pe[0] == '1') { if ((e = c->oc_prof.alloc(64 * 8)) != hipSuccess) return e; if ((e = c->oc_prof.zero()) != hipSuccess) return e; } }
+    c->oc_enabled = true;
+    return hipSuccess;
+}
+
 int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
+    if (c->oc_enabled) return launch_pcg_onchip(c, b, x, max_iters);
     hipStream_t st = c->stream;
     const SellA A = sell_arg(c->A);
     const int NB = c->NB;
@@ -620,7 +699,11 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     // ---- system matrix ----
     c->Ahat = admm_host::assemble_Ahat(nv, c->dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris, d->tri_idx,
                                        d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, c->pin_weight);
-    HIP_TRY(c->A.upload(admm_host::csr_to_sell(c->Ahat)));
+    {
+        const admm_host::Sell S = admm_host::csr_to_sell(c->Ahat);
+        for (int w : S.slice_width) c->A_wmax = std::max(c->A_wmax, w);
+        HIP_TRY(c->A.upload(S));
+    }
     {
         std::vector<double> mass(d->masses, d->masses + c->n3), dinv(c->n3);
         for (int vtx = 0; vtx < nv; ++vtx) {
@@ -644,6 +727,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->part.alloc(6 * (size_t)c->NB)); HIP_TRY(c->part_b.alloc(3 * (size_t)c->NB));
     HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
     HIP_TRY(c->counters.alloc(8 + 64)); HIP_TRY(c->counters.zero());
+    if (d->linsolver != 1) HIP_TRY(plan_pcg_onchip(c));
     if (d->linsolver != 1) {
         const char *env = getenv("ADMM_HIP_NO_RECYCLE");
         c->rc_enabled = !(env && env[0] == '1');
@@ -726,6 +810,7 @@ int admm_hip_get_state(admm_hip_ctx *c, double *x, double *v) {
     if (x) HIP_TRY(hipMemcpyAsync(x, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (v) HIP_TRY(hipMemcpyAsync(v, c->v.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)"); }
     return ADMM_HIP_OK;
 }
 
@@ -819,6 +904,7 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventSynchronize(c->ev_step1));
+        if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)"); }
         std::memset(stats, 0, sizeof(*stats));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_step0, c->ev_step1));
@@ -934,6 +1020,7 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     int h[8];
     HIP_TRY(hipMemcpyAsync(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)"); }
     if (iters) *iters = (c->linsolver == 1) ? h[2] : (c->linsolver == 2 ? c->uz_iters_step : h[0]);
     return ADMM_HIP_OK;
 }
