@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["csrc/admm_hip.hip", "csrc/host_setup.cpp"]
-HEADERS = ["csrc/kernels.hpp", "csrc/device_math.hpp", "csrc/host_setup.hpp", "../include/admm_hip.h"]
+HEADERS = sorted("csrc/" + f for f in os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")) if f.endswith(".hpp")) + ["../include/admm_hip.h"]
 OUT = os.path.join(HERE, "libadmm_hip.so")
 
 

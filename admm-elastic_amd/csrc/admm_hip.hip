@@ -167,7 +167,7 @@ struct admm_hip_ctx {
     // on-chip PCG (pcg_onchip.hpp): one persistent launch per solve when the system fits the chip
     bool oc_enabled = false;
     int oc_G = 0, oc_spb = 0, oc_T = 0, oc_wl = 0; size_t oc_lds = 0;
-    DevBuf<double> oc_ubuf, oc_part, oc_part_b;
+    DevBuf<double> oc_ubuf, oc_part;
     DevBuf<unsigned> oc_bar;
     DevBuf<unsigned long long> oc_prof;
     int solve_seq = 0;
@@ -209,7 +209,7 @@ struct admm_hip_ctx {
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release();
-        oc_ubuf.release(); oc_part.release(); oc_part_b.release(); oc_bar.release(); oc_prof.release();
+        oc_ubuf.release(); oc_part.release(); oc_bar.release(); oc_prof.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -288,7 +288,7 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.n_rows = c->A.n_rows; a.n_slices = c->A.n_slices;
     a.ptr = c->A.ptr.p; a.w = c->A.w.p; a.col = c->A.idx.p; a.val = c->A.val.p;
     a.m = c->m.p; a.dinv = c->dinv.p; a.b = b; a.x = x; a.u_out = c->cg_u.p;
-    a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.part_b = c->oc_part_b.p; a.bar = c->oc_bar.p;
+    a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.bar = c->oc_bar.p;
     a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
     a.spb = c->oc_spb; a.wl = c->oc_wl; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
     a.tol2 = c->pcg_tol * c->pcg_tol;
@@ -296,16 +296,18 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg_onchip<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     c->last_launched_iters = 0; // the verdict of the solve is written to cg_scal[0]
+    if (getenv("ADMM_HIP_OC_DEBUG")) { CgScal h; (void)hipMemcpyAsync(&h, c->cg_scal.p, sizeof(h), hipMemcpyDeviceToHost, st); (void)hipStreamSynchronize(st); fprintf(stderr, "[oc] seq %d iters %d (pipelined %d) conv %d gamma %.3e %.3e %.3e gb %.3e %.3e %.3e\n", h.seq, h.iters, h.pad_, h.converged, h.gamma[0], h.gamma[1], h.gamma[2], h.gamma_b[0], h.gamma_b[1], h.gamma_b[2]); }
     if (c->oc_prof.p) { // diagnosis only: per-phase time of block 0, mean over iterations 1..62
         std::vector<unsigned long long> h(64 * 8);
         if (hipMemcpyAsync(h.data(), c->oc_prof.p, h.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-        double d[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
-        for (int it = 1; it + 1 < 64 && h[(it + 1) * 8] > h[it * 8 + 5] && h[it * 8 + 5] > h[it * 8]; ++it, ++n) {
-            for (int k = 0; k < 5; ++k) d[k] += (double)(h[it * 8 + k + 1] - h[it * 8 + k]);
-            d[5] += (double)(h[(it + 1) * 8] - h[it * 8]);
+        double d[5] = {0, 0, 0, 0, 0}; int n = 0;
+        for (int it = 1; it + 1 < 64 && h[(it + 1) * 8] > h[it * 8 + 4] && h[it * 8 + 4] > h[it * 8]; ++it, ++n) {
+            for (int k = 0; k < 4; ++k) d[k] += (double)(h[it * 8 + k + 1] - h[it * 8 + k]);
+            d[4] += (double)(h[(it + 1) * 8] - h[it * 8]);
         }
-        if (n) fprintf(stderr, "[oc_prof] n=%d  barrier1 %.2f  spmv+partials %.2f  barrier2 %.2f  reduce %.2f  update+publish %.2f  | iteration %.2f us (100 MHz ticks)\n",
-                       n, d[0] / n / 100, d[1] / n / 100, d[2] / n / 100, d[3] / n / 100, d[4] / n / 100, d[5] / n / 100);
+        if (n) fprintf(stderr, "[oc_prof] n=%d  dots+publish %.2f  barrier %.2f  gather+reduce %.2f  update %.2f  | iteration %.2f us (100 MHz ticks)\n",
+                       n, d[0] / n / 100, d[1] / n / 100, d[2] / n / 100, d[3] / n / 100, d[4] / n / 100);
+        if (getenv("ADMM_HIP_OC_TRACE") && a.seq == atoi(getenv("ADMM_HIP_OC_TRACE"))) { std::vector<double> tr(1024); (void)hipMemcpy(tr.data(), (double *)c->oc_prof.p + 1024, 1024 * 8, hipMemcpyDeviceToHost); for (int i = 0; i < 420; ++i) fprintf(stderr, "[tr] %d gamma %.4e delta %.4e\n", i, tr[2 * i], tr[2 * i + 1]); }
         (void)hipMemsetAsync(c->oc_prof.p, 0, h.size() * 8, st);
     }
     return 0;
@@ -340,12 +342,11 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     if (e != hipSuccess) return e;
     if (per_cu < 1 || G > cus) return hipSuccess; // one block per CU keeps every block resident whatever the LDS split
     c->oc_G = G; c->oc_spb = spb; c->oc_T = T; c->oc_wl = wl; c->oc_lds = lds;
-    if ((e = c->oc_ubuf.alloc((size_t)ns * 64 * 4)) != hipSuccess) return e;
-    if ((e = c->oc_part.alloc((size_t)G * 8)) != hipSuccess) return e;
-    if ((e = c->oc_part_b.alloc((size_t)G * 4)) != hipSuccess) return e;
+    if ((e = c->oc_ubuf.alloc((size_t)2 * ns * 64 * 4)) != hipSuccess) return e;
+    if ((e = c->oc_part.alloc((size_t)2 * 8 * G)) != hipSuccess) return e;
     if ((e = c->oc_bar.alloc(32 * 16)) != hipSuccess) return e;
     if ((e = hipMemset(c->oc_ubuf.p, 0, c->oc_ubuf.n * sizeof(double))) != hipSuccess) return e;
-    { const char *pe = getenv("ADMM_HIP_OC_PROF"); if (pe && pe[0] == '1') { if ((e = c->oc_prof.alloc(64 * 8)) != hipSuccess) return e; if ((e = c->oc_prof.zero()) != hipSuccess) return e; } }
+    { const char *pe = getenv("ADMM_HIP_OC_PROF"); if (pe && pe[0] == '1') { if ((e = c->oc_prof.alloc(64 * 8 + 2048)) != hipSuccess) return e; if ((e = c->oc_prof.zero()) != hipSuccess) return e; } }
     c->oc_enabled = true;
     return hipSuccess;
 }

@@ -10,11 +10,25 @@
 //   * the only per-iteration memory traffic is the search-space vector u: 32 B per vertex published with
 //     write-through (sc1) stores and gathered with sc1 loads (per-XCD L2s are not coherent), plus one
 //     64-byte record of partial dot products per block;
-//   * two grid barriers per iteration (Chronopoulos-Gear CG has ONE reduction point: u visible -> SpMV ->
-//     partials visible -> alpha/beta), XCD-hierarchical counters, relaxed agent-scope polling, bounded
-//     spins (a barrier that cannot complete aborts the solve with an error instead of hanging the GPU);
+//   * ONE grid barrier per iteration: the recurrences are those of pipelined CG (Ghysels & Vanroose 2014),
+//     whose dot products (r,u), (w,u) use vectors that exist BEFORE the SpMV n = A M^-1 w, so a block
+//     publishes its slice of M^-1 w and its partial dot products together, crosses one barrier, and then
+//     gathers and reduces at the same time.  (Measured: a barrier costs ~2.6 us, draining the write-through
+//     stores ~2.5 us, so the Chronopoulos-Gear form with two of each per iteration ran at 17.6 us per
+//     iteration.)  Barrier: XCD-hierarchical counters, relaxed agent-scope polling, bounded spins (a barrier
+//     that cannot complete aborts the solve with an error instead of hanging the GPU);
+//   * pipelined CG carries w = A u by recurrence, so its recursive residual can drift from the true one.
+//     The stop rule is therefore applied to the TRUE residual: when the recurrence reports convergence the
+//     kernel recomputes r = b - A x, tests  r.M^-1 r <= tol^2 b.M^-1 b  (the rule of the launch path), and
+//     if the test fails, restarts CG from that true residual.  Pipelined CG is also known to stagnate -- and
+//     then blow up -- when asked for residuals near the FP64 floor of a system, so it is only used down to a
+//     relative residual of 1e-9 (kOcPipeFloor): below that, or after 50 iterations without a new residual
+//     minimum, the kernel continues SEAMLESSLY (same x, u, p, s, gamma, alpha) with the Chronopoulos-Gear
+//     recurrences, which recompute w = A u every iteration at the price of a second barrier.  A
+//     verification that fails twice without a 4x improvement means the FP64 floor has been reached: the
+//     solve stops as converged, as a recurrence-only CG would;
 //   * every block reduces the partial records in the same fixed order, so all blocks take the same
-//     convergence decision and the result is deterministic run to run.
+//     decisions and the result is deterministic run to run.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels.hpp"
@@ -29,9 +43,8 @@ struct OcArgs {
     const int *ptr, *w, *col; const double *val;   // SELL-64 of Ahat
     const double *m, *dinv, *b;
     double *x, *u_out;
-    double *ubuf;       // [64 n_slices][4] published u (x, y, z, pad)
-    double *part;       // [G][8]  per-block partial sums (gamma[3], delta[3])
-    double *part_b;     // [G][4]  per-block partial sums of b . dinv . b
+    double *ubuf;       // [2][64 n_slices][4] published vector (x, y, z, pad), double-buffered by phase parity
+    double *part;       // [2][8][G] per-block partial sums, double-buffered by phase parity
     unsigned *bar;      // barrier words, 16-word (64 B) stride: [0..7] group counters, [8] top, [9..16] generations, [17] abort
     int *counters; CgScal *scal; int *sig;
     unsigned long long *prof;   // diagnosis only (ADMM_HIP_OC_PROF=1): [64][8] timestamps of block 0
@@ -41,6 +54,8 @@ struct OcArgs {
 
 constexpr int kOcScratch = 2048;          // bytes of LDS ahead of the matrix slab
 constexpr unsigned kOcSpinLimit = 4000000u;
+constexpr double kOcPipeFloor = 1e-18;    // squared relative residual below which the pipelined recurrences are not trusted
+constexpr int kOcStagnation = 50;         // pipelined iterations without a new residual minimum before switching
 
 __device__ __forceinline__ void oc_store_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off, double a, double b) {
     union { double d[2]; v4u v; } t; t.d[0] = a; t.d[1] = b;
@@ -97,75 +112,117 @@ __device__ __forceinline__ bool oc_barrier(unsigned *bar, unsigned epoch, int G,
     return *ok_lds != 0;
 }
 
-// block-wide sums of NQ quantities over nw waves; result valid in every thread, fixed summation order
-template <int NQ>
-__device__ __forceinline__ void oc_block_sum(double *q, double *red, int nw) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+// Wave-wide sums of 8 quantities by a halving butterfly (10 double shuffles instead of 48): on return the
+// lanes with (lane >> 3) == id hold the wave total of q[id].  Fixed order -> deterministic.
+__device__ __forceinline__ double wave_sum8(const double *q) {
+    const int lane = threadIdx.x & 63;
+    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
+    double a[4], b[2], c;
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const double s = wave_sum(q[i]);
-        if (lane == 0) red[wv * NQ + i] = s;
+    for (int i = 0; i < 4; ++i) {
+        const double send = h5 ? q[i] : q[4 + i], keep = h5 ? q[4 + i] : q[i];
+        a[i] = keep + __shfl_xor(send, 32, 64);
     }
-    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        double s = 0.0;
-        for (int w = 0; w < nw; ++w) s += red[w * NQ + i];
-        q[i] = s;
+    for (int i = 0; i < 2; ++i) {
+        const double send = h4 ? a[i] : a[2 + i], keep = h4 ? a[2 + i] : a[i];
+        b[i] = keep + __shfl_xor(send, 16, 64);
     }
+    {
+        const double send = h3 ? b[0] : b[1], keep = h3 ? b[1] : b[0];
+        c = keep + __shfl_xor(send, 8, 64);
+    }
+    c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 1, 64);
+    return c;
+}
+
+// Block totals of q[0..5] -> this block's record of the given parity (SoA: quantity-major, so the readers
+// are coalesced).  One __syncthreads; `red` may be reused after the next barrier.
+__device__ __forceinline__ void oc_publish_partials(const double *q6, double *red, int nw, __amdgpu_buffer_rsrc_t rs_p, int par, int G) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double q8[8] = {q6[0], q6[1], q6[2], q6[3], q6[4], q6[5], 0.0, 0.0};
+    const double c = wave_sum8(q8);
+    if ((lane & 7) == 0 && lane < 48) red[wv * 8 + (lane >> 3)] = c;
     __syncthreads();
+    if (tid < 6) {
+        double sm = 0.0;
+        for (int w = 0; w < nw; ++w) sm += red[w * 8 + tid];
+        oc_store_sc1(rs_p, ((par * 8 + tid) * G + (int)blockIdx.x) * 8, sm);
+    }
 }
 
 // acc = sum_k Ahat(row, k) * in[col_k] for the three axes of this thread's row.  Columns [0, wl_s) come from
-// the LDS slab, the rest (only when a slice is wider than the slab) from global memory.  Two batches of four
-// gathers are kept in flight.
-template <bool FROM_UBUF>
-__device__ __forceinline__ void oc_row(__amdgpu_buffer_rsrc_t rs, const double *__restrict__ xin, const double *lv, const int *lc,
+// the LDS slab, the rest (only when a slice is wider than the slab) from global memory.  DEEP keeps two
+// batches of four gathers in flight (the <= 768-thread variant has the registers for it).
+template <bool FROM_UBUF, bool DEEP>
+__device__ __forceinline__ void oc_row(__amdgpu_buffer_rsrc_t rs, int buf_off, const double *__restrict__ xin, const double *lv, const int *lc,
                                        int wl_s, int w, const int *__restrict__ cpg, const double *__restrict__ vpg, double *acc) {
     acc[0] = acc[1] = acc[2] = 0.0;
     if (w == 0) return;
-    int c[4]; double v[4]; double g[12];
-    auto fetch = [&](int k, int *cc, double *vv) {
+    double g[12];
+    // the matrix values are read when a batch is consumed (LDS latency is small next to the gathers), so only
+    // the gathered vector entries occupy registers while they are in flight
+    auto gather = [&](int k, double *gg) {
+        int cc[4];
         if (k < wl_s) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { cc[i] = lc[64 * (k + i)]; vv[i] = lv[64 * (k + i)]; }
+            for (int i = 0; i < 4; ++i) cc[i] = lc[64 * (k + i)];
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { cc[i] = cpg[64 * (k + i)]; vv[i] = vpg[64 * (k + i)]; }
+            for (int i = 0; i < 4; ++i) cc[i] = cpg[64 * (k + i)];
         }
-    };
-    auto gather = [&](const int *cc, double *gg) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (FROM_UBUF) oc_load_sc1(rs, cc[i] * 32, gg + 3 * i);
+            if (FROM_UBUF) oc_load_sc1(rs, buf_off + cc[i] * 32, gg + 3 * i);
             else { const double *p = xin + 3 * (size_t)cc[i]; gg[3 * i] = p[0]; gg[3 * i + 1] = p[1]; gg[3 * i + 2] = p[2]; }
         }
     };
-    fetch(0, c, v);
-    gather(c, g);
-    for (int k = 4; k < w; k += 4) {
-        int cn[4]; double vn[4]; double gn[12];
-        fetch(k, cn, vn);
-        gather(cn, gn);
+    auto consume = [&](int k, const double *gg) {
+        double vv[4];
+        if (k < wl_s) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[0] = fma(v[i], g[3 * i], acc[0]); acc[1] = fma(v[i], g[3 * i + 1], acc[1]); acc[2] = fma(v[i], g[3 * i + 2], acc[2]);
-            c[i] = cn[i]; v[i] = vn[i];
+            for (int i = 0; i < 4; ++i) vv[i] = lv[64 * (k + i)];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vv[i] = vpg[64 * (k + i)];
         }
 #pragma unroll
-        for (int i = 0; i < 12; ++i) g[i] = gn[i];
-    }
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = fma(vv[i], gg[3 * i], acc[0]); acc[1] = fma(vv[i], gg[3 * i + 1], acc[1]); acc[2] = fma(vv[i], gg[3 * i + 2], acc[2]);
+        }
+    };
+    gather(0, g);
+    if (DEEP) {
+        for (int k = 4; k < w; k += 4) {
+            double gn[12];
+            gather(k, gn);
+            consume(k - 4, g);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        acc[0] = fma(v[i], g[3 * i], acc[0]); acc[1] = fma(v[i], g[3 * i + 1], acc[1]); acc[2] = fma(v[i], g[3 * i + 2], acc[2]);
+            for (int i = 0; i < 12; ++i) g[i] = gn[i];
+        }
+        consume(w - 4, g);
+    } else {
+        for (int k = 4; k < w; k += 4) {
+            consume(k - 4, g);
+            gather(k, g);
+        }
+        consume(w - 4, g);
     }
 }
 
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
+    constexpr bool DEEP = MAXT <= 768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *red = (double *)smem;                 // [16 * 9]
-    int *ok_lds = (int *)(smem + 16 * 9 * 8);     // barrier verdict
+    double *red = (double *)smem;                   // [16][8] wave partials
+    double *bc = (double *)(smem + 1024);           // [8] reduced scalars of the current phase
+    double *sc = (double *)(smem + 1088);           // [8] gamma_prev[3], alpha_prev[3]            (thread 0 only)
+    double *gbl = (double *)(smem + 1216);          // [4] b . M^-1 b per axis
+    double *glast = (double *)(smem + 1248);        // [4] last gamma per axis (reporting)
+    int *ok_lds = (int *)(smem + 1280);             // barrier verdict
+    double *ctl = (double *)(smem + 1296);          // [0] best ratio, [1] ratio of the last failed verification (thread 0 only);
+                                                    // [2..4] alpha, [5..7] beta of this iteration (broadcast)
+    int *ictl = (int *)(smem + 1360);               // [0] iterations since best, [1] failed verifications (thread 0 only); [2] action (broadcast)
     const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
     double *lv_all = (double *)(smem + kOcScratch);
     int *lc_all = (int *)(lv_all + (size_t)a.spb * a.wl * 64);
@@ -186,111 +243,213 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         int *lcw = lc_all + (size_t)wv * a.wl * 64 + lane;
         for (int k = 0; k < wl_s; ++k) { lvw[64 * k] = vpg[64 * k]; lcw[64 * k] = cpg[64 * k]; }
     }
-    __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)a.ubuf, 0, a.n_slices * 64 * 32, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)a.part, 0, a.G * 64, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)a.part_b, 0, a.G * 32, 0x00020000);
+    const int ub = a.n_slices * 64 * 32;    // bytes of one published-vector buffer
+    __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)a.ubuf, 0, 2 * ub, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)a.part, 0, 2 * 8 * a.G * 8, 0x00020000);
 
-    double rx[3], ru[3], rp[3], rsv[3], rd[3], rm[3], rid[3];
-    double q[9];
-    {   // u0 = dinv (b - A x0), partial b . dinv . b
-        double acc[3];
-        oc_row<false>(rs_u, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
+    double rx[3], ru[3], rw[3], rp[3], rsv[3], rz[3], rd[3], rm[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const size_t i = 3 * (size_t)(live ? row : 0) + j;
-            const double bi = live ? a.b[i] : 0.0;
-            rx[j] = live ? a.x[i] : 0.0; rd[j] = live ? a.dinv[i] : 0.0; rm[j] = live ? a.m[i] : 0.0;
-            rid[j] = live ? fast_rcp(rd[j]) : 0.0;
-            const double ri = bi - fma(rm[j], rx[j], acc[j]);
-            ru[j] = rd[j] * ri;
-            rp[j] = 0.0; rsv[j] = 0.0;
-            q[j] = bi * rd[j] * bi;
-        }
-        if (live_slice) { oc_store_sc1(rs_u, row * 32, ru[0], ru[1]); oc_store_sc1(rs_u, row * 32 + 16, ru[2]); }
-        oc_block_sum<3>(q, red, nw);
-        if (tid < 3) oc_store_sc1(rs_b, (int)blockIdx.x * 32 + 8 * tid, tid == 0 ? q[0] : (tid == 1 ? q[1] : q[2]));
+    for (int j = 0; j < 3; ++j) {
+        const size_t i = 3 * (size_t)(live ? row : 0) + j;
+        rx[j] = live ? a.x[i] : 0.0; rd[j] = live ? a.dinv[i] : 0.0; rm[j] = live ? a.m[i] : 0.0;
+        ru[j] = rw[j] = rp[j] = rsv[j] = rz[j] = 0.0;
     }
-
-    unsigned epoch = 0;
-    double g_prev[3] = {0, 0, 0}, a_prev[3] = {0, 0, 0}, gb[3] = {0, 0, 0}, g_last[3] = {0, 0, 0};
-    int iters = 0;
-    bool conv = false, aborted = false;
+    unsigned ph = 0;     // publish phase: buffer parity = ph & 1, barrier epoch = ph
     const bool prof = a.prof && blockIdx.x == 0 && tid == 0;
-#define OC_STAMP(slot) do { if (prof && it < 64) a.prof[it * 8 + (slot)] = wall_clock64(); } while (0)
-    for (int it = 0; it < a.max_iters; ++it) {
-        OC_STAMP(0);
-        if (!oc_barrier(a.bar, ++epoch, a.G, ok_lds, a.sig)) { aborted = true; break; }
-        OC_STAMP(1);
-        double acc[3], rw[3];
-        oc_row<true>(rs_u, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
+    int prof_n = 0;
+#define OC_STAMP(slot) do { if (prof && prof_n < 64) a.prof[prof_n * 8 + (slot)] = wall_clock64(); } while (0)
+
+    auto publish = [&](const double *v) {
+        if (live_slice) { const int off = (int)(ph & 1u) * ub + row * 32; oc_store_sc1(rs_u, off, v[0], v[1]); oc_store_sc1(rs_u, off + 16, v[2]); }
+    };
+    // after the barrier of phase ph: out = A (published vector), bc[0..5] = the six global sums
+    auto gather_and_reduce = [&](const double *self, double *out, bool do_gather, bool do_reduce) {
+        const int par = (int)(ph & 1u);
+        double rec[4] = {0.0, 0.0, 0.0, 0.0};
+        if (do_reduce && wv < 6) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int g = lane + 64 * j; if (g < a.G) rec[j] = oc_load_sc1_f64(rs_p, ((par * 8 + wv) * a.G + g) * 8); }
+        }
+        if (do_gather) {
+            double acc[3];
+            oc_row<true, DEEP>(rs_u, par * ub, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) out[j] = fma(rm[j], self[j], acc[j]);
+        }
+        if (!do_reduce) return;
+        if (wv < 6) {
+            const double sm = wave_sum(((rec[0] + rec[1]) + rec[2]) + rec[3]);
+            if (lane == 0) bc[wv] = sm;
+        }
+        for (int k = wv + nw; k < 6; k += nw) {   // blocks with fewer than 6 waves
+            double sm = 0.0;
+            for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_p, ((par * 8 + k) * a.G + g) * 8);
+            sm = wave_sum(sm);
+            if (lane == 0) bc[k] = sm;
+        }
+        __syncthreads();
+    };
+
+    // All scalar decisions (stop tests, alpha/beta, mode switches) are taken by thread 0, whose bookkeeping lives
+    // in LDS, and broadcast through LDS: uniform values would otherwise occupy registers in every lane, and the
+    // action code read back with readfirstlane keeps the control flow provably uniform.
+    int iters = 0, pipe_iters = 0;
+    bool conv = false, aborted = false;
+    auto action = [&]() -> int { __syncthreads(); return __builtin_amdgcn_readfirstlane(ictl[2]); };
+    // u = M^-1 (b - A x) from the x held in registers; gathers x from `xin` (plain loads, kernel start) or from
+    // the published copy; leaves gamma_true (and optionally b . M^-1 b) in q[0..5]
+    auto true_residual = [&](bool from_global, bool with_bnorm, double *q) -> bool {
+        double acc[3];
+        if (from_global) oc_row<false, DEEP>(rs_u, 0, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
+        else {
+            ++ph; publish(rx);
+            if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) return false;
+            oc_row<true, DEEP>(rs_u, (int)(ph & 1u) * ub, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            rw[j] = fma(rm[j], ru[j], acc[j]);
-            q[j] = ru[j] * ru[j] * rid[j];
-            q[3 + j] = rw[j] * ru[j];
+            const double bj = live ? a.b[3 * (size_t)row + j] : 0.0;
+            const double ri = bj - fma(rm[j], rx[j], acc[j]);
+            ru[j] = rd[j] * ri;
+            q[j] = ru[j] * ri;                               // r . M^-1 r
+            q[3 + j] = with_bnorm ? bj * rd[j] * bj : 0.0;   // b . M^-1 b
         }
-        {   // block partials -> this block's record
-            const int ln = tid & 63;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double sm = wave_sum(q[i]);
-                if (ln == 0) red[wv * 6 + i] = sm;
-            }
-            __syncthreads();
-            if (tid < 6) {
-                double sm = 0.0;
-                for (int ww = 0; ww < nw; ++ww) sm += red[ww * 6 + tid];
-                oc_store_sc1(rs_p, (int)blockIdx.x * 64 + 8 * tid, sm);
-            }
+        return true;
+    };
+    do {
+        // ---- start: TRUE residual of the warm start, stop test, w = A u ----------------------------------
+        {
+            double q[6];
+            true_residual(true, true, q);
+            ++ph; publish(ru);
+            oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
         }
-        OC_STAMP(2);
-        if (!oc_barrier(a.bar, ++epoch, a.G, ok_lds, a.sig)) { aborted = true; break; }
-        OC_STAMP(3);
-        // every block reduces all records in the same order (waves 0..3 only hold data)
+        if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+        gather_and_reduce(ru, rw, true, true);
+        if (tid == 0) {
+            bool c0 = true;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) q[i] = 0.0;
-        const int nrw = nw < 4 ? nw : 4;
-        if (wv < nrw) {
-            for (int i = tid; i < a.G; i += 64 * nrw) {
+            for (int j = 0; j < 3; ++j) { gbl[j] = bc[3 + j]; glast[j] = bc[j]; c0 = c0 && (bc[j] <= a.tol2 * bc[3 + j] + 1e-300); }
+            ctl[0] = 1e300; ctl[1] = 0.0; ictl[0] = 0; ictl[1] = 0; ictl[2] = c0 ? 1 : 0;
+        }
+        if (action() == 1) { conv = true; break; }
+        bool fresh = true, pipelined = true;
+        // ---- CG iterations: pipelined (one barrier) while trusted, Chronopoulos-Gear (two barriers) after ----
+        while (iters < a.max_iters) {
+            OC_STAMP(0);
+            double rn[3] = {0.0, 0.0, 0.0};
+            if (pipelined) {
+                double mm[3], q[6];
 #pragma unroll
-                for (int kk = 0; kk < 6; ++kk) q[kk] += oc_load_sc1_f64(rs_p, i * 64 + 8 * kk);
-                if (it == 0) {
+                for (int j = 0; j < 3; ++j) {
+                    mm[j] = rd[j] * rw[j];
+                    q[j] = (live ? ru[j] * ru[j] * fast_rcp(rd[j]) : 0.0);   // gamma = r . u
+                    q[3 + j] = rw[j] * ru[j];                                 // delta = w . u
+                }
+                ++ph; publish(mm);
+                oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
+                OC_STAMP(1);
+                if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                OC_STAMP(2);
+                gather_and_reduce(mm, rn, true, true);            // n = A M^-1 w, and the sums
+            } else {
+                double q[6];
+                ++ph; publish(ru);
+                if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                gather_and_reduce(ru, rw, true, false);           // w = A u, recomputed
 #pragma unroll
-                    for (int kk = 0; kk < 3; ++kk) q[6 + kk] += oc_load_sc1_f64(rs_b, i * 32 + 8 * kk);
+                for (int j = 0; j < 3; ++j) {
+                    q[j] = (live ? ru[j] * ru[j] * fast_rcp(rd[j]) : 0.0);
+                    q[3 + j] = rw[j] * ru[j];
+                }
+                ++ph;
+                oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
+                if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                gather_and_reduce(nullptr, nullptr, false, true);
+            }
+            OC_STAMP(3);
+            if (tid == 0) {   // action: 0 update, 1 verify on the true residual, 2 non-finite sums; +4: leave the pipelined form after the update
+                double ratio = 0.0;
+                bool below_trig = true, below_tol = true, below_floor = true;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    ratio = fmax(ratio, bc[j] / (gbl[j] + 1e-300));
+                    below_trig = below_trig && (bc[j] <= 0.9 * a.tol2 * gbl[j] + 1e-300);
+                    below_tol = below_tol && (bc[j] <= a.tol2 * gbl[j] + 1e-300);
+                    below_floor = below_floor && (bc[j] <= kOcPipeFloor * gbl[j] + 1e-300);
+                }
+                int act = 0;
+                if (!(ratio < 1e300)) act = 2;
+                else if (pipelined ? (below_trig && 0.9 * a.tol2 >= kOcPipeFloor) : below_tol) act = 1;
+                else {
+                    if (pipelined) {
+                        if (ratio < ctl[0]) { ctl[0] = ratio; ictl[0] = 0; } else ictl[0] += 1;
+                        if (below_floor || ictl[0] >= kOcStagnation) act = 4;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double g = bc[j], d = bc[3 + j];
+                        double alpha, beta;
+                        if (fresh) { beta = 0.0; alpha = (d > 0.0) ? g / d : 0.0; }
+                        else {
+                            const double gp = sc[j], ap = sc[3 + j];
+                            beta = (gp > 0.0) ? g / gp : 0.0;
+                            const double den = (ap != 0.0) ? d - beta * g / ap : d;
+                            alpha = (den > 0.0) ? g / den : 0.0;
+                        }
+                        sc[j] = g; sc[3 + j] = alpha; glast[j] = g;
+                        ctl[2 + j] = alpha; ctl[5 + j] = beta;
+                    }
+                }
+                ictl[2] = act;
+            }
+            const int act = action();
+            if (act == 2) break;                                  // non-finite sums: give up, reported as unconverged
+            if (act == 1) {
+                // TRUE residual at the current x; if it fails the test it replaces the recursive one and CG
+                // restarts from it (beta = 0) in the Chronopoulos-Gear form.
+                double q[6];
+                if (!true_residual(false, false, q)) { aborted = true; break; }
+                ++ph;
+                oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
+                if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                gather_and_reduce(nullptr, nullptr, false, true);
+                if (tid == 0) {
+                    bool ok = true;
+                    double tr = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        glast[j] = bc[j];
+                        ok = ok && (bc[j] <= a.tol2 * gbl[j] + 1e-300);
+                        tr = fmax(tr, bc[j] / (gbl[j] + 1e-300));
+                    }
+                    // a failed verification that did not improve on the previous one by 4x: FP64 floor reached
+                    const bool done = ok || (ictl[1] >= 1 && !(tr <= 0.25 * ctl[1]));
+                    ctl[1] = tr; ictl[1] += 1;
+                    ictl[2] = done ? 1 : 0;
+                }
+                if (action() == 1) { conv = true; break; }
+                pipelined = false; fresh = true;
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double alpha = ctl[2 + j], beta = ctl[5 + j];
+                rsv[j] = fma(beta, rsv[j], rw[j]);
+                rp[j] = fma(beta, rp[j], ru[j]);
+                rx[j] = fma(alpha, rp[j], rx[j]);
+                ru[j] = fma(-alpha * rd[j], rsv[j], ru[j]);     // u = M^-1 (r - alpha s)
+                if (pipelined) {
+                    rz[j] = fma(beta, rz[j], rn[j]);
+                    rw[j] = fma(-alpha, rz[j], rw[j]);
                 }
             }
+            ++iters; fresh = false;
+            if (pipelined) { ++pipe_iters; if (act & 4) pipelined = false; }
+            OC_STAMP(4);
+            if (prof) ++prof_n;
         }
-        if (it == 0) oc_block_sum<9>(q, red, nrw); else oc_block_sum<6>(q, red, nrw);
-        OC_STAMP(4);
-        double alpha[3], beta[3];
-        conv = true;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if (it == 0) gb[j] = q[6 + j];
-            g_last[j] = q[j];
-            conv = conv && (q[j] <= a.tol2 * gb[j] + 1e-300);
-        }
-        if (conv) break;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const double g = q[j], d = q[3 + j];
-            if (it == 0) { beta[j] = 0.0; alpha[j] = (d > 0.0) ? g / d : 0.0; }
-            else {
-                beta[j] = (g_prev[j] > 0.0) ? g / g_prev[j] : 0.0;
-                const double den = (a_prev[j] != 0.0) ? d - beta[j] * g / a_prev[j] : d;
-                alpha[j] = (den > 0.0) ? g / den : 0.0;
-            }
-            g_prev[j] = g; a_prev[j] = alpha[j];
-            const double pi = fma(beta[j], rp[j], ru[j]);
-            const double si = fma(beta[j], rsv[j], rw[j]);
-            rp[j] = pi; rsv[j] = si;
-            rx[j] = fma(alpha[j], pi, rx[j]);
-            ru[j] = fma(-alpha[j] * rd[j], si, ru[j]);      // u = M^-1 (r - alpha s)
-        }
-        ++iters;
-        if (live_slice) { oc_store_sc1(rs_u, row * 32, ru[0], ru[1]); oc_store_sc1(rs_u, row * 32 + 16, ru[2]); }
-        OC_STAMP(5);
-    }
+    } while (false);
 #undef OC_STAMP
     if (live) {
 #pragma unroll
@@ -299,8 +458,8 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     if (blockIdx.x == 0 && tid == 0) {
         CgScal o;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { o.gamma[j] = g_last[j]; o.alpha[j] = a_prev[j]; o.gamma_b[j] = gb[j]; }
-        o.converged = (conv && !aborted) ? 1 : 0; o.iters = iters; o.seq = a.seq; o.pad_ = 0;
+        for (int j = 0; j < 3; ++j) { o.gamma[j] = glast[j]; o.alpha[j] = 0.0; o.gamma_b[j] = gbl[j]; }
+        o.converged = (conv && !aborted) ? 1 : 0; o.iters = iters; o.seq = a.seq; o.pad_ = pipe_iters;
         a.scal[0] = o;
         atomicAdd(a.counters, iters);
         if (o.converged) {

