@@ -301,7 +301,8 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
         std::vector<unsigned long long> h(64 * 8);
         if (hipMemcpyAsync(h.data(), c->oc_prof.p, h.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
         double d[5] = {0, 0, 0, 0, 0}; int n = 0;
-        for (int it = 1; it + 1 < 64 && h[(it + 1) * 8] > h[it * 8 + 4] && h[it * 8 + 4] > h[it * 8]; ++it, ++n) {
+        fprintf(stderr, "[oc_prof] LDS fill %.2f  start phase %.2f  loop %.2f  epilogue %.2f us\n", (double)(h[63 * 8 + 1] - h[63 * 8]) / 100, (double)(h[63 * 8 + 2] - h[63 * 8 + 1]) / 100, (double)(h[63 * 8 + 3] - h[63 * 8 + 2]) / 100, (double)(h[63 * 8 + 4] - h[63 * 8 + 3]) / 100);
+        for (int it = 1; it + 1 < 63 && h[(it + 1) * 8] > h[it * 8 + 4] && h[it * 8 + 4] > h[it * 8]; ++it, ++n) {
             for (int k = 0; k < 4; ++k) d[k] += (double)(h[it * 8 + k + 1] - h[it * 8 + k]);
             d[4] += (double)(h[(it + 1) * 8] - h[it * 8]);
         }
@@ -330,10 +331,11 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     const int T = 64 * spb;
     const int wmax = c->A_wmax;
     const size_t lds_max = std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
-    if (lds_max < (size_t)kOcScratch + (size_t)T * 4 * 12) return hipSuccess;
-    int wl = (int)((lds_max - kOcScratch) / ((size_t)T * 12)) & ~3;
+    const size_t fixed = (size_t)kOcScratch + (size_t)spb * kOcStage;
+    if (lds_max < fixed + (size_t)T * 4 * 12) return hipSuccess;
+    int wl = (int)((lds_max - fixed) / ((size_t)T * 12)) & ~3;
     wl = std::min(wl, wmax);
-    const size_t lds = (size_t)kOcScratch + (size_t)T * wl * 12;
+    const size_t lds = fixed + (size_t)T * wl * 12;
     const void *fn = T <= 768 ? (const void *)k_pcg_onchip<768> : (const void *)k_pcg_onchip<1024>;
     if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     int per_cu = 0;
@@ -342,7 +344,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     if (e != hipSuccess) return e;
     if (per_cu < 1 || G > cus) return hipSuccess; // one block per CU keeps every block resident whatever the LDS split
     c->oc_G = G; c->oc_spb = spb; c->oc_T = T; c->oc_wl = wl; c->oc_lds = lds;
-    if ((e = c->oc_ubuf.alloc((size_t)2 * ns * 64 * 4)) != hipSuccess) return e;
+    if ((e = c->oc_ubuf.alloc((size_t)2 * ns * 64 * 3)) != hipSuccess) return e;
     if ((e = c->oc_part.alloc((size_t)2 * 8 * G)) != hipSuccess) return e;
     if ((e = c->oc_bar.alloc(32 * 16)) != hipSuccess) return e;
     if ((e = hipMemset(c->oc_ubuf.p, 0, c->oc_ubuf.n * sizeof(double))) != hipSuccess) return e;

@@ -43,7 +43,7 @@ struct OcArgs {
     const int *ptr, *w, *col; const double *val;   // SELL-64 of Ahat
     const double *m, *dinv, *b;
     double *x, *u_out;
-    double *ubuf;       // [2][64 n_slices][4] published vector (x, y, z, pad), double-buffered by phase parity
+    double *ubuf;       // [2][3][64 n_slices] published vector, per axis, double-buffered by phase parity
     double *part;       // [2][8][G] per-block partial sums, double-buffered by phase parity
     unsigned *bar;      // barrier words, 16-word (64 B) stride: [0..7] group counters, [8] top, [9..16] generations, [17] abort
     int *counters; CgScal *scal; int *sig;
@@ -52,7 +52,8 @@ struct OcArgs {
     double tol2;
 };
 
-constexpr int kOcScratch = 2048;          // bytes of LDS ahead of the matrix slab
+constexpr int kOcScratch = 6144;          // bytes of LDS scratch ahead of the per-wave staging area and the matrix slab
+constexpr int kOcStage = 3 * 64 * 8;      // per-wave staging area (publish transposition)
 constexpr unsigned kOcSpinLimit = 4000000u;
 constexpr double kOcPipeFloor = 1e-18;    // squared relative residual below which the pipelined recurrences are not trusted
 constexpr int kOcStagnation = 50;         // pipelined iterations without a new residual minimum before switching
@@ -65,11 +66,14 @@ __device__ __forceinline__ void oc_store_sc1(__amdgpu_buffer_rsrc_t rs, int byte
     union { double d; v2u v; } t; t.d = a;
     __builtin_amdgcn_raw_buffer_store_b64(t.v, rs, byte_off, 0, 16);
 }
-__device__ __forceinline__ void oc_load_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off, double *g) {
-    union { double d[2]; v4u v; } lo; union { double d; v2u v; } hi;
-    lo.v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
-    hi.v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off + 16, 0, 16);
-    g[0] = lo.d[0]; g[1] = lo.d[1]; g[2] = hi.d;
+// published vectors are stored per axis (SoA): a wave's gather of one neighbour column is then three fully
+// coalesced 512-byte requests (12 cache lines) instead of 32 lines of a padded 32-byte AoS record
+__device__ __forceinline__ void oc_load_sc1(__amdgpu_buffer_rsrc_t rs, int byte_off, int axis_stride, double *g) {
+    union { double d; v2u v; } t0, t1, t2;
+    t0.v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 16);
+    t1.v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off + axis_stride, 0, 16);
+    t2.v = __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off + 2 * axis_stride, 0, 16);
+    g[0] = t0.d; g[1] = t1.d; g[2] = t2.d;
 }
 __device__ __forceinline__ double oc_load_sc1_f64(__amdgpu_buffer_rsrc_t rs, int byte_off) {
     union { double d; v2u v; } t;
@@ -112,41 +116,49 @@ __device__ __forceinline__ bool oc_barrier(unsigned *bar, unsigned epoch, int G,
     return *ok_lds != 0;
 }
 
-// Wave-wide sums of 8 quantities by a halving butterfly (10 double shuffles instead of 48): on return the
-// lanes with (lane >> 3) == id hold the wave total of q[id].  Fixed order -> deterministic.
-__device__ __forceinline__ double wave_sum8(const double *q) {
-    const int lane = threadIdx.x & 63;
-    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
-    double a[4], b[2], c;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double send = h5 ? q[i] : q[4 + i], keep = h5 ? q[4 + i] : q[i];
-        a[i] = keep + __shfl_xor(send, 32, 64);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double send = h4 ? a[i] : a[2 + i], keep = h4 ? a[2 + i] : a[i];
-        b[i] = keep + __shfl_xor(send, 16, 64);
-    }
-    {
-        const double send = h3 ? b[0] : b[1], keep = h3 ? b[1] : b[0];
-        c = keep + __shfl_xor(send, 8, 64);
-    }
-    c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 1, 64);
-    return c;
+// One DPP lane exchange of a double (two 32-bit DPP moves; VALU only, the LDS pipe stays free)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
 
 // Block totals of q[0..5] -> this block's record of the given parity (SoA: quantity-major, so the readers
-// are coalesced).  One __syncthreads; `red` may be reused after the next barrier.
-__device__ __forceinline__ void oc_publish_partials(const double *q6, double *red, int nw, __amdgpu_buffer_rsrc_t rs_p, int par, int G) {
+// are coalesced).  Wave level: two halving butterfly steps inside each quad (8 -> 4 -> 2 quantities per lane),
+// then two rotation steps over the 16-lane row, all with DPP; the four rows of a wave and the waves of the
+// block are summed through LDS by six threads in a fixed order.  One __syncthreads; `red` may be reused after
+// the next barrier.
+__device__ __forceinline__ void oc_publish_partials(const double *q6, double *red /* [16][4][8] */, int nw, __amdgpu_buffer_rsrc_t rs_p, int par, int G) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double q8[8] = {q6[0], q6[1], q6[2], q6[3], q6[4], q6[5], 0.0, 0.0};
-    const double c = wave_sum8(q8);
-    if ((lane & 7) == 0 && lane < 48) red[wv * 8 + (lane >> 3)] = c;
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+    double a[4], b[2];
+    {   // xor 1: lanes with bit0 = 0 keep q0..q3, the others q4..q7 (q6 = q7 = 0)
+        const double s0 = b0 ? q6[0] : q6[4], s1 = b0 ? q6[1] : q6[5], s2 = b0 ? q6[2] : 0.0, s3 = b0 ? q6[3] : 0.0;
+        a[0] = (b0 ? q6[4] : q6[0]) + dpp_f64<0xB1>(s0);
+        a[1] = (b0 ? q6[5] : q6[1]) + dpp_f64<0xB1>(s1);
+        a[2] = (b0 ? 0.0 : q6[2]) + dpp_f64<0xB1>(s2);
+        a[3] = (b0 ? 0.0 : q6[3]) + dpp_f64<0xB1>(s3);
+    }
+    {   // xor 2: bit1 = 0 keeps a0, a1
+        const double s0 = b1 ? a[0] : a[2], s1 = b1 ? a[1] : a[3];
+        b[0] = (b1 ? a[2] : a[0]) + dpp_f64<0x4E>(s0);
+        b[1] = (b1 ? a[3] : a[1]) + dpp_f64<0x4E>(s1);
+    }
+    // lane (b0, b1) of a quad now holds the quad sums of quantities id = 4 b0 + 2 b1 + {0, 1}; sum over the four
+    // quads of the 16-lane row with rotations by 8 and 4 (they preserve the two low lane bits)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { b[i] += dpp_f64<0x128>(b[i]); b[i] += dpp_f64<0x124>(b[i]); }
+    if ((lane & 15) < 4) {
+        const int id = 4 * (lane & 1) + (lane & 2);
+        double *dst = red + ((wv * 4 + (lane >> 4)) * 8 + id);
+        dst[0] = b[0]; dst[1] = b[1];
+    }
     __syncthreads();
     if (tid < 6) {
         double sm = 0.0;
-        for (int w = 0; w < nw; ++w) sm += red[w * 8 + tid];
+        for (int r = 0; r < 4 * nw; ++r) sm += red[r * 8 + tid];
         oc_store_sc1(rs_p, ((par * 8 + tid) * G + (int)blockIdx.x) * 8, sm);
     }
 }
@@ -155,7 +167,7 @@ __device__ __forceinline__ void oc_publish_partials(const double *q6, double *re
 // the LDS slab, the rest (only when a slice is wider than the slab) from global memory.  DEEP keeps two
 // batches of four gathers in flight (the <= 768-thread variant has the registers for it).
 template <bool FROM_UBUF, bool DEEP>
-__device__ __forceinline__ void oc_row(__amdgpu_buffer_rsrc_t rs, int buf_off, const double *__restrict__ xin, const double *lv, const int *lc,
+__device__ __forceinline__ void oc_row(__amdgpu_buffer_rsrc_t rs, int buf_off, int axis_stride, const double *__restrict__ xin, const double *lv, const int *lc,
                                        int wl_s, int w, const int *__restrict__ cpg, const double *__restrict__ vpg, double *acc) {
     acc[0] = acc[1] = acc[2] = 0.0;
     if (w == 0) return;
@@ -173,7 +185,7 @@ __device__ __forceinline__ void oc_row(__amdgpu_buffer_rsrc_t rs, int buf_off, c
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (FROM_UBUF) oc_load_sc1(rs, buf_off + cc[i] * 32, gg + 3 * i);
+            if (FROM_UBUF) oc_load_sc1(rs, buf_off + cc[i] * 8, axis_stride, gg + 3 * i);
             else { const double *p = xin + 3 * (size_t)cc[i]; gg[3 * i] = p[0]; gg[3 * i + 1] = p[1]; gg[3 * i + 2] = p[2]; }
         }
     };
@@ -214,17 +226,19 @@ template <int MAXT>
 __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     constexpr bool DEEP = MAXT <= 768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *red = (double *)smem;                   // [16][8] wave partials
-    double *bc = (double *)(smem + 1024);           // [8] reduced scalars of the current phase
-    double *sc = (double *)(smem + 1088);           // [8] gamma_prev[3], alpha_prev[3]            (thread 0 only)
-    double *gbl = (double *)(smem + 1216);          // [4] b . M^-1 b per axis
-    double *glast = (double *)(smem + 1248);        // [4] last gamma per axis (reporting)
-    int *ok_lds = (int *)(smem + 1280);             // barrier verdict
-    double *ctl = (double *)(smem + 1296);          // [0] best ratio, [1] ratio of the last failed verification (thread 0 only);
-                                                    // [2..4] alpha, [5..7] beta of this iteration (broadcast)
-    int *ictl = (int *)(smem + 1360);               // [0] iterations since best, [1] failed verifications (thread 0 only); [2] action (broadcast)
+    double *red = (double *)smem;                   // [16][4][8] row partials of every wave
+    double *bc = (double *)(smem + 4096 + 1024);           // [8] reduced scalars of the current phase
+    double *sc = (double *)(smem + 4096 + 1088);           // [8] gamma_prev[3], alpha_prev[3]            (thread 0 only)
+    double *gbl = (double *)(smem + 4096 + 1216);          // [4] b . M^-1 b per axis
+    double *glast = (double *)(smem + 4096 + 1248);        // [4] last gamma per axis (reporting)
+    int *ok_lds = (int *)(smem + 4096 + 1280);             // barrier verdict
+    double *ctl = (double *)(smem + 4096 + 1296);          // [0] best ratio, [1] ratio of the last failed verification (thread 0 only);
+                                                    // [2..4] alpha, [5..7] beta of this iteration (broadcast); [8..10] 1 / (b . M^-1 b)
+    int *ictl = (int *)(smem + 4096 + 1392);               // [0] iterations since best, [1] failed verifications (thread 0 only); [2] action (broadcast)
     const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
-    double *lv_all = (double *)(smem + kOcScratch);
+    if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[63 * 8 + 0] = wall_clock64();
+    double *stg = (double *)(smem + kOcScratch) + (size_t)wv * (kOcStage / 8);   // this wave's staging area
+    double *lv_all = (double *)(smem + kOcScratch + (size_t)nw * kOcStage);
     int *lc_all = (int *)(lv_all + (size_t)a.spb * a.wl * 64);
     const double *lv = lv_all + (size_t)wv * a.wl * 64 + lane;
     const int *lc = lc_all + (size_t)wv * a.wl * 64 + lane;
@@ -243,7 +257,9 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         int *lcw = lc_all + (size_t)wv * a.wl * 64 + lane;
         for (int k = 0; k < wl_s; ++k) { lvw[64 * k] = vpg[64 * k]; lcw[64 * k] = cpg[64 * k]; }
     }
-    const int ub = a.n_slices * 64 * 32;    // bytes of one published-vector buffer
+    if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[63 * 8 + 1] = wall_clock64();
+    const int as = a.n_slices * 64 * 8;     // bytes of one axis of a published vector
+    const int ub = 3 * as;                  // bytes of one published-vector buffer
     __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)a.ubuf, 0, 2 * ub, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)a.part, 0, 2 * 8 * a.G * 8, 0x00020000);
 
@@ -257,10 +273,21 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     unsigned ph = 0;     // publish phase: buffer parity = ph & 1, barrier epoch = ph
     const bool prof = a.prof && blockIdx.x == 0 && tid == 0;
     int prof_n = 0;
-#define OC_STAMP(slot) do { if (prof && prof_n < 64) a.prof[prof_n * 8 + (slot)] = wall_clock64(); } while (0)
+#define OC_STAMP(slot) do { if (prof && prof_n < 63) a.prof[prof_n * 8 + (slot)] = wall_clock64(); } while (0)
 
+    // Publish this wave's 64 x 3 values per axis with 16-byte write-through stores (8-byte sc1 stores cost
+    // 2.7x per byte), transposed through the wave's LDS staging area: lanes 0..31 store the x pairs and then
+    // the z pairs, lanes 32..63 the y pairs.
     auto publish = [&](const double *v) {
-        if (live_slice) { const int off = (int)(ph & 1u) * ub + row * 32; oc_store_sc1(rs_u, off, v[0], v[1]); oc_store_sc1(rs_u, off + 16, v[2]); }
+        if (!live_slice) return;
+        stg[lane] = v[0]; stg[64 + lane] = v[1]; stg[128 + lane] = v[2];
+        const double2 xy = *reinterpret_cast<const double2 *>(stg + 2 * lane);          // x pairs | y pairs
+        const int base = (int)(ph & 1u) * ub + s * 512 + (lane & 31) * 16;
+        oc_store_sc1(rs_u, base + (lane >= 32 ? as : 0), xy.x, xy.y);
+        if (lane < 32) {
+            const double2 zz = *reinterpret_cast<const double2 *>(stg + 128 + 2 * lane);
+            oc_store_sc1(rs_u, base + 2 * as, zz.x, zz.y);
+        }
     };
     // after the barrier of phase ph: out = A (published vector), bc[0..5] = the six global sums
     auto gather_and_reduce = [&](const double *self, double *out, bool do_gather, bool do_reduce) {
@@ -272,7 +299,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         }
         if (do_gather) {
             double acc[3];
-            oc_row<true, DEEP>(rs_u, par * ub, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
+            oc_row<true, DEEP>(rs_u, par * ub, as, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
 #pragma unroll
             for (int j = 0; j < 3; ++j) out[j] = fma(rm[j], self[j], acc[j]);
         }
@@ -300,11 +327,11 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     // the published copy; leaves gamma_true (and optionally b . M^-1 b) in q[0..5]
     auto true_residual = [&](bool from_global, bool with_bnorm, double *q) -> bool {
         double acc[3];
-        if (from_global) oc_row<false, DEEP>(rs_u, 0, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
+        if (from_global) oc_row<false, DEEP>(rs_u, 0, 0, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
         else {
             ++ph; publish(rx);
             if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) return false;
-            oc_row<true, DEEP>(rs_u, (int)(ph & 1u) * ub, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
+            oc_row<true, DEEP>(rs_u, (int)(ph & 1u) * ub, as, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -329,11 +356,12 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         if (tid == 0) {
             bool c0 = true;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { gbl[j] = bc[3 + j]; glast[j] = bc[j]; c0 = c0 && (bc[j] <= a.tol2 * bc[3 + j] + 1e-300); }
+            for (int j = 0; j < 3; ++j) { gbl[j] = bc[3 + j]; ctl[8 + j] = 1.0 / (bc[3 + j] + 1e-300); glast[j] = bc[j]; c0 = c0 && (bc[j] <= a.tol2 * bc[3 + j] + 1e-300); }
             ctl[0] = 1e300; ctl[1] = 0.0; ictl[0] = 0; ictl[1] = 0; ictl[2] = c0 ? 1 : 0;
         }
         if (action() == 1) { conv = true; break; }
         bool fresh = true, pipelined = true;
+        if (prof) a.prof[63 * 8 + 2] = wall_clock64();
         // ---- CG iterations: pipelined (one barrier) while trusted, Chronopoulos-Gear (two barriers) after ----
         while (iters < a.max_iters) {
             OC_STAMP(0);
@@ -368,40 +396,45 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 gather_and_reduce(nullptr, nullptr, false, true);
             }
             OC_STAMP(3);
-            if (tid == 0) {   // action: 0 update, 1 verify on the true residual, 2 non-finite sums; +4: leave the pipelined form after the update
-                double ratio = 0.0;
-                bool below_trig = true, below_tol = true, below_floor = true;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    ratio = fmax(ratio, bc[j] / (gbl[j] + 1e-300));
-                    below_trig = below_trig && (bc[j] <= 0.9 * a.tol2 * gbl[j] + 1e-300);
-                    below_tol = below_tol && (bc[j] <= a.tol2 * gbl[j] + 1e-300);
-                    below_floor = below_floor && (bc[j] <= kOcPipeFloor * gbl[j] + 1e-300);
-                }
+            if (wv == 0) {   // lanes 0..2 = one axis each.  action: 0 update, 1 verify on the true residual, 2 non-finite sums; +4: leave the pipelined form after the update
+                const int j = lane < 3 ? lane : 0;
+                const double g = bc[j], d = bc[3 + j], gbj = gbl[j];
+                const double ratio = g * ctl[8 + j];                       // gamma / (b . M^-1 b)
+                const unsigned long long m3 = 7ull;
+                const bool finite = (__ballot(ratio < 1e300) & m3) == m3;
+                const bool below_trig = (__ballot(g <= 0.9 * a.tol2 * gbj + 1e-300) & m3) == m3;
+                const bool below_tol = (__ballot(g <= a.tol2 * gbj + 1e-300) & m3) == m3;
+                const bool below_floor = (__ballot(g <= kOcPipeFloor * gbj + 1e-300) & m3) == m3;
+                double rmax = fmax(ratio, __shfl(ratio, 1, 64));
+                rmax = fmax(rmax, __shfl(ratio, 2, 64));                   // valid in lane 0
                 int act = 0;
-                if (!(ratio < 1e300)) act = 2;
+                if (!finite) act = 2;
                 else if (pipelined ? (below_trig && 0.9 * a.tol2 >= kOcPipeFloor) : below_tol) act = 1;
                 else {
                     if (pipelined) {
-                        if (ratio < ctl[0]) { ctl[0] = ratio; ictl[0] = 0; } else ictl[0] += 1;
-                        if (below_floor || ictl[0] >= kOcStagnation) act = 4;
+                        int since = 0;
+                        if (lane == 0) {
+                            since = ictl[0] + 1;
+                            if (rmax < ctl[0]) { ctl[0] = rmax; since = 0; }
+                            ictl[0] = since;
+                        }
+                        since = __shfl(since, 0, 64);
+                        if (below_floor || since >= kOcStagnation) act = 4;
                     }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const double g = bc[j], d = bc[3 + j];
+                    if (lane < 3) {
                         double alpha, beta;
-                        if (fresh) { beta = 0.0; alpha = (d > 0.0) ? g / d : 0.0; }
+                        if (fresh) { beta = 0.0; alpha = (d > 0.0) ? g * fast_rcp(d) : 0.0; }
                         else {
                             const double gp = sc[j], ap = sc[3 + j];
-                            beta = (gp > 0.0) ? g / gp : 0.0;
-                            const double den = (ap != 0.0) ? d - beta * g / ap : d;
-                            alpha = (den > 0.0) ? g / den : 0.0;
+                            beta = (gp > 0.0) ? g * fast_rcp(gp) : 0.0;
+                            const double den = (ap != 0.0) ? d - beta * g * fast_rcp(ap) : d;
+                            alpha = (den > 0.0) ? g * fast_rcp(den) : 0.0;
                         }
                         sc[j] = g; sc[3 + j] = alpha; glast[j] = g;
                         ctl[2 + j] = alpha; ctl[5 + j] = beta;
                     }
                 }
-                ictl[2] = act;
+                if (lane == 0) ictl[2] = act;
             }
             const int act = action();
             if (act == 2) break;                                  // non-finite sums: give up, reported as unconverged
@@ -450,6 +483,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
             if (prof) ++prof_n;
         }
     } while (false);
+    if (prof) a.prof[63 * 8 + 3] = wall_clock64();
 #undef OC_STAMP
     if (live) {
 #pragma unroll
@@ -467,6 +501,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
             atomicMax(a.counters + 3, iters);
             a.counters[8 + (a.seq & 63)] = iters;
         }
+        if (prof) a.prof[63 * 8 + 4] = wall_clock64();
     }
 }
 
