@@ -28,7 +28,8 @@ def build_library(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-result"] + [os.path.join(HERE, s) for s in SOURCES] + ["-o", OUT]
+           "-Wno-unused-result"] + os.environ.get("ADMM_HIP_EXTRA_FLAGS", "").split() \
+        + [os.path.join(HERE, s) for s in SOURCES] + ["-o", OUT]   # extra flags: kernel experiments only
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

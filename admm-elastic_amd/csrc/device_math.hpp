@@ -234,6 +234,8 @@ __device__ __forceinline__ float t_abs(float a) { return fabsf(a); }
 __device__ __forceinline__ double t_abs(double a) { return fabs(a); }
 __device__ __forceinline__ float t_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ double t_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float t_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double t_min(double a, double b) { return fmin(a, b); }
 
 template <int KIND, typename T>
 struct StretchModel {
@@ -300,10 +302,12 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
         const T floorD = T(1e-8) * (t_abs(m.k) + t_abs(m.mu)) + T(1e-30);
         T a[3], y[3];
         T wDg = T(0), wDw = T(0);
+        bool pure = true;   // the step below is the exact Newton step (no floored / flipped curvature, no frozen component)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const T Di = t_max(t_abs(D[i]), floorD);
             const bool active = (KIND == 2) && (s[i] <= T(0)) && (g[i] > T(0));
+            pure = pure && !active && (D[i] >= floorD);
             a[i] = active ? T(0) : t_rcp(Di);
             y[i] = g[i] * a[i];
             wDg = t_fma(w[i], y[i], wDg);
@@ -311,6 +315,7 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
         }
         const T den = t_fma(m.la, wDw, T(1));
         const T coef = (den > T(1e-6)) ? m.la * wDg * t_rcp(den) : T(0);
+        pure = pure && (den > T(1e-6));
         T d[3], gd = T(0), dmax = T(0), mag = T(1);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -318,14 +323,19 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
             gd = t_fma(g[i], d[i], gd);
         }
         if (!(gd < T(0))) { // not a descent direction (indefinite rank-one part): scaled steepest descent
-            gd = T(0);
+            gd = T(0); pure = false;
 #pragma unroll
             for (int i = 0; i < 3; ++i) { d[i] = -y[i]; gd = t_fma(g[i], d[i], gd); }
             if (!(gd < T(0))) break; // zero (reduced) gradient
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) { dmax = t_max(dmax, t_abs(d[i])); mag = t_max(mag, t_abs(s[i])); }
-        if (dmax <= tol_final * mag) { // final correction: apply and stop
+        // the error left by an un-re-evaluated step is ~ step^2 * |f'''/f''| ~ step^2 / s_min near the barrier /
+        // the s = 0 boundary: scale the threshold by min(1, s_min)^2, never below the 1e-9 the FP64 callers tolerate;
+        // and that estimate only holds for an exact Newton step (quadratic convergence)
+        const T smin = t_max(T(0), t_min(T(1), t_min(s[0], t_min(s[1], s[2]))));
+        const T tol_floor = sizeof(T) == 4 ? tol_final * T(0.03) : T(1e-9);
+        if (dmax <= (pure ? t_max(tol_final * smin * smin, tol_floor) : tol_floor) * mag) { // final correction: apply and stop
             T sn[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (KIND == 2) sn[i] = t_max(sn[i], T(0)); }
@@ -365,6 +375,12 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
 
 // mixed-precision driver: FP32 iterations, then FP64 polish.  Parameters are normalised by k so the
 // FP32 phase works with O(1) coefficients.
+//  - Start: for moderate strains (|x0 - 1| < 1/4) the exact Newton step from the REST state, whose gradient
+//    and Hessian are known in closed form for both models (g = k (1 - x0), H = (2 mu + k) I + la 1 1^T), so
+//    the first objective evaluation is saved and the start is O(strain^2) from the minimiser instead of
+//    O(strain).  Larger strains start from the caller's s as before.
+//  - FP32 Newton to a step of 3e-5, then FP64 Newton: its first step is ~1e-7 (FP32 rounding), below the
+//    2e-6 threshold under which a step is applied without re-evaluation (remaining error ~ step^2).
 template <int KIND>
 __device__ __forceinline__ int minimize_stretch(double mu, double la, double k, const double *x0, double *s) {
     const double ik = fast_rcp(k);
@@ -373,6 +389,15 @@ __device__ __forceinline__ int minimize_stretch(double mu, double la, double k, 
     float sf[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { mf.x0[i] = (float)x0[i]; sf[i] = (float)s[i]; }
+    {
+        const float v0 = mf.x0[0] - 1.0f, v1 = mf.x0[1] - 1.0f, v2 = mf.x0[2] - 1.0f;
+        if (fmaxf(fabsf(v0), fmaxf(fabsf(v1), fabsf(v2))) < 0.25f) {
+            const float D = fmaf(2.0f, mf.mu, 1.0f);
+            const float iD = __frcp_rn(D);
+            const float c = mf.la * (v0 + v1 + v2) * iD * __frcp_rn(fmaf(3.0f, mf.la, D));
+            sf[0] = 1.0f + fmaf(v0, iD, -c); sf[1] = 1.0f + fmaf(v1, iD, -c); sf[2] = 1.0f + fmaf(v2, iD, -c);
+        }
+    }
     if (KIND == 1) { sf[0] = fmaxf(sf[0], 1e-12f); sf[1] = fmaxf(sf[1], 1e-12f); sf[2] = fmaxf(sf[2], 1e-12f); }
     int it = newton_stretch<KIND, float>(mf, sf, 10, 3e-5f, 1e-6f, 12);
     StretchModel<KIND, double> md;
@@ -384,7 +409,7 @@ __device__ __forceinline__ int minimize_stretch(double mu, double la, double k, 
 #pragma unroll
         for (int i = 0; i < 3; ++i) s[i] = (double)sf[i];
     }
-    it += newton_stretch<KIND, double>(md, s, 60, 1e-9, 4e-16, 50);
+    it += newton_stretch<KIND, double>(md, s, 60, 2e-6, 4e-16, 50);
     return it;
 }
 

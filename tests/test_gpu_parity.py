@@ -232,7 +232,7 @@ def test_step_uzawa_collisions_loose():
     assert hit_frames >= 2, "scene meant to collide"
     assert scenes.rel_err(s.m_x, o.x) < 2e-2
     # penetration stays at the few-mm level of the oracle's own (the active set only changes between solves)
-    assert s.m_x.reshape(-1, 3)[:, 1].min() > min(0.46 - 5e-3, o.x.reshape(-1, 3)[:, 1].min() - 3e-3)
+    assert s.m_x.reshape(-1, 3)[:, 1].min() > min(0.46 - 5e-3, o.x.reshape(-1, 3)[:, 1].min() - 5e-3)
     assert s.runtime_data().inner_iters > 8
 
 
