@@ -227,7 +227,28 @@ __device__ __forceinline__ void usvt(const double *U, const double *s, const dou
 __device__ __forceinline__ float t_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double t_rcp(double x) { return fast_rcp(x); }
 __device__ __forceinline__ float t_log(float x) { return __logf(x); }
+// ln(x) for finite normal x > 0 (the callers pass J = s0 s1 s2 with every s >= 1e-12).  x = m 2^e with
+// m in [sqrt(1/2), sqrt(2)); ln m = 2 atanh(z), z = (m - 1)/(m + 1), |z| <= 0.1716: ten odd-series terms give
+// < 1 ulp of truncation error.  ~30 instructions against ~120 for the library log (the NH polish is VALU-bound).
+__device__ __forceinline__ double fast_log(double x) {
+    const int hi = __double2hiint(x), lo = __double2loint(x);
+    int e = ((hi >> 20) & 0x7ff) - 1023;
+    double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, lo);   // [1, 2)
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    const double z = (m - 1.0) * fast_rcp(m + 1.0);
+    const double z2 = z * z;
+    double p = 1.0 / 21.0;
+    p = fma(p, z2, 1.0 / 19.0); p = fma(p, z2, 1.0 / 17.0); p = fma(p, z2, 1.0 / 15.0); p = fma(p, z2, 1.0 / 13.0);
+    p = fma(p, z2, 1.0 / 11.0); p = fma(p, z2, 1.0 / 9.0); p = fma(p, z2, 1.0 / 7.0); p = fma(p, z2, 1.0 / 5.0);
+    p = fma(p, z2, 1.0 / 3.0);
+    const double lm = fma(z * z2, 2.0 * p, 2.0 * z);                  // 2 z (1 + z^2 p)
+    return fma((double)e, 0.6931471805599453, lm);
+}
+#ifdef ADMM_LIBM_LOG
 __device__ __forceinline__ double t_log(double x) { return log(x); }
+#else
+__device__ __forceinline__ double t_log(double x) { return fast_log(x); }
+#endif
 __device__ __forceinline__ float t_fma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ double t_fma(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ float t_abs(float a) { return fabsf(a); }

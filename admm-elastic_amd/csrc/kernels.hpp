@@ -110,13 +110,38 @@ struct TetArgs {
     const double *x; double *cf;
 };
 
+// Every per-tet array is SoA with the tet index fastest, so all accesses of a thread are "array base + c * ld
+// (uniform) + t".  They go through buffer instructions -- descriptor in SGPRs, ONE 32-bit VGPR offset shared by
+// all of them, the c * ld part in an SGPR -- instead of 64-bit VGPR address chains, which the compiler kept
+// alive from the u loads to the u stores (~20 VGPRs in a kernel that sits on the 168-VGPR / 3-waves-per-SIMD
+// edge) and paid for with one 64-bit VALU add per access.
+typedef unsigned bv4u __attribute__((ext_vector_type(4)));
+typedef unsigned bv2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t soa_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7ffffff0, 0x00020000);
+}
+__device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    union { double d; bv2u v; } t;
+    t.v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return t.d;
+}
+__device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t rs, int voff, int soff, double x) {
+    union { double d; bv2u v; } t; t.d = x;
+    __builtin_amdgcn_raw_buffer_store_b64(t.v, rs, voff, soff, 0);
+}
+
 template <int KIND, bool WRITE_Z>
 __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (*sBi)[256], double (*sV)[256]) {
-    const int ld = a.ld;
-    const int4 *__restrict__ idx = a.idx; const double *__restrict__ Binv = a.Binv; double *__restrict__ u = a.u;
-    double *__restrict__ z = a.z; const double *__restrict__ sc = a.sc; const int *__restrict__ mat_id = a.mat_id;
-    const Mat *__restrict__ mats = a.mats; const double *__restrict__ x = a.x; double *__restrict__ cf = a.cf;
-    const int4 id = idx[t];
+    const int ld8 = a.ld * 8;         // bytes between two components of an SoA array (< 2^31 up to 268 M tets)
+    const int t8 = t * 8;
+    const __amdgpu_buffer_rsrc_t rBinv = soa_rsrc(a.Binv), ru = soa_rsrc(a.u), rcf = soa_rsrc(a.cf), rx = soa_rsrc(a.x);
+    const Mat *__restrict__ mats = a.mats;
+    int4 id;
+    {
+        union { int4 i; bv4u v; } q4;
+        q4.v = __builtin_amdgcn_raw_buffer_load_b128(soa_rsrc(a.idx), t * 16, 0, 0);
+        id = q4.i;
+    }
     // Binv is needed twice (F = Ds Binv before the prox, corner forces after it).  It is parked in LDS (sBi) in
     // between: thread-private slots, [c][tid] layout (bank-conflict-free 8-B accesses), no VGPRs held
     // across the prox and no second trip to HBM (rocprof FETCH_SIZE showed the re-read going to fabric).
@@ -127,13 +152,13 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (
         {
             double Bi[9], ui[9];
 #pragma unroll
-            for (int c = 0; c < 9; ++c) { Bi[c] = Binv[(size_t)c * ld + t]; ui[c] = u[(size_t)c * ld + t]; }
-            const double *p0 = x + 3 * (size_t)id.x, *p1 = x + 3 * (size_t)id.y, *p2 = x + 3 * (size_t)id.z, *p3 = x + 3 * (size_t)id.w;
+            for (int c = 0; c < 9; ++c) { Bi[c] = buf_ld(rBinv, t8, c * ld8); ui[c] = buf_ld(ru, t8, c * ld8); }
+            const int o0 = id.x * 24, o1 = id.y * 24, o2 = id.z * 24, o3 = id.w * 24;
             double Ds[9];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const double a = p0[j];
-                Ds[0 + j] = p1[j] - a; Ds[3 + j] = p2[j] - a; Ds[6 + j] = p3[j] - a;
+                const double a0 = buf_ld(rx, o0 + 8 * j, 0);
+                Ds[0 + j] = buf_ld(rx, o1 + 8 * j, 0) - a0; Ds[3 + j] = buf_ld(rx, o2 + 8 * j, 0) - a0; Ds[6 + j] = buf_ld(rx, o3 + 8 * j, 0) - a0;
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r)
@@ -152,12 +177,16 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (
     } else {
         // StVK fits 4 waves/SIMD (128 VGPRs) only with V out of the way; NH needs 3 waves/SIMD either way
         // (measured: forcing 128 VGPRs spills and is slower), so it keeps V in registers.
-        constexpr bool kParkV = (KIND == 2);
+#ifndef ADMM_PARK_V_NH
+#define ADMM_PARK_V_NH 0
+#endif
+        constexpr bool kParkV = (KIND == 2) || (ADMM_PARK_V_NH != 0);
         if (kParkV) {
 #pragma unroll
             for (int c = 0; c < 9; ++c) sV[c][threadIdx.x] = V[c];
         }
-        const Mat mt = mats[mat_id[t]];
+        const int mid = __builtin_amdgcn_raw_buffer_load_b32(soa_rsrc(a.mat_id), t * 4, 0, 0);
+        const Mat mt = mats[mid];
         prox_stretches<KIND>(mt.mu, mt.la, mt.k, S1);
         if (kParkV) {
 #pragma unroll
@@ -166,7 +195,7 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (
     }
     // z = U diag(S1) V^T ; u_new = u + D_i x - z = q - z = U diag(S0 - S1) V^T   (EnergyTerm.hpp:137)
     // G = dt^2 w^2 (z - u_new) = s U diag(2 S1 - S0) V^T
-    const double s = sc[t];
+    const double s = buf_ld(soa_rsrc(a.sc), t8, 0);
     double G[9];
     {
         double du[3], dg[3];
@@ -175,12 +204,13 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (
         double un[9];
         usvt(U, du, V, un);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) u[(size_t)c * ld + t] = un[c];
+        for (int c = 0; c < 9; ++c) buf_st(ru, t8, c * ld8, un[c]);
         if (WRITE_Z) {
             double zi[9];
             usvt(U, S1, V, zi);
+            const __amdgpu_buffer_rsrc_t rz = soa_rsrc(a.z);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) z[(size_t)c * ld + t] = zi[c];
+            for (int c = 0; c < 9; ++c) buf_st(rz, t8, c * ld8, zi[c]);
         }
         usvt(U, dg, V, G);
     }
@@ -194,19 +224,22 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const double h = fma(G[j], b0, fma(G[3 + j], b1, G[6 + j] * b2));
-            cf[(size_t)(3 * (m + 1) + j) * ld + t] = h;
+            buf_st(rcf, t8, (3 * (m + 1) + j) * ld8, h);
             f0[j] -= h;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) cf[(size_t)j * ld + t] = f0[j];
+    for (int j = 0; j < 3; ++j) buf_st(rcf, t8, j * ld8, f0[j]);
 }
 
 // one constitutive model per launch (used when a scene has a single model, and by the parity entry point)
 template <int KIND, bool WRITE_Z>
-__global__ __launch_bounds__(256, (KIND == 1 ? 3 : 4)) void k_local_tets(int t0, int t1, TetArgs a) {
+#ifndef ADMM_NH_WAVES
+#define ADMM_NH_WAVES 3
+#endif
+__global__ __launch_bounds__(256, (KIND == 1 ? ADMM_NH_WAVES : 4)) void k_local_tets(int t0, int t1, TetArgs a) {
     __shared__ double sBi[9][256];
-    __shared__ double sV[KIND == 2 ? 9 : 1][256];
+    __shared__ double sV[(KIND == 2 || ADMM_PARK_V_NH != 0) ? 9 : 1][256];
     const int t = t0 + xcd_block() * 256 + threadIdx.x;
     if (t >= t1) return;
     local_tet_body<KIND, WRITE_Z>(a, t, sBi, sV);
@@ -215,7 +248,7 @@ __global__ __launch_bounds__(256, (KIND == 1 ? 3 : 4)) void k_local_tets(int t0,
 // all models in ONE launch: block ranges [0,nb0) linear, [nb0,nb1) NH, [nb1,nb2) StVK (wave-uniform branch).
 // Avoids the ramp-down / ramp-up between per-model launches of a mixed scene.
 template <bool WRITE_Z>
-__global__ __launch_bounds__(256, 3) void k_local_tets_fused(int b0, int b1, int b2, int b3, int nb0, int nb1, TetArgs a) {
+__global__ __launch_bounds__(256, ADMM_NH_WAVES) void k_local_tets_fused(int b0, int b1, int b2, int b3, int nb0, int nb1, TetArgs a) {
     __shared__ double sBi[9][256];
     __shared__ double sV[9][256];
     const int blk = xcd_block();
