@@ -404,7 +404,7 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     hipLaunchKernelGGL(k_rc_resid, dim3(c->NB), dim3(256), 0, st, sell_arg(c->A), c->m.p, b, x, c->rc_r0.p, c->rc_xs.p);
     if (B.cnt > 0) {
         hipLaunchKernelGGL(k_rc_dots, dim3(c->NBR), dim3(256), 0, st, c->nv, B, c->rc_r0.p, b, c->dinv.p, c->rc_part.p, c->NBR);
-        hipLaunchKernelGGL(k_rc_solve, dim3(1), dim3(256), 0, st, B.cnt, c->rc_part.p, c->NBR, c->pcg_tol * c->pcg_tol, c->rc_coef.p);
+        hipLaunchKernelGGL(k_rc_solve, dim3(1), dim3(1024), 0, st, B.cnt, c->rc_part.p, c->NBR, c->pcg_tol * c->pcg_tol, c->rc_coef.p);
         hipLaunchKernelGGL(k_rc_apply, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, B, c->rc_coef.p, x);
     }
     const int rc = launch_pcg(c, b, x, c->pcg_max_iters);

@@ -60,6 +60,32 @@ __device__ __forceinline__ void block_sum(double *q, double *lds /* [4*NQ] */) {
     __syncthreads();
 }
 
+// One DPP lane exchange of a double (two 32-bit DPP moves; VALU only, the LDS pipe stays free)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Sums of 8 quantities over each 16-lane row of a wave, VALU only: two halving butterfly steps inside every quad
+// (8 -> 4 -> 2 quantities per lane, exact xor-1 / xor-2 quad permutes), then rotations by 8 and 4 over the row
+// (they preserve the two low lane bits).  On return the lanes with (lane & 15) < 4 hold the row sums of the
+// quantities id = 4 (lane & 1) + (lane & 2) + {0, 1} in r0, r1.  Fixed order -> deterministic.
+__device__ __forceinline__ void row_sum8(const double *q, double &r0, double &r1) {
+    const int lane = threadIdx.x & 63;
+    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+    double a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (b0 ? q[4 + i] : q[i]) + dpp_f64<0xB1>(b0 ? q[i] : q[4 + i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = (b1 ? a[2 + i] : a[i]) + dpp_f64<0x4E>(b1 ? a[i] : a[2 + i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { b[i] += dpp_f64<0x128>(b[i]); b[i] += dpp_f64<0x124>(b[i]); }
+    r0 = b[0]; r1 = b[1];
+}
+
 // XCD-aware block remap (MI355X: block b runs on XCD b % 8, each XCD has its own 4 MB L2).  Blocks that
 // land on the same XCD are given a CONTIGUOUS range of work, so neighbouring rows / elements -- which
 // share gathered cache lines -- hit the same L2 instead of re-fetching through the fabric.  Bijective on
@@ -623,7 +649,7 @@ constexpr int kRcQ = kRc * kRc + kRc + 2;
 __global__ __launch_bounds__(256) void k_rc_dots(int nv, RcBasis B, const double *__restrict__ r0, const double *__restrict__ b,
                                                  const double *__restrict__ dinv, double *__restrict__ part, int NBr) {
     const int cnt = B.cnt;
-    __shared__ double lds[4 * kRcQ];
+    __shared__ double red[16 * 8 * ((3 * kRcQ + 7) / 8)];
     double q[3][kRcQ];
 #pragma unroll
     for (int a = 0; a < 3; ++a)
@@ -647,12 +673,28 @@ __global__ __launch_bounds__(256) void k_rc_dots(int nv, RcBasis B, const double
             }
         }
     }
+    // block totals of the 3 x kRcQ quantities: DPP row sums (nine groups of eight), then the 16 (wave, row)
+    // partials of every quantity are added by one thread each
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        constexpr int NQ = 3 * kRcQ, NG = (NQ + 7) / 8;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        block_sum<kRcQ>(q[a], lds);
-        if (threadIdx.x == 0) {
+        for (int g = 0; g < NG; ++g) {
+            double q8[8];
 #pragma unroll
-            for (int i = 0; i < kRcQ; ++i) part[(size_t)(a * kRcQ + i) * NBr + blockIdx.x] = q[a][i];
+            for (int i = 0; i < 8; ++i) { const int f = 8 * g + i; q8[i] = (f < NQ) ? q[f / kRcQ][f % kRcQ] : 0.0; }
+            double r0, r1;
+            row_sum8(q8, r0, r1);
+            if ((lane & 15) < 4) {
+                double *dst = red + (wv * 4 + (lane >> 4)) * (8 * NG) + 8 * g + 4 * (lane & 1) + (lane & 2);
+                dst[0] = r0; dst[1] = r1;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < NQ) {
+            double sm = 0.0;
+            for (int r = 0; r < 16; ++r) sm += red[r * (8 * NG) + threadIdx.x];
+            part[(size_t)threadIdx.x * NBr + blockIdx.x] = sm;
         }
     }
 }
@@ -660,13 +702,13 @@ __global__ __launch_bounds__(256) void k_rc_dots(int nv, RcBasis B, const double
 // one block: finish the sums, solve the three cnt x cnt systems (symmetrised Cholesky that SKIPS numerically
 // null or dependent directions).  If r0 already meets pcg_tol on every axis the coefficients are exactly
 // zero: in a stationary state the stored pairs are round-off and must not perturb the iterate.
-__global__ __launch_bounds__(256) void k_rc_solve(int cnt, const double *__restrict__ part, int NBr, double tol2, double *__restrict__ coef) {
+__global__ __launch_bounds__(1024) void k_rc_solve(int cnt, const double *__restrict__ part, int NBr, double tol2, double *__restrict__ coef) {
     __shared__ double sums[3 * kRcQ];
     __shared__ int skip;
     const int t = threadIdx.x;
     {   // each wave reduces a strided subset of the 3 * kRcQ partial-sum rows
-        const int lane = t & 63, wv = t >> 6;
-        for (int qi = wv; qi < 3 * kRcQ; qi += 4) {
+        const int lane = t & 63, wv = t >> 6, nwv = (int)blockDim.x >> 6;
+        for (int qi = wv; qi < 3 * kRcQ; qi += nwv) {
             double s = 0.0;
             for (int i = lane; i < NBr; i += 64) s += part[(size_t)qi * NBr + i];
             s = wave_sum(s);

@@ -37,6 +37,10 @@ namespace admm_k {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+// LDS-qualified element types: pointers built by arithmetic on the dynamic LDS base otherwise decay to generic
+// (flat) pointers and every matrix access becomes a flat_load instead of a ds_read
+typedef __attribute__((address_space(3))) double LdsD;
+typedef __attribute__((address_space(3))) int LdsI;
 
 struct OcArgs {
     int n_rows, n_slices;
@@ -116,15 +120,6 @@ __device__ __forceinline__ bool oc_barrier(unsigned *bar, unsigned epoch, int G,
     return *ok_lds != 0;
 }
 
-// One DPP lane exchange of a double (two 32-bit DPP moves; VALU only, the LDS pipe stays free)
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
 // Block totals of q[0..5] -> this block's record of the given parity (SoA: quantity-major, so the readers
 // are coalesced).  Wave level: two halving butterfly steps inside each quad (8 -> 4 -> 2 quantities per lane),
 // then two rotation steps over the 16-lane row, all with DPP; the four rows of a wave and the waves of the
@@ -132,24 +127,9 @@ __device__ __forceinline__ double dpp_f64(double v) {
 // the next barrier.
 __device__ __forceinline__ void oc_publish_partials(const double *q6, double *red /* [16][4][8] */, int nw, __amdgpu_buffer_rsrc_t rs_p, int par, int G) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
-    double a[4], b[2];
-    {   // xor 1: lanes with bit0 = 0 keep q0..q3, the others q4..q7 (q6 = q7 = 0)
-        const double s0 = b0 ? q6[0] : q6[4], s1 = b0 ? q6[1] : q6[5], s2 = b0 ? q6[2] : 0.0, s3 = b0 ? q6[3] : 0.0;
-        a[0] = (b0 ? q6[4] : q6[0]) + dpp_f64<0xB1>(s0);
-        a[1] = (b0 ? q6[5] : q6[1]) + dpp_f64<0xB1>(s1);
-        a[2] = (b0 ? 0.0 : q6[2]) + dpp_f64<0xB1>(s2);
-        a[3] = (b0 ? 0.0 : q6[3]) + dpp_f64<0xB1>(s3);
-    }
-    {   // xor 2: bit1 = 0 keeps a0, a1
-        const double s0 = b1 ? a[0] : a[2], s1 = b1 ? a[1] : a[3];
-        b[0] = (b1 ? a[2] : a[0]) + dpp_f64<0x4E>(s0);
-        b[1] = (b1 ? a[3] : a[1]) + dpp_f64<0x4E>(s1);
-    }
-    // lane (b0, b1) of a quad now holds the quad sums of quantities id = 4 b0 + 2 b1 + {0, 1}; sum over the four
-    // quads of the 16-lane row with rotations by 8 and 4 (they preserve the two low lane bits)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { b[i] += dpp_f64<0x128>(b[i]); b[i] += dpp_f64<0x124>(b[i]); }
+    const double q8[8] = {q6[0], q6[1], q6[2], q6[3], q6[4], q6[5], 0.0, 0.0};
+    double b[2];
+    row_sum8(q8, b[0], b[1]);
     if ((lane & 15) < 4) {
         const int id = 4 * (lane & 1) + (lane & 2);
         double *dst = red + ((wv * 4 + (lane >> 4)) * 8 + id);
@@ -167,7 +147,7 @@ __device__ __forceinline__ void oc_publish_partials(const double *q6, double *re
 // the LDS slab, the rest (only when a slice is wider than the slab) from global memory.  DEEP keeps two
 // batches of four gathers in flight (the <= 768-thread variant has the registers for it).
 template <bool FROM_UBUF, bool DEEP>
-__device__ __forceinline__ void oc_row(__amdgpu_buffer_rsrc_t rs, int buf_off, int axis_stride, const double *__restrict__ xin, const double *lv, const int *lc,
+__device__ __forceinline__ void oc_row(__amdgpu_buffer_rsrc_t rs, int buf_off, int axis_stride, const double *__restrict__ xin, const LdsD *lv, const LdsI *lc,
                                        int wl_s, int w, const int *__restrict__ cpg, const double *__restrict__ vpg, double *acc) {
     acc[0] = acc[1] = acc[2] = 0.0;
     if (w == 0) return;
@@ -237,11 +217,11 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     int *ictl = (int *)(smem + 4096 + 1392);               // [0] iterations since best, [1] failed verifications (thread 0 only); [2] action (broadcast)
     const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
     if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[63 * 8 + 0] = wall_clock64();
-    double *stg = (double *)(smem + kOcScratch) + (size_t)wv * (kOcStage / 8);   // this wave's staging area
-    double *lv_all = (double *)(smem + kOcScratch + (size_t)nw * kOcStage);
-    int *lc_all = (int *)(lv_all + (size_t)a.spb * a.wl * 64);
-    const double *lv = lv_all + (size_t)wv * a.wl * 64 + lane;
-    const int *lc = lc_all + (size_t)wv * a.wl * 64 + lane;
+    LdsD *stg = (LdsD *)(smem + kOcScratch) + wv * (kOcStage / 8);   // this wave's staging area
+    LdsD *lv_all = (LdsD *)(smem + kOcScratch + nw * kOcStage);
+    LdsI *lc_all = (LdsI *)(lv_all + a.spb * a.wl * 64);
+    const LdsD *lv = lv_all + wv * a.wl * 64 + lane;
+    const LdsI *lc = lc_all + wv * a.wl * 64 + lane;
 
     const int s = __builtin_amdgcn_readfirstlane((int)blockIdx.x * a.spb + wv);
     const bool live_slice = s < a.n_slices;
@@ -253,8 +233,8 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     const int *cpg = a.col + base + lane;
     const double *vpg = a.val + base + lane;
     {   // the thread's matrix row -> LDS, once per solve
-        double *lvw = lv_all + (size_t)wv * a.wl * 64 + lane;
-        int *lcw = lc_all + (size_t)wv * a.wl * 64 + lane;
+        LdsD *lvw = lv_all + wv * a.wl * 64 + lane;
+        LdsI *lcw = lc_all + wv * a.wl * 64 + lane;
         for (int k = 0; k < wl_s; ++k) { lvw[64 * k] = vpg[64 * k]; lcw[64 * k] = cpg[64 * k]; }
     }
     if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[63 * 8 + 1] = wall_clock64();
@@ -281,12 +261,11 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     auto publish = [&](const double *v) {
         if (!live_slice) return;
         stg[lane] = v[0]; stg[64 + lane] = v[1]; stg[128 + lane] = v[2];
-        const double2 xy = *reinterpret_cast<const double2 *>(stg + 2 * lane);          // x pairs | y pairs
+        const double xy_x = stg[2 * lane], xy_y = stg[2 * lane + 1];                     // x pairs | y pairs
         const int base = (int)(ph & 1u) * ub + s * 512 + (lane & 31) * 16;
-        oc_store_sc1(rs_u, base + (lane >= 32 ? as : 0), xy.x, xy.y);
+        oc_store_sc1(rs_u, base + (lane >= 32 ? as : 0), xy_x, xy_y);
         if (lane < 32) {
-            const double2 zz = *reinterpret_cast<const double2 *>(stg + 128 + 2 * lane);
-            oc_store_sc1(rs_u, base + 2 * as, zz.x, zz.y);
+            oc_store_sc1(rs_u, base + 2 * as, stg[128 + 2 * lane], stg[129 + 2 * lane]);
         }
     };
     // after the barrier of phase ph: out = A (published vector), bc[0..5] = the six global sums
