@@ -293,6 +293,7 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.spb = c->oc_spb; a.wl = c->oc_wl; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
     a.tol2 = c->pcg_tol * c->pcg_tol;
     a.prof = c->oc_prof.p;
+    { const char *pb = getenv("ADMM_HIP_OC_PROF_BLOCK"); a.prof_block = pb ? atoi(pb) : 0; }
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg_onchip<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     c->last_launched_iters = 0; // the verdict of the solve is written to cg_scal[0]
@@ -300,14 +301,15 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     if (c->oc_prof.p) { // diagnosis only: per-phase time of block 0, mean over iterations 1..62
         std::vector<unsigned long long> h(64 * 8);
         if (hipMemcpyAsync(h.data(), c->oc_prof.p, h.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-        double d[5] = {0, 0, 0, 0, 0}; int n = 0;
+        double d[5] = {0, 0, 0, 0, 0}, drain = 0; int n = 0;
         fprintf(stderr, "[oc_prof] LDS fill %.2f  start phase %.2f  loop %.2f  epilogue %.2f us\n", (double)(h[63 * 8 + 1] - h[63 * 8]) / 100, (double)(h[63 * 8 + 2] - h[63 * 8 + 1]) / 100, (double)(h[63 * 8 + 3] - h[63 * 8 + 2]) / 100, (double)(h[63 * 8 + 4] - h[63 * 8 + 3]) / 100);
         for (int it = 1; it + 1 < 63 && h[(it + 1) * 8] > h[it * 8 + 4] && h[it * 8 + 4] > h[it * 8]; ++it, ++n) {
             for (int k = 0; k < 4; ++k) d[k] += (double)(h[it * 8 + k + 1] - h[it * 8 + k]);
+            drain += (double)(h[it * 8 + 5] - h[it * 8 + 1]);
             d[4] += (double)(h[(it + 1) * 8] - h[it * 8]);
         }
-        if (n) fprintf(stderr, "[oc_prof] n=%d  dots+publish %.2f  barrier %.2f  gather+reduce %.2f  update %.2f  | iteration %.2f us (100 MHz ticks)\n",
-                       n, d[0] / n / 100, d[1] / n / 100, d[2] / n / 100, d[3] / n / 100, d[4] / n / 100);
+        if (n) fprintf(stderr, "[oc_prof] n=%d  dots+publish %.2f  barrier %.2f  gather+reduce %.2f  update %.2f  | iteration %.2f us (100 MHz ticks); of the barrier, store drain %.2f\n",
+                       n, d[0] / n / 100, d[1] / n / 100, d[2] / n / 100, d[3] / n / 100, d[4] / n / 100, drain / n / 100);
         if (getenv("ADMM_HIP_OC_TRACE") && a.seq == atoi(getenv("ADMM_HIP_OC_TRACE"))) { std::vector<double> tr(1024); (void)hipMemcpy(tr.data(), (double *)c->oc_prof.p + 1024, 1024 * 8, hipMemcpyDeviceToHost); for (int i = 0; i < 420; ++i) fprintf(stderr, "[tr] %d gamma %.4e delta %.4e\n", i, tr[2 * i], tr[2 * i + 1]); }
         (void)hipMemsetAsync(c->oc_prof.p, 0, h.size() * 8, st);
     }

@@ -49,9 +49,10 @@ struct OcArgs {
     double *x, *u_out;
     double *ubuf;       // [2][3][64 n_slices] published vector, per axis, double-buffered by phase parity
     double *part;       // [2][8][G] per-block partial sums, double-buffered by phase parity
-    unsigned *bar;      // barrier words, 16-word (64 B) stride: [0..7] group counters, [8] top, [9..16] generations, [17] abort
+    unsigned *bar;      // barrier words, 16-word (64 B) stride: [0..7] group counters, [17] abort
     int *counters; CgScal *scal; int *sig;
-    unsigned long long *prof;   // diagnosis only (ADMM_HIP_OC_PROF=1): [64][8] timestamps of block 0
+    unsigned long long *prof;   // diagnosis only (ADMM_HIP_OC_PROF=1): [64][8] timestamps of block prof_block
+    int prof_block;
     int spb, wl, G, max_iters, seq;
     double tol2;
 };
@@ -86,35 +87,37 @@ __device__ __forceinline__ double oc_load_sc1_f64(__amdgpu_buffer_rsrc_t rs, int
 }
 
 // Grid barrier: every payload store before it was a write-through (sc1) store, so no release fence is
-// needed -- every wave drains its stores, one lane arrives.  Hierarchical: blocks of group (blockIdx & 7)
-// -- the XCD the block runs on, by observation; correctness does not depend on it -- count on their own
-// word, the last of a group counts on the top word, the last of all publishes the generation to all groups.
+// needed -- every wave drains its stores, one lane arrives.  Eight monotonic counters, one per group
+// (blockIdx & 7 = the XCD the block runs on, by observation; correctness does not depend on it): a block
+// arrives with ONE non-returning atomic on its group's counter (fire and forget: 32 arrivals per word, no
+// second level to wait for) and lanes 0..7 of wave 0 poll the eight counters with relaxed agent-scope loads
+// until each has reached (blocks in the group) x epoch.  Measured against the two-level form (per-group
+// counter -> top counter -> generation word): see DESIGN.md.
 __device__ __forceinline__ bool oc_barrier(unsigned *bar, unsigned epoch, int G, int *ok_lds, int *sig) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int x = (int)blockIdx.x & 7;
-        const unsigned nx = (unsigned)((G + 7 - x) >> 3);
-        const unsigned ng = (unsigned)(G < 8 ? G : 8);
-        const unsigned old = __hip_atomic_fetch_add(bar + 16 * x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == nx * epoch) {
-            const unsigned t = __hip_atomic_fetch_add(bar + 16 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (t + 1u == ng * epoch)
-                for (unsigned g = 0; g < ng; ++g)
-                    __hip_atomic_store(bar + 16 * (9 + g), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        if (lane == 0) __hip_atomic_fetch_add(bar + 16 * ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int x = lane & 7;
+        const unsigned need = (unsigned)((G + 7 - x) >> 3) * epoch;      // 0 for groups without blocks
+        unsigned *word = bar + 16 * (lane < 8 ? x : 17);                  // lane 8 watches the abort word in the same load
         int ok = 1;
         unsigned spins = 0;
-        while (__hip_atomic_load(bar + 16 * (9 + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > kOcSpinLimit || __hip_atomic_load(bar + 16 * 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(bar + 16 * 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(sig + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        while (true) {
+            const unsigned v = (lane < 9) ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (__all(lane >= 8 || v >= need)) break;
+            if (++spins > kOcSpinLimit || __any(lane == 8 && v != 0u)) {
+                if (lane == 0) {
+                    __hip_atomic_store(bar + 16 * 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sig + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 ok = 0;
                 break;
             }
+            __builtin_amdgcn_s_sleep(1);
         }
-        *ok_lds = ok;
+        if (lane == 0) *ok_lds = ok;
     }
     __syncthreads();
     return *ok_lds != 0;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                                                     // [2..4] alpha, [5..7] beta of this iteration (broadcast); [8..10] 1 / (b . M^-1 b)
     int *ictl = (int *)(smem + 4096 + 1392);               // [0] iterations since best, [1] failed verifications (thread 0 only); [2] action (broadcast)
     const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
-    if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[63 * 8 + 0] = wall_clock64();
+    if (a.prof && (int)blockIdx.x == a.prof_block && tid == 0) a.prof[63 * 8 + 0] = wall_clock64();
     LdsD *stg = (LdsD *)(smem + kOcScratch) + wv * (kOcStage / 8);   // this wave's staging area
     LdsD *lv_all = (LdsD *)(smem + kOcScratch + nw * kOcStage);
     LdsI *lc_all = (LdsI *)(lv_all + a.spb * a.wl * 64);
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         LdsI *lcw = lc_all + wv * a.wl * 64 + lane;
         for (int k = 0; k < wl_s; ++k) { lvw[64 * k] = vpg[64 * k]; lcw[64 * k] = cpg[64 * k]; }
     }
-    if (a.prof && blockIdx.x == 0 && tid == 0) a.prof[63 * 8 + 1] = wall_clock64();
+    if (a.prof && (int)blockIdx.x == a.prof_block && tid == 0) a.prof[63 * 8 + 1] = wall_clock64();
     const int as = a.n_slices * 64 * 8;     // bytes of one axis of a published vector
     const int ub = 3 * as;                  // bytes of one published-vector buffer
     __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)a.ubuf, 0, 2 * ub, 0x00020000);
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         ru[j] = rw[j] = rp[j] = rsv[j] = rz[j] = 0.0;
     }
     unsigned ph = 0;     // publish phase: buffer parity = ph & 1, barrier epoch = ph
-    const bool prof = a.prof && blockIdx.x == 0 && tid == 0;
+    const bool prof = a.prof && (int)blockIdx.x == a.prof_block && tid == 0;
     int prof_n = 0;
 #define OC_STAMP(slot) do { if (prof && prof_n < 63) a.prof[prof_n * 8 + (slot)] = wall_clock64(); } while (0)
 
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 ++ph; publish(mm);
                 oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
                 OC_STAMP(1);
+                if (a.prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); OC_STAMP(5); }
                 if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
                 OC_STAMP(2);
                 gather_and_reduce(mm, rn, true, true);            // n = A M^-1 w, and the sums
