@@ -432,3 +432,45 @@ def test_onchip_pcg_big_system_residual(big):
     for j in range(3):
         assert np.sum(r[:, j] ** 2 * dinv[:, j]) <= 1.05e-20 * np.sum(b.reshape(-1, 3)[:, j] ** 2 * dinv[:, j])
     assert np.abs(X - xt).max() < 1e-6
+
+
+def test_onchip_pcg_1024_thread_variant_and_global_columns():
+    """n = 60 Kuhn cube (226 981 vertices): 14 slices per CU -> the 1024-thread kernel variant, whose LDS slab
+    holds only the first 8 of the 16 matrix columns (the rest is read from global memory every iteration).
+    Checked against the launch path and against the host-side residual."""
+    import scipy.sparse as sp
+    from admm_elastic_amd import meshes
+    from admm_elastic_amd.solver import Lame
+    verts, tets = meshes.kuhn_cube(60)
+    sc = scenes.Scene()
+    sc.x = verts
+    sc.m = meshes.lumped_masses_tets(verts, tets)
+    sc.tets.append((verts, tets, Lame.soft_rubber(), pkg.TET_LINEAR, 0))
+    for i in np.nonzero(verts[:, 0] < 1e-9)[0]:
+        sc.pins[int(i)] = verts[i].copy()
+    sc.settings.update(admm_iters=2, linsolver=0, gravity=0.0)
+    nv = len(verts)
+    rng = np.random.default_rng(12)
+    xt = rng.standard_normal((nv, 3))
+    res = []
+    for launches in ("0", "1"):
+        os.environ["ADMM_HIP_PCG_LAUNCHES"] = launches
+        try:
+            s = sc.make_solver(pcg_tol=1e-9, pcg_max_iters=3000)
+        finally:
+            os.environ.pop("ADMM_HIP_PCG_LAUNCHES", None)
+        if launches == "0":
+            rp, ci, va = s.system_matrix()
+            Ah = sp.csr_matrix((va, ci, rp), shape=(nv, nv))
+            m = np.asarray(s.m_masses).reshape(-1, 3)
+            b = (m * xt + Ah @ xt).ravel()
+        x, it = s.global_solve(b, np.zeros(3 * nv))
+        res.append((x, it)); s.close()
+    (x_oc, it_oc), (x_l, it_l) = res
+    assert 0 < it_oc < 3000 and abs(it_oc - it_l) <= max(3, it_l // 20), (it_oc, it_l)
+    X = x_oc.reshape(-1, 3)
+    r = b.reshape(-1, 3) - (m * X + Ah @ X)
+    dinv = 1.0 / (m + Ah.diagonal()[:, None])
+    for j in range(3):
+        assert np.sum(r[:, j] ** 2 * dinv[:, j]) <= 1.05e-18 * np.sum(b.reshape(-1, 3)[:, j] ** 2 * dinv[:, j])
+    assert np.abs(x_oc - x_l).max() <= 1e-6 * np.abs(xt).max()
