@@ -1,0 +1,74 @@
+// CPU-only checks of the mesh layer (Meshes.hpp / AddMeshes.hpp): generators, lumped masses, surface
+// extraction, TetGen round trip, GrabbySphere, and that binding::add_tetmesh / add_trimesh fill the solver's
+// node vectors and energy-term list the way the reference's helpers do (AddMeshes.hpp:97-235).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include "AddMeshes.hpp"
+
+using namespace admm;
+
+#define CHECK(c) do { if (!(c)) { printf("FAILED: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    const std::string tmp = argc > 1 ? argv[1] : "/tmp/admm_test_mesh";
+    auto m = factory::make_tet_blocks(4, 3, 2);
+    CHECK(m->vertices.size() == 5 * 4 * 3 && m->tets.size() == 6 * 4 * 3 * 2);
+    double vol = 0.0;
+    for (int t = 0; t < (int)m->tets.size(); ++t) { CHECK(m->signed_volume(t) > 0.0); vol += m->signed_volume(t); }
+    CHECK(std::fabs(vol - 24.0) < 1e-12);
+    std::vector<double> masses;
+    m->weighted_masses(masses, 1522.0);
+    double ms = 0.0; for (double x : masses) { CHECK(x > 0.0); ms += x; }
+    CHECK(std::fabs(ms - 1522.0 * 24.0) < 1e-8);
+    std::vector<Vec3i> faces; m->surface_faces(faces);
+    CHECK(faces.size() == 2 * 2 * (4 * 3 + 4 * 2 + 3 * 2));            // two triangles per boundary cell face
+    std::vector<int> surf; m->surface_inds(surf);
+    CHECK(surf.size() == 5 * 4 * 3 - 3 * 2 * 1);                       // all but the interior vertices
+    // outward orientation: the closed surface has the mesh volume
+    double sv = 0.0;
+    for (const Vec3i &f : faces) sv += m->vertices[f[0]].dot(m->vertices[f[1]].cross(m->vertices[f[2]])) / 6.0;
+    CHECK(std::fabs(sv - 24.0) < 1e-10);
+    Vec3 lo, hi; m->bounds(lo, hi);
+    CHECK(lo[0] == 0 && hi[0] == 4 && hi[1] == 3 && hi[2] == 2);
+    // TetGen round trip (0-based) and a 1-based file with a flipped tet
+    meshio::save_tetgen(tmp, *m);
+    auto r = meshio::load_tetgen(tmp);
+    CHECK(r->vertices.size() == m->vertices.size() && r->tets.size() == m->tets.size());
+    for (size_t i = 0; i < m->tets.size(); ++i) for (int c = 0; c < 4; ++c) CHECK(r->tets[i][c] == m->tets[i][c]);
+    for (size_t i = 0; i < m->vertices.size(); ++i) CHECK((r->vertices[i] - m->vertices[i]).norm() == 0.0);
+    {
+        FILE *f = fopen((tmp + "_b.node").c_str(), "w");
+        fprintf(f, "# one tet, 1-based\n4 3 0 0\n1 0 0 0\n2 1 0 0\n3 0 1 0\n4 0 0 1\n"); fclose(f);
+        f = fopen((tmp + "_b.ele").c_str(), "w");
+        fprintf(f, "1 4 0\n1 1 3 2 4\n"); fclose(f);   // negatively oriented as written
+        auto b = meshio::load_tetgen(tmp + "_b");
+        CHECK(b->tets.size() == 1 && b->signed_volume(0) > 0.0);
+    }
+    auto p = factory::make_plane(5, 2.0, 0.5);
+    CHECK(p->vertices.size() == 36 && p->faces.size() == 50);
+    p->weighted_masses(masses, 1.0);
+    ms = 0.0; for (double x : masses) ms += x;
+    CHECK(std::fabs(ms - 4.0) < 1e-12);
+    // binding: nodes, masses (x3), energy terms, flags
+    Solver solver;
+    m->flags = binding::NOSELFCOLLISION | binding::NEOHOOKEAN;
+    binding::add_tetmesh(&solver, m, Lame::soft_rubber(), false);
+    CHECK(solver.m_x.size() == 3 * 60 && solver.m_masses.size() == 3 * 60 && solver.energyterms.size() == 144);
+    CHECK(solver.m_masses[0] == solver.m_masses[1] && solver.m_masses[1] == solver.m_masses[2] && solver.m_masses[0] > 0.0);
+    CHECK(dynamic_cast<NeoHookeanTet *>(solver.energyterms[0].get()) != nullptr);
+    GrabbySphere gs(Vec3(0, 0, 0), 1.01);
+    std::vector<int> inds; gs.get_indices(solver.m_x, inds);
+    CHECK(inds.size() == 4);   // (0,0,0), (1,0,0), (0,1,0), (0,0,1) of the tet block
+    p->flags = binding::NOSELFCOLLISION;
+    binding::add_trimesh(&solver, p, Lame(100, 0.1), false);
+    CHECK(solver.m_x.size() == 3 * (60 + 36) && solver.energyterms.size() == 144 + 50);
+    CHECK(dynamic_cast<TriEnergyTerm *>(solver.energyterms[144].get()) != nullptr);
+    CHECK(std::fabs(solver.m_x[3 * 60 + 1] - 0.5) < 1e-15);
+    p->flags = binding::STVK;
+    bool threw = false;
+    try { binding::add_trimesh(&solver, p, Lame(100, 0.1), false); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+    printf("SUCCESS\n");
+    return 0;
+}

@@ -1,0 +1,109 @@
+"""the C++ mesh layer (Meshes.hpp, AddMeshes.hpp) and the headless sample programs
+(samples/beams.cpp, samples/trianglestrain.cpp) on the C++ mirror of the reference API."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from admm_elastic_amd import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PK = os.path.join(ROOT, "admm-elastic_amd")
+
+
+def _compile(src, exe):
+    build.build_host_library()
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    deps = [src, build.OUT_HOST] + [os.path.join(PK, "host", "include", f) for f in os.listdir(os.path.join(PK, "host", "include"))]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-I" + os.path.join(PK, "host", "include"), src, "-L" + PK, "-ladmm_elastic",
+                        "-ladmm_hip", "-Wl,-rpath," + PK, "-o", exe], check=True)
+    return exe
+
+
+def _sample(name):
+    return _compile(os.path.join(ROOT, "samples", name + ".cpp"), os.path.join(ROOT, "samples", "_build", name))
+
+
+def test_mesh_layer_cpu(tmp_path):
+    exe = _compile(os.path.join(ROOT, "tests", "cpp", "test_meshes.cpp"), os.path.join(ROOT, "tests", "cpp", "_build", "test_meshes"))
+    r = subprocess.run([exe, str(tmp_path / "mesh")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "SUCCESS" in r.stdout, r.stdout + r.stderr
+
+
+def test_samples_build_and_print_help():
+    for name in ("beams", "trianglestrain"):
+        exe = _sample(name)
+        r = subprocess.run([exe, "-help"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and "-it" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+def test_beams_sample_matches_python_pipeline(tmp_path):
+    """BASELINE configs[0]: the C++ sample (own mesh generator, binding::add_tetmesh, moving pins) against the
+    same scene assembled in Python (tests/test_gpu_parity.py::test_step_parity_beams_config1, oracle-checked)."""
+    import admm_elastic_amd as pkg
+    from admm_elastic_amd import meshes
+    from admm_elastic_amd.solver import Lame
+    import scenes
+    exe = _sample("beams")
+    out = str(tmp_path / "beams")
+    r = subprocess.run([exe, "-it", "10", "-v", "0", "--frames", "6", "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]
+    x_cpp = np.loadtxt(out + ".xyz").ravel()
+    assert os.path.getsize(out + ".obj") > 1000
+    sc = scenes.Scene()
+    dt = 1.0 / 24.0
+    left, right = [], []
+    for kind, yoff in ((pkg.TET_LINEAR, 1.75), (pkg.TET_NEOHOOKEAN, 0.0), (pkg.TET_STVK, -1.75)):
+        verts, tets = meshes.tet_blocks(12, 3, 3, size=(4.0, 1.0, 1.0))
+        verts = verts - verts.mean(axis=0) + np.array([0.0, yoff, 0.0])
+        off = sc.add_tet_mesh(verts, tets, Lame(10000000.0, 0.399), kind)
+        left += [off + int(j) for j in np.nonzero(verts[:, 0] < verts[:, 0].min() + 1e-2)[0]]
+        right += [off + int(j) for j in np.nonzero(verts[:, 0] > verts[:, 0].max() - 1e-2)[0]]
+    pts = {v: sc.x[v].copy() for v in left + right}
+    for v in left + right:
+        sc.pins[v] = sc.x[v].copy()
+    sc.settings.update(admm_iters=10, linsolver=0, gravity=-9.8, timestep_s=dt)
+    s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=1000)
+    for frame in range(6):
+        for v in left:
+            pts[v] = pts[v] - np.array([dt, 0.0, 0.0])
+        for v in right:
+            pts[v] = pts[v] + np.array([dt, 0.0, 0.0])
+        keys = list(pts.keys())
+        s.set_pins(keys, [pts[k] for k in keys])
+        s.step()
+    assert x_cpp.size == s.m_x.size == 3 * 3 * 13 * 4 * 4
+    assert scenes.rel_err(x_cpp, s.m_x) < 1e-8, scenes.rel_err(x_cpp, s.m_x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ls", [0, 1, 2])
+def test_trianglestrain_sample_runs(tmp_path, ls):
+    """Two sheets, one strain-limited; free fall with -ls 0, onto a floor with the constraint-capable solvers.
+    Checks what the scene is about: the limited sheet stretches less, pins hold, nothing goes through the floor."""
+    exe = _sample("trianglestrain")
+    out = str(tmp_path / "cloth")
+    args = [exe, "-ls", str(ls), "-v", "0", "--frames", "12", "--cells", "10", "--out", out]
+    if ls != 0:
+        args += ["--floor", "-0.2"]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]
+    X = np.loadtxt(out + ".xyz")
+    assert X.shape == (242, 3) and np.isfinite(X).all()
+    right, left = X[:121], X[121:]                  # right sheet (no limits) was added first
+    assert right[:, 1].min() < 0.45 and left[:, 1].min() < 0.45           # both fell
+    if ls != 0:
+        assert X[:, 1].min() > -0.2 - 2e-2
+    # pinned corners (max-z edge, min / max x) stayed where they were: index (i * 11 + 10) for i = 0, 10
+    for sheet, x0 in ((right, 1.0), (left, -3.0)):
+        for i in (0, 10):
+            assert np.abs(sheet[i * 11 + 10] - np.array([x0 + 0.2 * i, 0.5, 1.0])).max() < 2e-2
+
+    def max_edge_stretch(S):
+        g = S.reshape(11, 11, 3)
+        e = np.concatenate([np.linalg.norm(g[1:] - g[:-1], axis=2).ravel(), np.linalg.norm(g[:, 1:] - g[:, :-1], axis=2).ravel()])
+        return e.max() / 0.2
+    assert max_edge_stretch(left) <= max_edge_stretch(right) + 1e-6
