@@ -270,7 +270,7 @@ void launch_gather(admm_hip_ctx *c) {
 // in-place RCCL sum all-reduce over xGMI; rank 0 contributed M x_bar and the pin terms.
 int launch_rhs(admm_hip_ctx *c) {
     launch_gather(c);
-    if (c->world > 1) {
+    if (c->world > 1 || c->comm) {
         if (!c->comm) return -2;
         ncclResult_t r = g_rccl.AllReduce(c->b.p, c->b.p, (size_t)c->n3, ncclDouble, ncclSum, c->comm, c->stream);
         if (r != ncclSuccess) return -3;
@@ -1062,7 +1062,10 @@ int admm_hip_comm_init(admm_hip_ctx *c, const char *id128, int rank, int world_s
     if (!c || !id128) return fail(ADMM_HIP_ERR_ARG, "comm_init: NULL argument");
     if (rank != c->rank || world_size != c->world)
         return fail(ADMM_HIP_ERR_ARG, "comm_init: rank/world_size differ from the ones the context was created with");
-    if (c->world <= 1) return ADMM_HIP_OK;
+    // a world of one needs no communicator; ADMM_HIP_FORCE_COMM=1 builds (and uses) one anyway so that the RCCL
+    // binding, the in-place all-reduce on the context's stream and its ordering against the persistent PCG kernel
+    // can be exercised on a single GPU (tests/test_multi_gpu.py)
+    if (c->world <= 1 && !(getenv("ADMM_HIP_FORCE_COMM") && getenv("ADMM_HIP_FORCE_COMM")[0] == '1')) return ADMM_HIP_OK;
     if (!g_rccl.load()) return fail(ADMM_HIP_ERR_COMM, "cannot load librccl");
     HIP_TRY(hipSetDevice(c->device));
     ncclUniqueId id;

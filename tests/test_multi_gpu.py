@@ -117,3 +117,29 @@ def test_rank_contexts_partition_the_local_step():
     assert np.abs(zs[:nrow_el] - z1[:nrow_el]).max() < 1e-12
     assert np.abs(us[:nrow_el] - u1[:nrow_el]).max() < 1e-12
     assert np.abs(bs - b1).max() <= 1e-9 * np.abs(b1).max()
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_path_on_one_gpu():
+    """The RCCL leg of the multi-GPU step on a single GPU: a communicator of world size 1 (ADMM_HIP_FORCE_COMM=1)
+    makes every ADMM iteration run the in-place ncclAllReduce of the right-hand side on the context's stream,
+    between the gather kernel and the persistent PCG kernel.  The all-reduce over one rank is the identity, so
+    the trajectory must equal the plain single-GPU one bit for bit."""
+    import ctypes as C
+    from admm_elastic_amd import capi
+    sc = scenes.mixed_cube_scene(6, admm_iters=6, linsolver=0)
+    ref = sc.make_solver(pcg_tol=1e-10, pcg_max_iters=500)
+    for _ in range(3):
+        ref.step()
+    s = sc.make_solver(pcg_tol=1e-10, pcg_max_iters=500)
+    os.environ["ADMM_HIP_FORCE_COMM"] = "1"
+    try:
+        buf = C.create_string_buffer(128)
+        capi.check(capi.lib().admm_hip_comm_unique_id(buf))
+        capi.check(capi.lib().admm_hip_comm_init(s._ctx, bytes(buf.raw), 0, 1))
+    finally:
+        os.environ.pop("ADMM_HIP_FORCE_COMM", None)
+    for _ in range(3):
+        s.step()
+    assert np.array_equal(s.m_x, ref.m_x)
+    assert s.runtime_data().unconverged_solves == 0
