@@ -167,7 +167,7 @@ struct admm_hip_ctx {
     // on-chip PCG (pcg_onchip.hpp): one persistent launch per solve when the system fits the chip
     bool oc_enabled = false;
     int oc_G = 0, oc_spb = 0, oc_T = 0, oc_wl = 0; size_t oc_lds = 0;
-    DevBuf<double> oc_ubuf, oc_part;
+    DevBuf<double> oc_ubuf, oc_part, oc_rc_part;
     DevBuf<unsigned> oc_bar;
     DevBuf<unsigned long long> oc_prof;
     int solve_seq = 0;
@@ -209,7 +209,7 @@ struct admm_hip_ctx {
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release();
-        oc_ubuf.release(); oc_part.release(); oc_bar.release(); oc_prof.release();
+        oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -281,9 +281,10 @@ int launch_rhs(admm_hip_ctx *c) {
 // PCG solve of A x = b, x = curr (warm start).  See the launch-control comment in admm_hip_ctx.
 constexpr int kChunk = 32;
 
-int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
+struct OcRc { bool on = false; RcBasis B{}; double *Eslot = nullptr, *Rslot = nullptr; };
+
+int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters, const OcRc &rc = OcRc()) {
     hipStream_t st = c->stream;
-    if (hipMemsetAsync(c->oc_bar.p, 0, c->oc_bar.n * sizeof(unsigned), st) != hipSuccess) return -1;
     OcArgs a{};
     a.n_rows = c->A.n_rows; a.n_slices = c->A.n_slices;
     a.ptr = c->A.ptr.p; a.w = c->A.w.p; a.col = c->A.idx.p; a.val = c->A.val.p;
@@ -292,6 +293,8 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
     a.spb = c->oc_spb; a.wl = c->oc_wl; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
     a.tol2 = c->pcg_tol * c->pcg_tol;
+    a.rc_on = rc.on ? 1 : 0; a.rc = rc.B; a.rc_xs = c->rc_xs.p; a.rc_r0 = c->rc_r0.p; a.rc_Eslot = rc.Eslot; a.rc_Rslot = rc.Rslot;
+    a.rc_part = c->oc_rc_part.p;
     a.prof = c->oc_prof.p;
     { const char *pb = getenv("ADMM_HIP_OC_PROF_BLOCK"); a.prof_block = pb ? atoi(pb) : 0; }
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
@@ -303,6 +306,7 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
         if (hipMemcpyAsync(h.data(), c->oc_prof.p, h.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
         double d[5] = {0, 0, 0, 0, 0}, drain = 0; int n = 0;
         fprintf(stderr, "[oc_prof] LDS fill %.2f  start phase %.2f  loop %.2f  epilogue %.2f us\n", (double)(h[63 * 8 + 1] - h[63 * 8]) / 100, (double)(h[63 * 8 + 2] - h[63 * 8 + 1]) / 100, (double)(h[63 * 8 + 3] - h[63 * 8 + 2]) / 100, (double)(h[63 * 8 + 4] - h[63 * 8 + 3]) / 100);
+        if (h[62 * 8 + 5]) fprintf(stderr, "[oc_prof] recycled start: x gather %.2f  pair loads + sums %.2f  barrier %.2f  read sums %.2f  cholesky %.2f (us)\n", (double)(h[62 * 8 + 1] - h[62 * 8]) / 100, (double)(h[62 * 8 + 2] - h[62 * 8 + 1]) / 100, (double)(h[62 * 8 + 3] - h[62 * 8 + 2]) / 100, (double)(h[62 * 8 + 4] - h[62 * 8 + 3]) / 100, (double)(h[62 * 8 + 5] - h[62 * 8 + 4]) / 100);
         for (int it = 1; it + 1 < 63 && h[(it + 1) * 8] > h[it * 8 + 4] && h[it * 8 + 4] > h[it * 8]; ++it, ++n) {
             for (int k = 0; k < 4; ++k) d[k] += (double)(h[it * 8 + k + 1] - h[it * 8 + k]);
             drain += (double)(h[it * 8 + 5] - h[it * 8 + 1]);
@@ -348,7 +352,9 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     c->oc_G = G; c->oc_spb = spb; c->oc_T = T; c->oc_wl = wl; c->oc_lds = lds;
     if ((e = c->oc_ubuf.alloc((size_t)2 * ns * 64 * 3)) != hipSuccess) return e;
     if ((e = c->oc_part.alloc((size_t)2 * 8 * G)) != hipSuccess) return e;
-    if ((e = c->oc_bar.alloc(32 * 16)) != hipSuccess) return e;
+    if ((e = c->oc_rc_part.alloc((size_t)72 * G)) != hipSuccess) return e;
+    if ((e = c->oc_bar.alloc(2 * 32 * 16)) != hipSuccess) return e;
+    if ((e = c->oc_bar.zero()) != hipSuccess) return e;
     if ((e = hipMemset(c->oc_ubuf.p, 0, c->oc_ubuf.n * sizeof(double))) != hipSuccess) return e;
     { const char *pe = getenv("ADMM_HIP_OC_PROF"); if (pe && pe[0] == '1') { if ((e = c->oc_prof.alloc(64 * 8 + 2048)) != hipSuccess) return e; if ((e = c->oc_prof.zero()) != hipSuccess) return e; } }
     c->oc_enabled = true;
@@ -403,6 +409,13 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     // basis: the (up to) kRc most recent pairs of THIS frame.  (Adding the previous frame's pair at the same
     // index was measured: it does not help the first solves of a frame.)
     for (int j = 1; j <= kRc && s - j >= 0; ++j) { B.E[B.cnt] = c->rc_E(par, s - j); B.R[B.cnt] = c->rc_R(par, s - j); ++B.cnt; }
+    static const bool rc_kernels = getenv("ADMM_HIP_RC_KERNELS") && getenv("ADMM_HIP_RC_KERNELS")[0] == '1';   // A/B: separate k_rc_* launches
+    if (c->oc_enabled && !rc_kernels) {   // projection, solve and the new pair in ONE persistent launch
+        OcRc rc; rc.on = true; rc.B = B; rc.Eslot = c->rc_E(par, s); rc.Rslot = c->rc_R(par, s);
+        const int r = launch_pcg_onchip(c, b, x, c->pcg_max_iters, rc);
+        c->rc_iter = s + 1;
+        return r;
+    }
     hipLaunchKernelGGL(k_rc_resid, dim3(c->NB), dim3(256), 0, st, sell_arg(c->A), c->m.p, b, x, c->rc_r0.p, c->rc_xs.p);
     if (B.cnt > 0) {
         hipLaunchKernelGGL(k_rc_dots, dim3(c->NBR), dim3(256), 0, st, c->nv, B, c->rc_r0.p, b, c->dinv.p, c->rc_part.p, c->NBR);

@@ -699,6 +699,58 @@ __global__ __launch_bounds__(256) void k_rc_dots(int nv, RcBasis B, const double
     }
 }
 
+// Coefficients of the Galerkin projection for ONE axis from its kRcQ sums S (G_ij = E_i.R_j at S[i*kRc+j],
+// g_i = E_i.r0 at S[16+i]): fully unrolled 4x4 masked Cholesky (static indices only: everything stays in
+// registers).  A direction is dropped (zero coefficient) when it is absent, numerically null, or dependent on the
+// accepted ones; `skip` (r0 already meets the tolerance) zeroes everything.
+template <typename SumPtr>
+__device__ __forceinline__ void rc_cholesky(SumPtr S, int cnt, bool skip, double *c) {
+    double G[kRc][kRc], g[kRc], L[kRc][kRc], y[kRc];
+    bool ok[kRc];
+    double gmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < kRc; ++i) {
+        g[i] = S[16 + i];
+#pragma unroll
+        for (int j = 0; j < kRc; ++j) { G[i][j] = 0.5 * (S[i * kRc + j] + S[j * kRc + i]); L[i][j] = 0.0; }
+        gmax = fmax(gmax, (i < cnt) ? G[i][i] : 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < kRc; ++i) {
+        double d = G[i][i];
+#pragma unroll
+        for (int k2 = 0; k2 < i; ++k2) d -= L[i][k2] * L[i][k2];
+        ok[i] = !skip && (i < cnt) && (G[i][i] > 1e-12 * gmax) && (d > 1e-10 * G[i][i]) && (d > 0.0);
+        const double ipiv = ok[i] ? fast_rsqrt(d) : 1.0;   // hardware seed + 2 Newton steps (IEEE sqrt / div sequences are slow
+        const double piv = ok[i] ? d * ipiv : 1.0;         // on one lane, and this runs on the critical path of every solve)
+        L[i][i] = piv;
+#pragma unroll
+        for (int k2 = 0; k2 < i; ++k2) L[i][k2] = ok[i] ? L[i][k2] : 0.0;
+#pragma unroll
+        for (int j = i + 1; j < kRc; ++j) {
+            double v = G[j][i];
+#pragma unroll
+            for (int k2 = 0; k2 < i; ++k2) v -= L[j][k2] * L[i][k2];
+            L[j][i] = ok[i] ? v * ipiv : 0.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kRc; ++i) {
+        double v = g[i];
+#pragma unroll
+        for (int k2 = 0; k2 < i; ++k2) v -= L[i][k2] * y[k2];
+        y[i] = ok[i] ? v * fast_rcp(L[i][i]) : 0.0;
+    }
+#pragma unroll
+    for (int i = kRc - 1; i >= 0; --i) {
+        double v = y[i];
+#pragma unroll
+        for (int k2 = i + 1; k2 < kRc; ++k2) v -= L[k2][i] * c[k2];
+        c[i] = ok[i] ? v * fast_rcp(L[i][i]) : 0.0;
+        if (!(c[i] == c[i])) c[i] = 0.0;
+    }
+}
+
 // one block: finish the sums, solve the three cnt x cnt systems (symmetrised Cholesky that SKIPS numerically
 // null or dependent directions).  If r0 already meets pcg_tol on every axis the coefficients are exactly
 // zero: in a stationary state the stored pairs are round-off and must not perturb the iterate.
@@ -723,52 +775,8 @@ __global__ __launch_bounds__(1024) void k_rc_solve(int cnt, const double *__rest
     }
     __syncthreads();
     if (t < 3) {
-        // fully unrolled 4x4 masked Cholesky (static indices only: everything stays in registers).  A direction is
-        // dropped (zero coefficient) when it is absent, numerically null, or dependent on the accepted ones.
-        const double *S = sums + kRcQ * t;
-        double G[kRc][kRc], g[kRc], L[kRc][kRc], y[kRc], c[kRc];
-        bool ok[kRc];
-        double gmax = 0.0;
-#pragma unroll
-        for (int i = 0; i < kRc; ++i) {
-            g[i] = S[16 + i];
-#pragma unroll
-            for (int j = 0; j < kRc; ++j) { G[i][j] = 0.5 * (S[i * kRc + j] + S[j * kRc + i]); L[i][j] = 0.0; }
-            gmax = fmax(gmax, (i < cnt) ? G[i][i] : 0.0);
-        }
-#pragma unroll
-        for (int i = 0; i < kRc; ++i) {
-            double d = G[i][i];
-#pragma unroll
-            for (int k2 = 0; k2 < i; ++k2) d -= L[i][k2] * L[i][k2];
-            ok[i] = !skip && (i < cnt) && (G[i][i] > 1e-12 * gmax) && (d > 1e-10 * G[i][i]) && (d > 0.0);
-            const double piv = ok[i] ? sqrt(d) : 1.0;
-            L[i][i] = piv;
-#pragma unroll
-            for (int k2 = 0; k2 < i; ++k2) L[i][k2] = ok[i] ? L[i][k2] : 0.0;
-#pragma unroll
-            for (int j = i + 1; j < kRc; ++j) {
-                double v = G[j][i];
-#pragma unroll
-                for (int k2 = 0; k2 < i; ++k2) v -= L[j][k2] * L[i][k2];
-                L[j][i] = ok[i] ? v / piv : 0.0;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < kRc; ++i) {
-            double v = g[i];
-#pragma unroll
-            for (int k2 = 0; k2 < i; ++k2) v -= L[i][k2] * y[k2];
-            y[i] = ok[i] ? v / L[i][i] : 0.0;
-        }
-#pragma unroll
-        for (int i = kRc - 1; i >= 0; --i) {
-            double v = y[i];
-#pragma unroll
-            for (int k2 = i + 1; k2 < kRc; ++k2) v -= L[k2][i] * c[k2];
-            c[i] = ok[i] ? v / L[i][i] : 0.0;
-            if (!(c[i] == c[i])) c[i] = 0.0;
-        }
+        double c[kRc];
+        rc_cholesky(sums + kRcQ * t, cnt, skip != 0, c);
 #pragma unroll
         for (int i = 0; i < kRc; ++i) coef[t * kRc + i] = c[i];
     }

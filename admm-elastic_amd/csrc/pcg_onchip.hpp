@@ -49,11 +49,17 @@ struct OcArgs {
     double *x, *u_out;
     double *ubuf;       // [2][3][64 n_slices] published vector, per axis, double-buffered by phase parity
     double *part;       // [2][8][G] per-block partial sums, double-buffered by phase parity
-    unsigned *bar;      // barrier words, 16-word (64 B) stride: [0..7] group counters, [17] abort
+    unsigned *bar;      // [2 sets][32 * 16] barrier words, 16-word (64 B) stride: [0..7] group counters, [17] abort
     int *counters; CgScal *scal; int *sig;
     unsigned long long *prof;   // diagnosis only (ADMM_HIP_OC_PROF=1): [64][8] timestamps of block prof_block
     int prof_block;
     int spb, wl, G, max_iters, seq;
+    // recycled (Galerkin) warm start inside the launch (replaces k_rc_resid / dots / solve / apply / record):
+    int rc_on;          // 1: project the initial error on the stored pairs, and store this solve's pair at the end
+    RcBasis rc;         // the (up to kRc) pairs (E_j, R_j = A E_j) to project on
+    double *rc_xs, *rc_r0;       // scratch: x and residual at entry (read back at the end for the new pair)
+    double *rc_Eslot, *rc_Rslot; // where this solve's pair goes
+    double *rc_part;             // [3 * kRcQ rounded up to 72][G] block partial sums of the projection
     double tol2;
 };
 
@@ -253,6 +259,10 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         rx[j] = live ? a.x[i] : 0.0; rd[j] = live ? a.dinv[i] : 0.0; rm[j] = live ? a.m[i] : 0.0;
         ru[j] = rw[j] = rp[j] = rsv[j] = rz[j] = 0.0;
     }
+    // Two sets of barrier counters, used by alternate solves: this launch counts on set (seq & 1) and clears the
+    // other one for the next launch (nobody touches it meanwhile), so no memset is needed between solves.
+    unsigned *const bar = a.bar + 32 * 16 * (a.seq & 1);
+    if (blockIdx.x == 0 && tid < 9) a.bar[32 * 16 * ((a.seq & 1) ^ 1) + 16 * (tid < 8 ? tid : 17)] = 0u;
     unsigned ph = 0;     // publish phase: buffer parity = ph & 1, barrier epoch = ph
     const bool prof = a.prof && (int)blockIdx.x == a.prof_block && tid == 0;
     int prof_n = 0;
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         if (from_global) oc_row<false, DEEP>(rs_u, 0, 0, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
         else {
             ++ph; publish(rx);
-            if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) return false;
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) return false;
             oc_row<true, DEEP>(rs_u, (int)(ph & 1u) * ub, as, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
         }
 #pragma unroll
@@ -329,11 +339,131 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         // ---- start: TRUE residual of the warm start, stop test, w = A u ----------------------------------
         {
             double q[6];
-            true_residual(true, true, q);
+            if (!a.rc_on) true_residual(true, true, q);
+            else {
+                // ---- recycled warm start (see k_rc_* in kernels.hpp for the launch-path version) ----------------
+                // r0 = b - A x0; A-orthogonal projection of the error on the stored exact pairs (E_j, A E_j):
+                // per axis G c = g with G_ij = E_i . R_j, g_i = E_i . r0;  x += E c,  r0 -= R c.
+                double acc[3], ri[3], bj[3];
+                const int cnt = a.rc.cnt;
+                double e[kRc][3], r[kRc][3];   // issued first: the HBM latency of the pairs hides behind the x gather
+#pragma unroll
+                for (int jj = 0; jj < kRc; ++jj)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const bool on = live && jj < cnt;
+                        e[jj][ax] = on ? a.rc.E[jj][3 * (size_t)row + ax] : 0.0;
+                        r[jj][ax] = on ? a.rc.R[jj][3 * (size_t)row + ax] : 0.0;
+                    }
+                if (prof) a.prof[62 * 8 + 0] = wall_clock64();
+                oc_row<false, DEEP>(rs_u, 0, 0, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
+                if (prof) a.prof[62 * 8 + 1] = wall_clock64();
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    bj[j] = live ? a.b[3 * (size_t)row + j] : 0.0;
+                    ri[j] = bj[j] - fma(rm[j], rx[j], acc[j]);
+                    if (live) { a.rc_xs[3 * (size_t)row + j] = rx[j]; a.rc_r0[3 * (size_t)row + j] = ri[j]; }
+                }
+                if (cnt > 0) {
+                    __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)a.rc_part, 0, 72 * a.G * 8, 0x00020000);
+                    // block totals of the 3 x kRcQ products: three rounds of 24 quantities (three DPP row reductions each)
+                    // through two alternating buffers in the still unused staging area -- one barrier per round
+#pragma unroll
+                    for (int g24 = 0; g24 < 3; ++g24) {
+                        double *buf = (double *)(smem + kOcScratch) + (g24 & 1) * (4 * nw * 24);   // [4 nw rows][24]; two of them = nw * kOcStage bytes
+#pragma unroll
+                        for (int h = 0; h < 3; ++h) {
+                            double q8[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const int f = 24 * g24 + 8 * h + i, ax = f / kRcQ, qi = f % kRcQ;     // compile-time after unrolling
+                                q8[i] = (f >= 3 * kRcQ) ? 0.0
+                                      : (qi < kRc * kRc) ? e[qi / kRc][ax < 3 ? ax : 0] * r[qi % kRc][ax < 3 ? ax : 0]
+                                      : (qi < kRc * kRc + kRc) ? e[(qi - kRc * kRc) % kRc][ax < 3 ? ax : 0] * ri[ax < 3 ? ax : 0]
+                                      : (qi == kRc * kRc + kRc) ? ri[ax < 3 ? ax : 0] * rd[ax < 3 ? ax : 0] * ri[ax < 3 ? ax : 0]
+                                      : bj[ax < 3 ? ax : 0] * rd[ax < 3 ? ax : 0] * bj[ax < 3 ? ax : 0];
+                            }
+                            double b0, b1;
+                            row_sum8(q8, b0, b1);
+                            if ((lane & 15) < 4) {
+                                double *dst = buf + (wv * 4 + (lane >> 4)) * 24 + 8 * h + 4 * (lane & 1) + (lane & 2);
+                                dst[0] = b0; dst[1] = b1;
+                            }
+                        }
+                        __syncthreads();
+                        for (int t = tid; t < 192; t += T) {   // t = quantity (24) x part (8): eight partial sums per quantity, combined by three shuffles
+                            const int qn = t >> 3, part = t & 7;
+                            double sm = 0.0;
+                            for (int rr = part; rr < 4 * nw; rr += 8) sm += buf[rr * 24 + qn];
+                            sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                            if (part == 0) oc_store_sc1(rs_r, ((24 * g24 + qn) * a.G + (int)blockIdx.x) * 8, sm);
+                        }
+                    }
+                    __syncthreads();
+                    if (prof) a.prof[62 * 8 + 2] = wall_clock64();
+                    ++ph;
+                    if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    if (prof) a.prof[62 * 8 + 3] = wall_clock64();
+                    {   // every block adds the G partials of every sum in the same order; wave wv takes sums wv, wv + nw, ...
+                        double v[6][4];
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) {
+                            const int k = wv + nw * t;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int g = lane + 64 * j;
+                                v[t][j] = (k < 3 * kRcQ && g < a.G) ? oc_load_sc1_f64(rs_r, (k * a.G + g) * 8) : 0.0;
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) {
+                            const int k = wv + nw * t;
+                            if (k < 3 * kRcQ) {
+                                const double sm = wave_sum(((v[t][0] + v[t][1]) + v[t][2]) + v[t][3]);
+                                if (lane == 0) red[k] = sm;
+                            }
+                        }
+                        for (int k = wv + 6 * nw; k < 3 * kRcQ; k += nw) {   // blocks with fewer than 11 waves
+                            double sm = 0.0;
+                            for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_r, (k * a.G + g) * 8);
+                            sm = wave_sum(sm);
+                            if (lane == 0) red[k] = sm;
+                        }
+                    }
+                    __syncthreads();
+                    if (prof) a.prof[62 * 8 + 4] = wall_clock64();
+                    double *coefL = red + 3 * kRcQ + 2;   // [3][kRc]
+                    if (tid < 3) {
+                        bool skip = true;    // r0 already meets the tolerance on every axis: the pairs must not perturb x
+                        for (int ax = 0; ax < 3; ++ax) skip = skip && (red[ax * kRcQ + 20] <= a.tol2 * red[ax * kRcQ + 21] + 1e-300);
+                        double c[kRc];
+                        rc_cholesky(red + kRcQ * tid, cnt, skip, c);
+#pragma unroll
+                        for (int i = 0; i < kRc; ++i) coefL[tid * kRc + i] = c[i];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+                        for (int jj = 0; jj < kRc; ++jj) {
+                            const double c = coefL[ax * kRc + jj];
+                            rx[ax] = fma(c, e[jj][ax], rx[ax]);
+                            ri[ax] = fma(-c, r[jj][ax], ri[ax]);
+                        }
+                    __syncthreads();   // coefL / red are reused below
+                    if (prof) a.prof[62 * 8 + 5] = wall_clock64();
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    ru[j] = rd[j] * ri[j];
+                    q[j] = ru[j] * ri[j];
+                    q[3 + j] = bj[j] * rd[j] * bj[j];
+                }
+            }
             ++ph; publish(ru);
             oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
         }
-        if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+        if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
         gather_and_reduce(ru, rw, true, true);
         if (tid == 0) {
             bool c0 = true;
@@ -360,13 +490,13 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
                 OC_STAMP(1);
                 if (a.prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); OC_STAMP(5); }
-                if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
                 OC_STAMP(2);
                 gather_and_reduce(mm, rn, true, true);            // n = A M^-1 w, and the sums
             } else {
                 double q[6];
                 ++ph; publish(ru);
-                if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
                 gather_and_reduce(ru, rw, true, false);           // w = A u, recomputed
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -375,7 +505,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 }
                 ++ph;
                 oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
-                if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
                 gather_and_reduce(nullptr, nullptr, false, true);
             }
             OC_STAMP(3);
@@ -428,7 +558,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 if (!true_residual(false, false, q)) { aborted = true; break; }
                 ++ph;
                 oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
-                if (!oc_barrier(a.bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
                 gather_and_reduce(nullptr, nullptr, false, true);
                 if (tid == 0) {
                     bool ok = true;
@@ -471,6 +601,14 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     if (live) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { a.x[3 * (size_t)row + j] = rx[j]; a.u_out[3 * (size_t)row + j] = ru[j]; }
+        if (a.rc_on) {   // this solve's pair: e = x - x_entry, A e = r_entry - r_final (exact: u carries the true residual)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const size_t i = 3 * (size_t)row + j;
+                a.rc_Eslot[i] = rx[j] - a.rc_xs[i];
+                a.rc_Rslot[i] = a.rc_r0[i] - ru[j] * fast_rcp(rd[j]);
+            }
+        }
     }
     if (blockIdx.x == 0 && tid == 0) {
         CgScal o;
