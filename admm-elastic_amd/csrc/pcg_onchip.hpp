@@ -6,17 +6,20 @@
 // L2 / Infinity Cache although the whole problem fits ON CHIP: 256 CUs x (160 KB LDS + 512 KB VGPRs).
 //   * block = one CU, wave = one 64-row SELL slice, thread = one vertex (3 dofs);
 //   * the thread's matrix row lives in LDS for the whole solve (loaded once, column-major per wave so the
-//     reads are conflict-free), its x / u / p / s / dinv / m entries live in registers;
-//   * the only per-iteration memory traffic is the search-space vector u: 32 B per vertex published with
-//     write-through (sc1) stores and gathered with sc1 loads (per-XCD L2s are not coherent), plus one
-//     64-byte record of partial dot products per block;
+//     reads are conflict-free ds_reads), its x / u / w / p / s / z / dinv / m entries live in registers;
+//   * the only per-iteration memory traffic is one vector: 24 B per vertex published per axis (SoA) with
+//     16-byte write-through (sc1) stores and gathered with sc1 loads (per-XCD L2s are not coherent), plus one
+//     record of six partial dot products per block;
 //   * ONE grid barrier per iteration: the recurrences are those of pipelined CG (Ghysels & Vanroose 2014),
 //     whose dot products (r,u), (w,u) use vectors that exist BEFORE the SpMV n = A M^-1 w, so a block
 //     publishes its slice of M^-1 w and its partial dot products together, crosses one barrier, and then
-//     gathers and reduces at the same time.  (Measured: a barrier costs ~2.6 us, draining the write-through
-//     stores ~2.5 us, so the Chronopoulos-Gear form with two of each per iteration ran at 17.6 us per
-//     iteration.)  Barrier: XCD-hierarchical counters, relaxed agent-scope polling, bounded spins (a barrier
-//     that cannot complete aborts the solve with an error instead of hanging the GPU);
+//     gathers and reduces at the same time.  (Measured per iteration: Chronopoulos-Gear with two barriers
+//     17.6 us; pipelined 9.0 us = 1.0 us draining the write-through stores + 2.4 us barrier + 3.1 us gather and
+//     reduction + the rest.)  Barrier: eight per-group counters, one fire-and-forget arrival, relaxed
+//     agent-scope polling, bounded spins (a barrier that cannot complete aborts the solve with an error instead
+//     of hanging the GPU); two counter sets alternate between solves so nothing is cleared between launches;
+//   * the recycled (Galerkin) warm start of the ADMM loop is the first phase of the same launch and the new
+//     (correction, A correction) pair is written in its epilogue;
 //   * pipelined CG carries w = A u by recurrence, so its recursive residual can drift from the true one.
 //     The stop rule is therefore applied to the TRUE residual: when the recurrence reports convergence the
 //     kernel recomputes r = b - A x, tests  r.M^-1 r <= tol^2 b.M^-1 b  (the rule of the launch path), and
