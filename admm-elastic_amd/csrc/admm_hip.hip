@@ -169,7 +169,8 @@ struct admm_hip_ctx {
     int oc_G = 0, oc_spb = 0, oc_T = 0, oc_wl = 0; size_t oc_lds = 0;
     DevBuf<double> oc_ubuf, oc_part, oc_rc_part;
     DevBuf<unsigned> oc_bar;
-    DevBuf<unsigned long long> oc_prof;
+    DevBuf<unsigned long long> oc_prof;   // diagnosis (ADMM_HIP_OC_PROF=1)
+    bool oc_debug = false; int oc_prof_block = 0;
     int solve_seq = 0;
     int marks_expected = 0;       // chunks closed so far (host count)
     int last_launched_iters = 0;
@@ -281,6 +282,37 @@ int launch_rhs(admm_hip_ctx *c) {
 // PCG solve of A x = b, x = curr (warm start).  See the launch-control comment in admm_hip_ctx.
 constexpr int kChunk = 32;
 
+// Diagnosis only (ADMM_HIP_OC_DEBUG=1 / ADMM_HIP_OC_PROF=1): synchronises after every solve and prints its verdict /
+// the per-phase times seen by block ADMM_HIP_OC_PROF_BLOCK (s_memrealtime ticks, 100 MHz).
+int oc_diagnostics(admm_hip_ctx *c, int seq) {
+    hipStream_t st = c->stream;
+    if (c->oc_debug) {
+        CgScal h;
+        if (hipMemcpyAsync(&h, c->cg_scal.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        fprintf(stderr, "[oc] seq %d iters %d (pipelined %d) conv %d gamma %.3e %.3e %.3e gb %.3e %.3e %.3e\n", h.seq, h.iters, h.pad_,
+                h.converged, h.gamma[0], h.gamma[1], h.gamma[2], h.gamma_b[0], h.gamma_b[1], h.gamma_b[2]);
+    }
+    if (!c->oc_prof.p) return 0;
+    std::vector<unsigned long long> h(64 * 8);
+    if (hipMemcpyAsync(h.data(), c->oc_prof.p, h.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+    auto us = [&](int a, int b) { return (double)(h[a] - h[b]) / 100.0; };
+    fprintf(stderr, "[oc_prof] seq %d: LDS fill %.2f  start phase %.2f  loop %.2f  epilogue %.2f us\n", seq, us(63 * 8 + 1, 63 * 8), us(63 * 8 + 2, 63 * 8 + 1),
+            us(63 * 8 + 3, 63 * 8 + 2), us(63 * 8 + 4, 63 * 8 + 3));
+    if (h[62 * 8 + 5])
+        fprintf(stderr, "[oc_prof] recycled start: x gather %.2f  pair loads + sums %.2f  barrier %.2f  read sums %.2f  cholesky %.2f (us)\n",
+                us(62 * 8 + 1, 62 * 8), us(62 * 8 + 2, 62 * 8 + 1), us(62 * 8 + 3, 62 * 8 + 2), us(62 * 8 + 4, 62 * 8 + 3), us(62 * 8 + 5, 62 * 8 + 4));
+    double d[5] = {0, 0, 0, 0, 0}, drain = 0; int n = 0;
+    for (int it = 1; it + 1 < 62 && h[(it + 1) * 8] > h[it * 8 + 4] && h[it * 8 + 4] > h[it * 8]; ++it, ++n) {
+        for (int k = 0; k < 4; ++k) d[k] += us(it * 8 + k + 1, it * 8 + k);
+        drain += us(it * 8 + 5, it * 8 + 1);
+        d[4] += us((it + 1) * 8, it * 8);
+    }
+    if (n) fprintf(stderr, "[oc_prof] n=%d  dots+publish %.2f  barrier %.2f  gather+reduce %.2f  update %.2f  | iteration %.2f us; of the barrier, store drain %.2f\n",
+                   n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, drain / n);
+    if (hipMemsetAsync(c->oc_prof.p, 0, h.size() * 8, st) != hipSuccess) return -1;
+    return 0;
+}
+
 struct OcRc { bool on = false; RcBasis B{}; double *Eslot = nullptr, *Rslot = nullptr; };
 
 int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters, const OcRc &rc = OcRc()) {
@@ -296,27 +328,11 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.rc_on = rc.on ? 1 : 0; a.rc = rc.B; a.rc_xs = c->rc_xs.p; a.rc_r0 = c->rc_r0.p; a.rc_Eslot = rc.Eslot; a.rc_Rslot = rc.Rslot;
     a.rc_part = c->oc_rc_part.p;
     a.prof = c->oc_prof.p;
-    { const char *pb = getenv("ADMM_HIP_OC_PROF_BLOCK"); a.prof_block = pb ? atoi(pb) : 0; }
+    a.prof_block = c->oc_prof_block;
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg_onchip<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     c->last_launched_iters = 0; // the verdict of the solve is written to cg_scal[0]
-    if (getenv("ADMM_HIP_OC_DEBUG")) { CgScal h; (void)hipMemcpyAsync(&h, c->cg_scal.p, sizeof(h), hipMemcpyDeviceToHost, st); (void)hipStreamSynchronize(st); fprintf(stderr, "[oc] seq %d iters %d (pipelined %d) conv %d gamma %.3e %.3e %.3e gb %.3e %.3e %.3e\n", h.seq, h.iters, h.pad_, h.converged, h.gamma[0], h.gamma[1], h.gamma[2], h.gamma_b[0], h.gamma_b[1], h.gamma_b[2]); }
-    if (c->oc_prof.p) { // diagnosis only: per-phase time of block 0, mean over iterations 1..62
-        std::vector<unsigned long long> h(64 * 8);
-        if (hipMemcpyAsync(h.data(), c->oc_prof.p, h.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-        double d[5] = {0, 0, 0, 0, 0}, drain = 0; int n = 0;
-        fprintf(stderr, "[oc_prof] LDS fill %.2f  start phase %.2f  loop %.2f  epilogue %.2f us\n", (double)(h[63 * 8 + 1] - h[63 * 8]) / 100, (double)(h[63 * 8 + 2] - h[63 * 8 + 1]) / 100, (double)(h[63 * 8 + 3] - h[63 * 8 + 2]) / 100, (double)(h[63 * 8 + 4] - h[63 * 8 + 3]) / 100);
-        if (h[62 * 8 + 5]) fprintf(stderr, "[oc_prof] recycled start: x gather %.2f  pair loads + sums %.2f  barrier %.2f  read sums %.2f  cholesky %.2f (us)\n", (double)(h[62 * 8 + 1] - h[62 * 8]) / 100, (double)(h[62 * 8 + 2] - h[62 * 8 + 1]) / 100, (double)(h[62 * 8 + 3] - h[62 * 8 + 2]) / 100, (double)(h[62 * 8 + 4] - h[62 * 8 + 3]) / 100, (double)(h[62 * 8 + 5] - h[62 * 8 + 4]) / 100);
-        for (int it = 1; it + 1 < 63 && h[(it + 1) * 8] > h[it * 8 + 4] && h[it * 8 + 4] > h[it * 8]; ++it, ++n) {
-            for (int k = 0; k < 4; ++k) d[k] += (double)(h[it * 8 + k + 1] - h[it * 8 + k]);
-            drain += (double)(h[it * 8 + 5] - h[it * 8 + 1]);
-            d[4] += (double)(h[(it + 1) * 8] - h[it * 8]);
-        }
-        if (n) fprintf(stderr, "[oc_prof] n=%d  dots+publish %.2f  barrier %.2f  gather+reduce %.2f  update %.2f  | iteration %.2f us (100 MHz ticks); of the barrier, store drain %.2f\n",
-                       n, d[0] / n / 100, d[1] / n / 100, d[2] / n / 100, d[3] / n / 100, d[4] / n / 100, drain / n / 100);
-        if (getenv("ADMM_HIP_OC_TRACE") && a.seq == atoi(getenv("ADMM_HIP_OC_TRACE"))) { std::vector<double> tr(1024); (void)hipMemcpy(tr.data(), (double *)c->oc_prof.p + 1024, 1024 * 8, hipMemcpyDeviceToHost); for (int i = 0; i < 420; ++i) fprintf(stderr, "[tr] %d gamma %.4e delta %.4e\n", i, tr[2 * i], tr[2 * i + 1]); }
-        (void)hipMemsetAsync(c->oc_prof.p, 0, h.size() * 8, st);
-    }
+    if (c->oc_debug || c->oc_prof.p) return oc_diagnostics(c, a.seq);
     return 0;
 }
 
@@ -356,7 +372,12 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     if ((e = c->oc_bar.alloc(2 * 32 * 16)) != hipSuccess) return e;
     if ((e = c->oc_bar.zero()) != hipSuccess) return e;
     if ((e = hipMemset(c->oc_ubuf.p, 0, c->oc_ubuf.n * sizeof(double))) != hipSuccess) return e;
-    { const char *pe = getenv("ADMM_HIP_OC_PROF"); if (pe && pe[0] == '1') { if ((e = c->oc_prof.alloc(64 * 8 + 2048)) != hipSuccess) return e; if ((e = c->oc_prof.zero()) != hipSuccess) return e; } }
+    {   // diagnosis switches, read once
+        const char *pe = getenv("ADMM_HIP_OC_PROF"), *pb = getenv("ADMM_HIP_OC_PROF_BLOCK"), *pd = getenv("ADMM_HIP_OC_DEBUG");
+        c->oc_debug = pd && pd[0] == '1';
+        c->oc_prof_block = pb ? atoi(pb) : 0;
+        if (pe && pe[0] == '1') { if ((e = c->oc_prof.alloc(64 * 8)) != hipSuccess) return e; if ((e = c->oc_prof.zero()) != hipSuccess) return e; }
+    }
     c->oc_enabled = true;
     return hipSuccess;
 }

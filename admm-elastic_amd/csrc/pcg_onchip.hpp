@@ -269,7 +269,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     unsigned ph = 0;     // publish phase: buffer parity = ph & 1, barrier epoch = ph
     const bool prof = a.prof && (int)blockIdx.x == a.prof_block && tid == 0;
     int prof_n = 0;
-#define OC_STAMP(slot) do { if (prof && prof_n < 63) a.prof[prof_n * 8 + (slot)] = wall_clock64(); } while (0)
+#define OC_STAMP(slot) do { if (prof && prof_n < 62) a.prof[prof_n * 8 + (slot)] = wall_clock64(); } while (0)
 
     // Publish this wave's 64 x 3 values per axis with 16-byte write-through stores (8-byte sc1 stores cost
     // 2.7x per byte), transposed through the wave's LDS staging area: lanes 0..31 store the x pairs and then
