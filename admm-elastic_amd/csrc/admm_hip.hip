@@ -289,8 +289,8 @@ int oc_diagnostics(admm_hip_ctx *c, int seq) {
     if (c->oc_debug) {
         CgScal h;
         if (hipMemcpyAsync(&h, c->cg_scal.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
-        fprintf(stderr, "[oc] seq %d iters %d (pipelined %d) conv %d gamma %.3e %.3e %.3e gb %.3e %.3e %.3e\n", h.seq, h.iters, h.pad_,
-                h.converged, h.gamma[0], h.gamma[1], h.gamma[2], h.gamma_b[0], h.gamma_b[1], h.gamma_b[2]);
+        fprintf(stderr, "[oc] seq %d iters %d (pipelined %d) verifications %d (last: true gamma / (tol^2 gamma_b) = %.2f) phases %d conv %d gamma %.3e %.3e %.3e gb %.3e %.3e %.3e\n", h.seq, h.iters, h.pad_,
+                (int)h.alpha[0], h.alpha[2], (int)h.alpha[1], h.converged, h.gamma[0], h.gamma[1], h.gamma[2], h.gamma_b[0], h.gamma_b[1], h.gamma_b[2]);
     }
     if (!c->oc_prof.p) return 0;
     std::vector<unsigned long long> h(64 * 8);

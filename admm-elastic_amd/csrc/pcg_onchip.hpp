@@ -70,6 +70,10 @@ constexpr int kOcScratch = 6144;          // bytes of LDS scratch ahead of the p
 constexpr int kOcStage = 3 * 64 * 8;      // per-wave staging area (publish transposition)
 constexpr unsigned kOcSpinLimit = 4000000u;
 constexpr double kOcPipeFloor = 1e-18;    // squared relative residual below which the pipelined recurrences are not trusted
+#ifndef ADMM_OC_TRIG
+#define ADMM_OC_TRIG 0.9
+#endif
+constexpr double kOcTrig = ADMM_OC_TRIG;  // the recurrence must report gamma <= kOcTrig tol^2 b.M^-1 b before the true residual is checked
 constexpr int kOcStagnation = 50;         // pipelined iterations without a new residual minimum before switching, once the
                                           // residual is within 100x of kOcPipeFloor (rounding-driven stagnation); above that
                                           // level plateaus of the residual norm are ordinary CG behaviour (measured: 13 of 40
@@ -521,14 +525,14 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 const double ratio = g * ctl[8 + j];                       // gamma / (b . M^-1 b)
                 const unsigned long long m3 = 7ull;
                 const bool finite = (__ballot(ratio < 1e300) & m3) == m3;
-                const bool below_trig = (__ballot(g <= 0.9 * a.tol2 * gbj + 1e-300) & m3) == m3;
+                const bool below_trig = (__ballot(g <= kOcTrig * a.tol2 * gbj + 1e-300) & m3) == m3;
                 const bool below_tol = (__ballot(g <= a.tol2 * gbj + 1e-300) & m3) == m3;
                 const bool below_floor = (__ballot(g <= kOcPipeFloor * gbj + 1e-300) & m3) == m3;
                 double rmax = fmax(ratio, __shfl(ratio, 1, 64));
                 rmax = fmax(rmax, __shfl(ratio, 2, 64));                   // valid in lane 0
                 int act = 0;
                 if (!finite) act = 2;
-                else if (pipelined ? (below_trig && 0.9 * a.tol2 >= kOcPipeFloor) : below_tol) act = 1;
+                else if (pipelined ? (below_trig && kOcTrig * a.tol2 >= kOcPipeFloor) : below_tol) act = 1;
                 else {
                     if (pipelined) {
                         int since = 0;
@@ -621,6 +625,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         CgScal o;
 #pragma unroll
         for (int j = 0; j < 3; ++j) { o.gamma[j] = glast[j]; o.alpha[j] = 0.0; o.gamma_b[j] = gbl[j]; }
+        o.alpha[0] = (double)ictl[1]; o.alpha[1] = (double)ph; o.alpha[2] = ctl[1] / a.tol2;   // diagnosis: verifications done, synchronisation phases, true gamma ratio / tol^2 at the last verification
         o.converged = (conv && !aborted) ? 1 : 0; o.iters = iters; o.seq = a.seq; o.pad_ = pipe_iters;
         a.scal[0] = o;
         atomicAdd(a.counters, iters);
