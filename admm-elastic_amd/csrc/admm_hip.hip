@@ -195,6 +195,7 @@ struct admm_hip_ctx {
     std::vector<int> color_ptr_h;
     DevBuf<int> color_nodes;
     SellDev gs_sell; DevBuf<int> gs_slot_node; DevBuf<double> gs_diag; std::vector<int> gs_color_slice;
+    DevBuf<double> gs_xb, gs_part2;   // two-colour scheme (k_gs_color2): roll-back copy, partial sums
     Obstacles obst{};
 
     ~admm_hip_ctx() {
@@ -209,7 +210,7 @@ struct admm_hip_ctx {
         gs_pin_flag.release(); gs_pin_xyz.release();
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
-        cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release();
+        cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
@@ -506,6 +507,21 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
     a.part = c->part.p; a.NBp = c->NB; a.tol2 = c->gs_tol * c->gs_tol; a.sweeps = c->counters.p + 2; a.total = c->counters.p;
     const SellA A = sell_arg(c->A);
     const int check = c->gs_tol > 0.0 ? 1 : 0;
+    if (check && c->n_colors == 2 && c->gs_xb.p && c->gs_max_iters > 0) {
+        // two colours: the residual test rides on the colour kernels (k_gs_color2), two launches per sweep
+        const int s00 = c->gs_color_slice[0], ns0 = c->gs_color_slice[1] - s00, s01 = c->gs_color_slice[1], ns1 = c->gs_color_slice[2] - s01;
+        const int nbB = (ns0 + 3) / 4, nbA = (ns1 + 3) / 4;
+        Gs2Args a2{a, c->gs_xb.p, c->gs_part2.p, c->gs_part2.p + 4 * (size_t)nbA, nbA, nbB, s00, ns0};
+        for (int it = 0; it < c->gs_max_iters; ++it) {
+            const int par = it & 1;
+            if (it == 0) hipLaunchKernelGGL((k_gs_color2<false, true, false>), dim3(nbB), dim3(256), 0, st, a2, s00, ns0, c->obst, 0, par);
+            else hipLaunchKernelGGL((k_gs_color2<true, true, false>), dim3(nbB), dim3(256), 0, st, a2, s00, ns0, c->obst, 0, par);
+            hipLaunchKernelGGL((k_gs_color2<false, true, true>), dim3(nbA), dim3(256), 0, st, a2, s01, ns1, c->obst, it > 0 ? 1 : 0, par);
+        }
+        hipLaunchKernelGGL((k_gs_color2<true, false, false>), dim3(nbB), dim3(256), 0, st, a2, s00, ns0, c->obst, 0, 0);
+        hipLaunchKernelGGL(k_gs_check2, dim3(1), dim3(256), 0, st, a2, (c->gs_max_iters - 1) & 1);
+        return;
+    }
     for (int it = 0; it < c->gs_max_iters; ++it) {
         bool first = true;
         for (int col = 0; col < c->n_colors; ++col) {
@@ -813,6 +829,12 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
             HIP_TRY(c->gs_sell.upload(g.sell));
             HIP_TRY(c->gs_slot_node.upload(g.slot_node)); HIP_TRY(c->gs_diag.upload(g.diag));
             c->gs_color_slice.assign(g.color_slice.begin(), g.color_slice.end());
+            const char *g3 = getenv("ADMM_HIP_GS_THREE_KERNELS");   // A/B switch, read at create
+            if (c->n_colors == 2 && !(g3 && g3[0] == '1')) {   // two-colour scheme: roll-back copy + partial sums (2 x 2 x nbA last colour, 2 x nbB first colour)
+                const int nbB = (c->gs_color_slice[1] - c->gs_color_slice[0] + 3) / 4, nbA = (c->gs_color_slice[2] - c->gs_color_slice[1] + 3) / 4;
+                HIP_TRY(c->gs_xb.alloc(c->n3)); HIP_TRY(c->gs_xb.zero());
+                HIP_TRY(c->gs_part2.alloc(4 * (size_t)nbA + 2 * (size_t)nbB)); HIP_TRY(c->gs_part2.zero());
+            }
         }
     }
     if (d->linsolver == 2) {

@@ -902,6 +902,141 @@ __global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nsli
     for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
 }
 
+// TWO-COLOUR meshes (bipartite coupling graph, e.g. Kuhn / make_tet_blocks meshes): the per-sweep residual test
+// (:136-140) needs no SpMV pass of its own.  After sweep k the rows of the LAST colour see only final neighbour
+// values, so their residuals are computed in their own colour kernel right after the update (POST); the rows of the
+// FIRST colour are untouched until sweep k+1 starts, so the first-colour kernel of sweep k+1 computes their
+// sweep-k residuals before it updates them (PRE).  The test of sweep k is then settled by the LAST-colour kernel
+// of sweep k+1 (every block re-reduces both partial arrays, deterministic); if the sweep had converged, the
+// first-colour update of sweep k+1 -- done speculatively -- is rolled back from the backup `xb` and the solve
+// stops exactly where the reference stops.  Two kernels per sweep instead of three.
+struct Gs2Args {
+    GsArgs g;
+    double *xb;          // [3 nv] backup of the first colour's values (roll-back)
+    double *partA;       // [2 (sweep parity)][2][nbA] last-colour partials  (|r|^2, |b|^2)
+    double *partB;       // [2][nbB]                   first-colour partials
+    int nbA, nbB;
+    int s0_first, ns_first;   // slices of the first colour (for the roll-back)
+};
+
+template <bool PRE, bool UPDATE, bool POST>
+__global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int nslices, Obstacles ob, int decide, int parity) {
+    const GsArgs &a = a2.g;
+    __shared__ double lds[8];
+    if (*a.done) return;
+    const int lane = threadIdx.x & 63;
+    if (decide) {   // last colour of sweep k+1: was sweep k converged?
+        double q[2] = {0.0, 0.0};
+        const double *pA = a2.partA + (size_t)(parity ^ 1) * 2 * a2.nbA;
+        for (int i = threadIdx.x; i < a2.nbA; i += 256) { q[0] += pA[i]; q[1] += pA[a2.nbA + i]; }
+        for (int i = threadIdx.x; i < a2.nbB; i += 256) { q[0] += a2.partB[i]; q[1] += a2.partB[a2.nbB + i]; }
+        block_sum<2>(q, lds);
+        const bool conv = q[0] / q[1] < a.tol2;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (conv) *a.done = 1; else { atomicAdd(a.sweeps, 1); atomicAdd(a.total, 1); }
+        }
+        if (conv) {   // undo the speculative first-colour update of this sweep
+            for (int ws = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); ws < a2.ns_first; ws += (int)gridDim.x * 4) {
+                const int v = a.slot_node[(size_t)64 * (a2.s0_first + ws) + lane];
+                if (v >= 0) {
+#pragma unroll
+                    for (int q3 = 0; q3 < 3; ++q3) a.x[3 * (size_t)v + q3] = a2.xb[3 * (size_t)v + q3];
+                }
+            }
+            return;
+        }
+    }
+    const int ws = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    double rs[2] = {0.0, 0.0};
+    if (ws < nslices) {
+        const int s = slice0 + ws;
+        const int v = a.slot_node[(size_t)64 * s + lane];
+        double LUx[3];
+        sell_row(a.S, s, lane, a.x, LUx);
+        if (v >= 0) {
+            const double ad = a.diag[(size_t)64 * s + lane];
+            const bool pinned = a.pin_flag && a.pin_flag[v];
+            double aii[3], cx[3], bi[3], nx[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                aii[q] = ad + a.m[3 * (size_t)v + q];
+                cx[q] = a.x[3 * (size_t)v + q];
+                bi[q] = a.b[3 * (size_t)v + q];
+                nx[q] = cx[q];
+            }
+            if (PRE) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double r = bi[q] - fma(aii[q], cx[q], LUx[q]);
+                    rs[0] = fma(r, r, rs[0]); rs[1] = fma(bi[q], bi[q], rs[1]);
+                    if (UPDATE) a2.xb[3 * (size_t)v + q] = cx[q];
+                }
+            }
+            if (UPDATE) {
+                if (pinned) { // :111-117
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
+                } else {
+                    double jac[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        jac[q] = (bi[q] - LUx[q]) / aii[q];
+                        nx[q] = (1.0 - a.omega) * cx[q] + a.omega * jac[q]; // :210
+                    }
+                    double n[3], p[3];
+                    if (ob.n > 0 && passive_hit(ob, nx, n, p)) { // constrained_segment_update :218-262
+                        double dx[3] = {jac[0] - p[0], jac[1] - p[1], jac[2] - p[2]};
+                        double nn[3] = {0.0, 0.0, 0.0}, uu[3], vv[3];
+                        if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0; // orthoG :171-177
+                        cross3(nn, n, uu);
+                        double il = 1.0 / sqrt(dot3(uu, uu));
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) uu[q] *= il;
+                        cross3(n, uu, vv);
+                        il = 1.0 / sqrt(dot3(vv, vv));
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) vv[q] *= il;
+                        const double t0 = dot3(uu, dx), t1 = dot3(vv, dx);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) nx[q] = uu[q] * t0 + vv[q] * t1 + p[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
+            }
+            if (POST) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double r = bi[q] - fma(aii[q], nx[q], LUx[q]);
+                    rs[0] = fma(r, r, rs[0]); rs[1] = fma(bi[q], bi[q], rs[1]);
+                }
+            }
+        }
+    }
+    if (PRE || POST) {
+        block_sum<2>(rs, lds);
+        if (threadIdx.x == 0) {
+            if (POST) { double *pA = a2.partA + (size_t)parity * 2 * a2.nbA; pA[blockIdx.x] = rs[0]; pA[a2.nbA + blockIdx.x] = rs[1]; }
+            else { a2.partB[blockIdx.x] = rs[0]; a2.partB[a2.nbB + blockIdx.x] = rs[1]; }
+        }
+    }
+}
+
+// settles the LAST sweep of the two-colour scheme (its first-colour residuals come from a PRE-only pass)
+__global__ __launch_bounds__(256) void k_gs_check2(Gs2Args a2, int parity) {
+    __shared__ double lds[8];
+    const GsArgs &a = a2.g;
+    if (*a.done) return;
+    double q[2] = {0.0, 0.0};
+    const double *pA = a2.partA + (size_t)parity * 2 * a2.nbA;
+    for (int i = threadIdx.x; i < a2.nbA; i += 256) { q[0] += pA[i]; q[1] += pA[a2.nbA + i]; }
+    for (int i = threadIdx.x; i < a2.nbB; i += 256) { q[0] += a2.partB[i]; q[1] += a2.partB[a2.nbB + i]; }
+    block_sum<2>(q, lds);
+    if (threadIdx.x == 0) {
+        if (q[0] / q[1] < a.tol2) *a.done = 1; else { atomicAdd(a.sweeps, 1); atomicAdd(a.total, 1); }
+    }
+}
+
 // residual test of one sweep (:136-140): partial sums of |b - A x|^2 and |b|^2
 __global__ __launch_bounds__(256) void k_gs_resid(SellA A, const double *__restrict__ m, const double *__restrict__ b,
                                                   const double *__restrict__ x, double *__restrict__ part, int NB,

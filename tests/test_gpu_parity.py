@@ -474,3 +474,35 @@ def test_onchip_pcg_1024_thread_variant_and_global_columns():
     for j in range(3):
         assert np.sum(r[:, j] ** 2 * dinv[:, j]) <= 1.05e-18 * np.sum(b.reshape(-1, 3)[:, j] ** 2 * dinv[:, j])
     assert np.abs(x_oc - x_l).max() <= 1e-6 * np.abs(xt).max()
+
+
+@pytest.mark.parametrize("floor", [None, 0.02])
+def test_gs_two_colour_scheme_equals_three_kernel_scheme(floor):
+    """Two-colour meshes settle the per-sweep residual test inside the colour kernels (k_gs_color2) and roll the
+    speculative half sweep back when the previous sweep had converged: same sweep count and bit-identical x as the
+    plain colour / colour / residual-SpMV sequence, for solves that stop early, late, and not at all."""
+    sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, admm_iters=4, linsolver=1, size=0.5)
+    if floor is not None:
+        sc.obstacles.append((0, [floor, 0.0, 0.0, 0.0]))
+    o = sc.make_oracle()
+    rng = np.random.default_rng(17)
+    xt = sc.x + 0.01 * rng.standard_normal(sc.x.shape)
+    for v, p in sc.pins.items():
+        xt[v] = p                       # a right-hand side the pinned system can actually reach
+    b = o.A @ xt.ravel()
+    for tol, mx in ((1e-2, 200), (1e-4, 400), (1e-10, 12)):
+        res = []
+        for three in ("0", "1"):
+            os.environ["ADMM_HIP_GS_THREE_KERNELS"] = three
+            try:
+                s = sc.make_solver(gs_tol=tol, gs_max_iters=mx)
+            finally:
+                os.environ.pop("ADMM_HIP_GS_THREE_KERNELS", None)
+            assert s.gs_colors()[1] == 2
+            x, it = s.global_solve(b, sc.x.ravel().copy())
+            res.append((x, it)); s.close()
+        (x2, it2), (x3, it3) = res
+        assert it2 == it3, (tol, it2, it3)
+        if floor is None:
+            assert (it2 < mx) == (tol > 1e-9)      # the loose tolerances stop early, the tight one runs out of sweeps
+        assert np.array_equal(x2, x3), (tol, np.abs(x2 - x3).max())
