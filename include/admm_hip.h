@@ -195,8 +195,9 @@ int admm_host_tet_rest(int32_t n, const int32_t *idx, const double *verts, doubl
 int admm_host_tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
 /* Lame (src/EnergyTerm.hpp:34-59) */
 void admm_host_lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);
-/* Greedy nodal colouring in index order on a CSR pattern (stands in for the absent
- * mcl::graphcolor::color_matrix, src/NodalMultiColorGS.hpp:57); returns the number of colours. */
+/* Greedy nodal colouring on a CSR pattern (role of the absent mcl::graphcolor::color_matrix,
+ * src/NodalMultiColorGS.hpp:57): the better of first-fit in index order and DSATUR; deterministic; returns the
+ * number of colours. */
 int admm_host_greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color);
 
 #ifdef __cplusplus
