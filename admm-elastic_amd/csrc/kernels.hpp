@@ -848,8 +848,9 @@ struct GsArgs {
 // run time, NodalMultiColorGS.hpp:194; the summation order is the row's column order, like the reference).
 __global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nslices, Obstacles ob, int decide) {
     __shared__ double lds[8];
-    if (*a.done) return;
+    const int done_flag = *a.done;   // consulted only before something is written (its load overlaps the row gather)
     if (decide) { // first colour of sweep i+1: was sweep i converged?  (NodalMultiColorGS.hpp:136-140)
+        if (done_flag) return;
         double q[2] = {0.0, 0.0};
         for (int i = threadIdx.x; i < a.NBp; i += 256) { q[0] += a.part[i]; q[1] += a.part[a.NBp + i]; }
         block_sum<2>(q, lds);
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nsli
     const int v = a.slot_node[(size_t)64 * s + lane];
     double LUx[3];
     sell_row(a.S, s, lane, a.x, LUx);
-    if (v < 0) return;
+    if (v < 0 || done_flag) return;
     if (a.pin_flag && a.pin_flag[v]) { // :111-117
 #pragma unroll
         for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = a.pin_xyz[3 * (size_t)v + q];
@@ -923,9 +924,12 @@ template <bool PRE, bool UPDATE, bool POST>
 __global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int nslices, Obstacles ob, int decide, int parity) {
     const GsArgs &a = a2.g;
     __shared__ double lds[8];
-    if (*a.done) return;
+    // `done` is only consulted where something would be written: its load overlaps the row gather instead of
+    // standing in front of it (these kernels are a few microseconds of pure latency)
+    const int done_flag = *a.done;
     const int lane = threadIdx.x & 63;
     if (decide) {   // last colour of sweep k+1: was sweep k converged?
+        if (done_flag) return;
         double q[2] = {0.0, 0.0};
         const double *pA = a2.partA + (size_t)(parity ^ 1) * 2 * a2.nbA;
         for (int i = threadIdx.x; i < a2.nbA; i += 256) { q[0] += pA[i]; q[1] += pA[a2.nbA + i]; }
@@ -969,10 +973,10 @@ __global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int n
                 for (int q = 0; q < 3; ++q) {
                     const double r = bi[q] - fma(aii[q], cx[q], LUx[q]);
                     rs[0] = fma(r, r, rs[0]); rs[1] = fma(bi[q], bi[q], rs[1]);
-                    if (UPDATE) a2.xb[3 * (size_t)v + q] = cx[q];
+                    if (UPDATE && !done_flag) a2.xb[3 * (size_t)v + q] = cx[q];
                 }
             }
-            if (UPDATE) {
+            if (UPDATE && !done_flag) {
                 if (pinned) { // :111-117
 #pragma unroll
                     for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
@@ -1015,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int n
     }
     if (PRE || POST) {
         block_sum<2>(rs, lds);
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && !done_flag) {
             if (POST) { double *pA = a2.partA + (size_t)parity * 2 * a2.nbA; pA[blockIdx.x] = rs[0]; pA[a2.nbA + blockIdx.x] = rs[1]; }
             else { a2.partB[blockIdx.x] = rs[0]; a2.partB[a2.nbB + blockIdx.x] = rs[1]; }
         }
@@ -1042,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_gs_resid(SellA A, const double *__restr
                                                   const double *__restrict__ x, double *__restrict__ part, int NB,
                                                   const int *__restrict__ done) {
     __shared__ double lds[8];
-    if (*done) return;
+    const int done_flag = *done;   // consulted only before the partials are written
     const int lane = threadIdx.x & 63;
     const int s = wave_slice();
     double q[2] = {0.0, 0.0};
@@ -1062,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_gs_resid(SellA A, const double *__restr
         }
     }
     block_sum<2>(q, lds);
-    if (threadIdx.x == 0) { part[blockIdx.x] = q[0]; part[NB + blockIdx.x] = q[1]; }
+    if (threadIdx.x == 0 && !done_flag) { part[blockIdx.x] = q[0]; part[NB + blockIdx.x] = q[1]; }
 }
 
 // one block: finish the reduction, count the sweep like the reference's `iter`, raise `done`
