@@ -156,18 +156,40 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t rs, int voff, int 
     __builtin_amdgcn_raw_buffer_store_b64(t.v, rs, voff, soff, 0);
 }
 
+// What one tet reads: loaded by tet_load (streams: Binv, u, scale, material id) and tet_gather (the four vertex
+// positions); all loads of a tet are issued before any of its arithmetic.
+struct TetIn { double Bi[9], ui[9], s; int mid; };
+struct TetPos { double p[12]; };
+
+__device__ __forceinline__ int4 tet_load_idx(const TetArgs &a, int t) {
+    union { int4 i; bv4u v; } q4;
+    q4.v = __builtin_amdgcn_raw_buffer_load_b128(soa_rsrc(a.idx), t * 16, 0, 0);
+    return q4.i;
+}
+template <int KIND>
+__device__ __forceinline__ void tet_load(const TetArgs &a, int t, TetIn &in) {
+    const int ld8 = a.ld * 8, t8 = t * 8;   // bytes between two components of an SoA array (< 2^31 up to 268 M tets)
+    const __amdgpu_buffer_rsrc_t rBinv = soa_rsrc(a.Binv), ru = soa_rsrc(a.u);
+#pragma unroll
+    for (int c = 0; c < 9; ++c) { in.Bi[c] = buf_ld(rBinv, t8, c * ld8); in.ui[c] = buf_ld(ru, t8, c * ld8); }
+    in.s = buf_ld(soa_rsrc(a.sc), t8, 0);
+    in.mid = (KIND == 0) ? 0 : __builtin_amdgcn_raw_buffer_load_b32(soa_rsrc(a.mat_id), t * 4, 0, 0);
+}
+__device__ __forceinline__ void tet_gather(const TetArgs &a, const int4 id, TetPos &x) {
+    const __amdgpu_buffer_rsrc_t rx = soa_rsrc(a.x);
+    const int o[4] = {id.x * 24, id.y * 24, id.z * 24, id.w * 24};
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) x.p[3 * v + j] = buf_ld(rx, o[v] + 8 * j, 0);
+}
+
+// prox + dual update + corner forces of one tet from its loaded inputs
 template <int KIND, bool WRITE_Z>
-__device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (*sBi)[256], double (*sV)[256]) {
-    const int ld8 = a.ld * 8;         // bytes between two components of an SoA array (< 2^31 up to 268 M tets)
-    const int t8 = t * 8;
-    const __amdgpu_buffer_rsrc_t rBinv = soa_rsrc(a.Binv), ru = soa_rsrc(a.u), rcf = soa_rsrc(a.cf), rx = soa_rsrc(a.x);
+__device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, const TetIn &in, const TetPos &x, double (*sBi)[256], double (*sV)[256]) {
+    const int ld8 = a.ld * 8, t8 = t * 8;
+    const __amdgpu_buffer_rsrc_t ru = soa_rsrc(a.u), rcf = soa_rsrc(a.cf);
     const Mat *__restrict__ mats = a.mats;
-    int4 id;
-    {
-        union { int4 i; bv4u v; } q4;
-        q4.v = __builtin_amdgcn_raw_buffer_load_b128(soa_rsrc(a.idx), t * 16, 0, 0);
-        id = q4.i;
-    }
     // Binv is needed twice (F = Ds Binv before the prox, corner forces after it).  It is parked in LDS (sBi) in
     // between: thread-private slots, [c][tid] layout (bank-conflict-free 8-B accesses), no VGPRs held
     // across the prox and no second trip to HBM (rocprof FETCH_SIZE showed the re-read going to fabric).
@@ -176,23 +198,19 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (
     {
         double q[9];
         {
-            double Bi[9], ui[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) { Bi[c] = buf_ld(rBinv, t8, c * ld8); ui[c] = buf_ld(ru, t8, c * ld8); }
-            const int o0 = id.x * 24, o1 = id.y * 24, o2 = id.z * 24, o3 = id.w * 24;
             double Ds[9];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const double a0 = buf_ld(rx, o0 + 8 * j, 0);
-                Ds[0 + j] = buf_ld(rx, o1 + 8 * j, 0) - a0; Ds[3 + j] = buf_ld(rx, o2 + 8 * j, 0) - a0; Ds[6 + j] = buf_ld(rx, o3 + 8 * j, 0) - a0;
+                const double a0 = x.p[j];
+                Ds[0 + j] = x.p[3 + j] - a0; Ds[3 + j] = x.p[6 + j] - a0; Ds[6 + j] = x.p[9 + j] - a0;
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int j = 0; j < 3; ++j)   // EnergyTerm.hpp:133-135  zi = D_i x + u_i
-                    q[r * 3 + j] = fma(Ds[j], Bi[r * 3 + 0], fma(Ds[3 + j], Bi[r * 3 + 1], fma(Ds[6 + j], Bi[r * 3 + 2], ui[r * 3 + j])));
+                    q[r * 3 + j] = fma(Ds[j], in.Bi[r * 3 + 0], fma(Ds[3 + j], in.Bi[r * 3 + 1], fma(Ds[6 + j], in.Bi[r * 3 + 2], in.ui[r * 3 + j])));
 #pragma unroll
-            for (int c = 0; c < 9; ++c) sBi[c][threadIdx.x] = Bi[c];
+            for (int c = 0; c < 9; ++c) sBi[c][threadIdx.x] = in.Bi[c];
         }
         signed_svd3(q, U, S0, V);   // q = U diag(S0) V^T to round-off: q itself is not needed any more
     }
@@ -211,8 +229,7 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (
 #pragma unroll
             for (int c = 0; c < 9; ++c) sV[c][threadIdx.x] = V[c];
         }
-        const int mid = __builtin_amdgcn_raw_buffer_load_b32(soa_rsrc(a.mat_id), t * 4, 0, 0);
-        const Mat mt = mats[mid];
+        const Mat mt = mats[in.mid];
         prox_stretches<KIND>(mt.mu, mt.la, mt.k, S1);
         if (kParkV) {
 #pragma unroll
@@ -221,7 +238,7 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (
     }
     // z = U diag(S1) V^T ; u_new = u + D_i x - z = q - z = U diag(S0 - S1) V^T   (EnergyTerm.hpp:137)
     // G = dt^2 w^2 (z - u_new) = s U diag(2 S1 - S0) V^T
-    const double s = buf_ld(soa_rsrc(a.sc), t8, 0);
+    const double s = in.s;
     double G[9];
     {
         double du[3], dg[3];
@@ -256,6 +273,15 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) buf_st(rcf, t8, j * ld8, f0[j]);
+}
+
+template <int KIND, bool WRITE_Z>
+__device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (*sBi)[256], double (*sV)[256]) {
+    TetIn in; TetPos x;
+    const int4 id = tet_load_idx(a, t);
+    tet_load<KIND>(a, t, in);
+    tet_gather(a, id, x);
+    tet_compute_store<KIND, WRITE_Z>(a, t, in, x, sBi, sV);
 }
 
 // one constitutive model per launch (used when a scene has a single model, and by the parity entry point)
