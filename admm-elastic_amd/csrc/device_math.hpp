@@ -115,7 +115,10 @@ __device__ __forceinline__ void signed_svd3(const double *F, double *U, double *
         float a11 = (float)(c11 * itr), a12 = (float)(c12 * itr), a22 = (float)(c22 * itr);
         float w0[3] = {1.f, 0.f, 0.f}, w1[3] = {0.f, 1.f, 0.f}, w2[3] = {0.f, 0.f, 1.f};
 #pragma unroll 1
-        for (int sweep = 0; sweep < 4; ++sweep) {
+#ifndef ADMM_F32_SWEEPS
+#define ADMM_F32_SWEEPS 4
+#endif
+        for (int sweep = 0; sweep < ADMM_F32_SWEEPS; ++sweep) {
             jacobi_rotate_f32(a00, a11, a01, a02, a12, w0, w1);
             jacobi_rotate_f32(a00, a22, a02, a01, a12, w0, w2);
             jacobi_rotate_f32(a11, a22, a12, a01, a02, w1, w2);
