@@ -169,6 +169,7 @@ struct admm_hip_ctx {
     int oc_G = 0, oc_spb = 0, oc_T = 0, oc_wl = 0; size_t oc_lds = 0;
     DevBuf<double> oc_ubuf, oc_part, oc_rc_part;
     DevBuf<unsigned> oc_bar;
+    DevBuf<int> oc_nbr; DevBuf<unsigned long long> oc_flags;   // neighbour hand-off of the pipelined iteration
     DevBuf<unsigned long long> oc_prof;   // diagnosis (ADMM_HIP_OC_PROF=1)
     bool oc_debug = false; int oc_prof_block = 0;
     int solve_seq = 0;
@@ -211,7 +212,7 @@ struct admm_hip_ctx {
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release();
-        oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release();
+        oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -323,6 +324,7 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.ptr = c->A.ptr.p; a.w = c->A.w.p; a.col = c->A.idx.p; a.val = c->A.val.p;
     a.m = c->m.p; a.dinv = c->dinv.p; a.b = b; a.x = x; a.u_out = c->cg_u.p;
     a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.bar = c->oc_bar.p;
+    a.nbr = c->oc_nbr.p; a.flags = c->oc_flags.p;
     a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
     a.spb = c->oc_spb; a.wl = c->oc_wl; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
     a.tol2 = c->pcg_tol * c->pcg_tol;
@@ -378,6 +380,31 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
         c->oc_debug = pd && pd[0] == '1';
         c->oc_prof_block = pb ? atoi(pb) : 0;
         if (pe && pe[0] == '1') { if ((e = c->oc_prof.alloc(64 * 8)) != hipSuccess) return e; if ((e = c->oc_prof.zero()) != hipSuccess) return e; }
+    }
+    {   // which blocks does every block gather from?  (rows of block b: [64 spb b, 64 spb (b + 1)))
+        const char *off = getenv("ADMM_HIP_OC_NO_NBR");
+        const int rows_pb = 64 * spb;
+        std::vector<int> nbr((size_t)G * 64, -1);
+        bool fits = !(off && off[0] == '1');
+        for (int b = 0; b < G && fits; ++b) {
+            std::vector<char> seen(G, 0);
+            int n = 0;
+            const int r1 = std::min(c->Ahat.n, rows_pb * (b + 1));
+            for (int r = rows_pb * b; r < r1 && fits; ++r)
+                for (int k = c->Ahat.rowptr[r]; k < c->Ahat.rowptr[r + 1]; ++k) {
+                    if (c->Ahat.val[k] == 0.0) continue;            // exact zeros are not in the SELL matrix
+                    const int bj = c->Ahat.col[k] / rows_pb;
+                    if (bj == b || seen[bj]) continue;
+                    seen[bj] = 1;
+                    if (n == 64) { fits = false; break; }
+                    nbr[(size_t)b * 64 + n++] = bj;
+                }
+        }
+        if (fits) {
+            if ((e = c->oc_nbr.upload(nbr)) != hipSuccess) return e;
+            if ((e = c->oc_flags.alloc((size_t)8 * G)) != hipSuccess) return e;
+            if ((e = c->oc_flags.zero()) != hipSuccess) return e;
+        }
     }
     c->oc_enabled = true;
     return hipSuccess;

@@ -54,6 +54,10 @@ struct OcArgs {
     double *part;       // [2][8][G] per-block partial sums, double-buffered by phase parity
     unsigned *bar;      // [2 sets][32 * 16] barrier words, 16-word (64 B) stride: [0..7] group counters, [17] abort
     int *counters; CgScal *scal; int *sig;
+    // neighbour hand-off of the pipelined iteration: a block may gather as soon as the blocks it reads from have
+    // published (their flags carry (solve, phase)); the grid barrier completes behind the gather
+    const int *nbr;               // [G][64] blocks whose rows this block's matrix rows reference (-1 = none); nullptr: feature off
+    unsigned long long *flags;    // [G] (8 words apart) last published (seq << 32 | phase) of every block
     unsigned long long *prof;   // diagnosis only (ADMM_HIP_OC_PROF=1): [64][8] timestamps of block prof_block
     int prof_block;
     int spb, wl, G, max_iters, seq;
@@ -118,6 +122,68 @@ __device__ __forceinline__ bool oc_barrier(unsigned *bar, unsigned epoch, int G,
         const int x = lane & 7;
         const unsigned need = (unsigned)((G + 7 - x) >> 3) * epoch;      // 0 for groups without blocks
         unsigned *word = bar + 16 * (lane < 8 ? x : 17);                  // lane 8 watches the abort word in the same load
+        int ok = 1;
+        unsigned spins = 0;
+        while (true) {
+            const unsigned v = (lane < 9) ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (__all(lane >= 8 || v >= need)) break;
+            if (++spins > kOcSpinLimit || __any(lane == 8 && v != 0u)) {
+                if (lane == 0) {
+                    __hip_atomic_store(bar + 16 * 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sig + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) *ok_lds = ok;
+    }
+    __syncthreads();
+    return *ok_lds != 0;
+}
+
+// Pipelined iteration, first half of the synchronisation: drain, announce (flag for the neighbours + arrival on the
+// grid barrier, both fire-and-forget), then wait only for the blocks this block gathers from.
+__device__ __forceinline__ bool oc_announce_and_wait_neighbours(unsigned *bar, unsigned long long *flags, const int *nbr, unsigned seq, unsigned epoch,
+                                                                int *ok_lds, int *sig) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        const unsigned long long tag = ((unsigned long long)seq << 32) | epoch;
+        if (lane == 0) {
+            __hip_atomic_store(flags + 8 * blockIdx.x, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(bar + 16 * ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const int nb = nbr[64 * blockIdx.x + lane];
+        int ok = 1;
+        unsigned spins = 0;
+        while (true) {
+            const unsigned long long v = (nb >= 0) ? __hip_atomic_load(flags + 8 * nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+            if (__all(v >= tag)) break;
+            if (++spins > kOcSpinLimit || ((spins & 255u) == 0u && __hip_atomic_load(bar + 16 * 17, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                if (lane == 0) {
+                    __hip_atomic_store(bar + 16 * 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sig + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) *ok_lds = ok;
+    }
+    __syncthreads();
+    return *ok_lds != 0;
+}
+// ... second half: the grid barrier this block has already arrived at (wave 0 polls the eight counters)
+__device__ __forceinline__ bool oc_barrier_wait(unsigned *bar, unsigned epoch, int G, int *ok_lds, int *sig) {
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        const int x = lane & 7;
+        const unsigned need = (unsigned)((G + 7 - x) >> 3) * epoch;
+        unsigned *word = bar + 16 * (lane < 8 ? x : 17);
         int ok = 1;
         unsigned spins = 0;
         while (true) {
@@ -500,9 +566,19 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
                 OC_STAMP(1);
                 if (a.prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); OC_STAMP(5); }
-                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
-                OC_STAMP(2);
-                gather_and_reduce(mm, rn, true, true);            // n = A M^-1 w, and the sums
+                if (a.nbr) {
+                    // gather as soon as the blocks this one reads from have published; the grid barrier completes
+                    // behind the gather and only gates the reduction of the partial sums
+                    if (!oc_announce_and_wait_neighbours(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; }
+                    OC_STAMP(2);
+                    gather_and_reduce(mm, rn, true, false);       // n = A M^-1 w
+                    if (!oc_barrier_wait(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    gather_and_reduce(nullptr, nullptr, false, true);   // the sums
+                } else {
+                    if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    OC_STAMP(2);
+                    gather_and_reduce(mm, rn, true, true);        // n = A M^-1 w, and the sums
+                }
             } else {
                 double q[6];
                 ++ph; publish(ru);
