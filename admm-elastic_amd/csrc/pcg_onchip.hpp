@@ -17,7 +17,11 @@
 //     17.6 us; pipelined 9.0 us = 1.0 us draining the write-through stores + 2.4 us barrier + 3.1 us gather and
 //     reduction + the rest.)  Barrier: eight per-group counters, one fire-and-forget arrival, relaxed
 //     agent-scope polling, bounded spins (a barrier that cannot complete aborts the solve with an error instead
-//     of hanging the GPU); two counter sets alternate between solves so nothing is cleared between launches;
+//     of hanging the GPU); two counter sets alternate between solves so nothing is cleared between launches.
+//     The gather does not wait for that barrier: a block announces its published slice with a (solve, phase)
+//     flag and starts gathering as soon as the <= 64 blocks whose rows its matrix rows reference have
+//     announced theirs (host-built neighbour lists; 1.6 us instead of 3.4 us); the barrier completes behind
+//     the gather and only gates the reduction of the partial sums.  8.2 us per iteration;
 //   * the recycled (Galerkin) warm start of the ADMM loop is the first phase of the same launch and the new
 //     (correction, A correction) pair is written in its epilogue;
 //   * pipelined CG carries w = A u by recurrence, so its recursive residual can drift from the true one.
