@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "AddMeshes.hpp"
+#include "ExplicitForce.hpp"
 
 using namespace admm;
 
@@ -69,6 +70,20 @@ int main(int argc, char **argv) {
     bool threw = false;
     try { binding::add_trimesh(&solver, p, Lame(100, 0.1), false); } catch (const std::runtime_error &) { threw = true; }
     CHECK(threw);
+    {   // WindForce (ExplicitForce.cpp:47-104) on one triangle, worked by hand: n = (0,0,1), area 1/2, v_r = (0,0,1.5)
+        //   force = -1000 * 0.5 * 1.5 * 1.5 * n = (0,0,-1125);  dv = 0.33 * dt * force = (0,0,-3.7125) at dt = 0.01
+        VecX x(9), v(9), m(9, 1.0);
+        const double px[9] = {0, 0, 0, 1, 0, 0, 0, 1, 0};
+        for (int i = 0; i < 9; ++i) { x[i] = px[i]; v[i] = (i % 3 == 2) ? 2.0 : 0.0; }
+        std::vector<int> tri = {0, 1, 2};
+        WindForce wind(tri);
+        wind.direction = Vec3(0.0, 0.0, 0.5);
+        wind.project(0.01, x, v, m);
+        for (int i = 0; i < 3; ++i) { CHECK(v[3 * i] == 0.0 && v[3 * i + 1] == 0.0); CHECK(std::fabs(v[3 * i + 2] - (2.0 - 3.7125)) < 1e-12); }
+        // plugged into the solver like the reference does (Solver.hpp:72, Solver.cpp:54)
+        solver.ext_forces.push_back(std::make_shared<WindForce>(tri));
+        CHECK(solver.ext_forces.size() == 1);
+    }
     printf("SUCCESS\n");
     return 0;
 }
