@@ -198,6 +198,15 @@ struct admm_hip_ctx {
     SellDev gs_sell; DevBuf<int> gs_slot_node; DevBuf<double> gs_diag; std::vector<int> gs_color_slice;
     DevBuf<double> gs_xb, gs_part2;   // two-colour scheme (k_gs_color2): roll-back copy, partial sums
     Obstacles obst{};
+    // dynamic (self-)collision (dyn_collide.hpp): one entry per TetMeshCollision, payload arrays per vertex
+    struct DynDev {
+        DynMesh m{};
+        DevBuf<int4> tet; DevBuf<int> tet_id, face, face_id; DevBuf<double> t_box, f_box, rest;
+        ~DynDev() { tet.release(); tet_id.release(); face.release(); face_id.release(); t_box.release(); f_box.release(); rest.release(); }
+    };
+    std::vector<std::unique_ptr<DynDev> > dyn;
+    DevBuf<int> dyn_face, surf_list; DevBuf<double> dyn_bary, dyn_n, dyn_dx; DevBuf<unsigned char> surf_mask;
+    int n_surf = 0;   // Solver::surface_inds (0 = every vertex is a collision candidate)
 
     ~admm_hip_ctx() {
         (void)hipSetDevice(device);
@@ -216,6 +225,7 @@ struct admm_hip_ctx {
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
+        dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
         if (gs_exec) (void)hipGraphExecDestroy(gs_exec);
         if (h_sig) (void)hipHostFree(h_sig);
@@ -478,6 +488,23 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     return rc;
 }
 
+// Collider::detect, dynamic objects (src/Collider.hpp:166-168,192-201): refit every tet tree at x, then query the
+// candidates against the objects in add_dynamic_collider order.  Payloads land in dyn_face / dyn_bary / dyn_n / dyn_dx.
+int enqueue_dyn_detect(admm_hip_ctx *c, const double *x) {
+    hipStream_t st = c->stream;
+    const int nq = c->n_surf > 0 ? c->n_surf : c->nv;
+    const int *qlist = c->n_surf > 0 ? c->surf_list.p : nullptr;
+    if (hipMemsetAsync(c->dyn_face.p, 0xff, 3 * (size_t)c->nv * sizeof(int), st) != hipSuccess) return -1;
+    for (auto &d : c->dyn) {
+        hipLaunchKernelGGL(k_dyn_refit0, dim3(blocks_for(d->m.tt.n[0])), dim3(256), 0, st, d->m, x);
+        for (int l = 1; l < d->m.tt.n_levels; ++l)
+            hipLaunchKernelGGL(k_dyn_refit_up, dim3(blocks_for(d->m.tt.n[l])), dim3(256), 0, st, d->m, l);
+        hipLaunchKernelGGL(k_dyn_query, dim3(blocks_for(nq)), dim3(256), 0, st, d->m, nq, qlist, x, c->dyn_face.p, c->dyn_bary.p,
+                           c->dyn_n.p, c->dyn_dx.p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // UzawaCG::solve (src/UzawaCG.hpp:57-125).  Host-driven outer loop (one stream sync per Schur-CG
 // iteration, negligible next to the inner solves); returns the reference's iteration count via *iters.
 int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
@@ -485,11 +512,25 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     const int nv = c->nv, gv = blocks_for(nv);
     *iters = 1;
     int nh = 0;
-    if (c->obst.n > 0) {
+    const bool dyn = !c->dyn.empty();
+    const int *dface = dyn ? c->dyn_face.p : nullptr;
+    const double *dbary = dyn ? c->dyn_bary.p : nullptr;
+    const int nq = c->n_surf > 0 ? c->n_surf : nv, gq = blocks_for(nq);
+    const int *qlist = c->n_surf > 0 ? c->surf_list.p : nullptr;
+    if (c->obst.n > 0 || dyn) {
         // Collider::detect at the current iterate + ConstraintSet::make_matrix (ck = sqrt(constraint_w))
+        const double ck = std::sqrt(std::max(0.0, c->constraint_w));
         if (hipMemsetAsync(c->counters.p + 6, 0, sizeof(int), st) != hipSuccess) return -1;
-        hipLaunchKernelGGL(k_uz_detect, dim3(gv), dim3(256), 0, st, nv, x, c->obst, std::sqrt(std::max(0.0, c->constraint_w)),
-                           c->uz_cn.p, c->uz_cc.p, c->counters.p + 6);
+        if (c->obst.n > 0)
+            hipLaunchKernelGGL(k_uz_detect, dim3(gv), dim3(256), 0, st, nv, x, c->obst, ck, c->uz_cn.p, c->uz_cc.p, c->counters.p + 6,
+                               c->n_surf > 0 ? c->surf_mask.p : nullptr);
+        else if (hipMemsetAsync(c->uz_cn.p, 0, c->n3 * sizeof(double), st) != hipSuccess ||
+                 hipMemsetAsync(c->uz_cc.p, 0, nv * sizeof(double), st) != hipSuccess) return -1;
+        if (dyn) {
+            if (enqueue_dyn_detect(c, x)) return -1;
+            hipLaunchKernelGGL(k_dyn_rows, dim3(gq), dim3(256), 0, st, nq, qlist, ck, c->uz_cn.p, c->uz_cc.p, c->dyn_face.p, c->dyn_n.p,
+                               c->counters.p + 6);
+        }
         if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
     }
@@ -500,17 +541,19 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     }
     if (nh == 0) return launch_pcg_recycled(c, b, x); // no constraints: one prefactored solve (:78-81)
     hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 0, b, c->uz_cn.p, c->uz_y.p, c->uz_q1.p);       // q1 = b - C^T y
+    if (dyn) hipLaunchKernelGGL(k_uz_ct_dyn, dim3(gq), dim3(256), 0, st, nq, qlist, 0, c->uz_cn.p, c->uz_y.p, dface, dbary, c->uz_q1.p);
     if (launch_pcg(c, c->uz_q1.p, x, c->pcg_max_iters)) return -1;                                               // x = A^-1 q1
-    hipLaunchKernelGGL(k_uz_resid, dim3(gv), dim3(256), 0, st, nv, x, c->uz_cn.p, c->uz_cc.p, c->uz_r.p, c->uz_d.p);
+    hipLaunchKernelGGL(k_uz_resid, dim3(gv), dim3(256), 0, st, nv, x, c->uz_cn.p, c->uz_cc.p, c->uz_r.p, c->uz_d.p, dface, dbary);
     if (hipMemsetAsync(c->uz_scal.p, 0, sizeof(UzScal), st) != hipSuccess) return -1;
     const double tol2 = c->uz_tol * c->uz_tol;
     UzScal h{};
     for (int it = 0; it < c->uz_max_iters; ++it) {
         hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 1, b, c->uz_cn.p, c->uz_d.p, c->uz_q1.p);   // q1 = C^T d
+        if (dyn) hipLaunchKernelGGL(k_uz_ct_dyn, dim3(gq), dim3(256), 0, st, nq, qlist, 1, c->uz_cn.p, c->uz_d.p, dface, dbary, c->uz_q1.p);
         if (hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) return -1;
         if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, c->pcg_max_iters)) return -1;                                  // q2 = A^-1 q1
         hipLaunchKernelGGL(k_uz_dots, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_q2.p, c->uz_cn.p, c->uz_d.p, c->uz_r.p, c->uz_q3.p,
-                           c->uz_part.p, c->NBU);
+                           c->uz_part.p, c->NBU, dface, dbary);
         hipLaunchKernelGGL(k_uz_alpha, dim3(1), dim3(256), 0, st, c->uz_part.p, c->NBU, c->uz_scal.p);
         hipLaunchKernelGGL(k_uz_step, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_scal.p, x, c->uz_q2.p, c->uz_y.p, c->uz_d.p, c->uz_r.p,
                            c->uz_q3.p, c->uz_part.p, c->NBU);
@@ -936,6 +979,134 @@ int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const dou
         HIP_TRY(hipMemcpy(c->pin_active.p, act.data(), act.size() * sizeof(int), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->pin_xyz.p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));
     }
+    return ADMM_HIP_OK;
+}
+
+// Solver::surface_inds (src/Solver.hpp:70): the vertices Collider::detect looks at (Collider.hpp:157,163)
+int admm_hip_set_surface_inds(admm_hip_ctx *c, int32_t n, const int32_t *inds) {
+    if (!c || n < 0 || (n > 0 && !inds)) return fail(ADMM_HIP_ERR_ARG, "set_surface_inds: bad input");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int> list;
+    std::vector<unsigned char> mask(c->nv, 0);
+    for (int i = 0; i < n; ++i) {
+        if (inds[i] < 0 || inds[i] >= c->nv) return fail(ADMM_HIP_ERR_ARG, "set_surface_inds: index out of range");
+        if (!mask[inds[i]]) list.push_back(inds[i]);   // a vertex is a candidate once
+        mask[inds[i]] = 1;
+    }
+    n = (int32_t)list.size();
+    c->surf_list.release(); c->surf_mask.release();
+    c->n_surf = n;
+    if (n > 0) { HIP_TRY(c->surf_list.upload(list)); HIP_TRY(c->surf_mask.upload(mask)); }
+    return ADMM_HIP_OK;
+}
+
+// Solver::add_dynamic_collider(TetMeshCollision(mesh, v_offset)) -- src/Solver.cpp:163-165, src/DynamicObject.hpp:45-64
+int admm_hip_add_dynamic_tetmesh(admm_hip_ctx *c, int32_t vert_offset, int32_t n_verts, const double *rest_verts,
+                                 int32_t n_tets, const int32_t *tets, int32_t n_faces, const int32_t *faces) {
+    if (!c || !rest_verts || !tets || n_verts <= 0 || n_tets <= 0 || vert_offset < 0 || vert_offset + n_verts > c->nv)
+        return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: bad input");
+    if (n_faces <= 0 || !faces) return fail(ADMM_HIP_ERR_ARG, "**TetMeshCollision Error: TetMesh needs surface faces");
+    if (c->linsolver == 0) return fail(ADMM_HIP_ERR_ARG, "**Solver::add_obstacle Error: No collisions with LDLT solver");
+    if (c->linsolver == 1)
+        return fail(ADMM_HIP_ERR_ARG, "dynamic colliders with NodalMultiColorGS (A + C^T C, re-coloured at every solve, "
+                                      "NodalMultiColorGS.hpp:80-86) are not implemented on the GPU: use linsolver 2 (UzawaCG)");
+    for (int i = 0; i < 4 * n_tets; ++i) if (tets[i] < 0 || tets[i] >= n_verts) return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: tet index out of range");
+    for (int i = 0; i < 3 * n_faces; ++i) if (faces[i] < 0 || faces[i] >= n_verts) return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: face index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    auto fill_levels = [](const admm_host::OctTree &T, OctLevels &L) {
+        L.n_levels = T.n_levels;
+        for (int l = 0; l < T.n_levels; ++l) { L.off[l] = T.level_off[l]; L.n[l] = T.level_n[l]; }
+        L.off[T.n_levels] = T.level_off[T.n_levels];
+    };
+    std::vector<double> cen(3 * (size_t)n_tets);
+    for (int t = 0; t < n_tets; ++t)
+        for (int a = 0; a < 3; ++a) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += rest_verts[3 * (size_t)tets[4 * (size_t)t + k] + a];
+            cen[3 * (size_t)t + a] = 0.25 * s;
+        }
+    const admm_host::OctTree TT = admm_host::build_octtree(n_tets, cen.data());
+    cen.assign(3 * (size_t)n_faces, 0.0);
+    for (int f = 0; f < n_faces; ++f)
+        for (int a = 0; a < 3; ++a) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += rest_verts[3 * (size_t)faces[3 * (size_t)f + k] + a];
+            cen[3 * (size_t)f + a] = s / 3.0;
+        }
+    const admm_host::OctTree FT = admm_host::build_octtree(n_faces, cen.data());
+    if (TT.n_levels > kOctMaxLevels || FT.n_levels > kOctMaxLevels) return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: mesh too large");
+    std::vector<int4> tet_s(TT.n_padded, make_int4(-1, -1, -1, -1));
+    std::vector<int> tet_id(TT.n_padded, -1), face_s(3 * (size_t)FT.n_padded, -1), face_id(FT.n_padded, -1);
+    for (int i = 0; i < TT.n_padded; ++i) {
+        const int t = TT.order[i];
+        if (t < 0) continue;
+        tet_s[i] = make_int4(tets[4 * (size_t)t] + vert_offset, tets[4 * (size_t)t + 1] + vert_offset, tets[4 * (size_t)t + 2] + vert_offset,
+                             tets[4 * (size_t)t + 3] + vert_offset);
+        tet_id[i] = t;
+    }
+    for (int i = 0; i < FT.n_padded; ++i) {
+        const int f = FT.order[i];
+        if (f < 0) continue;
+        for (int k = 0; k < 3; ++k) face_s[3 * (size_t)i + k] = faces[3 * (size_t)f + k];
+        face_id[i] = f;
+    }
+    const std::vector<double> fbox = admm_host::octtree_boxes_tris(FT, faces, rest_verts);
+    std::unique_ptr<admm_hip_ctx::DynDev> d(new admm_hip_ctx::DynDev());
+    HIP_TRY(d->tet.upload(tet_s)); HIP_TRY(d->tet_id.upload(tet_id)); HIP_TRY(d->face.upload(face_s)); HIP_TRY(d->face_id.upload(face_id));
+    HIP_TRY(d->f_box.upload(fbox));
+    HIP_TRY(d->t_box.alloc(6 * (size_t)TT.level_off[TT.n_levels]));
+    HIP_TRY(d->rest.upload(std::vector<double>(rest_verts, rest_verts + 3 * (size_t)n_verts)));
+    d->m.vert_offset = vert_offset; d->m.n_verts = n_verts;
+    fill_levels(TT, d->m.tt); fill_levels(FT, d->m.ft);
+    d->m.tet = d->tet.p; d->m.tet_id = d->tet_id.p; d->m.t_box = d->t_box.p;
+    d->m.face = d->face.p; d->m.face_id = d->face_id.p; d->m.f_box = d->f_box.p; d->m.rest = d->rest.p;
+    if (!c->dyn_face.p) {
+        HIP_TRY(c->dyn_face.alloc(3 * (size_t)c->nv)); HIP_TRY(c->dyn_bary.alloc(c->n3)); HIP_TRY(c->dyn_n.alloc(c->n3));
+        HIP_TRY(c->dyn_dx.alloc(c->nv));
+        HIP_TRY(c->dyn_bary.zero()); HIP_TRY(c->dyn_n.zero()); HIP_TRY(c->dyn_dx.zero());
+    }
+    c->dyn.push_back(std::move(d));
+    return ADMM_HIP_OK;
+}
+
+// Collider::detect for the dynamic objects at x (host vector) -- kernel-level entry point for the parity tests.
+// Hits come back in candidate order (surface_inds order, else vertex order).
+int admm_hip_detect_dynamic(admm_hip_ctx *c, const double *x, int32_t cap, int32_t *n_hits, int32_t *vert, int32_t *face,
+                            double *barys, double *normal, double *dx) {
+    if (!c || !x || !n_hits || cap < 0) return fail(ADMM_HIP_ERR_ARG, "detect_dynamic: bad input");
+    *n_hits = 0;
+    if (c->dyn.empty()) return ADMM_HIP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<double> xd;
+    HIP_TRY(xd.alloc(c->n3));
+    struct Free { DevBuf<double> &b; ~Free() { b.release(); } } guard{xd};
+    HIP_TRY(hipMemcpyAsync(xd.p, x, c->n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (enqueue_dyn_detect(c, xd.p)) return fail(ADMM_HIP_ERR_DEVICE, "detect_dynamic: launch failed");
+    std::vector<int> hf(3 * (size_t)c->nv), list;
+    std::vector<double> hb(c->n3), hn(c->n3), hd(c->nv);
+    HIP_TRY(hipMemcpyAsync(hf.data(), c->dyn_face.p, hf.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hb.data(), c->dyn_bary.p, hb.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hn.data(), c->dyn_n.p, hn.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hd.data(), c->dyn_dx.p, hd.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->n_surf > 0) { list.resize(c->n_surf); HIP_TRY(hipMemcpy(list.data(), c->surf_list.p, list.size() * sizeof(int), hipMemcpyDeviceToHost)); }
+    const int nq = c->n_surf > 0 ? c->n_surf : c->nv;
+    int n = 0;
+    for (int q = 0; q < nq; ++q) {
+        const int v = c->n_surf > 0 ? list[q] : q;
+        if (hf[3 * (size_t)v] < 0) continue;
+        if (n < cap) {
+            if (vert) vert[n] = v;
+            if (dx) dx[n] = hd[v];
+            for (int a = 0; a < 3; ++a) {
+                if (face) face[3 * (size_t)n + a] = hf[3 * (size_t)v + a];
+                if (barys) barys[3 * (size_t)n + a] = hb[3 * (size_t)v + a];
+                if (normal) normal[3 * (size_t)n + a] = hn[3 * (size_t)v + a];
+            }
+        }
+        ++n;
+    }
+    *n_hits = n;
     return ADMM_HIP_OK;
 }
 

@@ -1,0 +1,277 @@
+// dyn_collide.hpp -- dynamic (self-)collision on the GPU: TetMeshCollision (src/DynamicObject.hpp:31-121) as queried by
+// Collider::detect (src/Collider.hpp:152-212), feeding the dynamic rows of ConstraintSet::make_matrix
+// (src/ConstraintSet.hpp:92-110).  SURVEY 8(f) item 2.
+//
+// The reference rebuilds an mclscene AABB tree over the deformed tets at every detect (DynamicObject.hpp:66-69) and
+// keeps a static tree over the REST surface triangles (:56-58).  Here both are implicit 8-ary trees over primitives
+// sorted ONCE along a Morton curve of the rest centroids (host_setup.cpp: build_octtree): node i of level 0 covers
+// sorted primitives [8i, 8i+8), node i of level l covers nodes [8i, 8i+8) of level l-1.  No pointers, no per-detect
+// sort, no atomics: a detect REFITS the boxes of the tet tree bottom-up (one thread per node, one launch per level --
+// 7 launches at 1 M tets) and queries it with one lane per candidate vertex.  The order stays good under deformation
+// because neighbours at rest stay neighbours.
+//
+// What the absent traversal order would decide is decided by index (so the result does not depend on the traversal):
+// lowest tet index among the tets containing the vertex, lowest face index among equally near rest triangles.  FP64.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace admm_k {
+
+constexpr int kOctMaxLevels = 12;
+
+struct OctLevels { int n_levels; int off[kOctMaxLevels + 1]; int n[kOctMaxLevels]; };
+
+struct DynMesh {
+    int vert_offset, n_verts;
+    OctLevels tt;               // tets tree
+    const int4 *tet;            // [padded] GLOBAL vertex ids in sorted order (x = -1: padding)
+    const int *tet_id;          // [padded] original tet index
+    double *t_box;              // [6 * nodes] lo xyz, hi xyz -- refitted
+    OctLevels ft;               // rest-surface faces tree
+    const int *face;            // [3 * padded] LOCAL vertex ids in sorted order (-1: padding)
+    const int *face_id;         // [padded] original face index
+    const double *f_box;        // [6 * nodes] static
+    const double *rest;         // [3 * n_verts]
+};
+
+__device__ __forceinline__ void box_reset(double *b) {
+    b[0] = b[1] = b[2] = __builtin_inf(); b[3] = b[4] = b[5] = -__builtin_inf();
+}
+__device__ __forceinline__ void box_grow(double *b, const double *p) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { b[a] = fmin(b[a], p[a]); b[3 + a] = fmax(b[3 + a], p[a]); }
+}
+
+// level 0: box of 8 consecutive (sorted) tets at the current positions
+__global__ __launch_bounds__(256) void k_dyn_refit0(DynMesh M, const double *__restrict__ x) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M.tt.n[0]) return;
+    double b[6]; box_reset(b);
+    for (int k = 0; k < 8; ++k) {
+        const int4 t = M.tet[8 * (size_t)i + k];
+        if (t.x < 0) continue;
+        const int id[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const double p[3] = {x[3 * (size_t)id[c]], x[3 * (size_t)id[c] + 1], x[3 * (size_t)id[c] + 2]}; box_grow(b, p); }
+    }
+    double *o = M.t_box + 6 * (size_t)i;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) o[a] = b[a];
+}
+
+// level l >= 1: union of the (up to 8) child boxes
+__global__ __launch_bounds__(256) void k_dyn_refit_up(DynMesh M, int l) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M.tt.n[l]) return;
+    double b[6]; box_reset(b);
+    for (int k = 0; k < 8 && 8 * i + k < M.tt.n[l - 1]; ++k) {
+        const double *ch = M.t_box + 6 * (size_t)(M.tt.off[l - 1] + 8 * i + k);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { b[a] = fmin(b[a], ch[a]); b[3 + a] = fmax(b[3 + a], ch[3 + a]); }
+    }
+    double *o = M.t_box + 6 * (size_t)(M.tt.off[l] + i);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) o[a] = b[a];
+}
+
+__device__ __forceinline__ bool tet_barycentric(const double *x, const double *p0, const double *p1, const double *p2, const double *p3, double *b) {
+    double e1[3], e2[3], e3[3], r[3], cf[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { e1[c] = p1[c] - p0[c]; e2[c] = p2[c] - p0[c]; e3[c] = p3[c] - p0[c]; r[c] = x[c] - p0[c]; }
+    cross3(e2, e3, cf);
+    const double det = dot3(e1, cf);
+    if (det == 0.0 || !(det == det)) return false;
+    b[1] = dot3(r, cf) / det;
+    cross3(e3, e1, cf); b[2] = dot3(r, cf) / det;
+    cross3(e1, e2, cf); b[3] = dot3(r, cf) / det;
+    b[0] = 1.0 - b[1] - b[2] - b[3];
+    return true;
+}
+
+// Ericson, Real-Time Collision Detection 5.1.5: closest point of triangle (a,b,c) to p; returns the squared distance,
+// bc = barycentrics of the closest point
+__device__ __forceinline__ double closest_on_triangle(const double *p, const double *a, const double *b, const double *c, double *bc) {
+    double ab[3], ac[3], ap[3], bp[3], cp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; bp[i] = p[i] - b[i]; cp[i] = p[i] - c[i]; }
+    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap), d3 = dot3(ab, bp), d4 = dot3(ac, bp), d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    double u, v, w;
+    if (d1 <= 0.0 && d2 <= 0.0) { u = 1; v = 0; w = 0; }
+    else if (d3 >= 0.0 && d4 <= d3) { u = 0; v = 1; w = 0; }
+    else if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) { v = d1 / (d1 - d3); u = 1 - v; w = 0; }
+    else if (d6 >= 0.0 && d5 <= d6) { u = 0; v = 0; w = 1; }
+    else if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { w = d2 / (d2 - d6); u = 1 - w; v = 0; }
+    else if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) { w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); v = 1 - w; u = 0; }
+    else { const double den = 1.0 / (va + vb + vc); v = vb * den; w = vc * den; u = 1.0 - v - w; }
+    double d = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const double q = p[i] - (u * a[i] + v * b[i] + w * c[i]); d += q * q; }
+    bc[0] = u; bc[1] = v; bc[2] = w;
+    return d;
+}
+
+__device__ __forceinline__ bool box_contains(const double *b, const double *p) {
+    return p[0] >= b[0] && p[1] >= b[1] && p[2] >= b[2] && p[0] <= b[3] && p[1] <= b[4] && p[2] <= b[5];
+}
+__device__ __forceinline__ double box_dist2(const double *b, const double *p) {
+    double d = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const double e = fmax(fmax(b[a] - p[a], p[a] - b[3 + a]), 0.0); d += e * e; }
+    return d;
+}
+
+// TetMeshCollision::signed_distance for every candidate vertex (query == nullptr: vertices 0..nq-1).  A vertex that
+// already holds a dynamic payload (face >= 0, written by an earlier object) is skipped (DynamicObject.hpp:73).
+__global__ __launch_bounds__(256) void k_dyn_query(DynMesh M, int nq, const int *__restrict__ query, const double *__restrict__ x,
+                                                   int *__restrict__ face_out, double *__restrict__ bary_out,
+                                                   double *__restrict__ n_out, double *__restrict__ dx_out) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const int vg = query ? query[q] : q;
+    if (face_out[3 * (size_t)vg] >= 0) return;
+    const double px[3] = {x[3 * (size_t)vg], x[3 * (size_t)vg + 1], x[3 * (size_t)vg + 2]};
+    int stack[8 * kOctMaxLevels];
+    int sp = 0;
+    // ---- point in tet (:76-79): lowest original index among the tets that contain the vertex and do not touch it
+    int found = 0x7fffffff, found_pos = -1;
+    double fb[4] = {0, 0, 0, 0};
+    stack[sp++] = ((M.tt.n_levels - 1) << 27);
+    while (sp > 0) {
+        const int e = stack[--sp], l = e >> 27, i = e & 0x7ffffff;
+        if (l > 0) {
+            for (int k = 0; k < 8; ++k) {
+                const int j = 8 * i + k;
+                if (j >= M.tt.n[l - 1]) break;
+                if (box_contains(M.t_box + 6 * (size_t)(M.tt.off[l - 1] + j), px)) stack[sp++] = ((l - 1) << 27) | j;
+            }
+            continue;
+        }
+        for (int k = 0; k < 8; ++k) {
+            const int pos = 8 * i + k;
+            const int4 t = M.tet[pos];
+            if (t.x < 0) continue;
+            if (t.x == vg || t.y == vg || t.z == vg || t.w == vg) continue;
+            const int tid = M.tet_id[pos];
+            if (tid > found) continue;
+            double p[4][3];
+            const int id[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { p[c][0] = x[3 * (size_t)id[c]]; p[c][1] = x[3 * (size_t)id[c] + 1]; p[c][2] = x[3 * (size_t)id[c] + 2]; }
+            double b[4];
+            if (!tet_barycentric(px, p[0], p[1], p[2], p[3], b)) continue;
+            if (b[0] >= 0.0 && b[1] >= 0.0 && b[2] >= 0.0 && b[3] >= 0.0) { found = tid; found_pos = pos; fb[0] = b[0]; fb[1] = b[1]; fb[2] = b[2]; fb[3] = b[3]; }
+        }
+    }
+    if (found_pos < 0) return;
+    // ---- the same combination of the rest vertices (:92-97)
+    double rx[3] = {0, 0, 0};
+    {
+        const int4 t = M.tet[found_pos];
+        const int id[4] = {t.x - M.vert_offset, t.y - M.vert_offset, t.z - M.vert_offset, t.w - M.vert_offset};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) rx[a] += fb[c] * M.rest[3 * (size_t)id[c] + a];
+    }
+    // ---- nearest rest-surface triangle that does not touch the vertex (:99-104)
+    const int vl = vg - M.vert_offset;
+    double best = __builtin_inf(), bbc[3] = {0, 0, 0};
+    int best_id = 0x7fffffff, best_pos = -1;
+    sp = 0;
+    stack[sp++] = ((M.ft.n_levels - 1) << 27);
+    while (sp > 0) {
+        const int e = stack[--sp], l = e >> 27, i = e & 0x7ffffff;
+        if (l > 0) {
+            for (int k = 0; k < 8; ++k) {
+                const int j = 8 * i + k;
+                if (j >= M.ft.n[l - 1]) break;
+                if (!(box_dist2(M.f_box + 6 * (size_t)(M.ft.off[l - 1] + j), rx) > best)) stack[sp++] = ((l - 1) << 27) | j;
+            }
+            continue;
+        }
+        if (box_dist2(M.f_box + 6 * (size_t)(M.ft.off[0] + i), rx) > best) continue;
+        for (int k = 0; k < 8; ++k) {
+            const int pos = 8 * i + k;
+            const int f0 = M.face[3 * (size_t)pos], f1 = M.face[3 * (size_t)pos + 1], f2 = M.face[3 * (size_t)pos + 2];
+            if (f0 < 0) continue;
+            if (f0 == vl || f1 == vl || f2 == vl) continue;
+            double bc[3];
+            const double d = closest_on_triangle(rx, M.rest + 3 * (size_t)f0, M.rest + 3 * (size_t)f1, M.rest + 3 * (size_t)f2, bc);
+            const int fid = M.face_id[pos];
+            if (d < best || (d == best && fid < best_id)) { best = d; best_id = fid; best_pos = pos; bbc[0] = bc[0]; bbc[1] = bc[1]; bbc[2] = bc[2]; }
+        }
+    }
+    if (best_pos < 0) return;
+    const double dx = -sqrt(best);                 // :112
+    if (!(dx < 0.0)) return;                       // Collider.hpp:203
+    const int f[3] = {M.face[3 * (size_t)best_pos], M.face[3 * (size_t)best_pos + 1], M.face[3 * (size_t)best_pos + 2]};
+    double e1[3], e2[3], nr[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        e1[a] = M.rest[3 * (size_t)f[1] + a] - M.rest[3 * (size_t)f[0] + a];
+        e2[a] = M.rest[3 * (size_t)f[2] + a] - M.rest[3 * (size_t)f[0] + a];
+    }
+    cross3(e1, e2, nr);
+    const double il = 1.0 / sqrt(dot3(nr, nr));
+    dx_out[vg] = dx;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        face_out[3 * (size_t)vg + a] = f[a] + M.vert_offset;    // :113
+        bary_out[3 * (size_t)vg + a] = bbc[a];                  // :114
+        n_out[3 * (size_t)vg + a] = nr[a] * il;                 // :110-111, :115
+    }
+}
+
+// ConstraintSet::make_matrix, dynamic rows (ConstraintSet.hpp:92-110) in the per-vertex row storage of the Uzawa
+// kernels: a candidate with a dynamic payload counts as a row; if the vertex already holds a passive row the
+// dynamic row stays empty (`constrained`, :96-99), otherwise row = ck n^T (x_v - sum_j bary_j x_face_j), rhs 0.
+__global__ __launch_bounds__(256) void k_dyn_rows(int nq, const int *__restrict__ query, double ck, double *__restrict__ cn,
+                                                  double *__restrict__ cc, int *__restrict__ dface, const double *__restrict__ dn,
+                                                  int *__restrict__ nhits) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const int v = query ? query[q] : q;
+    if (dface[3 * (size_t)v] < 0) return;
+    atomicAdd(nhits, 1);
+    if (cn[3 * (size_t)v] != 0.0 || cn[3 * (size_t)v + 1] != 0.0 || cn[3 * (size_t)v + 2] != 0.0) { dface[3 * (size_t)v] = -1; return; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) cn[3 * (size_t)v + a] = ck * dn[3 * (size_t)v + a];
+    cc[v] = 0.0;
+}
+
+// the face-vertex part of C^T y: out += s * ck n bary_j y_v at face vertex j, s = +1 for (base - C^T y), -1 for C^T y.
+// Several rows may share a face vertex: FP64 atomic adds (the only atomics on data in this library; their order is
+// the only source of run-to-run round-off differences, and only while dynamic rows exist).
+__global__ __launch_bounds__(256) void k_uz_ct_dyn(int nq, const int *__restrict__ query, int mode, const double *__restrict__ cn,
+                                                   const double *__restrict__ y, const int *__restrict__ dface,
+                                                   const double *__restrict__ dbary, double *__restrict__ out) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const int v = query ? query[q] : q;
+    if (dface[3 * (size_t)v] < 0) return;
+    const double s = (mode == 0 ? 1.0 : -1.0) * y[v];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int f = dface[3 * (size_t)v + j];
+        const double w = s * dbary[3 * (size_t)v + j];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) atomicAdd(out + 3 * (size_t)f + a, w * cn[3 * (size_t)v + a]);
+    }
+}
+
+// the face-vertex part of one row of C applied to a node vector: - sum_j bary_j cn . vec_face_j (0 for other rows)
+__device__ __forceinline__ double dyn_row_faces(int v, const double *__restrict__ cn, const int *__restrict__ dface,
+                                                const double *__restrict__ dbary, const double *__restrict__ vec) {
+    if (dface == nullptr || dface[3 * (size_t)v] < 0) return 0.0;
+    double r = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int f = dface[3 * (size_t)v + j];
+        r -= dbary[3 * (size_t)v + j] * (cn[3 * (size_t)v] * vec[3 * (size_t)f] + cn[3 * (size_t)v + 1] * vec[3 * (size_t)f + 1] +
+                                         cn[3 * (size_t)v + 2] * vec[3 * (size_t)f + 2]);
+    }
+    return r;
+}
+
+} // namespace admm_k

@@ -3,6 +3,8 @@
 #include "host_setup.hpp"
 #include <algorithm>
 #include <cmath>
+#include <limits>
+#include <utility>
 #include <numeric>
 #include <set>
 #include <tuple>
@@ -341,6 +343,85 @@ void partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_
     const int64_t n = n_items;
     *begin = (int32_t)(n * rank / world_size);
     *end = (int32_t)(n * (rank + 1) / world_size);
+}
+
+} // namespace admm_host
+
+// ---------------------------------------------------------------------------------------------------
+// Implicit 8-ary tree over Morton-sorted primitives (dynamic self-collision)
+namespace admm_host {
+
+static inline uint64_t spread21(uint64_t v) { // 21 bits -> every third bit
+    v &= 0x1fffffULL;
+    v = (v | v << 32) & 0x1f00000000ffffULL;
+    v = (v | v << 16) & 0x1f0000ff0000ffULL;
+    v = (v | v << 8) & 0x100f00f00f00f00fULL;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ULL;
+    v = (v | v << 2) & 0x1249249249249249ULL;
+    return v;
+}
+
+OctTree build_octtree(int32_t n, const double *cen) {
+    OctTree T;
+    T.n_prims = n;
+    T.n_padded = std::max(8, (n + 7) / 8 * 8);
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) {
+            const double v = cen[3 * (size_t)i + c];
+            if (i == 0 || v < lo[c]) lo[c] = v;
+            if (i == 0 || v > hi[c]) hi[c] = v;
+        }
+    std::vector<std::pair<uint64_t, int32_t> > key(n);
+    for (int i = 0; i < n; ++i) {
+        uint64_t code = 0;
+        for (int c = 0; c < 3; ++c) {
+            const double ext = hi[c] - lo[c];
+            double t = ext > 0 ? (cen[3 * (size_t)i + c] - lo[c]) / ext : 0.0;
+            t = std::min(std::max(t, 0.0), 1.0);
+            code |= spread21((uint64_t)(t * 2097151.0)) << c;
+        }
+        key[i] = std::make_pair(code, i);
+    }
+    std::sort(key.begin(), key.end());
+    T.order.assign(T.n_padded, -1);
+    for (int i = 0; i < n; ++i) T.order[i] = key[i].second;
+    int cnt = T.n_padded / 8, off = 0;
+    for (;;) {
+        T.level_off.push_back(off); T.level_n.push_back(cnt);
+        off += cnt;
+        if (cnt == 1) break;
+        cnt = (cnt + 7) / 8;
+    }
+    T.level_off.push_back(off);
+    T.n_levels = (int)T.level_n.size();
+    return T;
+}
+
+std::vector<double> octtree_boxes_tris(const OctTree &T, const int32_t *faces, const double *verts) {
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<double> box(6 * (size_t)T.level_off[T.n_levels]);
+    for (size_t i = 0; i < box.size(); i += 6) { box[i] = box[i + 1] = box[i + 2] = inf; box[i + 3] = box[i + 4] = box[i + 5] = -inf; }
+    for (int i = 0; i < T.level_n[0]; ++i) {
+        double *b = &box[6 * (size_t)i];
+        for (int k = 0; k < 8; ++k) {
+            const int f = T.order[8 * (size_t)i + k];
+            if (f < 0) continue;
+            for (int c = 0; c < 3; ++c) {
+                const double *p = verts + 3 * (size_t)faces[3 * (size_t)f + c];
+                for (int a = 0; a < 3; ++a) { b[a] = std::min(b[a], p[a]); b[3 + a] = std::max(b[3 + a], p[a]); }
+            }
+        }
+    }
+    for (int l = 1; l < T.n_levels; ++l)
+        for (int i = 0; i < T.level_n[l]; ++i) {
+            double *b = &box[6 * (size_t)(T.level_off[l] + i)];
+            for (int k = 0; k < 8 && 8 * i + k < T.level_n[l - 1]; ++k) {
+                const double *ch = &box[6 * (size_t)(T.level_off[l - 1] + 8 * i + k)];
+                for (int a = 0; a < 3; ++a) { b[a] = std::min(b[a], ch[a]); b[3 + a] = std::max(b[3 + a], ch[3 + a]); }
+            }
+        }
+    return box;
 }
 
 } // namespace admm_host

@@ -53,6 +53,22 @@ struct GsSell {
 };
 GsSell build_gs_sell(const Csr &A, int n_colors, const std::vector<int32_t> &color);
 
+// Implicit 8-ary bounding-volume tree over primitives sorted along a Morton curve (dynamic self-collision,
+// src/DynamicObject.hpp: the reference builds mclscene AABB trees; here the ORDER is fixed once from the rest
+// centroids and only the boxes are refitted).  Level 0 node i covers sorted primitives [8 i, 8 i + 8), level l
+// node i covers level l-1 nodes [8 i, 8 i + 8); the last level has one node.  Boxes of all levels live in one
+// array, level l starting at node offset level_off[l].
+struct OctTree {
+    int32_t n_prims = 0, n_padded = 0, n_levels = 0;
+    std::vector<int32_t> order;       // [n_padded] sorted position -> original primitive index (-1 = padding)
+    std::vector<int32_t> level_off;   // [n_levels + 1] node offsets, level_off[n_levels] = total node count
+    std::vector<int32_t> level_n;     // [n_levels] nodes per level
+};
+// centroids [3 * n]; ties in the Morton code keep the original order
+OctTree build_octtree(int32_t n, const double *centroids);
+// boxes (lo xyz, hi xyz per node) of every level for triangles `faces` (local ids, sorted order given by tree.order)
+std::vector<double> octtree_boxes_tris(const OctTree &tree, const int32_t *faces, const double *verts);
+
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
 int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
 void lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);

@@ -1117,12 +1117,21 @@ __global__ __launch_bounds__(256) void k_gs_check(const double *__restrict__ par
 // constraint rows of ConstraintSet::make_matrix (src/ConstraintSet.hpp:59-116) for passive hits found by
 // Collider::detect (src/Collider.hpp:152-212).  A passive hit constrains ONE vertex (row = ck n^T at the
 // vertex, rhs = ck n.p), so C is stored per vertex: cn[nv][3] = ck n (0 when not hit), cc[nv] = ck n.p.
+// A dynamic hit (TetMeshCollision, dyn_collide.hpp) is also ONE row per vertex (ConstraintSet.hpp:96-99 keeps at
+// most one row per vertex) that additionally touches the three vertices of the hit face: dface[nv][3] (-1 = none),
+// dbary[nv][3]; row = cn^T (x_v - sum_j bary_j x_face_j), rhs 0.
 // The inner A^-1 applications are the GPU PCG above.
 struct UzScal { double denom, alpha, beta, rr; int stop; int iters; int nhits; int pad_; };
 
+} // namespace admm_k
+#include "dyn_collide.hpp"   // dynamic rows (TetMeshCollision): a row may also touch the three vertices of a face
+namespace admm_k {
+
 // Collider::detect for every vertex against the passive objects; builds the per-vertex constraint rows
+// (mask != nullptr: only the vertices of Solver::surface_inds are candidates, Collider.hpp:157,163)
 __global__ __launch_bounds__(256) void k_uz_detect(int nv, const double *__restrict__ x, Obstacles ob, double ck,
-                                                   double *__restrict__ cn, double *__restrict__ cc, int *__restrict__ nhits) {
+                                                   double *__restrict__ cn, double *__restrict__ cc, int *__restrict__ nhits,
+                                                   const unsigned char *__restrict__ mask) {
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= nv) return;
     const double xv[3] = {x[3 * (size_t)v], x[3 * (size_t)v + 1], x[3 * (size_t)v + 2]};
@@ -1143,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_uz_detect(int nv, const double *__restr
             }
         }
     }
-    const bool hit = best < 0.0;
+    const bool hit = best < 0.0 && (mask == nullptr || mask[v]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) cn[3 * (size_t)v + c] = hit ? ck * n[c] : 0.0;
     cc[v] = hit ? ck * dot3(n, p) : 0.0;
@@ -1165,23 +1174,25 @@ __global__ __launch_bounds__(256) void k_uz_ct(int nv, int mode, const double *_
 
 // r = C x - c ; d = r ; also clears y when the number of hits changed (UzawaCG.hpp:74)
 __global__ __launch_bounds__(256) void k_uz_resid(int nv, const double *__restrict__ x, const double *__restrict__ cn,
-                                                  const double *__restrict__ cc, double *__restrict__ r, double *__restrict__ d) {
+                                                  const double *__restrict__ cc, double *__restrict__ r, double *__restrict__ d,
+                                                  const int *__restrict__ dface, const double *__restrict__ dbary) {
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= nv) return;
     const double rv = cn[3 * (size_t)v] * x[3 * (size_t)v] + cn[3 * (size_t)v + 1] * x[3 * (size_t)v + 1] +
-                      cn[3 * (size_t)v + 2] * x[3 * (size_t)v + 2] - cc[v];
+                      cn[3 * (size_t)v + 2] * x[3 * (size_t)v + 2] - cc[v] + dyn_row_faces(v, cn, dface, dbary, x);
     r[v] = rv; d[v] = rv;
 }
 
 // q3 = C q2 ; partial sums of d.q3 and d.r
 __global__ __launch_bounds__(256) void k_uz_dots(int nv, const double *__restrict__ q2, const double *__restrict__ cn,
                                                  const double *__restrict__ d, const double *__restrict__ r,
-                                                 double *__restrict__ q3, double *__restrict__ part, int NBp) {
+                                                 double *__restrict__ q3, double *__restrict__ part, int NBp,
+                                                 const int *__restrict__ dface, const double *__restrict__ dbary) {
     __shared__ double lds[8];
     double q[2] = {0.0, 0.0};
     for (int v = blockIdx.x * 256 + threadIdx.x; v < nv; v += gridDim.x * 256) {
         const double t = cn[3 * (size_t)v] * q2[3 * (size_t)v] + cn[3 * (size_t)v + 1] * q2[3 * (size_t)v + 1] +
-                         cn[3 * (size_t)v + 2] * q2[3 * (size_t)v + 2];
+                         cn[3 * (size_t)v + 2] * q2[3 * (size_t)v + 2] + dyn_row_faces(v, cn, dface, dbary, q2);
         q3[v] = t;
         q[0] = fma(d[v], t, q[0]);
         q[1] = fma(d[v], r[v], q[1]);

@@ -68,6 +68,25 @@ def tet_volumes(verts, tets):
     return np.einsum("ij,ij->i", np.cross(v1 - v0, v2 - v0), v3 - v0) / 6.0
 
 
+def surface_faces(tets):
+    """Triangles that belong to exactly one tet, outward for positively oriented tets (mcl::TetMesh::need_faces,
+    used by TetMeshCollision, src/DynamicObject.hpp:48-57).  Returns [nf,3] int32, sorted by their vertex triple."""
+    tets = np.asarray(tets, dtype=np.int64).reshape(-1, 4)
+    loc = np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]])
+    tri = tets[:, loc].reshape(-1, 3)
+    key = np.sort(tri, axis=1)
+    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    keep = cnt[inv.ravel()] == 1
+    out = tri[keep]
+    order = np.lexsort(np.sort(out, axis=1).T[::-1])
+    return out[order].astype(np.int32)
+
+
+def surface_inds(tets):
+    """Vertices on the surface (mcl::TetMesh::surface_inds, samples/utils/AddMeshes.hpp:131-137)."""
+    return np.unique(surface_faces(tets)).astype(np.int32)
+
+
 def lumped_masses_tets(verts, tets, density=1522.0):
     """rho * vol / 4 to every corner (AddMeshes.hpp:113-122 uses density 1522 for tets). Returns [nv]."""
     vol = tet_volumes(verts, tets)

@@ -98,6 +98,20 @@ class Sphere:
         self.kind, self.params = 1, [float(center[0]), float(center[1]), float(center[2]), float(radius)]
 
 
+class TetMeshCollision:
+    """admm::TetMeshCollision (src/DynamicObject.hpp:31-121): self-collision proxy of one tet mesh.  verts = REST
+    vertices of the mesh, tets / faces index them (faces = surface triangles; meshes.surface_faces), v_offset = index
+    of the mesh's first vertex in the solver's node vector."""
+
+    def __init__(self, verts, tets, faces, v_offset):
+        self.rest = f64(verts).reshape(-1, 3).copy()
+        self.tets = i32(tets, (-1, 4)).copy()
+        self.faces = i32(faces, (-1, 3)).copy()
+        self.vert_offset = int(v_offset)
+        if self.faces.shape[0] == 0:
+            raise AdmmHipError(-1, "**TetMeshCollision Error: TetMesh needs surface faces")
+
+
 class Solver:
     """admm::Solver (src/Solver.hpp:32-124) on the MI355X hot path."""
 
@@ -109,6 +123,8 @@ class Solver:
         self._tris = []   # (idx[n,3], rest[n,4], weight[n], lmin[n], lmax[n])
         self._pins = {}   # vertex -> xyz   (ConstraintSet::pins)
         self._obstacles = []
+        self._dynamic = []      # TetMeshCollision objects (Collider::dynamic_objs)
+        self.surface_inds = []  # Solver::surface_inds (src/Solver.hpp:70): empty = every vertex is tested
         self._ctx = None
         self._settings = Settings()
         self._runtime = RuntimeData()
@@ -179,6 +195,22 @@ class Solver:
     def add_obstacle(self, obj):
         """Solver::add_obstacle (src/Solver.cpp:159-161)."""
         self._obstacles.append(obj)
+
+    def add_dynamic_collider(self, obj):
+        """Solver::add_dynamic_collider (src/Solver.cpp:163-165)."""
+        self._dynamic.append(obj)
+
+    def detect_dynamic(self, x=None):
+        """Collider::detect for the dynamic objects at x (default m_x): list of (vert, dx, face[3], barys[3], normal[3])
+        = DynamicCollision::Payload, in candidate order."""
+        self._need_ctx()
+        x = f64(self.m_x if x is None else x).ravel().copy()
+        nv = x.size // 3
+        n = C.c_int32(0)
+        vert = np.zeros(nv, np.int32); face = np.zeros((nv, 3), np.int32)
+        bary = np.zeros((nv, 3)); nrm = np.zeros((nv, 3)); dx = np.zeros(nv)
+        check(lib().admm_hip_detect_dynamic(self._ctx, dptr(x), nv, C.byref(n), iptr(vert), iptr(face), dptr(bary), dptr(nrm), dptr(dx)))
+        return [(int(vert[i]), dx[i], face[i].copy(), bary[i].copy(), nrm[i].copy()) for i in range(n.value)]
 
     def set_gs_colors(self, colors):
         self._gs_colors = i32(colors)
@@ -255,6 +287,12 @@ class Solver:
         ctx = C.c_void_p()
         check(lib().admm_hip_create(C.byref(d), C.byref(ctx)))
         self._ctx = ctx
+        if len(self.surface_inds):
+            si = i32(self.surface_inds)
+            check(lib().admm_hip_set_surface_inds(ctx, len(si), iptr(si)))
+        for o in self._dynamic:   # Solver.cpp:249-254 (LDLT: "No collisions with LDLT solver") is checked by the library
+            check(lib().admm_hip_add_dynamic_tetmesh(ctx, o.vert_offset, o.rest.shape[0], dptr(o.rest), o.tets.shape[0],
+                                                     iptr(o.tets), o.faces.shape[0], iptr(o.faces)))
         self.initialized = True
         return True
 

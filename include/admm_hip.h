@@ -149,6 +149,29 @@ int admm_hip_get_state(admm_hip_ctx *ctx, double *x, double *v);
  * at Solver.cpp:147-151); all other pins become inactive.  linsolver 1: the set is replaced freely. */
 int admm_hip_set_pins(admm_hip_ctx *ctx, int32_t n, const int32_t *vert, const double *xyz);
 
+/* Solver::surface_inds (src/Solver.hpp:70; filled by binding::add_tetmesh, samples/utils/AddMeshes.hpp:131-137): the
+ * vertices Collider::detect tests (src/Collider.hpp:157,163).  n = 0 -> every vertex (the reference's rule for an
+ * empty list).  Applies to passive detection of the UzawaCG path and to dynamic detection. */
+int admm_hip_set_surface_inds(admm_hip_ctx *ctx, int32_t n, const int32_t *inds);
+
+/* Solver::add_dynamic_collider(std::make_shared<TetMeshCollision>(mesh, vert_offset)) -- src/Solver.cpp:163-165,
+ * src/DynamicObject.hpp:45-64.  rest_verts [3*n_verts], tets [4*n_tets] and faces [3*n_faces] (the surface
+ * triangles, outward) index the mesh's OWN vertices; node id = local id + vert_offset.  At every ADMM iteration
+ * Collider::detect (src/Collider.hpp:166-168,192-201) refits the tet tree and runs TetMeshCollision::signed_distance
+ * (src/DynamicObject.hpp:72-119) for every candidate vertex; hits become the dynamic rows of
+ * ConstraintSet::make_matrix (src/ConstraintSet.hpp:92-110).  linsolver 2 only: 0 fails with the reference's
+ * "No collisions with LDLT solver" (src/Solver.cpp:249-254), 1 (A + C^T C re-coloured at every solve,
+ * src/NodalMultiColorGS.hpp:80-86) is not implemented and says so.  Call after admm_hip_create, in
+ * add_dynamic_collider order. */
+int admm_hip_add_dynamic_tetmesh(admm_hip_ctx *ctx, int32_t vert_offset, int32_t n_verts, const double *rest_verts,
+                                 int32_t n_tets, const int32_t *tets, int32_t n_faces, const int32_t *faces);
+
+/* Kernel-level entry point (parity tests): Collider::detect of the dynamic objects at x [3*n_verts] (host).
+ * Up to cap hits are written in candidate order: vert[h], face[3h] (node ids), barys[3h], normal[3h], dx[h]
+ * = DynamicCollision::Payload (src/Collider.hpp:40-53); *n_hits = number found (may exceed cap). */
+int admm_hip_detect_dynamic(admm_hip_ctx *ctx, const double *x, int32_t cap, int32_t *n_hits, int32_t *vert, int32_t *face,
+                            double *barys, double *normal, double *dx);
+
 /* Solver::step (src/Solver.cpp:35-110) on the device-resident state: gravity, x_bar, admm_iters x
  * {local step, collision detection, RHS, global solve}, velocity update.  No host<->device traffic
  * besides the launch stream; stats may be NULL. */

@@ -23,6 +23,9 @@
  *   - NodalMultiColorGS: sweeps restated; the colouring library (mclscene) is ABSENT =>
  *     "parity unpinned" for the colour order; colours are an input here.
  *
+ *   - TetMeshCollision (dynamic self-collision): the BVH traversals are mclscene's (ABSENT) => "parity
+ *     unpinned"; restated by brute force with index tie rules (see orc_detect_dynamic).
+ *
  * Layout conventions: 3x3 matrices are column-major (Eigen default), index c*3+r.
  */
 #include <math.h>
@@ -639,4 +642,110 @@ int orc_gs_solve(int nv, const int32_t *rp, const int32_t *ci, const double *val
         }
     }
     return iter;
+}
+
+/* ---- dynamic (self-)collision: TetMeshCollision ------------------------------------------------------------
+ * src/DynamicObject.hpp:31-121 (signed_distance), src/Collider.hpp:152-212 (detect: dynamic objects in order,
+ * "only resolve one dynamic collision at a time" = the first object with dx<0 keeps the payload).
+ * The AABB trees and the point-in-tet / nearest-triangle traversals are mclscene's (mcl::bvh, ABSENT
+ * un-vendored submodule) => PARITY UNPINNED at that boundary.  What the reference's own code fixes and this
+ * restates: the query skips primitives that contain the query vertex (:78,:100); inside a tet -> barycentric
+ * coordinates of the point in the CURRENT tet (:85-91) -> the same combination of the REST vertices (:92-97)
+ * -> nearest REST surface triangle (:99-104) -> dx = -|proj - restx|, face, barycentrics of proj in the rest
+ * triangle, normal of the REST triangle (:105-116).  Where the absent traversal order would decide, this
+ * restatement decides by index: lowest tet index among the containing tets, lowest face index among equally
+ * near triangles.  Arithmetic is FP64 throughout (the reference keeps the rest mesh in float).
+ * Closest point on a triangle: Ericson, Real-Time Collision Detection, 5.1.5 (Voronoi regions).          */
+static int tet_barycentric(const double *x, const double *p0, const double *p1, const double *p2, const double *p3, double *b) {
+    double E[9], r[3], cf[3];
+    for (int c = 0; c < 3; ++c) { E[c] = p1[c] - p0[c]; E[3 + c] = p2[c] - p0[c]; E[6 + c] = p3[c] - p0[c]; r[c] = x[c] - p0[c]; }
+    double det = det3(E);
+    if (det == 0.0 || !(det == det)) return 0;
+    cross3(E + 3, E + 6, cf); b[1] = (r[0] * cf[0] + r[1] * cf[1] + r[2] * cf[2]) / det;
+    cross3(E + 6, E, cf);     b[2] = (r[0] * cf[0] + r[1] * cf[1] + r[2] * cf[2]) / det;
+    cross3(E, E + 3, cf);     b[3] = (r[0] * cf[0] + r[1] * cf[1] + r[2] * cf[2]) / det;
+    b[0] = 1.0 - b[1] - b[2] - b[3];
+    return 1;
+}
+
+static double dot3v(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+/* returns |p - proj|^2; bc = barycentrics of proj w.r.t. (a,b,c) */
+static double closest_on_triangle(const double *p, const double *a, const double *b, const double *c, double *proj, double *bc) {
+    double ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; bp[i] = p[i] - b[i]; cp[i] = p[i] - c[i]; }
+    double d1 = dot3v(ab, ap), d2 = dot3v(ac, ap), d3 = dot3v(ab, bp), d4 = dot3v(ac, bp), d5 = dot3v(ab, cp), d6 = dot3v(ac, cp);
+    double u, v, w;
+    double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d1 <= 0.0 && d2 <= 0.0) { u = 1; v = 0; w = 0; }                                  /* vertex a */
+    else if (d3 >= 0.0 && d4 <= d3) { u = 0; v = 1; w = 0; }                              /* vertex b */
+    else if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) { v = d1 / (d1 - d3); u = 1 - v; w = 0; } /* edge ab */
+    else if (d6 >= 0.0 && d5 <= d6) { u = 0; v = 0; w = 1; }                              /* vertex c */
+    else if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { w = d2 / (d2 - d6); u = 1 - w; v = 0; } /* edge ac */
+    else if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) { w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); v = 1 - w; u = 0; } /* edge bc */
+    else { double den = 1.0 / (va + vb + vc); v = vb * den; w = vc * den; u = 1.0 - v - w; } /* face */
+    double d = 0.0;
+    for (int i = 0; i < 3; ++i) { proj[i] = u * a[i] + v * b[i] + w * c[i]; d += (p[i] - proj[i]) * (p[i] - proj[i]); }
+    bc[0] = u; bc[1] = v; bc[2] = w;
+    return d;
+}
+
+/* One TetMeshCollision against nq query vertices (query == NULL: vertices 0..nq-1) at positions x (global node
+ * vector).  tets / faces index the mesh's own vertices (0..n_mesh_verts-1), rest = its rest vertices; global id =
+ * local + vert_offset.  hit[q] != 0 on entry = an earlier object already holds the payload (skipped, :73).
+ * Outputs per query (written only for new hits): face (global ids), barys, normal, dx (<0).               */
+void orc_detect_dynamic(int nq, const int32_t *query, const double *x, int vert_offset, const double *rest,
+                        int ntets, const int32_t *tets, int nfaces, const int32_t *faces,
+                        int32_t *hit, int32_t *face_out, double *bary_out, double *normal_out, double *dx_out) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int q = 0; q < nq; ++q) {
+        if (hit[q]) continue;
+        const int vg = query ? query[q] : q, vl = vg - vert_offset;
+        const double *px = x + 3 * (size_t)vg;
+        int found = -1; double fb[4] = {0, 0, 0, 0};
+        for (int t = 0; t < ntets && found < 0; ++t) {
+            const int32_t *tt = tets + 4 * (size_t)t;
+            if (tt[0] == vl || tt[1] == vl || tt[2] == vl || tt[3] == vl) continue;          /* skip_vert_idx :78 */
+            const double *p0 = x + 3 * (size_t)(tt[0] + vert_offset), *p1 = x + 3 * (size_t)(tt[1] + vert_offset);
+            const double *p2 = x + 3 * (size_t)(tt[2] + vert_offset), *p3 = x + 3 * (size_t)(tt[3] + vert_offset);
+            /* cheap reject: bounding box */
+            int out = 0;
+            for (int c = 0; c < 3 && !out; ++c) {
+                double lo = fmin(fmin(p0[c], p1[c]), fmin(p2[c], p3[c])), hi = fmax(fmax(p0[c], p1[c]), fmax(p2[c], p3[c]));
+                out = (px[c] < lo) || (px[c] > hi);
+            }
+            if (out) continue;
+            double b[4];
+            if (!tet_barycentric(px, p0, p1, p2, p3, b)) continue;
+            if (b[0] >= 0.0 && b[1] >= 0.0 && b[2] >= 0.0 && b[3] >= 0.0) { found = t; memcpy(fb, b, sizeof fb); }
+        }
+        if (found < 0) continue;
+        const int32_t *tt = tets + 4 * (size_t)found;
+        double restx[3] = {0, 0, 0};
+        for (int k = 0; k < 4; ++k) for (int c = 0; c < 3; ++c) restx[c] += fb[k] * rest[3 * (size_t)tt[k] + c];   /* :92-97 */
+        int best = -1; double bd = DBL_MAX, bproj[3] = {0, 0, 0}, bbc[3] = {0, 0, 0};
+        for (int f = 0; f < nfaces; ++f) {
+            const int32_t *ff = faces + 3 * (size_t)f;
+            if (ff[0] == vl || ff[1] == vl || ff[2] == vl) continue;                           /* :100 */
+            double proj[3], bc[3];
+            double d = closest_on_triangle(restx, rest + 3 * (size_t)ff[0], rest + 3 * (size_t)ff[1], rest + 3 * (size_t)ff[2], proj, bc);
+            if (d < bd) { bd = d; best = f; memcpy(bproj, proj, sizeof proj); memcpy(bbc, bc, sizeof bc); }
+        }
+        if (best < 0) continue;   /* the reference throws (:102-104); a mesh whose every face touches the vertex */
+        const int32_t *ff = faces + 3 * (size_t)best;
+        const double *a = rest + 3 * (size_t)ff[0], *b = rest + 3 * (size_t)ff[1], *c = rest + 3 * (size_t)ff[2];
+        double e1[3], e2[3], nrm[3];
+        for (int i = 0; i < 3; ++i) { e1[i] = b[i] - a[i]; e2[i] = c[i] - a[i]; }
+        cross3(e1, e2, nrm);
+        double l = norm3(nrm);
+        double dx = -sqrt(bd);                                                                   /* :112 */
+        if (!(dx < 0.0)) continue;                                                               /* Collider.hpp:203 */
+        hit[q] = 1; dx_out[q] = dx;
+        for (int i = 0; i < 3; ++i) {
+            face_out[3 * (size_t)q + i] = ff[i] + vert_offset;                                   /* :113 */
+            bary_out[3 * (size_t)q + i] = bbc[i];                                                /* :114 */
+            normal_out[3 * (size_t)q + i] = nrm[i] / l;                                          /* :110-111,:115 */
+        }
+        (void)bproj;
+    }
 }

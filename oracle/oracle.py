@@ -77,6 +77,7 @@ def lib():
         L.orc_gs_solve.argtypes = [C.c_int, ip, ip, dp, dp, dp, C.c_int, ip, ip, ip, dp, C.c_int, ip, dp,
                                    C.c_double, C.c_int, C.c_double]
         L.orc_gs_solve.restype = C.c_int
+        L.orc_detect_dynamic.argtypes = [C.c_int, ip, dp, C.c_int, dp, C.c_int, ip, C.c_int, ip, ip, ip, dp, dp, dp]
         _lib = L
     return _lib
 
@@ -179,9 +180,12 @@ class OracleSolver:
 
     def __init__(self, x, masses, dt=1.0 / 24.0, gravity=-9.8, admm_iters=10, linsolver=0, constraint_w=-1.0,
                  tets=None, tris=None, pins=None, obstacles=(), mode=1, gs_colors=None,
-                 gs_max_iters=30, gs_tol=1e-10, gs_omega=1.9, uzawa_max_iters=20, uzawa_tol=1e-10, big=False):
+                 gs_max_iters=30, gs_tol=1e-10, gs_omega=1.9, uzawa_max_iters=20, uzawa_tol=1e-10, big=False,
+                 dynamic=(), surface_inds=None):
         """tets = dict(idx[n,4], verts(rest), kind[n], mu[n], la[n]); tris = dict(idx[n,3], verts, mu, la,
         limit_min, limit_max); pins = {vertex: xyz}; obstacles = [(kind, [4 params])];
+        dynamic = [dict(offset, rest[n,3], tets[nt,4] local, faces[nf,3] local)] (TetMeshCollision, in
+        add_dynamic_collider order); surface_inds = Solver::surface_inds (None / empty = every vertex);
         masses [3*nv]; mode 0 = reference stop rule, 1 = tight minimiser."""
         self.x = np.ascontiguousarray(x, dtype=np.float64).ravel().copy()
         self.dof = self.x.size
@@ -193,6 +197,14 @@ class OracleSolver:
         self.uz_max_iters, self.uz_tol = uzawa_max_iters, uzawa_tol
         self.obstacles = list(obstacles)
         self.pins = dict(pins or {})
+        self.dynamic = [dict(offset=int(d["offset"]), rest=np.ascontiguousarray(d["rest"], dtype=np.float64).reshape(-1, 3),
+                             tets=np.ascontiguousarray(d["tets"], dtype=np.int32).reshape(-1, 4),
+                             faces=np.ascontiguousarray(d["faces"], dtype=np.int32).reshape(-1, 3)) for d in dynamic]
+        self.surface_inds = None if surface_inds is None or len(surface_inds) == 0 else \
+            np.ascontiguousarray(surface_inds, dtype=np.int32)
+        if self.dynamic and linsolver == 1:
+            raise NotImplementedError("oracle: dynamic colliders with NodalMultiColorGS (A + C^T C, re-colouring) not restated")
+        self._dhits = []
         if self.obstacles and linsolver == 0:
             raise RuntimeError("**Solver::add_obstacle Error: No collisions with LDLT solver")
         self.inner_iters = 0
@@ -325,18 +337,52 @@ class OracleSolver:
             best = np.where(upd, dx, best)
             point[upd] = p[upd]; normal[upd] = n[upd]
         hit = np.nonzero(best < 0)[0]
+        if self.surface_inds is not None:                        # Collider.hpp:157,163: only the listed vertices
+            hit = np.array([i for i in self.surface_inds if best[i] < 0], dtype=int)
         return [(int(i), best[i], point[i].copy(), normal[i].copy()) for i in hit]
 
-    # -- ConstraintSet::make_matrix (ConstraintSet.hpp:59-116), passive hits only
-    def make_matrix(self, hits):
+    # -- Collider::detect with dynamic objects (Collider.hpp:192-201, DynamicObject.hpp:72-119); hits in query order
+    def detect_dynamic(self, x):
+        if not self.dynamic:
+            return []
+        L = lib()
+        q = self.surface_inds if self.surface_inds is not None else np.arange(self.nv, dtype=np.int32)
+        nq = len(q)
+        hit = np.zeros(nq, dtype=np.int32); face = np.full((nq, 3), -1, dtype=np.int32)
+        bary = np.zeros((nq, 3)); nrm = np.zeros((nq, 3)); dx = np.zeros(nq)
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        for d in self.dynamic:
+            L.orc_detect_dynamic(nq, _i(q), _p(xx), d["offset"], _p(d["rest"]), len(d["tets"]), _i(d["tets"]),
+                                 len(d["faces"]), _i(d["faces"]), _i(hit), _i(face), _p(bary), _p(nrm), _p(dx))
+        return [(int(q[i]), dx[i], face[i].copy(), bary[i].copy(), nrm[i].copy()) for i in np.nonzero(hit)[0]]
+
+    # -- ConstraintSet::make_matrix (ConstraintSet.hpp:59-116): passive rows, then dynamic rows; a vertex that already
+    #    holds a row keeps it and the later hit's row stays empty (`constrained`, :79-82,:96-99)
+    def make_matrix(self, hits, dhits=()):
         ck = np.sqrt(max(0.0, self.constraint_w))
         rows, cols, vals = [], [], []
-        c = np.zeros(len(hits))
+        c = np.zeros(len(hits) + len(dhits))
+        constrained = {}
         for i, (vi, dx, p, n) in enumerate(hits):
+            if constrained.get(vi, 0.0):
+                continue
+            if dx < 0.0:
+                constrained[vi] = dx
             c[i] = ck * n.dot(p)
             for j in range(3):
                 rows.append(i); cols.append(3 * vi + j); vals.append(ck * n[j])
-        Cm = sp.csr_matrix((vals, (rows, cols)), shape=(len(hits), self.dof))
+        for i, (vi, dx, face, bary, n) in enumerate(dhits):
+            if constrained.get(vi, 0.0):
+                continue
+            if dx < 0.0:
+                constrained[vi] = dx
+            ci = i + len(hits)
+            for j in range(3):
+                rows.append(ci); cols.append(3 * vi + j); vals.append(ck * n[j])
+            for k in range(3):
+                for j in range(3):
+                    rows.append(ci); cols.append(3 * int(face[k]) + j); vals.append(-ck * n[j] * bary[k])
+        Cm = sp.csr_matrix((vals, (rows, cols)), shape=(len(c), self.dof))
         return Cm, c
 
     # -- global solvers
@@ -345,7 +391,7 @@ class OracleSolver:
 
     def solve_uzawa(self, x, b, hits):
         """UzawaCG::solve (UzawaCG.hpp:57-125); returns (x, iters)."""
-        Cm, c = self.make_matrix(hits)
+        Cm, c = self.make_matrix(hits, self._dhits)
         if self.y.shape[0] != Cm.shape[0]:
             self.y = np.zeros(Cm.shape[0])
         if Cm.nnz == 0:
@@ -420,6 +466,7 @@ class OracleSolver:
         for _ in range(self.admm_iters):
             self.local_step(curr, z, u)                           # :84-87
             self._hits = self.detect_passive(curr) if self.linsolver != 1 else []   # :92-93
+            self._dhits = self.detect_dynamic(curr)
             b = self.rhs(Mxbar, z, u)                             # :98
             curr, it = self.global_solve(curr, b)                 # :99
             self.inner_iters += it

@@ -4,7 +4,7 @@ import numpy as np
 
 import admm_elastic_amd as pkg
 from admm_elastic_amd import meshes
-from admm_elastic_amd.solver import Floor, Lame, Settings, Solver, Sphere
+from admm_elastic_amd.solver import Floor, Lame, Settings, Solver, Sphere, TetMeshCollision
 from oracle import oracle as orc
 
 
@@ -15,6 +15,8 @@ class Scene:
         self.tris = []   # (verts_rest, idx, lame)
         self.pins = {}
         self.obstacles = []  # (kind, params)
+        self.dynamic = []    # dict(offset, rest, tets, faces): TetMeshCollision per mesh
+        self.surface_inds = []
         self.settings = dict(timestep_s=1.0 / 24.0, admm_iters=10, gravity=-9.8, linsolver=0, constraint_w=-1.0)
 
     def add_tet_mesh(self, verts, tets, lame, kind, density=1522.0):
@@ -23,6 +25,12 @@ class Scene:
         self.m = np.concatenate([self.m, meshes.lumped_masses_tets(verts, tets, density)])
         self.tets.append((verts, tets, lame, kind, off))
         return off
+
+    def add_self_collision(self, verts, tets, off):
+        """binding::add_tetmesh without NOSELFCOLLISION (samples/utils/AddMeshes.hpp:124-138)."""
+        faces = meshes.surface_faces(tets)
+        self.dynamic.append(dict(offset=off, rest=np.array(verts, dtype=np.float64), tets=np.asarray(tets, np.int32), faces=faces))
+        self.surface_inds.extend(int(i) + off for i in np.unique(faces))
 
     def add_tri_mesh(self, verts, tris, lame, density=1.0):
         off = self.x.shape[0]
@@ -46,6 +54,9 @@ class Scene:
             s.set_pins(list(self.pins.keys()), [self.pins[k] for k in self.pins])
         for kind, par in self.obstacles:
             s.add_obstacle(Floor(par[0]) if kind == 0 else Sphere(par[:3], par[3]))
+        for d in self.dynamic:
+            s.add_dynamic_collider(TetMeshCollision(d["rest"], d["tets"], d["faces"], d["offset"]))
+        s.surface_inds = list(self.surface_inds)
         st = Settings(**self.settings)
         for k, v in gpu_kw.items():
             setattr(st, k, v)
@@ -76,7 +87,7 @@ class Scene:
         return orc.OracleSolver(self.x, self.masses3(), dt=st["timestep_s"], gravity=st["gravity"],
                                 admm_iters=st["admm_iters"], linsolver=st["linsolver"], constraint_w=st["constraint_w"],
                                 tets=tets, tris=tris, pins=self.pins, obstacles=self.obstacles, mode=mode,
-                                gs_colors=gs_colors, big=big, **kw)
+                                gs_colors=gs_colors, big=big, dynamic=self.dynamic, surface_inds=self.surface_inds, **kw)
 
 
 def cube_scene(n, kind, lame=None, pin_face=True, size=1.0, **settings):
@@ -121,6 +132,26 @@ def cloth_scene(m, limits=(0.95, 1.05), floor=None, **settings):
         sc.pins[int(i)] = verts[i].copy()
     if floor is not None:
         sc.obstacles.append((0, [floor, 0.0, 0.0, 0.0]))
+    sc.settings.update(settings)
+    return sc
+
+
+def two_blocks_scene(n=3, overlap=0.2, floor=-0.4, kind=None, jitter=0.02, **settings):
+    """Two n-cell cubes with self-collision proxies, the upper one pushed `overlap` into the lower one (so the very
+    first detect finds dynamic hits) and shifted sideways; optional floor under the lower one.  UzawaCG (the
+    reference's torus.cpp set-up: dynamic mesh + Floor, linsolver 2).  Rest vertices are jittered so that no query
+    point is equidistant from two surface triangles (the index tie rules would otherwise be decided by round-off)."""
+    sc = Scene()
+    rng = np.random.default_rng(5)
+    lame = Lame(1.0e6, 0.3)
+    for b, shift in enumerate(((0.0, 0.0, 0.0), (0.13, 1.0 - overlap, 0.07))):
+        verts, tets = meshes.kuhn_cube(n)
+        verts = verts + (jitter / n) * rng.uniform(-1.0, 1.0, verts.shape) + np.asarray(shift)
+        off = sc.add_tet_mesh(verts, tets, lame, pkg.TET_LINEAR if kind is None else kind)
+        sc.add_self_collision(verts, tets, off)
+    if floor is not None:
+        sc.obstacles.append((0, [floor, 0.0, 0.0, 0.0]))
+    sc.settings.update(linsolver=2, admm_iters=5)
     sc.settings.update(settings)
     return sc
 
