@@ -546,19 +546,113 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
         gather_and_reduce(ru, rw, true, true);
         if (tid == 0) {
+            // The three axes are independent systems with their own b . M^-1 b.  An axis whose right-hand side vanishes
+            // (C^T d of a floor contact has no x / z part) or is > 15 orders below the largest one is measured against
+            // the largest one: its own norm cannot scale a stop test.  b = 0 altogether: the solution is x = 0.
+            const double gmax = fmax(bc[3], fmax(bc[4], bc[5]));
             bool c0 = true;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { gbl[j] = bc[3 + j]; ctl[8 + j] = 1.0 / (bc[3 + j] + 1e-300); glast[j] = bc[j]; c0 = c0 && (bc[j] <= a.tol2 * bc[3 + j] + 1e-300); }
-            ctl[0] = 1e300; ctl[1] = 0.0; ictl[0] = 0; ictl[1] = 0; ictl[2] = c0 ? 1 : 0;
+            for (int j = 0; j < 3; ++j) {
+                gbl[j] = fmax(bc[3 + j], 1e-30 * gmax);
+                ctl[8 + j] = gmax > 0.0 ? 1.0 / gbl[j] : 0.0;
+                glast[j] = bc[j];
+                c0 = c0 && (bc[j] <= a.tol2 * gbl[j] + 1e-300);
+            }
+            ctl[0] = 1e300; ctl[1] = 0.0; ictl[0] = 0; ictl[1] = 0; ictl[2] = !(gmax > 0.0) ? 3 : c0 ? 1 : 0;
         }
-        if (action() == 1) { conv = true; break; }
-        bool fresh = true, pipelined = true;
+        {
+            const int act0 = action();
+            if (act0 == 3) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { rx[j] = 0.0; ru[j] = 0.0; }
+                conv = true; break;
+            }
+            if (act0 == 1) { conv = true; break; }
+        }
+        bool fresh = true;
+        int restarts = 0;
         if (prof) a.prof[63 * 8 + 2] = wall_clock64();
-        // ---- CG iterations: pipelined (one barrier) while trusted, Chronopoulos-Gear (two barriers) after ----
+        // Decision on the sums of this iteration, taken by lanes 0..2 of wave 0 (one axis each) and broadcast through LDS.
+        // Returns the action: 0 update, 1 verify on the true residual, 2 non-finite / runaway sums; +4: leave the
+        // pipelined form after the update.  Side effects: alpha / beta of this iteration in ctl[2..7].
+        auto decide = [&](const bool pipelined) -> int {
+            if (wv == 0) {
+                const int j = lane < 3 ? lane : 0;
+                const double g = bc[j], d = bc[3 + j], gbj = gbl[j];
+                const double ratio = g * ctl[8 + j];                       // gamma / (b . M^-1 b)
+                const unsigned long long m3 = 7ull;
+                // finite, and not 1e8x (in norm) above the best residual seen: CG's residual norm is not monotone, but
+                // growth of that size is a recurrence that has lost the iterate
+                const bool finite = (__ballot(g < 1e290 && ratio < 1e290 && !(ratio > 1e16 * ctl[0])) & m3) == m3;
+                const bool below_trig = (__ballot(g <= kOcTrig * a.tol2 * gbj + 1e-300) & m3) == m3;
+                const bool below_tol = (__ballot(g <= a.tol2 * gbj + 1e-300) & m3) == m3;
+                const bool below_floor = (__ballot(g <= kOcPipeFloor * gbj + 1e-300) & m3) == m3;
+                double rmax = fmax(ratio, __shfl(ratio, 1, 64));
+                rmax = fmax(rmax, __shfl(ratio, 2, 64));                   // valid in lane 0
+                int act = 0;
+                if (!finite) act = 2;
+                else if (pipelined ? (below_trig && kOcTrig * a.tol2 >= kOcPipeFloor) : below_tol) act = 1;
+                else {
+                    int since = 0;
+                    if (lane == 0) {
+                        since = ictl[0] + 1;
+                        if (rmax < ctl[0]) { ctl[0] = rmax; since = 0; }
+                        ictl[0] = since;
+                    }
+                    since = __shfl(since, 0, 64);
+                    const double best = __shfl(ctl[0], 0, 64);
+                    if (pipelined && (below_floor || since >= (best <= 100.0 * kOcPipeFloor ? kOcStagnation : 4 * kOcStagnation))) act = 4;
+                    if (lane < 3) {
+                        double alpha = 0.0, beta;
+                        if (fresh) { beta = 0.0; if (pipelined) alpha = (d > 0.0) ? g * fast_rcp(d) : 0.0; }
+                        else {
+                            const double gp = sc[j];
+                            beta = (gp > 0.0) ? g * fast_rcp(gp) : 0.0;
+                            if (pipelined) {
+                                const double ap = sc[3 + j];
+                                const double den = (ap != 0.0) ? d - beta * g * fast_rcp(ap) : d;
+                                alpha = (den > 0.0) ? g * fast_rcp(den) : 0.0;
+                            }
+                        }
+                        sc[j] = g; sc[3 + j] = alpha; glast[j] = g;
+                        ctl[2 + j] = alpha; ctl[5 + j] = beta;
+                    }
+                }
+                if (lane == 0) ictl[2] = act;
+            }
+            return action();
+        };
+        // TRUE residual at the current x (into u).  1: it meets the tolerance, or the FP64 floor is reached (a failed
+        // verification that did not improve on the previous one by 4x); 0: it does not -- CG restarts from it; -1: aborted
+        auto verify = [&]() -> int {
+            double q[6];
+            if (!true_residual(false, false, q)) return -1;
+            ++ph;
+            oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) return -1;
+            gather_and_reduce(nullptr, nullptr, false, true);
+            if (tid == 0) {
+                bool ok = true;
+                double tr = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    glast[j] = bc[j];
+                    ok = ok && (bc[j] <= a.tol2 * gbl[j] + 1e-300);
+                    tr = fmax(tr, bc[j] * ctl[8 + j]);
+                }
+                const bool done = ok || (ictl[1] >= 1 && !(tr <= 0.25 * ctl[1]));
+                ctl[1] = tr; ictl[1] += 1;
+                ctl[0] = tr; ictl[0] = 0;     // the runaway test measures against the TRUE residual from here on
+                ictl[2] = done ? 1 : 0;
+            }
+            return action() == 1 ? 1 : 0;
+        };
+        // ---- pipelined CG (Ghysels-Vanroose): one synchronisation per iteration, while its recurrences are trusted ----
+        bool entry_restart = false, go_classic = false;
         while (iters < a.max_iters) {
             OC_STAMP(0);
             double rn[3] = {0.0, 0.0, 0.0};
-            if (pipelined) {
+            {
                 double mm[3], q[6];
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
@@ -583,91 +677,16 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                     OC_STAMP(2);
                     gather_and_reduce(mm, rn, true, true);        // n = A M^-1 w, and the sums
                 }
-            } else {
-                double q[6];
-                ++ph; publish(ru);
-                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
-                gather_and_reduce(ru, rw, true, false);           // w = A u, recomputed
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    q[j] = (live ? ru[j] * ru[j] * fast_rcp(rd[j]) : 0.0);
-                    q[3 + j] = rw[j] * ru[j];
-                }
-                ++ph;
-                oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
-                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
-                gather_and_reduce(nullptr, nullptr, false, true);
             }
             OC_STAMP(3);
-            if (wv == 0) {   // lanes 0..2 = one axis each.  action: 0 update, 1 verify on the true residual, 2 non-finite sums; +4: leave the pipelined form after the update
-                const int j = lane < 3 ? lane : 0;
-                const double g = bc[j], d = bc[3 + j], gbj = gbl[j];
-                const double ratio = g * ctl[8 + j];                       // gamma / (b . M^-1 b)
-                const unsigned long long m3 = 7ull;
-                const bool finite = (__ballot(ratio < 1e300) & m3) == m3;
-                const bool below_trig = (__ballot(g <= kOcTrig * a.tol2 * gbj + 1e-300) & m3) == m3;
-                const bool below_tol = (__ballot(g <= a.tol2 * gbj + 1e-300) & m3) == m3;
-                const bool below_floor = (__ballot(g <= kOcPipeFloor * gbj + 1e-300) & m3) == m3;
-                double rmax = fmax(ratio, __shfl(ratio, 1, 64));
-                rmax = fmax(rmax, __shfl(ratio, 2, 64));                   // valid in lane 0
-                int act = 0;
-                if (!finite) act = 2;
-                else if (pipelined ? (below_trig && kOcTrig * a.tol2 >= kOcPipeFloor) : below_tol) act = 1;
-                else {
-                    if (pipelined) {
-                        int since = 0;
-                        if (lane == 0) {
-                            since = ictl[0] + 1;
-                            if (rmax < ctl[0]) { ctl[0] = rmax; since = 0; }
-                            ictl[0] = since;
-                        }
-                        since = __shfl(since, 0, 64);
-                        const double best = __shfl(ctl[0], 0, 64);
-                        if (below_floor || since >= (best <= 100.0 * kOcPipeFloor ? kOcStagnation : 4 * kOcStagnation)) act = 4;
-                    }
-                    if (lane < 3) {
-                        double alpha, beta;
-                        if (fresh) { beta = 0.0; alpha = (d > 0.0) ? g * fast_rcp(d) : 0.0; }
-                        else {
-                            const double gp = sc[j], ap = sc[3 + j];
-                            beta = (gp > 0.0) ? g * fast_rcp(gp) : 0.0;
-                            const double den = (ap != 0.0) ? d - beta * g * fast_rcp(ap) : d;
-                            alpha = (den > 0.0) ? g * fast_rcp(den) : 0.0;
-                        }
-                        sc[j] = g; sc[3 + j] = alpha; glast[j] = g;
-                        ctl[2 + j] = alpha; ctl[5 + j] = beta;
-                    }
-                }
-                if (lane == 0) ictl[2] = act;
-            }
-            const int act = action();
-            if (act == 2) break;                                  // non-finite sums: give up, reported as unconverged
+            const int act = decide(true);
+            if (act == 2) { entry_restart = true; go_classic = true; break; }
             if (act == 1) {
-                // TRUE residual at the current x; if it fails the test it replaces the recursive one and CG
-                // restarts from it (beta = 0) in the Chronopoulos-Gear form.
-                double q[6];
-                if (!true_residual(false, false, q)) { aborted = true; break; }
-                ++ph;
-                oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
-                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
-                gather_and_reduce(nullptr, nullptr, false, true);
-                if (tid == 0) {
-                    bool ok = true;
-                    double tr = 0.0;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        glast[j] = bc[j];
-                        ok = ok && (bc[j] <= a.tol2 * gbl[j] + 1e-300);
-                        tr = fmax(tr, bc[j] / (gbl[j] + 1e-300));
-                    }
-                    // a failed verification that did not improve on the previous one by 4x: FP64 floor reached
-                    const bool done = ok || (ictl[1] >= 1 && !(tr <= 0.25 * ctl[1]));
-                    ctl[1] = tr; ictl[1] += 1;
-                    ictl[2] = done ? 1 : 0;
-                }
-                if (action() == 1) { conv = true; break; }
-                pipelined = false; fresh = true;
-                continue;
+                const int v = verify();
+                if (v < 0) { aborted = true; break; }
+                if (v == 1) { conv = true; break; }
+                go_classic = true; fresh = true;     // the true residual replaces the recursive one: restart (beta = 0)
+                break;
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -676,15 +695,68 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 rp[j] = fma(beta, rp[j], ru[j]);
                 rx[j] = fma(alpha, rp[j], rx[j]);
                 ru[j] = fma(-alpha * rd[j], rsv[j], ru[j]);     // u = M^-1 (r - alpha s)
-                if (pipelined) {
-                    rz[j] = fma(beta, rz[j], rn[j]);
-                    rw[j] = fma(-alpha, rz[j], rw[j]);
-                }
+                rz[j] = fma(beta, rz[j], rn[j]);
+                rw[j] = fma(-alpha, rz[j], rw[j]);
             }
-            ++iters; fresh = false;
-            if (pipelined) { ++pipe_iters; if (act & 4) pipelined = false; }
+            ++iters; ++pipe_iters; fresh = false;
             OC_STAMP(4);
             if (prof) ++prof_n;
+            if (act & 4) { go_classic = true; break; }            // seamless: same x, u, p, gamma
+        }
+        if (aborted || conv || !go_classic) break;
+        // ---- classic (Hestenes-Stiefel) CG, three synchronisations per iteration: gamma = r . u, then p, s = A p and
+        // delta = p . s.  delta is computed directly (no delta - beta gamma / alpha cancellation as in the one-reduction
+        // forms), which keeps the end game stable on ill-conditioned systems (free nearly incompressible bodies: cond ~ 1e7)
+        while (iters < a.max_iters) {
+            if (entry_restart) {
+                // Non-finite or runaway sums.  The entry x is still in global memory (x is written once, at the end):
+                // go back to it and restart from its true residual.  A second failure gives up: the solve is reported
+                // as unconverged and hands back the entry x, never a non-finite vector.
+                entry_restart = false;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) rx[j] = live ? a.x[3 * (size_t)row + j] : 0.0;
+                double q[6];
+                if (!true_residual(false, false, q)) { aborted = true; break; }
+                if (tid == 0) { ctl[0] = 1e300; ictl[0] = 0; }
+                if (++restarts > 1) break;
+                fresh = true;
+            }
+            double q[6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { q[j] = (live ? ru[j] * ru[j] * fast_rcp(rd[j]) : 0.0); q[3 + j] = 0.0; }
+            ++ph;
+            oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            gather_and_reduce(nullptr, nullptr, false, true);
+            const int act = decide(false);
+            if (act == 2) { entry_restart = true; continue; }
+            if (act == 1) {
+                const int v = verify();
+                if (v < 0) { aborted = true; break; }
+                if (v == 1) { conv = true; break; }
+                fresh = true;
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rp[j] = fma(ctl[5 + j], rp[j], ru[j]);    // p = u + beta p
+            ++ph; publish(rp);
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            gather_and_reduce(rp, rsv, true, false);                               // s = A p
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { q[j] = 0.0; q[3 + j] = rp[j] * rsv[j]; }
+            ++ph;
+            oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            gather_and_reduce(nullptr, nullptr, false, true);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double delta = bc[3 + j];
+                const double alpha = (delta > 0.0) ? glast[j] / delta : 0.0;
+                rx[j] = fma(alpha, rp[j], rx[j]);
+                ru[j] = fma(-alpha * rd[j], rsv[j], ru[j]);
+            }
+            __syncthreads();   // bc / glast are rewritten by the next iteration's reduction and decision
+            ++iters; fresh = false;
         }
     } while (false);
     if (prof) a.prof[63 * 8 + 3] = wall_clock64();

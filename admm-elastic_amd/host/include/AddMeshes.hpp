@@ -8,6 +8,7 @@
 #include <numeric>
 #include "Meshes.hpp"
 #include "Solver.hpp"
+#include "DynamicObject.hpp"
 #include "TetEnergyTerm.hpp"
 #include "TriEnergyTerm.hpp"
 
@@ -37,10 +38,10 @@ inline void add_tetmesh(admm::Solver *solver, std::shared_ptr<admm::TetMesh> &me
         for (int a = 0; a < 3; ++a) { x[3 * i + a] = mesh->vertices[i][a]; m3[3 * i + a] = masses[i]; }
     solver->add_nodes(x.data(), m3.data(), num_tet_verts);
     if (!(mesh->flags & NOSELFCOLLISION)) {
-        // The reference registers a TetMeshCollision (BVH from the absent mclscene) here.  Dynamic self-collision
-        // is outside the hot path this build covers; the surface vertices are still recorded.
-        static bool warned = false;
-        if (!warned) { std::cerr << "binding::add_tetmesh: dynamic self-collision is not part of the MI355X hot path (ignored)" << std::endl; warned = true; }
+        // Add a dynamic collider (samples/utils/AddMeshes.hpp:125-131)
+        mesh->need_faces();
+        std::shared_ptr<admm::TetMeshCollision> collision_mesh(new admm::TetMeshCollision(mesh, prev_tet_verts));
+        solver->add_dynamic_collider(collision_mesh);
         std::vector<int> surf;
         mesh->surface_inds(surf);
         for (int s : surf) solver->surface_inds.emplace_back(s + prev_tet_verts);

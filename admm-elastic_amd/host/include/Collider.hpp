@@ -1,6 +1,7 @@
 // Collider.hpp -- collision interfaces (reference: src/Collider.hpp).  On the MI355X build passive objects
 // are evaluated inside the HIP kernels, so only the analytic obstacles (PassiveObject.hpp: Floor, Sphere)
-// are accepted by Solver::initialize; the interfaces are kept so scene code compiles unchanged.
+// and tet-mesh self-collision proxies (DynamicObject.hpp: TetMeshCollision) are accepted by Solver::initialize;
+// the interfaces are kept so scene code compiles unchanged.
 #ifndef ADMM_COLLIDER_HPP
 #define ADMM_COLLIDER_HPP 1
 
@@ -11,10 +12,21 @@
 
 namespace admm {
 
-// src/Collider.hpp:32-61.  Self collision needs the BVH of the absent mclscene: out of scope.
+// src/Collider.hpp:32-61.  On the MI355X build detection runs on the GPU (csrc/dyn_collide.hpp), so an object is
+// accepted by Solver::initialize when it can describe itself as a tet mesh (TetMeshCollision, DynamicObject.hpp);
+// update() / signed_distance() are kept so scene code that overrides them compiles, but they are never called.
 class DynamicCollision {
 public:
+    struct Payload {                       // src/Collider.hpp:40-53
+        int vert_idx; Vec4i self_tet; double dx; Vec3 normal; Vec3i face; Vec3 barys;
+        Payload(int idx) : vert_idx(idx), self_tet(-1, -1, -1, -1), dx(std::numeric_limits<double>::max()), normal(0, 0, 0), face(-1, -1, -1), barys(0, 0, 0) {}
+    };
+    // flat description for admm_hip_add_dynamic_tetmesh (include/admm_hip.h)
+    struct DynFlat { int vert_offset; std::vector<double> rest; std::vector<int> tets, faces; };
     virtual ~DynamicCollision() {}
+    virtual void update(const VecX &x) { (void)x; }
+    virtual void signed_distance(const Vec3 &x, Payload &p) const { (void)x; (void)p; }
+    virtual bool flatten(DynFlat &f) const { (void)f; return false; }   // false = no GPU kernel for this object type
 };
 
 // src/Collider.hpp:66-83

@@ -24,7 +24,9 @@ namespace admm {
 struct TetMesh {
     std::vector<Vec3> vertices;
     std::vector<Vec4i> tets;
+    std::vector<Vec3i> faces;   // surface triangles, filled by need_faces() (mcl::TetMesh::faces)
     int flags = 0;   // binding::MeshFlags
+    void need_faces() { if (faces.empty()) surface_faces(faces); }
 
     void bounds(Vec3 &lo, Vec3 &hi) const {
         if (vertices.empty()) throw std::runtime_error("TetMesh::bounds: empty mesh");

@@ -318,8 +318,12 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
     }
     if (m_settings.linsolver == 0 && (m_constraints->collider->passive_objs.size() > 0 || m_constraints->collider->dynamic_objs.size() > 0))
         throw std::runtime_error("**Solver::add_obstacle Error: No collisions with LDLT solver"); // :249-254
-    if (m_constraints->collider->dynamic_objs.size() > 0)
-        throw std::runtime_error("Solver::initialize: dynamic (self-)collision objects are out of scope of the MI355X hot path");
+    std::vector<DynamicCollision::DynFlat> dyn_flat;
+    for (auto &obj : m_constraints->collider->dynamic_objs) {
+        DynamicCollision::DynFlat f;
+        if (!obj->flatten(f)) throw std::runtime_error("Solver::initialize: only TetMeshCollision dynamic colliders have GPU kernels");
+        dyn_flat.push_back(f);
+    }
 
     admm_hip_desc d;
     std::memset(&d, 0, sizeof(d));
@@ -348,6 +352,11 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
     admm_hip_ctx *ctx = nullptr;
     check(admm_hip_create(&d, &ctx), "Solver::initialize");
     m_ctx = ctx;
+    if (!surface_inds.empty())   // Collider::detect only looks at these vertices (src/Collider.hpp:157,163)
+        check(admm_hip_set_surface_inds(ctx, (int32_t)surface_inds.size(), surface_inds.data()), "Solver::initialize");
+    for (const DynamicCollision::DynFlat &f : dyn_flat)
+        check(admm_hip_add_dynamic_tetmesh(ctx, f.vert_offset, (int32_t)(f.rest.size() / 3), f.rest.data(), (int32_t)(f.tets.size() / 4),
+                                           f.tets.data(), (int32_t)(f.faces.size() / 3), f.faces.data()), "Solver::initialize");
     m_linsolver->attach(ctx);
     // keep the assembled matrix host-side (save_matrix, LinearSolver::matrix)
     int32_t nnz = 0;

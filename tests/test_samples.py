@@ -1,5 +1,5 @@
 """the C++ mesh layer (Meshes.hpp, AddMeshes.hpp) and the headless sample programs
-(samples/beams.cpp, samples/trianglestrain.cpp) on the C++ mirror of the reference API."""
+(samples/beams.cpp, samples/trianglestrain.cpp, samples/boxes.cpp) on the C++ mirror of the reference API."""
 import os
 import subprocess
 
@@ -33,7 +33,7 @@ def test_mesh_layer_cpu(tmp_path):
 
 
 def test_samples_build_and_print_help():
-    for name in ("beams", "trianglestrain"):
+    for name in ("beams", "trianglestrain", "boxes"):
         exe = _sample(name)
         r = subprocess.run([exe, "-help"], capture_output=True, text=True, timeout=60)
         assert r.returncode == 0 and "-it" in (r.stdout + r.stderr)
@@ -107,3 +107,22 @@ def test_trianglestrain_sample_runs(tmp_path, ls):
         e = np.concatenate([np.linalg.norm(g[1:] - g[:-1], axis=2).ravel(), np.linalg.norm(g[:, 1:] - g[:, :-1], axis=2).ravel()])
         return e.max() / 0.2
     assert max_edge_stretch(left) <= max_edge_stretch(right) + 1e-6
+
+
+@pytest.mark.gpu
+def test_boxes_sample_stacks(tmp_path):
+    """samples/boxes.cpp (tvcg2017/boxes.cpp headless, UzawaCG): binding::add_tetmesh registers a TetMeshCollision per box;
+    the lower box lands on the floor, the upper one on the lower one instead of falling through it.  Without the
+    dynamic colliders (checked with the same scene in Python) the upper box does pass through."""
+    exe = _sample("boxes")
+    out = str(tmp_path / "boxes")
+    r = subprocess.run([exe, "-v", "0", "--frames", "40", "--cells", "4", "--gap", "1.3", "--out", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    X = np.loadtxt(out + ".xyz")
+    nv = 5 ** 3
+    assert X.shape == (2 * nv, 3) and np.isfinite(X).all()
+    lower, upper = X[:nv], X[nv:]
+    assert lower[:, 1].min() > -1.0 - 3e-2                       # on the floor
+    assert lower[:, 1].min() < -0.9                              # ... and it did fall (started at -0.5)
+    assert upper[:, 1].min() > lower[:, 1].mean()                # the upper box rests on / above the lower one
+    assert upper[:, 1].min() < 0.5                               # ... after falling from 0.8
