@@ -30,10 +30,21 @@
 //     if the test fails, restarts CG from that true residual.  Pipelined CG is also known to stagnate -- and
 //     then blow up -- when asked for residuals near the FP64 floor of a system, so it is only used down to a
 //     relative residual of 1e-9 (kOcPipeFloor): below that, or after 50 iterations without a new residual
-//     minimum (200 while the residual is still far from that floor), the kernel continues SEAMLESSLY (same x, u, p, s, gamma, alpha) with the Chronopoulos-Gear
-//     recurrences, which recompute w = A u every iteration at the price of a second barrier.  A
-//     verification that fails twice without a 4x improvement means the FP64 floor has been reached: the
-//     solve stops as converged, as a recurrence-only CG would;
+//     minimum (200 while the residual is still far from that floor), the kernel continues SEAMLESSLY (same x, u, p,
+//     gamma) in the CLASSIC Hestenes-Stiefel form: p = u + beta p, s = A p, alpha = gamma / (p . s) -- three
+//     synchronisations per iteration, but p . A p is computed directly.  (The end game used to run the
+//     Chronopoulos-Gear recurrences, two synchronisations; their alpha = gamma / (delta - beta gamma / alpha') is a
+//     difference of nearly equal numbers near the floor, and on free nearly incompressible bodies -- cond ~ 1e7,
+//     the systems UzawaCG hands down with sparse right-hand sides C^T d -- it sent x to 1e254.  The end game is a
+//     few iterations of a solve, so the third synchronisation costs nothing measurable.)  A verification that fails
+//     twice without a 4x improvement means the FP64 floor has been reached: the solve stops as converged, as a
+//     recurrence-only CG would;
+//   * the three axes are independent systems (A = Ahat (x) I3) with their own b . M^-1 b; an axis whose right-hand
+//     side vanishes (C^T d of a floor contact has no x / z part) is measured against the largest axis, and b = 0
+//     returns x = 0 without iterating;
+//   * sums that turn non-finite, or grow 1e8x (in norm) above the best residual seen, send the solve back to the
+//     ENTRY x (still in global memory: x is written once, in the epilogue) and on in the classic form; a second
+//     failure returns the entry x, reported as unconverged -- never a non-finite vector;
 //   * every block reduces the partial records in the same fixed order, so all blocks take the same
 //     decisions and the result is deterministic run to run.
 #pragma once

@@ -409,6 +409,47 @@ def test_onchip_pcg_unconverged_and_cloth():
     assert abs(it_oc - it_l) <= max(3, it_l // 20), (it_oc, it_l)
 
 
+def _free_stiff_bodies(cells=3):
+    """two FREE blocks (no pins) of nearly incompressible rubber (E = 1e7, nu = 0.499): cond(D^-1 A) ~ 1e7 -- the
+    matrices of the tvcg2017 samples (boxes.cpp) as UzawaCG's inner solves see them"""
+    sc = scenes.Scene()
+    for i in range(2):
+        verts, tets = meshes.tet_blocks(cells, cells, cells)
+        verts = verts / cells + np.array([-0.5 + 0.013 * i, -0.5 + i * 1.3, -0.5 + 0.007 * i])
+        sc.add_tet_mesh(verts, tets, Lame.rubber(), pkg.TET_LINEAR)
+    sc.settings.update(linsolver=0, admm_iters=10)
+    return sc
+
+
+@pytest.mark.parametrize("tol", [1e-8, 1e-10, 1e-13])
+def test_onchip_pcg_ill_conditioned_sparse_rhs(tol):
+    """Regression: on these systems the one-reduction CG forms lost the iterate near the FP64 floor (x ~ 1e254 from a
+    3-entry right-hand side at tol 1e-12) and a right-hand side with an all-zero axis (C^T d of a floor contact) ended
+    the solve at iteration 0.  The kernel now finishes in the classic form with p . A p computed directly, measures an
+    axis with no right-hand side against the largest one, and never hands back a non-finite x."""
+    sc = _free_stiff_bodies()
+    o = sc.make_oracle()
+    s = sc.make_solver(pcg_tol=tol, pcg_max_iters=4000)
+    rng = np.random.default_rng(0)
+    x0 = sc.x.ravel().copy()
+    sparse = np.zeros(o.dof); sparse[[5, 100, 301]] = [1.0, -2.0, 0.5]
+    one_axis = np.zeros(o.dof); one_axis[1::3] = rng.standard_normal(o.nv) * (rng.random(o.nv) < 0.1)
+    for name, b in (("dense", o.A @ (x0 + 1e-3 * rng.standard_normal(o.dof))), ("sparse", sparse), ("one axis", one_axis)):
+        xe = o.solve_ldlt(b)
+        for start in (np.zeros(o.dof), x0):
+            xg, it = s.global_solve(b, start)
+            assert np.isfinite(xg).all() and 0 < it < 4000, (name, it)
+            # the stop test bounds the residual (checked below); the error may be up to cond ~ 1e7 times larger (it sits
+            # in the rigid modes, whose eigenvalue is the bare mass) and is never better than ~1e-10 in FP64
+            err = np.abs(xg - xe).max() / max(np.abs(xe).max(), np.abs(start).max())
+            assert err < max(1e3 * tol, 2e-9), (name, tol, err)
+            r = (b - o.A @ xg).reshape(-1, 3); dinv = 1.0 / o.A.diagonal().reshape(-1, 3); B = b.reshape(-1, 3)
+            scale = (B ** 2 * dinv).sum(axis=0).max()
+            assert ((r ** 2 * dinv).sum(axis=0) <= max(tol, 3e-11) ** 2 * 1.1 * scale).all(), (name, tol)
+    xg, it = s.global_solve(np.zeros(o.dof), x0)      # b = 0: the solution is x = 0, found without iterating
+    assert it == 0 and not xg.any()
+
+
 def test_onchip_pcg_big_system_residual(big):
     """~1M tets (all 256 CUs, 11 waves each): the returned x satisfies ||b - A x|| <= tol ||b|| in the
     D^-1 norm, checked on the host with the host-assembled matrix."""
