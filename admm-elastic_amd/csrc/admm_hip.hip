@@ -497,9 +497,11 @@ int enqueue_dyn_detect(admm_hip_ctx *c, const double *x) {
     if (hipMemsetAsync(c->dyn_face.p, 0xff, 3 * (size_t)c->nv * sizeof(int), st) != hipSuccess) return -1;
     for (auto &d : c->dyn) {
         hipLaunchKernelGGL(k_dyn_refit0, dim3(blocks_for(d->m.tt.n[0])), dim3(256), 0, st, d->m, x);
-        for (int l = 1; l < d->m.tt.n_levels; ++l)
+        int l = 1;
+        for (; l < d->m.tt.n_levels && d->m.tt.n[l] > 256; ++l)
             hipLaunchKernelGGL(k_dyn_refit_up, dim3(blocks_for(d->m.tt.n[l])), dim3(256), 0, st, d->m, l);
-        hipLaunchKernelGGL(k_dyn_query, dim3(blocks_for(nq)), dim3(256), 0, st, d->m, nq, qlist, x, c->dyn_face.p, c->dyn_bary.p,
+        if (l < d->m.tt.n_levels) hipLaunchKernelGGL(k_dyn_refit_top, dim3(1), dim3(256), 0, st, d->m, l);
+        hipLaunchKernelGGL(k_dyn_query, dim3((nq + 31) / 32), dim3(256), 0, st, d->m, nq, qlist, x, c->dyn_face.p, c->dyn_bary.p,
                            c->dyn_n.p, c->dyn_dx.p);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;

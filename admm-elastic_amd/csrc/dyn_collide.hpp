@@ -7,7 +7,7 @@
 // sorted ONCE along a Morton curve of the rest centroids (host_setup.cpp: build_octtree): node i of level 0 covers
 // sorted primitives [8i, 8i+8), node i of level l covers nodes [8i, 8i+8) of level l-1.  No pointers, no per-detect
 // sort, no atomics: a detect REFITS the boxes of the tet tree bottom-up (one thread per node, one launch per level --
-// 7 launches at 1 M tets) and queries it with one lane per candidate vertex.  The order stays good under deformation
+// 7 launches at 1 M tets) and queries it with eight lanes per candidate vertex (see k_dyn_query).  The order stays good under deformation
 // because neighbours at rest stay neighbours.
 //
 // What the absent traversal order would decide is decided by index (so the result does not depend on the traversal):
@@ -74,6 +74,26 @@ __global__ __launch_bounds__(256) void k_dyn_refit_up(DynMesh M, int l) {
     for (int a = 0; a < 6; ++a) o[a] = b[a];
 }
 
+// all levels from l0 up (each with at most 256 nodes: one per thread) in ONE block: the top of the tree is a handful of tiny levels,
+// and one launch per level would cost more than the work (5 us each)
+__global__ __launch_bounds__(256) void k_dyn_refit_top(DynMesh M, int l0) {
+    for (int l = l0; l < M.tt.n_levels; ++l) {
+        for (int i = (int)threadIdx.x; i < M.tt.n[l]; i += 256) {
+            double b[6]; box_reset(b);
+            for (int k = 0; k < 8 && 8 * i + k < M.tt.n[l - 1]; ++k) {
+                const double *ch = M.t_box + 6 * (size_t)(M.tt.off[l - 1] + 8 * i + k);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { b[a] = fmin(b[a], ch[a]); b[3 + a] = fmax(b[3 + a], ch[3 + a]); }
+            }
+            double *o = M.t_box + 6 * (size_t)(M.tt.off[l] + i);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) o[a] = b[a];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ bool tet_barycentric(const double *x, const double *p0, const double *p1, const double *p2, const double *p3, double *b) {
     double e1[3], e2[3], e3[3], r[3], cf[3];
 #pragma unroll
@@ -123,50 +143,72 @@ __device__ __forceinline__ double box_dist2(const double *b, const double *p) {
 
 // TetMeshCollision::signed_distance for every candidate vertex (query == nullptr: vertices 0..nq-1).  A vertex that
 // already holds a dynamic payload (face >= 0, written by an earlier object) is skipped (DynamicObject.hpp:73).
+//
+// EIGHT LANES PER CANDIDATE (8 candidates per wave, 32 per block): a tree node has 8 children and a leaf 8 primitives,
+// so every step of the traversal is one parallel test by the candidate's 8 lanes -- child boxes / tets / triangles are
+// loaded as one 384-byte (or 8 x int4) access, the verdicts are combined with a ballot or a 3-step butterfly, and
+// the traversal stack (identical for the 8 lanes) lives in LDS.  A lane-per-candidate version of the same traversal
+// spent 585 us per mesh at 1 M tets / 23 k candidates: a few hundred dependent loads per lane and only 360 waves on
+// the whole chip to hide them behind.
 __global__ __launch_bounds__(256) void k_dyn_query(DynMesh M, int nq, const int *__restrict__ query, const double *__restrict__ x,
                                                    int *__restrict__ face_out, double *__restrict__ bary_out,
                                                    double *__restrict__ n_out, double *__restrict__ dx_out) {
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nq) return;
-    const int vg = query ? query[q] : q;
-    if (face_out[3 * (size_t)vg] >= 0) return;
+    constexpr int kStack = 8 * kOctMaxLevels;
+    __shared__ int s_node[32][kStack];
+    __shared__ double s_dist[32][kStack];
+    const int tid = (int)threadIdx.x, grp = tid >> 3, sub = tid & 7, gsh = (tid & 63) & ~7;   // gsh: the group's first lane in its wave
+    const int q = (int)blockIdx.x * 32 + grp;
+    const int vg = q < nq ? (query ? query[q] : q) : 0;
+    const bool on = q < nq && face_out[3 * (size_t)vg] < 0;       // uniform over the group
+    volatile int *st = s_node[grp];
+    volatile double *sd = s_dist[grp];
     const double px[3] = {x[3 * (size_t)vg], x[3 * (size_t)vg + 1], x[3 * (size_t)vg + 2]};
-    int stack[8 * kOctMaxLevels];
-    int sp = 0;
+    auto group_bits = [&](bool pred) -> unsigned { return (unsigned)((__ballot(pred) >> gsh) & 0xffull); };
     // ---- point in tet (:76-79): lowest original index among the tets that contain the vertex and do not touch it
     int found = 0x7fffffff, found_pos = -1;
     double fb[4] = {0, 0, 0, 0};
-    stack[sp++] = ((M.tt.n_levels - 1) << 27);
-    while (sp > 0) {
-        const int e = stack[--sp], l = e >> 27, i = e & 0x7ffffff;
-        if (l > 0) {
-            for (int k = 0; k < 8; ++k) {
-                const int j = 8 * i + k;
-                if (j >= M.tt.n[l - 1]) break;
-                if (box_contains(M.t_box + 6 * (size_t)(M.tt.off[l - 1] + j), px)) stack[sp++] = ((l - 1) << 27) | j;
-            }
-            continue;
-        }
-        for (int k = 0; k < 8; ++k) {
-            const int pos = 8 * i + k;
-            const int4 t = M.tet[pos];
-            if (t.x < 0) continue;
-            if (t.x == vg || t.y == vg || t.z == vg || t.w == vg) continue;
-            const int tid = M.tet_id[pos];
-            if (tid > found) continue;
-            double p[4][3];
-            const int id[4] = {t.x, t.y, t.z, t.w};
+    int sp = 0;
+    if (on) { if (sub == 0) st[0] = ((M.tt.n_levels - 1) << 27); sp = 1; }
+    while (__any(sp > 0)) {
+        if (sp > 0) {
+            __builtin_amdgcn_wave_barrier();
+            const int e = st[--sp], l = e >> 27, i = e & 0x7ffffff;
+            __builtin_amdgcn_wave_barrier();
+            if (l > 0) {
+                const int j = 8 * i + sub;
+                const bool in = j < M.tt.n[l - 1] && box_contains(M.t_box + 6 * (size_t)(M.tt.off[l - 1] + j), px);
+                const unsigned m = group_bits(in);
+                if (in) st[sp + __popc(m & ((1u << sub) - 1u))] = ((l - 1) << 27) | j;
+                sp += __popc(m);
+            } else {
+                const int pos = 8 * i + sub;
+                const int4 t = M.tet[pos];
+                int cand = 0x7fffffff;
+                double b[4] = {0, 0, 0, 0};
+                if (t.x >= 0 && t.x != vg && t.y != vg && t.z != vg && t.w != vg) {
+                    double p[4][3];
+                    const int id[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { p[c][0] = x[3 * (size_t)id[c]]; p[c][1] = x[3 * (size_t)id[c] + 1]; p[c][2] = x[3 * (size_t)id[c] + 2]; }
-            double b[4];
-            if (!tet_barycentric(px, p[0], p[1], p[2], p[3], b)) continue;
-            if (b[0] >= 0.0 && b[1] >= 0.0 && b[2] >= 0.0 && b[3] >= 0.0) { found = tid; found_pos = pos; fb[0] = b[0]; fb[1] = b[1]; fb[2] = b[2]; fb[3] = b[3]; }
+                    for (int c = 0; c < 4; ++c) { p[c][0] = x[3 * (size_t)id[c]]; p[c][1] = x[3 * (size_t)id[c] + 1]; p[c][2] = x[3 * (size_t)id[c] + 2]; }
+                    if (tet_barycentric(px, p[0], p[1], p[2], p[3], b) && b[0] >= 0.0 && b[1] >= 0.0 && b[2] >= 0.0 && b[3] >= 0.0)
+                        cand = M.tet_id[pos];
+                }
+                int mn = cand;
+                mn = min(mn, __shfl_xor(mn, 1, 64)); mn = min(mn, __shfl_xor(mn, 2, 64)); mn = min(mn, __shfl_xor(mn, 4, 64));
+                const unsigned own = group_bits(cand == mn && mn != 0x7fffffff);     // tet ids are unique: one lane
+                if (mn < found) {
+                    const int src = gsh + __ffs(own) - 1;
+                    found = mn; found_pos = __shfl(pos, src, 64);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) fb[c] = __shfl(b[c], src, 64);
+                }
+            }
         }
     }
-    if (found_pos < 0) return;
+    const bool hit_tet = on && found_pos >= 0;
     // ---- the same combination of the rest vertices (:92-97)
     double rx[3] = {0, 0, 0};
-    {
+    if (hit_tet) {
         const int4 t = M.tet[found_pos];
         const int id[4] = {t.x - M.vert_offset, t.y - M.vert_offset, t.z - M.vert_offset, t.w - M.vert_offset};
 #pragma unroll
@@ -174,35 +216,61 @@ __global__ __launch_bounds__(256) void k_dyn_query(DynMesh M, int nq, const int 
 #pragma unroll
             for (int a = 0; a < 3; ++a) rx[a] += fb[c] * M.rest[3 * (size_t)id[c] + a];
     }
-    // ---- nearest rest-surface triangle that does not touch the vertex (:99-104)
+    // ---- nearest rest-surface triangle that does not touch the vertex (:99-104): depth-first, NEAREST child first
+    // (children are pushed far-to-near with their box distance and re-tested against the current best when popped),
+    // so the first leaf reached is close to the query and almost everything else is pruned
     const int vl = vg - M.vert_offset;
     double best = __builtin_inf(), bbc[3] = {0, 0, 0};
     int best_id = 0x7fffffff, best_pos = -1;
     sp = 0;
-    stack[sp++] = ((M.ft.n_levels - 1) << 27);
-    while (sp > 0) {
-        const int e = stack[--sp], l = e >> 27, i = e & 0x7ffffff;
-        if (l > 0) {
-            for (int k = 0; k < 8; ++k) {
-                const int j = 8 * i + k;
-                if (j >= M.ft.n[l - 1]) break;
-                if (!(box_dist2(M.f_box + 6 * (size_t)(M.ft.off[l - 1] + j), rx) > best)) stack[sp++] = ((l - 1) << 27) | j;
+    if (hit_tet) { if (sub == 0) { st[0] = ((M.ft.n_levels - 1) << 27); sd[0] = 0.0; } sp = 1; }
+    while (__any(sp > 0)) {
+        if (sp > 0) {
+            __builtin_amdgcn_wave_barrier();
+            --sp;
+            const int e = st[sp];
+            const double de = sd[sp];
+            __builtin_amdgcn_wave_barrier();
+            const int l = e >> 27, i = e & 0x7ffffff;
+            if (!(de > best)) {
+                if (l > 0) {
+                    const int j = 8 * i + sub;
+                    const bool valid = j < M.ft.n[l - 1];
+                    const double d = valid ? box_dist2(M.f_box + 6 * (size_t)(M.ft.off[l - 1] + j), rx) : __builtin_inf();
+                    const bool keep = valid && !(d > best);
+                    int rank = 0;     // position among the kept children, farthest first
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const double dk = __shfl(d, gsh + k, 64);
+                        const int kk = __shfl((int)keep, gsh + k, 64);
+                        rank += (kk && (dk > d || (dk == d && k < sub))) ? 1 : 0;
+                    }
+                    if (keep) { st[sp + rank] = ((l - 1) << 27) | j; sd[sp + rank] = d; }
+                    sp += __popc(group_bits(keep));
+                } else {
+                    int pos = 8 * i + sub;
+                    const int f0 = M.face[3 * (size_t)pos], f1 = M.face[3 * (size_t)pos + 1], f2 = M.face[3 * (size_t)pos + 2];
+                    double d = __builtin_inf(), bc[3] = {0, 0, 0};
+                    int fid = 0x7fffffff;
+                    if (f0 >= 0 && f0 != vl && f1 != vl && f2 != vl) {
+                        d = closest_on_triangle(rx, M.rest + 3 * (size_t)f0, M.rest + 3 * (size_t)f1, M.rest + 3 * (size_t)f2, bc);
+                        fid = M.face_id[pos];
+                    }
+#pragma unroll
+                    for (int o = 1; o < 8; o <<= 1) {     // butterfly arg-min on (distance, face index)
+                        const double od = __shfl_xor(d, o, 64);
+                        const int oid = __shfl_xor(fid, o, 64), opos = __shfl_xor(pos, o, 64);
+                        const double o0 = __shfl_xor(bc[0], o, 64), o1 = __shfl_xor(bc[1], o, 64), o2 = __shfl_xor(bc[2], o, 64);
+                        if (od < d || (od == d && oid < fid)) { d = od; fid = oid; pos = opos; bc[0] = o0; bc[1] = o1; bc[2] = o2; }
+                    }
+                    if (fid != 0x7fffffff && (d < best || (d == best && fid < best_id))) {
+                        best = d; best_id = fid; best_pos = pos; bbc[0] = bc[0]; bbc[1] = bc[1]; bbc[2] = bc[2];
+                    }
+                }
             }
-            continue;
-        }
-        if (box_dist2(M.f_box + 6 * (size_t)(M.ft.off[0] + i), rx) > best) continue;
-        for (int k = 0; k < 8; ++k) {
-            const int pos = 8 * i + k;
-            const int f0 = M.face[3 * (size_t)pos], f1 = M.face[3 * (size_t)pos + 1], f2 = M.face[3 * (size_t)pos + 2];
-            if (f0 < 0) continue;
-            if (f0 == vl || f1 == vl || f2 == vl) continue;
-            double bc[3];
-            const double d = closest_on_triangle(rx, M.rest + 3 * (size_t)f0, M.rest + 3 * (size_t)f1, M.rest + 3 * (size_t)f2, bc);
-            const int fid = M.face_id[pos];
-            if (d < best || (d == best && fid < best_id)) { best = d; best_id = fid; best_pos = pos; bbc[0] = bc[0]; bbc[1] = bc[1]; bbc[2] = bc[2]; }
         }
     }
-    if (best_pos < 0) return;
+    if (!hit_tet || best_pos < 0 || sub != 0) return;
     const double dx = -sqrt(best);                 // :112
     if (!(dx < 0.0)) return;                       // Collider.hpp:203
     const int f[3] = {M.face[3 * (size_t)best_pos], M.face[3 * (size_t)best_pos + 1], M.face[3 * (size_t)best_pos + 2]};
