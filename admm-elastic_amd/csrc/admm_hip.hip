@@ -103,6 +103,8 @@ struct admm_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_step0 = nullptr, ev_step1 = nullptr;
+    hipEvent_t ev_coll0 = nullptr, ev_coll1 = nullptr;   // around Collider::detect (UzawaCG path), when stats are requested
+    bool timing = false; double coll_ms_step = 0.0;
     std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration (+1) when stats are requested
 
     int nv = 0, n3 = 0;
@@ -229,6 +231,8 @@ struct admm_hip_ctx {
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
         if (gs_exec) (void)hipGraphExecDestroy(gs_exec);
         if (h_sig) (void)hipHostFree(h_sig);
+        if (ev_coll0) (void)hipEventDestroy(ev_coll0);
+        if (ev_coll1) (void)hipEventDestroy(ev_coll1);
         if (ev_step0) (void)hipEventDestroy(ev_step0);
         if (ev_step1) (void)hipEventDestroy(ev_step1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -522,6 +526,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     if (c->obst.n > 0 || dyn) {
         // Collider::detect at the current iterate + ConstraintSet::make_matrix (ck = sqrt(constraint_w))
         const double ck = std::sqrt(std::max(0.0, c->constraint_w));
+        if (c->timing && hipEventRecord(c->ev_coll0, st) != hipSuccess) return -1;
         if (hipMemsetAsync(c->counters.p + 6, 0, sizeof(int), st) != hipSuccess) return -1;
         if (c->obst.n > 0)
             hipLaunchKernelGGL(k_uz_detect, dim3(gv), dim3(256), 0, st, nv, x, c->obst, ck, c->uz_cn.p, c->uz_cc.p, c->counters.p + 6,
@@ -533,8 +538,10 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
             hipLaunchKernelGGL(k_dyn_rows, dim3(gq), dim3(256), 0, st, nq, qlist, ck, c->uz_cn.p, c->uz_cc.p, c->dyn_face.p, c->dyn_n.p,
                                c->counters.p + 6);
         }
+        if (c->timing && hipEventRecord(c->ev_coll1, st) != hipSuccess) return -1;
         if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (c->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_coll0, c->ev_coll1) == hipSuccess) c->coll_ms_step += ms; }
     }
     c->uz_last_hits = nh;
     if (nh != c->uz_prev_hits) { // multipliers are kept only while the number of rows is unchanged (UzawaCG.hpp:74)
@@ -1137,6 +1144,8 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
             c->ev_phase.push_back(e);
         }
     }
+    c->timing = timed; c->coll_ms_step = 0.0;
+    if (timed && !c->ev_coll0) { HIP_TRY(hipEventCreate(&c->ev_coll0)); HIP_TRY(hipEventCreate(&c->ev_coll1)); }
     HIP_TRY(hipEventRecord(c->ev_step0, st));
     // counters[5] (closed chunks) must stay monotone across steps: only [0..4] are reset
     c->uz_iters_step = 0;
@@ -1159,6 +1168,7 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
         if (launch_global(c, c->b.p, c->curr.p))   // Solver.cpp:99
             return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     }
+    c->timing = false;
     if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * admm_iters], st));
     hipLaunchKernelGGL(k_finish, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, 1.0 / c->dt, c->x.p, c->v.p, c->curr.p);
     HIP_TRY(hipEventRecord(c->ev_step1, st));
@@ -1176,6 +1186,9 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 2])); stats->rhs_ms += ms;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 3])); stats->global_ms += ms;
         }
+        // collision_ms = Collider::detect + constraint rows (Solver.cpp:90-95); it runs inside the global phase here
+        stats->collision_ms = c->coll_ms_step;
+        stats->global_ms = std::max(0.0, stats->global_ms - c->coll_ms_step);
         int h[8];
         HIP_TRY(hipMemcpy(h, c->counters.p, 8 * sizeof(int), hipMemcpyDeviceToHost));
         CgScal sc[2];

@@ -21,6 +21,6 @@ print("detect_dynamic (incl. H2D/D2H of the test hook): %d hits, %.1f ms" % (len
 s.upload()
 for f in range(frames):
     t0 = time.time(); s.step_device(stats=True); rd = s.runtime_data()
-    print("frame %d: %.1f ms, inner %d, local %.3f global %.3f ms" % (f, 1e3 * (time.time() - t0), rd.inner_iters, rd.local_ms, rd.global_ms), flush=True)
+    print("frame %d: %.1f ms, inner %d, local %.3f global %.3f collision %.3f ms" % (f, 1e3 * (time.time() - t0), rd.inner_iters, rd.local_ms, rd.global_ms, rd.collision_ms), flush=True)
 s.download()
 print("finite", np.isfinite(s.m_x).all())

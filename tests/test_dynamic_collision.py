@@ -174,6 +174,7 @@ def test_step_with_self_collision():
     o = sc.make_oracle()
     s.step(); o.step()
     assert s.runtime_data().inner_iters > 5
+    assert s.runtime_data().collision_ms > 0.0          # RuntimeData::collision_ms = detect + constraint rows
     assert scenes.rel_err(s.m_x, o.x) < 1e-6
     dyn_frames = 0
     for _ in range(14):
