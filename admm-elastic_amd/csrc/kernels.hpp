@@ -146,6 +146,23 @@ typedef unsigned bv2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t soa_rsrc(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7ffffff0, 0x00020000);
 }
+// cache policy of the per-element STREAMS (read or written exactly once per launch) -- gfx950 aux bits: 1 = sc0, 2 = nt
+// (non-temporal: first in line for eviction), 16 = sc1.  The gathered vertex positions keep the default policy.
+#ifndef ADMM_STREAM_LD_AUX
+#define ADMM_STREAM_LD_AUX 0
+#endif
+#ifndef ADMM_STREAM_ST_AUX
+#define ADMM_STREAM_ST_AUX 0
+#endif
+__device__ __forceinline__ double buf_ld_stream(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    union { double d; bv2u v; } t;
+    t.v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, ADMM_STREAM_LD_AUX);
+    return t.d;
+}
+__device__ __forceinline__ void buf_st_stream(__amdgpu_buffer_rsrc_t rs, int voff, int soff, double x) {
+    union { double d; bv2u v; } t; t.d = x;
+    __builtin_amdgcn_raw_buffer_store_b64(t.v, rs, voff, soff, ADMM_STREAM_ST_AUX);
+}
 __device__ __forceinline__ double buf_ld(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     union { double d; bv2u v; } t;
     t.v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
@@ -171,8 +188,8 @@ __device__ __forceinline__ void tet_load(const TetArgs &a, int t, TetIn &in) {
     const int ld8 = a.ld * 8, t8 = t * 8;   // bytes between two components of an SoA array (< 2^31 up to 268 M tets)
     const __amdgpu_buffer_rsrc_t rBinv = soa_rsrc(a.Binv), ru = soa_rsrc(a.u);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) { in.Bi[c] = buf_ld(rBinv, t8, c * ld8); in.ui[c] = buf_ld(ru, t8, c * ld8); }
-    in.s = buf_ld(soa_rsrc(a.sc), t8, 0);
+    for (int c = 0; c < 9; ++c) { in.Bi[c] = buf_ld_stream(rBinv, t8, c * ld8); in.ui[c] = buf_ld_stream(ru, t8, c * ld8); }
+    in.s = buf_ld_stream(soa_rsrc(a.sc), t8, 0);
     in.mid = (KIND == 0) ? 0 : __builtin_amdgcn_raw_buffer_load_b32(soa_rsrc(a.mat_id), t * 4, 0, 0);
 }
 __device__ __forceinline__ void tet_gather(const TetArgs &a, const int4 id, TetPos &x) {
@@ -247,7 +264,7 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, const
         double un[9];
         usvt(U, du, V, un);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) buf_st(ru, t8, c * ld8, un[c]);
+        for (int c = 0; c < 9; ++c) buf_st_stream(ru, t8, c * ld8, un[c]);
         if (WRITE_Z) {
             double zi[9];
             usvt(U, S1, V, zi);
@@ -267,12 +284,12 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, const
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const double h = fma(G[j], b0, fma(G[3 + j], b1, G[6 + j] * b2));
-            buf_st(rcf, t8, (3 * (m + 1) + j) * ld8, h);
+            buf_st_stream(rcf, t8, (3 * (m + 1) + j) * ld8, h);
             f0[j] -= h;
         }
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) buf_st(rcf, t8, j * ld8, f0[j]);
+    for (int j = 0; j < 3; ++j) buf_st_stream(rcf, t8, j * ld8, f0[j]);
 }
 
 template <int KIND, bool WRITE_Z>
