@@ -209,6 +209,10 @@ struct admm_hip_ctx {
     std::vector<std::unique_ptr<DynDev> > dyn;
     DevBuf<int> dyn_face, surf_list; DevBuf<double> dyn_bary, dyn_n, dyn_dx; DevBuf<unsigned char> surf_mask;
     int n_surf = 0;   // Solver::surface_inds (0 = every vertex is a collision candidate)
+    // dynamic hits inside the multi-colour GS (per solve: hit list, touched rows, mask, residual partials)
+    DevBuf<DynHit> gsd_hits; DevBuf<unsigned char> gsd_skip; DevBuf<double> gsd_part;
+    DevBuf<int> gsd_int; DevBuf<double> gsd_dbl; DevBuf<int4> gsd_hnode;
+    int gsd_last_hits = 0;
 
     ~admm_hip_ctx() {
         (void)hipSetDevice(device);
@@ -227,6 +231,7 @@ struct admm_hip_ctx {
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
+        gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
         if (gs_exec) (void)hipGraphExecDestroy(gs_exec);
@@ -612,7 +617,8 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
             first = false;
         }
         if (check)
-            hipLaunchKernelGGL(k_gs_resid, dim3(c->NB), dim3(256), 0, st, A, c->m.p, b, x, c->part.p, c->NB, c->counters.p + 1);
+            hipLaunchKernelGGL(k_gs_resid, dim3(c->NB), dim3(256), 0, st, A, c->m.p, b, x, c->part.p, c->NB, c->counters.p + 1,
+                               (const unsigned char *)nullptr);
     }
     // the last sweep is settled by a dedicated one-block kernel
     hipLaunchKernelGGL(k_gs_check, dim3(1), dim3(256), 0, st, c->part.p, c->NB, c->gs_tol * c->gs_tol, c->counters.p + 1,
@@ -637,6 +643,142 @@ void launch_gs(admm_hip_ctx *c, const double *b, double *x) {
     }
     if (c->gs_exec && hipGraphLaunch(c->gs_exec, c->stream) == hipSuccess) return;
     enqueue_gs(c, b, x); // capture unavailable: plain launches
+}
+
+// NodalMultiColorGS::solve with dynamic hits (src/NodalMultiColorGS.hpp:75-86): detect, and if anything was hit sweep
+// A + C^T C -- untouched nodes with the SELL colour kernels (skip mask), touched nodes with k_gs_touched over new colours.
+int launch_gs_dynamic(admm_hip_ctx *c, const double *b, double *x) {
+    hipStream_t st = c->stream;
+    const int nv = c->nv;
+    const int nq = c->n_surf > 0 ? c->n_surf : nv;
+    const int *qlist = c->n_surf > 0 ? c->surf_list.p : nullptr;
+    if (c->timing && hipEventRecord(c->ev_coll0, st) != hipSuccess) return -1;
+    if (enqueue_dyn_detect(c, x)) return -1;
+    if (hipMemsetAsync(c->counters.p + 6, 0, sizeof(int), st) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_dyn_compact, dim3(blocks_for(nq)), dim3(256), 0, st, nq, qlist, c->dyn_face.p, c->dyn_bary.p, c->dyn_n.p,
+                       c->gsd_hits.p, (int)c->gsd_hits.n, c->counters.p + 6);
+    if (c->timing && hipEventRecord(c->ev_coll1, st) != hipSuccess) return -1;
+    int nh = 0;
+    if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (c->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_coll0, c->ev_coll1) == hipSuccess) c->coll_ms_step += ms; }
+    c->gsd_last_hits = nh;
+    if (nh == 0) { launch_gs(c, b, x); return 0; }
+    std::vector<DynHit> hits(nh);
+    if (hipMemcpy(hits.data(), c->gsd_hits.p, nh * sizeof(DynHit), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    std::sort(hits.begin(), hits.end(), [](const DynHit &p, const DynHit &q) { return p.v < q.v; });
+    // touched nodes and their hits
+    std::map<int, int> tix;
+    for (const DynHit &h : hits) { const int nd[4] = {h.v, h.f0, h.f1, h.f2}; for (int k = 0; k < 4; ++k) tix.emplace(nd[k], 0); }
+    std::vector<int> touched; touched.reserve(tix.size());
+    for (auto &kv : tix) { kv.second = (int)touched.size(); touched.push_back(kv.first); }
+    const int nt = (int)touched.size();
+    std::vector<std::vector<std::pair<int, double> > > inc(nt);
+    std::vector<std::vector<int> > adj(nt);
+    for (int h = 0; h < nh; ++h) {
+        const int nd[4] = {hits[h].v, hits[h].f0, hits[h].f1, hits[h].f2};
+        const double cf[4] = {1.0, -hits[h].b[0], -hits[h].b[1], -hits[h].b[2]};
+        for (int k = 0; k < 4; ++k) {
+            inc[tix[nd[k]]].emplace_back(h, cf[k]);
+            for (int l = 0; l < 4; ++l) if (nd[l] != nd[k]) adj[tix[nd[k]]].push_back(tix[nd[l]]);
+        }
+    }
+    for (int t = 0; t < nt; ++t) {
+        const int v = touched[t];
+        for (int k = c->Ahat.rowptr[v]; k < c->Ahat.rowptr[v + 1]; ++k) {
+            const int j = c->Ahat.col[k];
+            if (j == v || c->Ahat.val[k] == 0.0) continue;
+            auto it = tix.find(j);
+            if (it != tix.end()) adj[t].push_back(it->second);
+        }
+    }
+    // first fit over new colours, increasing node order (the rule the oracle restates: oracle.py recolor_touched)
+    std::vector<int> extra(nt, -1);
+    int n_extra = 0;
+    for (int t = 0; t < nt; ++t) {
+        std::vector<char> used(n_extra + 1, 0);
+        for (int u : adj[t]) if (extra[u] >= 0) used[extra[u]] = 1;
+        int e = 0;
+        while (used[e]) ++e;
+        extra[t] = e; n_extra = std::max(n_extra, e + 1);
+    }
+    // group by new colour (stable: node order inside a colour)
+    std::vector<int> order(nt), cstart(n_extra + 1, 0);
+    for (int t = 0; t < nt; ++t) cstart[extra[t] + 1] += 1;
+    for (int e = 0; e < n_extra; ++e) cstart[e + 1] += cstart[e];
+    { std::vector<int> pos(cstart.begin(), cstart.end() - 1); for (int t = 0; t < nt; ++t) order[pos[extra[t]]++] = t; }
+    // flat arrays: [node | rptr | hptr | rcol | hidx] ints, [rval | hcoef | hc | hn] doubles
+    std::vector<int> node(nt), rptr(nt + 1, 0), hptr(nt + 1, 0), rcol, hidx;
+    std::vector<double> rval, hcoef, hc(4 * (size_t)nh), hn(3 * (size_t)nh);
+    std::vector<int4> hnode(nh);
+    for (int i = 0; i < nt; ++i) {
+        const int t = order[i], v = touched[t];
+        node[i] = v;
+        for (int k = c->Ahat.rowptr[v]; k < c->Ahat.rowptr[v + 1]; ++k) { rcol.push_back(c->Ahat.col[k]); rval.push_back(c->Ahat.val[k]); }
+        rptr[i + 1] = (int)rcol.size();
+        for (auto &pr : inc[t]) { hidx.push_back(pr.first); hcoef.push_back(pr.second); }
+        hptr[i + 1] = (int)hidx.size();
+    }
+    for (int h = 0; h < nh; ++h) {
+        hnode[h] = make_int4(hits[h].v, hits[h].f0, hits[h].f1, hits[h].f2);
+        hc[4 * (size_t)h] = 1.0;
+        for (int k = 0; k < 3; ++k) { hc[4 * (size_t)h + 1 + k] = -hits[h].b[k]; hn[3 * (size_t)h + k] = hits[h].n[k]; }
+    }
+    std::vector<int> ints; ints.reserve(node.size() + rptr.size() + hptr.size() + rcol.size() + hidx.size());
+    const size_t o_node = 0, o_rptr = o_node + node.size(), o_hptr = o_rptr + rptr.size(), o_rcol = o_hptr + hptr.size(), o_hidx = o_rcol + rcol.size();
+    ints.insert(ints.end(), node.begin(), node.end()); ints.insert(ints.end(), rptr.begin(), rptr.end());
+    ints.insert(ints.end(), hptr.begin(), hptr.end()); ints.insert(ints.end(), rcol.begin(), rcol.end()); ints.insert(ints.end(), hidx.begin(), hidx.end());
+    std::vector<double> dbl;
+    const size_t o_rval = 0, o_hcoef = o_rval + rval.size(), o_hc = o_hcoef + hcoef.size(), o_hn = o_hc + hc.size();
+    dbl.insert(dbl.end(), rval.begin(), rval.end()); dbl.insert(dbl.end(), hcoef.begin(), hcoef.end());
+    dbl.insert(dbl.end(), hc.begin(), hc.end()); dbl.insert(dbl.end(), hn.begin(), hn.end());
+    if (c->gsd_int.n < ints.size()) { c->gsd_int.release(); if (c->gsd_int.alloc(2 * ints.size()) != hipSuccess) return -1; }
+    if (c->gsd_dbl.n < dbl.size()) { c->gsd_dbl.release(); if (c->gsd_dbl.alloc(2 * dbl.size()) != hipSuccess) return -1; }
+    if (c->gsd_hnode.n < hnode.size()) { c->gsd_hnode.release(); if (c->gsd_hnode.alloc(2 * hnode.size()) != hipSuccess) return -1; }
+    std::vector<unsigned char> mask(nv, 0);
+    for (int v : touched) mask[v] = 1;
+    if (hipMemcpyAsync(c->gsd_int.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(c->gsd_dbl.p, dbl.data(), dbl.size() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(c->gsd_hnode.p, hnode.data(), hnode.size() * sizeof(int4), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(c->gsd_skip.p, mask.data(), nv, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;   // the host vectors die at the end of this function
+    GsDyn d{};
+    d.n_touched = nt; d.n_hits = nh;
+    d.node = c->gsd_int.p + o_node; d.rptr = c->gsd_int.p + o_rptr; d.hptr = c->gsd_int.p + o_hptr; d.rcol = c->gsd_int.p + o_rcol; d.hidx = c->gsd_int.p + o_hidx;
+    d.rval = c->gsd_dbl.p + o_rval; d.hcoef = c->gsd_dbl.p + o_hcoef; d.hc = c->gsd_dbl.p + o_hc; d.hn = c->gsd_dbl.p + o_hn;
+    d.hnode = c->gsd_hnode.p;
+    d.ck2 = std::max(0.0, c->constraint_w);
+    // the sweeps (plain launches: the colour structure changes with every solve, so there is nothing to capture)
+    (void)hipMemsetAsync(c->counters.p + 1, 0, 2 * sizeof(int), st);
+    const int NBp = c->NB + 1;
+    GsArgs a{};
+    a.S = sell_arg(c->gs_sell); a.slot_node = c->gs_slot_node.p; a.diag = c->gs_diag.p; a.m = c->m.p; a.b = b; a.x = x;
+    a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p;
+    a.omega = c->gs_omega; a.done = c->counters.p + 1;
+    a.part = c->gsd_part.p; a.NBp = NBp; a.tol2 = c->gs_tol * c->gs_tol; a.sweeps = c->counters.p + 2; a.total = c->counters.p;
+    a.skip = c->gsd_skip.p;
+    const SellA A = sell_arg(c->A);
+    const int check = c->gs_tol > 0.0 ? 1 : 0;
+    for (int it = 0; it < c->gs_max_iters; ++it) {
+        bool first = true;
+        for (int col = 0; col < c->n_colors; ++col) {
+            const int s0 = c->gs_color_slice[col], ns = c->gs_color_slice[col + 1] - s0;
+            if (ns == 0) continue;
+            const int decide = (first && it > 0) ? (check ? 2 : 1) : 0;
+            hipLaunchKernelGGL(k_gs_color, dim3((ns + 3) / 4), dim3(256), 0, st, a, s0, ns, c->obst, decide);
+            first = false;
+        }
+        for (int e = 0; e < n_extra; ++e)
+            hipLaunchKernelGGL(k_gs_touched, dim3((cstart[e + 1] - cstart[e] + 63) / 64), dim3(64), 0, st, a, d, cstart[e], cstart[e + 1], c->obst);
+        if (check) {
+            hipLaunchKernelGGL(k_gs_resid, dim3(c->NB), dim3(256), 0, st, A, c->m.p, b, x, c->gsd_part.p, NBp, c->counters.p + 1,
+                               (const unsigned char *)c->gsd_skip.p);
+            hipLaunchKernelGGL(k_gs_touched_resid, dim3(1), dim3(256), 0, st, a, d, c->gsd_part.p, NBp, c->NB);
+        }
+    }
+    hipLaunchKernelGGL(k_gs_check, dim3(1), dim3(256), 0, st, c->gsd_part.p, NBp, c->gs_tol * c->gs_tol, c->counters.p + 1,
+                       c->counters.p + 2, c->counters.p, check);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int validate(const admm_hip_desc *d) {
@@ -1016,9 +1158,6 @@ int admm_hip_add_dynamic_tetmesh(admm_hip_ctx *c, int32_t vert_offset, int32_t n
         return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: bad input");
     if (n_faces <= 0 || !faces) return fail(ADMM_HIP_ERR_ARG, "**TetMeshCollision Error: TetMesh needs surface faces");
     if (c->linsolver == 0) return fail(ADMM_HIP_ERR_ARG, "**Solver::add_obstacle Error: No collisions with LDLT solver");
-    if (c->linsolver == 1)
-        return fail(ADMM_HIP_ERR_ARG, "dynamic colliders with NodalMultiColorGS (A + C^T C, re-coloured at every solve, "
-                                      "NodalMultiColorGS.hpp:80-86) are not implemented on the GPU: use linsolver 2 (UzawaCG)");
     for (int i = 0; i < 4 * n_tets; ++i) if (tets[i] < 0 || tets[i] >= n_verts) return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: tet index out of range");
     for (int i = 0; i < 3 * n_faces; ++i) if (faces[i] < 0 || faces[i] >= n_verts) return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: face index out of range");
     HIP_TRY(hipSetDevice(c->device));
@@ -1069,6 +1208,10 @@ int admm_hip_add_dynamic_tetmesh(admm_hip_ctx *c, int32_t vert_offset, int32_t n
     fill_levels(TT, d->m.tt); fill_levels(FT, d->m.ft);
     d->m.tet = d->tet.p; d->m.tet_id = d->tet_id.p; d->m.t_box = d->t_box.p;
     d->m.face = d->face.p; d->m.face_id = d->face_id.p; d->m.f_box = d->f_box.p; d->m.rest = d->rest.p;
+    if (c->linsolver == 1 && !c->gsd_skip.p) {
+        HIP_TRY(c->gsd_hits.alloc((size_t)c->nv)); HIP_TRY(c->gsd_skip.alloc((size_t)c->nv)); HIP_TRY(c->gsd_skip.zero());
+        HIP_TRY(c->gsd_part.alloc(2 * ((size_t)c->NB + 1))); HIP_TRY(c->gsd_part.zero());
+    }
     if (!c->dyn_face.p) {
         HIP_TRY(c->dyn_face.alloc(3 * (size_t)c->nv)); HIP_TRY(c->dyn_bary.alloc(c->n3)); HIP_TRY(c->dyn_n.alloc(c->n3));
         HIP_TRY(c->dyn_dx.alloc(c->nv));
@@ -1120,7 +1263,10 @@ int admm_hip_detect_dynamic(admm_hip_ctx *c, const double *x, int32_t cap, int32
 }
 
 static int launch_global(admm_hip_ctx *c, const double *b, double *x) {
-    if (c->linsolver == 1) { launch_gs(c, b, x); return 0; }
+    if (c->linsolver == 1) {
+        if (!c->dyn.empty()) return launch_gs_dynamic(c, b, x);
+        launch_gs(c, b, x); return 0;
+    }
     if (c->linsolver == 2) {
         int it = 1;
         const int rc = launch_uzawa(c, b, x, &it);

@@ -342,4 +342,134 @@ __device__ __forceinline__ double dyn_row_faces(int v, const double *__restrict_
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Dynamic hits in the multi-colour Gauss-Seidel (src/NodalMultiColorGS.hpp:80-86): the reference adds the penalty
+// C^T C to A and re-colours.  C^T C couples only the four nodes of a hit (vertex + face vertices) and breaks the
+// Ahat (x) I3 structure only in THEIR rows, so the matrix is never formed: every other node keeps its row of A, its
+// colour and the SELL kernels (k_gs_color with the `skip` mask); the touched nodes are re-coloured on the host over
+// new colours that follow the old ones (first fit in node order; conflicts = shared hit or non-zero of Ahat -- the
+// colouring library is absent, the rule is shared with the oracle) and swept here, one lane per node, from a compact
+// copy of their Ahat rows plus their hits:
+//   (C^T C x)_(a,s) = ck^2 c_a n_s sum_k c_k n . x_k     (c = 1 at the vertex, -bary_j at face vertex j)
+struct GsDyn {
+    int n_touched, n_hits;
+    const int *node;                 // [n_touched] node ids, grouped by new colour
+    const int *rptr;                 // [n_touched + 1] the node's row of Ahat: rcol / rval (diagonal included)
+    const int *rcol; const double *rval;
+    const int *hptr;                 // [n_touched + 1] the node's hits: hidx (hit), hcoef (c_a)
+    const int *hidx; const double *hcoef;
+    const int4 *hnode;               // [n_hits] vertex, face vertices
+    const double *hc;                // [n_hits][4]
+    const double *hn;                // [n_hits][3]
+    double ck2;
+};
+
+// off-diagonal row sums LUx and diagonals aii of the three rows of touched node t in M = A + C^T C, exactly as
+// segment_update reads them (:180-215): exact zeros of Ahat skipped, same-node cross-axis terms of C^T C included
+__device__ __forceinline__ void gsd_rows(const GsDyn &d, int t, int a, const double *__restrict__ m, const double *__restrict__ x,
+                                         double *LUx, double *aii) {
+    double ad = 0.0;
+    LUx[0] = LUx[1] = LUx[2] = 0.0;
+    for (int k = d.rptr[t]; k < d.rptr[t + 1]; ++k) {
+        const double v = d.rval[k];
+        const int j = d.rcol[k];
+        if (j == a) { ad = v; continue; }
+        if (v == 0.0) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) LUx[s] = fma(v, x[3 * (size_t)j + s], LUx[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) aii[s] = ad + m[3 * (size_t)a + s];
+    const double xa[3] = {x[3 * (size_t)a], x[3 * (size_t)a + 1], x[3 * (size_t)a + 2]};
+    for (int k = d.hptr[t]; k < d.hptr[t + 1]; ++k) {
+        const int h = d.hidx[k];
+        const double ca = d.hcoef[k];
+        const int4 nd = d.hnode[h];
+        const int id[4] = {nd.x, nd.y, nd.z, nd.w};
+        const double n[3] = {d.hn[3 * (size_t)h], d.hn[3 * (size_t)h + 1], d.hn[3 * (size_t)h + 2]};
+        double sh = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            sh += d.hc[4 * (size_t)h + q] * (n[0] * x[3 * (size_t)id[q]] + n[1] * x[3 * (size_t)id[q] + 1] + n[2] * x[3 * (size_t)id[q] + 2]);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const double w = d.ck2 * ca * n[s];
+            aii[s] += w * ca * n[s];
+            LUx[s] += w * (sh - ca * n[s] * xa[s]);
+        }
+    }
+}
+
+// one NEW colour of one sweep: touched nodes [t0, t1)
+__global__ __launch_bounds__(64) void k_gs_touched(GsArgs a, GsDyn d, int t0, int t1, Obstacles ob) {
+    const int t = t0 + (int)(blockIdx.x * 64 + threadIdx.x);
+    if (t >= t1 || *a.done) return;
+    const int v = d.node[t];
+    if (a.pin_flag && a.pin_flag[v]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = a.pin_xyz[3 * (size_t)v + q];
+        return;
+    }
+    double LUx[3], aii[3], jac[3], nx[3];
+    gsd_rows(d, t, v, a.m, a.x, LUx, aii);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        jac[q] = (a.b[3 * (size_t)v + q] - LUx[q]) / aii[q];
+        nx[q] = (1.0 - a.omega) * a.x[3 * (size_t)v + q] + a.omega * jac[q];
+    }
+    double n[3], p[3];
+    if (ob.n > 0 && passive_hit(ob, nx, n, p)) {
+        double dx[3] = {jac[0] - p[0], jac[1] - p[1], jac[2] - p[2]};
+        double nn[3] = {0.0, 0.0, 0.0}, uu[3], vv[3];
+        if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0;
+        cross3(nn, n, uu);
+        double il = 1.0 / sqrt(dot3(uu, uu));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) uu[q] *= il;
+        cross3(n, uu, vv);
+        il = 1.0 / sqrt(dot3(vv, vv));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) vv[q] *= il;
+        const double t0d = dot3(uu, dx), t1d = dot3(vv, dx);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) nx[q] = uu[q] * t0d + vv[q] * t1d + p[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
+}
+
+// |b - M x|^2 over the touched rows (one block) -> the extra slot `slot` of the residual partials (:136-140)
+__global__ __launch_bounds__(256) void k_gs_touched_resid(GsArgs a, GsDyn d, double *__restrict__ part, int NBp, int slot) {
+    __shared__ double lds[8];
+    const int done_flag = *a.done;
+    double q[2] = {0.0, 0.0};
+    for (int t = threadIdx.x; t < d.n_touched; t += 256) {
+        const int v = d.node[t];
+        double LUx[3], aii[3];
+        gsd_rows(d, t, v, a.m, a.x, LUx, aii);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { const double r = a.b[3 * (size_t)v + s] - LUx[s] - aii[s] * a.x[3 * (size_t)v + s]; q[0] = fma(r, r, q[0]); }
+    }
+    block_sum<2>(q, lds);
+    if (threadIdx.x == 0 && !done_flag) { part[slot] = q[0]; part[NBp + slot] = 0.0; }
+}
+
+// compaction of the dynamic payloads into a hit list (order arbitrary; the host sorts by vertex)
+struct DynHit { int v, f0, f1, f2; double b[3]; double n[3]; };
+__global__ __launch_bounds__(256) void k_dyn_compact(int nq, const int *__restrict__ query, const int *__restrict__ dface,
+                                                     const double *__restrict__ dbary, const double *__restrict__ dn,
+                                                     DynHit *__restrict__ out, int cap, int *__restrict__ count) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const int v = query ? query[q] : q;
+    if (dface[3 * (size_t)v] < 0) return;
+    const int i = atomicAdd(count, 1);
+    if (i >= cap) return;
+    DynHit h;
+    h.v = v; h.f0 = dface[3 * (size_t)v]; h.f1 = dface[3 * (size_t)v + 1]; h.f2 = dface[3 * (size_t)v + 2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { h.b[s] = dbary[3 * (size_t)v + s]; h.n[s] = dn[3 * (size_t)v + s]; }
+    out[i] = h;
+}
+
 } // namespace admm_k

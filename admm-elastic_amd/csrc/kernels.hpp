@@ -884,6 +884,8 @@ struct GsArgs {
     // residual test of the PREVIOUS sweep, decided here by every block of the first colour kernel of a sweep
     // (deterministic re-reduction of the k_gs_resid partials; saves one launch per sweep)
     const double *part; int NBp; double tol2; int *sweeps; int *total;
+    const unsigned char *skip;  // nodes whose rows are not rows of A in this solve (touched by dynamic hits: they are
+                                // swept by k_gs_touched); nullptr when there are none
 };
 
 // one colour of one sweep: wave = one 64-node slice of that colour, lane = node.  The off-diagonal row sum is
@@ -911,6 +913,7 @@ __global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nsli
     double LUx[3];
     sell_row(a.S, s, lane, a.x, LUx);
     if (v < 0 || done_flag) return;
+    if (a.skip && a.skip[v]) return;
     if (a.pin_flag && a.pin_flag[v]) { // :111-117
 #pragma unroll
         for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = a.pin_xyz[3 * (size_t)v + q];
@@ -1087,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_gs_check2(Gs2Args a2, int parity) {
 // residual test of one sweep (:136-140): partial sums of |b - A x|^2 and |b|^2
 __global__ __launch_bounds__(256) void k_gs_resid(SellA A, const double *__restrict__ m, const double *__restrict__ b,
                                                   const double *__restrict__ x, double *__restrict__ part, int NB,
-                                                  const int *__restrict__ done) {
+                                                  const int *__restrict__ done, const unsigned char *__restrict__ skip) {
     __shared__ double lds[8];
     const int done_flag = *done;   // consulted only before the partials are written
     const int lane = threadIdx.x & 63;
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_gs_resid(SellA A, const double *__restr
                 const size_t i = 3 * (size_t)row + j;
                 const double bi = b[i];
                 const double ri = bi - fma(m[i], x[i], acc[j]);
-                q[0] = fma(ri, ri, q[0]);
+                if (!(skip && skip[row])) q[0] = fma(ri, ri, q[0]);   // rows touched by dynamic hits: k_gs_touched_resid
                 q[1] = fma(bi, bi, q[1]);
             }
         }

@@ -159,10 +159,11 @@ int admm_hip_set_surface_inds(admm_hip_ctx *ctx, int32_t n, const int32_t *inds)
  * triangles, outward) index the mesh's OWN vertices; node id = local id + vert_offset.  At every ADMM iteration
  * Collider::detect (src/Collider.hpp:166-168,192-201) refits the tet tree and runs TetMeshCollision::signed_distance
  * (src/DynamicObject.hpp:72-119) for every candidate vertex; hits become the dynamic rows of
- * ConstraintSet::make_matrix (src/ConstraintSet.hpp:92-110).  linsolver 2 only: 0 fails with the reference's
- * "No collisions with LDLT solver" (src/Solver.cpp:249-254), 1 (A + C^T C re-coloured at every solve,
- * src/NodalMultiColorGS.hpp:80-86) is not implemented and says so.  Call after admm_hip_create, in
- * add_dynamic_collider order. */
+ * ConstraintSet::make_matrix (src/ConstraintSet.hpp:92-110): hard constraints of the Schur CG with linsolver 2
+ * (src/UzawaCG.hpp), the penalty A + C^T C swept by the multi-colour GS with linsolver 1
+ * (src/NodalMultiColorGS.hpp:75-86; the matrix is not formed and not re-coloured as a whole: only the nodes of the
+ * hits are re-coloured, see csrc/dyn_collide.hpp).  linsolver 0 fails with the reference's "No collisions with LDLT
+ * solver" (src/Solver.cpp:249-254).  Call after admm_hip_create, in add_dynamic_collider order. */
 int admm_hip_add_dynamic_tetmesh(admm_hip_ctx *ctx, int32_t vert_offset, int32_t n_verts, const double *rest_verts,
                                  int32_t n_tets, const int32_t *tets, int32_t n_faces, const int32_t *faces);
 

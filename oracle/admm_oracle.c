@@ -749,3 +749,64 @@ void orc_detect_dynamic(int nq, const int32_t *query, const double *x, int vert_
         (void)bproj;
     }
 }
+
+/* NodalMultiColorGS::solve on a GENERAL dof x dof matrix (src/NodalMultiColorGS.hpp:60-146, segment_update :180-215,
+ * constrained_segment_update :218-262): the sweeps after "A <- A + C^T C" for dynamic hits (:80-86), where the rows
+ * of a node are no longer three copies of one scalar row.  M in CSR (3 nv rows); everything else as orc_gs_solve.
+ * The re-colouring of M (:85, mclscene, ABSENT) is an input. */
+int orc_gs_solve_full(int nv, const int32_t *rp, const int32_t *ci, const double *val,
+                      const double *b, double *x,
+                      int ncolors, const int32_t *cptr, const int32_t *cnodes,
+                      const int32_t *pin_flag, const double *pin_xyz,
+                      int nobj, const int32_t *okind, const double *opar,
+                      double omega, int max_iters, double tol) {
+    double bnorm = 1.0, tol2 = tol * tol;
+    if (tol > 0) { bnorm = 0.0; for (int i = 0; i < 3 * nv; ++i) bnorm += b[i] * b[i]; }
+    int iter = 0;
+    for (; iter < max_iters; ++iter) {
+        for (int c = 0; c < ncolors; ++c) {
+            int beg = cptr[c], end = cptr[c + 1];
+#pragma omp parallel for schedule(static) if (end - beg > 31)
+            for (int ii = beg; ii < end; ++ii) {
+                int v = cnodes[ii];
+                if (pin_flag && pin_flag[v]) { for (int s = 0; s < 3; ++s) x[3 * v + s] = pin_xyz[3 * v + s]; continue; }
+                double LUx[3] = {0, 0, 0}, aii[3] = {0, 0, 0}, nx[3], jac[3];
+                for (int s = 0; s < 3; ++s) {
+                    int row = 3 * v + s;
+                    for (int k = rp[row]; k < rp[row + 1]; ++k) {
+                        if (fabs(val[k]) <= 0.0) continue;              /* :194 */
+                        if (ci[k] == row) { aii[s] = val[k]; continue; }
+                        LUx[s] += val[k] * x[ci[k]];
+                    }
+                }
+                for (int s = 0; s < 3; ++s) {
+                    jac[s] = (b[3 * v + s] - LUx[s]) / aii[s];
+                    nx[s] = (1.0 - omega) * x[3 * v + s] + omega * jac[s]; /* :210 */
+                }
+                double n[3], p[3];
+                if (nobj > 0 && passive_hit(nobj, okind, opar, nx, n, p)) {
+                    double dx[3], nn[3] = {0, 0, 0}, uu[3], vv[3];
+                    for (int s = 0; s < 3; ++s) dx[s] = jac[s] - p[s];
+                    if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0;
+                    cross3(nn, n, uu); double l = norm3(uu); for (int s = 0; s < 3; ++s) uu[s] /= l;
+                    cross3(n, uu, vv); l = norm3(vv); for (int s = 0; s < 3; ++s) vv[s] /= l;
+                    double t0 = uu[0] * dx[0] + uu[1] * dx[1] + uu[2] * dx[2];
+                    double t1 = vv[0] * dx[0] + vv[1] * dx[1] + vv[2] * dx[2];
+                    for (int s = 0; s < 3; ++s) nx[s] = uu[s] * t0 + vv[s] * t1 + p[s];
+                }
+                for (int s = 0; s < 3; ++s) x[3 * v + s] = nx[s];
+            }
+        }
+        if (tol > 0) { /* :136-140 */
+            double err = 0.0;
+#pragma omp parallel for schedule(static) reduction(+:err)
+            for (int row = 0; row < 3 * nv; ++row) {
+                double a = 0.0;
+                for (int k = rp[row]; k < rp[row + 1]; ++k) a += val[k] * x[ci[k]];
+                double r = b[row] - a; err += r * r;
+            }
+            if (err / bnorm < tol2) break;
+        }
+    }
+    return iter;
+}

@@ -77,6 +77,9 @@ def lib():
         L.orc_gs_solve.argtypes = [C.c_int, ip, ip, dp, dp, dp, C.c_int, ip, ip, ip, dp, C.c_int, ip, dp,
                                    C.c_double, C.c_int, C.c_double]
         L.orc_gs_solve.restype = C.c_int
+        L.orc_gs_solve_full.argtypes = [C.c_int, ip, ip, dp, dp, dp, C.c_int, ip, ip, ip, dp, C.c_int, ip, dp,
+                                        C.c_double, C.c_int, C.c_double]
+        L.orc_gs_solve_full.restype = C.c_int
         L.orc_detect_dynamic.argtypes = [C.c_int, ip, dp, C.c_int, dp, C.c_int, ip, C.c_int, ip, ip, ip, dp, dp, dp]
         _lib = L
     return _lib
@@ -175,6 +178,40 @@ def tri_rest(verts, tris):
 PIN_WEIGHT = np.sqrt(lame(10000000.0, 0.499)[2] * 2.0)  # src/SpringEnergyTerm.hpp:47-52
 
 
+def recolor_touched(base_colors, Ah, dhits):
+    """Colouring of A + C^T C (NodalMultiColorGS.hpp:85; the reference's colouring library is ABSENT, so this rule is
+    the build's own, shared with the GPU): nodes that no hit touches keep their colour (their rows are rows of A);
+    the touched nodes (hit vertex + the three face vertices) are taken out and coloured again, in increasing node
+    order, first-fit over NEW colours placed after the old ones, two touched nodes conflicting when they share a hit
+    or a non-zero of Ahat.  Sweep order: old colours (without the touched nodes), then the new ones."""
+    colors = np.array(base_colors, dtype=np.int32).copy()
+    K = int(colors.max()) + 1
+    touched = sorted({int(v) for h in dhits for v in [h[0], *h[2]]})
+    tset = {v: i for i, v in enumerate(touched)}
+    adj = [set() for _ in touched]
+    for h in dhits:
+        nodes = [int(h[0])] + [int(f) for f in h[2]]
+        for a in nodes:
+            for bb in nodes:
+                if a != bb:
+                    adj[tset[a]].add(tset[bb])
+    for v in touched:
+        for k in range(Ah.indptr[v], Ah.indptr[v + 1]):
+            j = int(Ah.indices[k])
+            if j != v and j in tset and Ah.data[k] != 0.0:
+                adj[tset[v]].add(tset[j])
+    extra = [-1] * len(touched)
+    for i in range(len(touched)):
+        used = {extra[j] for j in adj[i] if extra[j] >= 0}
+        e = 0
+        while e in used:
+            e += 1
+        extra[i] = e
+    for i, v in enumerate(touched):
+        colors[v] = K + extra[i]
+    return colors
+
+
 class OracleSolver:
     """Restatement of admm::Solver for tets / tris / pins / Floor / Sphere."""
 
@@ -202,8 +239,6 @@ class OracleSolver:
                              faces=np.ascontiguousarray(d["faces"], dtype=np.int32).reshape(-1, 3)) for d in dynamic]
         self.surface_inds = None if surface_inds is None or len(surface_inds) == 0 else \
             np.ascontiguousarray(surface_inds, dtype=np.int32)
-        if self.dynamic and linsolver == 1:
-            raise NotImplementedError("oracle: dynamic colliders with NodalMultiColorGS (A + C^T C, re-colouring) not restated")
         self._dhits = []
         if self.obstacles and linsolver == 0:
             raise RuntimeError("**Solver::add_obstacle Error: No collisions with LDLT solver")
@@ -435,6 +470,22 @@ class OracleSolver:
         opar = np.ascontiguousarray(np.array([o[1] for o in self.obstacles], dtype=np.float64).reshape(-1, 4))
         x = np.ascontiguousarray(x).copy()
         b = np.ascontiguousarray(b)
+        if self._dhits:
+            # dynamic hits: A <- A + C^T C, b <- b + C^T c (c = 0), re-colour (NodalMultiColorGS.hpp:80-86)
+            Cm, c = self.make_matrix([], self._dhits)
+            M = (self.A + Cm.T @ Cm).tocsr(); M.sort_indices()
+            colors = recolor_touched(self.gs_colors, self.Ah, self._dhits)
+            nc2 = int(colors.max()) + 1
+            order2 = np.argsort(colors, kind="stable").astype(np.int32)
+            cptr2 = np.zeros(nc2 + 1, dtype=np.int32)
+            np.cumsum(np.bincount(colors, minlength=nc2), out=cptr2[1:])
+            b2 = np.ascontiguousarray(b + Cm.T @ c)
+            it = L.orc_gs_solve_full(self.nv, _i(np.ascontiguousarray(M.indptr, dtype=np.int32)),
+                                     _i(np.ascontiguousarray(M.indices, dtype=np.int32)), _p(np.ascontiguousarray(M.data)), _p(b2), _p(x),
+                                     nc2, _i(cptr2), _i(order2), _i(pin_flag) if self.pins else None, _p(pin_xyz), len(self.obstacles),
+                                     _i(okind) if len(okind) else None, _p(opar) if len(okind) else None,
+                                     self.gs_omega, self.gs_max_iters, self.gs_tol)
+            return x, it
         rp = np.ascontiguousarray(self.Ah.indptr, dtype=np.int32); ci = np.ascontiguousarray(self.Ah.indices, dtype=np.int32)
         va = np.ascontiguousarray(self.Ah.data)
         it = L.orc_gs_solve(self.nv, _i(rp), _i(ci), _p(va), _p(b), _p(x), nc, _i(cptr), _i(order),

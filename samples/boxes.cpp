@@ -1,10 +1,9 @@
 // Headless version of the reference's samples/tvcg2017/boxes.cpp: two unit boxes with self-collision proxies
 // (binding::add_tetmesh without NOSELFCOLLISION registers a TetMeshCollision per mesh), the second one two units above
 // the first, Lame::rubber(), a Floor at y = -1: the lower box lands on the floor, the upper one on the lower one.
-// The reference's sample loads samples/data/box768 (768 tets) and runs the multi-colour GS (-ls 1); here the boxes
-// come from factory::make_tet_blocks (5^3 cells = 750 tets) and the default solver is UzawaCG (-ls 2, the set-up of
-// tvcg2017/torus.cpp): dynamic rows inside the GS sweeps (A + C^T C, re-coloured at every solve) are not implemented
-// on the GPU and the library says so.
+// The reference's sample loads samples/data/box768 (768 tets); here the boxes come from factory::make_tet_blocks
+// (5^3 cells = 750 tets).  Default solver as in the reference: the multi-colour GS (-ls 1) with the collision penalty
+// C^T C added to the rows of the touched nodes; -ls 2 (UzawaCG, the set-up of tvcg2017/torus.cpp) works as well.
 //   usage: boxes [Settings flags] [--frames N] [--cells M] [--gap G] [--out prefix]
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +16,7 @@ using namespace admm;
 
 int main(int argc, char **argv) {
     Solver::Settings settings;
-    settings.linsolver = 2;
+    settings.linsolver = 1; // NCMCGS (boxes.cpp:46)
     int frames = 48, cells = 5;
     double gap = 2.0;   // the reference's trans_up = i * 2
     std::string out;

@@ -94,10 +94,26 @@ def test_oracle_dynamic_rows():
     assert Cm2.shape[0] == 1 + len(dh) and Cm2[1].nnz == 0 and Cm2[0].nnz == 3
 
 
-def test_oracle_gs_with_dynamic_colliders_is_not_restated():
-    sc = scenes.two_blocks_scene(2, linsolver=1)
-    with pytest.raises(NotImplementedError):
-        sc.make_oracle(gs_colors=np.zeros(len(sc.x), np.int32))
+def test_oracle_gs_recolouring_rule():
+    """NodalMultiColorGS.hpp:80-86 re-colours A + C^T C (library absent).  The build's rule: untouched nodes keep their
+    colour, touched nodes get new colours after the old ones, first fit in node order; the result is a proper colouring
+    of the node graph of A + C^T C."""
+    sc = scenes.two_blocks_scene(3, linsolver=1)
+    s = sc.make_solver(init=False)
+    from admm_elastic_amd import capi
+    rp, ci, _ = s.host_matrix(sc.product_settings)
+    base, _ = capi.greedy_coloring(rp, ci)
+    o = sc.make_oracle(gs_colors=base)
+    dh = o.detect_dynamic(o.x)
+    col = orc.recolor_touched(base, o.Ah, dh)
+    touched = sorted({int(v) for h in dh for v in [h[0], *h[2]]})
+    K = base.max() + 1
+    assert (col[touched] >= K).all() and (np.delete(col, touched) == np.delete(base, touched)).all()
+    Cm, _ = o.make_matrix([], dh)
+    M = (o.A + Cm.T @ Cm).tocoo()
+    a, b = M.row // 3, M.col // 3
+    off = (a != b) & (M.data != 0)
+    assert (col[a[off]] != col[b[off]]).all()
 
 
 # ------------------------------------------------------------------------------------------ GPU: parity with the oracle
@@ -188,6 +204,63 @@ def test_step_with_self_collision():
     assert X[nvb:, 1].min() > X[:nvb, 1].mean()
 
 
+def _gs_pair(n, floor, **kw):
+    """GPU solver + oracle on the two-blocks scene with the multi-colour GS, sharing the base colouring"""
+    sc = scenes.two_blocks_scene(n, floor=floor, linsolver=1, **kw)
+    s = sc.make_solver()
+    o = sc.make_oracle(gs_colors=s.gs_colors()[0])
+    return sc, s, o
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("floor", [None, 0.02])
+def test_global_solve_gs_dynamic_rows(floor):
+    """NodalMultiColorGS::solve with dynamic hits (NodalMultiColorGS.hpp:75-146): A + C^T C swept colour by colour --
+    the GPU never forms the matrix (untouched rows from the SELL, touched rows from their hits), the oracle does;
+    sweep for sweep on the shared colouring, with and without in-sweep floor projection."""
+    sc, s, o = _gs_pair(3, floor)
+    rng = np.random.default_rng(4)
+    x = sc.x.ravel().copy()
+    b = o.A @ (x + 0.001 * rng.standard_normal(x.size))
+    o._dhits = o.detect_dynamic(x)
+    assert len(o._dhits) > 5
+    xo, ito = o.solve_gs(x, b)
+    xg, itg = s.global_solve(b, x)
+    assert itg == ito == 30
+    assert np.abs(xg - xo).max() < 1e-9, np.abs(xg - xo).max()
+    # the penalty acts: the same solve without the proxies leaves the blocks interpenetrating
+    o._dhits = []
+    xfree, _ = o.solve_gs(x, b)
+    assert np.abs(xg - xfree).max() > 1e-3
+    if floor is not None:      # vertices projected on the floor never satisfy their row: no convergence to test
+        return
+    # a converging case: the residual test of A + C^T C stops both at the same sweep
+    sc2 = scenes.two_blocks_scene(3, floor=floor, linsolver=1)
+    s2 = sc2.make_solver(gs_tol=1e-3, gs_max_iters=200)
+    o2 = sc2.make_oracle(gs_colors=s2.gs_colors()[0], gs_tol=1e-3, gs_max_iters=200)
+    o2._dhits = o2.detect_dynamic(x)
+    xo2, ito2 = o2.solve_gs(x, b)
+    xg2, itg2 = s2.global_solve(b, x)
+    assert 0 < ito2 < 200 and itg2 == ito2
+    assert np.abs(xg2 - xo2).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_step_gs_with_self_collision():
+    """Whole steps with -ls 1 (the reference's boxes.cpp set-up).  First frame tight, later frames loose (active set)."""
+    sc, s, o = _gs_pair(3, -0.3)
+    s.step(); o.step()
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7
+    dyn_frames = 0
+    for _ in range(14):
+        s.step(); o.step()
+        dyn_frames += 1 if len(o._dhits) else 0
+    assert dyn_frames >= 1 and np.isfinite(s.m_x).all()
+    assert scenes.rel_err(s.m_x, o.x) < 5e-2
+    X = s.m_x.reshape(-1, 3); nvb = len(X) // 2
+    assert X[nvb:, 1].min() > X[:nvb, 1].mean()
+
+
 @pytest.mark.gpu
 def test_surface_inds_restrict_passive_detection():
     """Collider.hpp:157,163: with Solver::surface_inds set, only those vertices are tested against the obstacles."""
@@ -210,9 +283,6 @@ def test_surface_inds_restrict_passive_detection():
 def test_dynamic_collider_errors():
     sc = scenes.two_blocks_scene(2, linsolver=0, floor=None)
     with pytest.raises(AdmmHipError, match="No collisions with LDLT solver"):      # Solver.cpp:249-254
-        sc.make_solver()
-    sc = scenes.two_blocks_scene(2, linsolver=1, floor=None)
-    with pytest.raises(AdmmHipError, match="not implemented"):
         sc.make_solver()
     sc = scenes.two_blocks_scene(2, floor=None)
     sc.dynamic[0]["faces"] = np.zeros((0, 3), np.int32)

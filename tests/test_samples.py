@@ -110,13 +110,15 @@ def test_trianglestrain_sample_runs(tmp_path, ls):
 
 
 @pytest.mark.gpu
-def test_boxes_sample_stacks(tmp_path):
-    """samples/boxes.cpp (tvcg2017/boxes.cpp headless, UzawaCG): binding::add_tetmesh registers a TetMeshCollision per box;
-    the lower box lands on the floor, the upper one on the lower one instead of falling through it.  Without the
-    dynamic colliders (checked with the same scene in Python) the upper box does pass through."""
+@pytest.mark.parametrize("ls", [1, 2])
+def test_boxes_sample_stacks(tmp_path, ls):
+    """samples/boxes.cpp (tvcg2017/boxes.cpp headless): binding::add_tetmesh registers a TetMeshCollision per box; the lower
+    box lands on the floor, the upper one on the lower one instead of falling through it -- with the reference's default
+    solver (-ls 1, penalty rows inside the GS sweeps) and with UzawaCG (-ls 2, hard constraints)."""
     exe = _sample("boxes")
     out = str(tmp_path / "boxes")
-    r = subprocess.run([exe, "-v", "0", "--frames", "40", "--cells", "4", "--gap", "1.3", "--out", out], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, "-ls", str(ls), "-v", "0", "--frames", "40", "--cells", "4", "--gap", "1.3", "--out", out],
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
     X = np.loadtxt(out + ".xyz")
     nv = 5 ** 3
