@@ -33,7 +33,7 @@ def test_mesh_layer_cpu(tmp_path):
 
 
 def test_samples_build_and_print_help():
-    for name in ("beams", "trianglestrain", "boxes"):
+    for name in ("beams", "trianglestrain", "boxes", "bunnyexpand"):
         exe = _sample(name)
         r = subprocess.run([exe, "-help"], capture_output=True, text=True, timeout=60)
         assert r.returncode == 0 and "-it" in (r.stdout + r.stderr)
@@ -128,3 +128,17 @@ def test_boxes_sample_stacks(tmp_path, ls):
     assert lower[:, 1].min() < -0.9                              # ... and it did fall (started at -0.5)
     assert upper[:, 1].min() > lower[:, 1].mean()                # the upper box rests on / above the lower one
     assert upper[:, 1].min() < 0.5                               # ... after falling from 0.8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["rand", "point"])
+def test_bunnyexpand_sample_recovers(mode):
+    """samples/bunnyexpand.cpp (sca2016/bunnyexpand.cpp headless): all vertices scrambled / collapsed to a point, no
+    gravity -- the Neo-Hookean prox brings every tet back through inversion to its rest shape."""
+    exe = _sample("bunnyexpand")
+    r = subprocess.run([exe, mode, "-v", "0", "--frames", "60", "--cells", "4", "--size", "1", "--lame", "soft"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    last = [ln for ln in r.stdout.splitlines() if ln.startswith("bunnyexpand:")][-1]
+    inverted = int(last.split(" frames, ")[1].split(" tets")[0])
+    worst = float(last.rsplit(" ", 1)[1])
+    assert inverted == 0 and worst < 1e-3, last
