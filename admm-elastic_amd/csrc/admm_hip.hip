@@ -126,7 +126,7 @@ struct admm_hip_ctx {
     DevBuf<double> x, v, m, Mxbar, curr, b, dinv;
     // tets (sorted by constitutive model; perm[new] = caller's index)
     int nt = 0, ldt = 0;
-    int kind_begin[4] = {0, 0, 0, 0}; // [linear | NH (+spline) | StVK | end]
+    int kind_begin[5] = {0, 0, 0, 0, 0}; // [linear | NH (+ NH spline) | StVK (+ StVK spline) | co-rotated spline | end]
     std::vector<int> tet_perm;
     DevBuf<int4> t_idx;
     DevBuf<double> t_Binv, t_u, t_z, t_sc, t_cf;
@@ -257,7 +257,10 @@ void launch_local(admm_hip_ctx *c) {
     if (c->nt > 0) {
         const int b0 = c->kind_begin[0], b1 = c->kind_begin[1], b2 = c->kind_begin[2], b3 = c->kind_begin[3];
         const TetArgs a{c->ldt, c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p};
+        const int b4 = c->kind_begin[4];
         const int kinds = (b1 > b0) + (b2 > b1) + (b3 > b2);
+        if (b4 > b3)      // co-rotated spline tets: their own launch (no BASELINE config mixes them in)
+            hipLaunchKernelGGL((k_local_tets<3, WRITE_Z>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, b3, b4, a);
         if (kinds >= 2) { // mixed scene: one launch over all models
             const int n0 = blocks_for(b1 - b0), n1 = blocks_for(b2 - b1), n2 = blocks_for(b3 - b2);
             hipLaunchKernelGGL((k_local_tets_fused<WRITE_Z>), dim3(n0 + n1 + n2), dim3(256), 0, st, b0, b1, b2, b3, n0, n0 + n1, a);
@@ -804,7 +807,7 @@ int validate(const admm_hip_desc *d) {
         if (d->tri_idx[i] < 0 || d->tri_idx[i] >= d->n_verts) return fail(ADMM_HIP_ERR_ARG, "tri index out of range");
     for (int i = 0; i < d->n_tets; ++i) {
         if (!(d->tet_weight[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "Some weight leq 0 (EnergyTerm.hpp:124-126)");
-        if (d->tet_kind[i] < 0 || d->tet_kind[i] > 3) return fail(ADMM_HIP_ERR_ARG, "unknown tet kind");
+        if (d->tet_kind[i] < 0 || d->tet_kind[i] > ADMM_TET_SPLINE_COROTATED) return fail(ADMM_HIP_ERR_ARG, "unknown tet kind");
     }
     for (int i = 0; i < d->n_tris; ++i) {
         if (!(d->tri_weight[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "Some weight leq 0 (EnergyTerm.hpp:124-126)");
@@ -875,13 +878,16 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     c->nt = te - tb; c->ldt = c->nt + 1;
     if (c->nt > 0) {
         const int nt = c->nt, ld = c->ldt;
-        auto grp = [&](int k) { return k == ADMM_TET_LINEAR ? 0 : (k == ADMM_TET_STVK ? 2 : 1); };
+        auto grp = [&](int k) {   // xu::NeoHookean / xu::StVK splines (kappa = 0) ARE the NH / StVK models
+            return k == ADMM_TET_LINEAR ? 0 : (k == ADMM_TET_STVK || k == ADMM_TET_SPLINE_STVK) ? 2 : k == ADMM_TET_SPLINE_COROTATED ? 3 : 1;
+        };
         c->tet_perm.resize(nt);
         std::iota(c->tet_perm.begin(), c->tet_perm.end(), tb);
         std::stable_sort(c->tet_perm.begin(), c->tet_perm.end(), [&](int a, int b) { return grp(d->tet_kind[a]) < grp(d->tet_kind[b]); });
-        int cnt[3] = {0, 0, 0};
+        int cnt[4] = {0, 0, 0, 0};
         for (int t = tb; t < te; ++t) cnt[grp(d->tet_kind[t])]++;
-        c->kind_begin[0] = 0; c->kind_begin[1] = cnt[0]; c->kind_begin[2] = cnt[0] + cnt[1]; c->kind_begin[3] = nt;
+        c->kind_begin[0] = 0; c->kind_begin[1] = cnt[0]; c->kind_begin[2] = cnt[0] + cnt[1]; c->kind_begin[3] = cnt[0] + cnt[1] + cnt[2];
+        c->kind_begin[4] = nt;
         std::map<std::tuple<double, double, double>, int> mat_map;
         std::vector<Mat> mats;
         std::vector<int4> idx(nt);

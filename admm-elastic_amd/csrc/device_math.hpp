@@ -223,6 +223,7 @@ __device__ __forceinline__ void usvt(const double *U, const double *s, const dou
 // ---- principal-stretch objectives --------------------------------------------------------------
 // KIND 1: Neo-Hookean  Psi = mu/2 (I1 - ln I3 - 3) + lambda/8 ln^2 I3     (TetEnergyTerm.cpp:173-182)
 // KIND 2: StVK         Psi = mu |E|^2 + lambda/2 tr(E)^2, E_i=(s_i^2-1)/2  (TetEnergyTerm.cpp:220-226)
+// KIND 3: co-rotated   Psi = mu sum (s_i-1)^2 + lambda/2 (sum s_i - 3)^2   (SplineTet with xu::CoRotated, kappa = 0)
 // objective = Psi(s) + k/2 |s - x0|^2                                      (:184-192, :210-218)
 // The model is templated on the scalar type: the same Newton runs first in FP32 (cheap iterations that
 // get within ~1e-6 of the minimiser) and then in FP64 (one or two polishing iterations).  Newton is
@@ -283,6 +284,22 @@ struct StretchModel {
                 q = t_fma(d, d, q);
             }
             return T(0.5) * mu * (f - T(3)) - mu * lJ + T(0.5) * la * lJ * lJ + T(0.5) * k * q;
+        } else if (KIND == 3) {
+            // co-rotated linear: Psi = mu sum (s_i - 1)^2 + la/2 (sum s_i - 3)^2  (xu::CoRotated, XuSpline.hpp:84-96,
+            // with kappa = 0: sum f(s_i) + sum g(s_i s_j) collapses to this); quadratic, H = (2 mu + k) I + la 1 1^T
+            const T tr = s[0] + s[1] + s[2] - T(3);
+            T ee = T(0), q = T(0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const T e = s[i] - T(1);
+                const T d = s[i] - x0[i];
+                w[i] = T(1);
+                g[i] = t_fma(T(2) * mu, e, t_fma(la, tr, k * d));
+                D[i] = t_fma(T(2), mu, k);
+                ee = t_fma(e, e, ee);
+                q = t_fma(d, d, q);
+            }
+            return mu * ee + T(0.5) * la * tr * tr + T(0.5) * k * q;
         } else {
             const T ss = s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
             const T trE = T(0.5) * (ss - T(3));
@@ -300,7 +317,7 @@ struct StretchModel {
             return mu * ee + T(0.5) * la * trE * trE + T(0.5) * k * q;
         }
     }
-    // NH needs s > 0 (log barrier); StVK accepts s >= 0 (value() returns FLT_MAX only for s < 0)
+    // NH needs s > 0 (log barrier); StVK / co-rotated accept s >= 0 (value() returns FLT_MAX only for s < 0)
     __device__ __forceinline__ bool feasible(const T *s) const {
         if (KIND == 1) return s[0] > T(0) && s[1] > T(0) && s[2] > T(0);
         return s[0] >= T(0) && s[1] >= T(0) && s[2] >= T(0);
@@ -330,7 +347,7 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const T Di = t_max(t_abs(D[i]), floorD);
-            const bool active = (KIND == 2) && (s[i] <= T(0)) && (g[i] > T(0));
+            const bool active = (KIND >= 2) && (s[i] <= T(0)) && (g[i] > T(0));
             pure = pure && !active && (D[i] >= floorD);
             a[i] = active ? T(0) : t_rcp(Di);
             y[i] = g[i] * a[i];
@@ -362,7 +379,7 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
         if (dmax <= (pure ? t_max(tol_final * smin * smin, tol_floor) : tol_floor) * mag) { // final correction: apply and stop
             T sn[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (KIND == 2) sn[i] = t_max(sn[i], T(0)); }
+            for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (KIND >= 2) sn[i] = t_max(sn[i], T(0)); }
             if (m.feasible(sn)) {
 #pragma unroll
                 for (int i = 0; i < 3; ++i) s[i] = sn[i];
@@ -378,7 +395,7 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 sn[i] = t_fma(t, d[i], s[i]);
-                if (KIND == 2) sn[i] = t_max(sn[i], T(0));
+                if (KIND >= 2) sn[i] = t_max(sn[i], T(0));
                 gs = t_fma(g[i], sn[i] - s[i], gs);
             }
             if (m.feasible(sn)) {
@@ -440,7 +457,7 @@ __device__ __forceinline__ int minimize_stretch(double mu, double la, double k, 
 // Prox in principal stretches.  S (in) = signed stretches of q = D_i x + u_i; S (out) = stretches of z.
 // KIND 0, linear tet (src/TetEnergyTerm.cpp:73-92): z = (P + q)/2 with P = U V^T (signed factors)
 //         == U diag((1 + S)/2) V^T.
-// KIND 1/2, hyperelastic (src/TetEnergyTerm.cpp:114-136): minimise over the stretches.
+// KIND 1/2/3, hyperelastic (src/TetEnergyTerm.cpp:114-136): minimise over the stretches.
 template <int KIND>
 __device__ __forceinline__ void prox_stretches(double mu, double la, double k, double *S) {
     if (KIND == 0) {

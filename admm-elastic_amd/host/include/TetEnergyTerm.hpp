@@ -2,7 +2,9 @@
 #ifndef ADMM_TETENERGYTERM_HPP
 #define ADMM_TETENERGYTERM_HPP 1
 
+#include <memory>
 #include "EnergyTerm.hpp"
+#include "XuSpline.hpp"
 
 namespace admm {
 
@@ -12,7 +14,7 @@ public:
     TetEnergyTerm(const Vec4i &tet, const std::vector<Vec3> &verts, const Lame &lame);
     int get_dim() const { return 9; }
     double get_weight() const { return weight; }
-    bool flatten(FlatTerm &out) const;
+    virtual bool flatten(FlatTerm &out) const;
     virtual int kind() const { return 0; } // ADMM_TET_LINEAR
 protected:
     void get_reduction(std::vector<Triplet> &triplets);
@@ -42,12 +44,20 @@ protected:
     double energy(const VecX &F);
 };
 
-// src/TetEnergyTerm.hpp:176-206 with its default spline (xu::NeoHookean, kappa = 0).  Custom splines have
-// no GPU kernel and are not offered.
+// src/TetEnergyTerm.hpp:176-206.  Defaults to xu::NeoHookean(mu, lambda, 0) like the reference (:191-195); the second
+// constructor takes one of the reference's splines (XuSpline.hpp).  kappa != 0 or a user-defined spline: no GPU kernel,
+// flatten() returns false and Solver::initialize says so.
 class SplineTet : public NeoHookeanTet {
 public:
-    SplineTet(const Vec4i &tet, const std::vector<Vec3> &verts, const Lame &lame) : NeoHookeanTet(tet, verts, lame) {}
-    int kind() const { return 3; }
+    SplineTet(const Vec4i &tet, const std::vector<Vec3> &verts, const Lame &lame)
+        : NeoHookeanTet(tet, verts, lame), spline(std::make_shared<xu::NeoHookean>(lame.mu, lame.lambda, 0.0)) {}
+    SplineTet(const Vec4i &tet, const std::vector<Vec3> &verts, const Lame &lame, std::shared_ptr<xu::Spline> spline_)
+        : NeoHookeanTet(tet, verts, lame), spline(spline_) {}
+    int kind() const { int kd = 3; double m, l; spline->flatten(kd, m, l); return kd; }
+    bool flatten(FlatTerm &out) const;
+    std::shared_ptr<xu::Spline> spline;
+protected:
+    double energy(const VecX &F);   // src/TetEnergyTerm.cpp:243-247 on the signed stretches, times the volume
 };
 
 // src/TetEnergyTerm.hpp:35-51

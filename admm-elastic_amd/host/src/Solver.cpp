@@ -198,6 +198,21 @@ double StVKTet::energy(const VecX &F) { // src/TetEnergyTerm.cpp:220-226
     return (lame.mu * dd + 0.5 * lame.lambda * tr * tr) * volume;
 }
 
+bool SplineTet::flatten(FlatTerm &o) const {
+    if (!TetEnergyTerm::flatten(o)) return false;
+    int kd = 0; double m = 0, l = 0;
+    if (!spline || !spline->flatten(kd, m, l)) return false;   // kappa != 0 or a user-defined spline: no kernel
+    o.kind = kd; o.mu = m; o.lambda = l;                       // the spline's constants; k stays the tet's (TetEnergyTerm.hpp:192-204)
+    return true;
+}
+double SplineTet::energy(const VecX &F) {
+    double U[9], S[3], V[9];
+    host_signed_svd3(F.data(), U, S, V);
+    if (S[2] < 0) S[2] = -S[2];
+    return (spline->f(S[0]) + spline->f(S[1]) + spline->f(S[2]) + spline->g(S[0] * S[1]) + spline->g(S[1] * S[2]) + spline->g(S[2] * S[0]) +
+            spline->h(S[0] * S[1] * S[2])) * volume;
+}
+
 // ---------------------------------------------------------------- tris / pins -----------------------
 TriEnergyTerm::TriEnergyTerm(const Vec3i &tri_, const std::vector<Vec3> &verts, const Lame &lame_)
     : tri(tri_), lame(lame_), area(0.0), weight(0.0) {

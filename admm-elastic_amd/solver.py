@@ -11,7 +11,7 @@ import numpy as np
 from . import capi
 from .capi import AdmmHipError, Desc, Stats, check, dptr, f64, i32, iptr, lib
 
-TET_LINEAR, TET_NEOHOOKEAN, TET_STVK, TET_SPLINE_NH = 0, 1, 2, 3
+TET_LINEAR, TET_NEOHOOKEAN, TET_STVK, TET_SPLINE_NH, TET_SPLINE_STVK, TET_SPLINE_COROTATED = 0, 1, 2, 3, 4, 5
 LS_LDLT, LS_NCMCGS, LS_UZAWACG = 0, 1, 2
 
 
@@ -151,17 +151,20 @@ class Solver:
         self.m_masses = np.concatenate([self.m_masses, m])
         return self.m_x.size // 3
 
-    def add_tets(self, verts, inds, lame, kind=TET_LINEAR, vertex_offset=0):
+    def add_tets(self, verts, inds, lame, kind=TET_LINEAR, vertex_offset=0, spline=None):
         """create_tets_from_mesh<IN_SCALAR,TYPE> (src/TetEnergyTerm.hpp:35-51) + the TetEnergyTerm ctor
         (src/TetEnergyTerm.cpp:31-48).  verts are the REST positions the indices refer to; kind selects
-        TetEnergyTerm / NeoHookeanTet / StVKTet / SplineTet.  Raises on an inverted rest tet."""
+        TetEnergyTerm / NeoHookeanTet / StVKTet / SplineTet (TET_SPLINE_*: xu::NeoHookean / StVK / CoRotated with
+        kappa = 0; `spline` = a Lame holding the spline's own mu / lambda, default the tet's, as the SplineTet
+        constructors do, src/TetEnergyTerm.hpp:192-204).  Raises on an inverted rest tet."""
         inds = i32(inds, (-1, 4))
         Binv, vol = capi.tet_rest(verts, inds)
         k = lame.bulk_modulus()
         n = inds.shape[0]
         w = np.sqrt(k * vol)
-        self._tets.append((inds + vertex_offset, Binv, w, np.full(n, kind, np.int32), np.full(n, lame.mu),
-                           np.full(n, lame.lambda_), np.full(n, k)))
+        sp = spline if spline is not None else lame
+        self._tets.append((inds + vertex_offset, Binv, w, np.full(n, kind, np.int32), np.full(n, sp.mu),
+                           np.full(n, sp.lambda_), np.full(n, k)))
         return n
 
     def add_tris(self, verts, inds, lame, vertex_offset=0):

@@ -38,9 +38,14 @@ typedef enum {
     ADMM_HIP_ERR_COMM = -5      /* RCCL failure */
 } admm_hip_status;
 
-/* tet constitutive models -- src/TetEnergyTerm.hpp:57 (linear), :116 (NeoHookean), :142 (StVK),
- * :176 (SplineTet with its default xu::NeoHookean spline, which is algebraically the NH model) */
-enum { ADMM_TET_LINEAR = 0, ADMM_TET_NEOHOOKEAN = 1, ADMM_TET_STVK = 2, ADMM_TET_SPLINE_NH = 3 };
+/* tet constitutive models -- src/TetEnergyTerm.hpp:57 (linear), :116 (NeoHookean), :142 (StVK), :176 (SplineTet).
+ * SplineTet carries an xu::Spline (src/XuSpline.hpp); the three splines the reference ships are accepted with
+ * kappa = 0: xu::NeoHookean (the default, algebraically the NH model), xu::StVK (algebraically the StVK model) and
+ * xu::CoRotated (co-rotated linear: mu sum (s_i-1)^2 + lambda/2 (sum s_i - 3)^2).  tet_mu / tet_lambda are the
+ * SPLINE's constants, tet_k the tet's bulk modulus (src/TetEnergyTerm.hpp:192-204).  User-defined splines and the
+ * kappa compression term (src/XuSpline.hpp:44-45) have no kernel. */
+enum { ADMM_TET_LINEAR = 0, ADMM_TET_NEOHOOKEAN = 1, ADMM_TET_STVK = 2, ADMM_TET_SPLINE_NH = 3, ADMM_TET_SPLINE_STVK = 4,
+       ADMM_TET_SPLINE_COROTATED = 5 };
 
 /* global solvers -- Solver::Settings::linsolver, src/Solver.hpp:46 ("0=LDLT, 1=NCMCGS, 2=UzawaCG").
  * 0: the prefactored LDLT (src/LinearSolver.hpp:59-92) is replaced by a Jacobi-preconditioned CG on

@@ -168,7 +168,8 @@ double orc_energy_tet_linear(const double *F, double k, double vol) {
     return 0.5 * k * vol * e;
 }
 
-/* ---- principal-stretch objectives: kind 1 = NeoHookean, 2 = StVK, 3 = Spline(NH default) ---- */
+/* ---- principal-stretch objectives: kind 1 = NeoHookean, 2 = StVK, 3 / 4 / 5 = SplineTet with xu::NeoHookean (the default) /
+ * xu::StVK / xu::CoRotated, kappa = 0 ---- */
 typedef struct { int kind; double mu, lambda, k; double x0[3]; } prox_problem;
 
 #define ORC_FLT_MAX 3.40282346638528859812e+38 /* std::numeric_limits<float>::max() */
@@ -178,6 +179,31 @@ static double xu_nh_f(double mu, double x) { return 0.5 * mu * (x * x - 1.0); }
 static double xu_nh_h(double mu, double la, double x) { double l = log(x); return -mu * l + 0.5 * la * l * l; }
 static double xu_nh_df(double mu, double x) { return mu * x; }
 static double xu_nh_dh(double mu, double la, double x) { return -mu / x + la * log(x) / x; }
+
+/* Xu spline StVK (src/XuSpline.hpp:64-82) and CoRotated (:84-96), kappa = 0 (no compression term):
+ * Psi = sum f(x_i) + sum g(x_i x_j) + h(x_0 x_1 x_2)  (TetEnergyTerm.cpp:243-247) */
+static double xu_f(int kind, double mu, double la, double x) {
+    if (kind == 3) return xu_nh_f(mu, x);
+    if (kind == 4) { double x2 = x * x; return 0.125 * la * (x2 * x2 - 6.0 * x2 + 5.0) + 0.25 * mu * (x2 - 1.0) * (x2 - 1.0); }
+    return 0.5 * la * (x * x - 6.0 * x + 5.0) + mu * (x - 1.0) * (x - 1.0);
+}
+static double xu_g(int kind, double la, double x) {
+    if (kind == 3) return 0.0;
+    if (kind == 4) return 0.25 * la * (x * x - 1.0);
+    return la * (x - 1.0);
+}
+static double xu_h(int kind, double mu, double la, double x) { return kind == 3 ? xu_nh_h(mu, la, x) : 0.0; }
+static double xu_df(int kind, double mu, double la, double x) {
+    if (kind == 3) return xu_nh_df(mu, x);
+    if (kind == 4) { double x2 = x * x; return 0.125 * la * (4.0 * x2 * x - 12.0 * x) + mu * x * (x2 - 1.0); }
+    return 0.5 * la * (2.0 * x - 6.0) + 2.0 * mu * (x - 1.0);
+}
+static double xu_dg(int kind, double la, double x) {
+    if (kind == 3) return 0.0;
+    if (kind == 4) return 0.5 * la * x;
+    return la;
+}
+static double xu_dh(int kind, double mu, double la, double x) { return kind == 3 ? xu_nh_dh(mu, la, x) : 0.0; }
 
 static double energy_density(const prox_problem *p, const double *x) {
     if (p->kind == 1) { /* TetEnergyTerm.cpp:173-182 */
@@ -189,9 +215,11 @@ static double energy_density(const prox_problem *p, const double *x) {
         double st[3], tr = 0.0, dd = 0.0;
         for (int i = 0; i < 3; ++i) { st[i] = 0.5 * (x[i] * x[i] - 1.0); tr += st[i]; dd += st[i] * st[i]; }
         return p->mu * dd + p->lambda * 0.5 * tr * tr;
-    } else { /* TetEnergyTerm.cpp:243-247 with xu::NeoHookean (g == 0) */
-        return xu_nh_f(p->mu, x[0]) + xu_nh_f(p->mu, x[1]) + xu_nh_f(p->mu, x[2])
-             + xu_nh_h(p->mu, p->lambda, x[0] * x[1] * x[2]);
+    } else { /* TetEnergyTerm.cpp:243-247: kind 3 xu::NeoHookean (g == 0), 4 xu::StVK, 5 xu::CoRotated */
+        const int kd = p->kind;
+        return xu_f(kd, p->mu, p->lambda, x[0]) + xu_f(kd, p->mu, p->lambda, x[1]) + xu_f(kd, p->mu, p->lambda, x[2])
+             + xu_g(kd, p->lambda, x[0] * x[1]) + xu_g(kd, p->lambda, x[1] * x[2]) + xu_g(kd, p->lambda, x[2] * x[0])
+             + xu_h(kd, p->mu, p->lambda, x[0] * x[1] * x[2]);
     }
 }
 
@@ -217,11 +245,12 @@ static double prox_gradient(const prox_problem *p, const double *x, double *g) {
         for (int i = 0; i < 3; ++i)
             g[i] = p->mu * x[i] * (x[i] * x[i] - 1.0) + 0.5 * p->lambda * (xx - 3.0) * x[i]
                  + p->k * (x[i] - p->x0[i]);
-    } else {
-        double hp = xu_nh_dh(p->mu, p->lambda, x[0] * x[1] * x[2]);
-        g[0] = xu_nh_df(p->mu, x[0]) + hp * x[1] * x[2] + p->k * (x[0] - p->x0[0]);
-        g[1] = xu_nh_df(p->mu, x[1]) + hp * x[2] * x[0] + p->k * (x[1] - p->x0[1]);
-        g[2] = xu_nh_df(p->mu, x[2]) + hp * x[0] * x[1] + p->k * (x[2] - p->x0[2]);
+    } else { /* TetEnergyTerm.cpp:259-265 */
+        const int kd = p->kind; const double mu = p->mu, la = p->lambda;
+        double hp = xu_dh(kd, mu, la, x[0] * x[1] * x[2]);
+        g[0] = xu_df(kd, mu, la, x[0]) + xu_dg(kd, la, x[0] * x[1]) * x[1] + xu_dg(kd, la, x[2] * x[0]) * x[2] + hp * x[1] * x[2] + p->k * (x[0] - p->x0[0]);
+        g[1] = xu_df(kd, mu, la, x[1]) + xu_dg(kd, la, x[1] * x[2]) * x[2] + xu_dg(kd, la, x[0] * x[1]) * x[0] + hp * x[2] * x[0] + p->k * (x[1] - p->x0[1]);
+        g[2] = xu_df(kd, mu, la, x[2]) + xu_dg(kd, la, x[2] * x[0]) * x[0] + xu_dg(kd, la, x[1] * x[2]) * x[1] + hp * x[0] * x[1] + p->k * (x[2] - p->x0[2]);
     }
     return prox_value(p, x);
 }
@@ -236,7 +265,11 @@ static void prox_hessian(const prox_problem *p, const double *x, double *H) {
             for (int j = 0; j < 3; ++j) M3(H, i, j) = p->lambda * xi[i] * xi[j];
         for (int i = 0; i < 3; ++i)
             M3(H, i, i) += p->mu * (1.0 + xi[i] * xi[i]) - p->lambda * lJ * xi[i] * xi[i] + p->k;
-    } else {
+    } else if (p->kind == 5) { /* co-rotated: Psi = mu sum (x_i - 1)^2 + lambda/2 (sum x_i - 3)^2, quadratic */
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M3(H, i, j) = p->lambda;
+        for (int i = 0; i < 3; ++i) M3(H, i, i) += 2.0 * p->mu + p->k;
+    } else { /* StVK, also as xu::StVK (kind 4) */
         double xx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) M3(H, i, j) = p->lambda * x[i] * x[j];
@@ -329,7 +362,7 @@ static int lbfgs3(const prox_problem *p, double *x, int max_iters) {
  * frozen and trial points are projected back onto x >= 0. */
 static int newton3(const prox_problem *p, double *x, int max_iters) {
     int it = 0;
-    const int proj = (p->kind == 2);
+    const int proj = (p->kind == 2 || p->kind == 4 || p->kind == 5);   /* no log barrier: the feasible set is x >= 0 */
     for (; it < max_iters; ++it) {
         double g[3], H[9];
         double f = prox_gradient(p, x, g);
@@ -383,7 +416,7 @@ static int newton3(const prox_problem *p, double *x, int max_iters) {
 
 /*
  * src/TetEnergyTerm.cpp:114-136 -- HyperElasticTet::prox.
- * kind 1 NH, 2 StVK, 3 Spline(NH).  mode 0 = reference stop rule only (L-BFGS), mode 1 = "tight"
+ * kind 1 NH, 2 StVK, 3 / 4 / 5 Spline(NH / StVK / CoRotated).  mode 0 = reference stop rule only (L-BFGS), mode 1 = "tight"
  * (L-BFGS then Newton polish to the exact minimiser).  Returns minimiser iterations.
  */
 int orc_prox_tet_hyper(int kind, double mu, double lambda, double k, double *z, int mode) {

@@ -219,7 +219,7 @@ class OracleSolver:
                  tets=None, tris=None, pins=None, obstacles=(), mode=1, gs_colors=None,
                  gs_max_iters=30, gs_tol=1e-10, gs_omega=1.9, uzawa_max_iters=20, uzawa_tol=1e-10, big=False,
                  dynamic=(), surface_inds=None):
-        """tets = dict(idx[n,4], verts(rest), kind[n], mu[n], la[n]); tris = dict(idx[n,3], verts, mu, la,
+        """tets = dict(idx[n,4], verts(rest), kind[n], mu[n], la[n][, k[n]]); tris = dict(idx[n,3], verts, mu, la,
         limit_min, limit_max); pins = {vertex: xyz}; obstacles = [(kind, [4 params])];
         dynamic = [dict(offset, rest[n,3], tets[nt,4] local, faces[nf,3] local)] (TetMeshCollision, in
         add_dynamic_collider order); surface_inds = Solver::surface_inds (None / empty = every vertex);
@@ -256,7 +256,9 @@ class OracleSolver:
             self.t_kind = np.ascontiguousarray(np.broadcast_to(tets["kind"], (self.nt,)), dtype=np.int32)
             self.t_mu = np.ascontiguousarray(np.broadcast_to(tets["mu"], (self.nt,)), dtype=np.float64)
             self.t_la = np.ascontiguousarray(np.broadcast_to(tets["la"], (self.nt,)), dtype=np.float64)
-            self.t_k = self.t_la + (2.0 / 3.0) * self.t_mu
+            # k = the TET's bulk modulus (EnergyTerm.hpp:41); mu / la may be a SplineTet's own spline constants
+            self.t_k = (np.ascontiguousarray(np.broadcast_to(tets["k"], (self.nt,)), dtype=np.float64) if "k" in tets
+                        else self.t_la + (2.0 / 3.0) * self.t_mu)
             self.t_w = np.sqrt(self.t_k * vol)                    # TetEnergyTerm.cpp:46-47
             if np.any(self.t_w <= 0):
                 raise RuntimeError("**EnergyTerm::get_reduction Error: Some weight leq 0")

@@ -41,6 +41,15 @@ def test_cpp_lineartet_known_answers():
 
 def test_cpp_scene_builds():
     _build_exe("test_scene")
+    _build_exe("test_splines")
+
+
+@pytest.mark.gpu
+def test_cpp_spline_tets():
+    """SplineTet with xu::NeoHookean / StVK / CoRotated (src/XuSpline.hpp) on the C++ mirror."""
+    exe = _build_exe("test_splines")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SUCCESS" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu

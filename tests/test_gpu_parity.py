@@ -15,7 +15,8 @@ import scenes
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.npz")
-KINDS = {"linear": pkg.TET_LINEAR, "neohookean": pkg.TET_NEOHOOKEAN, "stvk": pkg.TET_STVK, "spline": pkg.TET_SPLINE_NH}
+KINDS = {"linear": pkg.TET_LINEAR, "neohookean": pkg.TET_NEOHOOKEAN, "stvk": pkg.TET_STVK, "spline": pkg.TET_SPLINE_NH,
+         "spline_stvk": pkg.TET_SPLINE_STVK, "spline_corotated": pkg.TET_SPLINE_COROTATED}
 
 
 def deformed(sc, amp, seed):
@@ -132,6 +133,28 @@ def test_step_parity_cube_ldlt(kind):
     assert np.abs(s.m_v - o.v).max() <= 1e-5 * max(1.0, np.abs(o.v).max())
     assert np.abs(o.x - sc.x.ravel()).max() > 1e-3   # the scene actually moved
     assert s.runtime_data().inner_iters > 0 and s.runtime_data().last_solve_converged == 1
+
+
+@pytest.mark.parametrize("kind", ["spline_stvk", "spline_corotated"])
+def test_step_parity_spline_tets(kind):
+    """SplineTet with xu::StVK / xu::CoRotated (kappa = 0), spline constants different from the tet's Lame
+    (src/TetEnergyTerm.hpp:197-204): whole steps against the oracle, whose objective is pinned on the real XuSpline.hpp."""
+    sc = scenes.cube_scene(4, KINDS[kind], admm_iters=10, linsolver=0)
+    verts, tets, lame, kd, off = sc.tets[0]
+    spline = Lame(2.0e7, 0.3)
+    s = pkg.Solver()
+    s.add_nodes(sc.x, sc.masses3())
+    s.add_tets(verts, tets, lame, kd, spline=spline)
+    s.set_pins(list(sc.pins.keys()), [sc.pins[k] for k in sc.pins])
+    st = scenes.Settings(**sc.settings); st.pcg_tol = 1e-11; st.pcg_max_iters = 400
+    assert s.initialize(st)
+    o = orc.OracleSolver(sc.x, sc.masses3(), admm_iters=10, linsolver=0, pins=sc.pins, mode=1,
+                         tets=dict(idx=tets, verts=sc.x, kind=np.full(len(tets), kd, np.int32), mu=spline.mu, la=spline.lambda_,
+                                   k=lame.bulk_modulus()))
+    for _ in range(4):
+        s.step(); o.step()
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7, scenes.rel_err(s.m_x, o.x)
+    assert np.abs(s.m_x - sc.x.ravel()).max() > 1e-3      # it moved
 
 
 def test_step_parity_mixed_materials():
