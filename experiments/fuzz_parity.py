@@ -1,6 +1,7 @@
 """Randomised GPU-vs-oracle parity sweep (run on a GPU box): random jittered Kuhn meshes, materials, Lame parameters,
 pins, gravity, initial velocities, ADMM iteration counts and global solvers.  Prints the worst position error."""
 import os, sys, time
+os.environ.setdefault("OMP_NUM_THREADS", "8")   # the oracle's GS opens one tiny OpenMP region per colour: 256 host threads make it 100x slower
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import numpy as np
@@ -9,7 +10,7 @@ from admm_elastic_amd import meshes
 from admm_elastic_amd.solver import Lame
 import scenes
 
-KINDS = [pkg.TET_LINEAR, pkg.TET_NEOHOOKEAN, pkg.TET_STVK, pkg.TET_SPLINE_NH]
+KINDS = [pkg.TET_LINEAR, pkg.TET_NEOHOOKEAN, pkg.TET_STVK, pkg.TET_SPLINE_NH, pkg.TET_SPLINE_STVK, pkg.TET_SPLINE_COROTATED]
 seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 worst = 0.0; fails = 0; t0 = time.time()
 for seed in range(seeds):
