@@ -883,7 +883,18 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         };
         c->tet_perm.resize(nt);
         std::iota(c->tet_perm.begin(), c->tet_perm.end(), tb);
-        std::stable_sort(c->tet_perm.begin(), c->tet_perm.end(), [&](int a, int b) { return grp(d->tet_kind[a]) < grp(d->tet_kind[b]); });
+        // inside a model group: by the lowest vertex index (then the index sum), i.e. in the order their vertices are laid out -- the
+        // position gathers of the local step and the corner-force gathers of the RHS then walk memory as coherently as the
+        // caller's vertex numbering allows, whatever order the tets arrive in (shuffled tets of the 1 M-tet cube: local step
+        // 108 -> 71 us, RHS gather 208 -> 45 us; generator order: unchanged)
+        auto vsum = [&](int t) { return (long long)d->tet_idx[4 * (size_t)t] + d->tet_idx[4 * (size_t)t + 1] + d->tet_idx[4 * (size_t)t + 2] + d->tet_idx[4 * (size_t)t + 3]; };
+        auto vmin = [&](int t) { return std::min(std::min(d->tet_idx[4 * (size_t)t], d->tet_idx[4 * (size_t)t + 1]), std::min(d->tet_idx[4 * (size_t)t + 2], d->tet_idx[4 * (size_t)t + 3])); };
+        std::stable_sort(c->tet_perm.begin(), c->tet_perm.end(), [&](int a, int b) {
+            const int ga = grp(d->tet_kind[a]), gb = grp(d->tet_kind[b]);
+            if (ga != gb) return ga < gb;
+            const int ma = vmin(a), mb = vmin(b);
+            return ma != mb ? ma < mb : vsum(a) < vsum(b);
+        });
         int cnt[4] = {0, 0, 0, 0};
         for (int t = tb; t < te; ++t) cnt[grp(d->tet_kind[t])]++;
         c->kind_begin[0] = 0; c->kind_begin[1] = cnt[0]; c->kind_begin[2] = cnt[0] + cnt[1]; c->kind_begin[3] = cnt[0] + cnt[1] + cnt[2];

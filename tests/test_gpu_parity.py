@@ -157,6 +157,30 @@ def test_step_parity_spline_tets(kind):
     assert np.abs(s.m_x - sc.x.ravel()).max() > 1e-3      # it moved
 
 
+def test_tet_order_does_not_matter():
+    """The library sorts the tets it is given (by model, then by lowest vertex index: memory-coherent gathers whatever
+    order a mesh file lists them in); outputs keep the CALLER's row order.  Shuffled input = same z / u rows, same step."""
+    sc = scenes.mixed_cube_scene(5, admm_iters=6)
+    sc2 = scenes.mixed_cube_scene(5, admm_iters=6)
+    rng = np.random.default_rng(3)
+    perms = []
+    for i, (verts, tets, lame, kind, off) in enumerate(sc2.tets):
+        p = rng.permutation(len(tets)); perms.append(p)
+        sc2.tets[i] = (verts, tets[p], lame, kind, off)
+    s, s2 = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=500), sc2.make_solver(pcg_tol=1e-12, pcg_max_iters=500)
+    x = deformed(sc, 0.02, 5)
+    u0 = 0.03 * rng.standard_normal(s.num_rows())
+    rows = np.concatenate([9 * (o + p)[:, None] + np.arange(9) for o, p in zip(np.cumsum([0] + [len(t[1]) for t in sc.tets[:-1]]), perms)]).ravel()
+    pad = np.arange(9 * sum(len(t[1]) for t in sc.tets), s.num_rows())          # pin rows keep their place
+    rows = np.concatenate([rows, pad])
+    z, u = s.local_step(x, u0)
+    z2, u2 = s2.local_step(x, u0[rows])
+    assert np.array_equal(z2, z[rows]) and np.array_equal(u2, u[rows])         # per-element work is order-independent: bitwise
+    for _ in range(3):
+        s.step(); s2.step()
+    assert scenes.rel_err(s2.m_x, s.m_x) < 1e-10
+
+
 def test_step_parity_mixed_materials():
     sc = scenes.mixed_cube_scene(6, admm_iters=20, linsolver=0)
     s, o = run_both(sc, 3, pcg_tol=1e-11, pcg_max_iters=300)
