@@ -77,6 +77,7 @@ SYMBOLS = [
     ("admm_host_tri_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     ("admm_host_greedy_coloring", C.c_int, [C.c_int32, c_int_p, c_int_p, c_int_p]),
+    ("admm_host_locality_order", None, [C.c_int32, C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, c_double_p]),
 ]
 
 _lib = None
@@ -154,6 +155,15 @@ def greedy_coloring(rowptr, col):
     color = np.empty(n, dtype=np.int32)
     nc = lib().admm_host_greedy_coloring(n, iptr(rowptr), iptr(col), iptr(color))
     return color, nc
+
+
+def locality_order(n_verts, elems):
+    """admm_host_locality_order: (new_id[n_verts], span_before, span_after) for tets [n,4] or triangles [n,3]."""
+    elems = i32(elems)
+    new_id = np.zeros(n_verts, np.int32)
+    sb, sa = C.c_double(0), C.c_double(0)
+    lib().admm_host_locality_order(n_verts, elems.shape[0], elems.shape[1], iptr(elems), iptr(new_id), C.byref(sb), C.byref(sa))
+    return new_id, sb.value, sa.value
 
 
 def partition(n_items, world_size, rank):

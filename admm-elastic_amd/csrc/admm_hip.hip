@@ -1544,4 +1544,9 @@ int admm_host_greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *c
     return admm_host::greedy_coloring(n, rowptr, col, color);
 }
 
+void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id,
+                              double *span_before, double *span_after) {
+    admm_host::locality_order(n_verts, n_elems, corners, idx, new_id, span_before, span_after);
+}
+
 } // extern "C"

@@ -425,3 +425,52 @@ std::vector<double> octtree_boxes_tris(const OctTree &T, const int32_t *faces, c
 }
 
 } // namespace admm_host
+
+// ---------------------------------------------------------------------------------------------------
+// Reverse Cuthill-McKee vertex ordering (mesh preprocessing; see admm_host_locality_order in admm_hip.h)
+namespace admm_host {
+
+static double mean_edge_span(int32_t n_elems, int32_t corners, const int32_t *idx, const int32_t *id) {
+    double s = 0.0; long long cnt = 0;
+    for (int e = 0; e < n_elems; ++e)
+        for (int a = 0; a < corners; ++a)
+            for (int b = a + 1; b < corners; ++b) {
+                const int i = idx[(size_t)corners * e + a], j = idx[(size_t)corners * e + b];
+                s += std::fabs((double)(id ? id[i] : i) - (double)(id ? id[j] : j)); ++cnt;
+            }
+    return cnt ? s / (double)cnt : 0.0;
+}
+
+void locality_order(int32_t nv, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id, double *span_before,
+                    double *span_after) {
+    // adjacency (CSR, duplicates removed)
+    std::vector<std::vector<int32_t> > adj(nv);
+    for (int e = 0; e < n_elems; ++e)
+        for (int a = 0; a < corners; ++a)
+            for (int b = 0; b < corners; ++b)
+                if (a != b) adj[idx[(size_t)corners * e + a]].push_back(idx[(size_t)corners * e + b]);
+    for (auto &l : adj) { std::sort(l.begin(), l.end()); l.erase(std::unique(l.begin(), l.end()), l.end()); }
+    std::vector<int32_t> order; order.reserve(nv);
+    std::vector<char> seen(nv, 0);
+    // start vertices: lowest degree first (a cheap stand-in for a pseudo-peripheral search), one per component
+    std::vector<int32_t> by_degree(nv);
+    std::iota(by_degree.begin(), by_degree.end(), 0);
+    std::stable_sort(by_degree.begin(), by_degree.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+    for (int32_t start : by_degree) {
+        if (seen[start]) continue;
+        size_t head = order.size();
+        order.push_back(start); seen[start] = 1;
+        while (head < order.size()) {
+            const int32_t v = order[head++];
+            std::vector<int32_t> next;
+            for (int32_t w : adj[v]) if (!seen[w]) { seen[w] = 1; next.push_back(w); }
+            std::stable_sort(next.begin(), next.end(), [&](int a, int b) { return adj[a].size() < adj[b].size(); });
+            order.insert(order.end(), next.begin(), next.end());
+        }
+    }
+    for (int32_t i = 0; i < nv; ++i) new_id[order[nv - 1 - i]] = i;     // reversed
+    if (span_before) *span_before = mean_edge_span(n_elems, corners, idx, nullptr);
+    if (span_after) *span_after = mean_edge_span(n_elems, corners, idx, new_id);
+}
+
+} // namespace admm_host

@@ -69,6 +69,11 @@ OctTree build_octtree(int32_t n, const double *centroids);
 // boxes (lo xyz, hi xyz per node) of every level for triangles `faces` (local ids, sorted order given by tree.order)
 std::vector<double> octtree_boxes_tris(const OctTree &tree, const int32_t *faces, const double *verts);
 
+// Locality ordering of mesh vertices: reverse Cuthill-McKee on the vertex graph of the elements (corners = 3 or 4).
+// new_id[v] = position of vertex v in the ordering.  span_before / span_after = mean |i - j| over element edges.
+void locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id,
+                    double *span_before, double *span_after);
+
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
 int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
 void lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);

@@ -8,6 +8,7 @@
 #define ADMM_MESHES_HPP 1
 
 #include <algorithm>
+#include <cstdint>
 #include <array>
 #include <cstdio>
 #include <fstream>
@@ -18,6 +19,10 @@
 #include <string>
 #include <vector>
 #include "MiniLinAlg.hpp"
+
+// include/admm_hip.h (libadmm_hip.so): reverse Cuthill-McKee vertex ordering, host only
+extern "C" void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id,
+                                         double *span_before, double *span_after);
 
 namespace admm {
 
@@ -48,6 +53,24 @@ struct TetMesh {
             const double w = density * signed_volume((int)t) / 4.0;
             for (int c = 0; c < 4; ++c) m[tets[t][c]] += w;
         }
+    }
+    // Mesh preprocessing for the GPU: give the vertices a numbering with locality (admm_host_locality_order; the kernels
+    // gather by vertex index).  Renumbers vertices, tets and faces when the mean edge span shrinks by more than 2x (or
+    // force); returns new_id (identity when nothing was done) for everything else the caller indexes by vertex.
+    std::vector<int> renumber_for_locality(bool force = false) {
+        const int nv = (int)vertices.size(), nt = (int)tets.size();
+        std::vector<int32_t> idx(4 * (size_t)nt), new_id(nv);
+        for (int t = 0; t < nt; ++t) for (int c = 0; c < 4; ++c) idx[4 * (size_t)t + c] = tets[t][c];
+        double before = 0, after = 0;
+        admm_host_locality_order(nv, nt, 4, idx.data(), new_id.data(), &before, &after);
+        std::vector<int> out(nv);
+        if (!force && !(after < 0.5 * before)) { for (int i = 0; i < nv; ++i) out[i] = i; return out; }
+        std::vector<Vec3> nvtx(nv);
+        for (int i = 0; i < nv; ++i) { nvtx[new_id[i]] = vertices[i]; out[i] = new_id[i]; }
+        vertices.swap(nvtx);
+        for (Vec4i &t : tets) for (int c = 0; c < 4; ++c) t[c] = new_id[t[c]];
+        for (Vec3i &f : faces) for (int c = 0; c < 3; ++c) f[c] = new_id[f[c]];
+        return out;
     }
     // faces that belong to exactly one tet, outward orientation
     void surface_faces(std::vector<Vec3i> &faces) const {

@@ -103,6 +103,19 @@ def lumped_masses_tris(verts, tris, density=1.0):
     return m
 
 
+def renumber_for_locality(verts, elems, force=False):
+    """Vertex numbering with locality (capi.locality_order, reverse Cuthill-McKee) for a mesh whose numbering has none:
+    returns (verts, elems, new_id) renumbered when the mean edge span shrinks by more than 2x (or force), else unchanged
+    with new_id = identity.  Everything indexed by vertex (pins, surface lists) goes through new_id."""
+    from . import capi
+    verts = np.asarray(verts); elems = np.asarray(elems, dtype=np.int32)
+    new_id, before, after = capi.locality_order(len(verts), elems)
+    if not force and not (after < 0.5 * before):
+        return verts, elems, np.arange(len(verts), dtype=np.int32)
+    out = np.empty_like(verts); out[new_id] = verts
+    return out, new_id[elems].astype(np.int32), new_id
+
+
 def load_tetgen(node_path, ele_path):
     """TetGen .node/.ele reader (the reference's samples/data format, 0- or 1-indexed)."""
     with open(node_path) as f:

@@ -228,6 +228,16 @@ void admm_host_lame(double youngs, double poisson, double *mu, double *lambda, d
  * src/NodalMultiColorGS.hpp:57): the better of first-fit in index order and DSATUR; deterministic; returns the
  * number of colours. */
 int admm_host_greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color);
+/* Mesh preprocessing (no counterpart in the reference, whose CPU solvers do not care): a vertex numbering with locality.
+ * The kernels gather positions, corner forces and matrix rows by vertex index, and the on-chip PCG hands vector slices
+ * between the blocks that own neighbouring index ranges, so the numbering a mesh arrives with decides how coherent all of
+ * that is (1 M-tet cube: lexicographic numbering 1.37 ms per ADMM iteration, randomly renumbered 3.57 ms).  Reverse
+ * Cuthill-McKee on the element graph; idx = [corners * n_elems] vertex ids (corners 3 or 4); new_id[v] = new index of
+ * vertex v; span_before / span_after (may be NULL) = mean |i - j| over element edges, the figure to decide by.  The
+ * caller renumbers its mesh (vertices, elements, pins) BEFORE building the solver: the library never renumbers behind
+ * the API (m_x keeps the caller's order). */
+void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id,
+                              double *span_before, double *span_after);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,7 @@ int main(int argc, char **argv) {
     try {
         std::shared_ptr<TetMesh> mesh = mesh_prefix.empty() ? factory::make_tet_blocks(cells, cells, cells) : meshio::load_tetgen(mesh_prefix);
         if (mesh_prefix.empty()) mesh->scale(size / cells, size / cells, size / cells);
+        else mesh->renumber_for_locality();   // mesh files number their vertices in insertion order: give the GPU a local numbering
         mesh->flags |= binding::NOSELFCOLLISION | binding::NEOHOOKEAN;
         Solver solver;
         const Lame lame = lame_name == "soft" ? Lame::soft_rubber() : lame_name == "verysoft" ? Lame::very_soft_rubber() : Lame::rubber();

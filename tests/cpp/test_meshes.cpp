@@ -32,6 +32,29 @@ int main(int argc, char **argv) {
     CHECK(std::fabs(sv - 24.0) < 1e-10);
     Vec3 lo, hi; m->bounds(lo, hi);
     CHECK(lo[0] == 0 && hi[0] == 4 && hi[1] == 3 && hi[2] == 2);
+    {   // renumber_for_locality: a scrambled numbering is replaced (same geometry per tet), a good one is left alone
+        auto g = factory::make_tet_blocks(6, 6, 6);
+        const std::vector<int> keep = g->renumber_for_locality();
+        for (size_t i = 0; i < keep.size(); ++i) CHECK(keep[i] == (int)i);
+        auto sh = factory::make_tet_blocks(6, 6, 6);
+        const int nv = (int)sh->vertices.size();
+        std::vector<int> p(nv);
+        for (int i = 0; i < nv; ++i) p[i] = (int)(((long long)i * 7919) % nv);      // 7919 is coprime with 343: a permutation
+        std::vector<Vec3> vv(nv);
+        for (int i = 0; i < nv; ++i) vv[p[i]] = sh->vertices[i];
+        sh->vertices = vv;
+        for (Vec4i &t : sh->tets) for (int c = 0; c < 4; ++c) t[c] = p[t[c]];
+        auto span = [](const TetMesh &mm) { double s = 0; for (const Vec4i &t : mm.tets) for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) s += std::abs(t[a] - t[b]); return s / (6.0 * mm.tets.size()); };
+        const double before = span(*sh);
+        const std::vector<int> nid = sh->renumber_for_locality();
+        CHECK(span(*sh) < 0.5 * before);
+        std::vector<char> seen(nv, 0);
+        for (int i = 0; i < nv; ++i) { CHECK(nid[i] >= 0 && nid[i] < nv && !seen[nid[i]]); seen[nid[i]] = 1; }
+        for (size_t t = 0; t < sh->tets.size(); ++t) {
+            CHECK(std::fabs(sh->signed_volume((int)t) - g->signed_volume((int)t)) < 1e-12);
+            for (int c = 0; c < 4; ++c) CHECK((sh->vertices[sh->tets[t][c]] - g->vertices[g->tets[t][c]]).norm() == 0.0);
+        }
+    }
     // TetGen round trip (0-based) and a 1-based file with a flipped tet
     meshio::save_tetgen(tmp, *m);
     auto r = meshio::load_tetgen(tmp);

@@ -107,3 +107,24 @@ def test_bad_descriptions_are_rejected():
     with pytest.raises(pkg.AdmmHipError):            # TriEnergyTerm.cpp:32
         Solver().add_tris(*meshes.cloth_grid(2), lame)
     assert Solver().initialize(Settings()) is False  # Solver.cpp:180-183
+
+
+def test_locality_order_is_a_permutation_that_shrinks_the_span():
+    """admm_host_locality_order (reverse Cuthill-McKee): a randomly numbered cube gets a numbering at least as local as the
+    generator's; meshes.renumber_for_locality renumbers consistently and leaves a good numbering alone."""
+    verts, tets = meshes.kuhn_cube(12)
+    nv = len(verts)
+    _, lex, _ = capi.locality_order(nv, tets)
+    p = np.random.default_rng(0).permutation(nv)
+    inv = np.empty(nv, np.int64); inv[p] = np.arange(nv)
+    v2, t2 = verts[inv], p[tets].astype(np.int32)
+    new_id, before, after = capi.locality_order(nv, t2)
+    assert sorted(int(i) for i in new_id) == list(range(nv)) and before > 3 * lex and after <= 1.05 * lex, (lex, before, after)
+    v3, t3, nid = meshes.renumber_for_locality(v2, t2)
+    assert np.array_equal(v3[t3], v2[t2]) and np.array_equal(nid, new_id)
+    v4, t4, nid4 = meshes.renumber_for_locality(verts, tets)
+    assert v4 is verts or np.array_equal(v4, verts)
+    assert np.array_equal(nid4, np.arange(nv))
+    tris = meshes.cloth_grid(10)[1]
+    nid_t, _, _ = capi.locality_order(121, tris)                     # triangles too
+    assert sorted(nid_t) == list(range(121))
