@@ -48,6 +48,7 @@ class Stats(C.Structure):
         ("global_ms", C.c_double), ("local_ms", C.c_double), ("collision_ms", C.c_double),
         ("inner_iters", C.c_int32), ("admm_iters", C.c_int32), ("step_ms", C.c_double),
         ("last_solve_converged", C.c_int32), ("n_constraints", C.c_int32), ("rhs_ms", C.c_double), ("unconverged_solves", C.c_int32), ("pcg_launched_iters", C.c_int32), ("pcg_iters_per_solve", C.c_int32 * 64),
+        ("local_kernel_ms", C.c_double),
     ]
 
 

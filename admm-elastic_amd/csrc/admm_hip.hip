@@ -105,6 +105,8 @@ struct admm_hip_ctx {
     hipEvent_t ev_step0 = nullptr, ev_step1 = nullptr;
     hipEvent_t ev_coll0 = nullptr, ev_coll1 = nullptr;   // around Collider::detect (UzawaCG path), when stats are requested
     bool timing = false; double coll_ms_step = 0.0;
+    // kernel-level timing of the tet local-step launches (device wall clock, kernels.hpp: ts_enter / ts_exit)
+    DevBuf<unsigned long long> lk_ts, lk_out; int lk_tsn = 0, lk_launch = 0, lk_cap = 0; double lk_tick_ms = 0.0;
     std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration (+1) when stats are requested
 
     int nv = 0, n3 = 0;
@@ -232,6 +234,7 @@ struct admm_hip_ctx {
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
         gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
+        lk_ts.release(); lk_out.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
         if (gs_exec) (void)hipGraphExecDestroy(gs_exec);
@@ -256,11 +259,17 @@ void launch_local(admm_hip_ctx *c) {
     hipStream_t st = c->stream;
     if (c->nt > 0) {
         const int b0 = c->kind_begin[0], b1 = c->kind_begin[1], b2 = c->kind_begin[2], b3 = c->kind_begin[3];
-        const TetArgs a{c->ldt, c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p};
+        TetArgs a{c->ldt, c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p, nullptr, 0};
+        auto stamp = [&]() {   // the next launch gets its own pair of stamp arrays
+            if (c->timing && c->lk_launch < c->lk_cap) { a.ts = c->lk_ts.p + (size_t)c->lk_launch * 2 * c->lk_tsn; a.ts_n = c->lk_tsn; c->lk_launch += 1; }
+            else a.ts = nullptr;
+        };
         const int b4 = c->kind_begin[4];
         const int kinds = (b1 > b0) + (b2 > b1) + (b3 > b2);
+        if (b4 > b3) stamp();
         if (b4 > b3)      // co-rotated spline tets: their own launch (no BASELINE config mixes them in)
             hipLaunchKernelGGL((k_local_tets<3, WRITE_Z>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, b3, b4, a);
+        if (b3 > b0) stamp();
         if (kinds >= 2) { // mixed scene: one launch over all models
             const int n0 = blocks_for(b1 - b0), n1 = blocks_for(b2 - b1), n2 = blocks_for(b3 - b2);
             hipLaunchKernelGGL((k_local_tets_fused<WRITE_Z>), dim3(n0 + n1 + n2), dim3(256), 0, st, b0, b1, b2, b3, n0, n0 + n1, a);
@@ -1307,7 +1316,19 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
             c->ev_phase.push_back(e);
         }
     }
-    c->timing = timed; c->coll_ms_step = 0.0;
+    c->timing = timed; c->coll_ms_step = 0.0; c->lk_launch = 0;
+    if (timed && c->nt > 0) {
+        const int tsn = 4 * (blocks_for(c->nt) + 4), cap = 2 * admm_iters;
+        if (c->lk_tsn != tsn || c->lk_cap < cap) {
+            c->lk_ts.release(); c->lk_out.release();
+            HIP_TRY(c->lk_ts.alloc((size_t)cap * 2 * tsn)); HIP_TRY(c->lk_out.alloc(2 * (size_t)cap));
+            c->lk_tsn = tsn; c->lk_cap = cap;
+            int khz = 0;
+            HIP_TRY(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device));
+            c->lk_tick_ms = khz > 0 ? 1.0 / (double)khz : 1e-5;     // wall_clock64 ticks: 100 MHz on gfx950
+        }
+        HIP_TRY(hipMemsetAsync(c->lk_ts.p, 0, (size_t)cap * 2 * tsn * sizeof(unsigned long long), st));
+    }
     if (timed && !c->ev_coll0) { HIP_TRY(hipEventCreate(&c->ev_coll0)); HIP_TRY(hipEventCreate(&c->ev_coll1)); }
     HIP_TRY(hipEventRecord(c->ev_step0, st));
     // counters[5] (closed chunks) must stay monotone across steps: only [0..4] are reset
@@ -1333,6 +1354,8 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
     }
     c->timing = false;
     if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * admm_iters], st));
+    if (timed && c->lk_launch > 0)
+        hipLaunchKernelGGL(k_ts_reduce, dim3(c->lk_launch), dim3(256), 0, st, c->lk_ts.p, c->lk_tsn, c->lk_launch, c->lk_out.p);
     hipLaunchKernelGGL(k_finish, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, 1.0 / c->dt, c->x.p, c->v.p, c->curr.p);
     HIP_TRY(hipEventRecord(c->ev_step1, st));
     HIP_TRY(hipGetLastError());
@@ -1348,6 +1371,12 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s], c->ev_phase[3 * s + 1])); stats->local_ms += ms;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 2])); stats->rhs_ms += ms;
             HIP_TRY(hipEventElapsedTime(&ms, c->ev_phase[3 * s + 1], c->ev_phase[3 * s + 3])); stats->global_ms += ms;
+        }
+        if (c->lk_launch > 0) {
+            std::vector<unsigned long long> tt(2 * (size_t)c->lk_launch);
+            HIP_TRY(hipMemcpy(tt.data(), c->lk_out.p, tt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (int i = 0; i < c->lk_launch; ++i)
+                if (tt[2 * i + 1] > tt[2 * i]) stats->local_kernel_ms += (double)(tt[2 * i + 1] - tt[2 * i]) * c->lk_tick_ms;
         }
         // collision_ms = Collider::detect + constraint rows (Solver.cpp:90-95); it runs inside the global phase here
         stats->collision_ms = c->coll_ms_step;

@@ -134,7 +134,42 @@ struct TetArgs {
     int ld;
     const int4 *idx; const double *Binv; double *u; double *z; const double *sc; const int *mat_id; const Mat *mats;
     const double *x; double *cf;
+    // kernel-level timing (stats only): every wave stores the device wall clock at entry in ts[wave slot] and, once its
+    // stores have drained, at exit in ts[ts_n + wave slot]; nullptr = off.  max(exit) - min(entry) is the launch's
+    // duration as rocprofv3 reports it, without the dispatch gaps an event pair around the launch also counts.
+    unsigned long long *ts; int ts_n;
 };
+__device__ __forceinline__ void ts_enter(const TetArgs &a) {
+    if (a.ts && (threadIdx.x & 63) == 0) a.ts[blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64();
+}
+__device__ __forceinline__ void ts_exit(const TetArgs &a) {
+    if (a.ts) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0) a.ts[a.ts_n + blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64();
+    }
+}
+// per launch slot: min over the waves' entry stamps (0 = wave never ran), max over their exit stamps
+__global__ __launch_bounds__(256) void k_ts_reduce(const unsigned long long *__restrict__ ts, int ts_n, int n_launches,
+                                                   unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long lo[256], hi[256];
+    const unsigned long long *base = ts + 2 * (size_t)ts_n * blockIdx.x;
+    unsigned long long mn = ~0ull, mx = 0ull;
+    for (int i = threadIdx.x; i < ts_n; i += 256) {
+        const unsigned long long a = base[i], b = base[ts_n + i];
+        if (a != 0ull && a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+    lo[threadIdx.x] = mn; hi[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            if (lo[threadIdx.x + o] < lo[threadIdx.x]) lo[threadIdx.x] = lo[threadIdx.x + o];
+            if (hi[threadIdx.x + o] > hi[threadIdx.x]) hi[threadIdx.x] = hi[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && (int)blockIdx.x < n_launches) { out[2 * blockIdx.x] = lo[0]; out[2 * blockIdx.x + 1] = hi[0]; }
+}
 
 // Every per-tet array is SoA with the tet index fastest, so all accesses of a thread are "array base + c * ld
 // (uniform) + t".  They go through buffer instructions -- descriptor in SGPRs, ONE 32-bit VGPR offset shared by
@@ -310,8 +345,9 @@ __global__ __launch_bounds__(256, (KIND == 1 ? ADMM_NH_WAVES : 4)) void k_local_
     __shared__ double sBi[9][256];
     __shared__ double sV[(KIND == 2 || ADMM_PARK_V_NH != 0) ? 9 : 1][256];
     const int t = t0 + xcd_block() * 256 + threadIdx.x;
-    if (t >= t1) return;
-    local_tet_body<KIND, WRITE_Z>(a, t, sBi, sV);
+    ts_enter(a);
+    if (t < t1) local_tet_body<KIND, WRITE_Z>(a, t, sBi, sV);
+    ts_exit(a);
 }
 
 // all models in ONE launch: block ranges [0,nb0) linear, [nb0,nb1) NH, [nb1,nb2) StVK (wave-uniform branch).
@@ -321,6 +357,7 @@ __global__ __launch_bounds__(256, ADMM_NH_WAVES) void k_local_tets_fused(int b0,
     __shared__ double sBi[9][256];
     __shared__ double sV[9][256];
     const int blk = xcd_block();
+    ts_enter(a);
     if (blk < nb0) {
         const int t = b0 + blk * 256 + threadIdx.x;
         if (t < b1) local_tet_body<0, WRITE_Z>(a, t, sBi, sV);
@@ -331,6 +368,7 @@ __global__ __launch_bounds__(256, ADMM_NH_WAVES) void k_local_tets_fused(int b0,
         const int t = b2 + (blk - nb1) * 256 + threadIdx.x;
         if (t < b3) local_tet_body<2, WRITE_Z>(a, t, sBi, sV);
     }
+    ts_exit(a);
 }
 
 // LOCAL STEP, triangles (src/TriEnergyTerm.cpp:54-101): F (3x2) = [x1-x0, x2-x0] rest

@@ -75,6 +75,7 @@ class RuntimeData:
         self.global_ms = 0.0
         self.local_ms = 0.0
         self.collision_ms = 0.0
+        self.local_kernel_ms = 0.0   # tet local-step kernel durations (device clock); local_ms = the phase incl. dispatch gaps
         self.inner_iters = 0
         self.step_ms = 0.0
         self.last_solve_converged = 0
@@ -327,6 +328,7 @@ class Solver:
             r.global_ms, r.local_ms, r.collision_ms = st.global_ms, st.local_ms, st.collision_ms
             r.inner_iters, r.step_ms, r.last_solve_converged = st.inner_iters, st.step_ms, st.last_solve_converged
             r.rhs_ms, r.unconverged_solves, r.pcg_launched_iters = st.rhs_ms, st.unconverged_solves, st.pcg_launched_iters
+            r.local_kernel_ms = st.local_kernel_ms
             r.pcg_iters_per_solve = list(st.pcg_iters_per_solve)[:min(it, 64)]
         else:
             check(lib().admm_hip_step(self._ctx, it, s.gravity, None))

@@ -173,13 +173,14 @@ def main():
     sync()
     # Timed region.  Every step also records HIP events (on the context's own stream) around its
     # prox kernels; reading them back costs one stream sync per frame, which is inside the timing.
-    local_ms = rhs_ms = global_ms = 0.0
+    local_ms = rhs_ms = global_ms = lk_ms = 0.0
     inner = unconv = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         s.step_device(stats=True)
         rd = s.runtime_data()
         local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms; inner += rd.inner_iters
+        lk_ms += rd.local_kernel_ms
         unconv += rd.unconverged_solves
     sync()
     elapsed = time.perf_counter() - t0
@@ -226,11 +227,19 @@ def main():
             launches = iters * args.steps
             # (with N ranks, rank 0 times its own element block: nt / N elements per launch)
             bytes_per_launch = ((188.0 if w["kinds"] == "cloth" else 304.0) + 24.0 * nv / nt) * nt / world
+            # Duration of one launch, measured live in the timed region on the context's own stream, three ways that bracket
+            # each other: (1) `avg_launch_us` = interval between two hipEventRecords around the launch (kernel + the two
+            # dispatch gaps: the CONSERVATIVE figure, used for `achieved` / `frac`); (2) rocprofv3 --kernel-trace of the same
+            # command (profiles/): 4-5 us shorter; (3) `kernel_us_device_clock`: every wave stamps the device wall clock at
+            # entry and, once its stores have drained, at exit -- max exit - min entry is another 2-3 us shorter than rocprofv3
+            # (it misses the dispatch ramp-up and the end-of-kernel cache release).
             avg_s = 1e-3 * local_ms / launches
             achieved = bytes_per_launch / avg_s / 1e9
             out["roofline"] = {"kernel": "k_local_tris" if w["kinds"] == "cloth" else "k_local_tets (all constitutive models of one ADMM iteration)", "bound": "hbm",
                                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": pmc_traffic(args.workload), "avg_launch_us": 1e6 * avg_s,
+                               "timing": "hipEventRecord pair around the launch, context stream",
+                               "kernel_us_device_clock": (1e3 * lk_ms / launches) if lk_ms > 0 else None,
                                "algorithmic_bytes_per_launch": bytes_per_launch}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)

@@ -133,6 +133,10 @@ typedef struct {
     int32_t unconverged_solves;   /* PCG solves of this step that did not meet pcg_tol (0 = every solve converged) */
     int32_t pcg_launched_iters;   /* PCG iterations launched for the last solve (converged ones exit early on the device) */
     int32_t pcg_iters_per_solve[64]; /* linsolver 0: PCG iterations of each ADMM iteration's solve (first 64) */
+    double local_kernel_ms;       /* sum of the tet local-step KERNEL durations of this step, from the device wall clock
+                                   * (every wave stamps its entry and, after its stores have drained, its exit; duration =
+                                   * max exit - min entry): what rocprofv3 --kernel-trace reports.  local_ms above is the
+                                   * PHASE between two event records, dispatch gaps included.  0 when there are no tets. */
 } admm_hip_stats;
 
 const char *admm_hip_last_error(void);
