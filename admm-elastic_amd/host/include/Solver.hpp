@@ -15,70 +15,80 @@
 
 namespace admm {
 
+namespace solver_detail {
+
+// Solver::Settings (src/Solver.hpp:39-50): command-line switches in the comments
+struct SolverSettings {
+    SolverSettings() : timestep_s(1.0 / 24.0), verbose(1), admm_iters(10), gravity(-9.8), linsolver(0), constraint_w(-1) {}
+    double timestep_s;   // -dt
+    int verbose;         // -v
+    int admm_iters;      // -it
+    double gravity;      // -g
+    int linsolver;       // -ls  0 = LDLT (here: GPU PCG), 1 = NCMCGS, 2 = UzawaCG
+    double constraint_w; // -ck  (-1 = automatic)
+    void help();
+    bool parse_args(int argc, char **argv);   // true when help() was printed
+};
+
+// Solver::RuntimeData (src/Solver.hpp:54-61): filled from admm_hip_stats after every step
+struct SolverRuntimeData {
+    SolverRuntimeData() : global_ms(0), local_ms(0), collision_ms(0), inner_iters(0) {}
+    double global_ms, local_ms, collision_ms;
+    int inner_iters;
+    void print(const SolverSettings &settings);
+};
+
+} // namespace solver_detail
+
 class Solver {
 public:
-    // src/Solver.hpp:39-50
-    struct Settings {
-        bool parse_args(int argc, char **argv); // returns true if help() was printed
-        void help();
-        double timestep_s;   // -dt
-        int verbose;         // -v
-        int admm_iters;      // -it
-        double gravity;      // -g
-        int linsolver;       // -ls  0=LDLT(->GPU PCG), 1=NCMCGS, 2=UzawaCG
-        double constraint_w; // -ck
-        Settings() : timestep_s(1.0 / 24.0), verbose(1), admm_iters(10), gravity(-9.8), linsolver(0), constraint_w(-1) {}
-    };
-    // src/Solver.hpp:54-61
-    struct RuntimeData {
-        double global_ms, local_ms, collision_ms;
-        int inner_iters;
-        RuntimeData() : global_ms(0), local_ms(0), collision_ms(0), inner_iters(0) {}
-        void print(const Settings &settings);
-    };
+    typedef solver_detail::SolverSettings Settings;
+    typedef solver_detail::SolverRuntimeData RuntimeData;
 
     Solver();
     virtual ~Solver();
 
-    VecX m_x, m_v, m_masses;          // per-node x3 (src/Solver.hpp:66-68)
-    std::vector<int> surface_inds;
-    std::vector<std::shared_ptr<ExplicitForce> > ext_forces;
+    // ---- scene data the callers fill directly (src/Solver.hpp:66-73) ----
+    VecX m_x, m_v, m_masses;                                      // three entries per node
     std::vector<std::shared_ptr<EnergyTerm> > energyterms;
+    std::vector<std::shared_ptr<ExplicitForce> > ext_forces;
+    std::vector<int> surface_inds;                                // collision candidates (empty = every node)
 
-    template <typename T> int add_nodes(T *x, T *m, int n_verts); // src/Solver.hpp:127-141
+    // ---- the life cycle (all virtual in the reference as well) ----
+    virtual bool initialize(const Settings &settings_ = Settings());
+    virtual void step();
     virtual void set_pins(const std::vector<int> &inds, const std::vector<Vec3> &points = std::vector<Vec3>());
     virtual void add_obstacle(std::shared_ptr<PassiveCollision> obj);
     virtual void add_dynamic_collider(std::shared_ptr<DynamicCollision> obj);
-    virtual bool initialize(const Settings &settings_ = Settings());
-    virtual void step();
-    virtual const RuntimeData &runtime_data() { return m_runtime; }
     virtual void save_matrix(const std::string &filename);
+    virtual const RuntimeData &runtime_data() { return m_runtime; }
     const Settings &settings() { return m_settings; }
-    // GPU-side extras
+
+    // appends n_verts nodes (positions x, masses m, three values each); returns the new node count (src/Solver.hpp:127-141)
+    template <typename T> int add_nodes(T *x, T *m, int n_verts) {
+        const int old_size = m_x.size(), extra = 3 * n_verts;
+        m_x.conservativeResize(old_size + extra);
+        m_v.conservativeResize(old_size + extra);
+        m_masses.conservativeResize(old_size + extra);
+        for (int i = 0; i < extra; ++i) { m_x[old_size + i] = x[i]; m_masses[old_size + i] = m[i]; m_v[old_size + i] = 0.0; }
+        return (old_size + extra) / 3;
+    }
+
+    // ---- additions of the GPU build ----
+    int device;                                                   // HIP device ordinal used by initialize() (default 0)
     std::shared_ptr<LinearSolver> linear_solver() { return m_linsolver; }
-    int device; // HIP device ordinal used by initialize() (default 0)
 
 protected:
+    void release();
+    void *m_ctx;                                                  // admm_hip_ctx
+    bool initialized;
     Settings m_settings;
     RuntimeData m_runtime;
-    bool initialized;
-    std::shared_ptr<LinearSolver> m_linsolver;
+    SparseMat solver_termA;                                       // Ahat: A = diag(m) + Ahat (x) I3
     std::shared_ptr<ConstraintSet> m_constraints;
+    std::shared_ptr<LinearSolver> m_linsolver;
     std::unordered_map<int, std::shared_ptr<SpringPin> > m_pin_energies;
-    SparseMat solver_termA; // Ahat: A = diag(m) + Ahat (x) I3
-    void *m_ctx;            // admm_hip_ctx
-    void release();
 };
-
-template <typename T>
-int Solver::add_nodes(T *x, T *m, int n_verts) {
-    const int prev_n = m_x.size(), n3 = n_verts * 3;
-    m_x.conservativeResize(prev_n + n3);
-    m_v.conservativeResize(prev_n + n3);
-    m_masses.conservativeResize(prev_n + n3);
-    for (int i = 0; i < n3; ++i) { m_x[prev_n + i] = x[i]; m_v[prev_n + i] = 0.0; m_masses[prev_n + i] = m[i]; }
-    return (prev_n + n3) / 3;
-}
 
 } // namespace admm
 #endif

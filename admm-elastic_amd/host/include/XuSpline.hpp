@@ -1,9 +1,10 @@
 // XuSpline.hpp -- the spline family of SplineTet (reference: src/XuSpline.hpp; Xu, Sin, Zhu, Barbic 2015,
 // "Nonlinear Material Design Using Principal Stretches").  Psi = sum f(s_i) + sum g(s_i s_j) + h(s_0 s_1 s_2).
-// The three classes the reference ships keep their names, constructors and f/g/h formulas (host-side energy
-// evaluation); on the GPU each of them, with kappa = 0, IS one of the closed-form models (NeoHookean -> NH, StVK -> StVK,
-// CoRotated -> co-rotated linear), which is how SplineTet::flatten hands it to the kernels.  A spline with
-// kappa != 0, or a user-defined subclass, has no kernel: Solver::initialize rejects it (no CPU fallback).
+// The interface (xu::Spline with f / g / h and their derivatives) and the three named splines keep the reference's
+// names and constructor arguments.  On the GPU each named spline with kappa = 0 IS one of the closed-form stretch models
+// (NeoHookean -> NH, StVK -> StVK, CoRotated -> co-rotated linear), which is how SplineTet::flatten hands it to the
+// kernels; the host-side f / g / h below only serve EnergyTerm::energy.  A spline with kappa != 0, or a user-defined
+// subclass, has no kernel: Solver::initialize rejects it (no CPU fallback).
 #ifndef ADMM_XUSPLINE_HPP
 #define ADMM_XUSPLINE_HPP 1
 
@@ -21,51 +22,59 @@ public:
     virtual double df(double x) const = 0;
     virtual double dg(double x) const = 0;
     virtual double dh(double x) const = 0;
-    // Eq. 16: compression term (src/XuSpline.hpp:44-45)
-    static double compress_term(double kappa, double x) { return (kappa / 12.0) * std::pow((1.0 - x) / 6.0, 3.0); }
-    static double d_compress_term(double kappa, double x) { return (-kappa / 24.0) * (std::pow((1.0 - x) / (6.0), 2.0)); }
-    // GPU description: the ADMM_TET_SPLINE_* kind and the spline's constants; false = no kernel
-    virtual bool flatten(int &kind, double &mu, double &lambda) const { (void)kind; (void)mu; (void)lambda; return false; }
+    // compression term of the paper's Eq. 16 and its derivative as the reference evaluates them (src/XuSpline.hpp:44-45)
+    static double compress_term(double kappa, double x) { const double t = (1.0 - x) / 6.0; return kappa * t * t * t / 12.0; }
+    static double d_compress_term(double kappa, double x) { const double t = (1.0 - x) / 6.0; return -kappa * t * t / 24.0; }
+    // GPU description: ADMM_TET_SPLINE_* kind and the spline's Lame constants; false = no kernel for this spline
+    virtual bool flatten(int &kind, double &mu_out, double &lambda_out) const { (void)kind; (void)mu_out; (void)lambda_out; return false; }
 };
 
-class NeoHookean : public Spline {   // src/XuSpline.hpp:48-62
+namespace detail {
+
+// The three shipped splines differ only in the polynomial / logarithmic pieces below; one class evaluates all of them.
+enum Model { kNeoHookean = 3, kStVK = 4, kCoRotated = 5 };   // = the ADMM_TET_SPLINE_* kinds of include/admm_hip.h
+
+template <Model M>
+class LameSpline : public Spline {
 public:
-    NeoHookean(double mu_, double lambda_, double kappa_) : mu(mu_), lambda(lambda_), kappa(kappa_) {}
+    LameSpline(double mu_, double lambda_, double kappa_) : mu(mu_), lambda(lambda_), kappa(kappa_) {}
     const double mu, lambda, kappa;
-    double f(double x) const { return 0.5 * mu * (x * x - 1.0); }
-    double g(double) const { return 0.0; }
-    double h(double x) const { const double l = std::log(x); return -mu * l + 0.5 * lambda * l * l + compress_term(kappa, x); }
-    double df(double x) const { return mu * x; }
-    double dg(double) const { return 0.0; }
-    double dh(double x) const { return -mu / x + lambda * std::log(x) / x + d_compress_term(kappa, x); }
-    bool flatten(int &kind, double &m, double &l) const { kind = 3; m = mu; l = lambda; return kappa == 0.0; }
+
+    double f(double s) const {
+        const double s2 = s * s;
+        if (M == kNeoHookean) return mu * (s2 - 1.0) / 2.0;
+        if (M == kStVK) return lambda * (s2 * s2 - 6.0 * s2 + 5.0) / 8.0 + mu * (s2 - 1.0) * (s2 - 1.0) / 4.0;
+        return lambda * (s2 - 6.0 * s + 5.0) / 2.0 + mu * (s - 1.0) * (s - 1.0);
+    }
+    double df(double s) const {
+        if (M == kNeoHookean) return mu * s;
+        if (M == kStVK) return lambda * (s * s * s - 3.0 * s) / 2.0 + mu * s * (s * s - 1.0);
+        return lambda * (s - 3.0) + 2.0 * mu * (s - 1.0);
+    }
+    double g(double p) const { return M == kNeoHookean ? 0.0 : M == kStVK ? lambda * (p * p - 1.0) / 4.0 : lambda * (p - 1.0); }
+    double dg(double p) const { return M == kNeoHookean ? 0.0 : M == kStVK ? lambda * p / 2.0 : lambda; }
+    double h(double J) const {
+        double v = compress_term(kappa, J);
+        if (M == kNeoHookean) { const double lJ = std::log(J); v += lJ * (lambda * lJ / 2.0 - mu); }
+        return v;
+    }
+    double dh(double J) const {
+        double v = d_compress_term(kappa, J);
+        if (M == kNeoHookean) v += (lambda * std::log(J) - mu) / J;
+        return v;
+    }
+    bool flatten(int &kind, double &mu_out, double &lambda_out) const {
+        kind = (int)M; mu_out = mu; lambda_out = lambda;
+        return kappa == 0.0;
+    }
 };
 
-class StVK : public Spline {         // src/XuSpline.hpp:64-82
-public:
-    StVK(double mu_, double lambda_, double kappa_) : mu(mu_), lambda(lambda_), kappa(kappa_) {}
-    const double mu, lambda, kappa;
-    double f(double x) const { const double x2 = x * x; return 0.125 * lambda * (x2 * x2 - 6.0 * x2 + 5.0) + 0.25 * mu * (x2 - 1.0) * (x2 - 1.0); }
-    double g(double x) const { return 0.25 * lambda * (x * x - 1.0); }
-    double h(double x) const { return compress_term(kappa, x); }
-    double df(double x) const { const double x2 = x * x; return 0.125 * lambda * (4.0 * x2 * x - 12.0 * x) + mu * x * (x2 - 1.0); }
-    double dg(double x) const { return 0.5 * lambda * x; }
-    double dh(double x) const { return d_compress_term(kappa, x); }
-    bool flatten(int &kind, double &m, double &l) const { kind = 4; m = mu; l = lambda; return kappa == 0.0; }
-};
+} // namespace detail
 
-class CoRotated : public Spline {    // src/XuSpline.hpp:84-96
-public:
-    CoRotated(double mu_, double lambda_, double kappa_) : mu(mu_), lambda(lambda_), kappa(kappa_) {}
-    const double mu, lambda, kappa;
-    double f(double x) const { return 0.5 * lambda * (x * x - 6.0 * x + 5.0) + mu * (x - 1.0) * (x - 1.0); }
-    double g(double x) const { return lambda * (x - 1.0); }
-    double h(double x) const { return compress_term(kappa, x); }
-    double df(double x) const { return 0.5 * lambda * (2.0 * x - 6.0) + 2.0 * mu * (x - 1.0); }
-    double dg(double) const { return lambda; }
-    double dh(double x) const { return d_compress_term(kappa, x); }
-    bool flatten(int &kind, double &m, double &l) const { kind = 5; m = mu; l = lambda; return kappa == 0.0; }
-};
+// src/XuSpline.hpp:48-62, :64-82, :84-96 -- same names and (mu, lambda, kappa) constructors
+struct NeoHookean : detail::LameSpline<detail::kNeoHookean> { NeoHookean(double mu_, double lambda_, double kappa_) : LameSpline(mu_, lambda_, kappa_) {} };
+struct StVK : detail::LameSpline<detail::kStVK> { StVK(double mu_, double lambda_, double kappa_) : LameSpline(mu_, lambda_, kappa_) {} };
+struct CoRotated : detail::LameSpline<detail::kCoRotated> { CoRotated(double mu_, double lambda_, double kappa_) : LameSpline(mu_, lambda_, kappa_) {} };
 
 } // namespace xu
 } // namespace admm

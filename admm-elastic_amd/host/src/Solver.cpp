@@ -258,7 +258,7 @@ int LinearSolver::solve(VecX &x, const VecX &b) {
 }
 
 // ---------------------------------------------------------------- Solver ----------------------------
-Solver::Solver() : device(0), initialized(false), m_constraints(std::make_shared<ConstraintSet>()), m_ctx(nullptr) {}
+Solver::Solver() : device(0), m_ctx(nullptr), initialized(false), m_constraints(std::make_shared<ConstraintSet>()) {}
 Solver::~Solver() { release(); }
 void Solver::release() { if (m_ctx) { admm_hip_destroy((admm_hip_ctx *)m_ctx); m_ctx = nullptr; } }
 
@@ -434,7 +434,7 @@ void Solver::Settings::help() {
            "\t-ck: constraint weights (-1 = auto) \n==========================================\n");
 }
 
-void Solver::RuntimeData::print(const Settings &settings) { // src/Solver.cpp:309-319
+void Solver::RuntimeData::print(const Solver::Settings &settings) { // src/Solver.cpp:309-319
     const double n = double(settings.admm_iters);
     std::cout << "\nTotal global step: " << global_ms << "ms\nTotal local step: " << local_ms << "ms\nTotal collision update: " << collision_ms
               << "ms\nAvg global step: " << global_ms / n << "ms\nAvg local step: " << local_ms / n << "ms\nAvg collision update: "

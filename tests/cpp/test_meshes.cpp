@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include "AddMeshes.hpp"
 #include "ExplicitForce.hpp"
+#include "XuSpline.hpp"
 
 using namespace admm;
 
@@ -54,6 +55,27 @@ int main(int argc, char **argv) {
             CHECK(std::fabs(sh->signed_volume((int)t) - g->signed_volume((int)t)) < 1e-12);
             for (int c = 0; c < 4; ++c) CHECK((sh->vertices[sh->tets[t][c]] - g->vertices[g->tets[t][c]]).norm() == 0.0);
         }
+    }
+    {   // xu:: splines (XuSpline.hpp): the header's shared evaluation against the formulas of the paper written out per
+        // spline (f, g, h and derivatives, kappa included), and the kinds / constants flatten() reports
+        const double mu = 3.0, la = 7.0, ka = 2.0;
+        xu::NeoHookean sn(mu, la, ka); xu::StVK ss(mu, la, ka); xu::CoRotated sc(mu, la, ka);
+        for (double x = 0.3; x < 2.5; x += 0.37) {
+            const double x2 = x * x, l = std::log(x), ct = (ka / 12.0) * std::pow((1.0 - x) / 6.0, 3.0), dct = (-ka / 24.0) * std::pow((1.0 - x) / 6.0, 2.0);
+            const double e[18] = {0.5 * mu * (x2 - 1), 0, -mu * l + 0.5 * la * l * l + ct, mu * x, 0, -mu / x + la * l / x + dct,
+                                  0.125 * la * (x2 * x2 - 6 * x2 + 5) + 0.25 * mu * (x2 - 1) * (x2 - 1), 0.25 * la * (x2 - 1), ct,
+                                  0.125 * la * (4 * x2 * x - 12 * x) + mu * x * (x2 - 1), 0.5 * la * x, dct,
+                                  0.5 * la * (x2 - 6 * x + 5) + mu * (x - 1) * (x - 1), la * (x - 1), ct, 0.5 * la * (2 * x - 6) + 2 * mu * (x - 1), la, dct};
+            const double g[18] = {sn.f(x), sn.g(x), sn.h(x), sn.df(x), sn.dg(x), sn.dh(x), ss.f(x), ss.g(x), ss.h(x), ss.df(x), ss.dg(x), ss.dh(x),
+                                  sc.f(x), sc.g(x), sc.h(x), sc.df(x), sc.dg(x), sc.dh(x)};
+            for (int i = 0; i < 18; ++i) CHECK(std::fabs(e[i] - g[i]) <= 1e-12 * (1 + std::fabs(e[i])));
+        }
+        int kd; double m_, l_;
+        CHECK(!sn.flatten(kd, m_, l_));                                             // kappa != 0: no kernel
+        xu::StVK s0(mu, la, 0.0); CHECK(s0.flatten(kd, m_, l_) && kd == 4 && m_ == mu && l_ == la);
+        xu::CoRotated c0(mu, la, 0.0); CHECK(c0.flatten(kd, m_, l_) && kd == 5);
+        xu::NeoHookean n0(mu, la, 0.0); CHECK(n0.flatten(kd, m_, l_) && kd == 3);
+        CHECK(n0.mu == mu && n0.lambda == la && n0.kappa == 0.0);                   // public constants as in the reference
     }
     // TetGen round trip (0-based) and a 1-based file with a flipped tet
     meshio::save_tetgen(tmp, *m);
