@@ -142,6 +142,25 @@ def test_detect_parity(n, amp):
 
 
 @pytest.mark.gpu
+def test_detect_tiny_meshes():
+    """Smallest possible objects: two single tets (trees of one padded leaf group), one corner of the second inside the
+    first; and a mesh that touches nothing."""
+    sc = scenes.Scene()
+    t0 = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    t1 = np.array([[0.2, 0.25, 0.15], [1.2, 1.3, 0.2], [1.3, 0.2, 1.1], [0.3, 1.4, 1.2]])
+    one = np.array([[0, 1, 2, 3]], np.int32)
+    for v in (t0, t1, t0 + 10.0):
+        if meshes.tet_volumes(v, one)[0] < 0:
+            v = v[[0, 2, 1, 3]]
+        off = sc.add_tet_mesh(v, one, scenes.Lame(1e6, 0.3), pkg.TET_LINEAR)
+        sc.add_self_collision(v, one, off)
+    sc.settings.update(linsolver=2)
+    ho = sc.make_oracle().detect_dynamic(sc.x.ravel())
+    assert [h[0] for h in ho] == [4]                       # the corner of the second tet that sits inside the first
+    _same_hits(sc.make_solver().detect_dynamic(sc.x.ravel()), ho)
+
+
+@pytest.mark.gpu
 def test_detect_three_meshes_first_object_keeps_the_payload():
     """A vertex inside two other meshes at once: the object added first answers (DynamicObject.hpp:73)."""
     sc = scenes.two_blocks_scene(2, floor=None)
