@@ -130,6 +130,7 @@ struct admm_hip_ctx {
     int nt = 0, ldt = 0;
     int kind_begin[5] = {0, 0, 0, 0, 0}; // [linear | NH (+ NH spline) | StVK (+ StVK spline) | co-rotated spline | end]
     std::vector<int> tet_perm;
+    std::vector<int> tri_perm;        // device slot -> caller's triangle index (sorted like the tets: lowest vertex first)
     DevBuf<int4> t_idx;
     DevBuf<double> t_Binv, t_u, t_z, t_sc, t_cf;
     DevBuf<int> t_mat;
@@ -939,8 +940,18 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         const int n = c->ntri, ld = c->ldr;
         std::vector<int4> idx(n);
         std::vector<double> rest((size_t)4 * ld, 0.0), sc(ld, 0.0), lmin(ld, -100.0), lmax(ld, 100.0);
+        c->tri_perm.resize(n);
+        std::iota(c->tri_perm.begin(), c->tri_perm.end(), rb);
+        auto rmin = [&](int t) { return std::min(d->tri_idx[3 * (size_t)t], std::min(d->tri_idx[3 * (size_t)t + 1], d->tri_idx[3 * (size_t)t + 2])); };
+        auto rsum = [&](int t) { return (long long)d->tri_idx[3 * (size_t)t] + d->tri_idx[3 * (size_t)t + 1] + d->tri_idx[3 * (size_t)t + 2]; };
+        std::stable_sort(c->tri_perm.begin(), c->tri_perm.end(), [&](int a, int b) {   // same locality rule as the tets
+            const int ma = rmin(a), mb = rmin(b);
+            return ma != mb ? ma < mb : rsum(a) < rsum(b);
+        });
+        std::vector<int32_t> tri_sorted(3 * (size_t)n);
         for (int t = 0; t < n; ++t) {
-            const int o = rb + t;
+            const int o = c->tri_perm[t];
+            for (int k = 0; k < 3; ++k) tri_sorted[3 * (size_t)t + k] = d->tri_idx[3 * (size_t)o + k];
             idx[t] = make_int4(d->tri_idx[3 * o], d->tri_idx[3 * o + 1], d->tri_idx[3 * o + 2], 0);
             for (int k = 0; k < 4; ++k) rest[(size_t)k * ld + t] = d->tri_rest[4 * (size_t)o + k];
             sc[t] = dt2 * d->tri_weight[o] * d->tri_weight[o];
@@ -951,7 +962,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->r_u.alloc((size_t)6 * ld)); HIP_TRY(c->r_u.zero());
         HIP_TRY(c->r_z.alloc((size_t)6 * ld)); HIP_TRY(c->r_z.zero());
         HIP_TRY(c->r_cf.alloc((size_t)12 * ld)); HIP_TRY(c->r_cf.zero());
-        HIP_TRY(c->r_inc.upload(admm_host::incidence_sell(nv, n, 3, d->tri_idx + 3 * (size_t)rb, n * 4)));
+        HIP_TRY(c->r_inc.upload(admm_host::incidence_sell(nv, n, 3, tri_sorted.data(), n * 4)));
     }
     // ---- pins ----
     double max_w = 0.0;
@@ -1416,7 +1427,7 @@ static void rows_to_dev(const admm_hip_ctx *c, const double *rows, std::vector<d
         for (int k = 0; k < 9; ++k) tu[(size_t)k * c->ldt + n] = rows[9 * (size_t)c->tet_perm[n] + k];
     const double *r = rows + 9 * (size_t)c->nt_total;
     for (int t = 0; t < c->ntri; ++t)
-        for (int k = 0; k < 6; ++k) ru[(size_t)k * c->ldr + t] = r[6 * (size_t)(c->tri_begin + t) + k];
+        for (int k = 0; k < 6; ++k) ru[(size_t)k * c->ldr + t] = r[6 * (size_t)c->tri_perm[t] + k];
     r += 6 * (size_t)c->ntri_total;
     for (int p = 0; p < c->npin_terms; ++p)
         for (int k = 0; k < 3; ++k) pu[3 * (size_t)p + k] = r[6 * (size_t)p + k];
@@ -1426,7 +1437,7 @@ static void dev_to_rows(const admm_hip_ctx *c, const std::vector<double> &tu, co
         for (int k = 0; k < 9; ++k) rows[9 * (size_t)c->tet_perm[n] + k] = tu[(size_t)k * c->ldt + n];
     double *r = rows + 9 * (size_t)c->nt_total;
     for (int t = 0; t < c->ntri; ++t)
-        for (int k = 0; k < 6; ++k) r[6 * (size_t)(c->tri_begin + t) + k] = ru[(size_t)k * c->ldr + t];
+        for (int k = 0; k < 6; ++k) r[6 * (size_t)c->tri_perm[t] + k] = ru[(size_t)k * c->ldr + t];
     r += 6 * (size_t)c->ntri_total;
     for (int p = 0; p < c->npin_terms; ++p) {
         for (int k = 0; k < 3; ++k) r[6 * (size_t)p + k] = pu[3 * (size_t)p + k];

@@ -181,6 +181,26 @@ def test_tet_order_does_not_matter():
     assert scenes.rel_err(s2.m_x, s.m_x) < 1e-10
 
 
+def test_triangle_order_does_not_matter():
+    """Same for triangles: shuffled input, same rows (bitwise) and the same trajectory."""
+    sc = scenes.cloth_scene(12)
+    sc2 = scenes.cloth_scene(12)
+    rng = np.random.default_rng(4)
+    verts, tris, lame, off = sc2.tris[0]
+    p = rng.permutation(len(tris))
+    sc2.tris[0] = (verts, tris[p], lame, off)
+    s, s2 = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=800), sc2.make_solver(pcg_tol=1e-12, pcg_max_iters=800)
+    x = scenes.perturb(sc.x, 0.01, seed=6).ravel()
+    u0 = 0.03 * rng.standard_normal(s.num_rows())
+    rows = np.concatenate([(6 * p[:, None] + np.arange(6)).ravel(), np.arange(6 * len(tris), s.num_rows())])
+    z, u = s.local_step(x, u0)
+    z2, u2 = s2.local_step(x, u0[rows])
+    assert np.array_equal(z2, z[rows]) and np.array_equal(u2, u[rows])
+    for _ in range(3):
+        s.step(); s2.step()
+    assert scenes.rel_err(s2.m_x, s.m_x) < 1e-9
+
+
 def test_step_parity_mixed_materials():
     sc = scenes.mixed_cube_scene(6, admm_iters=20, linsolver=0)
     s, o = run_both(sc, 3, pcg_tol=1e-11, pcg_max_iters=300)
