@@ -106,6 +106,7 @@ struct admm_hip_ctx {
     hipEvent_t ev_coll0 = nullptr, ev_coll1 = nullptr;   // around Collider::detect (UzawaCG path), when stats are requested
     bool timing = false; double coll_ms_step = 0.0;
     // kernel-level timing of the tet local-step launches (device wall clock, kernels.hpp: ts_enter / ts_exit)
+    int oc_poly_m = 0; double oc_lmax = 2.0, oc_poly_ratio = 30.0;   // Chebyshev preconditioner of the on-chip PCG
     DevBuf<unsigned long long> lk_ts, lk_out; int lk_tsn = 0, lk_launch = 0, lk_cap = 0; double lk_tick_ms = 0.0;
     std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration (+1) when stats are requested
 
@@ -360,11 +361,24 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
     a.spb = c->oc_spb; a.wl = c->oc_wl; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
     a.tol2 = c->pcg_tol * c->pcg_tol;
+    a.poly_m = c->oc_poly_m;
+    if (a.poly_m >= 2) {   // Chebyshev coefficients on [lmax / ratio, lmax]
+        const double hi = c->oc_lmax, lo = hi / c->oc_poly_ratio;
+        const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
+        double rho = 1.0 / sigma;
+        a.cheb_inv_theta = 1.0 / theta;
+        for (int k = 0; k < 8; ++k) {
+            const double rn = 1.0 / (2.0 * sigma - rho);
+            a.cheb_c1[k] = rn * rho; a.cheb_c2[k] = 2.0 * rn / delta;
+            rho = rn;
+        }
+    }
     a.rc_on = rc.on ? 1 : 0; a.rc = rc.B; a.rc_xs = c->rc_xs.p; a.rc_r0 = c->rc_r0.p; a.rc_Eslot = rc.Eslot; a.rc_Rslot = rc.Rslot;
     a.rc_part = c->oc_rc_part.p;
     a.prof = c->oc_prof.p;
     a.prof_block = c->oc_prof_block;
-    if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    if (a.poly_m >= 2 && c->oc_nbr.p && c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768, true>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    else if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg_onchip<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     c->last_launched_iters = 0; // the verdict of the solve is written to cg_scal[0]
     if (c->oc_debug || c->oc_prof.p) return oc_diagnostics(c, a.seq);
@@ -395,6 +409,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     const size_t lds = fixed + (size_t)T * wl * 12;
     const void *fn = T <= 768 ? (const void *)k_pcg_onchip<768> : (const void *)k_pcg_onchip<1024>;
     if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     int per_cu = 0;
     if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<1024>, T, lds);
@@ -1026,6 +1041,23 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
             for (int j = 0; j < 3; ++j) dinv[3 * (size_t)vtx + j] = 1.0 / (mass[3 * (size_t)vtx + j] + diag);
         }
         HIP_TRY(c->m.upload(mass)); HIP_TRY(c->dinv.upload(dinv));
+        // rigorous upper bound of the spectrum of D^-1 A (Gershgorin on D^-1/2 A D^-1/2, per axis): the interval of the
+        // Chebyshev preconditioner of the on-chip PCG must contain the largest eigenvalue
+        double lmax = 1.0;
+        for (int vtx = 0; vtx < nv; ++vtx)
+            for (int j = 0; j < 3; ++j) {
+                const double di = dinv[3 * (size_t)vtx + j];
+                double row = 1.0;
+                for (int k = c->Ahat.rowptr[vtx]; k < c->Ahat.rowptr[vtx + 1]; ++k) {
+                    const int col = c->Ahat.col[k];
+                    if (col != vtx) row += std::fabs(c->Ahat.val[k]) * std::sqrt(di * dinv[3 * (size_t)col + j]);
+                }
+                lmax = std::max(lmax, row);
+            }
+        c->oc_lmax = lmax;
+        const char *pm = getenv("ADMM_HIP_OC_POLY"), *pr = getenv("ADMM_HIP_OC_POLY_RATIO");
+        c->oc_poly_m = pm ? std::max(0, std::min(8, atoi(pm))) : 0;
+        if (pr && atof(pr) > 1.0) c->oc_poly_ratio = atof(pr);
     }
     HIP_TRY(c->x.alloc(c->n3)); HIP_TRY(c->x.zero());
     HIP_TRY(c->v.alloc(c->n3)); HIP_TRY(c->v.zero());

@@ -83,6 +83,10 @@ struct OcArgs {
     double *rc_Eslot, *rc_Rslot; // where this solve's pair goes
     double *rc_part;             // [3 * kRcQ rounded up to 72][G] block partial sums of the projection
     double tol2;
+    // Chebyshev polynomial of D^-1 A as preconditioner (poly_m = degree, 0 / 1 = plain Jacobi): u = sum_k d_k with
+    // d_0 = D^-1 r / theta, d_{k+1} = c1[k] d_k + c2[k] (res_k - D^-1 A d_k)  (Saad, Iterative Methods, Alg. 12.1)
+    int poly_m;
+    double cheb_inv_theta, cheb_c1[8], cheb_c2[8];
 };
 
 constexpr int kOcScratch = 6144;          // bytes of LDS scratch ahead of the per-wave staging area and the matrix slab
@@ -225,9 +229,10 @@ __device__ __forceinline__ bool oc_barrier_wait(unsigned *bar, unsigned epoch, i
 // then two rotation steps over the 16-lane row, all with DPP; the four rows of a wave and the waves of the
 // block are summed through LDS by six threads in a fixed order.  One __syncthreads; `red` may be reused after
 // the next barrier.
-__device__ __forceinline__ void oc_publish_partials(const double *q6, double *red /* [16][4][8] */, int nw, __amdgpu_buffer_rsrc_t rs_p, int par, int G) {
+__device__ __forceinline__ void oc_publish_partials(const double *q6, double *red /* [16][4][8] */, int nw, __amdgpu_buffer_rsrc_t rs_p, int par, int G,
+                                                    double q7 = 0.0, int nq = 6) {
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double q8[8] = {q6[0], q6[1], q6[2], q6[3], q6[4], q6[5], 0.0, 0.0};
+    const double q8[8] = {q6[0], q6[1], q6[2], q6[3], q6[4], q6[5], q7, 0.0};
     double b[2];
     row_sum8(q8, b[0], b[1]);
     if ((lane & 15) < 4) {
@@ -236,7 +241,7 @@ __device__ __forceinline__ void oc_publish_partials(const double *q6, double *re
         dst[0] = b[0]; dst[1] = b[1];
     }
     __syncthreads();
-    if (tid < 6) {
+    if (tid < nq) {
         double sm = 0.0;
         for (int r = 0; r < 4 * nw; ++r) sm += red[r * 8 + tid];
         oc_store_sc1(rs_p, ((par * 8 + tid) * G + (int)blockIdx.x) * 8, sm);
@@ -302,7 +307,9 @@ __device__ __forceinline__ void oc_row(__amdgpu_buffer_rsrc_t rs, int buf_off, i
     }
 }
 
-template <int MAXT>
+// POLY = the build with the Chebyshev-preconditioned loop (its own instantiation: the extra live values must not
+// cost the default kernel registers)
+template <int MAXT, bool POLY = false>
 __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     constexpr bool DEEP = MAXT <= 768;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -373,25 +380,28 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         }
     };
     // after the barrier of phase ph: out = A (published vector), bc[0..5] = the six global sums
+    int nsum = 6;      // sums per record (7 in the polynomial mode: + the Jacobi-norm residual)
+    int rec_par = -1;  // record buffer to reduce from; -1 = the phase parity (one phase per iteration)
     auto gather_and_reduce = [&](const double *self, double *out, bool do_gather, bool do_reduce) {
-        const int par = (int)(ph & 1u);
+        const int vpar = (int)(ph & 1u);
+        const int par = rec_par >= 0 ? rec_par : vpar;
         double rec[4] = {0.0, 0.0, 0.0, 0.0};
-        if (do_reduce && wv < 6) {
+        if (do_reduce && wv < nsum) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const int g = lane + 64 * j; if (g < a.G) rec[j] = oc_load_sc1_f64(rs_p, ((par * 8 + wv) * a.G + g) * 8); }
         }
         if (do_gather) {
             double acc[3];
-            oc_row<true, DEEP>(rs_u, par * ub, as, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
+            oc_row<true, DEEP>(rs_u, vpar * ub, as, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
 #pragma unroll
             for (int j = 0; j < 3; ++j) out[j] = fma(rm[j], self[j], acc[j]);
         }
         if (!do_reduce) return;
-        if (wv < 6) {
+        if (wv < nsum) {
             const double sm = wave_sum(((rec[0] + rec[1]) + rec[2]) + rec[3]);
             if (lane == 0) bc[wv] = sm;
         }
-        for (int k = wv + nw; k < 6; k += nw) {   // blocks with fewer than 6 waves
+        for (int k = wv + nw; k < nsum; k += nw) {   // blocks with fewer waves than sums
             double sm = 0.0;
             for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_p, ((par * 8 + k) * a.G + g) * 8);
             sm = wave_sum(sm);
@@ -658,9 +668,112 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
             }
             return action() == 1 ? 1 : 0;
         };
-        // ---- pipelined CG (Ghysels-Vanroose): one synchronisation per iteration, while its recurrences are trusted ----
         bool entry_restart = false, go_classic = false;
-        while (iters < a.max_iters) {
+        // ---- Chebyshev-preconditioned CG (Chronopoulos-Gear single-reduction form) ---------------------------------------
+        // The iteration of this kernel costs one exchange of a vector (publish + neighbour hand-off + gather: no grid
+        // barrier) plus one grid-wide reduction round, and the reduction round is the larger half.  u = P(D^-1 A) D^-1 r
+        // with a degree-m Chebyshev polynomial costs m - 1 more exchanges per iteration and cuts the number of
+        // iterations -- i.e. of reduction rounds -- by about m + 1 at ~1.2x the matrix-vector products.  r lives in the
+        // registers of the pipelined form's z.  Stop test: the Jacobi-norm residual r . D^-1 r of every iteration rides in
+        // a seventh sum (the three axes added up after scaling by their 1 / b.D^-1 b: at most 3x stricter than the
+        // per-axis rule); it triggers the same true-residual verification as before.  Anything irregular (runaway or
+        // non-finite sums, failed verification) hands over to the classic Jacobi form below with a restart.
+        const bool poly = POLY && a.poly_m >= 2 && a.nbr != nullptr && kOcTrig * a.tol2 >= kOcPipeFloor;
+        if (POLY && poly) {
+            double *chb = (double *)(smem + 5632);     // [16] c1[8], c2[8] (indexed by a run-time k: LDS, not registers)
+            if (tid < 16) chb[tid] = tid < 8 ? a.cheb_c1[tid & 7] : a.cheb_c2[tid & 7];
+            __syncthreads();
+            nsum = 7;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rz[j] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;       // r (u = D^-1 r so far)
+            double rho_best = 1e300;
+            while (iters < a.max_iters) {
+                double res[3], dd[3], t[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { res[j] = rd[j] * rz[j]; dd[j] = res[j] * a.cheb_inv_theta; ru[j] = 0.0; }
+                bool fail = false;
+                for (int k = 0; k < a.poly_m; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) ru[j] += dd[j];
+                    if (k == a.poly_m - 1) break;
+                    ++ph; publish(dd);
+                    if (!oc_announce_and_wait_neighbours(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { fail = true; break; }
+                    gather_and_reduce(dd, t, true, false);                                   // t = A d
+                    const double c1 = chb[k], c2 = chb[8 + k];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { res[j] = fma(-rd[j], t[j], res[j]); dd[j] = fma(c1, dd[j], c2 * res[j]); }
+                }
+                if (fail) { aborted = true; break; }
+                ++ph; publish(ru);
+                if (!oc_announce_and_wait_neighbours(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; }
+                gather_and_reduce(ru, rw, true, false);                                      // w = A u
+                double q[6], rho = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    q[j] = rz[j] * ru[j];                                                    // gamma = r . u
+                    q[3 + j] = rw[j] * ru[j];                                                // delta = w . u
+                    rho = fma(rz[j] * rd[j] * rz[j], ctl[8 + j], rho);                       // sum_j r.D^-1 r / b.D^-1 b
+                }
+                // records alternate by ITERATION (an iteration is m + 1 phases: with the phase parity a block that runs
+                // ahead through the neighbour-synchronised exchanges could overwrite a record others still reduce)
+                ++ph;
+                rec_par = iters & 1;
+                oc_publish_partials(q, red, nw, rs_p, rec_par, a.G, rho, 7);
+                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { rec_par = -1; aborted = true; break; }
+                gather_and_reduce(nullptr, nullptr, false, true);
+                rec_par = -1;
+                if (wv == 0) {   // lanes 0..2 = one axis each
+                    const int j = lane < 3 ? lane : 0;
+                    const double g = bc[j], d = bc[3 + j], rr = bc[6];
+                    const unsigned long long m3 = 7ull;
+                    const bool finite = (__ballot(g < 1e290 && g >= 0.0 && d < 1e290) & m3) == m3 && rr < 1e290 && !(rr > 1e16 * rho_best);
+                    int act = 0;
+                    if (!finite) act = 2;
+                    else if (rr <= kOcTrig * a.tol2) act = 1;
+                    else if (lane < 3) {
+                        double alpha, beta;
+                        if (fresh) { beta = 0.0; alpha = (d > 0.0) ? g / d : 0.0; }
+                        else {
+                            const double gp = sc[j], ap = sc[3 + j];
+                            beta = (gp > 0.0) ? g / gp : 0.0;
+                            const double den = (ap != 0.0) ? d - beta * g / ap : d;
+                            alpha = (den > 0.0) ? g / den : 0.0;
+                        }
+                        sc[j] = g; sc[3 + j] = alpha;
+                        ctl[2 + j] = alpha; ctl[5 + j] = beta;
+                    }
+                    rho_best = fmin(rho_best, rr);
+                    if (lane == 0) ictl[2] = act;
+                }
+                const int act = action();
+                if (act == 2) { entry_restart = true; go_classic = true; break; }
+                if (act == 1) {
+                    const int v = verify();
+                    if (v < 0) { aborted = true; break; }
+                    if (v == 1) { conv = true; break; }
+                    go_classic = true; fresh = true;
+                    break;
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double alpha = ctl[2 + j], beta = ctl[5 + j];
+                    rp[j] = fma(beta, rp[j], ru[j]);
+                    rsv[j] = fma(beta, rsv[j], rw[j]);
+                    rx[j] = fma(alpha, rp[j], rx[j]);
+                    rz[j] = fma(-alpha, rsv[j], rz[j]);
+                }
+                __syncthreads();   // ctl / bc are rewritten by the next iteration
+                ++iters; ++pipe_iters; fresh = false;
+            }
+            nsum = 6;
+            if (!conv && !go_classic && !aborted) {   // iteration cap: leave u = D^-1 r behind (epilogue, recycled pair)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ru[j] = rd[j] * rz[j];
+            }
+            if (aborted || conv || !go_classic) break;
+        }
+        // ---- pipelined CG (Ghysels-Vanroose): one synchronisation per iteration, while its recurrences are trusted ----
+        while (!poly && iters < a.max_iters) {
             OC_STAMP(0);
             double rn[3] = {0.0, 0.0, 0.0};
             {

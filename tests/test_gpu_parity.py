@@ -517,6 +517,24 @@ def test_onchip_pcg_ill_conditioned_sparse_rhs(tol):
     assert it == 0 and not xg.any()
 
 
+def test_onchip_pcg_chebyshev_mode(monkeypatch):
+    """ADMM_HIP_OC_POLY=m: the Chebyshev-preconditioned loop of the on-chip kernel (default off -- measured slower, DESIGN
+    section 9) gives the same solution in about 1 / (m + 1) of the iterations."""
+    sc = scenes.cube_scene(26, KINDS["neohookean"])
+    o = sc.make_oracle()
+    b = o.A @ np.random.default_rng(9).standard_normal(o.dof)
+    xo = o.solve_ldlt(b)
+    its = {}
+    for m in (0, 3):
+        monkeypatch.setenv("ADMM_HIP_OC_POLY", str(m))
+        s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=2000)     # (the mode is off below 1e-9, like the pipelined form)
+        x, its[m] = s.global_solve(b, np.zeros(o.dof))
+        assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo), m
+        s.close()
+    monkeypatch.delenv("ADMM_HIP_OC_POLY")
+    assert 0 < its[3] < 0.5 * its[0], its
+
+
 def test_onchip_pcg_big_system_residual(big):
     """~1M tets (all 256 CUs, 11 waves each): the returned x satisfies ||b - A x|| <= tol ||b|| in the
     D^-1 norm, checked on the host with the host-assembled matrix."""
