@@ -1360,7 +1360,9 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
         }
     }
     c->timing = timed; c->coll_ms_step = 0.0; c->lk_launch = 0;
-    if (timed && c->nt > 0) {
+    // opt-in (ADMM_HIP_KERNEL_CLOCK=1): the stamps themselves cost the local-step launch ~1.4 us (2 %)
+    static const bool kernel_clock = [] { const char *e = getenv("ADMM_HIP_KERNEL_CLOCK"); return e && e[0] == '1'; }();
+    if (timed && c->nt > 0 && kernel_clock) {
         const int tsn = 4 * (blocks_for(c->nt) + 4), cap = 2 * admm_iters;
         if (c->lk_tsn != tsn || c->lk_cap < cap) {
             c->lk_ts.release(); c->lk_out.release();

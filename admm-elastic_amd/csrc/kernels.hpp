@@ -134,8 +134,8 @@ struct TetArgs {
     int ld;
     const int4 *idx; const double *Binv; double *u; double *z; const double *sc; const int *mat_id; const Mat *mats;
     const double *x; double *cf;
-    // kernel-level timing (stats only): every wave stores the device wall clock at entry in ts[wave slot] and, once its
-    // stores have drained, at exit in ts[ts_n + wave slot]; nullptr = off.  max(exit) - min(entry) is the launch's
+    // kernel-level timing (stats only): every wave stores the device wall clock at entry in ts[wave slot] and at exit in
+    // ts[ts_n + wave slot]; nullptr = off.  max(exit) - min(entry) is the launch's
     // duration as rocprofv3 reports it, without the dispatch gaps an event pair around the launch also counts.
     unsigned long long *ts; int ts_n;
 };
@@ -143,10 +143,9 @@ __device__ __forceinline__ void ts_enter(const TetArgs &a) {
     if (a.ts && (threadIdx.x & 63) == 0) a.ts[blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64();
 }
 __device__ __forceinline__ void ts_exit(const TetArgs &a) {
-    if (a.ts) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if ((threadIdx.x & 63) == 0) a.ts[a.ts_n + blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64();
-    }
+    // (no wait for the wave's own stores here: holding the wave slot until they have drained made the kernel itself 4 us
+    // longer; the stamp therefore precedes the drain of the last stores, ~1 us)
+    if (a.ts && (threadIdx.x & 63) == 0) a.ts[a.ts_n + blockIdx.x * 4 + (threadIdx.x >> 6)] = wall_clock64();
 }
 // per launch slot: min over the waves' entry stamps (0 = wave never ran), max over their exit stamps
 __global__ __launch_bounds__(256) void k_ts_reduce(const unsigned long long *__restrict__ ts, int ts_n, int n_launches,

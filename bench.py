@@ -230,9 +230,10 @@ def main():
             # Duration of one launch, measured live in the timed region on the context's own stream, three ways that bracket
             # each other: (1) `avg_launch_us` = interval between two hipEventRecords around the launch (kernel + the two
             # dispatch gaps: the CONSERVATIVE figure, used for `achieved` / `frac`); (2) rocprofv3 --kernel-trace of the same
-            # command (profiles/): 4-5 us shorter; (3) `kernel_us_device_clock`: every wave stamps the device wall clock at
-            # entry and, once its stores have drained, at exit -- max exit - min entry is another 2-3 us shorter than rocprofv3
-            # (it misses the dispatch ramp-up and the end-of-kernel cache release).
+            # command (profiles/): 4-5 us shorter; (3) `kernel_us_device_clock` (only with ADMM_HIP_KERNEL_CLOCK=1: the stamps
+            # cost the launch ~2 %): every wave stamps the device wall clock at entry and exit -- max exit - min entry is
+            # another 2-3 us shorter than rocprofv3 (it misses the dispatch ramp-up, the drain of the last stores and the
+            # end-of-kernel cache release).
             avg_s = 1e-3 * local_ms / launches
             achieved = bytes_per_launch / avg_s / 1e9
             out["roofline"] = {"kernel": "k_local_tris" if w["kinds"] == "cloth" else "k_local_tets (all constitutive models of one ADMM iteration)", "bound": "hbm",

@@ -136,7 +136,8 @@ typedef struct {
     double local_kernel_ms;       /* sum of the tet local-step KERNEL durations of this step, from the device wall clock
                                    * (every wave stamps its entry and, after its stores have drained, its exit; duration =
                                    * max exit - min entry): what rocprofv3 --kernel-trace reports.  local_ms above is the
-                                   * PHASE between two event records, dispatch gaps included.  0 when there are no tets. */
+                                   * PHASE between two event records, dispatch gaps included.  Opt-in (ADMM_HIP_KERNEL_CLOCK=1:
+                                   * the stamps cost the launch ~2 %); 0 otherwise, or when there are no tets. */
 } admm_hip_stats;
 
 const char *admm_hip_last_error(void);
