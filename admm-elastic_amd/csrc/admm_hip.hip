@@ -107,6 +107,7 @@ struct admm_hip_ctx {
     bool timing = false; double coll_ms_step = 0.0;
     // kernel-level timing of the tet local-step launches (device wall clock, kernels.hpp: ts_enter / ts_exit)
     int oc_poly_m = 0; double oc_lmax = 2.0, oc_poly_ratio = 30.0;   // Chebyshev preconditioner of the on-chip PCG
+    DevBuf<signed char> oc_color; bool oc_bssor = false;             // block-local symmetric GS preconditioner (2-colourable Ahat)
     DevBuf<unsigned long long> lk_ts, lk_out; int lk_tsn = 0, lk_launch = 0, lk_cap = 0; double lk_tick_ms = 0.0;
     std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration (+1) when stats are requested
 
@@ -236,7 +237,7 @@ struct admm_hip_ctx {
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
         gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
-        lk_ts.release(); lk_out.release();
+        lk_ts.release(); lk_out.release(); oc_color.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
         if (gs_exec) (void)hipGraphExecDestroy(gs_exec);
@@ -377,7 +378,9 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.rc_part = c->oc_rc_part.p;
     a.prof = c->oc_prof.p;
     a.prof_block = c->oc_prof_block;
-    if (a.poly_m >= 2 && c->oc_nbr.p && c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768, true>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    a.row_color = c->oc_bssor ? c->oc_color.p : nullptr;
+    if (a.row_color && c->oc_nbr.p && c->oc_T <= 768 && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<768, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    else if (a.poly_m >= 2 && c->oc_nbr.p && c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768, 1>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg_onchip<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     c->last_launched_iters = 0; // the verdict of the solve is written to cg_scal[0]
@@ -409,7 +412,8 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     const size_t lds = fixed + (size_t)T * wl * 12;
     const void *fn = T <= 768 ? (const void *)k_pcg_onchip<768> : (const void *)k_pcg_onchip<1024>;
     if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     int per_cu = 0;
     if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<1024>, T, lds);
@@ -451,6 +455,27 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
             if ((e = c->oc_nbr.upload(nbr)) != hipSuccess) return e;
             if ((e = c->oc_flags.alloc((size_t)8 * G)) != hipSuccess) return e;
             if ((e = c->oc_flags.zero()) != hipSuccess) return e;
+        }
+    }
+    {   // block-local symmetric Gauss-Seidel preconditioner: needs a 2-colouring of the non-zero pattern of Ahat
+        const char *bs = getenv("ADMM_HIP_OC_BSSOR");
+        c->oc_bssor = false;
+        if (!(bs && bs[0] == '0') && c->oc_nbr.p && T <= 768) {   // on by default; ADMM_HIP_OC_BSSOR=0 = plain Jacobi (A/B)
+            const int nv = c->Ahat.n;
+            std::vector<int32_t> rp(nv + 1, 0), ci;
+            for (int i = 0; i < nv; ++i) {
+                for (int k = c->Ahat.rowptr[i]; k < c->Ahat.rowptr[i + 1]; ++k)
+                    if (c->Ahat.val[k] != 0.0 || c->Ahat.col[k] == i) ci.push_back(c->Ahat.col[k]);
+                rp[i + 1] = (int32_t)ci.size();
+            }
+            std::vector<int32_t> col(nv, 0);
+            const int nc = admm_host::greedy_coloring(nv, rp.data(), ci.data(), col.data());
+            if (nc <= 2) {
+                std::vector<signed char> c8(nv);
+                for (int i = 0; i < nv; ++i) c8[i] = (signed char)col[i];
+                if ((e = c->oc_color.upload(c8)) != hipSuccess) return e;
+                c->oc_bssor = true;
+            }
         }
     }
     c->oc_enabled = true;

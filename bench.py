@@ -209,7 +209,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload + (" (n=%d override)" % args.n if args.n else ""), "elements": nt, "verts": nv,
                    "admm_iters_per_step": iters, "global_solver": "multicolor-GS(30 sweeps)" if w["linsolver"] == 1 else
-                   "Jacobi-PCG (one persistent on-chip launch per solve, pipelined CG) tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters),
+                   "PCG (one persistent on-chip launch per solve, pipelined CG, block-local symmetric Gauss-Seidel preconditioner) tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters),
                    "parallelism": "element-block x%d" % world if world > 1 else "single-gpu"},
         "ms_per_frame": ms_per_step,
         "split_ms_per_admm_iter": {"local": local_ms / (iters * args.steps), "rhs": rhs_ms / (iters * args.steps),

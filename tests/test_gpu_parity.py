@@ -517,22 +517,28 @@ def test_onchip_pcg_ill_conditioned_sparse_rhs(tol):
     assert it == 0 and not xg.any()
 
 
-def test_onchip_pcg_chebyshev_mode(monkeypatch):
-    """ADMM_HIP_OC_POLY=m: the Chebyshev-preconditioned loop of the on-chip kernel (default off -- measured slower, DESIGN
-    section 9) gives the same solution in about 1 / (m + 1) of the iterations."""
+def test_onchip_pcg_preconditioner_modes(monkeypatch):
+    """The three preconditioners of the on-chip kernel give the same solution: plain Jacobi (ADMM_HIP_OC_BSSOR=0), the
+    block-local symmetric Gauss-Seidel (default on 2-colourable meshes: ~1.6x fewer iterations, no extra exchange) and
+    the Chebyshev polynomial (ADMM_HIP_OC_POLY=3, default off: fewer iterations but slower)."""
     sc = scenes.cube_scene(26, KINDS["neohookean"])
     o = sc.make_oracle()
     b = o.A @ np.random.default_rng(9).standard_normal(o.dof)
     xo = o.solve_ldlt(b)
     its = {}
-    for m in (0, 3):
-        monkeypatch.setenv("ADMM_HIP_OC_POLY", str(m))
-        s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=2000)     # (the mode is off below 1e-9, like the pipelined form)
-        x, its[m] = s.global_solve(b, np.zeros(o.dof))
-        assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo), m
+    for name, env in (("jacobi", {"ADMM_HIP_OC_BSSOR": "0"}), ("bssor", {}), ("cheb3", {"ADMM_HIP_OC_BSSOR": "0", "ADMM_HIP_OC_POLY": "3"})):
+        for k in ("ADMM_HIP_OC_BSSOR", "ADMM_HIP_OC_POLY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=2000)     # (both extra modes are off below 1e-9, like the pipelined form)
+        x, its[name] = s.global_solve(b, np.zeros(o.dof))
+        assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo), name
+        x2, it2 = s.global_solve(b, np.zeros(o.dof))
+        assert it2 == its[name] and np.array_equal(x, x2), name          # deterministic
         s.close()
-    monkeypatch.delenv("ADMM_HIP_OC_POLY")
-    assert 0 < its[3] < 0.5 * its[0], its
+    assert 0 < its["cheb3"] < 0.5 * its["jacobi"], its
+    assert 0 < its["bssor"] < 0.75 * its["jacobi"], its
 
 
 def test_onchip_pcg_big_system_residual(big):
