@@ -460,7 +460,9 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     {   // block-local symmetric Gauss-Seidel preconditioner: needs a 2-colouring of the non-zero pattern of Ahat
         const char *bs = getenv("ADMM_HIP_OC_BSSOR");
         c->oc_bssor = false;
-        if (!(bs && bs[0] == '0') && c->oc_nbr.p && T <= 768) {   // on by default; ADMM_HIP_OC_BSSOR=0 = plain Jacobi (A/B)
+        // on by default; ADMM_HIP_OC_BSSOR=0 = plain Jacobi (A/B).  Rows wider than the 32-bit local-entry mask would make
+        // the sweep unsymmetric: such meshes keep Jacobi.
+        if (!(bs && bs[0] == '0') && c->oc_nbr.p && T <= 768 && c->A_wmax <= 32) {
             const int nv = c->Ahat.n;
             std::vector<int32_t> rp(nv + 1, 0), ci;
             for (int i = 0; i < nv; ++i) {
