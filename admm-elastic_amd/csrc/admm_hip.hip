@@ -380,6 +380,7 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.prof_block = c->oc_prof_block;
     a.row_color = c->oc_bssor ? c->oc_color.p : nullptr;
     if (a.row_color && c->oc_nbr.p && c->oc_T <= 768 && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<768, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    else if (a.row_color && c->oc_nbr.p && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<1024, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else if (a.poly_m >= 2 && c->oc_nbr.p && c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768, 1>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg_onchip<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
@@ -414,6 +415,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     int per_cu = 0;
     if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<1024>, T, lds);
@@ -462,7 +464,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
         c->oc_bssor = false;
         // on by default; ADMM_HIP_OC_BSSOR=0 = plain Jacobi (A/B).  Rows wider than the 32-bit local-entry mask would make
         // the sweep unsymmetric: such meshes keep Jacobi.
-        if (!(bs && bs[0] == '0') && c->oc_nbr.p && T <= 768 && c->A_wmax <= 32) {
+        if (!(bs && bs[0] == '0') && c->oc_nbr.p && c->A_wmax <= 32) {
             const int nv = c->Ahat.n;
             std::vector<int32_t> rp(nv + 1, 0), ci;
             for (int i = 0; i < nv; ++i) {
