@@ -48,7 +48,8 @@ enum { ADMM_TET_LINEAR = 0, ADMM_TET_NEOHOOKEAN = 1, ADMM_TET_STVK = 2, ADMM_TET
        ADMM_TET_SPLINE_COROTATED = 5 };
 
 /* global solvers -- Solver::Settings::linsolver, src/Solver.hpp:46 ("0=LDLT, 1=NCMCGS, 2=UzawaCG").
- * 0: the prefactored LDLT (src/LinearSolver.hpp:59-92) is replaced by a Jacobi-preconditioned CG on
+ * 0: the prefactored LDLT (src/LinearSolver.hpp:59-92) is replaced by a preconditioned CG (Jacobi, or a block-local
+ *    symmetric Gauss-Seidel sweep on 2-colourable meshes) on
  *    the GPU iterated to pcg_tol; 1: nodal multi-colour SOR (src/NodalMultiColorGS.hpp); 2: Schur-
  *    complement CG (src/UzawaCG.hpp) whose inner LDLT solves are the same GPU PCG. */
 enum { ADMM_LS_LDLT_AS_PCG = 0, ADMM_LS_NCMCGS = 1, ADMM_LS_UZAWACG = 2 };
