@@ -4,7 +4,7 @@ import shutil
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["csrc/admm_hip.hip", "csrc/host_setup.cpp"]
+SOURCES = ["csrc/admm_hip.hip", "csrc/host_setup.cpp", "csrc/oc_plan.cpp"]
 HEADERS = sorted("csrc/" + f for f in os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")) if f.endswith(".hpp")) + ["../include/admm_hip.h"]
 OUT = os.path.join(HERE, "libadmm_hip.so")
 

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     ("admm_host_greedy_coloring", C.c_int, [C.c_int32, c_int_p, c_int_p, c_int_p]),
     ("admm_host_locality_order", None, [C.c_int32, C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, c_double_p]),
+    ("admm_host_oc_plan", C.c_int, [C.POINTER(Desc), C.c_int32, C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, C.POINTER(C.c_int64)]),
 ]
 
 _lib = None

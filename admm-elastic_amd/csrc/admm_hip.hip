@@ -179,18 +179,24 @@ struct admm_hip_ctx {
     DevBuf<int> oc_nbr; DevBuf<unsigned long long> oc_flags;   // neighbour hand-off of the pipelined iteration
     DevBuf<unsigned long long> oc_prof;   // diagnosis (ADMM_HIP_OC_PROF=1)
     bool oc_debug = false; int oc_prof_block = 0;
+    // general-mesh plan of the on-chip PCG (oc_plan.cpp): internal row order, its SELL, slab shares, two-level data
+    bool oc_plan = false, oc_coarse = false; int oc_rows = 0, oc_bcols = 0, oc_nc = 0, oc_ncp = 0;
+    SellDev oc_A; DevBuf<int> oc_orig, oc_ldsoff, oc_wls; DevBuf<signed char> oc_agg; DevBuf<double> oc_mdiag, oc_ainv, oc_cbuf;
+    int64_t oc_stat[6] = {0, 0, 0, 0, 0, 0};   // nnz, stored, on chip, block-local, max neighbour blocks, coarse unknowns
+    int n3i = 0;   // length of the solver-internal scratch vectors (recycled pairs): max(n3, 3 * oc_rows)
     int solve_seq = 0;
     int marks_expected = 0;       // chunks closed so far (host count)
     int last_launched_iters = 0;
     // recycled warm start (k_rc_*): ring of kRc (correction, initial residual) pairs
-    // Pairs are kept per (frame parity, ADMM iteration index) -- 2 x kRcSlots x 2 vectors, sized for 288 GB
-    // of HBM rather than for a cache; the projection basis of solve s is the last kRc pairs of the frame.
-    static constexpr int kRcSlots = 64;
+    // The projection basis of solve s is the last kRc pairs of the frame, so the pairs live in a ring of kRc + 1 slots
+    // (the slot being written is never one of the kRc being read): 2 (kRc + 1) node vectors, allocated only when the
+    // recycled start is enabled.
+    static constexpr int kRcSlots = kRc + 1;
     DevBuf<double> rc_buf, rc_r0, rc_xs, rc_part, rc_coef;
     int rc_iter = 0, rc_frame = 0, rc_prev_valid = 0, NBR = 1; // pairs of the previous frame valid for s < rc_prev_valid
     bool rc_enabled = true;
-    double *rc_E(int parity, int s) { return rc_buf.p + ((size_t)(parity * kRcSlots + s) * 2 + 0) * (size_t)n3; }
-    double *rc_R(int parity, int s) { return rc_buf.p + ((size_t)(parity * kRcSlots + s) * 2 + 1) * (size_t)n3; }
+    double *rc_E(int s) { return rc_buf.p + ((size_t)(s % kRcSlots) * 2 + 0) * (size_t)n3i; }
+    double *rc_R(int s) { return rc_buf.p + ((size_t)(s % kRcSlots) * 2 + 1) * (size_t)n3i; }
     // UzawaCG (per-vertex constraint rows)
     DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part;
     DevBuf<UzScal> uz_scal;
@@ -232,6 +238,7 @@ struct admm_hip_ctx {
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release();
+        oc_A.release(); oc_orig.release(); oc_ldsoff.release(); oc_wls.release(); oc_agg.release(); oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
@@ -354,9 +361,14 @@ struct OcRc { bool on = false; RcBasis B{}; double *Eslot = nullptr, *Rslot = nu
 int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters, const OcRc &rc = OcRc()) {
     hipStream_t st = c->stream;
     OcArgs a{};
-    a.n_rows = c->A.n_rows; a.n_slices = c->A.n_slices;
-    a.ptr = c->A.ptr.p; a.w = c->A.w.p; a.col = c->A.idx.p; a.val = c->A.val.p;
-    a.m = c->m.p; a.dinv = c->dinv.p; a.b = b; a.x = x; a.u_out = c->cg_u.p;
+    const SellDev &S = c->oc_plan ? c->oc_A : c->A;
+    a.n_rows = S.n_rows; a.n_slices = S.n_slices;
+    a.ptr = S.ptr.p; a.w = S.w.p; a.col = S.idx.p; a.val = S.val.p;
+    a.m = c->oc_plan ? c->oc_mdiag.p : c->m.p; a.dinv = c->dinv.p; a.b = b; a.x = x; a.u_out = c->cg_u.p;
+    if (c->oc_plan) {
+        a.orig = c->oc_orig.p; a.lds_off = c->oc_ldsoff.p; a.wl_s = c->oc_wls.p; a.bcols = c->oc_bcols;
+        if (c->oc_coarse) { a.agg_of_slice = c->oc_agg.p; a.ainv = c->oc_ainv.p; a.cbuf = c->oc_cbuf.p; a.nc = c->oc_nc; a.ncp = c->oc_ncp; }
+    }
     a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.bar = c->oc_bar.p;
     a.nbr = c->oc_nbr.p; a.flags = c->oc_flags.p;
     a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
@@ -379,7 +391,9 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.prof = c->oc_prof.p;
     a.prof_block = c->oc_prof_block;
     a.row_color = c->oc_bssor ? c->oc_color.p : nullptr;
-    if (a.row_color && c->oc_nbr.p && c->oc_T <= 768 && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<768, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    if (c->oc_plan && c->oc_coarse && c->oc_nbr.p && c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768, 3>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    else if (c->oc_plan && c->oc_coarse && c->oc_nbr.p) hipLaunchKernelGGL((k_pcg_onchip<1024, 3>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    else if (a.row_color && c->oc_nbr.p && c->oc_T <= 768 && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<768, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else if (a.row_color && c->oc_nbr.p && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<1024, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else if (a.poly_m >= 2 && c->oc_nbr.p && c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768, 1>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
@@ -410,19 +424,54 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     if (lds_max < fixed + (size_t)T * 4 * 12) return hipSuccess;
     int wl = (int)((lds_max - fixed) / ((size_t)T * 12)) & ~3;
     wl = std::min(wl, wmax);
-    const size_t lds = fixed + (size_t)T * wl * 12;
+    size_t lds = fixed + (size_t)T * wl * 12;
+    // General-mesh plan (default; ADMM_HIP_OC_PLAN=0 keeps the rows in the caller's order, the round-1 layout): compact
+    // blocks by graph bisection, rows sorted by length inside the aggregates, per-slice slab shares, two-level
+    // preconditioner (ADMM_HIP_OC_COARSE=0: Jacobi on the same layout).
+    admm_host::OcPlan plan;
+    {
+        const char *pe = getenv("ADMM_HIP_OC_PLAN"), *ce = getenv("ADMM_HIP_OC_COARSE");
+        if (!(pe && pe[0] == '0') && c->oc_poly_m < 2) {
+            std::vector<double> mass(c->n3);
+            if ((e = hipMemcpy(mass.data(), c->m.p, mass.size() * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return e;
+            const int lds_cols = (int)((lds_max - fixed) / (64 * 12));
+            plan = admm_host::build_oc_plan(c->Ahat, mass.data(), G, spb, lds_cols, !(ce && ce[0] == '0'));
+            if (plan.ok) {
+                c->oc_plan = true;
+                c->oc_rows = plan.n_rows; c->oc_bcols = plan.bcols;
+                lds = fixed + (size_t)plan.bcols * 64 * 12;
+                if ((e = c->oc_A.upload(plan.A)) != hipSuccess) return e;
+                if ((e = c->oc_orig.upload(plan.orig)) != hipSuccess) return e;
+                if ((e = c->oc_ldsoff.upload(plan.lds_off)) != hipSuccess) return e;
+                if ((e = c->oc_wls.upload(plan.wl_s)) != hipSuccess) return e;
+                if ((e = c->oc_mdiag.upload(plan.mdiag)) != hipSuccess) return e;
+                c->oc_coarse = plan.coarse_ok && plan.nbr_ok;
+                if (c->oc_coarse) {
+                    c->oc_nc = plan.nc; c->oc_ncp = plan.ncp;
+                    if ((e = c->oc_agg.upload(plan.agg_of_slice)) != hipSuccess) return e;
+                    if ((e = c->oc_ainv.upload(plan.ainv)) != hipSuccess) return e;
+                    if ((e = c->oc_cbuf.alloc((size_t)2 * 3 * plan.ncp)) != hipSuccess) return e;
+                    if ((e = c->oc_cbuf.zero()) != hipSuccess) return e;
+                }
+                c->oc_stat[0] = plan.stat_nnz; c->oc_stat[1] = plan.stat_stored; c->oc_stat[2] = plan.stat_onchip; c->oc_stat[3] = plan.stat_local;
+                c->oc_stat[4] = plan.nbr_max; c->oc_stat[5] = c->oc_coarse ? plan.nc : 0;
+            }
+        }
+    }
     const void *fn = T <= 768 ? (const void *)k_pcg_onchip<768> : (const void *)k_pcg_onchip<1024>;
     if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<1024, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     int per_cu = 0;
     if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<1024>, T, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1 || G > cus) return hipSuccess; // one block per CU keeps every block resident whatever the LDS split
     c->oc_G = G; c->oc_spb = spb; c->oc_T = T; c->oc_wl = wl; c->oc_lds = lds;
-    if ((e = c->oc_ubuf.alloc((size_t)2 * ns * 64 * 3)) != hipSuccess) return e;
+    if ((e = c->oc_ubuf.alloc((size_t)2 * (c->oc_plan ? G * spb : ns) * 64 * 3)) != hipSuccess) return e;
     if ((e = c->oc_part.alloc((size_t)2 * 8 * G)) != hipSuccess) return e;
     if ((e = c->oc_rc_part.alloc((size_t)72 * G)) != hipSuccess) return e;
     if ((e = c->oc_bar.alloc(2 * 32 * 16)) != hipSuccess) return e;
@@ -439,7 +488,8 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
         const int rows_pb = 64 * spb;
         std::vector<int> nbr((size_t)G * 64, -1);
         bool fits = !(off && off[0] == '1');
-        for (int b = 0; b < G && fits; ++b) {
+        if (c->oc_plan) { fits = fits && plan.nbr_ok; if (fits) nbr = plan.nbr; }
+        for (int b = 0; b < G && fits && !c->oc_plan; ++b) {
             std::vector<char> seen(G, 0);
             int n = 0;
             const int r1 = std::min(c->Ahat.n, rows_pb * (b + 1));
@@ -464,7 +514,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
         c->oc_bssor = false;
         // on by default; ADMM_HIP_OC_BSSOR=0 = plain Jacobi (A/B).  Rows wider than the 32-bit local-entry mask would make
         // the sweep unsymmetric: such meshes keep Jacobi.
-        if (!(bs && bs[0] == '0') && c->oc_nbr.p && c->A_wmax <= 32) {
+        if (!(bs && bs[0] == '0') && c->oc_nbr.p && c->A_wmax <= 32 && !c->oc_plan) {
             const int nv = c->Ahat.n;
             std::vector<int32_t> rp(nv + 1, 0), ci;
             for (int i = 0; i < nv; ++i) {
@@ -527,16 +577,15 @@ int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
 // The ADMM global solve with the recycled (Galerkin) warm start around the PCG.
 int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     const int s = c->rc_iter;
-    if (!c->rc_enabled || s >= admm_hip_ctx::kRcSlots) return launch_pcg(c, b, x, c->pcg_max_iters);
+    if (!c->rc_enabled) return launch_pcg(c, b, x, c->pcg_max_iters);
     hipStream_t st = c->stream;
-    const int par = c->rc_frame & 1;
     RcBasis B{};
     // basis: the (up to) kRc most recent pairs of THIS frame.  (Adding the previous frame's pair at the same
     // index was measured: it does not help the first solves of a frame.)
-    for (int j = 1; j <= kRc && s - j >= 0; ++j) { B.E[B.cnt] = c->rc_E(par, s - j); B.R[B.cnt] = c->rc_R(par, s - j); ++B.cnt; }
+    for (int j = 1; j <= kRc && s - j >= 0; ++j) { B.E[B.cnt] = c->rc_E(s - j); B.R[B.cnt] = c->rc_R(s - j); ++B.cnt; }
     static const bool rc_kernels = getenv("ADMM_HIP_RC_KERNELS") && getenv("ADMM_HIP_RC_KERNELS")[0] == '1';   // A/B: separate k_rc_* launches
-    if (c->oc_enabled && !rc_kernels) {   // projection, solve and the new pair in ONE persistent launch
-        OcRc rc; rc.on = true; rc.B = B; rc.Eslot = c->rc_E(par, s); rc.Rslot = c->rc_R(par, s);
+    if (c->oc_enabled && (!rc_kernels || c->oc_plan)) {   // (the plan's pairs live in its internal row order: k_rc_* cannot read them)   // projection, solve and the new pair in ONE persistent launch
+        OcRc rc; rc.on = true; rc.B = B; rc.Eslot = c->rc_E(s); rc.Rslot = c->rc_R(s);
         const int r = launch_pcg_onchip(c, b, x, c->pcg_max_iters, rc);
         c->rc_iter = s + 1;
         return r;
@@ -549,7 +598,7 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     }
     const int rc = launch_pcg(c, b, x, c->pcg_max_iters);
     hipLaunchKernelGGL(k_rc_record, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, x, c->rc_xs.p, c->rc_r0.p, c->cg_u.p, c->dinv.p,
-                       c->rc_E(par, s), c->rc_R(par, s));
+                       c->rc_E(s), c->rc_R(s));
     c->rc_iter = s + 1;
     return rc;
 }
@@ -843,6 +892,11 @@ int validate(const admm_hip_desc *d) {
     if (d->struct_size != (int32_t)sizeof(admm_hip_desc)) return fail(ADMM_HIP_ERR_ARG, "desc.struct_size mismatch");
     if (d->n_verts < 1 || !d->masses) return fail(ADMM_HIP_ERR_ARG, "Problem with node data (Solver.cpp:180-183)");
     if (d->n_tets < 0 || d->n_tris < 0 || d->n_pins < 0) return fail(ADMM_HIP_ERR_ARG, "negative count");
+    // the kernels address the per-element SoA arrays and the node vectors with 32-bit byte offsets (buffer instructions):
+    // the largest array of a context, cf[12][n + 1] doubles, and the node vectors must stay below 2^31 bytes
+    if ((int64_t)96 * ((int64_t)d->n_tets + 1) >= ((int64_t)1 << 31) || (int64_t)96 * ((int64_t)d->n_tris + 1) >= ((int64_t)1 << 31) ||
+        (int64_t)24 * d->n_verts >= ((int64_t)1 << 31))
+        return fail(ADMM_HIP_ERR_ARG, "scene too large for one context (limit: 22.3 M tets / tris, 89 M vertices per rank)");
     if (d->n_tets && (!d->tet_idx || !d->tet_Binv || !d->tet_weight || !d->tet_kind || !d->tet_mu || !d->tet_lambda || !d->tet_k))
         return fail(ADMM_HIP_ERR_ARG, "tet arrays missing");
     if (d->n_tris && (!d->tri_idx || !d->tri_rest || !d->tri_weight || !d->tri_limit_min || !d->tri_limit_max))
@@ -1106,9 +1160,12 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         const char *env = getenv("ADMM_HIP_NO_RECYCLE");
         c->rc_enabled = !(env && env[0] == '1');
         c->NBR = std::max(1, std::min((nv + 255) / 256, 256));
-        HIP_TRY(c->rc_buf.alloc((size_t)2 * admm_hip_ctx::kRcSlots * 2 * c->n3));
-        HIP_TRY(c->rc_r0.alloc(c->n3)); HIP_TRY(c->rc_xs.alloc(c->n3));
-        HIP_TRY(c->rc_part.alloc((size_t)3 * kRcQ * c->NBR)); HIP_TRY(c->rc_coef.alloc(3 * kRc)); HIP_TRY(c->rc_coef.zero());
+        c->n3i = std::max(c->n3, 3 * c->oc_rows);
+        if (c->rc_enabled) {
+            HIP_TRY(c->rc_buf.alloc((size_t)admm_hip_ctx::kRcSlots * 2 * c->n3i));
+            HIP_TRY(c->rc_r0.alloc(c->n3i)); HIP_TRY(c->rc_xs.alloc(c->n3i));
+            HIP_TRY(c->rc_part.alloc((size_t)3 * kRcQ * c->NBR)); HIP_TRY(c->rc_coef.alloc(3 * kRc)); HIP_TRY(c->rc_coef.zero());
+        }
     }
 
     if (d->linsolver == 1) {
@@ -1197,6 +1254,9 @@ int admm_hip_get_state(admm_hip_ctx *c, double *x, double *v) {
 int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const double *xyz) {
     if (!c || n < 0 || (n > 0 && (!vert || !xyz))) return fail(ADMM_HIP_ERR_ARG, "set_pins: Bad input (Solver.cpp:118-120)");
     HIP_TRY(hipSetDevice(c->device));
+    // admm_hip_step without stats returns while its kernels are still in flight on the context's (non-blocking)
+    // stream: the pin data must not change under them
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->linsolver == 1) {
         std::vector<int> flag(c->nv, 0);
         std::vector<double> p((size_t)c->n3, 0.0);
@@ -1235,6 +1295,7 @@ int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const dou
 int admm_hip_set_surface_inds(admm_hip_ctx *c, int32_t n, const int32_t *inds) {
     if (!c || n < 0 || (n > 0 && !inds)) return fail(ADMM_HIP_ERR_ARG, "set_surface_inds: bad input");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // a step may still be in flight (see admm_hip_set_pins)
     std::vector<int> list;
     std::vector<unsigned char> mask(c->nv, 0);
     for (int i = 0; i < n; ++i) {
@@ -1259,6 +1320,7 @@ int admm_hip_add_dynamic_tetmesh(admm_hip_ctx *c, int32_t vert_offset, int32_t n
     for (int i = 0; i < 4 * n_tets; ++i) if (tets[i] < 0 || tets[i] >= n_verts) return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: tet index out of range");
     for (int i = 0; i < 3 * n_faces; ++i) if (faces[i] < 0 || faces[i] >= n_verts) return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: face index out of range");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // a step may still be in flight (see admm_hip_set_pins)
     auto fill_levels = [](const admm_host::OctTree &T, OctLevels &L) {
         L.n_levels = T.n_levels;
         for (int l = 0; l < T.n_levels; ++l) { L.off[l] = T.level_off[l]; L.n[l] = T.level_n[l]; }
@@ -1625,6 +1687,34 @@ int admm_host_assemble_matrix(const admm_hip_desc *d, int32_t *rowptr, int32_t *
     if (rowptr) std::copy(A.rowptr.begin(), A.rowptr.end(), rowptr);
     if (col) std::copy(A.col.begin(), A.col.end(), col);
     if (val) std::copy(A.val.begin(), A.val.end(), val);
+    return ADMM_HIP_OK;
+}
+int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int32_t lds_cols, int32_t *row_vertex,
+                      int32_t *row_aggregate, double *coarse_inv, int64_t *stats) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if (n_blocks < 1 || spb < 1 || spb > 16 || (int64_t)n_blocks * spb * 64 < d->n_verts) return fail(ADMM_HIP_ERR_ARG, "oc_plan: blocks x slices do not hold the vertices");
+    const double dt = d->dt > 0.0 ? d->dt : 1.0 / 24.0;
+    double mu, la, k;
+    admm_host::lame(10000000.0, 0.499, &mu, &la, &k);
+    const double pw = d->pin_weight > 0 ? d->pin_weight : std::sqrt(k * 2.0);
+    const bool pins_as_terms = (d->linsolver == 0 || d->linsolver == 2);
+    const admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
+                                                      d->tri_idx, d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, pw);
+    const admm_host::OcPlan P = admm_host::build_oc_plan(A, d->masses, n_blocks, spb, lds_cols, coarse_inv != nullptr);
+    if (!P.ok) return fail(ADMM_HIP_ERR_ARG, "oc_plan: a block does not fit its slots");
+    if (row_vertex) std::copy(P.orig.begin(), P.orig.end(), row_vertex);
+    if (row_aggregate)
+        for (int32_t r = 0; r < P.n_rows; ++r)
+            row_aggregate[r] = P.orig[r] < 0 ? -1 : (r / (64 * spb)) * admm_host::kOcSub + P.agg_of_slice[r / 64];
+    if (coarse_inv) {
+        if (!P.coarse_ok) return fail(ADMM_HIP_ERR_ARG, "oc_plan: no coarse space (masses differ between the axes, or too many blocks)");
+        for (int i = 0; i < P.nc; ++i) std::copy(P.ainv.begin() + (size_t)i * P.ncp, P.ainv.begin() + (size_t)i * P.ncp + P.nc, coarse_inv + (size_t)i * P.nc);
+    }
+    if (stats) {
+        stats[0] = P.stat_nnz; stats[1] = P.stat_stored; stats[2] = P.stat_onchip; stats[3] = P.stat_local;
+        stats[4] = P.nbr_ok ? P.nbr_max : -1; stats[5] = P.coarse_ok ? P.nc : 0; stats[6] = P.n_rows; stats[7] = P.bcols;
+    }
     return ADMM_HIP_OK;
 }
 void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end) {

@@ -74,6 +74,31 @@ std::vector<double> octtree_boxes_tris(const OctTree &tree, const int32_t *faces
 void locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id,
                     double *span_before, double *span_after);
 
+// Plan of the on-chip PCG for general meshes (oc_plan.cpp): internal row order (compact blocks of `spb` wavefronts, each
+// split into kOcSub compact aggregates), the system matrix in that order (off-diagonal non-zeros, SELL-64), the part of
+// every slice that fits the LDS slab, the neighbour-block lists and the dense inverse of the aggregate coarse matrix.
+constexpr int kOcSub = 4;
+struct OcPlan {
+    bool ok = false;
+    int G = 0, spb = 0, sub = kOcSub;
+    int32_t n_rows = 0;                 // G * spb * 64 internal rows (dummy rows: orig = -1)
+    std::vector<int32_t> orig;          // [n_rows] internal row -> vertex
+    std::vector<int32_t> pos;           // [n_verts] vertex -> internal row
+    Sell A;                             // internal numbering, off-diagonal non-zeros
+    std::vector<double> mdiag;          // [3 n_rows] mass + diagonal of Ahat (0 for dummy rows)
+    std::vector<int32_t> wl_s, lds_off; // [n_slices] columns of the slice kept in LDS, their offset (columns) in the block's slab
+    int bcols = 0;                      // slab columns of the fullest block
+    std::vector<int32_t> nbr;           // [G][64] blocks a block's rows reference (-1 = none)
+    bool nbr_ok = false; int nbr_max = 0;
+    std::vector<signed char> agg_of_slice;   // [G spb] aggregate (0..kOcSub-1) of every wavefront
+    int nc = 0, ncp = 0;                // coarse unknowns (G * kOcSub), padded row length of ainv
+    bool coarse_ok = false;
+    std::vector<double> ainv;           // [nc][ncp] (P^T A P)^-1
+    int64_t stat_nnz = 0, stat_stored = 0, stat_onchip = 0, stat_local = 0;
+};
+// A = Ahat (mass not included), mass3 [3 n]; lds_cols = slab columns (64 entries of 12 B each) one block may use
+OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_cols, bool want_coarse);
+
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
 int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
 void lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);

@@ -219,7 +219,7 @@ __device__ __forceinline__ int4 tet_load_idx(const TetArgs &a, int t) {
 }
 template <int KIND>
 __device__ __forceinline__ void tet_load(const TetArgs &a, int t, TetIn &in) {
-    const int ld8 = a.ld * 8, t8 = t * 8;   // bytes between two components of an SoA array (< 2^31 up to 268 M tets)
+    const int ld8 = a.ld * 8, t8 = t * 8;   // bytes between two components of an SoA array (the largest offset, 12 ld 8 for cf, stays < 2^31: admm_hip_create rejects more than 22.3 M elements)
     const __amdgpu_buffer_rsrc_t rBinv = soa_rsrc(a.Binv), ru = soa_rsrc(a.u);
 #pragma unroll
     for (int c = 0; c < 9; ++c) { in.Bi[c] = buf_ld_stream(rBinv, t8, c * ld8); in.ui[c] = buf_ld_stream(ru, t8, c * ld8); }

@@ -129,3 +129,104 @@ def load_tetgen(node_path, ele_path):
     nt = int(rows[0][0])
     tets = np.array([[int(r[1]), int(r[2]), int(r[3]), int(r[4])] for r in rows[1:1 + nt]], dtype=np.int32) - first
     return verts, tets
+
+
+# ---- unstructured synthetic body (BASELINE configs[2]: "1M-tet synthetic bunny/dragon") -------------------------------
+# corner c of a lattice cell = (c & 1, (c >> 1) & 1, (c >> 2) & 1); for every corner the three cell faces that do NOT
+# contain it, each as its four corners in cyclic order
+def _pull_faces():
+    faces = np.zeros((8, 3, 4), dtype=np.int64)
+    for c in range(8):
+        for a in range(3):
+            side = 1 - ((c >> a) & 1)
+            b, d = (a + 1) % 3, (a + 2) % 3
+            cyc = []
+            for (ub, ud) in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                cyc.append((side << a) | (ub << b) | (ud << d))
+            faces[c, a] = cyc
+    return faces
+
+
+def _blob_inside(p):
+    """Implicit bunny-like body in the unit box: union of ellipsoids (body, head, two ears, tail, two feet)."""
+    parts = [  # centre, radii
+        ((0.45, 0.36, 0.50), (0.30, 0.24, 0.26)),   # body
+        ((0.70, 0.60, 0.50), (0.15, 0.15, 0.15)),   # head
+        ((0.72, 0.82, 0.41), (0.045, 0.17, 0.06)),  # ears
+        ((0.72, 0.82, 0.59), (0.045, 0.17, 0.06)),
+        ((0.14, 0.36, 0.50), (0.08, 0.08, 0.08)),   # tail
+        ((0.60, 0.14, 0.36), (0.16, 0.07, 0.08)),   # feet
+        ((0.60, 0.14, 0.64), (0.16, 0.07, 0.08)),
+    ]
+    inside = np.zeros(len(p), dtype=bool)
+    for c, r in parts:
+        q = (p - np.asarray(c)) / np.asarray(r)
+        inside |= np.einsum("ij,ij->i", q, q) <= 1.0
+    return inside
+
+
+def unstructured_blob(n, jitter=0.15, seed=0, shuffle=True):
+    """Deterministic unstructured tet mesh: an n^3 lattice over the unit box, vertices jittered by up to `jitter` cells,
+    every cell split into 6 tets by a *pulling* triangulation on a random global vertex priority (the cell's
+    lowest-priority corner is coned to the three faces that do not contain it, every face is split along the diagonal
+    through ITS lowest-priority corner -- a face's split depends only on the global priorities, so neighbouring cells
+    agree and the mesh conforms), and only the cells inside an implicit bunny-like body kept.  Vertex valences then range
+    from 4 to 26 like a TetGen mesh (a Kuhn lattice has 14 everywhere, 8 of them exact-zero couplings), element shapes
+    vary, nothing in the system matrix cancels and the graph is not 2-colourable.  shuffle: vertices and tets are
+    randomly renumbered (a mesh file's order carries no locality; callers run renumber_for_locality like the samples do).
+    n = 118 -> ~1.0 M tets.  Returns verts [nv,3], tets [nt,4] int32 (positively oriented)."""
+    rng = np.random.default_rng(seed)
+    g = np.arange(n + 1)
+    gx, gy, gz = np.meshgrid(g, g, g, indexing="ij")
+    lat = np.stack([gx, gy, gz], axis=-1).reshape(-1, 3).astype(np.float64)
+    pos = (lat + jitter * (2.0 * rng.random(lat.shape) - 1.0)) / n
+    prio = rng.permutation(len(lat))
+
+    def vid(i, j, k):
+        return (i * (n + 1) + j) * (n + 1) + k
+
+    c = np.arange(n)
+    ci, cj, ck = (a.ravel() for a in np.meshgrid(c, c, c, indexing="ij"))
+    centre = (np.stack([ci, cj, ck], axis=1) + 0.5) / n
+    keep = _blob_inside(centre)
+    ci, cj, ck = ci[keep], cj[keep], ck[keep]
+    corners = np.stack([vid(ci + (q & 1), cj + ((q >> 1) & 1), ck + ((q >> 2) & 1)) for q in range(8)], axis=1)  # [nc,8]
+    cp = prio[corners]
+    vstar = np.argmin(cp, axis=1)                                   # lowest-priority corner of the cell
+    fl = _pull_faces()[vstar]                                       # [nc,3,4] local corner ids of the opposite faces
+    fg = np.take_along_axis(corners[:, None, :].repeat(3, 1), fl, axis=2)   # global ids
+    fstar = np.argmin(prio[fg], axis=2)                             # lowest-priority corner of every face
+    roll = (fstar[:, :, None] + np.arange(4)[None, None, :]) % 4
+    fg = np.take_along_axis(fg, roll, axis=2)                       # that corner first, cyclic order kept
+    apex = np.take_along_axis(corners, vstar[:, None], axis=1)[:, 0]
+    tets = []
+    for f in range(3):
+        for (b, d) in ((1, 2), (2, 3)):
+            tets.append(np.stack([apex, fg[:, f, 0], fg[:, f, b], fg[:, f, d]], axis=1))
+    tets = np.stack(tets, axis=1).reshape(-1, 4)
+    vol = tet_volumes(pos, tets)
+    flip = vol < 0
+    tets[flip] = tets[flip][:, [0, 1, 3, 2]]
+    vol = np.abs(vol)
+    if not (vol.min() > 1e-3 / (6.0 * n ** 3)):
+        raise ValueError("unstructured_blob: jitter too large (degenerate tet)")
+    used = np.unique(tets)
+    new = np.full(len(lat), -1, dtype=np.int64)
+    if shuffle:
+        new[used] = rng.permutation(len(used))
+        tets = tets[rng.permutation(len(tets))]
+    else:
+        new[used] = np.arange(len(used))
+    verts = np.empty((len(used), 3)); verts[new[used]] = pos[used]
+    return verts, new[tets].astype(np.int32)
+
+
+def valence_stats(nv, elems):
+    """Vertex valences of a mesh (edges per vertex; the row of Ahat has valence + 1 entries): dict(min, mean, max)."""
+    e = np.asarray(elems, dtype=np.int64)
+    k = e.shape[1]
+    pairs = np.concatenate([np.stack([e[:, a], e[:, b]], 1) for a in range(k) for b in range(a + 1, k)])
+    pairs.sort(axis=1)
+    pairs = np.unique(pairs, axis=0)
+    deg = np.bincount(pairs.ravel(), minlength=nv)
+    return dict(min=int(deg.min()), mean=float(deg.mean()), max=int(deg.max()))

@@ -33,6 +33,10 @@ WORKLOADS = {
     # configs[4]: 316 x 316-cell cloth (199 712 tris), Lame(100, 0.1) with strain limits 0.95/1.05, two corner
     # pins, Floor, multi-colour GS with in-sweep pins and plane projection, 10 ADMM iters/step
     "cloth200k_gs_floor": dict(n=316, kinds="cloth", linsolver=1, admm_iters=10),
+    # configs[2] as named ("synthetic bunny/dragon"): unstructured body (meshes.unstructured_blob: jittered lattice, random
+    # pulling triangulation, carved by an implicit bunny-like surface; valences 3..26), randomly numbered like a mesh file
+    # and renumbered by renumber_for_locality like the samples do; NH / StVK by slab, feet pinned
+    "blob1m_mix": dict(n=118, kinds="blob", linsolver=0, admm_iters=20),
     "cube1m_linear": dict(n=55, kinds="linear", linsolver=0, admm_iters=20),   # diagnostic: cheapest prox
     "cube1m_stvk": dict(n=55, kinds="stvk", linsolver=0, admm_iters=20),
 }
@@ -47,6 +51,9 @@ def build_scene(w, n_override=None):
     if w["kinds"] == "cloth":
         sc = scenes.cloth_scene(n, limits=(0.95, 1.05), floor=0.3, admm_iters=w["admm_iters"], linsolver=w["linsolver"])
         return sc, len(sc.tris[0][1]), len(sc.x)
+    if w["kinds"] == "blob":
+        sc = scenes.blob_scene(n, admm_iters=w["admm_iters"], linsolver=w["linsolver"])
+        return sc, sum(len(t[1]) for t in sc.tets), len(sc.x)
     verts, tets = meshes.kuhn_cube(n)
     sc = scenes.Scene()
     sc.x = verts
@@ -142,11 +149,25 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here, exactly as the driver's
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` line does (one process per GPU, RCCL)
+        import socket
+        import subprocess
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
     import torch
     import admm_elastic_amd as pkg
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if pkg.device_count() < (local_rank + 1 if world > 1 else 1):
+        raise SystemExit("bench.py: rank %d needs HIP device %d, %d visible (the hot path has no CPU fallback)" % (rank, local_rank, pkg.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -245,6 +245,18 @@ int admm_host_greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *c
 void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id,
                               double *span_before, double *span_after);
 
+/* The plan admm_hip_create makes for the on-chip PCG of linsolver 0 / 2 (the GPU replacement of LDLTSolver::solve,
+ * src/LinearSolver.hpp:87-90), without a GPU -- diagnostics and tests.  The solve renumbers the rows internally (the
+ * caller's numbering is kept at the API): n_blocks compact blocks (one per CU) of slices_per_block wavefronts, every block
+ * split into 4 compact aggregates that carry the coarse space of the two-level preconditioner
+ * M^-1 = D^-1 + P (P^T A P)^-1 P^T.  row_vertex [64 * n_blocks * slices_per_block]: vertex of every internal row (-1 =
+ * unused slot); row_aggregate (same length): coarse unknown of the row (block * 4 + aggregate); coarse_inv [nc * nc], nc =
+ * 4 * n_blocks: (P^T A P)^-1, row-major (NULL to skip); stats [8]: off-diagonal non-zeros, stored SELL entries, entries
+ * held in LDS, block-local non-zeros, most neighbour blocks of a block, coarse unknowns (0 = two-level off), internal
+ * rows, LDS columns used.  lds_cols = LDS budget of a block in columns of 64 twelve-byte entries. */
+int admm_host_oc_plan(const admm_hip_desc *desc, int32_t n_blocks, int32_t slices_per_block, int32_t lds_cols,
+                      int32_t *row_vertex, int32_t *row_aggregate, double *coarse_inv, int64_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

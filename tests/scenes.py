@@ -167,3 +167,22 @@ def rel_err(a, b, x_ref=None):
     ref = b if x_ref is None else np.asarray(x_ref).reshape(-1, 3)
     diag = np.linalg.norm(ref.max(axis=0) - ref.min(axis=0))
     return np.linalg.norm(a - b, axis=1).max() / max(diag, 1e-300)
+
+
+def blob_scene(n, jitter=0.15, seed=0, **settings):
+    """BASELINE configs[2] on an UNSTRUCTURED body: meshes.unstructured_blob (valences 3..26, not 2-colourable, no exact
+    zeros in Ahat), numbered randomly like a mesh file and renumbered for locality as the samples do; Neo-Hookean / StVK
+    by z-slab, soft rubber, the feet (y < 0.1) pinned."""
+    sc = Scene()
+    verts, tets = meshes.unstructured_blob(n, jitter=jitter, seed=seed)
+    verts, tets, _ = meshes.renumber_for_locality(verts, tets, force=True)
+    cz = verts[tets].mean(axis=1)[:, 2]
+    slab = (cz * 8).astype(int) % 2
+    sc.x = verts; sc.m = meshes.lumped_masses_tets(verts, tets)
+    lame = Lame.soft_rubber()
+    sc.tets.append((verts, tets[slab == 0], lame, pkg.TET_NEOHOOKEAN, 0))
+    sc.tets.append((verts, tets[slab == 1], lame, pkg.TET_STVK, 0))
+    for i in np.nonzero(verts[:, 1] < 0.1)[0]:
+        sc.pins[int(i)] = verts[i].copy()
+    sc.settings.update(settings)
+    return sc

@@ -1,0 +1,89 @@
+"""The host-side plan of the on-chip PCG for general meshes (csrc/oc_plan.cpp; replaces the prefactored solve of
+src/LinearSolver.hpp:87-90): internal row order, aggregates and the dense coarse inverse, checked on the CPU by running
+the two-level preconditioned CG it describes in numpy / scipy."""
+import numpy as np
+import scipy.sparse as sp
+
+import scenes
+
+
+def _system(sc):
+    s = sc.make_solver(init=False)
+    rp, ci, va = s.host_matrix(sc.product_settings)
+    nv = len(sc.x)
+    A = (sp.csr_matrix((va, ci, rp), shape=(nv, nv)) + sp.diags(sc.m)).tocsr()
+    return s, A
+
+
+def _pcg(A, b, prec, tol=1e-8, maxit=2000):
+    dinv = 1.0 / A.diagonal()
+    x = np.zeros_like(b); r = b.copy(); z = prec(r); p = z.copy(); rz = r @ z; b2 = b @ (dinv * b)
+    for it in range(maxit):
+        Ap = A @ p; al = rz / (p @ Ap); x += al * p; r -= al * Ap
+        if r @ (dinv * r) <= tol * tol * b2:
+            return x, it + 1
+        z = prec(r); rz2 = r @ z; p = z + (rz2 / rz) * p; rz = rz2
+    return x, maxit
+
+
+def _check_plan(sc, G, spb):
+    s, A = _system(sc)
+    nv = A.shape[0]
+    plan = s.host_oc_plan(G, spb, settings=sc.product_settings)
+    rv, ra, st = plan["row_vertex"], plan["row_aggregate"], plan["stats"]
+    live = rv >= 0
+    # every vertex has exactly one row; blocks and aggregates are what the slot says
+    assert np.array_equal(np.sort(rv[live]), np.arange(nv))
+    assert st["rows"] == 64 * G * spb and st["coarse_unknowns"] == 4 * G
+    assert np.array_equal(ra[live] // 4, np.nonzero(live)[0] // (64 * spb))
+    assert (ra[~live] == -1).all()
+    agg = np.empty(nv, np.int64); agg[rv[live]] = ra[live]
+    # rows of a wavefront belong to one aggregate
+    per_wave = ra.reshape(-1, 64)
+    for wv in per_wave:
+        assert len(set(wv[wv >= 0])) <= 1
+    # the coarse inverse is the inverse of P^T A P (empty aggregates: unit diagonal)
+    nc = 4 * G
+    P = sp.csr_matrix((np.ones(nv), (np.arange(nv), agg)), shape=(nv, nc))
+    Ac = (P.T @ A @ P).toarray()
+    empty = np.diag(Ac) == 0
+    Ac[empty, empty] = 1.0
+    err = np.abs(plan["coarse_inv"] @ Ac - np.eye(nc)).max()
+    assert err < 1e-8, err
+    # the two-level preconditioner needs markedly fewer iterations than Jacobi and solves the same system
+    dinv = 1.0 / A.diagonal()
+    b = A @ np.random.default_rng(0).standard_normal(nv)
+    x0, it_j = _pcg(A, b, lambda r: dinv * r, tol=1e-11)
+    x1, it_2 = _pcg(A, b, lambda r: dinv * r + P @ (plan["coarse_inv"] @ (P.T @ r)), tol=1e-11)
+    assert np.abs(x1 - x0).max() <= 1e-7 * np.abs(x0).max()
+    return it_j, it_2, st
+
+
+def test_plan_unstructured_body():
+    sc = scenes.blob_scene(30, admm_iters=5, linsolver=0)      # 16 k tets, valences 3..26
+    it_j, it_2, st = _check_plan(sc, 16, 4)
+    assert it_2 < 0.75 * it_j, (it_j, it_2)
+    # compact blocks: most of the couplings stay inside a block, few neighbour blocks
+    assert st["block_local"] > 0.6 * st["nnz"] and 0 < st["max_neighbour_blocks"] <= 15
+    # rows sorted by length inside the aggregates (three wavefronts each at the real block size): bounded padding
+    sc = scenes.blob_scene(44, admm_iters=5, linsolver=0)
+    st = sc.make_solver(init=False).host_oc_plan(16, 12, settings=sc.product_settings, coarse=False)["stats"]
+    assert st["stored"] < 1.7 * st["nnz"] and st["on_chip"] >= 0.75 * st["stored"], st
+
+
+def test_plan_structured_cube_and_cloth():
+    sc = scenes.mixed_cube_scene(12, admm_iters=5, linsolver=0)
+    it_j, it_2, st = _check_plan(sc, 9, 4)
+    assert it_2 < it_j
+    sc = scenes.cloth_scene(40, admm_iters=5, linsolver=0)
+    it_j, it_2, st = _check_plan(sc, 7, 4)
+    assert it_2 < it_j
+
+
+def test_plan_rejects_too_few_slots():
+    import pytest
+    import admm_elastic_amd as pkg
+    sc = scenes.cube_scene(6, pkg.TET_NEOHOOKEAN, linsolver=0)
+    s = sc.make_solver(init=False)
+    with pytest.raises(pkg.AdmmHipError):
+        s.host_oc_plan(2, 2, settings=sc.product_settings)      # 256 slots for 343 vertices
