@@ -19,6 +19,7 @@
 #include "host_setup.hpp"
 #include "kernels.hpp"
 #include "pcg_onchip.hpp"
+#include "pcg_onchip2.hpp"
 
 using namespace admm_k;
 
@@ -180,8 +181,9 @@ struct admm_hip_ctx {
     DevBuf<unsigned long long> oc_prof;   // diagnosis (ADMM_HIP_OC_PROF=1)
     bool oc_debug = false; int oc_prof_block = 0;
     // general-mesh plan of the on-chip PCG (oc_plan.cpp): internal row order, its SELL, slab shares, two-level data
-    bool oc_plan = false, oc_coarse = false; int oc_rows = 0, oc_bcols = 0, oc_nc = 0, oc_ncp = 0;
-    SellDev oc_A; DevBuf<int> oc_orig, oc_ldsoff, oc_wls; DevBuf<signed char> oc_agg; DevBuf<double> oc_mdiag, oc_ainv, oc_cbuf;
+    bool oc_plan = false, oc_coarse = false; int oc_rows = 0, oc_bcols = 0, oc_nc = 0, oc_ncp = 0, oc_veclen = 0;
+    SellDev oc_A; DevBuf<int> oc_orig, oc_ldsoff, oc_wls, oc_haloptr, oc_halosrc; DevBuf<unsigned short> oc_col16;
+    DevBuf<double> oc_mdiag, oc_ainv, oc_cbuf;
     int64_t oc_stat[6] = {0, 0, 0, 0, 0, 0};   // nnz, stored, on chip, block-local, max neighbour blocks, coarse unknowns
     int n3i = 0;   // length of the solver-internal scratch vectors (recycled pairs): max(n3, 3 * oc_rows)
     int solve_seq = 0;
@@ -238,7 +240,8 @@ struct admm_hip_ctx {
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release();
-        oc_A.release(); oc_orig.release(); oc_ldsoff.release(); oc_wls.release(); oc_agg.release(); oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release();
+        oc_A.release(); oc_orig.release(); oc_ldsoff.release(); oc_wls.release(); oc_haloptr.release(); oc_halosrc.release(); oc_col16.release();
+        oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
@@ -339,6 +342,19 @@ int oc_diagnostics(admm_hip_ctx *c, int seq) {
     std::vector<unsigned long long> h(64 * 8);
     if (hipMemcpyAsync(h.data(), c->oc_prof.p, h.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
     auto us = [&](int a, int b) { return (double)(h[a] - h[b]) / 100.0; };
+    if (c->oc_plan) {   // k_pcg2: eight stamps per pipelined iteration
+        fprintf(stderr, "[oc_prof] seq %d: LDS fill %.2f  start phase %.2f  loop + end game %.2f  epilogue %.2f us\n", seq, us(63 * 8 + 1, 63 * 8), us(63 * 8 + 2, 63 * 8 + 1),
+                us(63 * 8 + 3, 63 * 8 + 2), us(63 * 8 + 4, 63 * 8 + 3));
+        double d[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int n = 0;
+        for (int it = 0; it + 1 < 62 && h[(it + 1) * 8] > h[it * 8 + 7] && h[it * 8 + 7] > h[it * 8]; ++it, ++n) {
+            for (int k = 0; k < 7; ++k) d[k] += us(it * 8 + k + 1, it * 8 + k);
+            d[7] += us((it + 1) * 8, it * 8);
+        }
+        if (n) fprintf(stderr, "[oc_prof] n=%d  m+publish %.2f  neighbour wait %.2f  halo+rows %.2f  record %.2f  barrier %.2f  reduce+coarse %.2f  decide+update %.2f | iteration %.2f us\n",
+                       n, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6] / n, d[7] / n);
+        if (hipMemsetAsync(c->oc_prof.p, 0, h.size() * 8, st) != hipSuccess) return -1;
+        return 0;
+    }
     fprintf(stderr, "[oc_prof] seq %d: LDS fill %.2f  start phase %.2f  loop %.2f  epilogue %.2f us\n", seq, us(63 * 8 + 1, 63 * 8), us(63 * 8 + 2, 63 * 8 + 1),
             us(63 * 8 + 3, 63 * 8 + 2), us(63 * 8 + 4, 63 * 8 + 3));
     if (h[62 * 8 + 5])
@@ -358,17 +374,38 @@ int oc_diagnostics(admm_hip_ctx *c, int seq) {
 
 struct OcRc { bool on = false; RcBasis B{}; double *Eslot = nullptr, *Rslot = nullptr; };
 
+// General-mesh plan: k_pcg2 (pcg_onchip2.hpp)
+int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, const OcRc &rc) {
+    hipStream_t st = c->stream;
+    Oc2Args a{};
+    a.n_rows = c->oc_rows; a.n_slices = c->oc_A.n_slices;
+    a.ptr = c->oc_A.ptr.p; a.w = c->oc_A.w.p; a.val = c->oc_A.val.p; a.col16 = c->oc_col16.p;
+    a.lds_off = c->oc_ldsoff.p; a.wl_s = c->oc_wls.p; a.bcols = c->oc_bcols;
+    a.orig = c->oc_orig.p; a.halo_ptr = c->oc_haloptr.p; a.halo_src = c->oc_halosrc.p; a.vec_len = c->oc_veclen;
+    a.mdiag = c->oc_mdiag.p; a.dinv = c->dinv.p; a.b = b; a.x = x; a.u_out = c->cg_u.p;
+    a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.bar = c->oc_bar.p;
+    a.nbr = c->oc_nbr.p; a.flags = c->oc_flags.p;
+    a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
+    a.prof = c->oc_prof.p; a.prof_block = c->oc_prof_block;
+    a.spb = c->oc_spb; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
+    a.tol2 = c->pcg_tol * c->pcg_tol;
+    a.rc_on = rc.on ? 1 : 0; a.rc = rc.B; a.rc_xs = c->rc_xs.p; a.rc_r0 = c->rc_r0.p; a.rc_Eslot = rc.Eslot; a.rc_Rslot = rc.Rslot;
+    a.rc_part = c->oc_rc_part.p;
+    if (c->oc_coarse) { a.ainv = c->oc_ainv.p; a.cbuf = c->oc_cbuf.p; a.nc = c->oc_nc; a.ncp = c->oc_ncp; }
+    if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    else hipLaunchKernelGGL((k_pcg2<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    c->last_launched_iters = 0;
+    if (c->oc_debug || c->oc_prof.p) return oc_diagnostics(c, a.seq);
+    return 0;
+}
+
 int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters, const OcRc &rc = OcRc()) {
+    if (c->oc_plan) return launch_pcg2(c, b, x, max_iters, rc);
     hipStream_t st = c->stream;
     OcArgs a{};
-    const SellDev &S = c->oc_plan ? c->oc_A : c->A;
-    a.n_rows = S.n_rows; a.n_slices = S.n_slices;
-    a.ptr = S.ptr.p; a.w = S.w.p; a.col = S.idx.p; a.val = S.val.p;
-    a.m = c->oc_plan ? c->oc_mdiag.p : c->m.p; a.dinv = c->dinv.p; a.b = b; a.x = x; a.u_out = c->cg_u.p;
-    if (c->oc_plan) {
-        a.orig = c->oc_orig.p; a.lds_off = c->oc_ldsoff.p; a.wl_s = c->oc_wls.p; a.bcols = c->oc_bcols;
-        if (c->oc_coarse) { a.agg_of_slice = c->oc_agg.p; a.ainv = c->oc_ainv.p; a.cbuf = c->oc_cbuf.p; a.nc = c->oc_nc; a.ncp = c->oc_ncp; }
-    }
+    a.n_rows = c->A.n_rows; a.n_slices = c->A.n_slices;
+    a.ptr = c->A.ptr.p; a.w = c->A.w.p; a.col = c->A.idx.p; a.val = c->A.val.p;
+    a.m = c->m.p; a.dinv = c->dinv.p; a.b = b; a.x = x; a.u_out = c->cg_u.p;
     a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.bar = c->oc_bar.p;
     a.nbr = c->oc_nbr.p; a.flags = c->oc_flags.p;
     a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
@@ -391,9 +428,7 @@ int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters
     a.prof = c->oc_prof.p;
     a.prof_block = c->oc_prof_block;
     a.row_color = c->oc_bssor ? c->oc_color.p : nullptr;
-    if (c->oc_plan && c->oc_coarse && c->oc_nbr.p && c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768, 3>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
-    else if (c->oc_plan && c->oc_coarse && c->oc_nbr.p) hipLaunchKernelGGL((k_pcg_onchip<1024, 3>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
-    else if (a.row_color && c->oc_nbr.p && c->oc_T <= 768 && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<768, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    if (a.row_color && c->oc_nbr.p && c->oc_T <= 768 && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<768, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else if (a.row_color && c->oc_nbr.p && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<1024, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else if (a.poly_m >= 2 && c->oc_nbr.p && c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768, 1>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
@@ -414,8 +449,14 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     const int cus = prop.multiProcessorCount, ns = c->A.n_slices;
     if (ns <= 0 || cus <= 0) return hipSuccess;
     int G = std::min(cus, ns);
-    const int spb = (ns + G - 1) / G;
+    int spb = (ns + G - 1) / G;
     if (spb > 16) return hipSuccess;
+    {   // general-mesh plan: the two-level preconditioner lets every thread handle two coarse unknowns (4 G <= 2 x 64 spb);
+        // small systems therefore use fewer, larger blocks (which also makes their grid barrier cheaper)
+        const char *pe = getenv("ADMM_HIP_OC_PLAN");
+        if (!(pe && pe[0] == '0'))
+            while (spb < 16 && (ns + spb - 1) / spb > 32 * spb) ++spb;
+    }
     G = (ns + spb - 1) / spb;
     const int T = 64 * spb;
     const int wmax = c->A_wmax;
@@ -425,30 +466,39 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     int wl = (int)((lds_max - fixed) / ((size_t)T * 12)) & ~3;
     wl = std::min(wl, wmax);
     size_t lds = fixed + (size_t)T * wl * 12;
-    // General-mesh plan (default; ADMM_HIP_OC_PLAN=0 keeps the rows in the caller's order, the round-1 layout): compact
-    // blocks by graph bisection, rows sorted by length inside the aggregates, per-slice slab shares, two-level
-    // preconditioner (ADMM_HIP_OC_COARSE=0: Jacobi on the same layout).
+    // General-mesh plan (default; ADMM_HIP_OC_PLAN=0 keeps the rows in the caller's order and the round-1 kernel,
+    // pcg_onchip.hpp): compact blocks by graph bisection, rows sorted by length, local vector + halo list + slab in LDS,
+    // two-level preconditioner (ADMM_HIP_OC_COARSE=0: Jacobi on the same layout) -- oc_plan.cpp, pcg_onchip2.hpp.
     admm_host::OcPlan plan;
     {
         const char *pe = getenv("ADMM_HIP_OC_PLAN"), *ce = getenv("ADMM_HIP_OC_COARSE");
         if (!(pe && pe[0] == '0') && c->oc_poly_m < 2) {
             std::vector<double> mass(c->n3);
             if ((e = hipMemcpy(mass.data(), c->m.p, mass.size() * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return e;
-            const int lds_cols = (int)((lds_max - fixed) / (64 * 12));
-            plan = admm_host::build_oc_plan(c->Ahat, mass.data(), G, spb, lds_cols, !(ce && ce[0] == '0'));
-            if (plan.ok) {
+            plan = admm_host::build_oc_plan(c->Ahat, mass.data(), G, spb, (int)lds_max - kOc2Scratch, !(ce && ce[0] == '0'));
+            if (plan.ok && plan.bcols >= 4) {
                 c->oc_plan = true;
-                c->oc_rows = plan.n_rows; c->oc_bcols = plan.bcols;
-                lds = fixed + (size_t)plan.bcols * 64 * 12;
-                if ((e = c->oc_A.upload(plan.A)) != hipSuccess) return e;
-                if ((e = c->oc_orig.upload(plan.orig)) != hipSuccess) return e;
+                c->oc_rows = plan.n_rows; c->oc_bcols = plan.bcols; c->oc_veclen = plan.vec_len;
+                lds = (size_t)kOc2Scratch + (size_t)3 * 8 * plan.vec_len + (size_t)plan.bcols * 64 * 10;
+                if ((e = c->oc_A.ptr.upload(plan.A.slice_ptr)) != hipSuccess) return e;
+                if ((e = c->oc_A.w.upload(plan.A.slice_width)) != hipSuccess) return e;
+                if ((e = c->oc_A.val.upload(plan.A.val)) != hipSuccess) return e;
+                c->oc_A.n_rows = plan.A.n_rows; c->oc_A.n_slices = plan.A.n_slices;
+                if ((e = c->oc_col16.upload(plan.col16)) != hipSuccess) return e;
+                std::vector<int> oa(plan.orig);
+                for (size_t r = 0; r < oa.size(); ++r) if (oa[r] >= 0) oa[r] |= (int)plan.row_agg[r] << 28;
+                if ((e = c->oc_orig.upload(oa)) != hipSuccess) return e;
                 if ((e = c->oc_ldsoff.upload(plan.lds_off)) != hipSuccess) return e;
                 if ((e = c->oc_wls.upload(plan.wl_s)) != hipSuccess) return e;
+                if ((e = c->oc_haloptr.upload(plan.halo_ptr)) != hipSuccess) return e;
+                {   // never empty: the kernel reads two entries per thread unconditionally guarded by nh
+                    std::vector<int> hs(plan.halo_src); if (hs.empty()) hs.push_back(0);
+                    if ((e = c->oc_halosrc.upload(hs)) != hipSuccess) return e;
+                }
                 if ((e = c->oc_mdiag.upload(plan.mdiag)) != hipSuccess) return e;
-                c->oc_coarse = plan.coarse_ok && plan.nbr_ok;
+                c->oc_coarse = plan.coarse_ok && plan.nc <= 2 * T;
                 if (c->oc_coarse) {
                     c->oc_nc = plan.nc; c->oc_ncp = plan.ncp;
-                    if ((e = c->oc_agg.upload(plan.agg_of_slice)) != hipSuccess) return e;
                     if ((e = c->oc_ainv.upload(plan.ainv)) != hipSuccess) return e;
                     if ((e = c->oc_cbuf.alloc((size_t)2 * 3 * plan.ncp)) != hipSuccess) return e;
                     if ((e = c->oc_cbuf.zero()) != hipSuccess) return e;
@@ -463,15 +513,15 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<1024, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg2<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     int per_cu = 0;
     if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<1024>, T, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1 || G > cus) return hipSuccess; // one block per CU keeps every block resident whatever the LDS split
     c->oc_G = G; c->oc_spb = spb; c->oc_T = T; c->oc_wl = wl; c->oc_lds = lds;
-    if ((e = c->oc_ubuf.alloc((size_t)2 * (c->oc_plan ? G * spb : ns) * 64 * 3)) != hipSuccess) return e;
+    if ((e = c->oc_ubuf.alloc((size_t)2 * (c->oc_plan ? G * spb : ns) * 64 * (c->oc_plan ? 4 : 3))) != hipSuccess) return e;
     if ((e = c->oc_part.alloc((size_t)2 * 8 * G)) != hipSuccess) return e;
     if ((e = c->oc_rc_part.alloc((size_t)72 * G)) != hipSuccess) return e;
     if ((e = c->oc_bar.alloc(2 * 32 * 16)) != hipSuccess) return e;
@@ -1689,7 +1739,7 @@ int admm_host_assemble_matrix(const admm_hip_desc *d, int32_t *rowptr, int32_t *
     if (val) std::copy(A.val.begin(), A.val.end(), val);
     return ADMM_HIP_OK;
 }
-int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int32_t lds_cols, int32_t *row_vertex,
+int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int32_t lds_bytes, int32_t *row_vertex,
                       int32_t *row_aggregate, double *coarse_inv, int64_t *stats) {
     int rc = validate(d);
     if (rc) return rc;
@@ -1701,19 +1751,19 @@ int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int
     const bool pins_as_terms = (d->linsolver == 0 || d->linsolver == 2);
     const admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
                                                       d->tri_idx, d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, pw);
-    const admm_host::OcPlan P = admm_host::build_oc_plan(A, d->masses, n_blocks, spb, lds_cols, coarse_inv != nullptr);
+    const admm_host::OcPlan P = admm_host::build_oc_plan(A, d->masses, n_blocks, spb, lds_bytes, coarse_inv != nullptr);
     if (!P.ok) return fail(ADMM_HIP_ERR_ARG, "oc_plan: a block does not fit its slots");
     if (row_vertex) std::copy(P.orig.begin(), P.orig.end(), row_vertex);
     if (row_aggregate)
         for (int32_t r = 0; r < P.n_rows; ++r)
-            row_aggregate[r] = P.orig[r] < 0 ? -1 : (r / (64 * spb)) * admm_host::kOcSub + P.agg_of_slice[r / 64];
+            row_aggregate[r] = P.orig[r] < 0 ? -1 : (r / (64 * spb)) * admm_host::kOcSub + P.row_agg[r];
     if (coarse_inv) {
         if (!P.coarse_ok) return fail(ADMM_HIP_ERR_ARG, "oc_plan: no coarse space (masses differ between the axes, or too many blocks)");
         for (int i = 0; i < P.nc; ++i) std::copy(P.ainv.begin() + (size_t)i * P.ncp, P.ainv.begin() + (size_t)i * P.ncp + P.nc, coarse_inv + (size_t)i * P.nc);
     }
     if (stats) {
         stats[0] = P.stat_nnz; stats[1] = P.stat_stored; stats[2] = P.stat_onchip; stats[3] = P.stat_local;
-        stats[4] = P.nbr_ok ? P.nbr_max : -1; stats[5] = P.coarse_ok ? P.nc : 0; stats[6] = P.n_rows; stats[7] = P.bcols;
+        stats[4] = P.nbr_ok ? P.nbr_max : -1; stats[5] = P.coarse_ok ? P.nc : 0; stats[6] = P.nh_max; stats[7] = P.bcols;
     }
     return ADMM_HIP_OK;
 }

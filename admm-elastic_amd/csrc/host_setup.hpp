@@ -75,8 +75,9 @@ void locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int
                     double *span_before, double *span_after);
 
 // Plan of the on-chip PCG for general meshes (oc_plan.cpp): internal row order (compact blocks of `spb` wavefronts, each
-// split into kOcSub compact aggregates), the system matrix in that order (off-diagonal non-zeros, SELL-64), the part of
-// every slice that fits the LDS slab, the neighbour-block lists and the dense inverse of the aggregate coarse matrix.
+// split into kOcSub compact aggregates), the system matrix in that order (off-diagonal non-zeros, SELL-64, 16-bit columns
+// into the block's local vector = own rows + halo list), the part of every slice that fits the LDS slab, the
+// neighbour-block lists and the dense inverse of the aggregate coarse matrix.
 constexpr int kOcSub = 4;
 struct OcPlan {
     bool ok = false;
@@ -84,20 +85,23 @@ struct OcPlan {
     int32_t n_rows = 0;                 // G * spb * 64 internal rows (dummy rows: orig = -1)
     std::vector<int32_t> orig;          // [n_rows] internal row -> vertex
     std::vector<int32_t> pos;           // [n_verts] vertex -> internal row
-    Sell A;                             // internal numbering, off-diagonal non-zeros
+    std::vector<signed char> row_agg;   // [n_rows] aggregate (0..kOcSub-1) of the row inside its block
+    Sell A;                             // widths / offsets / values (idx unused: see col16)
+    std::vector<uint16_t> col16;        // local column of entry (slice s, column k, lane l) at slice_ptr[s] + ((k / 4) 64 + l) 4 + k % 4
     std::vector<double> mdiag;          // [3 n_rows] mass + diagonal of Ahat (0 for dummy rows)
+    std::vector<int32_t> halo_ptr, halo_src;   // [G + 1], internal rows of the halo entries of every block (sorted)
+    int32_t nh_max = 0, nh_cap = 0, vec_len = 0;   // largest halo, rounded up to 64, entries per axis of the local vector
     std::vector<int32_t> wl_s, lds_off; // [n_slices] columns of the slice kept in LDS, their offset (columns) in the block's slab
     int bcols = 0;                      // slab columns of the fullest block
     std::vector<int32_t> nbr;           // [G][64] blocks a block's rows reference (-1 = none)
     bool nbr_ok = false; int nbr_max = 0;
-    std::vector<signed char> agg_of_slice;   // [G spb] aggregate (0..kOcSub-1) of every wavefront
     int nc = 0, ncp = 0;                // coarse unknowns (G * kOcSub), padded row length of ainv
     bool coarse_ok = false;
     std::vector<double> ainv;           // [nc][ncp] (P^T A P)^-1
     int64_t stat_nnz = 0, stat_stored = 0, stat_onchip = 0, stat_local = 0;
 };
-// A = Ahat (mass not included), mass3 [3 n]; lds_cols = slab columns (64 entries of 12 B each) one block may use
-OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_cols, bool want_coarse);
+// A = Ahat (mass not included), mass3 [3 n]; lds_bytes = LDS one block may spend on its local vector and matrix slab
+OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_bytes, bool want_coarse);
 
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
 int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);

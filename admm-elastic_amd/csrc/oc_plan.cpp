@@ -7,11 +7,13 @@
 //   * vertices -> G compact blocks by recursive graph bisection (level structures from a pseudo-peripheral vertex,
 //     Simon 1991): on the 1 M-tet unstructured body 81 % of the non-zeros are block-local, against 46 % for the index
 //     strips of a reverse Cuthill-McKee numbering;
-//   * every block -> kOcSub compact aggregates (whole wavefronts each): the coarse space of the two-level
-//     preconditioner  M^-1 = D^-1 + P (P^T A P)^-1 P^T  (P = aggregate indicator vectors; the dense inverse of the
-//     <= 1024 x 1024 coarse matrix is formed here once, the system matrix of a scene never changes, src/Solver.cpp:225-226);
-//   * rows of an aggregate sorted by length, so that the 64 rows of a wavefront (one SELL slice) have similar lengths and
-//     the slab is not spent on padding; the diagonal is not stored (it is 1 / dinv - m).
+//   * every block -> kOcSub compact aggregates: the coarse space of the two-level preconditioner
+//     M^-1 = D^-1 + P (P^T A P)^-1 P^T  (P = aggregate indicator vectors; the dense inverse of the <= 1024 x 1024 coarse
+//     matrix is formed here once, the system matrix of a scene never changes, src/Solver.cpp:225-226);
+//   * rows of a block sorted by length, so that the 64 rows of a wavefront (one SELL slice) have similar lengths and the
+//     slab is not spent on padding; the diagonal is not stored (it is 1 / dinv - m);
+//   * columns as 16-bit indices into the block's LOCAL vector: own rows first, then the block's halo list (the rows of
+//     other blocks its matrix rows reference, each fetched once per product).
 #include "host_setup.hpp"
 #include <algorithm>
 #include <cmath>
@@ -141,11 +143,12 @@ bool spd_inverse(int n, std::vector<double> &a) {
 
 } // namespace
 
-OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_cols, bool want_coarse) {
+OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_bytes, bool want_coarse) {
     OcPlan P;
     const int32_t nv = A.n;
+    const int T = 64 * spb;
     P.G = G; P.spb = spb; P.sub = kOcSub;
-    P.n_rows = G * spb * 64;
+    P.n_rows = G * T;
     const Graph g = coupling_graph(A);
     // ---- blocks, then aggregates inside every block ----
     std::vector<int32_t> part_of(nv, 0), mark(nv, 0);
@@ -159,13 +162,6 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
     }
     std::vector<std::vector<int32_t> > blocks(G);
     for (int32_t v = 0; v < nv; ++v) blocks[part_of[v]].push_back(v);
-    // waves of aggregate a of a block: [wave0[a], wave0[a + 1])
-    int wave0[kOcSub + 1];
-    for (int a = 0; a <= kOcSub; ++a) wave0[a] = (spb * a) / kOcSub;
-    P.agg_of_slice.assign((size_t)G * spb, 0);
-    for (int b = 0; b < G; ++b)
-        for (int a = 0; a < kOcSub; ++a)
-            for (int w = wave0[a]; w < wave0[a + 1]; ++w) P.agg_of_slice[(size_t)b * spb + w] = (signed char)a;
     P.orig.assign(P.n_rows, -1);
     P.pos.assign(nv, -1);
     std::vector<int32_t> len(nv, 0);
@@ -174,42 +170,50 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
     for (int b = 0; b < G; ++b) {
         std::vector<int32_t> &mem = blocks[b];
         const int32_t nb = (int32_t)mem.size();
-        if (nb > 64 * spb) { P.ok = false; return P; }
-        // aggregate sizes proportional to their wave counts (an aggregate with no wave gets nothing)
-        int32_t sizes[kOcSub];
-        int32_t given = 0;
-        for (int a = 0; a < kOcSub; ++a) {
-            const int64_t hi = ((int64_t)nb * wave0[a + 1] + spb - 1) / spb;
-            sizes[a] = (int32_t)std::min<int64_t>(hi, nb) - given;
-            sizes[a] = std::min(sizes[a], 64 * (wave0[a + 1] - wave0[a]));
-            given += sizes[a];
-        }
-        // rounding may leave a few members over: hand them to aggregates with room
-        for (int a = 0; a < kOcSub && given < nb; ++a) {
-            const int32_t room = 64 * (wave0[a + 1] - wave0[a]) - sizes[a];
-            const int32_t add = std::min(room, nb - given);
-            sizes[a] += add; given += add;
-        }
+        if (nb > T) { P.ok = false; return P; }
         if (nb > 0) {
+            int32_t sizes[kOcSub]; int nz_map[kOcSub]; int nnz = 0;
+            for (int a = 0; a < kOcSub; ++a) {
+                const int32_t sz = (int32_t)(((int64_t)nb * (a + 1)) / kOcSub - ((int64_t)nb * a) / kOcSub);
+                if (sz > 0) { sizes[nnz] = sz; nz_map[nnz] = a; ++nnz; }
+            }
             const int32_t idb = next_id++;
             for (int32_t v : mem) mark[v] = idb;
             std::vector<int32_t> copy(mem);
-            // empty parts are legal for bisect only at the ends of the list; compact the non-empty ones
-            int32_t nz_sizes[kOcSub]; int nz_map[kOcSub]; int nnz = 0;
-            for (int a = 0; a < kOcSub; ++a) if (sizes[a] > 0) { nz_sizes[nnz] = sizes[a]; nz_map[nnz] = a; ++nnz; }
-            bisect(g, copy, nz_sizes, nnz, 0, mark, next_id, seen, agg_part);
+            bisect(g, copy, sizes, nnz, 0, mark, next_id, seen, agg_part);
             for (int32_t v : mem) agg_part[v] = nz_map[agg_part[v]];
         }
-        // rows of an aggregate: longest first (ties: vertex index), laid into the aggregate's waves
-        for (int a = 0; a < kOcSub; ++a) {
-            std::vector<int32_t> rows;
-            for (int32_t v : mem) if (agg_part[v] == a) rows.push_back(v);
-            std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) { return len[x] != len[y] ? len[x] > len[y] : x < y; });
-            int32_t slot = (b * spb + wave0[a]) * 64;
-            for (int32_t v : rows) { P.orig[slot] = v; P.pos[v] = slot; ++slot; }
-        }
+        // rows of the block: longest first (ties: aggregate, vertex) -> the 64 rows of a wavefront have similar lengths
+        std::vector<int32_t> rows(mem);
+        std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) {
+            if (len[x] != len[y]) return len[x] > len[y];
+            if (agg_part[x] != agg_part[y]) return agg_part[x] < agg_part[y];
+            return x < y;
+        });
+        int32_t slot = b * T;
+        for (int32_t v : rows) { P.orig[slot] = v; P.pos[v] = slot; ++slot; }
     }
-    // ---- SELL of the off-diagonal non-zeros, internal numbering ----
+    P.row_agg.assign(P.n_rows, 0);
+    for (int32_t r = 0; r < P.n_rows; ++r) if (P.orig[r] >= 0) P.row_agg[r] = (signed char)agg_part[P.orig[r]];
+    // ---- halo lists: the rows of other blocks a block's matrix rows reference, sorted ----
+    P.halo_ptr.assign(G + 1, 0);
+    std::vector<std::vector<int32_t> > halo(G);
+    for (int b = 0; b < G; ++b) {
+        std::vector<int32_t> &h = halo[b];
+        for (int32_t v : blocks[b])
+            for (int32_t k = g.ptr[v]; k < g.ptr[v + 1]; ++k)
+                if (part_of[g.adj[k]] != b) h.push_back(P.pos[g.adj[k]]);
+        std::sort(h.begin(), h.end());
+        h.erase(std::unique(h.begin(), h.end()), h.end());
+        P.halo_ptr[b + 1] = P.halo_ptr[b] + (int32_t)h.size();
+        P.nh_max = std::max(P.nh_max, (int32_t)h.size());
+    }
+    P.halo_src.reserve(P.halo_ptr[G]);
+    for (int b = 0; b < G; ++b) P.halo_src.insert(P.halo_src.end(), halo[b].begin(), halo[b].end());
+    P.nh_cap = (P.nh_max + 63) / 64 * 64;
+    if (T + P.nh_cap > 65535) { P.ok = false; return P; }
+    // ---- SELL of the off-diagonal non-zeros: values + 16-bit local columns (own row = internal row - block base, halo
+    //      entry h = T + h), four columns of a lane packed into one 8-byte word ----
     Sell &S = P.A;
     S.n_rows = P.n_rows; S.n_slices = G * spb;
     S.slice_ptr.assign(S.n_slices + 1, 0); S.slice_width.assign(S.n_slices, 0);
@@ -220,41 +224,68 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
         S.slice_width[s] = w;
         S.slice_ptr[s + 1] = S.slice_ptr[s] + 64 * w;
     }
-    S.idx.assign(S.slice_ptr[S.n_slices], 0); S.val.assign(S.slice_ptr[S.n_slices], 0.0);
+    S.val.assign(S.slice_ptr[S.n_slices], 0.0);
+    P.col16.assign(S.slice_ptr[S.n_slices], 0);
     P.mdiag.assign(3 * (size_t)P.n_rows, 0.0);
-    for (int32_t s = 0; s < S.n_slices; ++s)
+    for (int32_t s = 0; s < S.n_slices; ++s) {
+        const int b = s / spb;
+        const std::vector<int32_t> &h = halo[b];
         for (int l = 0; l < 64; ++l) {
             const int32_t r = 64 * s + l, v = P.orig[r];
+            const uint16_t self = (uint16_t)(r - b * T);
             int32_t k = 0;
+            auto put = [&](uint16_t c, double x) {
+                S.val[(size_t)S.slice_ptr[s] + 64 * k + l] = x;
+                P.col16[(size_t)S.slice_ptr[s] + ((size_t)(k >> 2) * 64 + l) * 4 + (k & 3)] = c;
+                ++k;
+            };
             if (v >= 0) {
-                // columns in increasing INTERNAL order (neighbouring lanes then tend to read neighbouring entries)
-                std::vector<std::pair<int32_t, double> > ent;
+                std::vector<std::pair<int32_t, double> > ent;   // (local index, value), increasing local index
                 double diag = 0.0;
                 for (int32_t q = A.rowptr[v]; q < A.rowptr[v + 1]; ++q) {
-                    if (A.col[q] == v) { diag = A.val[q]; continue; }
-                    if (A.val[q] != 0.0) ent.emplace_back(P.pos[A.col[q]], A.val[q]);
+                    const int32_t cv = A.col[q];
+                    if (cv == v) { diag = A.val[q]; continue; }
+                    if (A.val[q] == 0.0) continue;
+                    const int32_t pr = P.pos[cv];
+                    int32_t lc;
+                    if (part_of[cv] == b) lc = pr - b * T;
+                    else lc = T + (int32_t)(std::lower_bound(h.begin(), h.end(), pr) - h.begin());
+                    ent.emplace_back(lc, A.val[q]);
                 }
                 std::sort(ent.begin(), ent.end());
-                for (auto &e : ent) { const size_t o = (size_t)S.slice_ptr[s] + 64 * k + l; S.idx[o] = e.first; S.val[o] = e.second; ++k; }
+                for (auto &e : ent) put((uint16_t)e.first, e.second);
                 for (int j = 0; j < 3; ++j) P.mdiag[3 * (size_t)r + j] = mass3[3 * (size_t)v + j] + diag;
             }
-            for (; k < S.slice_width[s]; ++k) { const size_t o = (size_t)S.slice_ptr[s] + 64 * k + l; S.idx[o] = r; S.val[o] = 0.0; }
+            while (k < S.slice_width[s]) put(self, 0.0);   // padding: zero times the row's own entry
         }
-    // ---- LDS slab: columns of every slice held on chip ----
+    }
+    // ---- LDS: the block's local vector (3 axes x (T + halo)) and the slab (10 bytes per entry) ----
+    P.vec_len = T + P.nh_cap;
+    const int lds_cols = std::max(0, (lds_bytes - 3 * 8 * P.vec_len) / (64 * 10)) / 4 * 4;
     P.wl_s.assign(S.n_slices, 0); P.lds_off.assign(S.n_slices, 0);
     P.bcols = 0;
     for (int b = 0; b < G; ++b) {
         int cap = 0;
         for (int w = 0; w < spb; ++w) cap = std::max(cap, S.slice_width[b * spb + w]);
         auto total = [&](int c) { int t = 0; for (int w = 0; w < spb; ++w) t += std::min(S.slice_width[b * spb + w], c); return t; };
-        while (cap > 4 && total(cap) > lds_cols) cap -= 4;
+        while (cap > 0 && total(cap) > lds_cols) cap -= 4;
         int off = 0;
         for (int w = 0; w < spb; ++w) {
             const int s = b * spb + w;
-            P.wl_s[s] = std::min(std::min(S.slice_width[s], cap), std::max(0, lds_cols - off) / 4 * 4);
+            P.wl_s[s] = std::min(S.slice_width[s], cap);
             P.lds_off[s] = off;
             off += P.wl_s[s];
         }
+        // columns left over go to the widest slices, four at a time
+        for (bool more = true; more && off + 4 <= lds_cols;) {
+            more = false;
+            for (int w = 0; w < spb && off + 4 <= lds_cols; ++w) {
+                const int s = b * spb + w;
+                if (P.wl_s[s] < S.slice_width[s]) { P.wl_s[s] += 4; off += 4; more = true; }
+            }
+        }
+        off = 0;
+        for (int w = 0; w < spb; ++w) { P.lds_off[b * spb + w] = off; off += P.wl_s[b * spb + w]; }
         P.bcols = std::max(P.bcols, off);
     }
     {   // statistics
@@ -270,14 +301,13 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
     for (int b = 0; b < G && P.nbr_ok; ++b) {
         std::vector<char> sb(G, 0);
         int n = 0;
-        for (int32_t v : blocks[b])
-            for (int32_t k = g.ptr[v]; k < g.ptr[v + 1]; ++k) {
-                const int bj = part_of[g.adj[k]];
-                if (bj == b || sb[bj]) continue;
-                sb[bj] = 1;
-                if (n == 64) { P.nbr_ok = false; break; }
-                P.nbr[(size_t)b * 64 + n++] = bj;
-            }
+        for (int32_t pr : halo[b]) {
+            const int bj = pr / T;
+            if (sb[bj]) continue;
+            sb[bj] = 1;
+            if (n == 64) { P.nbr_ok = false; break; }
+            P.nbr[(size_t)b * 64 + n++] = bj;
+        }
         P.nbr_max = std::max(P.nbr_max, n);
     }
     // ---- coarse space: aggregate indicators; (P^T A P)^-1 dense ----
@@ -296,10 +326,10 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
             Ac[(size_t)ci * nc + ci] += mass3[3 * (size_t)v];
             for (int32_t q = A.rowptr[v]; q < A.rowptr[v + 1]; ++q) Ac[(size_t)ci * nc + agg[A.col[q]]] += A.val[q];
         }
-        // empty aggregates (blocks smaller than their slots): unit diagonal, they never receive a residual
+        // empty aggregates (tiny blocks): unit diagonal, they never receive a residual
         for (int c = 0; c < nc; ++c) if (Ac[(size_t)c * nc + c] == 0.0) Ac[(size_t)c * nc + c] = 1.0;
         for (int i = 0; i < nc; ++i)   // symmetrise the round-off
-            for (int j = 0; j < i; ++j) { const double s = 0.5 * (Ac[(size_t)i * nc + j] + Ac[(size_t)j * nc + i]); Ac[(size_t)i * nc + j] = s; Ac[(size_t)j * nc + i] = s; }
+            for (int j = 0; j < i; ++j) { const double sm = 0.5 * (Ac[(size_t)i * nc + j] + Ac[(size_t)j * nc + i]); Ac[(size_t)i * nc + j] = sm; Ac[(size_t)j * nc + i] = sm; }
         if (spd_inverse(nc, Ac)) {
             P.ainv.assign((size_t)nc * P.ncp, 0.0);
             for (int i = 0; i < nc; ++i) std::memcpy(&P.ainv[(size_t)i * P.ncp], &Ac[(size_t)i * nc], nc * sizeof(double));

@@ -93,21 +93,9 @@ struct OcArgs {
     double cheb_inv_theta, cheb_c1[8], cheb_c2[8];
     // block-local symmetric Gauss-Seidel preconditioner (MODE 2): colour (0 / 1) of every row of a 2-colourable Ahat
     const signed char *row_color;
-    // general-mesh plan (oc_plan.cpp; nullptr / 0 = rows in the caller's order, one slab width `wl` for every wave):
-    const int *orig;            // [n_rows] internal row -> vertex (-1 = dummy row); x, b, dinv are indexed by vertex,
-                                // m (= mass + diagonal of Ahat: the SELL then holds only off-diagonal entries), the
-                                // recycled pairs and every scratch vector by internal row
-    const int *lds_off, *wl_s;  // [n_slices] slab offset (columns inside the block's slab) and columns held in LDS
-    int bcols;                  // slab columns per block
-    // two-level preconditioner (MODE 3):  M^-1 = D^-1 + P (P^T A P)^-1 P^T,  P = indicator vectors of kOcSub compact
-    // aggregates per block (whole wavefronts each)
-    const signed char *agg_of_slice;   // [n_slices] aggregate (0 .. kOcSub-1) of every wavefront
-    const double *ainv;         // [nc][ncp] dense inverse of the coarse matrix
-    double *cbuf;               // [2][3][ncp] aggregate sums published by the blocks, double-buffered by barrier parity
-    int nc, ncp;
 };
-constexpr int kOcSubK = 4;      // = admm_host::kOcSub
 
+constexpr int kOcSubK = 4;                // aggregates per block of the two-level preconditioner (= admm_host::kOcSub, pcg_onchip2.hpp)
 constexpr int kOcScratch = 6144;          // bytes of LDS scratch ahead of the per-wave staging area and the matrix slab
 constexpr int kOcStage = 3 * 64 * 8;      // per-wave staging area (publish transposition)
 constexpr unsigned kOcSpinLimit = 4000000u;
@@ -183,6 +171,7 @@ __device__ __forceinline__ bool oc_barrier(unsigned *bar, unsigned epoch, int G,
 
 // Pipelined iteration, first half of the synchronisation: drain, announce (flag for the neighbours + arrival on the
 // grid barrier, both fire-and-forget), then wait only for the blocks this block gathers from.
+// (ARRIVE = false: flag and wait only -- pcg_onchip2.hpp crosses its grid barrier after the gather)
 template <bool ARRIVE = true>
 __device__ __forceinline__ bool oc_announce_and_wait_neighbours(unsigned *bar, unsigned long long *flags, const int *nbr, unsigned seq, unsigned epoch,
                                                                 int *ok_lds, int *sig) {
@@ -348,26 +337,22 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     if (a.prof && (int)blockIdx.x == a.prof_block && tid == 0) a.prof[63 * 8 + 0] = wall_clock64();
     LdsD *stg = (LdsD *)(smem + kOcScratch) + wv * (kOcStage / 8);   // this wave's staging area
     LdsD *lv_all = (LdsD *)(smem + kOcScratch + nw * kOcStage);
+    LdsI *lc_all = (LdsI *)(lv_all + a.spb * a.wl * 64);
+    const LdsD *lv = lv_all + wv * a.wl * 64 + lane;
+    const LdsI *lc = lc_all + wv * a.wl * 64 + lane;
+
     const int s = __builtin_amdgcn_readfirstlane((int)blockIdx.x * a.spb + wv);
     const bool live_slice = s < a.n_slices;
-    // slab: one width `wl` for every wave, or (general-mesh plan) this slice's own share of the block's `bcols` columns
-    const int slab_cols = a.lds_off ? a.bcols : a.spb * a.wl;
-    const int slab_off = __builtin_amdgcn_readfirstlane(a.lds_off ? (live_slice ? a.lds_off[s] : 0) : wv * a.wl);
-    LdsI *lc_all = (LdsI *)(lv_all + slab_cols * 64);
-    const LdsD *lv = lv_all + slab_off * 64 + lane;
-    const LdsI *lc = lc_all + slab_off * 64 + lane;
-
     const int row = s * 64 + lane;
-    const int vi = (live_slice && row < a.n_rows) ? (a.orig ? a.orig[row] : row) : -1;   // the vertex this row belongs to
-    const bool live = vi >= 0;
+    const bool live = live_slice && row < a.n_rows;
     const int w = live_slice ? a.w[s] : 0;
     const int base = live_slice ? a.ptr[s] : 0;
-    const int wl_s = __builtin_amdgcn_readfirstlane(a.wl_s ? (live_slice ? a.wl_s[s] : 0) : (w < a.wl ? w : a.wl));
+    const int wl_s = w < a.wl ? w : a.wl;
     const int *cpg = a.col + base + lane;
     const double *vpg = a.val + base + lane;
     {   // the thread's matrix row -> LDS, once per solve
-        LdsD *lvw = lv_all + slab_off * 64 + lane;
-        LdsI *lcw = lc_all + slab_off * 64 + lane;
+        LdsD *lvw = lv_all + wv * a.wl * 64 + lane;
+        LdsI *lcw = lc_all + wv * a.wl * 64 + lane;
         for (int k = 0; k < wl_s; ++k) { lvw[64 * k] = vpg[64 * k]; lcw[64 * k] = cpg[64 * k]; }
     }
     if (a.prof && (int)blockIdx.x == a.prof_block && tid == 0) a.prof[63 * 8 + 1] = wall_clock64();
@@ -379,19 +364,15 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     double rx[3], ru[3], rw[3], rp[3], rsv[3], rz[3], rd[3], rm[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const size_t i = 3 * (size_t)(live ? vi : 0) + j;
-        rx[j] = live ? a.x[i] : 0.0; rd[j] = live ? a.dinv[i] : 0.0; rm[j] = live ? a.m[a.orig ? 3 * (size_t)row + j : i] : 0.0;
+        const size_t i = 3 * (size_t)(live ? row : 0) + j;
+        rx[j] = live ? a.x[i] : 0.0; rd[j] = live ? a.dinv[i] : 0.0; rm[j] = live ? a.m[i] : 0.0;
         ru[j] = rw[j] = rp[j] = rsv[j] = rz[j] = 0.0;
     }
     // Two sets of barrier counters, used by alternate solves: this launch counts on set (seq & 1) and clears the
     // other one for the next launch (nobody touches it meanwhile), so no memset is needed between solves.
     unsigned *const bar = a.bar + 32 * 16 * (a.seq & 1);
     if (blockIdx.x == 0 && tid < 9) a.bar[32 * 16 * ((a.seq & 1) ^ 1) + 16 * (tid < 8 ? tid : 17)] = 0u;
-    unsigned ph = 0;     // publish phase of the vector: buffer parity = ph & 1, tag of the neighbour flags
-    unsigned be = 0;     // grid-barrier epoch (arrivals of this block so far); record parity = be & 1.  Every phase of the
-                         // Jacobi / Chebyshev / block-GS forms is one publish AND one barrier (ph == be throughout); the
-                         // two-level form (MODE 3) exchanges the vector between neighbours only and crosses its one grid
-                         // barrier per iteration after the gather, so the two counters part there
+    unsigned ph = 0;     // publish phase: buffer parity = ph & 1, barrier epoch = ph
     const bool prof = a.prof && (int)blockIdx.x == a.prof_block && tid == 0;
     int prof_n = 0;
 #define OC_STAMP(slot) do { if (prof && prof_n < 62) a.prof[prof_n * 8 + (slot)] = wall_clock64(); } while (0)
@@ -414,7 +395,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     int rec_par = -1;  // record buffer to reduce from; -1 = the phase parity (one phase per iteration)
     auto gather_and_reduce = [&](const double *self, double *out, bool do_gather, bool do_reduce) {
         const int vpar = (int)(ph & 1u);
-        const int par = rec_par >= 0 ? rec_par : (int)(be & 1u);
+        const int par = rec_par >= 0 ? rec_par : vpar;
         double rec[4] = {0.0, 0.0, 0.0, 0.0};
         if (do_reduce && wv < nsum) {
 #pragma unroll
@@ -498,84 +479,6 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                              // correctness -- a colour-1 row writes only its own slot and reads only colour-0 slots -- but the
                              // version without them measured 3 % slower: 914 vs 943 ADMM it/s.)
     };
-    // MODE 3 -- two-level preconditioner  M^-1 = D^-1 + P Ac^-1 P^T  (P = indicators of this block's kOcSubK aggregates,
-    // Ac = P^T A P, its dense inverse formed once on the host: the system matrix of a scene never changes).  The coarse
-    // part needs P^T v of ALL blocks, i.e. an all-to-all of 3 kOcSubK numbers per block: it rides on the ONE grid barrier
-    // of an iteration, next to the partial dot products -- see the loop below.  The aggregates are whole wavefronts, so
-    // P^T v is a wave sum and P y a wave-uniform value.
-    const bool two_level = MODE == 3 && a.ainv != nullptr && a.nbr != nullptr && a.agg_of_slice != nullptr && kOcTrig * a.tol2 >= kOcPipeFloor;
-    double *wsum = (double *)(smem + 4096);            // [16][3] wave sums
-    double *ycur = (double *)(smem + 4096 + 384);      // [kOcSubK][3] result of the last coarse solve
-    double *yw = ycur + 3 * kOcSubK, *yz = ycur + 6 * kOcSubK;   // coarse parts carried by the w and z recurrences
-    int *aggw = (int *)(smem + 4096 + 384 + 9 * kOcSubK * 8);     // [16] aggregate of every wave of this block
-    const int myagg = (MODE == 3 && two_level && live_slice) ? (int)a.agg_of_slice[s] : 0;
-    if (MODE == 3 && two_level) {
-        if (tid < 16) aggw[tid] = (tid < nw && (int)blockIdx.x * a.spb + tid < a.n_slices) ? (int)a.agg_of_slice[(int)blockIdx.x * a.spb + tid] : -1;
-        if (tid < 3 * kOcSubK) { yw[tid] = 0.0; yz[tid] = 0.0; ycur[tid] = 0.0; }
-        __syncthreads();
-    }
-    __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void *)a.cbuf, 0, (MODE == 3 && a.cbuf) ? 2 * 3 * a.ncp * 8 : 0, 0x00020000);
-    // P^T v of this block's aggregates -> the published coarse vector of the given parity
-    auto agg_publish = [&](const double *v, int par) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const double sm = wave_sum(live ? v[j] : 0.0);
-            if (lane == 0) wsum[3 * wv + j] = sm;
-        }
-        __syncthreads();
-        if (tid < 3 * kOcSubK) {
-            const int ag = tid / 3, j = tid - 3 * ag;
-            double sm = 0.0;
-            for (int k = 0; k < nw; ++k) sm += (aggw[k] == ag) ? wsum[3 * k + j] : 0.0;
-            oc_store_sc1(rs_c, ((par * 3 + j) * a.ncp + (int)blockIdx.x * kOcSubK + ag) * 8, sm);
-        }
-    };
-    // after the grid barrier: ycur = (rows of Ac^-1 of this block's aggregates) x (published coarse vector)
-    auto coarse_solve = [&](int par) {
-        double acc[3 * kOcSubK];
-#pragma unroll
-        for (int i = 0; i < 3 * kOcSubK; ++i) acc[i] = 0.0;
-        for (int c = tid; c < a.nc; c += T) {
-            double cn[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) cn[j] = oc_load_sc1_f64(rs_c, ((par * 3 + j) * a.ncp + c) * 8);
-#pragma unroll
-            for (int ag = 0; ag < kOcSubK; ++ag) {
-                const double ai = a.ainv[(size_t)((int)blockIdx.x * kOcSubK + ag) * a.ncp + c];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc[3 * ag + j] = fma(ai, cn[j], acc[3 * ag + j]);
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < (3 * kOcSubK + 7) / 8; ++h) {
-            double q8[8], b0, b1;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) q8[i] = (8 * h + i < 3 * kOcSubK) ? acc[(8 * h + i < 3 * kOcSubK) ? 8 * h + i : 0] : 0.0;
-            row_sum8(q8, b0, b1);
-            if ((lane & 15) < 4) {
-                double *dst = red + ((wv * 4 + (lane >> 4)) * 8 + 4 * (lane & 1) + (lane & 2));
-                dst[0] = b0; dst[1] = b1;
-            }
-            __syncthreads();
-            if (tid < 8 && 8 * h + tid < 3 * kOcSubK) {
-                double sm = 0.0;
-                for (int r = 0; r < 4 * nw; ++r) sm += red[r * 8 + tid];
-                ycur[8 * h + tid] = sm;
-            }
-            __syncthreads();
-        }
-    };
-    // y = (P Ac^-1 P^T v) on this thread's row: one all-to-all (its own grid barrier)
-    auto coarse_apply = [&](const double *v, double *y) -> bool {
-        ++be;
-        const int par = (int)(be & 1u);
-        agg_publish(v, par);
-        if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return false;
-        coarse_solve(par);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) y[j] = live ? ycur[3 * myagg + j] : 0.0;
-        return true;
-    };
     // All scalar decisions (stop tests, alpha/beta, mode switches) are taken by thread 0, whose bookkeeping lives
     // in LDS, and broadcast through LDS: uniform values would otherwise occupy registers in every lane, and the
     // action code read back with readfirstlane keeps the control flow provably uniform.
@@ -586,15 +489,15 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
     // the published copy; leaves gamma_true (and optionally b . M^-1 b) in q[0..5]
     auto true_residual = [&](bool from_global, bool with_bnorm, double *q) -> bool {
         double acc[3];
-        if (from_global && !a.orig) oc_row<false, DEEP>(rs_u, 0, 0, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
-        else {   // (internal row order: the column indices are internal, x is stored by vertex -- gather the published copy)
-            ++ph; ++be; publish(rx);
-            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return false;
+        if (from_global) oc_row<false, DEEP>(rs_u, 0, 0, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
+        else {
+            ++ph; publish(rx);
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) return false;
             oc_row<true, DEEP>(rs_u, (int)(ph & 1u) * ub, as, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double bj = live ? a.b[3 * (size_t)vi + j] : 0.0;
+            const double bj = live ? a.b[3 * (size_t)row + j] : 0.0;
             const double ri = bj - fma(rm[j], rx[j], acc[j]);
             ru[j] = rd[j] * ri;
             q[j] = ru[j] * ri;                               // r . M^-1 r
@@ -606,7 +509,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         // ---- start: TRUE residual of the warm start, stop test, w = A u ----------------------------------
         {
             double q[6];
-            if (!a.rc_on) { if (!true_residual(true, true, q)) { aborted = true; break; } }
+            if (!a.rc_on) true_residual(true, true, q);
             else {
                 // ---- recycled warm start (see k_rc_* in kernels.hpp for the launch-path version) ----------------
                 // r0 = b - A x0; A-orthogonal projection of the error on the stored exact pairs (E_j, A E_j):
@@ -623,16 +526,11 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                         r[jj][ax] = on ? a.rc.R[jj][3 * (size_t)row + ax] : 0.0;
                     }
                 if (prof) a.prof[62 * 8 + 0] = wall_clock64();
-                if (!a.orig) oc_row<false, DEEP>(rs_u, 0, 0, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
-                else {
-                    ++ph; ++be; publish(rx);
-                    if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
-                    oc_row<true, DEEP>(rs_u, (int)(ph & 1u) * ub, as, nullptr, lv, lc, wl_s, w, cpg, vpg, acc);
-                }
+                oc_row<false, DEEP>(rs_u, 0, 0, a.x, lv, lc, wl_s, w, cpg, vpg, acc);
                 if (prof) a.prof[62 * 8 + 1] = wall_clock64();
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    bj[j] = live ? a.b[3 * (size_t)vi + j] : 0.0;
+                    bj[j] = live ? a.b[3 * (size_t)row + j] : 0.0;
                     ri[j] = bj[j] - fma(rm[j], rx[j], acc[j]);
                     if (live) { a.rc_xs[3 * (size_t)row + j] = rx[j]; a.rc_r0[3 * (size_t)row + j] = ri[j]; }
                 }
@@ -673,8 +571,8 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                     }
                     __syncthreads();
                     if (prof) a.prof[62 * 8 + 2] = wall_clock64();
-                    ++ph; ++be;
-                    if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    ++ph;
+                    if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
                     if (prof) a.prof[62 * 8 + 3] = wall_clock64();
                     {   // every block adds the G partials of every sum in the same order; wave wv takes sums wv, wv + nw, ...
                         double v[6][4];
@@ -737,18 +635,10 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 for (int j = 0; j < 3; ++j) rr[j] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
                 block_prec(rr, ru);
             }
-            if (MODE == 3 && two_level) {   // r explicitly, u = D^-1 r + P Ac^-1 P^T r (q above stays the Jacobi norm)
-                double y[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) rr[j] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
-                if (!coarse_apply(rr, y)) { aborted = true; break; }
-#pragma unroll
-                for (int j = 0; j < 3; ++j) ru[j] += y[j];
-            }
-            ++ph; ++be; publish(ru);
-            oc_publish_partials(q, red, nw, rs_p, (int)(be & 1u), a.G);
+            ++ph; publish(ru);
+            oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
         }
-        if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+        if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
         gather_and_reduce(ru, rw, true, true);
         if (tid == 0) {
             // The three axes are independent systems with their own b . M^-1 b.  An axis whose right-hand side vanishes
@@ -773,7 +663,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 conv = true; break;
             }
             if (act0 == 1) {
-                if ((MODE == 2 && bssor) || (MODE == 3 && two_level)) {   // the epilogue expects u = D^-1 r
+                if (MODE == 2 && bssor) {   // the epilogue expects u = D^-1 r
 #pragma unroll
                     for (int j = 0; j < 3; ++j) ru[j] = rd[j] * rr[j];
                 }
@@ -838,9 +728,9 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
         auto verify = [&]() -> int {
             double q[6];
             if (!true_residual(false, false, q)) return -1;
-            ++ph; ++be;
-            oc_publish_partials(q, red, nw, rs_p, (int)(be & 1u), a.G);
-            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return -1;
+            ++ph;
+            oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) return -1;
             gather_and_reduce(nullptr, nullptr, false, true);
             if (tid == 0) {
                 bool ok = true;
@@ -886,7 +776,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) ru[j] += dd[j];
                     if (k == a.poly_m - 1) break;
-                    ++ph; ++be; publish(dd);
+                    ++ph; publish(dd);
                     if (!oc_announce_and_wait_neighbours(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { fail = true; break; }
                     gather_and_reduce(dd, t, true, false);                                   // t = A d
                     const double c1 = chb[k], c2 = chb[8 + k];
@@ -894,7 +784,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                     for (int j = 0; j < 3; ++j) { res[j] = fma(-rd[j], t[j], res[j]); dd[j] = fma(c1, dd[j], c2 * res[j]); }
                 }
                 if (fail) { aborted = true; break; }
-                ++ph; ++be; publish(ru);
+                ++ph; publish(ru);
                 if (!oc_announce_and_wait_neighbours(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; }
                 gather_and_reduce(ru, rw, true, false);                                      // w = A u
                 double q[6], rho = 0.0;
@@ -906,10 +796,10 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 }
                 // records alternate by ITERATION (an iteration is m + 1 phases: with the phase parity a block that runs
                 // ahead through the neighbour-synchronised exchanges could overwrite a record others still reduce)
-                ++ph; ++be;
+                ++ph;
                 rec_par = iters & 1;
                 oc_publish_partials(q, red, nw, rs_p, rec_par, a.G, rho, 7);
-                if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { rec_par = -1; aborted = true; break; }
+                if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { rec_par = -1; aborted = true; break; }
                 gather_and_reduce(nullptr, nullptr, false, true);
                 rec_par = -1;
                 if (wv == 0) {   // lanes 0..2 = one axis each
@@ -978,11 +868,11 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                     q[3 + j] = rw[j] * ru[j];                                                // delta = w . u
                     rho = fma(rr[j] * rd[j] * rr[j], ctl[8 + j], rho);
                 }
-                ++ph; ++be; publish(mm);
-                oc_publish_partials(q, red, nw, rs_p, (int)(be & 1u), a.G, rho, 7);
+                ++ph; publish(mm);
+                oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G, rho, 7);
                 if (!oc_announce_and_wait_neighbours(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; }
                 gather_and_reduce(mm, rn, true, false);                                      // n = A m
-                if (!oc_barrier_wait(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                if (!oc_barrier_wait(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
                 gather_and_reduce(nullptr, nullptr, false, true);
                 if (wv == 0) {
                     const int j = lane < 3 ? lane : 0;
@@ -1028,100 +918,6 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                     ru[j] = fma(-alpha, rq[j], ru[j]);
                     rw[j] = fma(-alpha, rz[j], rw[j]);
                 }
-                ++iters; ++pipe_iters; fresh = false;
-            }
-            nsum = 6;
-            if (!conv && !go_classic && !aborted) {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) ru[j] = rd[j] * rr[j];
-            }
-            if (aborted || conv || !go_classic) break;
-        }
-        // ---- pipelined CG with the two-level preconditioner (MODE 3) -------------------------------------------------------
-        // General recurrences as in MODE 2.  m = M^-1 w needs P^T w of all blocks; it is carried by recurrence like w itself:
-        // with y_w = Ac^-1 P^T w and y_z = Ac^-1 P^T z (this block's kOcSubK x 3 entries only),  n = A m  gives
-        // y_n = Ac^-1 P^T n after ONE all-to-all of the aggregate sums of n, then y_z = y_n + beta y_z, y_w -= alpha y_z.
-        // That all-to-all shares the iteration's grid barrier with the partial dot products, so an iteration is: publish m,
-        // neighbour hand-off (flags, no barrier), gather n = A m, publish {P^T n, dots}, ONE grid barrier, reduce, update.
-        if (MODE == 3 && two_level) {
-            {
-                double y[3];
-                if (!coarse_apply(rw, y)) { aborted = true; break; }
-                if (tid < 3 * kOcSubK) { yw[tid] = ycur[tid]; yz[tid] = 0.0; }
-                __syncthreads();
-            }
-            nsum = 7;
-            double rho_best = 1e300;
-            while (iters < a.max_iters) {
-                double mm[3], rn[3] = {0.0, 0.0, 0.0}, q[6], rho = 0.0;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    mm[j] = live ? fma(rd[j], rw[j], yw[3 * myagg + j]) : 0.0;               // m = M^-1 w
-                    q[j] = rr[j] * ru[j];                                                    // gamma = r . u
-                    q[3 + j] = rw[j] * ru[j];                                                // delta = w . u
-                    rho = fma(rr[j] * rd[j] * rr[j], ctl[8 + j], rho);
-                }
-                ++ph; publish(mm);
-                if (!oc_announce_and_wait_neighbours<false>(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; }
-                gather_and_reduce(mm, rn, true, false);                                      // n = A m
-                ++be;
-                const int par = (int)(be & 1u);
-                agg_publish(rn, par);
-                oc_publish_partials(q, red, nw, rs_p, par, a.G, rho, 7);
-                if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
-                gather_and_reduce(nullptr, nullptr, false, true);
-                coarse_solve(par);                                                           // ycur = Ac^-1 P^T n
-                if (wv == 0) {
-                    const int j = lane < 3 ? lane : 0;
-                    const double g = bc[j], d = bc[3 + j], rs = bc[6];
-                    const unsigned long long m3 = 7ull;
-                    const bool finite = (__ballot(g < 1e290 && g >= 0.0 && d < 1e290) & m3) == m3 && rs < 1e290 && !(rs > 1e16 * rho_best);
-                    int act = 0;
-                    if (!finite) act = 2;
-                    else if (rs <= kOcTrig * a.tol2) act = 1;
-                    else if (lane < 3) {
-                        double alpha, beta;
-                        if (fresh) { beta = 0.0; alpha = (d > 0.0) ? g / d : 0.0; }
-                        else {
-                            const double gp = sc[j], ap = sc[3 + j];
-                            beta = (gp > 0.0) ? g / gp : 0.0;
-                            const double den = (ap != 0.0) ? d - beta * g / ap : d;
-                            alpha = (den > 0.0) ? g / den : 0.0;
-                        }
-                        sc[j] = g; sc[3 + j] = alpha;
-                        ctl[2 + j] = alpha; ctl[5 + j] = beta;
-                    }
-                    rho_best = fmin(rho_best, rs);
-                    if (lane == 0) ictl[2] = act;
-                }
-                const int act = action();
-                if (act == 2) { entry_restart = true; go_classic = true; break; }
-                if (act == 1) {
-                    const int v = verify();
-                    if (v < 0) { aborted = true; break; }
-                    if (v == 1) { conv = true; break; }
-                    go_classic = true; fresh = true;
-                    break;
-                }
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double alpha = ctl[2 + j], beta = ctl[5 + j];
-                    rz[j] = fma(beta, rz[j], rn[j]);
-                    rq[j] = fma(beta, rq[j], mm[j]);
-                    rsv[j] = fma(beta, rsv[j], rw[j]);
-                    rp[j] = fma(beta, rp[j], ru[j]);
-                    rx[j] = fma(alpha, rp[j], rx[j]);
-                    rr[j] = fma(-alpha, rsv[j], rr[j]);
-                    ru[j] = fma(-alpha, rq[j], ru[j]);
-                    rw[j] = fma(-alpha, rz[j], rw[j]);
-                }
-                if (tid < 3 * kOcSubK) {
-                    const int j = tid % 3;
-                    const double zz = fma(ctl[5 + j], yz[tid], ycur[tid]);
-                    yz[tid] = zz;
-                    yw[tid] = fma(-ctl[2 + j], zz, yw[tid]);
-                }
-                __syncthreads();   // yw is read, ctl / bc / ycur are rewritten by the next iteration
                 ++iters; ++pipe_iters; fresh = false;
             }
             nsum = 6;
@@ -1132,7 +928,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
             if (aborted || conv || !go_classic) break;
         }
         // ---- pipelined CG (Ghysels-Vanroose): one synchronisation per iteration, while its recurrences are trusted ----
-        while (!poly && !(MODE == 2 && bssor) && !(MODE == 3 && two_level) && iters < a.max_iters) {
+        while (!poly && !(MODE == 2 && bssor) && iters < a.max_iters) {
             OC_STAMP(0);
             double rn[3] = {0.0, 0.0, 0.0};
             {
@@ -1143,8 +939,8 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                     q[j] = (live ? ru[j] * ru[j] * fast_rcp(rd[j]) : 0.0);   // gamma = r . u
                     q[3 + j] = rw[j] * ru[j];                                 // delta = w . u
                 }
-                ++ph; ++be; publish(mm);
-                oc_publish_partials(q, red, nw, rs_p, (int)(be & 1u), a.G);
+                ++ph; publish(mm);
+                oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
                 OC_STAMP(1);
                 if (a.prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); OC_STAMP(5); }
                 if (a.nbr) {
@@ -1153,10 +949,10 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                     if (!oc_announce_and_wait_neighbours(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; }
                     OC_STAMP(2);
                     gather_and_reduce(mm, rn, true, false);       // n = A M^-1 w
-                    if (!oc_barrier_wait(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    if (!oc_barrier_wait(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
                     gather_and_reduce(nullptr, nullptr, false, true);   // the sums
                 } else {
-                    if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
                     OC_STAMP(2);
                     gather_and_reduce(mm, rn, true, true);        // n = A M^-1 w, and the sums
                 }
@@ -1197,7 +993,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
                 // as unconverged and hands back the entry x, never a non-finite vector.
                 entry_restart = false;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) rx[j] = live ? a.x[3 * (size_t)vi + j] : 0.0;
+                for (int j = 0; j < 3; ++j) rx[j] = live ? a.x[3 * (size_t)row + j] : 0.0;
                 double q[6];
                 if (!true_residual(false, false, q)) { aborted = true; break; }
                 if (tid == 0) { ctl[0] = 1e300; ictl[0] = 0; }
@@ -1207,9 +1003,9 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
             double q[6];
 #pragma unroll
             for (int j = 0; j < 3; ++j) { q[j] = (live ? ru[j] * ru[j] * fast_rcp(rd[j]) : 0.0); q[3 + j] = 0.0; }
-            ++ph; ++be;
-            oc_publish_partials(q, red, nw, rs_p, (int)(be & 1u), a.G);
-            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            ++ph;
+            oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
             gather_and_reduce(nullptr, nullptr, false, true);
             const int act = decide(false);
             if (act == 2) { entry_restart = true; continue; }
@@ -1222,14 +1018,14 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) rp[j] = fma(ctl[5 + j], rp[j], ru[j]);    // p = u + beta p
-            ++ph; ++be; publish(rp);
-            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            ++ph; publish(rp);
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
             gather_and_reduce(rp, rsv, true, false);                               // s = A p
 #pragma unroll
             for (int j = 0; j < 3; ++j) { q[j] = 0.0; q[3 + j] = rp[j] * rsv[j]; }
-            ++ph; ++be;
-            oc_publish_partials(q, red, nw, rs_p, (int)(be & 1u), a.G);
-            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            ++ph;
+            oc_publish_partials(q, red, nw, rs_p, (int)(ph & 1u), a.G);
+            if (!oc_barrier(bar, ph, a.G, ok_lds, a.sig)) { aborted = true; break; }
             gather_and_reduce(nullptr, nullptr, false, true);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -1246,7 +1042,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg_onchip(OcArgs a) {
 #undef OC_STAMP
     if (live) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { a.x[3 * (size_t)vi + j] = rx[j]; a.u_out[3 * (size_t)vi + j] = ru[j]; }
+        for (int j = 0; j < 3; ++j) { a.x[3 * (size_t)row + j] = rx[j]; a.u_out[3 * (size_t)row + j] = ru[j]; }
         if (a.rc_on) {   // this solve's pair: e = x - x_entry, A e = r_entry - r_final (exact: u carries the true residual)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {

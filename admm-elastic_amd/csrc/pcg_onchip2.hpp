@@ -1,0 +1,678 @@
+// pcg_onchip2.hpp -- the global solve of the ADMM step for GENERAL meshes: one persistent launch, two-level preconditioned
+// pipelined CG, every matrix-vector product out of LDS.
+//
+// Replaces the prefactored LDLT solve of src/LinearSolver.hpp:87-90 (same system, stop rule on the TRUE residual
+// r . D^-1 r <= tol^2 b . D^-1 b as in pcg_onchip.hpp, whose synchronisation primitives, safeguards and end game this
+// kernel shares).  What is new against pcg_onchip.hpp (kept as the A/B reference, ADMM_HIP_OC_PLAN=0):
+//   * the rows live in the plan's internal order (oc_plan.cpp): block = one CU = a COMPACT patch of the mesh (recursive
+//     graph bisection), 81 % of the non-zeros of the unstructured 1 M-tet body are block-local (index strips: 46 %);
+//   * a block keeps a LOCAL VECTOR in LDS: its own 64 spb entries plus its halo list -- the rows of other blocks its
+//     matrix rows reference, each fetched ONCE per product (one 8-byte sc1 load per axis) instead of once per referencing
+//     non-zero.  The product itself then runs entirely out of LDS: values (8 B) + 16-bit local columns, four columns per
+//     8-byte word.  On the unstructured body the gather of pcg_onchip.hpp issued 40 global loads per row and product
+//     (25 us per iteration); here a block issues ~3 per halo entry (~1 per row);
+//   * two-level preconditioner  M^-1 = D^-1 + P (P^T A P)^-1 P^T  with P = indicator vectors of kOcSub compact aggregates
+//     per block (<= 1024 coarse unknowns; the dense inverse is formed once on the host -- the system matrix of a scene
+//     never changes, src/Solver.cpp:225-226).  Jacobi needs 131 (cube) / 55 (unstructured body) iterations per solve of the
+//     1 M-tet benches, the block-local Gauss-Seidel sweep of pcg_onchip.hpp 85 / --, this 35 / 11.  The coarse part needs
+//     P^T v of ALL blocks: an all-to-all of 12 numbers per block.  It costs no extra synchronisation: m = M^-1 w is carried
+//     like w itself -- with y_w = Ac^-1 P^T w and y_z = Ac^-1 P^T z (this block's 4 x 3 entries), n = A m gives
+//     y_n = Ac^-1 P^T n after one all-to-all of the aggregate sums of n, then y_z = y_n + beta y_z, y_w -= alpha y_z --
+//     and that all-to-all rides on the iteration's one grid barrier next to the partial dot products.  An iteration is:
+//     publish m; neighbour hand-off (flags, no barrier); halo fetch; n = A m out of LDS; publish {P^T n, dots}; ONE grid
+//     barrier; reduce; coarse rows; update.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+#include "pcg_onchip.hpp"
+
+namespace admm_k {
+
+struct Oc2Args {
+    int n_rows, n_slices;            // internal rows (= 64 n_slices), slices (= G spb)
+    const int *ptr, *w;              // per slice: entry offset into val / col16, width (multiple of 4)
+    const double *val;               // entry (s, k, lane) at ptr[s] + 64 k + lane
+    const unsigned short *col16;     // its local column at ptr[s] + ((k / 4) 64 + lane) 4 + k % 4
+    const int *lds_off, *wl_s;       // per slice: slab offset (columns) and columns held in LDS
+    int bcols;                       // slab columns per block
+    const int *orig;                 // [n_rows] vertex | aggregate << 28 (-1 = dummy row)
+    const int *halo_ptr, *halo_src;  // [G + 1]; internal rows of the halo entries (sorted per block)
+    int vec_len;                     // entries per axis of the local vector: 64 spb own + halo capacity
+    const double *mdiag, *dinv, *b;  // mass + diag(Ahat) by internal row; dinv, b by vertex
+    double *x, *u_out;               // by vertex
+    double *ubuf;                    // [2][n_rows][4] published vector (x, y, z, pad: one 32-byte sector per row, so a halo
+                                     // entry is ONE request), double-buffered by phase parity
+    double *part;                    // [2][8][G] per-block partial sums, double-buffered by barrier parity
+    unsigned *bar;                   // barrier words (see pcg_onchip.hpp)
+    const int *nbr; unsigned long long *flags;
+    int *counters; CgScal *scal; int *sig;
+    unsigned long long *prof; int prof_block;
+    int spb, G, max_iters, seq;
+    double tol2;
+    int rc_on; RcBasis rc; double *rc_xs, *rc_r0, *rc_Eslot, *rc_Rslot, *rc_part;   // recycled warm start (internal rows)
+    const double *ainv; double *cbuf; int nc, ncp;   // two-level: [nc][ncp] coarse inverse, [2][3][ncp] published aggregate sums
+};
+
+constexpr int kOc2Scratch = 4096;   // bytes of LDS scratch ahead of the local vector and the matrix slab
+typedef __attribute__((address_space(3))) unsigned long long LdsU64;
+
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *red = (double *)smem;                   // [16][24] wave totals of up to 24 quantities
+    double *res24 = (double *)(smem + 3072);        // [24] their block totals
+    double *bc = (double *)(smem + 3328);           // [8] reduced scalars of the current phase
+    double *sc = (double *)(smem + 3392);           // [8] gamma_prev[3], alpha_prev[3]
+    double *gbl = (double *)(smem + 3456);          // [4] b . D^-1 b per axis
+    double *glast = (double *)(smem + 3488);        // [4] last gamma per axis (reporting)
+    double *ctl = (double *)(smem + 3520);          // [0] best ratio, [1] ratio of the last failed verification; [2..4] alpha,
+                                                    // [5..7] beta of this iteration; [8..10] 1 / (b . D^-1 b)
+    int *ictl = (int *)(smem + 3616);               // [0] iterations since best, [1] failed verifications, [2] action
+    int *ok_lds = (int *)(smem + 3632);
+    double *ycur = (double *)(smem + 3648);         // [kOcSubK][3] result of the last coarse solve
+    double *yw = ycur + 3 * kOcSubK, *yz = ycur + 6 * kOcSubK;   // coarse parts carried by the w and z recurrences
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
+    const bool prof = a.prof && (int)blockIdx.x == a.prof_block && tid == 0;
+    if (prof) a.prof[63 * 8 + 0] = wall_clock64();
+    const int NV = a.vec_len;
+    LdsD *vec = (LdsD *)(smem + kOc2Scratch);                    // [3][NV]: own entries [0, T), halo entries [T, T + nh)
+    LdsD *lv_all = vec + 3 * NV;                                 // slab values [bcols][64]
+    LdsU64 *lc_all = (LdsU64 *)(lv_all + a.bcols * 64);          // slab columns [bcols / 4][64] x 4 x 16 bit
+
+    const int s = __builtin_amdgcn_readfirstlane((int)blockIdx.x * a.spb + wv);
+    const int row = s * 64 + lane;
+    const int oa = a.orig[row];
+    const bool live = oa >= 0;
+    const int vi = live ? (oa & 0x0fffffff) : 0;       // the vertex this row belongs to
+    const int myagg = live ? (oa >> 28) & 3 : 0;
+    const int w = __builtin_amdgcn_readfirstlane(a.w[s]);
+    const int base = __builtin_amdgcn_readfirstlane(a.ptr[s]);
+    const int wl_s = __builtin_amdgcn_readfirstlane(a.wl_s[s]);
+    const int slab_off = __builtin_amdgcn_readfirstlane(a.lds_off[s]);
+    const double *vpg = a.val + base + lane;
+    const unsigned long long *cpg = (const unsigned long long *)(a.col16 + base) + lane;
+    const LdsD *lv = lv_all + slab_off * 64 + lane;
+    const LdsU64 *lc = lc_all + (slab_off >> 2) * 64 + lane;
+    {   // the thread's matrix row -> LDS, once per solve
+        LdsD *lvw = lv_all + slab_off * 64 + lane;
+        LdsU64 *lcw = lc_all + (slab_off >> 2) * 64 + lane;
+        for (int k = 0; k < wl_s; ++k) lvw[64 * k] = vpg[64 * k];
+        for (int k = 0; k < (wl_s >> 2); ++k) lcw[64 * k] = cpg[64 * k];
+    }
+    const int hp0 = a.halo_ptr[blockIdx.x], nh = a.halo_ptr[blockIdx.x + 1] - hp0;
+    // the halo entries this thread fetches (two per thread cover nh <= 2 T; more are read from the list every time)
+    const int hs0 = tid < nh ? a.halo_src[hp0 + tid] : 0, hs1 = tid + T < nh ? a.halo_src[hp0 + tid + T] : 0;
+    if (prof) a.prof[63 * 8 + 1] = wall_clock64();
+    const int ub = a.n_rows * 32;           // bytes of one published-vector buffer
+    __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)a.ubuf, 0, 2 * ub, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)a.part, 0, 2 * 8 * a.G * 8, 0x00020000);
+    const bool two_level = a.ainv != nullptr && a.nc <= 2 * T && kOcTrig * a.tol2 >= kOcPipeFloor;
+    __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void *)a.cbuf, 0, a.cbuf ? 2 * 3 * a.ncp * 8 : 0, 0x00020000);
+
+    double rx[3], ru[3], rw[3], rp[3], rsv[3], rz[3], rq[3], rr[3], rd[3], rm[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        rx[j] = live ? a.x[3 * (size_t)vi + j] : 0.0; rd[j] = live ? a.dinv[3 * (size_t)vi + j] : 0.0;
+        rm[j] = live ? a.mdiag[3 * (size_t)row + j] : 0.0;
+        ru[j] = rw[j] = rp[j] = rsv[j] = rz[j] = rq[j] = rr[j] = 0.0;
+    }
+    unsigned *const bar = a.bar + 32 * 16 * (a.seq & 1);
+    if (blockIdx.x == 0 && tid < 9) a.bar[32 * 16 * ((a.seq & 1) ^ 1) + 16 * (tid < 8 ? tid : 17)] = 0u;
+    if (tid < 3 * kOcSubK) { yw[tid] = 0.0; yz[tid] = 0.0; ycur[tid] = 0.0; }
+    unsigned ph = 0;     // publish phase of the vector: buffer parity = ph & 1, tag of the neighbour flags
+    unsigned be = 0;     // grid-barrier epoch (arrivals of this block so far); record parity = be & 1
+    int prof_n = 0;
+#define OC2_STAMP(slot) do { if (prof && prof_n < 62) a.prof[prof_n * 8 + (slot)] = wall_clock64(); } while (0)
+
+    // own entries -> local vector and -> this wave's 64 sectors of ubuf: two 16-byte write-through stores per lane, each
+    // instruction covering 1 KB of whole sectors (lane pairs write the two halves of a row's sector: half-written sectors
+    // from a row-per-lane layout measured 3x slower to drain); transposed through the local vector
+    auto publish = [&](const double *v) {
+        LdsD *o = vec + wv * 64;
+        o[lane] = v[0]; o[NV + lane] = v[1]; o[2 * NV + lane] = v[2];
+        const int r0 = lane >> 1, hi = lane & 1;
+        const int bo = (int)(ph & 1u) * ub + s * 2048 + lane * 16;
+        const double a0 = o[(hi ? 2 * NV : 0) + r0], a1 = hi ? 0.0 : o[NV + r0];
+        const double b0 = o[(hi ? 2 * NV : 0) + 32 + r0], b1 = hi ? 0.0 : o[NV + 32 + r0];
+        oc_store_sc1(rs_u, bo, a0, a1);
+        oc_store_sc1(rs_u, bo + 1024, b0, b1);
+    };
+    // after the synchronisation of phase ph: halo entries -> local vector, then out = A v from LDS
+    auto halo_and_rows = [&](const double *self, double *out) {
+        const int vb = (int)(ph & 1u) * ub;
+        for (int h = tid, it = 0; h < nh; h += T, ++it) {
+            const int src = it == 0 ? hs0 : it == 1 ? hs1 : a.halo_src[hp0 + h];
+            union { double d[2]; v4u v; } g0, g1;
+            g0.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, vb + src * 32, 0, 16);
+            g1.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, vb + src * 32 + 16, 0, 16);
+            vec[T + h] = g0.d[0]; vec[NV + T + h] = g0.d[1]; vec[2 * NV + T + h] = g1.d[0];
+        }
+        __syncthreads();
+        double acc[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < w; k += 4) {
+            unsigned long long cc; double vv[4];
+            if (k < wl_s) {
+                cc = lc[64 * (k >> 2)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vv[i] = lv[64 * (k + i)];
+            } else {
+                cc = cpg[64 * (k >> 2)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vv[i] = vpg[64 * (k + i)];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = (int)((cc >> (16 * i)) & 0xffffull);
+                acc[0] = fma(vv[i], vec[c], acc[0]); acc[1] = fma(vv[i], vec[NV + c], acc[1]); acc[2] = fma(vv[i], vec[2 * NV + c], acc[2]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[j] = fma(rm[j], self[j], acc[j]);
+    };
+    // block totals of 8 NG quantities -> res24 (valid after the call for all threads); fixed order -> deterministic
+    auto block_sums = [&](const double *q24, auto ng_tag) {
+        constexpr int NG = decltype(ng_tag)::value;
+#pragma unroll
+        for (int h = 0; h < NG; ++h) {
+            double b0, b1;
+            row_sum8(q24 + 8 * h, b0, b1);
+            b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64);
+            b0 += __shfl_xor(b0, 32, 64); b1 += __shfl_xor(b1, 32, 64);
+            if (lane < 4) {
+                double *dst = red + wv * 24 + 8 * h + 4 * (lane & 1) + (lane & 2);
+                dst[0] = b0; dst[1] = b1;
+            }
+        }
+        __syncthreads();
+        if (tid < 8 * NG) {
+            double sm = 0.0;
+            for (int k = 0; k < nw; ++k) sm += red[k * 24 + tid];
+            res24[tid] = sm;
+        }
+        __syncthreads();
+    };
+    auto block_sums24 = [&](const double *q24) { block_sums(q24, std::integral_constant<int, 3>()); };
+    // this block's record: q7[0..6] -> part (parity par) and, two-level, P^T v -> cbuf (parity par)
+    auto publish_record = [&](const double *q7, const double *v, int par) {
+        double q24[24];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q24[i] = i < 7 ? q7[i] : 0.0;
+#pragma unroll
+        for (int ag = 0; ag < kOcSubK; ++ag)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) q24[8 + 3 * ag + j] = (v != nullptr && live && myagg == ag) ? v[j] : 0.0;
+#pragma unroll
+        for (int i = 8 + 3 * kOcSubK; i < 24; ++i) q24[i] = 0.0;
+        block_sums24(q24);
+        if (tid < 7) oc_store_sc1(rs_p, ((par * 8 + tid) * a.G + (int)blockIdx.x) * 8, res24[tid]);
+        else if (v != nullptr && tid >= 8 && tid < 8 + 3 * kOcSubK) {
+            const int ag = (tid - 8) / 3, j = (tid - 8) - 3 * ag;
+            oc_store_sc1(rs_c, ((par * 3 + j) * a.ncp + (int)blockIdx.x * kOcSubK + ag) * 8, res24[tid]);
+        }
+    };
+    // after the grid barrier: bc[0..nsum) = the global sums of the records of parity par
+    auto reduce_records = [&](int par, int nsum) {
+        for (int k = wv; k < nsum; k += nw) {
+            double rec[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int g = lane + 64 * i; rec[i] = g < a.G ? oc_load_sc1_f64(rs_p, ((par * 8 + k) * a.G + g) * 8) : 0.0; }
+            double sm = (rec[0] + rec[1]) + (rec[2] + rec[3]);
+            for (int g = lane + 256; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_p, ((par * 8 + k) * a.G + g) * 8);
+            sm = wave_sum(sm);
+            if (lane == 0) bc[k] = sm;
+        }
+        __syncthreads();
+    };
+    // The rows of Ac^-1 of this block's aggregates, columns tid and tid + T: constant over the solve, fetched (L2) ahead
+    // of the grid barrier so that their latency hides behind it
+    struct AinvRows { double v[2][kOcSubK]; };
+    auto ainv_prefetch = [&](AinvRows &ar) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c = tid + it * T;
+#pragma unroll
+            for (int ag = 0; ag < kOcSubK; ++ag) ar.v[it][ag] = c < a.nc ? a.ainv[(size_t)((int)blockIdx.x * kOcSubK + ag) * a.ncp + c] : 0.0;
+        }
+    };
+    // after the grid barrier: bc[0..nsum) = global sums of the records, ycur = (rows of Ac^-1 of this block's aggregates) x
+    // (published coarse vector), all of parity par.  Every global load is issued before the first use.
+    auto reduce_and_coarse = [&](int par, int nsum, const AinvRows &ar) {
+        double rec[4] = {0.0, 0.0, 0.0, 0.0}, cn[2][3];
+        if (wv < nsum) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const int g = lane + 64 * i; rec[i] = g < a.G ? oc_load_sc1_f64(rs_p, ((par * 8 + wv) * a.G + g) * 8) : 0.0; }
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int c = tid + it * T;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cn[it][j] = c < a.nc ? oc_load_sc1_f64(rs_c, ((par * 3 + j) * a.ncp + c) * 8) : 0.0;
+        }
+        if (wv < nsum) {
+            double sm = (rec[0] + rec[1]) + (rec[2] + rec[3]);
+            for (int g = lane + 256; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_p, ((par * 8 + wv) * a.G + g) * 8);
+            sm = wave_sum(sm);
+            if (lane == 0) bc[wv] = sm;
+        }
+        for (int k = wv + nw; k < nsum; k += nw) {   // blocks with fewer waves than sums
+            double sm = 0.0;
+            for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_p, ((par * 8 + k) * a.G + g) * 8);
+            sm = wave_sum(sm);
+            if (lane == 0) bc[k] = sm;
+        }
+        double q16[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) q16[i] = 0.0;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int ag = 0; ag < kOcSubK; ++ag)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) q16[3 * ag + j] = fma(ar.v[it][ag], cn[it][j], q16[3 * ag + j]);
+        block_sums(q16, std::integral_constant<int, 2>());
+        if (tid < 3 * kOcSubK) ycur[tid] = res24[tid];
+        __syncthreads();
+    };
+    // y = (P Ac^-1 P^T v) on this thread's row: one all-to-all (its own grid barrier)
+    auto coarse_apply = [&](const double *v, double *y) -> bool {
+        ++be;
+        const int par = (int)(be & 1u);
+        const double z7[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        publish_record(z7, v, par);
+        AinvRows ar;
+        ainv_prefetch(ar);
+        if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return false;
+        reduce_and_coarse(par, 0, ar);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) y[j] = live ? ycur[3 * myagg + j] : 0.0;
+        return true;
+    };
+    int iters = 0, pipe_iters = 0;
+    bool conv = false, aborted = false;
+    auto action = [&]() -> int { __syncthreads(); return __builtin_amdgcn_readfirstlane(ictl[2]); };
+    // u = D^-1 (b - A x) from the x held in registers (x goes through the published copy: the columns are local indices);
+    // leaves r . D^-1 r (and optionally b . D^-1 b) in q[0..5]
+    auto true_residual = [&](bool with_bnorm, double *q, double *ri_out) -> bool {
+        double ax[3];
+        ++ph; ++be; publish(rx);
+        if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return false;
+        halo_and_rows(rx, ax);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double bj = live ? a.b[3 * (size_t)vi + j] : 0.0;
+            const double ri = bj - ax[j];
+            if (ri_out) ri_out[j] = ri;
+            ru[j] = rd[j] * ri;
+            q[j] = ru[j] * ri;
+            q[3 + j] = with_bnorm ? bj * rd[j] * bj : 0.0;
+        }
+        __syncthreads();   // the local vector is rewritten by the next publish
+        return true;
+    };
+    do {
+        // ---- start: TRUE residual of the warm start (after the recycled projection), stop test, w = A u ---------------
+        {
+            double q[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (!a.rc_on) { if (!true_residual(true, q, nullptr)) { aborted = true; break; } }
+            else {
+                // recycled warm start (see pcg_onchip.hpp / k_rc_* in kernels.hpp): A-orthogonal projection of the initial
+                // error on the stored exact pairs (E_j, R_j = A E_j): per axis G c = g, x += E c, r0 -= R c
+                double ri[3], bj[3];
+                const int cnt = a.rc.cnt;
+                double e[kRc][3], r[kRc][3];
+#pragma unroll
+                for (int jj = 0; jj < kRc; ++jj)
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax) {
+                        const bool on = live && jj < cnt;
+                        e[jj][ax] = on ? a.rc.E[jj][3 * (size_t)row + ax] : 0.0;
+                        r[jj][ax] = on ? a.rc.R[jj][3 * (size_t)row + ax] : 0.0;
+                    }
+                if (!true_residual(true, q, ri)) { aborted = true; break; }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    bj[j] = live ? a.b[3 * (size_t)vi + j] : 0.0;
+                    if (live) { a.rc_xs[3 * (size_t)row + j] = rx[j]; a.rc_r0[3 * (size_t)row + j] = ri[j]; }
+                }
+                if (cnt > 0) {
+                    __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)a.rc_part, 0, 72 * a.G * 8, 0x00020000);
+                    // block totals of the 3 x kRcQ products, 24 at a time
+#pragma unroll
+                    for (int g24 = 0; g24 < 3; ++g24) {
+                        double q24[24];
+#pragma unroll
+                        for (int i = 0; i < 24; ++i) {
+                            const int f = 24 * g24 + i, ax = f / kRcQ, qi = f % kRcQ;     // compile-time after unrolling
+                            q24[i] = (f >= 3 * kRcQ) ? 0.0
+                                   : (qi < kRc * kRc) ? e[qi / kRc][ax < 3 ? ax : 0] * r[qi % kRc][ax < 3 ? ax : 0]
+                                   : (qi < kRc * kRc + kRc) ? e[(qi - kRc * kRc) % kRc][ax < 3 ? ax : 0] * ri[ax < 3 ? ax : 0]
+                                   : (qi == kRc * kRc + kRc) ? ri[ax < 3 ? ax : 0] * rd[ax < 3 ? ax : 0] * ri[ax < 3 ? ax : 0]
+                                   : bj[ax < 3 ? ax : 0] * rd[ax < 3 ? ax : 0] * bj[ax < 3 ? ax : 0];
+                        }
+                        block_sums24(q24);
+                        if (tid < 24) oc_store_sc1(rs_r, ((24 * g24 + tid) * a.G + (int)blockIdx.x) * 8, res24[tid]);
+                    }
+                    ++be;
+                    if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    double *sums = (double *)(smem + kOc2Scratch);   // [3 kRcQ + 2 + 3 kRc] in the (idle) local vector
+                    for (int k = wv; k < 3 * kRcQ; k += nw) {
+                        double sm = 0.0;
+                        for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_r, (k * a.G + g) * 8);
+                        sm = wave_sum(sm);
+                        if (lane == 0) sums[k] = sm;
+                    }
+                    __syncthreads();
+                    double *coefL = sums + 3 * kRcQ + 2;   // [3][kRc]
+                    if (tid < 3) {
+                        bool skip = true;    // r0 already meets the tolerance on every axis: the pairs must not perturb x
+                        for (int ax = 0; ax < 3; ++ax) skip = skip && (sums[ax * kRcQ + 20] <= a.tol2 * sums[ax * kRcQ + 21] + 1e-300);
+                        double c[kRc];
+                        rc_cholesky(sums + kRcQ * tid, cnt, skip, c);
+#pragma unroll
+                        for (int i = 0; i < kRc; ++i) coefL[tid * kRc + i] = c[i];
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int ax = 0; ax < 3; ++ax)
+#pragma unroll
+                        for (int jj = 0; jj < kRc; ++jj) {
+                            const double c = coefL[ax * kRc + jj];
+                            rx[ax] = fma(c, e[jj][ax], rx[ax]);
+                            ri[ax] = fma(-c, r[jj][ax], ri[ax]);
+                        }
+                    __syncthreads();   // the local vector is rewritten by the next publish
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    ru[j] = rd[j] * ri[j];
+                    q[j] = ru[j] * ri[j];
+                    q[3 + j] = bj[j] * rd[j] * bj[j];
+                }
+            }
+            // r explicitly; u = M^-1 r (q stays the Jacobi norm)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rr[j] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
+            if (two_level) {
+                double y[3];
+                if (!coarse_apply(rr, y)) { aborted = true; break; }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ru[j] += y[j];
+            }
+            ++ph; ++be; publish(ru);
+            publish_record(q, nullptr, (int)(be & 1u));
+        }
+        if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+        halo_and_rows(ru, rw);                       // w = A u
+        reduce_records((int)(be & 1u), 6);
+        if (tid == 0) {
+            // The three axes are independent systems with their own b . D^-1 b.  An axis whose right-hand side vanishes or is
+            // > 15 orders below the largest one is measured against the largest one.  b = 0 altogether: the solution is x = 0.
+            const double gmax = fmax(bc[3], fmax(bc[4], bc[5]));
+            bool c0 = true;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                gbl[j] = fmax(bc[3 + j], 1e-30 * gmax);
+                ctl[8 + j] = gmax > 0.0 ? 1.0 / gbl[j] : 0.0;
+                glast[j] = bc[j];
+                c0 = c0 && (bc[j] <= a.tol2 * gbl[j] + 1e-300);
+            }
+            ctl[0] = 1e300; ctl[1] = 0.0; ictl[0] = 0; ictl[1] = 0; ictl[2] = !(gmax > 0.0) ? 3 : c0 ? 1 : 0;
+        }
+        {
+            const int act0 = action();
+            if (act0 == 3) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { rx[j] = 0.0; ru[j] = 0.0; }
+                conv = true; break;
+            }
+            if (act0 == 1) {   // the epilogue expects u = D^-1 r
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ru[j] = rd[j] * rr[j];
+                conv = true; break;
+            }
+        }
+        bool fresh = true;
+        int restarts = 0;
+        if (prof) a.prof[63 * 8 + 2] = wall_clock64();
+        // TRUE residual at the current x (into u = D^-1 r).  1: it meets the tolerance, or the FP64 floor is reached (a failed
+        // verification that did not improve on the previous one by 4x); 0: it does not -- CG restarts from it; -1: aborted
+        auto verify = [&]() -> int {
+            double q[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (!true_residual(false, q, nullptr)) return -1;
+            ++be;
+            publish_record(q, nullptr, (int)(be & 1u));
+            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return -1;
+            reduce_records((int)(be & 1u), 3);
+            if (tid == 0) {
+                bool ok = true;
+                double tr = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    glast[j] = bc[j];
+                    ok = ok && (bc[j] <= a.tol2 * gbl[j] + 1e-300);
+                    tr = fmax(tr, bc[j] * ctl[8 + j]);
+                }
+                const bool done = ok || (ictl[1] >= 1 && !(tr <= 0.25 * ctl[1]));
+                ctl[1] = tr; ictl[1] += 1;
+                ctl[0] = tr; ictl[0] = 0;
+                ictl[2] = done ? 1 : 0;
+            }
+            return action() == 1 ? 1 : 0;
+        };
+        bool entry_restart = false, go_classic = false;
+        AinvRows ar;   // this block's rows of Ac^-1 stay in registers for the whole loop
+        if (two_level) ainv_prefetch(ar);
+        // ---- pipelined CG (general recurrences of Ghysels & Vanroose: r and q = M^-1 s carried explicitly) with the
+        //      two-level (or, without a coarse space, the Jacobi) preconditioner.  Used down to a relative residual of 1e-9
+        //      (kOcPipeFloor); anything irregular hands over to the classic form below ----
+        if (kOcTrig * a.tol2 >= kOcPipeFloor) {
+            if (two_level) {
+                double y[3];
+                if (!coarse_apply(rw, y)) { aborted = true; break; }
+                if (tid < 3 * kOcSubK) { yw[tid] = ycur[tid]; yz[tid] = 0.0; }
+                __syncthreads();
+            }
+            double rho_best = 1e300;
+            while (iters < a.max_iters) {
+                OC2_STAMP(0);
+                double mm[3], rn[3], q[7];
+                q[6] = 0.0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    mm[j] = live ? fma(rd[j], rw[j], two_level ? yw[3 * myagg + j] : 0.0) : 0.0;   // m = M^-1 w
+                    q[j] = rr[j] * ru[j];                                                    // gamma = r . u
+                    q[3 + j] = rw[j] * ru[j];                                                // delta = w . u
+                    q[6] = fma(rr[j] * rd[j] * rr[j], ctl[8 + j], q[6]);                     // Jacobi-norm residual (stop test)
+                }
+                ++ph; publish(mm);
+                OC2_STAMP(1);
+                if (a.nbr) {
+                    if (!oc_announce_and_wait_neighbours<false>(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; }
+                } else {   // more than 64 neighbour blocks somewhere: a grid barrier orders the exchange
+                    ++be;
+                    if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                }
+                OC2_STAMP(2);
+                halo_and_rows(mm, rn);                                                       // n = A m
+                OC2_STAMP(3);
+                ++be;
+                const int par = (int)(be & 1u);
+                publish_record(q, two_level ? rn : nullptr, par);
+                OC2_STAMP(4);
+                if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                OC2_STAMP(5);
+                if (two_level) reduce_and_coarse(par, 7, ar);                                // the sums, and ycur = Ac^-1 P^T n
+                else reduce_records(par, 7);
+                OC2_STAMP(6);
+                if (wv == 0) {
+                    const int j = lane < 3 ? lane : 0;
+                    const double g = bc[j], d = bc[3 + j], rs = bc[6];
+                    const unsigned long long m3 = 7ull;
+                    const bool finite = (__ballot(g < 1e290 && g >= 0.0 && d < 1e290) & m3) == m3 && rs < 1e290 && !(rs > 1e16 * rho_best);
+                    int act = 0;
+                    if (!finite) act = 2;
+                    else if (rs <= kOcTrig * a.tol2) act = 1;
+                    else if (lane < 3) {
+                        double alpha, beta;
+                        if (fresh) { beta = 0.0; alpha = (d > 0.0) ? g / d : 0.0; }
+                        else {
+                            const double gp = sc[j], ap = sc[3 + j];
+                            beta = (gp > 0.0) ? g / gp : 0.0;
+                            const double den = (ap != 0.0) ? d - beta * g / ap : d;
+                            alpha = (den > 0.0) ? g / den : 0.0;
+                        }
+                        sc[j] = g; sc[3 + j] = alpha; glast[j] = g;
+                        ctl[2 + j] = alpha; ctl[5 + j] = beta;
+                    }
+                    rho_best = fmin(rho_best, rs);
+                    if (lane == 0) ictl[2] = act;
+                }
+                const int act = action();
+                if (act == 2) { entry_restart = true; go_classic = true; break; }
+                if (act == 1) {
+                    const int v = verify();
+                    if (v < 0) { aborted = true; break; }
+                    if (v == 1) { conv = true; break; }
+                    go_classic = true; fresh = true;     // the true residual replaces the recursive one: restart (beta = 0)
+                    break;
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double alpha = ctl[2 + j], beta = ctl[5 + j];
+                    rz[j] = fma(beta, rz[j], rn[j]);
+                    rq[j] = fma(beta, rq[j], mm[j]);
+                    rsv[j] = fma(beta, rsv[j], rw[j]);
+                    rp[j] = fma(beta, rp[j], ru[j]);
+                    rx[j] = fma(alpha, rp[j], rx[j]);
+                    rr[j] = fma(-alpha, rsv[j], rr[j]);
+                    ru[j] = fma(-alpha, rq[j], ru[j]);
+                    rw[j] = fma(-alpha, rz[j], rw[j]);
+                }
+                if (two_level && tid < 3 * kOcSubK) {
+                    const int j = tid % 3;
+                    const double zz = fma(ctl[5 + j], yz[tid], ycur[tid]);
+                    yz[tid] = zz;
+                    yw[tid] = fma(-ctl[2 + j], zz, yw[tid]);
+                }
+                __syncthreads();   // yw is read, ctl / bc / ycur / the local vector are rewritten by the next iteration
+                ++iters; ++pipe_iters; fresh = false;
+                OC2_STAMP(7);
+                if (prof) ++prof_n;
+            }
+            if (!conv && !go_classic && !aborted) {   // iteration cap: leave u = D^-1 r behind (epilogue, recycled pair)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) ru[j] = rd[j] * rr[j];
+            }
+            if (aborted || conv || !go_classic) break;
+        } else {   // tolerances below the pipelined floor: classic form from the start; u = D^-1 r
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ru[j] = rd[j] * rr[j];
+        }
+        // ---- classic (Hestenes-Stiefel) CG with the Jacobi preconditioner, three synchronisations per iteration: gamma =
+        // r . u, then p, s = A p and delta = p . s computed directly (stable end game on ill-conditioned systems) ----
+        while (iters < a.max_iters) {
+            if (entry_restart) {
+                // Non-finite or runaway sums: back to the entry x (still in global memory) and its true residual.  A second
+                // failure gives up: the solve is reported as unconverged and hands back the entry x.
+                entry_restart = false;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) rx[j] = live ? a.x[3 * (size_t)vi + j] : 0.0;
+                double q[7];
+                if (!true_residual(false, q, nullptr)) { aborted = true; break; }
+                if (tid == 0) { ctl[0] = 1e300; ictl[0] = 0; }
+                if (++restarts > 1) break;
+                fresh = true;
+            }
+            double q[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) q[j] = (live ? ru[j] * ru[j] * fast_rcp(rd[j]) : 0.0);
+            ++be;
+            publish_record(q, nullptr, (int)(be & 1u));
+            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            reduce_records((int)(be & 1u), 3);
+            if (wv == 0) {   // lanes 0..2 = one axis each
+                const int j = lane < 3 ? lane : 0;
+                const double g = bc[j], gbj = gbl[j];
+                const double ratio = g * ctl[8 + j];
+                const unsigned long long m3 = 7ull;
+                const bool finite = (__ballot(g < 1e290 && ratio < 1e290 && !(ratio > 1e16 * ctl[0])) & m3) == m3;
+                const bool below_tol = (__ballot(g <= a.tol2 * gbj + 1e-300) & m3) == m3;
+                double rmax = fmax(ratio, __shfl(ratio, 1, 64));
+                rmax = fmax(rmax, __shfl(ratio, 2, 64));
+                int act = 0;
+                if (!finite) act = 2;
+                else if (below_tol) act = 1;
+                else {
+                    if (lane == 0 && rmax < ctl[0]) ctl[0] = rmax;
+                    if (lane < 3) {
+                        const double gp = sc[j];
+                        const double beta = (!fresh && gp > 0.0) ? g * fast_rcp(gp) : 0.0;
+                        sc[j] = g; sc[3 + j] = 0.0; glast[j] = g;
+                        ctl[5 + j] = beta;
+                    }
+                }
+                if (lane == 0) ictl[2] = act;
+            }
+            const int act = action();
+            if (act == 2) { entry_restart = true; continue; }
+            if (act == 1) {
+                const int v = verify();
+                if (v < 0) { aborted = true; break; }
+                if (v == 1) { conv = true; break; }
+                fresh = true;
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rp[j] = fma(ctl[5 + j], rp[j], ru[j]);    // p = u + beta p
+            ++ph; ++be; publish(rp);
+            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            halo_and_rows(rp, rsv);                                                // s = A p
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { q[j] = 0.0; q[3 + j] = rp[j] * rsv[j]; }
+            ++be;
+            publish_record(q, nullptr, (int)(be & 1u));
+            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            reduce_records((int)(be & 1u), 6);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double delta = bc[3 + j];
+                const double alpha = (delta > 0.0) ? glast[j] / delta : 0.0;
+                rx[j] = fma(alpha, rp[j], rx[j]);
+                ru[j] = fma(-alpha * rd[j], rsv[j], ru[j]);
+            }
+            __syncthreads();   // bc / glast are rewritten by the next iteration's reduction and decision
+            ++iters; fresh = false;
+        }
+    } while (false);
+    if (prof) a.prof[63 * 8 + 3] = wall_clock64();
+#undef OC2_STAMP
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { a.x[3 * (size_t)vi + j] = rx[j]; a.u_out[3 * (size_t)vi + j] = ru[j]; }
+        if (a.rc_on) {   // this solve's pair: e = x - x_entry, A e = r_entry - r_final (exact: u carries the true residual)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const size_t i = 3 * (size_t)row + j;
+                a.rc_Eslot[i] = rx[j] - a.rc_xs[i];
+                a.rc_Rslot[i] = a.rc_r0[i] - ru[j] * fast_rcp(rd[j]);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        CgScal o;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o.gamma[j] = glast[j]; o.alpha[j] = 0.0; o.gamma_b[j] = gbl[j]; }
+        o.alpha[0] = (double)ictl[1]; o.alpha[1] = (double)be; o.alpha[2] = ctl[1] / a.tol2;
+        o.converged = (conv && !aborted) ? 1 : 0; o.iters = iters; o.seq = a.seq; o.pad_ = pipe_iters;
+        a.scal[0] = o;
+        atomicAdd(a.counters, iters);
+        if (o.converged) {
+            atomicAdd(a.counters + 4, 1);
+            atomicMax(a.counters + 3, iters);
+            a.counters[8 + (a.seq & 63)] = iters;
+        }
+        if (prof) a.prof[63 * 8 + 4] = wall_clock64();
+    }
+}
+
+} // namespace admm_k

@@ -277,7 +277,7 @@ class Solver:
         check(lib().admm_host_assemble_matrix(C.byref(d), iptr(rp), iptr(ci), dptr(va), C.byref(nnz)))
         return rp, ci, va
 
-    def host_oc_plan(self, n_blocks, slices_per_block, lds_cols=181, settings=None, coarse=True):
+    def host_oc_plan(self, n_blocks, slices_per_block, lds_bytes=159744, settings=None, coarse=True):
         """The plan the library makes for the on-chip PCG of this scene (admm_host_oc_plan, no GPU): dict(row_vertex,
         row_aggregate, coarse_inv, stats)."""
         d = self.make_desc(settings if settings is not None else self._settings)
@@ -286,8 +286,8 @@ class Solver:
         nc = 4 * n_blocks
         ci = np.zeros((nc, nc)) if coarse else None
         st = (C.c_int64 * 8)()
-        check(lib().admm_host_oc_plan(C.byref(d), n_blocks, slices_per_block, lds_cols, iptr(rv), iptr(ra), dptr(ci) if coarse else None, st))
-        keys = ("nnz", "stored", "on_chip", "block_local", "max_neighbour_blocks", "coarse_unknowns", "rows", "lds_cols")
+        check(lib().admm_host_oc_plan(C.byref(d), n_blocks, slices_per_block, lds_bytes, iptr(rv), iptr(ra), dptr(ci) if coarse else None, st))
+        keys = ("nnz", "stored", "on_chip", "block_local", "max_neighbour_blocks", "coarse_unknowns", "max_halo", "lds_cols")
         return dict(row_vertex=rv, row_aggregate=ra, coarse_inv=ci, stats=dict(zip(keys, list(st))))
 
     def initialize(self, settings=None):

@@ -252,9 +252,9 @@ void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners,
  * M^-1 = D^-1 + P (P^T A P)^-1 P^T.  row_vertex [64 * n_blocks * slices_per_block]: vertex of every internal row (-1 =
  * unused slot); row_aggregate (same length): coarse unknown of the row (block * 4 + aggregate); coarse_inv [nc * nc], nc =
  * 4 * n_blocks: (P^T A P)^-1, row-major (NULL to skip); stats [8]: off-diagonal non-zeros, stored SELL entries, entries
- * held in LDS, block-local non-zeros, most neighbour blocks of a block, coarse unknowns (0 = two-level off), internal
- * rows, LDS columns used.  lds_cols = LDS budget of a block in columns of 64 twelve-byte entries. */
-int admm_host_oc_plan(const admm_hip_desc *desc, int32_t n_blocks, int32_t slices_per_block, int32_t lds_cols,
+ * held in LDS, block-local non-zeros, most neighbour blocks of a block (-1: more than 64), coarse unknowns (0 = two-level
+ * off), largest halo list, LDS slab columns used.  lds_bytes = LDS a block may spend on its local vector and matrix slab. */
+int admm_host_oc_plan(const admm_hip_desc *desc, int32_t n_blocks, int32_t slices_per_block, int32_t lds_bytes,
                       int32_t *row_vertex, int32_t *row_aggregate, double *coarse_inv, int64_t *stats);
 
 #ifdef __cplusplus

@@ -518,27 +518,64 @@ def test_onchip_pcg_ill_conditioned_sparse_rhs(tol):
 
 
 def test_onchip_pcg_preconditioner_modes(monkeypatch):
-    """The three preconditioners of the on-chip kernel give the same solution: plain Jacobi (ADMM_HIP_OC_BSSOR=0), the
-    block-local symmetric Gauss-Seidel (default on 2-colourable meshes: ~1.6x fewer iterations, no extra exchange) and
-    the Chebyshev polynomial (ADMM_HIP_OC_POLY=3, default off: fewer iterations but slower)."""
+    """Every preconditioner of the two on-chip kernels gives the same solution.  General-mesh kernel (pcg_onchip2.hpp, the
+    default): two-level (aggregate coarse space) and plain Jacobi (ADMM_HIP_OC_COARSE=0) on the plan's internal row order.
+    Round-1 kernel (pcg_onchip.hpp, ADMM_HIP_OC_PLAN=0, rows in the caller's order): Jacobi (ADMM_HIP_OC_BSSOR=0), the
+    block-local symmetric Gauss-Seidel sweep of 2-colourable meshes and the Chebyshev polynomial (ADMM_HIP_OC_POLY=3)."""
     sc = scenes.cube_scene(26, KINDS["neohookean"])
     o = sc.make_oracle()
     b = o.A @ np.random.default_rng(9).standard_normal(o.dof)
     xo = o.solve_ldlt(b)
     its = {}
-    for name, env in (("jacobi", {"ADMM_HIP_OC_BSSOR": "0"}), ("bssor", {}), ("cheb3", {"ADMM_HIP_OC_BSSOR": "0", "ADMM_HIP_OC_POLY": "3"})):
-        for k in ("ADMM_HIP_OC_BSSOR", "ADMM_HIP_OC_POLY"):
+    keys = ("ADMM_HIP_OC_BSSOR", "ADMM_HIP_OC_POLY", "ADMM_HIP_OC_PLAN", "ADMM_HIP_OC_COARSE")
+    for name, env in (("two_level", {}), ("plan_jacobi", {"ADMM_HIP_OC_COARSE": "0"}),
+                      ("jacobi", {"ADMM_HIP_OC_PLAN": "0", "ADMM_HIP_OC_BSSOR": "0"}), ("bssor", {"ADMM_HIP_OC_PLAN": "0"}),
+                      ("cheb3", {"ADMM_HIP_OC_PLAN": "0", "ADMM_HIP_OC_BSSOR": "0", "ADMM_HIP_OC_POLY": "3"})):
+        for k in keys:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=2000)     # (both extra modes are off below 1e-9, like the pipelined form)
+        s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=2000)     # (the extra modes are off below 1e-9, like the pipelined form)
         x, its[name] = s.global_solve(b, np.zeros(o.dof))
         assert np.linalg.norm(x - xo) <= 1e-6 * np.linalg.norm(xo), name
         x2, it2 = s.global_solve(b, np.zeros(o.dof))
         assert it2 == its[name] and np.array_equal(x, x2), name          # deterministic
         s.close()
+    for k in keys:
+        monkeypatch.delenv(k, raising=False)
     assert 0 < its["cheb3"] < 0.5 * its["jacobi"], its
     assert 0 < its["bssor"] < 0.75 * its["jacobi"], its
+    assert abs(its["plan_jacobi"] - its["jacobi"]) <= 0.1 * its["jacobi"], its     # same method, other row order
+    assert 0 < its["two_level"] < 0.6 * its["jacobi"], its
+
+
+def test_unstructured_mesh_global_solve_vs_exact():
+    """The general-mesh path on an UNSTRUCTURED body (52 k tets, valences 3..26, 8+ colours, no exact zeros in Ahat): the
+    on-chip two-level PCG against the oracle's exact (sparse direct) solve of the same system, cold and warm start."""
+    sc = scenes.blob_scene(44, admm_iters=5, linsolver=0)
+    assert sum(len(t[1]) for t in sc.tets) > 50000
+    o = sc.make_oracle(big=True)
+    s = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=3000)
+    rng = np.random.default_rng(2)
+    xt = rng.standard_normal(o.dof)
+    b = o.A @ xt
+    xe = o.solve_ldlt(b)
+    for start in (np.zeros(o.dof), xe + 1e-3 * rng.standard_normal(o.dof)):
+        xg, it = s.global_solve(b, start)
+        assert 0 < it < 3000
+        assert np.abs(xg - xe).max() <= 1e-8 * np.abs(xe).max(), np.abs(xg - xe).max()
+    s.close()
+
+
+def test_unstructured_mesh_whole_step_vs_oracle():
+    """Whole frames on the unstructured body (NH + StVK) against the oracle: BASELINE's bar is 1e-5 of the bounding box."""
+    sc = scenes.blob_scene(24, admm_iters=10, linsolver=0)
+    s = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=3000)
+    o = sc.make_oracle(mode=1)
+    for _ in range(3):
+        s.step(); o.step()
+    assert s.runtime_data().unconverged_solves == 0
+    assert scenes.rel_err(s.m_x, o.x) < 2e-7, scenes.rel_err(s.m_x, o.x)
 
 
 def test_onchip_pcg_big_system_residual(big):

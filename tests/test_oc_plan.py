@@ -34,14 +34,15 @@ def _check_plan(sc, G, spb):
     live = rv >= 0
     # every vertex has exactly one row; blocks and aggregates are what the slot says
     assert np.array_equal(np.sort(rv[live]), np.arange(nv))
-    assert st["rows"] == 64 * G * spb and st["coarse_unknowns"] == 4 * G
+    assert len(rv) == 64 * G * spb and st["coarse_unknowns"] == 4 * G
     assert np.array_equal(ra[live] // 4, np.nonzero(live)[0] // (64 * spb))
     assert (ra[~live] == -1).all()
     agg = np.empty(nv, np.int64); agg[rv[live]] = ra[live]
-    # rows of a wavefront belong to one aggregate
-    per_wave = ra.reshape(-1, 64)
-    for wv in per_wave:
-        assert len(set(wv[wv >= 0])) <= 1
+    # the rows of a block are sorted by length (longest first): similar lengths inside a wavefront
+    deg = np.diff((A != 0).astype(int).tocsr().indptr) - 1
+    for blk in rv.reshape(G, -1):
+        d = deg[blk[blk >= 0]]
+        assert (np.diff(d) <= 0).all()
     # the coarse inverse is the inverse of P^T A P (empty aggregates: unit diagonal)
     nc = 4 * G
     P = sp.csr_matrix((np.ones(nv), (np.arange(nv), agg)), shape=(nv, nc))
@@ -65,10 +66,10 @@ def test_plan_unstructured_body():
     assert it_2 < 0.75 * it_j, (it_j, it_2)
     # compact blocks: most of the couplings stay inside a block, few neighbour blocks
     assert st["block_local"] > 0.6 * st["nnz"] and 0 < st["max_neighbour_blocks"] <= 15
-    # rows sorted by length inside the aggregates (three wavefronts each at the real block size): bounded padding
+    # rows sorted by length at the real block size (12 wavefronts): little padding, (nearly) everything in LDS
     sc = scenes.blob_scene(44, admm_iters=5, linsolver=0)
     st = sc.make_solver(init=False).host_oc_plan(16, 12, settings=sc.product_settings, coarse=False)["stats"]
-    assert st["stored"] < 1.7 * st["nnz"] and st["on_chip"] >= 0.75 * st["stored"], st
+    assert st["stored"] < 1.35 * st["nnz"] and st["on_chip"] >= 0.9 * st["stored"], st
 
 
 def test_plan_structured_cube_and_cloth():
