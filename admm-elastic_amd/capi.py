@@ -68,6 +68,7 @@ SYMBOLS = [
     ("admm_hip_local_step", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     ("admm_hip_global_solve", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int_p]),
     ("admm_hip_num_rows", C.c_int, [C.c_void_p]),
+    ("admm_hip_probe_sync", C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
     ("admm_hip_get_matrix", C.c_int, [C.c_void_p, c_int_p, c_int_p, c_double_p, c_int_p]),
     ("admm_hip_get_colors", C.c_int, [C.c_void_p, c_int_p, c_int_p]),
     ("admm_hip_comm_unique_id", C.c_int, [C.c_char_p]),

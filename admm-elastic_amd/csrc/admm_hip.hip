@@ -515,6 +515,8 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg2<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_sync_probe<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (T > 768 && (e = hipFuncSetAttribute((const void *)k_sync_probe<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     int per_cu = 0;
     if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<1024>, T, lds);
@@ -1674,6 +1676,42 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     HIP_TRY(hipStreamSynchronize(st));
     if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)"); }
     if (iters) *iters = (c->linsolver == 1) ? h[2] : (c->linsolver == 2 ? c->uz_iters_step : h[0]);
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_probe_sync(admm_hip_ctx *c, int32_t n, double *us_all_to_all, double *us_exchange, int64_t *plan_stats) {
+    if (!c || n < 1) return fail(ADMM_HIP_ERR_ARG, "probe_sync: bad input");
+    if (us_all_to_all) *us_all_to_all = 0.0;
+    if (us_exchange) *us_exchange = 0.0;
+    if (plan_stats) for (int i = 0; i < 6; ++i) plan_stats[i] = c->oc_stat[i];
+    if (!c->oc_enabled || !c->oc_plan || !c->oc_nbr.p) return ADMM_HIP_OK;    // no on-chip plan: nothing to probe
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    double out[2] = {0.0, 0.0};
+    for (int mode = 0; mode < 2; ++mode) {
+        Oc2Args a{};
+        a.n_rows = c->oc_rows; a.halo_ptr = c->oc_haloptr.p; a.halo_src = c->oc_halosrc.p; a.vec_len = c->oc_veclen;
+        a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.bar = c->oc_bar.p; a.nbr = c->oc_nbr.p; a.flags = c->oc_flags.p;
+        a.sig = c->d_sig; a.spb = c->oc_spb; a.G = c->oc_G;
+        for (int rep = 0; rep < 2; ++rep) {     // first launch warms up
+            a.seq = ++c->solve_seq;
+            HIP_TRY(hipEventRecord(e0, st));
+            if (c->oc_T <= 768) hipLaunchKernelGGL((k_sync_probe<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a, (int)n, mode, (double *)nullptr);
+            else hipLaunchKernelGGL((k_sync_probe<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a, (int)n, mode, (double *)nullptr);
+            HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(hipEventSynchronize(e1));
+        }
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        out[mode] = 1e3 * (double)ms / (double)n;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "probe_sync: a grid barrier timed out"); }
+    if (us_all_to_all) *us_all_to_all = out[0];
+    if (us_exchange) *us_exchange = out[1];
     return ADMM_HIP_OK;
 }
 

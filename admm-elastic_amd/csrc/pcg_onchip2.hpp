@@ -675,4 +675,63 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
     }
 }
 
+// Latency floor of the two synchronisations an iteration of k_pcg2 is made of, measured on the same grid with the same
+// primitives and payloads but no arithmetic (admm_hip_probe_sync, bench.py "roofline_global"):
+//   mode 0: n x { 19 block sums -> record -> grid barrier -> read all records }          (the all-to-all)
+//   mode 1: n x { publish 32 B per row -> neighbour flags -> halo fetch into LDS }        (the vector exchange)
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void k_sync_probe(Oc2Args a, int n, int mode, double *sink) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *ok_lds = (int *)(smem + 3632);
+    double *bc = (double *)(smem + 3328);
+    const int T = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = T >> 6;
+    const int NV = a.vec_len;
+    LdsD *vec = (LdsD *)(smem + kOc2Scratch);
+    const int s = (int)blockIdx.x * a.spb + wv, row = s * 64 + lane;
+    const int hp0 = a.halo_ptr[blockIdx.x], nh = a.halo_ptr[blockIdx.x + 1] - hp0;
+    const int ub = a.n_rows * 32;
+    __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)a.ubuf, 0, 2 * ub, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)a.part, 0, 2 * 8 * a.G * 8, 0x00020000);
+    unsigned *const bar = a.bar + 32 * 16 * (a.seq & 1);
+    if (blockIdx.x == 0 && tid < 9) a.bar[32 * 16 * ((a.seq & 1) ^ 1) + 16 * (tid < 8 ? tid : 17)] = 0u;
+    double acc = (double)row;
+    unsigned ph = 0, be = 0;
+    for (int it = 0; it < n; ++it) {
+        if (mode == 0) {
+            ++be;
+            const int par = (int)(be & 1u);
+            if (tid < 7) oc_store_sc1(rs_p, ((par * 8 + tid) * a.G + (int)blockIdx.x) * 8, acc);
+            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) break;
+            if (wv < 7) {
+                double sm = 0.0;
+                for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_p, ((par * 8 + wv) * a.G + g) * 8);
+                sm = wave_sum(sm);
+                if (lane == 0) bc[wv] = sm;
+            }
+            __syncthreads();
+            acc = acc * 0.5 + bc[0] * 1e-300;
+        } else {
+            ++ph;
+            LdsD *o = vec + wv * 64;
+            o[lane] = acc; o[NV + lane] = acc; o[2 * NV + lane] = acc;
+            const int bo = (int)(ph & 1u) * ub + s * 2048 + lane * 16;
+            oc_store_sc1(rs_u, bo, o[lane >> 1], o[NV + (lane >> 1)]);
+            oc_store_sc1(rs_u, bo + 1024, o[32 + (lane >> 1)], o[NV + 32 + (lane >> 1)]);
+            if (!oc_announce_and_wait_neighbours<false>(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) break;
+            for (int h = tid; h < nh; h += T) {
+                const int src = a.halo_src[hp0 + h];
+                union { double d[2]; v4u v; } g0, g1;
+                g0.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)(ph & 1u) * ub + src * 32, 0, 16);
+                g1.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, (int)(ph & 1u) * ub + src * 32 + 16, 0, 16);
+                vec[T + h] = g0.d[0]; vec[NV + T + h] = g0.d[1]; vec[2 * NV + T + h] = g1.d[0];
+            }
+            __syncthreads();
+            acc = acc * 0.5 + vec[T + (tid % (nh > 0 ? nh : 1))] * 1e-300;
+            __syncthreads();
+        }
+    }
+    if (sink && acc == 12345.678) sink[0] = acc;   // keeps the loop alive
+    (void)nw;
+}
+
 } // namespace admm_k

@@ -358,6 +358,14 @@ class Solver:
         dist.broadcast_object_list(obj, src=0)
         check(lib().admm_hip_comm_init(self._ctx, obj[0], s.rank, s.world_size))
 
+    def probe_sync(self, n=200):
+        """admm_hip_probe_sync: (us per all-to-all, us per vector exchange, plan statistics dict) of the on-chip PCG."""
+        self._need_ctx()
+        a = C.c_double(0.0); b = C.c_double(0.0); st = (C.c_int64 * 6)()
+        check(lib().admm_hip_probe_sync(self._ctx, n, C.byref(a), C.byref(b), st))
+        keys = ("nnz", "stored", "on_chip", "block_local", "max_neighbour_blocks", "coarse_unknowns")
+        return a.value, b.value, dict(zip(keys, list(st)))
+
     def runtime_data(self):
         return self._runtime
 

@@ -3,12 +3,14 @@
 A "step" = one Solver::step() (one frame) = `admm_iters` ADMM iterations {local step, RHS gather,
 global solve} on a device-resident state (no host<->device traffic inside the timed region).
 
-  python bench.py --gpus 1 --steps K --warmup W [--workload cube1m_mix|cube1m_nh|cube100k_gs]
+  python bench.py --gpus 1 --steps K --warmup W [--workload blob1m_mix|cube1m_mix|cube1m_nh|cube100k_gs|...]
 
 Workloads (BASELINE.json `configs`):
-  cube1m_mix   configs[2]: n=55 Kuhn cube (998 250 tets), StVK / Neo-Hookean by z-slab, soft rubber,
-               x=0 face pinned, g=-9.8, dt=1/24, 20 ADMM iters/step, global solve = GPU PCG (the
-               "UzawaCG" config has no active constraints, so its solve IS the prefactored solve)
+  blob1m_mix   configs[2] as named ("1M-tet synthetic bunny/dragon, StVK + Neo-Hookean mix"): the DEFAULT.  Unstructured
+               body (meshes.unstructured_blob, 1 012 608 tets / 183 844 verts, valences 3..26), soft rubber, feet pinned,
+               g=-9.8, dt=1/24, 20 ADMM iters/step, global solve = GPU PCG (the "UzawaCG" config has no active
+               constraints, so its solve IS the prefactored solve)
+  cube1m_mix   the same config on the n=55 Kuhn cube (998 250 tets; round 1's headline mesh), x=0 face pinned
   cube1m_nh    same mesh, all Neo-Hookean (the north-star's target mesh)
   cube100k_gs  configs[1]: n=26 (105 456 tets), Neo-Hookean, multi-colour GS global step
 
@@ -81,7 +83,7 @@ def cpu_baseline(w, budget_s=12.0):
     from oracle import oracle as orc
     import scenes  # noqa: F401
     cores = os.cpu_count() or 1
-    n_s = min(w["n"], 20 if w["kinds"] != "cloth" else 100)  # the sample: 48 000 tets / 20 000 tris
+    n_s = min(w["n"], {"cloth": 100, "blob": 44}.get(w["kinds"], 20))  # the sample: 48 000 tets (cube) / 52 000 (body) / 20 000 tris
     sc, nt, nv = build_scene(w, n_override=n_s)
     sc.settings["admm_iters"] = 5
     colors = None
@@ -113,13 +115,14 @@ def cpu_baseline(w, budget_s=12.0):
         o.step(); iters += o.admm_iters
     dt = time.perf_counter() - t0
     its = iters / dt
-    return dict(value=its * nt / 1e6, unit="M tet-ADMM-iterations/s", admm_iters_per_s_at_sample=its, cores=threads,
-                kind="port", sample="%d-tet Kuhn cube (n=%d), same materials/solver family, %d ADMM iterations in %.1f s; "
-                "oracle = OpenMP local step (L-BFGS, reference stop rule) + %s; host has %d hardware threads" %
-                (nt, n_s, iters, dt, "30 multi-colour SOR sweeps" if w["linsolver"] == 1 else "SuperLU direct solve (prefactored)", cores))
+    shape = "unstructured body" if w["kinds"] == "blob" else "cloth" if w["kinds"] == "cloth" else "Kuhn cube"
+    solver = "30 multi-colour SOR sweeps" if w["linsolver"] == 1 else "SuperLU direct solve (prefactored)"
+    return dict(value=its * nt / 1e6, unit="M element-ADMM-iterations/s", admm_iters_per_s_at_sample=its, cores=threads, kind="port",
+                sample="%d-element %s (n=%d), same materials/solver family, %d ADMM iterations in %.1f s; oracle = OpenMP local step "
+                       "(L-BFGS, reference stop rule) + %s; host has %d hardware threads" % (nt, shape, n_s, iters, dt, solver, cores))
 
 
-def pmc_traffic(workload):
+def pmc_traffic(workload, key="local_step_bytes_per_launch"):
     """HBM/fabric bytes per launch of the local-step kernels from the committed rocprofv3 PMC passes
     (profiles/*pmc*.json: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; FETCH_SIZE doubled per
     MI355X_MICROARCH.md, calibrated on k_predict/k_finish).  None when no profile of this workload exists."""
@@ -130,9 +133,9 @@ def pmc_traffic(workload):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload") != workload or "local_step_bytes_per_launch" not in d:
+        if d.get("workload") != workload or key not in d:
             continue
-        best = d["local_step_bytes_per_launch"]
+        best = d[key]
     return best
 
 
@@ -141,7 +144,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cube1m_mix", choices=list(WORKLOADS))
+    ap.add_argument("--workload", default="blob1m_mix", choices=list(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override cells per edge (testing only)")
     ap.add_argument("--pcg-tol", type=float, default=1e-8)
     ap.add_argument("--pcg-max-iters", type=int, default=600)
@@ -230,7 +233,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload + (" (n=%d override)" % args.n if args.n else ""), "elements": nt, "verts": nv,
                    "admm_iters_per_step": iters, "global_solver": "multicolor-GS(30 sweeps)" if w["linsolver"] == 1 else
-                   "PCG (one persistent on-chip launch per solve, pipelined CG, block-local symmetric Gauss-Seidel preconditioner) tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters),
+                   "PCG (one persistent on-chip launch per solve: two-level preconditioned pipelined CG, matrix and vectors in LDS) tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters),
                    "parallelism": "element-block x%d" % world if world > 1 else "single-gpu"},
         "ms_per_frame": ms_per_step,
         "split_ms_per_admm_iter": {"local": local_ms / (iters * args.steps), "rhs": rhs_ms / (iters * args.steps),
@@ -242,6 +245,28 @@ def main():
         "finite": finite, "pcie_inclusive_admm_it_per_s": pcie_value,
     }
     if rank == 0:
+        if w["kinds"] != "cloth":
+            from admm_elastic_amd import meshes as _m
+            tets_all = np.concatenate([t[1] + t[4] for t in sc.tets])
+            out["config"]["vertex_valence"] = _m.valence_stats(nv, tets_all)   # edges per vertex (row of Ahat = valence + 1)
+        if not args.no_roofline and w["linsolver"] != 1 and world == 1:
+            # The time-dominant kernel: the whole PCG solve is ONE persistent launch whose matrix and vectors stay in LDS /
+            # registers, so it has no HBM roofline; an iteration is two dependent synchronisations -- the vector exchange
+            # between neighbour blocks and the all-to-all of the block records behind one grid barrier.  Their latency floor
+            # is measured live on the same grid with the kernel's own primitives (admm_hip_probe_sync).
+            a2a, xch, pst = s.probe_sync(200)
+            n_solves = iters * args.steps
+            it_per_solve = inner / max(n_solves, 1)
+            solve_us = 1e3 * (global_ms - rhs_ms) / max(n_solves, 1)
+            us_it = solve_us / max(it_per_solve, 1e-9)
+            out["roofline_global"] = {
+                "kernel": "k_pcg2 (whole two-level PCG solve, one persistent launch per ADMM iteration)",
+                "bound": "synchronisation latency (grid barrier + neighbour exchange); data on chip",
+                "iterations_per_solve": it_per_solve, "solve_us": solve_us, "us_per_iteration_incl_solve_overhead": us_it,
+                "floor_us_per_iteration": a2a + xch, "floor_all_to_all_us": a2a, "floor_exchange_us": xch,
+                "frac": (a2a + xch) / us_it if us_it > 0 else None,
+                "plan": pst, "pmc_bytes_per_iteration": pmc_traffic(args.workload, "pcg_bytes_per_iteration"),
+            }
         if not args.no_roofline:
             # dominant single kernel = the per-tet prox kernel (local step).  ALGORITHMIC bytes per tet per
             # ADMM iteration: 16 idx + 72 Binv + 72 u read + 72 u write + 72 z write + 24 nv/nt.

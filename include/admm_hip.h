@@ -201,6 +201,14 @@ int admm_hip_local_step(admm_hip_ctx *ctx, const double *x, double *u_inout, dou
  * through *iters.  Uses the context's linsolver, pins and obstacles. */
 int admm_hip_global_solve(admm_hip_ctx *ctx, const double *b, double *x_inout, int32_t *iters);
 
+/* Diagnostics of the on-chip PCG (linsolver 0 / 2; no reference counterpart): the latency floor of the two
+ * synchronisations one CG iteration consists of, measured on this context's grid with the kernel's own primitives and
+ * payloads but no arithmetic, as microseconds per repetition over n repetitions: the all-to-all (block record -> grid barrier
+ * -> every block reads every record) and the vector exchange (publish 32 B per row -> neighbour flags -> halo fetch).  0 when
+ * the context has no on-chip plan.  plan_stats [6] (may be NULL): off-diagonal non-zeros, stored SELL entries, entries held in
+ * LDS, block-local non-zeros, most neighbour blocks of a block, coarse unknowns of the two-level preconditioner. */
+int admm_hip_probe_sync(admm_hip_ctx *ctx, int32_t n, double *us_all_to_all, double *us_exchange, int64_t *plan_stats);
+
 /* Sizes: R = rows of D (9*n_tets + 6*n_tris + 6*n_pin_terms). */
 int admm_hip_num_rows(const admm_hip_ctx *ctx);
 
