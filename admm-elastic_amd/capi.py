@@ -40,6 +40,7 @@ class Desc(C.Structure):
         ("n_obstacles", C.c_int32), ("obstacle_kind", c_int_p), ("obstacle_params", c_double_p),
         ("gs_colors", c_int_p),
         ("rank", C.c_int32), ("world_size", C.c_int32),
+        ("tet_kappa", c_double_p),
     ]
 
 

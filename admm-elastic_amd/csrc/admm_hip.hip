@@ -131,14 +131,14 @@ struct admm_hip_ctx {
     DevBuf<double> x, v, m, Mxbar, curr, b, dinv;
     // tets (sorted by constitutive model; perm[new] = caller's index)
     int nt = 0, ldt = 0;
-    int kind_begin[5] = {0, 0, 0, 0, 0}; // [linear | NH (+ NH spline) | StVK (+ StVK spline) | co-rotated spline | end]
+    int kind_begin[6] = {0, 0, 0, 0, 0, 0}; // [linear | NH (+ NH spline) | StVK (+ StVK spline) | co-rotated spline | splines with kappa != 0 | end]
     std::vector<int> tet_perm;
     std::vector<int> tri_perm;        // device slot -> caller's triangle index (sorted like the tets: lowest vertex first)
     DevBuf<int4> t_idx;
     DevBuf<double> t_Binv, t_u, t_z, t_sc, t_cf;
     DevBuf<int> t_mat;
     DevBuf<Mat> mats;
-    SellDev t_inc;
+    SellDev t_inc; DevBuf<int> g_order;   // incidence lists, and the vertex every row of them gathers for
     // tris
     int ntri = 0, ldr = 0;
     DevBuf<int4> r_idx;
@@ -185,6 +185,12 @@ struct admm_hip_ctx {
     SellDev oc_A; DevBuf<int> oc_orig, oc_ldsoff, oc_wls, oc_haloptr, oc_halosrc; DevBuf<unsigned short> oc_col16;
     DevBuf<double> oc_mdiag, oc_ainv, oc_cbuf;
     int64_t oc_stat[6] = {0, 0, 0, 0, 0, 0};   // nnz, stored, on chip, block-local, max neighbour blocks, coarse unknowns
+    // Recovery from a grid barrier that cannot complete (the persistent PCG kernel needs all its blocks resident at once:
+    // another persistent kernel, a second context or CU masking can break that).  The state at the last point known to be
+    // good is kept, with the steps issued since; a timed-out barrier (detected at the next synchronisation) switches the
+    // context to the launch-per-iteration PCG for good, restores that state and replays the steps.
+    DevBuf<double> bk_x, bk_v; std::vector<std::pair<int, double> > pending; bool oc_gave_up = false;
+    int test_abort_seq = 0;   // tests only (ADMM_HIP_TEST_ABORT_SOLVE=k): the k-th on-chip solve of the context finds its barrier aborted
     int n3i = 0;   // length of the solver-internal scratch vectors (recycled pairs): max(n3, 3 * oc_rows)
     int solve_seq = 0;
     int marks_expected = 0;       // chunks closed so far (host count)
@@ -232,7 +238,7 @@ struct admm_hip_ctx {
         if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
         x.release(); v.release(); m.release(); Mxbar.release(); curr.release(); b.release(); dinv.release();
         t_idx.release(); t_Binv.release(); t_u.release(); t_z.release(); t_sc.release(); t_cf.release();
-        t_mat.release(); mats.release(); t_inc.release();
+        t_mat.release(); mats.release(); t_inc.release(); g_order.release();
         r_idx.release(); r_rest.release(); r_u.release(); r_z.release(); r_sc.release(); r_cf.release();
         r_lmin.release(); r_lmax.release(); r_inc.release();
         vert_pin.release(); pin_active.release(); pin_xyz.release(); pin_u.release(); pin_z.release();
@@ -242,6 +248,7 @@ struct admm_hip_ctx {
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release();
         oc_A.release(); oc_orig.release(); oc_ldsoff.release(); oc_wls.release(); oc_haloptr.release(); oc_halosrc.release(); oc_col16.release();
         oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release();
+        bk_x.release(); bk_v.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
@@ -260,6 +267,10 @@ struct admm_hip_ctx {
     }
 };
 
+static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_stats *stats);
+static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last);
+static int settle(admm_hip_ctx *c);
+
 namespace {
 
 inline int blocks_for(int n) { return (n + 255) / 256; }
@@ -277,8 +288,12 @@ void launch_local(admm_hip_ctx *c) {
             if (c->timing && c->lk_launch < c->lk_cap) { a.ts = c->lk_ts.p + (size_t)c->lk_launch * 2 * c->lk_tsn; a.ts_n = c->lk_tsn; c->lk_launch += 1; }
             else a.ts = nullptr;
         };
-        const int b4 = c->kind_begin[4];
+        const int b4 = c->kind_begin[4], b5 = c->kind_begin[5];
         const int kinds = (b1 > b0) + (b2 > b1) + (b3 > b2);
+        if (b5 > b4) {    // SplineTet splines with a compression term: their own launch
+            stamp();
+            hipLaunchKernelGGL((k_local_tets<4, WRITE_Z>), dim3(blocks_for(b5 - b4)), dim3(256), 0, st, b4, b5, a);
+        }
         if (b4 > b3) stamp();
         if (b4 > b3)      // co-rotated spline tets: their own launch (no BASELINE config mixes them in)
             hipLaunchKernelGGL((k_local_tets<3, WRITE_Z>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, b3, b4, a);
@@ -309,6 +324,7 @@ void launch_gather(admm_hip_ctx *c) {
         a.pin_u = c->pin_u.p; a.pin_z = c->pin_z.p; a.pin_sc = c->dt * c->dt * c->pin_weight * c->pin_weight;
     }
     a.x = c->curr.p; a.Mxbar = c->Mxbar.p; a.b = c->b.p; a.add_mxbar = (c->rank == 0) ? 1 : 0;
+    a.order = c->g_order.p;
     const int grid = std::max(1, (a.n_slices + 3) / 4);
     hipLaunchKernelGGL(k_gather_rhs, dim3(grid), dim3(256), 0, c->stream, a);
 }
@@ -388,6 +404,8 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
     a.prof = c->oc_prof.p; a.prof_block = c->oc_prof_block;
     a.spb = c->oc_spb; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
+    if (c->test_abort_seq > 0 && a.seq == c->test_abort_seq)   // test hook: raise the abort word of this solve's barrier set
+        if (hipMemsetAsync(c->oc_bar.p + 32 * 16 * (a.seq & 1) + 16 * 17, 1, sizeof(unsigned), st) != hipSuccess) return -1;
     a.tol2 = c->pcg_tol * c->pcg_tol;
     a.rc_on = rc.on ? 1 : 0; a.rc = rc.B; a.rc_xs = c->rc_xs.p; a.rc_r0 = c->rc_r0.p; a.rc_Eslot = rc.Eslot; a.rc_Rslot = rc.Rslot;
     a.rc_part = c->oc_rc_part.p;
@@ -585,6 +603,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
         }
     }
     c->oc_enabled = true;
+    { const char *ta = getenv("ADMM_HIP_TEST_ABORT_SOLVE"); c->test_abort_seq = ta ? atoi(ta) : 0; }
     return hipSuccess;
 }
 
@@ -1034,11 +1053,22 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         admm_host::partition(d->n_tris, c->world, c->rank, &rb, &re);
     }
     c->nt_total = d->n_tets; c->ntri_total = d->n_tris; c->tri_begin = rb;
+    // rows of the vertex -> (element, corner) incidence lists (k_gather_rhs): by list length inside 512-vertex windows
+    std::vector<int32_t> g_order;
+    {
+        // (this rank's elements only: the lists are built from them)
+        const char *gw = getenv("ADMM_HIP_GATHER_SORT");
+        g_order = admm_host::incidence_row_order(nv, te - tb, d->tet_idx + 4 * (size_t)tb, re - rb, d->tri_idx + 3 * (size_t)rb, gw ? atoi(gw) : 0);
+        HIP_TRY(c->g_order.upload(std::vector<int>(g_order.begin(), g_order.end())));
+    }
     // ---- tets: sort by constitutive model (wave-uniform code paths), build the material table ----
     c->nt = te - tb; c->ldt = c->nt + 1;
     if (c->nt > 0) {
         const int nt = c->nt, ld = c->ldt;
-        auto grp = [&](int k) {   // xu::NeoHookean / xu::StVK splines (kappa = 0) ARE the NH / StVK models
+        auto kap = [&](int t) { return (d->tet_kappa && d->tet_kind[t] >= ADMM_TET_SPLINE_NH) ? d->tet_kappa[t] : 0.0; };
+        auto grp_t = [&](int t) {   // xu::NeoHookean / xu::StVK splines with kappa = 0 ARE the NH / StVK models
+            const int k = d->tet_kind[t];
+            if (kap(t) != 0.0) return 4;
             return k == ADMM_TET_LINEAR ? 0 : (k == ADMM_TET_STVK || k == ADMM_TET_SPLINE_STVK) ? 2 : k == ADMM_TET_SPLINE_COROTATED ? 3 : 1;
         };
         c->tet_perm.resize(nt);
@@ -1050,16 +1080,16 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         auto vsum = [&](int t) { return (long long)d->tet_idx[4 * (size_t)t] + d->tet_idx[4 * (size_t)t + 1] + d->tet_idx[4 * (size_t)t + 2] + d->tet_idx[4 * (size_t)t + 3]; };
         auto vmin = [&](int t) { return std::min(std::min(d->tet_idx[4 * (size_t)t], d->tet_idx[4 * (size_t)t + 1]), std::min(d->tet_idx[4 * (size_t)t + 2], d->tet_idx[4 * (size_t)t + 3])); };
         std::stable_sort(c->tet_perm.begin(), c->tet_perm.end(), [&](int a, int b) {
-            const int ga = grp(d->tet_kind[a]), gb = grp(d->tet_kind[b]);
+            const int ga = grp_t(a), gb = grp_t(b);
             if (ga != gb) return ga < gb;
             const int ma = vmin(a), mb = vmin(b);
             return ma != mb ? ma < mb : vsum(a) < vsum(b);
         });
-        int cnt[4] = {0, 0, 0, 0};
-        for (int t = tb; t < te; ++t) cnt[grp(d->tet_kind[t])]++;
-        c->kind_begin[0] = 0; c->kind_begin[1] = cnt[0]; c->kind_begin[2] = cnt[0] + cnt[1]; c->kind_begin[3] = cnt[0] + cnt[1] + cnt[2];
-        c->kind_begin[4] = nt;
-        std::map<std::tuple<double, double, double>, int> mat_map;
+        int cnt[5] = {0, 0, 0, 0, 0};
+        for (int t = tb; t < te; ++t) cnt[grp_t(t)]++;
+        c->kind_begin[0] = 0;
+        for (int gI = 0; gI < 5; ++gI) c->kind_begin[gI + 1] = c->kind_begin[gI] + cnt[gI];
+        std::map<std::tuple<double, double, double, double, int>, int> mat_map;
         std::vector<Mat> mats;
         std::vector<int4> idx(nt);
         std::vector<double> Binv((size_t)9 * ld, 0.0), sc(ld, 0.0);
@@ -1069,9 +1099,10 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
             idx[n] = make_int4(d->tet_idx[4 * o], d->tet_idx[4 * o + 1], d->tet_idx[4 * o + 2], d->tet_idx[4 * o + 3]);
             for (int k = 0; k < 9; ++k) Binv[(size_t)k * ld + n] = d->tet_Binv[9 * (size_t)o + k];
             sc[n] = dt2 * d->tet_weight[o] * d->tet_weight[o];
-            auto key = std::make_tuple(d->tet_mu[o], d->tet_lambda[o], d->tet_k[o]);
+            const int stype = d->tet_kind[o] == ADMM_TET_SPLINE_STVK ? 1 : d->tet_kind[o] == ADMM_TET_SPLINE_COROTATED ? 2 : 0;
+            auto key = std::make_tuple(d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), kap(o) != 0.0 ? stype : 0);
             auto it = mat_map.find(key);
-            if (it == mat_map.end()) { it = mat_map.emplace(key, (int)mats.size()).first; mats.push_back(Mat{d->tet_mu[o], d->tet_lambda[o], d->tet_k[o]}); }
+            if (it == mat_map.end()) { it = mat_map.emplace(key, (int)mats.size()).first; mats.push_back(Mat{d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), stype, 0}); }
             mat[n] = it->second;
         }
         HIP_TRY(c->t_idx.upload(idx)); HIP_TRY(c->t_Binv.upload(Binv)); HIP_TRY(c->t_sc.upload(sc));
@@ -1082,7 +1113,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         // incidence on the permuted numbering
         std::vector<int32_t> pidx((size_t)4 * nt);
         for (int n = 0; n < nt; ++n) { pidx[4 * n] = idx[n].x; pidx[4 * n + 1] = idx[n].y; pidx[4 * n + 2] = idx[n].z; pidx[4 * n + 3] = idx[n].w; }
-        HIP_TRY(c->t_inc.upload(admm_host::incidence_sell(nv, nt, 4, pidx.data(), nt * 4)));
+        HIP_TRY(c->t_inc.upload(admm_host::incidence_sell(nv, nt, 4, pidx.data(), nt * 4, g_order.data())));
     }
     // ---- tris ----
     c->ntri = re - rb; c->ldr = c->ntri + 1;
@@ -1112,7 +1143,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->r_u.alloc((size_t)6 * ld)); HIP_TRY(c->r_u.zero());
         HIP_TRY(c->r_z.alloc((size_t)6 * ld)); HIP_TRY(c->r_z.zero());
         HIP_TRY(c->r_cf.alloc((size_t)12 * ld)); HIP_TRY(c->r_cf.zero());
-        HIP_TRY(c->r_inc.upload(admm_host::incidence_sell(nv, n, 3, tri_sorted.data(), n * 4)));
+        HIP_TRY(c->r_inc.upload(admm_host::incidence_sell(nv, n, 3, tri_sorted.data(), n * 4, g_order.data())));
     }
     // ---- pins ----
     double max_w = 0.0;
@@ -1289,6 +1320,14 @@ int admm_hip_set_state(admm_hip_ctx *c, const double *x, const double *v) {
     if (v) HIP_TRY(hipMemcpyAsync(c->v.p, v, c->n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     else HIP_TRY(hipMemsetAsync(c->v.p, 0, c->n3 * sizeof(double), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_sig && c->h_sig[2]) {   // the steps before this call hit a barrier time-out; their result is overwritten anyway
+        c->h_sig[2] = 0; c->oc_gave_up = true; c->oc_enabled = false;
+        if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
+        HIP_TRY(hipMemcpy(c->x.p, x, c->n3 * sizeof(double), hipMemcpyHostToDevice));
+        if (v) HIP_TRY(hipMemcpy(c->v.p, v, c->n3 * sizeof(double), hipMemcpyHostToDevice));
+        else HIP_TRY(hipMemset(c->v.p, 0, c->n3 * sizeof(double)));
+    }
+    c->pending.clear();
     c->state_set = true;
     return ADMM_HIP_OK;
 }
@@ -1299,7 +1338,12 @@ int admm_hip_get_state(admm_hip_ctx *c, double *x, double *v) {
     if (x) HIP_TRY(hipMemcpyAsync(x, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (v) HIP_TRY(hipMemcpyAsync(v, c->v.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)"); }
+    if (c->h_sig && c->h_sig[2]) {   // replay on the launch path, then read the state again
+        if (int rc = recover_from_abort(c, nullptr)) return rc;
+        if (x) HIP_TRY(hipMemcpy(x, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost));
+        if (v) HIP_TRY(hipMemcpy(v, c->v.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    c->pending.clear();
     return ADMM_HIP_OK;
 }
 
@@ -1309,6 +1353,7 @@ int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const dou
     // admm_hip_step without stats returns while its kernels are still in flight on the context's (non-blocking)
     // stream: the pin data must not change under them
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = settle(c)) return rc;     // (steps still pending are replayed, if need be, with the OLD pins)
     if (c->linsolver == 1) {
         std::vector<int> flag(c->nv, 0);
         std::vector<double> p((size_t)c->n3, 0.0);
@@ -1488,11 +1533,8 @@ static int launch_global(admm_hip_ctx *c, const double *b, double *x) {
     return launch_pcg_recycled(c, b, x);
 }
 
-int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_stats *stats) {
-    if (!c) return fail(ADMM_HIP_ERR_ARG, "step: NULL context");
-    if (!c->state_set) return fail(ADMM_HIP_ERR_STATE, "step: call admm_hip_set_state first");
-    if (admm_iters < 0) return fail(ADMM_HIP_ERR_ARG, "step: admm_iters < 0");
-    HIP_TRY(hipSetDevice(c->device));
+constexpr int kStepAborted = -100;   // step_impl: a grid barrier of the on-chip PCG timed out (seen at the final synchronisation)
+static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_stats *stats) {
     hipStream_t st = c->stream;
     const bool timed = stats != nullptr;
     if (timed) {
@@ -1549,7 +1591,7 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventSynchronize(c->ev_step1));
-        if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)"); }
+        if (c->h_sig && c->h_sig[2]) return kStepAborted;
         std::memset(stats, 0, sizeof(*stats));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_step0, c->ev_step1));
@@ -1595,6 +1637,58 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
         }
     }
     return ADMM_HIP_OK;
+}
+
+// A timed-out grid barrier was seen after a stream synchronisation: give up the persistent kernel, go back to the last
+// good state and replay.  Single-GPU contexts only (a replay on one rank would issue all-reduces the others do not).
+static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
+    c->h_sig[2] = 0;
+    if (c->world > 1 || c->comm || c->pending.empty() || !c->bk_x.p)
+        return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)");
+    if (!c->oc_gave_up) fprintf(stderr, "[admm_hip] on-chip PCG: a grid barrier timed out (blocks not co-resident?) -- falling back to the launch-per-iteration PCG and replaying %d step(s)\n", (int)c->pending.size());
+    c->oc_gave_up = true; c->oc_enabled = false;
+    if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
+    HIP_TRY(hipMemcpyAsync(c->x.p, c->bk_x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->v.p, c->bk_v.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const std::vector<std::pair<int, double> > todo(c->pending);
+    c->pending.clear();
+    for (size_t i = 0; i < todo.size(); ++i) {
+        const int rc = step_impl(c, todo[i].first, todo[i].second, i + 1 == todo.size() ? stats_of_last : nullptr);
+        if (rc) return rc == kStepAborted ? fail(ADMM_HIP_ERR_DEVICE, "PCG: barrier time-out during the replay") : rc;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ADMM_HIP_OK;
+}
+// after a stream synchronisation: everything issued so far is known to be good, or is replayed
+static int settle(admm_hip_ctx *c) {
+    if (c->h_sig && c->h_sig[2]) return recover_from_abort(c, nullptr);
+    c->pending.clear();
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_stats *stats) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "step: NULL context");
+    if (!c->state_set) return fail(ADMM_HIP_ERR_STATE, "step: call admm_hip_set_state first");
+    if (admm_iters < 0) return fail(ADMM_HIP_ERR_ARG, "step: admm_iters < 0");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->oc_enabled && c->linsolver != 1 && c->world == 1 && !c->comm) {
+        if (c->pending.empty()) {   // the state every later replay starts from
+            if (!c->bk_x.p) { HIP_TRY(c->bk_x.alloc(c->n3)); HIP_TRY(c->bk_v.alloc(c->n3)); }
+            HIP_TRY(hipMemcpyAsync(c->bk_x.p, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->bk_v.p, c->v.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (c->pending.size() >= 4096) {   // a long chain of unsynchronised steps: settle it
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (int rc = settle(c)) return rc;
+            HIP_TRY(hipMemcpyAsync(c->bk_x.p, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->bk_v.p, c->v.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
+        c->pending.emplace_back(admm_iters, gravity);
+    }
+    const int rc = step_impl(c, admm_iters, gravity, stats);
+    if (rc == kStepAborted) return recover_from_abort(c, stats);
+    if (rc == ADMM_HIP_OK && stats) c->pending.clear();   // a timed step ends with a synchronisation and the check
+    return rc;
 }
 
 // z/u between the reference row layout (AoS, caller's term order) and the device SoA (sorted tets)

@@ -458,6 +458,126 @@ __device__ __forceinline__ int minimize_stretch(double mu, double la, double k, 
 // KIND 0, linear tet (src/TetEnergyTerm.cpp:73-92): z = (P + q)/2 with P = U V^T (signed factors)
 //         == U diag((1 + S)/2) V^T.
 // KIND 1/2/3, hyperelastic (src/TetEnergyTerm.cpp:114-136): minimise over the stretches.
+// ---- xu:: splines WITH their compression term (SplineTet with a spline constructed with kappa != 0) --------------------
+// Psi(s) = Psi_spline(s) + c(J),  J = s0 s1 s2,  c(J) = kappa/12 ((1 - J)/6)^3      (src/XuSpline.hpp:43-45, Eq. 16 of Xu et al.)
+// c' = -kappa/24 ((1 - J)/6)^2 as the reference writes it; c'' = kappa/72 (1 - J)/6.  The Hessian of c(J) is
+// c'' dJ dJ^T + c' d2J (d2J_ij = s_k off the diagonal): not diagonal-plus-rank-one next to the StVK / co-rotated terms, so
+// this (rare) model runs a Newton with the dense 3 x 3 Hessian, FP64 only.  type: 0 xu::NeoHookean, 1 xu::StVK, 2 xu::CoRotated.
+struct SplineKappaModel {
+    int type;
+    double mu, la, k, kappa, x0[3];
+    __device__ __forceinline__ bool feasible(const double *s) const {
+        if (type == 0) return s[0] > 0.0 && s[1] > 0.0 && s[2] > 0.0;
+        return s[0] >= 0.0 && s[1] >= 0.0 && s[2] >= 0.0;
+    }
+    // value, gradient, Hessian H = {h00, h01, h02, h11, h12, h22}
+    __device__ __forceinline__ double eval(const double *s, double *g, double *H) const {
+        double D[3], w[3], f;
+        if (type == 0) { StretchModel<1, double> m; m.mu = mu; m.la = la; m.k = k; m.x0[0] = x0[0]; m.x0[1] = x0[1]; m.x0[2] = x0[2]; f = m.eval(s, g, D, w); }
+        else if (type == 1) { StretchModel<2, double> m; m.mu = mu; m.la = la; m.k = k; m.x0[0] = x0[0]; m.x0[1] = x0[1]; m.x0[2] = x0[2]; f = m.eval(s, g, D, w); }
+        else { StretchModel<3, double> m; m.mu = mu; m.la = la; m.k = k; m.x0[0] = x0[0]; m.x0[1] = x0[1]; m.x0[2] = x0[2]; f = m.eval(s, g, D, w); }
+        H[0] = fma(la * w[0], w[0], D[0]); H[1] = la * w[0] * w[1]; H[2] = la * w[0] * w[2];
+        H[3] = fma(la * w[1], w[1], D[1]); H[4] = la * w[1] * w[2]; H[5] = fma(la * w[2], w[2], D[2]);
+        const double J = s[0] * s[1] * s[2], t = (1.0 - J) * (1.0 / 6.0);
+        const double c0 = kappa * (1.0 / 12.0) * t * t * t, c1 = -kappa * (1.0 / 24.0) * t * t, c2 = kappa * (1.0 / 72.0) * t;
+        const double dJ[3] = {s[1] * s[2], s[2] * s[0], s[0] * s[1]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[i] = fma(c1, dJ[i], g[i]);
+        H[0] = fma(c2 * dJ[0], dJ[0], H[0]); H[3] = fma(c2 * dJ[1], dJ[1], H[3]); H[5] = fma(c2 * dJ[2], dJ[2], H[5]);
+        H[1] += fma(c2 * dJ[0], dJ[1], c1 * s[2]); H[2] += fma(c2 * dJ[0], dJ[2], c1 * s[1]); H[4] += fma(c2 * dJ[1], dJ[2], c1 * s[0]);
+        return f + c0;
+    }
+};
+// argmin_s Psi(s) + c(J) + k/2 |s - x0|^2: projected, safeguarded Newton with the dense Hessian (Cholesky of the free block,
+// scaled steepest descent when it is not positive definite), Armijo backtracking; iterated until the step is below 1e-9.
+__device__ __forceinline__ int newton_stretch_dense(const SplineKappaModel &m, double *s, int max_it) {
+    double g[3], H[6];
+    double f = m.eval(s, g, H);
+    const double fscale = 4.0 * (fabs(m.mu) + fabs(m.la) + fabs(m.k));
+    int it = 0;
+#pragma unroll 1
+    for (; it < max_it; ++it) {
+        bool fr[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fr[i] = !(m.type != 0 && s[i] <= 0.0 && g[i] > 0.0);   // components held at the bound
+        // frozen components: unit row / column, zero right-hand side
+        const double a00 = fr[0] ? H[0] : 1.0, a11 = fr[1] ? H[3] : 1.0, a22 = fr[2] ? H[5] : 1.0;
+        const double a01 = (fr[0] && fr[1]) ? H[1] : 0.0, a02 = (fr[0] && fr[2]) ? H[2] : 0.0, a12 = (fr[1] && fr[2]) ? H[4] : 0.0;
+        const double r0 = fr[0] ? -g[0] : 0.0, r1 = fr[1] ? -g[1] : 0.0, r2 = fr[2] ? -g[2] : 0.0;
+        double d[3];
+        bool newton = false;
+        const double floorD = 1e-8 * (fabs(m.k) + fabs(m.mu)) + 1e-30;
+        if (a00 > floorD) {   // LDL^T of the 3 x 3
+            const double l10 = a01 / a00, l20 = a02 / a00;
+            const double d1 = a11 - l10 * a01;
+            if (d1 > floorD) {
+                const double l21 = (a12 - l20 * a01) / d1;
+                const double d2 = a22 - l20 * a02 - l21 * l21 * d1;
+                if (d2 > floorD) {
+                    const double y0 = r0, y1 = r1 - l10 * y0, y2 = r2 - l20 * y0 - l21 * y1;
+                    d[2] = y2 / d2;
+                    d[1] = y1 / d1 - l21 * d[2];
+                    d[0] = y0 / a00 - l10 * d[1] - l20 * d[2];
+                    newton = true;
+                }
+            }
+        }
+        double gd = 0.0;
+        if (newton) { gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2]; newton = gd < 0.0; }
+        if (!newton) {   // scaled steepest descent on the free components
+            d[0] = r0 / fmax(fabs(a00), floorD); d[1] = r1 / fmax(fabs(a11), floorD); d[2] = r2 / fmax(fabs(a22), floorD);
+            gd = g[0] * d[0] + g[1] * d[1] + g[2] * d[2];
+            if (!(gd < 0.0)) break;   // zero (reduced) gradient
+        }
+        const double dmax = fmax(fabs(d[0]), fmax(fabs(d[1]), fabs(d[2])));
+        const double mag = fmax(1.0, fmax(fabs(s[0]), fmax(fabs(s[1]), fabs(s[2]))));
+        if (dmax <= 1e-9 * mag) {   // final correction: apply and stop
+            double sn[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (m.type != 0) sn[i] = fmax(sn[i], 0.0); }
+            if (m.feasible(sn)) { s[0] = sn[0]; s[1] = sn[1]; s[2] = sn[2]; }
+            ++it;
+            break;
+        }
+        double t = 1.0, sn[3], gn[3], Hn[6], fn = f;
+        bool ok = false;
+#pragma unroll 1
+        for (int ls = 0; ls < 50; ++ls) {
+            double gs = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sn[i] = fma(t, d[i], s[i]);
+                if (m.type != 0) sn[i] = fmax(sn[i], 0.0);
+                gs = fma(g[i], sn[i] - s[i], gs);
+            }
+            if (m.feasible(sn)) {
+                fn = m.eval(sn, gn, Hn);
+                if (fn <= f + 1e-4 * gs + 4e-16 * (fabs(f) + fscale)) { ok = true; break; }
+            }
+            t *= 0.5;
+        }
+        if (!ok) break;
+        f = fn;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { s[i] = sn[i]; g[i] = gn[i]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) H[i] = Hn[i];
+    }
+    return it;
+}
+// HyperElasticTet::prox on the stretches (src/TetEnergyTerm.cpp:124-135) for a spline with kappa != 0
+__device__ __forceinline__ void prox_stretches_kappa(int type, double mu, double la, double k, double kappa, double *S) {
+    SplineKappaModel m;
+    const double ik = fast_rcp(k);
+    m.type = type; m.mu = mu * ik; m.la = la * ik; m.k = 1.0; m.kappa = kappa * ik;
+    m.x0[0] = S[0]; m.x0[1] = S[1]; m.x0[2] = S[2];       // :124 set_x0 (before the fix-ups)
+    const double eps = 1e-6;
+    if (fabs(S[0]) < eps && fabs(S[1]) < eps && fabs(S[2]) < eps) { S[0] = eps; S[1] = eps; S[2] = eps; } // :128-131
+    if (S[2] < 0.0) S[2] = -S[2];                           // :133
+    if (type == 0) { S[0] = fmax(S[0], 1e-12); S[1] = fmax(S[1], 1e-12); S[2] = fmax(S[2], 1e-12); }
+    newton_stretch_dense(m, S, 200);
+}
+
 template <int KIND>
 __device__ __forceinline__ void prox_stretches(double mu, double la, double k, double *S) {
     if (KIND == 0) {

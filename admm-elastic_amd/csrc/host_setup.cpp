@@ -136,7 +136,7 @@ Sell csr_to_sell(const Csr &A) {
     return S;
 }
 
-Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t pad_code) {
+Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t pad_code, const int32_t *row_vertex) {
     std::vector<int32_t> cnt(n_verts + 1, 0);
     for (int64_t i = 0; i < (int64_t)n_elems * corners; ++i) cnt[idx[i] + 1]++;
     for (int32_t i = 0; i < n_verts; ++i) cnt[i + 1] += cnt[i];
@@ -149,29 +149,36 @@ Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int
     S.n_slices = (n_verts + 63) / 64;
     S.slice_ptr.assign(S.n_slices + 1, 0);
     S.slice_width.assign(S.n_slices, 0);
+    auto vert = [&](int32_t r) { return row_vertex ? row_vertex[r] : r; };   // row r of the SELL gathers for this vertex
     for (int32_t s = 0; s < S.n_slices; ++s) {
         int32_t w = 0;
-        for (int32_t r = 64 * s; r < std::min(n_verts, 64 * s + 64); ++r) w = std::max(w, cnt[r + 1] - cnt[r]);
+        for (int32_t r = 64 * s; r < std::min(n_verts, 64 * s + 64); ++r) w = std::max(w, cnt[vert(r) + 1] - cnt[vert(r)]);
         w = std::max(8, (w + 7) / 8 * 8); // the gather kernel consumes 8 incidences per pipelined round
         S.slice_width[s] = w;
         S.slice_ptr[s + 1] = S.slice_ptr[s] + 64 * w;
     }
     S.idx.assign(S.slice_ptr[S.n_slices], pad_code);
     for (int32_t r = 0; r < n_verts; ++r) {
-        const int32_t s = r / 64, l = r % 64;
-        for (int32_t k = 0; k < cnt[r + 1] - cnt[r]; ++k) S.idx[(size_t)S.slice_ptr[s] + 64 * k + l] = lst[cnt[r] + k];
+        const int32_t s = r / 64, l = r % 64, v = vert(r);
+        for (int32_t k = 0; k < cnt[v + 1] - cnt[v]; ++k) S.idx[(size_t)S.slice_ptr[s] + 64 * k + l] = lst[cnt[v] + k];
     }
     return S;
 }
 
-// Node colouring for the multi-colour Gauss-Seidel.  (The reference delegates to mcl::graphcolor::color_matrix, which is
-// absent; any valid colouring yields a correct multi-colour Gauss-Seidel, only the sweep order differs.)
-// Two greedy colourings, the one with fewer colours wins (ties: natural order): every colour is one kernel launch
-// per Gauss-Seidel sweep, so a colour saved is 1 / (n_colors + 1) of the solve.
-//   (a) first-fit in natural vertex order;
-//   (b) DSATUR (Brelaz): always colour the vertex whose neighbours already use the most distinct colours (ties: larger
-//       degree, then smaller index) -- exact on bipartite graphs, and finds the 3-colouring of a triangulated grid
-//       where natural-order first-fit needs 4.
+// Row order of the incidence lists: inside every window of 512 consecutive vertices the vertices with the most incident
+// elements come first, so the 64 rows of a slice have similar lengths (unstructured 1 M-tet body: 2.17x -> 1.24x stored
+// per real incidence) while a slice still gathers from one neighbourhood of the mesh.
+std::vector<int32_t> incidence_row_order(int32_t n_verts, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int32_t window) {
+    std::vector<int32_t> cnt(n_verts, 0), order(n_verts);
+    for (int64_t i = 0; i < (int64_t)4 * n_tets; ++i) cnt[tet_idx[i]]++;
+    for (int64_t i = 0; i < (int64_t)3 * n_tris; ++i) cnt[tri_idx[i]]++;
+    std::iota(order.begin(), order.end(), 0);
+    if (window < 2) return order;
+    for (int32_t b = 0; b < n_verts; b += window)
+        std::stable_sort(order.begin() + b, order.begin() + std::min(n_verts, b + window), [&](int32_t x, int32_t y) { return cnt[x] > cnt[y]; });
+    return order;
+}
+
 static int first_fit_natural(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color) {
     int ncol = 0;
     std::vector<int32_t> mark;

@@ -38,7 +38,9 @@ Csr assemble_Ahat(int32_t n_verts, double dt,
 Sell csr_to_sell(const Csr &A);
 
 // vertex -> list of (element, corner) codes, code = elem * stride + corner; padding = pad_code
-Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t pad_code);
+// row_vertex (optional, a permutation of the vertices): row r of the SELL holds the list of vertex row_vertex[r]
+Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t pad_code, const int32_t *row_vertex = nullptr);
+std::vector<int32_t> incidence_row_order(int32_t n_verts, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int32_t window);
 
 int greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color);
 

@@ -19,7 +19,7 @@ namespace admm_k {
 
 using namespace admm_dev;
 
-struct Mat { double mu, la, k; };
+struct Mat { double mu, la, k, kappa; int type, pad_; };   // kappa / type: SplineTet splines with a compression term (KIND 4)
 
 constexpr int kMaxObst = 8;
 struct Obstacles {
@@ -269,6 +269,9 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, const
     for (int i = 0; i < 3; ++i) S1[i] = S0[i];
     if (KIND == 0) {
         prox_stretches<0>(0.0, 0.0, 0.0, S1);
+    } else if (KIND == 4) {   // xu:: spline with kappa != 0 (dense-Hessian Newton; rare, not tuned)
+        const Mat mt = mats[in.mid];
+        prox_stretches_kappa(mt.type, mt.mu, mt.la, mt.k, mt.kappa, S1);
     } else {
         // StVK fits 4 waves/SIMD (128 VGPRs) only with V out of the way; NH needs 3 waves/SIMD either way
         // (measured: forcing 128 VGPRs spills and is slower), so it keeps V in registers.
@@ -340,7 +343,7 @@ template <int KIND, bool WRITE_Z>
 #ifndef ADMM_NH_WAVES
 #define ADMM_NH_WAVES 3
 #endif
-__global__ __launch_bounds__(256, (KIND == 1 ? ADMM_NH_WAVES : 4)) void k_local_tets(int t0, int t1, TetArgs a) {
+__global__ __launch_bounds__(256, (KIND == 1 ? ADMM_NH_WAVES : KIND == 4 ? 2 : 4)) void k_local_tets(int t0, int t1, TetArgs a) {
     __shared__ double sBi[9][256];
     __shared__ double sV[(KIND == 2 || ADMM_PARK_V_NH != 0) ? 9 : 1][256];
     const int t = t0 + xcd_block() * 256 + threadIdx.x;
@@ -429,6 +432,7 @@ struct GatherArgs {
     const double *Mxbar;       // added when add_mxbar
     double *b;
     int add_mxbar;             // 1 on a single GPU / on rank 0
+    const int *order;          // [nv] vertex gathered by every row (rows sorted by list length inside 512-vertex windows)
 };
 
 // sum of the corner forces incident to this lane's vertex (incidence widths are multiples of 8; padding
@@ -466,7 +470,8 @@ __global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
     const int s = wave_slice();
     if (s >= a.n_slices) return;
     {
-        const int v = s * 64 + lane;
+        const int r = s * 64 + lane;
+        const int v = r < a.nv ? a.order[r] : a.nv;
         double acc[3] = {0.0, 0.0, 0.0};
         if (a.t_inc) gather_corners(a.t_inc + a.t_ptr[s] + lane, a.t_w[s], a.t_cf, a.t_ld, acc);
         if (a.r_inc) gather_corners(a.r_inc + a.r_ptr[s] + lane, a.r_w[s], a.r_cf, a.r_ld, acc);

@@ -36,6 +36,7 @@ struct FlatTerm {
     double weight;
     int kind;           // ADMM_TET_*
     double mu, lambda, k, limit_min, limit_max;
+    double kappa = 0.0; // SplineTet: compression term of the xu:: spline (src/XuSpline.hpp:43-45)
     double pin[3];
     int active;
 };

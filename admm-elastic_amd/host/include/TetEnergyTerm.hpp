@@ -45,15 +45,15 @@ protected:
 };
 
 // src/TetEnergyTerm.hpp:176-206.  Defaults to xu::NeoHookean(mu, lambda, 0) like the reference (:191-195); the second
-// constructor takes one of the reference's splines (XuSpline.hpp).  kappa != 0 or a user-defined spline: no GPU kernel,
-// flatten() returns false and Solver::initialize says so.
+// constructor takes one of the reference's splines (XuSpline.hpp), with or without compression term.  A user-defined
+// spline has no GPU kernel: flatten() returns false and Solver::initialize says so.
 class SplineTet : public NeoHookeanTet {
 public:
     SplineTet(const Vec4i &tet, const std::vector<Vec3> &verts, const Lame &lame)
         : NeoHookeanTet(tet, verts, lame), spline(std::make_shared<xu::NeoHookean>(lame.mu, lame.lambda, 0.0)) {}
     SplineTet(const Vec4i &tet, const std::vector<Vec3> &verts, const Lame &lame, std::shared_ptr<xu::Spline> spline_)
         : NeoHookeanTet(tet, verts, lame), spline(spline_) {}
-    int kind() const { int kd = 3; double m, l; spline->flatten(kd, m, l); return kd; }
+    int kind() const { int kd = 3; double m, l, kp; spline->flatten(kd, m, l, kp); return kd; }
     bool flatten(FlatTerm &out) const;
     std::shared_ptr<xu::Spline> spline;
 protected:

@@ -25,8 +25,11 @@ public:
     // compression term of the paper's Eq. 16 and its derivative as the reference evaluates them (src/XuSpline.hpp:44-45)
     static double compress_term(double kappa, double x) { const double t = (1.0 - x) / 6.0; return kappa * t * t * t / 12.0; }
     static double d_compress_term(double kappa, double x) { const double t = (1.0 - x) / 6.0; return -kappa * t * t / 24.0; }
-    // GPU description: ADMM_TET_SPLINE_* kind and the spline's Lame constants; false = no kernel for this spline
-    virtual bool flatten(int &kind, double &mu_out, double &lambda_out) const { (void)kind; (void)mu_out; (void)lambda_out; return false; }
+    // GPU description: ADMM_TET_SPLINE_* kind, the spline's Lame constants and compression term; false = no kernel for this
+    // (user-defined) spline
+    virtual bool flatten(int &kind, double &mu_out, double &lambda_out, double &kappa_out) const {
+        (void)kind; (void)mu_out; (void)lambda_out; (void)kappa_out; return false;
+    }
 };
 
 namespace detail {
@@ -63,9 +66,9 @@ public:
         if (M == kNeoHookean) v += (lambda * std::log(J) - mu) / J;
         return v;
     }
-    bool flatten(int &kind, double &mu_out, double &lambda_out) const {
-        kind = (int)M; mu_out = mu; lambda_out = lambda;
-        return kappa == 0.0;
+    bool flatten(int &kind, double &mu_out, double &lambda_out, double &kappa_out) const {
+        kind = (int)M; mu_out = mu; lambda_out = lambda; kappa_out = kappa;
+        return true;
     }
 };
 

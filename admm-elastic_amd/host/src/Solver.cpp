@@ -22,13 +22,14 @@ void check(int rc, const char *what) {
 // gathers flat arrays for admm_hip_desc
 struct Flat {
     std::vector<int32_t> tet_idx, tet_kind, tri_idx, pin_vert, pin_active;
-    std::vector<double> tet_Binv, tet_w, tet_mu, tet_la, tet_k, tri_rest, tri_w, tri_lmin, tri_lmax, pin_xyz;
+    std::vector<double> tet_Binv, tet_w, tet_mu, tet_la, tet_k, tet_kappa, tri_rest, tri_w, tri_lmin, tri_lmax, pin_xyz;
     double pin_weight = 0.0;
     void add(const FlatTerm &t) {
         if (t.type == FlatTerm::TET) {
             for (int i = 0; i < 4; ++i) tet_idx.push_back(t.idx[i]);
             for (int i = 0; i < 9; ++i) tet_Binv.push_back(t.mat[i]);
             tet_w.push_back(t.weight); tet_kind.push_back(t.kind); tet_mu.push_back(t.mu); tet_la.push_back(t.lambda); tet_k.push_back(t.k);
+            tet_kappa.push_back(t.kappa);
         } else if (t.type == FlatTerm::TRI) {
             for (int i = 0; i < 3; ++i) tri_idx.push_back(t.idx[i]);
             for (int i = 0; i < 4; ++i) tri_rest.push_back(t.mat[i]);
@@ -42,7 +43,7 @@ struct Flat {
     void fill(admm_hip_desc &d) const {
         d.n_tets = (int32_t)tet_w.size();
         d.tet_idx = tet_idx.data(); d.tet_Binv = tet_Binv.data(); d.tet_weight = tet_w.data(); d.tet_kind = tet_kind.data();
-        d.tet_mu = tet_mu.data(); d.tet_lambda = tet_la.data(); d.tet_k = tet_k.data();
+        d.tet_mu = tet_mu.data(); d.tet_lambda = tet_la.data(); d.tet_k = tet_k.data(); d.tet_kappa = tet_kappa.data();
         d.n_tris = (int32_t)tri_w.size();
         d.tri_idx = tri_idx.data(); d.tri_rest = tri_rest.data(); d.tri_weight = tri_w.data();
         d.tri_limit_min = tri_lmin.data(); d.tri_limit_max = tri_lmax.data();
@@ -200,9 +201,9 @@ double StVKTet::energy(const VecX &F) { // src/TetEnergyTerm.cpp:220-226
 
 bool SplineTet::flatten(FlatTerm &o) const {
     if (!TetEnergyTerm::flatten(o)) return false;
-    int kd = 0; double m = 0, l = 0;
-    if (!spline || !spline->flatten(kd, m, l)) return false;   // kappa != 0 or a user-defined spline: no kernel
-    o.kind = kd; o.mu = m; o.lambda = l;                       // the spline's constants; k stays the tet's (TetEnergyTerm.hpp:192-204)
+    int kd = 0; double m = 0, l = 0, kp = 0;
+    if (!spline || !spline->flatten(kd, m, l, kp)) return false;   // a user-defined spline: no kernel
+    o.kind = kd; o.mu = m; o.lambda = l; o.kappa = kp;             // the spline's constants; k stays the tet's (TetEnergyTerm.hpp:192-204)
     return true;
 }
 double SplineTet::energy(const VecX &F) {

@@ -152,12 +152,13 @@ class Solver:
         self.m_masses = np.concatenate([self.m_masses, m])
         return self.m_x.size // 3
 
-    def add_tets(self, verts, inds, lame, kind=TET_LINEAR, vertex_offset=0, spline=None):
+    def add_tets(self, verts, inds, lame, kind=TET_LINEAR, vertex_offset=0, spline=None, kappa=0.0):
         """create_tets_from_mesh<IN_SCALAR,TYPE> (src/TetEnergyTerm.hpp:35-51) + the TetEnergyTerm ctor
         (src/TetEnergyTerm.cpp:31-48).  verts are the REST positions the indices refer to; kind selects
         TetEnergyTerm / NeoHookeanTet / StVKTet / SplineTet (TET_SPLINE_*: xu::NeoHookean / StVK / CoRotated with
-        kappa = 0; `spline` = a Lame holding the spline's own mu / lambda, default the tet's, as the SplineTet
-        constructors do, src/TetEnergyTerm.hpp:192-204).  Raises on an inverted rest tet."""
+        their compression term `kappa`, src/XuSpline.hpp:43-45 -- 0 as the reference's SplineTet constructors pass;
+        `spline` = a Lame holding the spline's own mu / lambda, default the tet's, as the SplineTet constructors do,
+        src/TetEnergyTerm.hpp:192-204).  Raises on an inverted rest tet."""
         inds = i32(inds, (-1, 4))
         Binv, vol = capi.tet_rest(verts, inds)
         k = lame.bulk_modulus()
@@ -165,7 +166,7 @@ class Solver:
         w = np.sqrt(k * vol)
         sp = spline if spline is not None else lame
         self._tets.append((inds + vertex_offset, Binv, w, np.full(n, kind, np.int32), np.full(n, sp.mu),
-                           np.full(n, sp.lambda_), np.full(n, k)))
+                           np.full(n, sp.lambda_), np.full(n, k), np.full(n, float(kappa) if kind >= TET_SPLINE_NH else 0.0)))
         return n
 
     def add_tris(self, verts, inds, lame, vertex_offset=0):
@@ -228,7 +229,7 @@ class Solver:
         out = dict(
             tet_idx=cat(T, 0, (0, 4), np.int32), tet_Binv=cat(T, 1, (0, 9), np.float64), tet_weight=cat(T, 2, (0,), np.float64),
             tet_kind=cat(T, 3, (0,), np.int32), tet_mu=cat(T, 4, (0,), np.float64), tet_lambda=cat(T, 5, (0,), np.float64),
-            tet_k=cat(T, 6, (0,), np.float64),
+            tet_k=cat(T, 6, (0,), np.float64), tet_kappa=cat(T, 7, (0,), np.float64),
             tri_idx=cat(R, 0, (0, 3), np.int32), tri_rest=cat(R, 1, (0, 4), np.float64), tri_weight=cat(R, 2, (0,), np.float64),
             tri_limit_min=cat(R, 3, (0,), np.float64), tri_limit_max=cat(R, 4, (0,), np.float64),
             pin_vert=i32(list(self._pins.keys())),
@@ -250,6 +251,7 @@ class Solver:
         d.n_tets = f["tet_idx"].shape[0]
         d.tet_idx, d.tet_Binv, d.tet_weight = iptr(f["tet_idx"]), dptr(f["tet_Binv"]), dptr(f["tet_weight"])
         d.tet_kind, d.tet_mu, d.tet_lambda, d.tet_k = iptr(f["tet_kind"]), dptr(f["tet_mu"]), dptr(f["tet_lambda"]), dptr(f["tet_k"])
+        d.tet_kappa = dptr(f["tet_kappa"]) if f["tet_kappa"].any() else None
         d.n_tris = f["tri_idx"].shape[0]
         d.tri_idx, d.tri_rest, d.tri_weight = iptr(f["tri_idx"]), dptr(f["tri_rest"]), dptr(f["tri_weight"])
         d.tri_limit_min, d.tri_limit_max = dptr(f["tri_limit_min"]), dptr(f["tri_limit_max"])

@@ -40,10 +40,10 @@ typedef enum {
 
 /* tet constitutive models -- src/TetEnergyTerm.hpp:57 (linear), :116 (NeoHookean), :142 (StVK), :176 (SplineTet).
  * SplineTet carries an xu::Spline (src/XuSpline.hpp); the three splines the reference ships are accepted with
- * kappa = 0: xu::NeoHookean (the default, algebraically the NH model), xu::StVK (algebraically the StVK model) and
- * xu::CoRotated (co-rotated linear: mu sum (s_i-1)^2 + lambda/2 (sum s_i - 3)^2).  tet_mu / tet_lambda are the
- * SPLINE's constants, tet_k the tet's bulk modulus (src/TetEnergyTerm.hpp:192-204).  User-defined splines and the
- * kappa compression term (src/XuSpline.hpp:44-45) have no kernel. */
+ * : xu::NeoHookean (the default; with kappa = 0 algebraically the NH model), xu::StVK (with kappa = 0 algebraically the
+ * StVK model) and xu::CoRotated (co-rotated linear: mu sum (s_i-1)^2 + lambda/2 (sum s_i - 3)^2).  tet_mu / tet_lambda are
+ * the SPLINE's constants, tet_kappa its compression term (src/XuSpline.hpp:44-45; 0 = none), tet_k the tet's bulk modulus
+ * (src/TetEnergyTerm.hpp:192-204).  User-defined splines have no kernel. */
 enum { ADMM_TET_LINEAR = 0, ADMM_TET_NEOHOOKEAN = 1, ADMM_TET_STVK = 2, ADMM_TET_SPLINE_NH = 3, ADMM_TET_SPLINE_STVK = 4,
        ADMM_TET_SPLINE_COROTATED = 5 };
 
@@ -118,6 +118,11 @@ typedef struct {
      * the rank (tets and tris separately), assembles the full matrix, and replicates the global solve. */
     int32_t rank;
     int32_t world_size;
+
+    /* SplineTet with a spline constructed with a compression term (src/XuSpline.hpp:43-45, the `kappa` of xu::NeoHookean /
+     * xu::StVK / xu::CoRotated): [n_tets] or NULL (= 0 everywhere, what the reference's own SplineTet constructors pass,
+     * src/TetEnergyTerm.hpp:194).  Read for the ADMM_TET_SPLINE_* kinds only. */
+    const double *tet_kappa;
 } admm_hip_desc;
 
 /* Maps 1:1 onto Solver::RuntimeData (src/Solver.hpp:54-61) plus GPU-side extras. */

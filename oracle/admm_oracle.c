@@ -169,12 +169,18 @@ double orc_energy_tet_linear(const double *F, double k, double vol) {
 }
 
 /* ---- principal-stretch objectives: kind 1 = NeoHookean, 2 = StVK, 3 / 4 / 5 = SplineTet with xu::NeoHookean (the default) /
- * xu::StVK / xu::CoRotated, kappa = 0 ---- */
-typedef struct { int kind; double mu, lambda, k; double x0[3]; } prox_problem;
+ * xu::StVK / xu::CoRotated with their compression term kappa (src/XuSpline.hpp:43-45; 0 as the reference constructs them) ---- */
+typedef struct { int kind; double mu, lambda, k, kappa; double x0[3]; } prox_problem;
 
 #define ORC_FLT_MAX 3.40282346638528859812e+38 /* std::numeric_limits<float>::max() */
 
-/* Xu spline NeoHookean (src/XuSpline.hpp:48-62), kappa = 0 as constructed at TetEnergyTerm.hpp:194 */
+/* Eq. 16 compression term of the xu:: splines and its derivative, exactly as src/XuSpline.hpp:44-45 writes them (the
+ * second derivative is derived: it is only used by the "tight" Newton polish) */
+static double xu_compress(double kappa, double x) { double t = (1.0 - x) / 6.0; return (kappa / 12.0) * t * t * t; }
+static double xu_d_compress(double kappa, double x) { double t = (1.0 - x) / 6.0; return (-kappa / 24.0) * t * t; }
+static double xu_dd_compress(double kappa, double x) { return (kappa / 72.0) * ((1.0 - x) / 6.0); }
+
+/* Xu spline NeoHookean (src/XuSpline.hpp:48-62); kappa = 0 as constructed at TetEnergyTerm.hpp:194 */
 static double xu_nh_f(double mu, double x) { return 0.5 * mu * (x * x - 1.0); }
 static double xu_nh_h(double mu, double la, double x) { double l = log(x); return -mu * l + 0.5 * la * l * l; }
 static double xu_nh_df(double mu, double x) { return mu * x; }
@@ -192,7 +198,7 @@ static double xu_g(int kind, double la, double x) {
     if (kind == 4) return 0.25 * la * (x * x - 1.0);
     return la * (x - 1.0);
 }
-static double xu_h(int kind, double mu, double la, double x) { return kind == 3 ? xu_nh_h(mu, la, x) : 0.0; }
+static double xu_h(int kind, double mu, double la, double kappa, double x) { return (kind == 3 ? xu_nh_h(mu, la, x) : 0.0) + xu_compress(kappa, x); }
 static double xu_df(int kind, double mu, double la, double x) {
     if (kind == 3) return xu_nh_df(mu, x);
     if (kind == 4) { double x2 = x * x; return 0.125 * la * (4.0 * x2 * x - 12.0 * x) + mu * x * (x2 - 1.0); }
@@ -203,7 +209,7 @@ static double xu_dg(int kind, double la, double x) {
     if (kind == 4) return 0.5 * la * x;
     return la;
 }
-static double xu_dh(int kind, double mu, double la, double x) { return kind == 3 ? xu_nh_dh(mu, la, x) : 0.0; }
+static double xu_dh(int kind, double mu, double la, double kappa, double x) { return (kind == 3 ? xu_nh_dh(mu, la, x) : 0.0) + xu_d_compress(kappa, x); }
 
 static double energy_density(const prox_problem *p, const double *x) {
     if (p->kind == 1) { /* TetEnergyTerm.cpp:173-182 */
@@ -219,7 +225,7 @@ static double energy_density(const prox_problem *p, const double *x) {
         const int kd = p->kind;
         return xu_f(kd, p->mu, p->lambda, x[0]) + xu_f(kd, p->mu, p->lambda, x[1]) + xu_f(kd, p->mu, p->lambda, x[2])
              + xu_g(kd, p->lambda, x[0] * x[1]) + xu_g(kd, p->lambda, x[1] * x[2]) + xu_g(kd, p->lambda, x[2] * x[0])
-             + xu_h(kd, p->mu, p->lambda, x[0] * x[1] * x[2]);
+             + xu_h(kd, p->mu, p->lambda, p->kappa, x[0] * x[1] * x[2]);
     }
 }
 
@@ -247,7 +253,7 @@ static double prox_gradient(const prox_problem *p, const double *x, double *g) {
                  + p->k * (x[i] - p->x0[i]);
     } else { /* TetEnergyTerm.cpp:259-265 */
         const int kd = p->kind; const double mu = p->mu, la = p->lambda;
-        double hp = xu_dh(kd, mu, la, x[0] * x[1] * x[2]);
+        double hp = xu_dh(kd, mu, la, p->kappa, x[0] * x[1] * x[2]);
         g[0] = xu_df(kd, mu, la, x[0]) + xu_dg(kd, la, x[0] * x[1]) * x[1] + xu_dg(kd, la, x[2] * x[0]) * x[2] + hp * x[1] * x[2] + p->k * (x[0] - p->x0[0]);
         g[1] = xu_df(kd, mu, la, x[1]) + xu_dg(kd, la, x[1] * x[2]) * x[2] + xu_dg(kd, la, x[0] * x[1]) * x[0] + hp * x[2] * x[0] + p->k * (x[1] - p->x0[1]);
         g[2] = xu_df(kd, mu, la, x[2]) + xu_dg(kd, la, x[2] * x[0]) * x[0] + xu_dg(kd, la, x[1] * x[2]) * x[1] + hp * x[0] * x[1] + p->k * (x[2] - p->x0[2]);
@@ -275,6 +281,13 @@ static void prox_hessian(const prox_problem *p, const double *x, double *H) {
             for (int j = 0; j < 3; ++j) M3(H, i, j) = p->lambda * x[i] * x[j];
         for (int i = 0; i < 3; ++i)
             M3(H, i, i) += p->mu * (3.0 * x[i] * x[i] - 1.0) + 0.5 * p->lambda * (xx - 3.0) + p->k;
+    }
+    if (p->kind >= 3 && p->kappa != 0.0) {   /* c(J), J = x0 x1 x2:  c'' dJ dJ^T + c' d2J  (d2J_ij = x_k off the diagonal) */
+        const double J = x[0] * x[1] * x[2];
+        const double c1 = xu_d_compress(p->kappa, J), c2 = xu_dd_compress(p->kappa, J);
+        const double dJ[3] = {x[1] * x[2], x[2] * x[0], x[0] * x[1]};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M3(H, i, j) += c2 * dJ[i] * dJ[j] + (i == j ? 0.0 : c1 * x[3 - i - j]);
     }
 }
 
@@ -419,11 +432,11 @@ static int newton3(const prox_problem *p, double *x, int max_iters) {
  * kind 1 NH, 2 StVK, 3 / 4 / 5 Spline(NH / StVK / CoRotated).  mode 0 = reference stop rule only (L-BFGS), mode 1 = "tight"
  * (L-BFGS then Newton polish to the exact minimiser).  Returns minimiser iterations.
  */
-int orc_prox_tet_hyper(int kind, double mu, double lambda, double k, double *z, int mode) {
+int orc_prox_tet_hyper_k(int kind, double mu, double lambda, double k, double kappa, double *z, int mode) {
     double U[9], S[3], V[9];
     orc_signed_svd3(z, S, U, V);
     prox_problem p;
-    p.kind = kind; p.mu = mu; p.lambda = lambda; p.k = k;
+    p.kind = kind; p.mu = mu; p.lambda = lambda; p.k = k; p.kappa = kind >= 3 ? kappa : 0.0;
     p.x0[0] = S[0]; p.x0[1] = S[1]; p.x0[2] = S[2];           /* :124 set_x0 BEFORE the fix-ups */
     const double eps = 1e-6;
     if (fabs(S[0]) < eps && fabs(S[1]) < eps && fabs(S[2]) < eps) { S[0] = S[1] = S[2] = eps; } /* :128-131 */
@@ -435,15 +448,26 @@ int orc_prox_tet_hyper(int kind, double mu, double lambda, double k, double *z, 
     return it;
 }
 
-double orc_prox_value(int kind, double mu, double lambda, double k, const double *x0, const double *x) {
-    prox_problem p; p.kind = kind; p.mu = mu; p.lambda = lambda; p.k = k;
+int orc_prox_tet_hyper(int kind, double mu, double lambda, double k, double *z, int mode) {
+    return orc_prox_tet_hyper_k(kind, mu, lambda, k, 0.0, z, mode);
+}
+
+/* SplineProx::value / ::gradient with the spline's compression term kappa (kinds 3..5; ignored for 1, 2) */
+double orc_prox_value_k(int kind, double mu, double lambda, double k, double kappa, const double *x0, const double *x) {
+    prox_problem p; p.kind = kind; p.mu = mu; p.lambda = lambda; p.k = k; p.kappa = kind >= 3 ? kappa : 0.0;
     memcpy(p.x0, x0, sizeof(p.x0));
     return prox_value(&p, x);
 }
-void orc_prox_gradient(int kind, double mu, double lambda, double k, const double *x0, const double *x, double *g) {
-    prox_problem p; p.kind = kind; p.mu = mu; p.lambda = lambda; p.k = k;
+void orc_prox_gradient_k(int kind, double mu, double lambda, double k, double kappa, const double *x0, const double *x, double *g) {
+    prox_problem p; p.kind = kind; p.mu = mu; p.lambda = lambda; p.k = k; p.kappa = kind >= 3 ? kappa : 0.0;
     memcpy(p.x0, x0, sizeof(p.x0));
     prox_gradient(&p, x, g);
+}
+double orc_prox_value(int kind, double mu, double lambda, double k, const double *x0, const double *x) {
+    return orc_prox_value_k(kind, mu, lambda, k, 0.0, x0, x);
+}
+void orc_prox_gradient(int kind, double mu, double lambda, double k, const double *x0, const double *x, double *g) {
+    orc_prox_gradient_k(kind, mu, lambda, k, 0.0, x0, x, g);
 }
 
 /* src/TriEnergyTerm.cpp:73-101 -- triangle prox on the 3x2 F (col-major, 6 doubles) + strain limit */
@@ -517,9 +541,9 @@ int orc_tri_rest(const double *v0, const double *v1, const double *v2, double *r
 
 /* tets: F = [x1-x0,x2-x0,x3-x0] * Binv, equal to D_i x with the D-block of TetEnergyTerm.cpp:50-71.
  * z,u: AoS [nt][9] in the reference's row order (row 3r+j <-> F(j,r)).  x: [nv][3]. */
-void orc_local_tets(int nt, const int32_t *idx, const double *Binv, const int32_t *kind,
-                    const double *mu, const double *lambda, const double *k,
-                    const double *x, double *z, double *u, int mode) {
+void orc_local_tets_k(int nt, const int32_t *idx, const double *Binv, const int32_t *kind,
+                      const double *mu, const double *lambda, const double *k, const double *kappa,
+                      const double *x, double *z, double *u, int mode) {
 #pragma omp parallel for schedule(static)
     for (int t = 0; t < nt; ++t) {
         const int32_t *id = idx + 4 * t;
@@ -536,9 +560,14 @@ void orc_local_tets(int nt, const int32_t *idx, const double *Binv, const int32_
         double *ui = u + 9 * t;
         for (int i = 0; i < 9; ++i) zi[i] = Dix[i] + ui[i];            /* EnergyTerm.hpp:135 */
         if (kind[t] == 0) orc_prox_tet_linear(zi);
-        else orc_prox_tet_hyper(kind[t], mu[t], lambda[t], k[t], zi, mode);
+        else orc_prox_tet_hyper_k(kind[t], mu[t], lambda[t], k[t], kappa ? kappa[t] : 0.0, zi, mode);
         for (int i = 0; i < 9; ++i) { ui[i] += Dix[i] - zi[i]; z[9 * t + i] = zi[i]; } /* :137-139 */
     }
+}
+void orc_local_tets(int nt, const int32_t *idx, const double *Binv, const int32_t *kind,
+                    const double *mu, const double *lambda, const double *k,
+                    const double *x, double *z, double *u, int mode) {
+    orc_local_tets_k(nt, idx, Binv, kind, mu, lambda, k, (const double *)0, x, z, u, mode);
 }
 
 /* tris: rows i and 3+i <-> columns of the 3x2 F = [x1-x0,x2-x0] * rest (TriEnergyTerm.cpp:54-69) */

@@ -71,6 +71,11 @@ def lib():
         L.orc_tri_rest.argtypes = [dp, dp, dp, dp, dp]
         L.orc_tri_rest.restype = C.c_int
         L.orc_local_tets.argtypes = [C.c_int, ip, dp, ip, dp, dp, dp, dp, dp, dp, C.c_int]
+        L.orc_local_tets_k.argtypes = [C.c_int, ip, dp, ip, dp, dp, dp, dp, dp, dp, dp, C.c_int]
+        L.orc_prox_tet_hyper_k.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, C.c_int]
+        L.orc_prox_value_k.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp]
+        L.orc_prox_value_k.restype = C.c_double
+        L.orc_prox_gradient_k.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp, dp, dp]
         L.orc_local_tris.argtypes = [C.c_int, ip, dp, dp, dp, dp, dp, dp]
         L.orc_local_pins.argtypes = [C.c_int, ip, dp, ip, dp, dp, dp]
         L.orc_csr_matvec.argtypes = [C.c_int, ip, ip, dp, dp, dp]
@@ -109,6 +114,23 @@ def ref_lib():
     L.ref_ldlt_solve.restype = C.c_int
     L.ref_xu_spline.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp]
     return L
+
+
+def xu_spline(which, mu, la, kappa, x):
+    """The three splines the reference ships, src/XuSpline.hpp:48-96 (which = 0 NeoHookean, 1 StVK, 2 CoRotated), with
+    the compression term of :44-45: returns (f, g, h, df, dg, dh) at x.  Pinned on the real header through
+    tests/golden/ref_vectors.npz (tests/test_oracle_vs_ref.py)."""
+    t = (1.0 - x) / 6.0
+    comp, dcomp = (kappa / 12.0) * t ** 3, (-kappa / 24.0) * t ** 2
+    if which == 0:
+        lx = np.log(x)
+        return (0.5 * mu * (x * x - 1.0), 0.0, -mu * lx + 0.5 * la * lx * lx + comp, mu * x, 0.0, -mu / x + la * lx / x + dcomp)
+    x2 = x * x
+    if which == 1:
+        return (0.125 * la * (x2 * x2 - 6.0 * x2 + 5.0) + 0.25 * mu * (x2 - 1.0) ** 2, 0.25 * la * (x2 - 1.0), comp,
+                0.125 * la * (4.0 * x2 * x - 12.0 * x) + mu * x * (x2 - 1.0), 0.5 * la * x, dcomp)
+    return (0.5 * la * (x2 - 6.0 * x + 5.0) + mu * (x - 1.0) ** 2, la * (x - 1.0), comp,
+            0.5 * la * (2.0 * x - 6.0) + 2.0 * mu * (x - 1.0), la, dcomp)
 
 
 # ---- small wrappers -------------------------------------------------------------------------------
@@ -259,6 +281,7 @@ class OracleSolver:
             # k = the TET's bulk modulus (EnergyTerm.hpp:41); mu / la may be a SplineTet's own spline constants
             self.t_k = (np.ascontiguousarray(np.broadcast_to(tets["k"], (self.nt,)), dtype=np.float64) if "k" in tets
                         else self.t_la + (2.0 / 3.0) * self.t_mu)
+            self.t_kappa = np.ascontiguousarray(np.broadcast_to(tets.get("kappa", 0.0), (self.nt,)), dtype=np.float64)  # xu:: splines
             self.t_w = np.sqrt(self.t_k * vol)                    # TetEnergyTerm.cpp:46-47
             if np.any(self.t_w <= 0):
                 raise RuntimeError("**EnergyTerm::get_reduction Error: Some weight leq 0")
@@ -337,8 +360,8 @@ class OracleSolver:
         o = 0
         if self.nt:
             zz = np.ascontiguousarray(z[o:o + 9 * self.nt]); uu = np.ascontiguousarray(u[o:o + 9 * self.nt])
-            L.orc_local_tets(self.nt, _i(self.t_idx), _p(self.t_Binv), _i(self.t_kind), _p(self.t_mu), _p(self.t_la),
-                             _p(self.t_k), _p(curr_x), _p(zz), _p(uu), self.mode)
+            L.orc_local_tets_k(self.nt, _i(self.t_idx), _p(self.t_Binv), _i(self.t_kind), _p(self.t_mu), _p(self.t_la),
+                               _p(self.t_k), _p(self.t_kappa), _p(curr_x), _p(zz), _p(uu), self.mode)
             z[o:o + 9 * self.nt] = zz; u[o:o + 9 * self.nt] = uu
             o += 9 * self.nt
         if self.ntri:

@@ -70,11 +70,11 @@ int main(int argc, char **argv) {
                                   sc.f(x), sc.g(x), sc.h(x), sc.df(x), sc.dg(x), sc.dh(x)};
             for (int i = 0; i < 18; ++i) CHECK(std::fabs(e[i] - g[i]) <= 1e-12 * (1 + std::fabs(e[i])));
         }
-        int kd; double m_, l_;
-        CHECK(!sn.flatten(kd, m_, l_));                                             // kappa != 0: no kernel
-        xu::StVK s0(mu, la, 0.0); CHECK(s0.flatten(kd, m_, l_) && kd == 4 && m_ == mu && l_ == la);
-        xu::CoRotated c0(mu, la, 0.0); CHECK(c0.flatten(kd, m_, l_) && kd == 5);
-        xu::NeoHookean n0(mu, la, 0.0); CHECK(n0.flatten(kd, m_, l_) && kd == 3);
+        int kd; double m_, l_, k_;
+        CHECK(sn.flatten(kd, m_, l_, k_) && kd == 3 && k_ == ka);                   // the compression term travels with the spline
+        xu::StVK s0(mu, la, 0.0); CHECK(s0.flatten(kd, m_, l_, k_) && kd == 4 && m_ == mu && l_ == la && k_ == 0.0);
+        xu::CoRotated c0(mu, la, 0.0); CHECK(c0.flatten(kd, m_, l_, k_) && kd == 5);
+        xu::NeoHookean n0(mu, la, 0.0); CHECK(n0.flatten(kd, m_, l_, k_) && kd == 3);
         CHECK(n0.mu == mu && n0.lambda == la && n0.kappa == 0.0);                   // public constants as in the reference
     }
     // TetGen round trip (0-based) and a 1-based file with a flipped tet

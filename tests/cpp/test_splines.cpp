@@ -2,7 +2,8 @@
 //   * xu::StVK(mu, lambda, 0) is the StVK model: SplineTet(..., StVK spline) and StVKTet give the same trajectory;
 //   * xu::NeoHookean likewise against NeoHookeanTet; xu::CoRotated runs and pulls a stretched cube back;
 //   * the spline's own constants are used (a stiffer spline than the tet's Lame changes the result);
-//   * kappa != 0 has no kernel: Solver::initialize throws instead of running something else.
+//   * a compression term (kappa != 0) changes the result and stays finite; a user-defined spline has no kernel:
+//     Solver::initialize refuses instead of running something else.
 #include <cmath>
 #include <cstdio>
 #include <iostream>
@@ -62,8 +63,19 @@ int main() {
         check(finite && std::fabs((xmax - xmin) - 1.0) < 0.05, "SplineTet(xu::CoRotated): the cube stretched by 1.2 along x is back near its rest length");
     }
     {
-        run([&](const Vec4i &t, const std::vector<Vec3> &v) { return std::make_shared<SplineTet>(t, v, lame, std::make_shared<xu::StVK>(lame.mu, lame.lambda, 100.0)); }, 1, t0);
-        check(t0, "kappa != 0: initialize refuses (no kernel, no CPU fallback)");
+        VecX a = run([&](const Vec4i &t, const std::vector<Vec3> &v) { return std::make_shared<SplineTet>(t, v, lame, std::make_shared<xu::StVK>(lame.mu, lame.lambda, 0.0)); }, 5, t0);
+        VecX b = run([&](const Vec4i &t, const std::vector<Vec3> &v) { return std::make_shared<SplineTet>(t, v, lame, std::make_shared<xu::StVK>(lame.mu, lame.lambda, 50.0 * lame.mu)); }, 5, t1);
+        bool finite = !t0 && !t1;
+        for (int i = 0; finite && i < b.size(); ++i) finite = std::isfinite(b[i]);
+        check(finite && maxdiff(a, b) > 1e-9, "SplineTet(xu::StVK, kappa != 0): runs on the GPU, finite, and the compression term changes the result");
+    }
+    {
+        struct MySpline : xu::Spline {   // a user-defined spline: no kernel
+            double f(double x) const { return x * x; } double g(double) const { return 0; } double h(double) const { return 0; }
+            double df(double x) const { return 2 * x; } double dg(double) const { return 0; } double dh(double) const { return 0; }
+        };
+        run([&](const Vec4i &t, const std::vector<Vec3> &v) { return std::make_shared<SplineTet>(t, v, lame, std::make_shared<MySpline>()); }, 1, t0);
+        check(t0, "user-defined spline: initialize refuses (no kernel, no CPU fallback)");
     }
     std::printf(fail ? "FAILURE\n" : "SUCCESS\n");
     return fail ? 1 : 0;

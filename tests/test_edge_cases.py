@@ -110,3 +110,34 @@ def test_error_paths_keep_the_reference_messages():
     bad.m[:] = 0.0
     with pytest.raises(pkg.AdmmHipError, match="mass"):
         bad.make_solver()
+
+
+@pytest.mark.gpu
+def test_barrier_timeout_falls_back_and_replays(monkeypatch):
+    """the persistent PCG kernel needs its blocks co-resident; when a grid barrier cannot complete (here:
+    injected with the test hook ADMM_HIP_TEST_ABORT_SOLVE) the context must not fail the step -- it switches to the
+    launch-per-iteration PCG, restores the last good state and replays the steps issued since, also when those steps
+    were issued without statistics (asynchronously)."""
+    import scenes
+    sc = scenes.mixed_cube_scene(8, admm_iters=6, linsolver=0)
+    ref = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=2000)
+    for _ in range(4):
+        ref.step()
+    monkeypatch.setenv("ADMM_HIP_TEST_ABORT_SOLVE", "15")     # 3rd frame, 3rd ADMM iteration
+    s = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=2000)
+    monkeypatch.delenv("ADMM_HIP_TEST_ABORT_SOLVE")
+    s.upload()
+    for _ in range(3):
+        s.step_device(stats=False)          # asynchronous: the time-out is only seen at the next synchronisation
+    s.step_device(stats=True)
+    s.download()
+    assert np.isfinite(s.m_x).all()
+    assert scenes.rel_err(s.m_x, ref.m_x) < 1e-8, scenes.rel_err(s.m_x, ref.m_x)
+    assert s.runtime_data().unconverged_solves == 0
+    # the same with the time-out inside a step that asks for statistics
+    monkeypatch.setenv("ADMM_HIP_TEST_ABORT_SOLVE", "8")
+    s2 = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=2000)
+    monkeypatch.delenv("ADMM_HIP_TEST_ABORT_SOLVE")
+    for _ in range(4):
+        s2.step()
+    assert scenes.rel_err(s2.m_x, ref.m_x) < 1e-8

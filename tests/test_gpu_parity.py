@@ -14,7 +14,6 @@ from oracle import oracle as orc
 import scenes
 
 pytestmark = pytest.mark.gpu
-GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.npz")
 KINDS = {"linear": pkg.TET_LINEAR, "neohookean": pkg.TET_NEOHOOKEAN, "stvk": pkg.TET_STVK, "spline": pkg.TET_SPLINE_NH,
          "spline_stvk": pkg.TET_SPLINE_STVK, "spline_corotated": pkg.TET_SPLINE_COROTATED}
 
@@ -62,8 +61,8 @@ def test_local_step_mixed_materials_and_rhs():
 
 
 def test_local_step_tris_pins_and_golden():
-    import test_oracle_vs_ref as T
-    verts, tris, x, u0, mu, la, limits = T.tri_case()
+    import ref_cases as R
+    verts, tris, x, u0, mu, la, limits = R.tri_case()
     sc = scenes.Scene()
     lame = Lame(100.0, 0.1); lame.limit_min, lame.limit_max = limits
     sc.add_tri_mesh(verts, tris, lame)
@@ -75,9 +74,62 @@ def test_local_step_tris_pins_and_golden():
     zo = np.zeros(o.R); uo = uu.copy()
     o.local_step(x.ravel(), zo, uo)
     assert np.abs(z - zo).max() < 1e-11 and np.abs(u - uo).max() < 1e-11
-    g = np.load(GOLD)   # what the real reference TriEnergyTerm returned for this input
+    g = R.ref_out("tri0")   # what the real reference TriEnergyTerm returned for this input
     n = 6 * len(tris)
-    assert np.abs(z[:n] - g["tri_z"]).max() < 1e-11 and np.abs(u[:n] - g["tri_u"]).max() < 1e-11
+    assert np.abs(z[:n] - g["z"]).max() < 1e-11 and np.abs(u[:n] - g["u"]).max() < 1e-11
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_tri_local_step_vs_reference_vectors(case):
+    """k_local_tris against what the REAL TriEnergyTerm.cpp returned (tests/golden/ref_vectors.npz: with strain limits,
+    without, and with a one-sided limit) -- not through the oracle."""
+    import ref_cases as R
+    limits = R.TRI_LIMITS[case]
+    verts, tris, x, u0, mu, la, _ = R.tri_case(limits=limits)
+    sc = scenes.Scene()
+    lame = Lame(100.0, 0.1); lame.limit_min, lame.limit_max = limits
+    sc.add_tri_mesh(verts, tris, lame)
+    s = sc.make_solver()
+    z, u = s.local_step(x.ravel(), u0)
+    g = R.ref_out("tri%d" % case)
+    assert np.abs(z - g["z"]).max() < 1e-11 and np.abs(u - g["u"]).max() < 1e-11
+
+
+def test_pin_local_step_vs_reference_vectors():
+    """The SpringPin local step fused into k_gather_rhs against what the REAL SpringEnergyTerm.hpp returned (active and
+    inactive pins, non-zero duals; rows 3..5 of a pin block are never populated by the reference)."""
+    import ref_cases as R
+    nv, x, vidx, pins, act, u = R.pin_case()
+    sc = scenes.Scene()
+    verts, tets = pkg.meshes.kuhn_cube(1)          # the pins need a scene: one cell of tets on vertices 0..7 (+ 2 free nodes)
+    sc.x = np.concatenate([verts, [[2.0, 2.0, 2.0], [3.0, 3.0, 3.0]]]); sc.m = np.ones(nv)
+    sc.tets.append((verts, tets, Lame.soft_rubber(), pkg.TET_LINEAR, 0))
+    for v, p in zip(vidx, pins):
+        sc.pins[int(v)] = p.copy()
+    s = sc.make_solver()
+    # inactive pin: Solver::set_pins with the active subset (src/Solver.cpp:126-156)
+    on = [int(v) for v, a_ in zip(vidx, act) if a_]
+    s.set_pins(on, [sc.pins[v] for v in on])
+    R_ = s.num_rows()
+    uu = np.zeros(R_); uu[R_ - 18:] = u
+    z, un = s.local_step(x, uu)
+    g = R.ref_out("pin")
+    rows = np.array([0, 1, 2, 6, 7, 8, 12, 13, 14])
+    assert np.abs(z[R_ - 18:][rows] - g["z"][rows]).max() < 1e-13 and np.abs(un[R_ - 18:][rows] - g["u"][rows]).max() < 1e-13
+
+
+def test_global_solve_vs_eigen_ldlt_vector():
+    """The on-chip PCG against the solution the REAL Eigen::SimplicialLDLT (LDLTSolver, src/LinearSolver.hpp:79-90) returned
+    for the same assembled system and right-hand side."""
+    import ref_cases as R
+    o, A, b = R.ldlt_case()
+    sc = scenes.Scene()
+    verts, tets = pkg.meshes.kuhn_cube(3)
+    sc.add_tet_mesh(verts, tets, Lame.soft_rubber(), pkg.TET_NEOHOOKEAN)
+    s = sc.make_solver(pcg_tol=1e-13, pcg_max_iters=2000)
+    x, it = s.global_solve(b, np.zeros_like(b))
+    xr = R.ref_out("ldlt")["x"]
+    assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
 
 
 def test_global_solve_pcg_matches_exact():
@@ -155,6 +207,46 @@ def test_step_parity_spline_tets(kind):
         s.step(); o.step()
     assert scenes.rel_err(s.m_x, o.x) < 1e-7, scenes.rel_err(s.m_x, o.x)
     assert np.abs(s.m_x - sc.x.ravel()).max() > 1e-3      # it moved
+
+
+@pytest.mark.parametrize("kind", ["spline", "spline_stvk", "spline_corotated"])
+def test_spline_tets_with_compression_term(kind):
+    """SplineTet with a spline constructed with kappa != 0 (compression term, src/XuSpline.hpp:43-45; the reference's own
+    constructors pass 0): kernel-level local step (stretched, compressed and inverted tets) and whole steps against the
+    oracle, whose spline functions are pinned on the real XuSpline.hpp with kappa != 0 (tests/test_oracle_vs_ref.py).
+    The kappa term must matter (results differ from kappa = 0)."""
+    kd = KINDS[kind]
+    sc = scenes.cube_scene(4, kd, admm_iters=10, linsolver=0)
+    verts, tets, lame, _, off = sc.tets[0]
+    spline = Lame(2.0e7, 0.3)
+    kappa = 40.0 * spline.mu
+
+    def make(kap):
+        s = pkg.Solver()
+        s.add_nodes(sc.x, sc.masses3())
+        s.add_tets(verts, tets, lame, kd, spline=spline, kappa=kap)
+        s.set_pins(list(sc.pins.keys()), [sc.pins[k] for k in sc.pins])
+        st = scenes.Settings(**sc.settings); st.pcg_tol = 1e-11; st.pcg_max_iters = 400
+        assert s.initialize(st)
+        return s
+    s, s0 = make(kappa), make(0.0)
+    o = orc.OracleSolver(sc.x, sc.masses3(), admm_iters=10, linsolver=0, pins=sc.pins, mode=1,
+                         tets=dict(idx=tets, verts=sc.x, kind=np.full(len(tets), kd, np.int32), mu=spline.mu, la=spline.lambda_,
+                                   k=lame.bulk_modulus(), kappa=kappa))
+    # kernel level: compressed / stretched / a few inverted elements, non-zero duals
+    rng = np.random.default_rng(12)
+    x = (sc.x * np.array([0.7, 1.2, 0.8]) + 0.03 * rng.standard_normal(sc.x.shape))
+    x[5] = x[5] + np.array([0.9, -0.4, 0.3])          # drags its tets through inversion
+    u0 = np.zeros(s.num_rows()); u0[:9 * len(tets)] = 0.02 * rng.standard_normal(9 * len(tets))
+    z, u = s.local_step(x.ravel(), u0)
+    zo = np.zeros(o.R); uo = u0.copy()
+    o.local_step(x.ravel(), zo, uo)
+    assert np.abs(z - zo).max() < 5e-8 and np.abs(u - uo).max() < 5e-8, (np.abs(z - zo).max(), np.abs(u - uo).max())
+    z0, _ = s0.local_step(x.ravel(), u0)
+    assert np.abs(z - z0).max() > 1e-4                # the compression term is not a no-op
+    for _ in range(3):
+        s.step(); o.step()
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7, scenes.rel_err(s.m_x, o.x)
 
 
 def test_tet_order_does_not_matter():

@@ -143,3 +143,50 @@ def test_rccl_allreduce_path_on_one_gpu():
         s.step()
     assert np.array_equal(s.m_x, ref.m_x)
     assert s.runtime_data().unconverged_solves == 0
+
+
+def _rccl_worker(rank, world, port, n, frames, q):
+    """One rank of a real multi-GPU run: own device, RCCL communicator, product contexts."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # only carries the 128-byte RCCL id
+    sc = scenes.mixed_cube_scene(n, admm_iters=6, linsolver=0)
+    s = sc.make_solver(device=rank, rank=rank, world_size=world, pcg_tol=1e-10, pcg_max_iters=500)
+    s.comm_init(dist)
+    for _ in range(frames):
+        s.step()
+    q.put((rank, s.m_x.copy(), s.runtime_data().unconverged_solves))
+    dist.barrier()
+    s.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_two_gpus_match_single_context():
+    """A real world-2 step (element-block partition, ncclAllReduce of the partial right-hand side over xGMI between the
+    gather kernel and the persistent PCG kernel, replicated solve) on two devices reproduces the single-context
+    trajectory.  Needs two GPUs: skipped on the 1-GPU test boxes, run wherever the driver has a multi-GPU node."""
+    if pkg.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    import torch.multiprocessing as mp
+    n, frames, world = 6, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, n, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sc = scenes.mixed_cube_scene(n, admm_iters=6, linsolver=0)
+    ref = sc.make_solver(pcg_tol=1e-10, pcg_max_iters=500)
+    for _ in range(frames):
+        ref.step()
+    for rank, x, unconv in res:
+        assert unconv == 0
+        assert scenes.rel_err(x, ref.m_x) < 1e-9, (rank, scenes.rel_err(x, ref.m_x))   # summation order of the partial RHS differs
+    assert np.array_equal(res[0][1], res[1][1])      # the replicated solves see the same all-reduced right-hand side

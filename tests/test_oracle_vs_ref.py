@@ -1,60 +1,30 @@
-"""Pins the C restatement (oracle/admm_oracle.c) against the REAL reference sources compiled in
-place into oracle/_ref/libadmm_ref.so (oracle/ref_driver.cpp): FastSVD.hpp signed_svd,
-TriEnergyTerm.cpp, SpringEnergyTerm.hpp, EnergyTerm::update, ConstraintSet::make_matrix,
-Collider::detect, XuSpline.hpp, Eigen::SimplicialLDLT -- and against the golden vectors those
-produced (tests/golden/ref_vectors.npz, generated by tests/golden/make_golden.py)."""
-import ctypes as C
-import os
-
+"""Pins the C restatement (oracle/admm_oracle.c) against the REAL reference: FastSVD.hpp signed_svd, TriEnergyTerm.cpp,
+SpringEnergyTerm.hpp, EnergyTerm::update, ConstraintSet::make_matrix, Collider::detect, XuSpline.hpp,
+Eigen::SimplicialLDLT, Lame.  The reference's outputs come from tests/ref_cases.py: LIVE from the reference sources
+compiled in place (oracle/_ref/libadmm_ref.so) where /root/reference exists -- and then also checked against the stored
+file -- and from tests/golden/ref_vectors.npz (tests/golden/make_golden.py) everywhere else, so a clean clone pins
+exactly as much as the build container."""
 import numpy as np
 import pytest
 import scipy.sparse as sp
 
 from oracle import oracle as orc
-from admm_elastic_amd import meshes
-
-GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_vectors.npz")
-dp = orc.dp
+import ref_cases as R
+from ref_cases import _p, _i, ref_out, svd_cases, tri_case  # noqa: F401
 
 
-def _p(a):
-    return a.ctypes.data_as(orc.dp)
+def test_golden_file_is_complete_and_current():
+    """Every case has stored vectors; where the live reference exists they agree with it (ref_out asserts that)."""
+    stored = set(k.split("/")[0] for k in R.gold().files)
+    assert stored == set(R.CASES), stored ^ set(R.CASES)
+    for name in R.CASES:
+        assert ref_out(name)
 
 
-def _i(a):
-    return a.ctypes.data_as(orc.ip)
-
-
-@pytest.fixture(scope="module")
-def ref():
-    L = orc.ref_lib()
-    if L is None:
-        pytest.skip("oracle/_ref not built (reference sources absent on this box)")
-    return L
-
-
-@pytest.fixture(scope="module")
-def gold():
-    return np.load(GOLD)
-
-
-def svd_cases():
-    rng = np.random.default_rng(7)
-    cases = [rng.standard_normal((3, 3)) for _ in range(40)]
-    cases += [np.eye(3), np.diag([2.0, 1.0, 0.5]), -np.eye(3), np.diag([1.0, 1.0, -1.0]), np.diag([3.0, 3.0, 1.0]),
-              np.diag([1.0, 1e-9, 1e-9]), np.zeros((3, 3)), 1e-8 * rng.standard_normal((3, 3))]
-    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
-    cases += [q, -q, q @ np.diag([1.5, 1.5, 0.2]), q @ np.diag([1.0, 0.7, -0.3]) @ q.T]
-    return cases
-
-
-def test_signed_svd_matches_reference(ref):
-    for F in svd_cases():
+def test_signed_svd_matches_reference():
+    g = ref_out("svd")
+    for F, Sr, Ur, Vr in zip(g["F"], g["S"], g["U"], g["V"]):
         U, S, V = orc.signed_svd3(F)
-        a = np.ascontiguousarray(F.T).copy()
-        Ur = np.zeros(9); Sr = np.zeros(3); Vr = np.zeros(9)
-        ref.ref_signed_svd(_p(a), _p(Sr), _p(Ur), _p(Vr))
-        Ur = Ur.reshape(3, 3).T; Vr = Vr.reshape(3, 3).T
         scale = max(1.0, np.abs(F).max())
         assert np.allclose(S, Sr, atol=1e-12 * scale), (F, S, Sr)
         assert np.allclose(U @ np.diag(S) @ V.T, F, atol=1e-12 * scale)
@@ -64,31 +34,14 @@ def test_signed_svd_matches_reference(ref):
             assert np.allclose(np.abs(np.sum(U * Ur, axis=0)), 1.0, atol=1e-9)
 
 
-def test_signed_svd_matches_golden(gold):
-    for F, Sr in zip(gold["svd_F"], gold["svd_S"]):
-        U, S, V = orc.signed_svd3(F)
-        assert np.allclose(S, Sr, atol=1e-12 * max(1.0, np.abs(F).max()))
-
-
-def tri_case(m=6, seed=3, limits=(0.95, 1.05)):
-    verts, tris = meshes.cloth_grid(m, 1.0, 0.5)
-    rng = np.random.default_rng(seed)
-    verts = verts + 0.02 * rng.standard_normal(verts.shape)       # non-trivial rest shapes
-    x = verts + 0.1 * rng.standard_normal(verts.shape)
-    u = 0.05 * rng.standard_normal(6 * len(tris))
-    mu, la, _ = orc.lame(100.0, 0.1)
-    return verts, tris, x, u, mu, la, limits
-
-
-@pytest.mark.parametrize("limits", [(0.95, 1.05), (-100.0, 100.0), (0.5, 1.01)])
-def test_tri_local_step_matches_reference(ref, limits):
+@pytest.mark.parametrize("case", range(len(R.TRI_LIMITS)))
+def test_tri_local_step_matches_reference(case):
+    limits = R.TRI_LIMITS[case]
     verts, tris, x, u, mu, la, _ = tri_case(limits=limits)
     n, nv = len(tris), len(verts)
-    zr = np.zeros(6 * n); ur = u.copy(); w = np.zeros(n)
-    tr, tc, tv = np.zeros(18 * n, np.int32), np.zeros(18 * n, np.int32), np.zeros(18 * n)
-    nnz = ref.ref_tri_local_step(n, _i(np.ascontiguousarray(tris)), nv, _p(np.ascontiguousarray(verts)), mu, la,
-                                 limits[0], limits[1], _p(np.ascontiguousarray(x)), _p(zr), _p(ur), _p(w), _i(tr), _i(tc), _p(tv))
-    assert nnz == 18 * n
+    g = ref_out("tri%d" % case)
+    zr, ur, w, tr, tc, tv = g["z"], g["u"], g["w"], g["D_row"], g["D_col"], g["D_val"]
+    assert int(g["nnz"][0]) == 18 * n
     o = orc.OracleSolver(x, np.ones(3 * nv), tris=dict(idx=tris, verts=verts, mu=mu, la=la, limit_min=limits[0], limit_max=limits[1]))
     z = np.zeros(6 * n); uo = u.copy()
     o.local_step(x.ravel(), z, uo)
@@ -98,36 +51,23 @@ def test_tri_local_step_matches_reference(ref, limits):
     assert np.allclose(z, zr, atol=1e-12) and np.allclose(uo, ur, atol=1e-12)
 
 
-def test_tri_matches_golden(gold):
-    verts, tris, x, u, mu, la, limits = tri_case()
-    o = orc.OracleSolver(x, np.ones(3 * len(verts)), tris=dict(idx=tris, verts=verts, mu=mu, la=la, limit_min=limits[0], limit_max=limits[1]))
-    z = np.zeros(6 * len(tris)); uo = u.copy()
-    o.local_step(x.ravel(), z, uo)
-    assert np.allclose(z, gold["tri_z"], atol=1e-12) and np.allclose(uo, gold["tri_u"], atol=1e-12)
-
-
-def test_pin_local_step_matches_reference(ref):
-    rng = np.random.default_rng(5)
-    nv = 10
-    x = rng.standard_normal(3 * nv)
-    vidx = np.array([2, 7, 4], np.int32); pins = rng.standard_normal((3, 3)); act = np.array([1, 0, 1], np.int32)
-    u = np.zeros(18); u[[0, 1, 2, 6, 7, 8, 12, 13, 14]] = rng.standard_normal(9)
-    zr = np.zeros(18); ur = u.copy()
-    w = ref.ref_pin_local_step(3, _i(vidx), _p(pins), _i(act), nv, _p(x), _p(zr), _p(ur))
-    assert abs(w - orc.PIN_WEIGHT) < 1e-9
+def test_pin_local_step_matches_reference():
+    nv, x, vidx, pins, act, u = R.pin_case()
+    g = ref_out("pin")
+    zr, ur = g["z"], g["u"]
+    assert abs(float(g["w"][0]) - orc.PIN_WEIGHT) < 1e-9
     z = np.zeros(18); uo = u.copy()
     orc.lib().orc_local_pins(3, _i(vidx), _p(pins), _i(act), _p(x), _p(z), _p(uo))
     rows = [0, 1, 2, 6, 7, 8, 12, 13, 14]  # rows 3..5 of a SpringPin block are never populated
     assert np.allclose(z[rows], zr[rows], atol=1e-14) and np.allclose(uo[rows], ur[rows], atol=1e-14)
 
 
-def test_floor_constraints_match_reference(ref):
-    rng = np.random.default_rng(9)
-    nv = 50
-    x = rng.standard_normal((nv, 3))
-    for cw in (1.0, 37.5):
-        rv = np.zeros(nv, np.int32); rc = np.zeros(nv); coef = np.zeros(3 * nv)
-        rows = ref.ref_floor_constraints(nv, _p(np.ascontiguousarray(x)), -0.2, cw, nv, _i(rv), _p(rc), _p(coef))
+def test_floor_constraints_match_reference():
+    x, y0 = R.floor_case()
+    nv = len(x)
+    for case, cw in enumerate(R.FLOOR_CW):
+        g = ref_out("floor%d" % case)
+        rows, rv, rc, coef = int(g["rows"][0]), g["vert"], g["c"], g["coef"].ravel()
         o = orc.OracleSolver(x, np.ones(3 * nv), linsolver=2, constraint_w=cw, obstacles=[(0, [-0.2, 0, 0, 0])])
         hits = o.detect_passive(x.ravel())
         Cm, c = o.make_matrix(hits)
@@ -139,17 +79,10 @@ def test_floor_constraints_match_reference(ref):
             assert abs(cv - rc[r]) < 1e-13 and np.allclose(co, coef[3 * r:3 * r + 3], atol=1e-14)
 
 
-def test_exact_solve_matches_eigen_ldlt(ref):
+def test_exact_solve_matches_eigen_ldlt():
     """scipy SuperLU (oracle's LDLT stand-in) vs the real Eigen::SimplicialLDLT on an assembled A."""
-    verts, tets = meshes.kuhn_cube(3)
-    mu, la, _ = orc.lame(1e7, 0.399)
-    m = np.repeat(meshes.lumped_masses_tets(verts, tets), 3)
-    o = orc.OracleSolver(verts, m, tets=dict(idx=tets, verts=verts, kind=1, mu=mu, la=la))
-    A = o.A.tocsr(); A.sort_indices()
-    b = np.random.default_rng(1).standard_normal(A.shape[0])
-    x = np.zeros_like(b)
-    rc = ref.ref_ldlt_solve(A.shape[0], _i(A.indptr.astype(np.int32)), _i(A.indices.astype(np.int32)), _p(A.data), 1, _p(b), _p(x))
-    assert rc == 0
+    o, A, b = R.ldlt_case()
+    x = ref_out("ldlt")["x"]
     xo = o.solve_ldlt(b)
     assert np.linalg.norm(x - xo) <= 1e-9 * np.linalg.norm(xo)
     # A = M + Ahat (x) I3: no cross-axis coupling (SURVEY 8-a2)
@@ -157,15 +90,23 @@ def test_exact_solve_matches_eigen_ldlt(ref):
     assert np.all(coo.row % 3 == coo.col % 3)
 
 
-def test_xu_neohookean_spline_is_the_nh_model(ref):
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_xu_splines_match_reference(which):
+    """f, g, h, df, dg, dh of xu::NeoHookean / StVK / CoRotated (src/XuSpline.hpp:48-96) with and without the compression
+    term (kappa != 0, :44-45): the Python restatement against the real header's values."""
+    mu, la, _ = orc.lame(1e6, 0.3)
+    for case, kappa in enumerate(R.SPLINE_KAPPAS):
+        tab = ref_out("spline%d_%d" % (which, case))["fgh"]
+        for x, row in zip(R.SPLINE_X, tab):
+            got = np.array(orc.xu_spline(which, mu, la, kappa, float(x)))
+            assert np.allclose(got, row, rtol=1e-13, atol=1e-9 * (1.0 + np.abs(row).max())), (which, kappa, x, got, row)
+
+
+def test_xu_neohookean_spline_is_the_nh_model():
     """SplineTet's default spline (TetEnergyTerm.hpp:191-195) equals NeoHookeanTet's density."""
     mu, la, k = orc.lame(1e6, 0.3)
-    out = np.zeros(6)
     for s in ([1.1, 0.9, 1.3], [0.5, 0.6, 2.0]):
-        e = 0.0
-        for si in s:
-            ref.ref_xu_spline(0, mu, la, 0.0, si, _p(out)); e += out[0]
-        ref.ref_xu_spline(0, mu, la, 0.0, s[0] * s[1] * s[2], _p(out)); e += out[2]
+        e = sum(orc.xu_spline(0, mu, la, 0.0, si)[0] for si in s) + orc.xu_spline(0, mu, la, 0.0, s[0] * s[1] * s[2])[2]
         x0 = np.array(s)
         v1 = orc.lib().orc_prox_value(1, mu, la, k, _p(x0), _p(x0))
         v3 = orc.lib().orc_prox_value(3, mu, la, k, _p(x0), _p(x0))
@@ -173,15 +114,15 @@ def test_xu_neohookean_spline_is_the_nh_model(ref):
 
 
 @pytest.mark.parametrize("which,kind", [(0, 3), (1, 4), (2, 5)])
-def test_xu_spline_prox_objective_matches_reference(ref, which, kind):
-    """SplineTet::SplineProx::value / gradient (TetEnergyTerm.cpp:243-265) assembled from the REAL xu::NeoHookean / StVK /
-    CoRotated (src/XuSpline.hpp, kappa = 0) against the oracle's kinds 3 / 4 / 5; and xu::StVK is the StVK model."""
+@pytest.mark.parametrize("kappa", R.SPLINE_KAPPAS)
+def test_xu_spline_prox_objective_matches_reference(which, kind, kappa):
+    """SplineTet::SplineProx::value / gradient (TetEnergyTerm.cpp:243-265) assembled from the xu:: spline functions (pinned
+    on the real src/XuSpline.hpp above, kappa = 0 and kappa != 0) against the oracle's kinds 3 / 4 / 5; and xu::StVK is the
+    StVK model."""
     mu, la, k = orc.lame(1e6, 0.3)
-    out = np.zeros(6)
 
     def spl(x):
-        ref.ref_xu_spline(which, mu, la, 0.0, float(x), _p(out))
-        return out.copy()     # f, g, h, df, dg, dh
+        return orc.xu_spline(which, mu, la, kappa, float(x))     # f, g, h, df, dg, dh
     rng = np.random.default_rng(5)
     for _ in range(20):
         x = rng.uniform(0.4, 1.8, 3); x0 = rng.uniform(0.4, 1.8, 3)
@@ -192,17 +133,16 @@ def test_xu_spline_prox_objective_matches_reference(ref, which, kind):
             spl(x[0])[3] + spl(x[0] * x[1])[4] * x[1] + spl(x[2] * x[0])[4] * x[2] + hp * x[1] * x[2] + k * (x[0] - x0[0]),
             spl(x[1])[3] + spl(x[1] * x[2])[4] * x[2] + spl(x[0] * x[1])[4] * x[0] + hp * x[2] * x[0] + k * (x[1] - x0[1]),
             spl(x[2])[3] + spl(x[2] * x[0])[4] * x[0] + spl(x[1] * x[2])[4] * x[1] + hp * x[0] * x[1] + k * (x[2] - x0[2])])
-        vo = orc.lib().orc_prox_value(kind, mu, la, k, _p(x0), _p(x))
+        vo = orc.lib().orc_prox_value_k(kind, mu, la, k, kappa, _p(x0), _p(x))
         go = np.zeros(3)
-        orc.lib().orc_prox_gradient(kind, mu, la, k, _p(x0), _p(x), _p(go))
+        orc.lib().orc_prox_gradient_k(kind, mu, la, k, kappa, _p(x0), _p(x), _p(go))
         assert abs(vo - val) <= 1e-12 * abs(val) + 1e-9
         assert np.abs(go - grad).max() <= 1e-12 * np.abs(grad).max() + 1e-9
-        if kind == 4:       # the same numbers as StVKTet::StVKProx (TetEnergyTerm.cpp:210-237)
+        if kind == 4 and kappa == 0.0:       # the same numbers as StVKTet::StVKProx (TetEnergyTerm.cpp:210-237)
             assert abs(orc.lib().orc_prox_value(2, mu, la, k, _p(x0), _p(x)) - vo) <= 1e-9 * abs(vo)
 
 
-def test_lame_matches_reference(ref):
-    mu, la, k = C.c_double(), C.c_double(), C.c_double()
-    for E, nu in ((1e7, 0.499), (1e7, 0.399), (1e6, 0.299), (100.0, 0.1)):
-        ref.ref_lame(E, nu, C.byref(mu), C.byref(la), C.byref(k))
-        assert np.allclose(orc.lame(E, nu), (mu.value, la.value, k.value), rtol=1e-15)
+def test_lame_matches_reference():
+    tab = ref_out("lame")["mlk"]
+    for (E, nu), row in zip(R.LAME_CASES, tab):
+        assert np.allclose(orc.lame(E, nu), row, rtol=1e-15)
