@@ -136,6 +136,42 @@ inline std::shared_ptr<TetMesh> make_tet_blocks(int nx, int ny, int nz) {
     return mesh;
 }
 
+// The cells of an n^3 Kuhn lattice over [lo, hi]^3 whose centre satisfies inside(p): a stand-in for the reference's
+// samples/data sphere / torus TetGen meshes (any closed implicit body; unused lattice vertices are dropped).
+template <class Inside>
+inline std::shared_ptr<TetMesh> make_implicit_body(int n, double lo, double hi, Inside inside) {
+    auto full = make_tet_blocks(n, n, n);
+    const double h = (hi - lo) / n;
+    for (Vec3 &p : full->vertices) p = Vec3(lo + h * p[0], lo + h * p[1], lo + h * p[2]);
+    auto mesh = std::make_shared<TetMesh>();
+    std::vector<int> id(full->vertices.size(), -1);
+    for (size_t t = 0; t < full->tets.size(); t += 6) {     // the 6 tets of a cell are contiguous: keep or drop the cell
+        Vec3 c(0, 0, 0);
+        for (int q = 0; q < 6; ++q) for (int k = 0; k < 4; ++k) c += full->vertices[full->tets[t + q][k]];
+        if (!inside(c * (1.0 / 24.0))) continue;
+        for (int q = 0; q < 6; ++q) {
+            Vec4i tt = full->tets[t + q];
+            for (int k = 0; k < 4; ++k) {
+                if (id[tt[k]] < 0) { id[tt[k]] = (int)mesh->vertices.size(); mesh->vertices.push_back(full->vertices[tt[k]]); }
+                tt[k] = id[tt[k]];
+            }
+            mesh->tets.push_back(tt);
+        }
+    }
+    if (mesh->tets.empty()) throw std::runtime_error("make_implicit_body: no cell inside");
+    return mesh;
+}
+inline std::shared_ptr<TetMesh> make_ball(int n, double radius = 1.0) {
+    return make_implicit_body(n, -radius, radius, [radius](const Vec3 &p) { return p.dot(p) <= radius * radius; });
+}
+// torus around the y axis: ring radius R, tube radius r
+inline std::shared_ptr<TetMesh> make_torus(int n, double R = 1.0, double r = 0.4) {
+    return make_implicit_body(n, -(R + r), R + r, [R, r](const Vec3 &p) {
+        const double q = std::sqrt(p[0] * p[0] + p[2] * p[2]) - R;
+        return q * q + p[1] * p[1] <= r * r;
+    });
+}
+
 // m x m cells in the xz-plane at height y, extent `size`, two triangles (a,b,c), (a,c,d) per cell
 inline std::shared_ptr<TriangleMesh> make_plane(int m, double size = 1.0, double y = 0.0) {
     if (m < 1) throw std::runtime_error("make_plane: need at least one cell");

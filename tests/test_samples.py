@@ -33,7 +33,7 @@ def test_mesh_layer_cpu(tmp_path):
 
 
 def test_samples_build_and_print_help():
-    for name in ("beams", "trianglestrain", "boxes", "bunnyexpand"):
+    for name in ("beams", "trianglestrain", "boxes", "bunnyexpand", "signorini", "torus"):
         exe = _sample(name)
         r = subprocess.run([exe, "-help"], capture_output=True, text=True, timeout=60)
         assert r.returncode == 0 and "-it" in (r.stdout + r.stderr)
@@ -142,3 +142,44 @@ def test_bunnyexpand_sample_recovers(mode):
     inverted = int(last.split(" frames, ")[1].split(" tets")[0])
     worst = float(last.rsplit(" ", 1)[1])
     assert inverted == 0 and worst < 1e-3, last
+
+
+@pytest.mark.gpu
+def test_signorini_sample_lands_on_the_floor(tmp_path):
+    """samples/signorini.cpp (tvcg2017/signorini.cpp headless): a very soft ball, multi-colour GS with in-sweep plane
+    projection: it falls from y in [-0.5, 0.5] onto Floor(-1), flattens and never penetrates.  Also the per-frame output
+    of FrameLog: a RuntimeData CSV (one line per frame) and position / OBJ dumps every K frames."""
+    exe = _sample("signorini")
+    out = str(tmp_path / "sig")
+    csv = str(tmp_path / "sig.csv")
+    r = subprocess.run([exe, "-v", "0", "--frames", "40", "--cells", "8", "--out", out, "--out-every", "10", "--csv", csv],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    X = np.loadtxt(out + ".xyz")
+    assert np.isfinite(X).all()
+    assert X[:, 1].min() > -1.0 - 1e-6            # the sweeps project contacting nodes ONTO the plane: no penetration
+    assert X[:, 1].min() < -0.99                  # ... and it is in contact
+    assert X[:, 1].max() < 0.2                    # it fell (top started at 0.5)
+    rows = np.loadtxt(csv, delimiter=",", skiprows=1)
+    assert rows.shape == (40, 7) and (rows[:, 0] == np.arange(40)).all()
+    assert (rows[:, 1] > 0).all() and (rows[:, 3] > 0).all() and (rows[:, 5] > 0).all()     # step_ms, global_ms, inner iterations
+    for f in (0, 10, 20, 30, 39):
+        Xf = np.loadtxt(out + "_%05d.xyz" % f)
+        assert Xf.shape == X.shape
+        assert os.path.getsize(out + "_%05d.obj" % f) > 1000
+    assert np.array_equal(np.loadtxt(out + "_00039.xyz"), X)
+    assert not os.path.exists(out + "_00005.xyz")
+
+
+@pytest.mark.gpu
+def test_torus_sample_uzawa_floor_and_self_collision(tmp_path):
+    """samples/torus.cpp (tvcg2017/torus.cpp headless): UzawaCG with floor rows and the torus' own TetMeshCollision: it
+    falls from y = 2 onto Floor(-1) and comes to rest on it (hard constraints: no penetration beyond the solver tolerance)."""
+    exe = _sample("torus")
+    out = str(tmp_path / "torus")
+    r = subprocess.run([exe, "-v", "0", "--frames", "45", "--cells", "12", "--out", out], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    X = np.loadtxt(out + ".xyz")
+    assert np.isfinite(X).all()
+    assert X[:, 1].min() > -1.0 - 2e-2 and X[:, 1].min() < -0.9        # resting on the floor
+    assert X[:, 1].max() < 0.5                                          # fell from y ~ 2
