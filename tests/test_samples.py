@@ -162,7 +162,8 @@ def test_signorini_sample_lands_on_the_floor(tmp_path):
     assert X[:, 1].max() < 0.2                    # it fell (top started at 0.5)
     rows = np.loadtxt(csv, delimiter=",", skiprows=1)
     assert rows.shape == (40, 7) and (rows[:, 0] == np.arange(40)).all()
-    assert (rows[:, 1] > 0).all() and (rows[:, 3] > 0).all() and (rows[:, 5] > 0).all()     # step_ms, global_ms, inner iterations
+    assert (rows[:, 1] > 0).all() and (rows[:, 3] > 0).all()          # step_ms, global_ms
+    assert (rows[:, 5] >= 0).all() and rows[:, 5].max() > 0           # inner iterations (free fall: the first sweep's residual test passes at once)
     for f in (0, 10, 20, 30, 39):
         Xf = np.loadtxt(out + "_%05d.xyz" % f)
         assert Xf.shape == X.shape
