@@ -208,7 +208,8 @@ struct admm_hip_ctx {
     // UzawaCG (per-vertex constraint rows)
     DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part;
     DevBuf<UzScal> uz_scal;
-    int uz_prev_hits = -1, uz_last_hits = 0, NBU = 1, uz_iters_step = 0;
+    int uz_prev_hits = -1, uz_last_hits = 0, NBU = 1, uz_iters_step = 0, uz_prev_iters = 0;
+    bool uz_freeze = false, uz_detected = false;   // tests (ADMM_HIP_UZ_FREEZE=1): Collider::detect only in the first ADMM iteration of a step
     // GS: the whole solve (colours x sweeps + residual tests, ~500 tiny launches) is captured once into a
     // hipGraph and replayed -- the per-colour kernels are far below the host launch rate
     hipGraphExec_t gs_exec = nullptr;
@@ -388,7 +389,7 @@ int oc_diagnostics(admm_hip_ctx *c, int seq) {
     return 0;
 }
 
-struct OcRc { bool on = false; RcBasis B{}; double *Eslot = nullptr, *Rslot = nullptr; };
+struct OcRc { bool on = false; RcBasis B{}; double *Eslot = nullptr, *Rslot = nullptr; const int *skip = nullptr; };
 
 // General-mesh plan: k_pcg2 (pcg_onchip2.hpp)
 int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, const OcRc &rc) {
@@ -410,6 +411,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.rc_on = rc.on ? 1 : 0; a.rc = rc.B; a.rc_xs = c->rc_xs.p; a.rc_r0 = c->rc_r0.p; a.rc_Eslot = rc.Eslot; a.rc_Rslot = rc.Rslot;
     a.rc_part = c->oc_rc_part.p;
     if (c->oc_coarse) { a.ainv = c->oc_ainv.p; a.cbuf = c->oc_cbuf.p; a.nc = c->oc_nc; a.ncp = c->oc_ncp; }
+    a.skip = rc.skip;
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg2<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     c->last_launched_iters = 0;
@@ -607,8 +609,8 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     return hipSuccess;
 }
 
-int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
-    if (c->oc_enabled) return launch_pcg_onchip(c, b, x, max_iters);
+int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters, const int *skip = nullptr) {
+    if (c->oc_enabled) { OcRc rc; rc.skip = skip; return launch_pcg_onchip(c, b, x, max_iters, rc); }
     hipStream_t st = c->stream;
     const SellA A = sell_arg(c->A);
     const int NB = c->NB;
@@ -705,7 +707,9 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     const double *dbary = dyn ? c->dyn_bary.p : nullptr;
     const int nq = c->n_surf > 0 ? c->n_surf : nv, gq = blocks_for(nq);
     const int *qlist = c->n_surf > 0 ? c->surf_list.p : nullptr;
-    if (c->obst.n > 0 || dyn) {
+    if (c->uz_freeze && c->uz_detected) nh = c->uz_last_hits;     // frozen active set: the rows of this step's first detect
+    else if (c->obst.n > 0 || dyn) {
+        c->uz_detected = true;
         // Collider::detect at the current iterate + ConstraintSet::make_matrix (ck = sqrt(constraint_w))
         const double ck = std::sqrt(std::max(0.0, c->constraint_w));
         if (c->timing && hipEventRecord(c->ev_coll0, st) != hipSuccess) return -1;
@@ -738,22 +742,35 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     if (hipMemsetAsync(c->uz_scal.p, 0, sizeof(UzScal), st) != hipSuccess) return -1;
     const double tol2 = c->uz_tol * c->uz_tol;
     UzScal h{};
-    for (int it = 0; it < c->uz_max_iters; ++it) {
-        hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 1, b, c->uz_cn.p, c->uz_d.p, c->uz_q1.p);   // q1 = C^T d
-        if (dyn) hipLaunchKernelGGL(k_uz_ct_dyn, dim3(gq), dim3(256), 0, st, nq, qlist, 1, c->uz_cn.p, c->uz_d.p, dface, dbary, c->uz_q1.p);
-        if (hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) return -1;
-        if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, c->pcg_max_iters)) return -1;                                  // q2 = A^-1 q1
-        hipLaunchKernelGGL(k_uz_dots, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_q2.p, c->uz_cn.p, c->uz_d.p, c->uz_r.p, c->uz_q3.p,
-                           c->uz_part.p, c->NBU, dface, dbary);
-        hipLaunchKernelGGL(k_uz_alpha, dim3(1), dim3(256), 0, st, c->uz_part.p, c->NBU, c->uz_scal.p);
-        hipLaunchKernelGGL(k_uz_step, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_scal.p, x, c->uz_q2.p, c->uz_y.p, c->uz_d.p, c->uz_r.p,
-                           c->uz_q3.p, c->uz_part.p, c->NBU);
-        hipLaunchKernelGGL(k_uz_beta, dim3(1), dim3(256), 0, st, c->uz_part.p, c->NBU, tol2, c->uz_scal.p);
-        hipLaunchKernelGGL(k_uz_dir, dim3(gv), dim3(256), 0, st, nv, c->uz_scal.p, c->uz_r.p, c->uz_d.p);
+    // Schur-complement CG (src/UzawaCG.hpp:92-120).  The stop decision is taken on the device (k_uz_beta / k_uz_alpha set
+    // UzScal::stop; every later kernel of the loop -- the inner PCG launch included -- is then a no-op), so the host does
+    // not synchronise per iteration: it enqueues as many iterations as the previous solve needed, looks at the flag, and
+    // continues two at a time.
+    const int *stop_flag = &c->uz_scal.p->stop;
+    int launched = 0;
+    int chunk = std::max(1, std::min(c->uz_max_iters, c->uz_prev_iters > 0 ? c->uz_prev_iters + 1 : 4));
+    while (launched < c->uz_max_iters) {
+        const int n = std::min(chunk, c->uz_max_iters - launched);
+        for (int it = 0; it < n; ++it) {
+            hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 1, b, c->uz_cn.p, c->uz_d.p, c->uz_q1.p);   // q1 = C^T d
+            if (dyn) hipLaunchKernelGGL(k_uz_ct_dyn, dim3(gq), dim3(256), 0, st, nq, qlist, 1, c->uz_cn.p, c->uz_d.p, dface, dbary, c->uz_q1.p);
+            if (hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) return -1;
+            if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, c->pcg_max_iters, stop_flag)) return -1;                       // q2 = A^-1 q1
+            hipLaunchKernelGGL(k_uz_dots, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_q2.p, c->uz_cn.p, c->uz_d.p, c->uz_r.p, c->uz_q3.p,
+                               c->uz_part.p, c->NBU, dface, dbary);
+            hipLaunchKernelGGL(k_uz_alpha, dim3(1), dim3(256), 0, st, c->uz_part.p, c->NBU, c->uz_scal.p);
+            hipLaunchKernelGGL(k_uz_step, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_scal.p, x, c->uz_q2.p, c->uz_y.p, c->uz_d.p, c->uz_r.p,
+                               c->uz_q3.p, c->uz_part.p, c->NBU);
+            hipLaunchKernelGGL(k_uz_beta, dim3(1), dim3(256), 0, st, c->uz_part.p, c->NBU, tol2, c->uz_scal.p);
+            hipLaunchKernelGGL(k_uz_dir, dim3(gv), dim3(256), 0, st, nv, c->uz_scal.p, c->uz_r.p, c->uz_d.p);
+        }
+        launched += n;
         if (hipMemcpyAsync(&h, c->uz_scal.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         if (h.stop) break;
+        chunk = 2;
     }
+    c->uz_prev_iters = h.iters;
     *iters = h.iters;
     return 0;
 }
@@ -1297,6 +1314,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         }
     }
     if (d->linsolver == 2) {
+        { const char *fz = getenv("ADMM_HIP_UZ_FREEZE"); c->uz_freeze = fz && fz[0] == '1'; }
         c->NBU = std::max(1, std::min((nv + 255) / 256, 256));
         HIP_TRY(c->uz_cn.alloc(c->n3)); HIP_TRY(c->uz_cn.zero());
         HIP_TRY(c->uz_q1.alloc(c->n3)); HIP_TRY(c->uz_q2.alloc(c->n3)); HIP_TRY(c->uz_q2.zero());
@@ -1562,7 +1580,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     if (timed && !c->ev_coll0) { HIP_TRY(hipEventCreate(&c->ev_coll0)); HIP_TRY(hipEventCreate(&c->ev_coll1)); }
     HIP_TRY(hipEventRecord(c->ev_step0, st));
     // counters[5] (closed chunks) must stay monotone across steps: only [0..4] are reset
-    c->uz_iters_step = 0;
+    c->uz_iters_step = 0; c->uz_detected = false;
     c->rc_prev_valid = c->rc_iter; c->rc_frame += 1; c->rc_iter = 0;   // this frame's pairs become "previous frame"
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
     hipLaunchKernelGGL(k_predict, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, c->dt, gravity, c->x.p, c->v.p, c->m.p,

@@ -1266,6 +1266,7 @@ __global__ __launch_bounds__(256) void k_uz_dots(int nv, const double *__restric
 // alpha = d.r / d.q3 (stop when the denominator vanishes, UzawaCG.hpp:103-105)
 __global__ __launch_bounds__(256) void k_uz_alpha(const double *__restrict__ part, int NBp, UzScal *sc) {
     __shared__ double lds[8];
+    if (sc->stop) return;
     double q[2] = {0.0, 0.0};
     for (int i = threadIdx.x; i < NBp; i += 256) { q[0] += part[i]; q[1] += part[NBp + i]; }
     block_sum<2>(q, lds);

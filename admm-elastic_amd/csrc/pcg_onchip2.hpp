@@ -51,6 +51,8 @@ struct Oc2Args {
     double tol2;
     int rc_on; RcBasis rc; double *rc_xs, *rc_r0, *rc_Eslot, *rc_Rslot, *rc_part;   // recycled warm start (internal rows)
     const double *ainv; double *cbuf; int nc, ncp;   // two-level: [nc][ncp] coarse inverse, [2][3][ncp] published aggregate sums
+    const int *skip;     // optional: *skip != 0 (set by an earlier kernel of the stream, e.g. UzawaCG's stop flag) makes the
+                         // launch a no-op -- lets the host enqueue outer iterations ahead without synchronising
 };
 
 constexpr int kOc2Scratch = 4096;   // bytes of LDS scratch ahead of the local vector and the matrix slab
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
     const int ub = a.n_rows * 32;           // bytes of one published-vector buffer
     __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void *)a.ubuf, 0, 2 * ub, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)a.part, 0, 2 * 8 * a.G * 8, 0x00020000);
-    const bool two_level = a.ainv != nullptr && a.nc <= 2 * T && kOcTrig * a.tol2 >= kOcPipeFloor;
+    const bool two_level = a.ainv != nullptr && a.nc <= 2 * T;
     __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void *)a.cbuf, 0, a.cbuf ? 2 * 3 * a.ncp * 8 : 0, 0x00020000);
 
     double rx[3], ru[3], rw[3], rp[3], rsv[3], rz[3], rq[3], rr[3], rd[3], rm[3];
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
     }
     unsigned *const bar = a.bar + 32 * 16 * (a.seq & 1);
     if (blockIdx.x == 0 && tid < 9) a.bar[32 * 16 * ((a.seq & 1) ^ 1) + 16 * (tid < 8 ? tid : 17)] = 0u;
+    if (a.skip && *a.skip) return;    // (after the clearing above: the next launch counts on the set this one cleared)
     if (tid < 3 * kOcSubK) { yw[tid] = 0.0; yz[tid] = 0.0; ycur[tid] = 0.0; }
     unsigned ph = 0;     // publish phase of the vector: buffer parity = ph & 1, tag of the neighbour flags
     unsigned be = 0;     // grid-barrier epoch (arrivals of this block so far); record parity = be & 1
@@ -463,110 +466,145 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
         AinvRows ar;   // this block's rows of Ac^-1 stay in registers for the whole loop
         if (two_level) ainv_prefetch(ar);
         // ---- pipelined CG (general recurrences of Ghysels & Vanroose: r and q = M^-1 s carried explicitly) with the
-        //      two-level (or, without a coarse space, the Jacobi) preconditioner.  Used down to a relative residual of 1e-9
-        //      (kOcPipeFloor); anything irregular hands over to the classic form below ----
-        if (kOcTrig * a.tol2 >= kOcPipeFloor) {
-            if (two_level) {
-                double y[3];
-                if (!coarse_apply(rw, y)) { aborted = true; break; }
-                if (tid < 3 * kOcSubK) { yw[tid] = ycur[tid]; yz[tid] = 0.0; }
-                __syncthreads();
-            }
-            double rho_best = 1e300;
-            while (iters < a.max_iters) {
-                OC2_STAMP(0);
-                double mm[3], rn[3], q[7];
-                q[6] = 0.0;
+        //      two-level (or, without a coarse space, the Jacobi) preconditioner.  The recurrences are trusted for nine orders
+        //      of magnitude per PASS (kOcPipeFloor): a pass ends when the recursive residual reports the tolerance -- or
+        //      1e-9 of the pass's starting residual, or stagnates -- and is followed by a verification on the TRUE residual;
+        //      if that fails the next pass restarts from the true residual (residual replacement), so tolerances below 1e-9
+        //      (UzawaCG's inner solves) still run in this form.  Anything irregular hands over to the classic form below ----
+        {
+            // u = M^-1 r, w = A u, y_w from the residual in rr / ru = D^-1 r (the state a pass starts from)
+            auto start_pass = [&](bool have_uw) -> bool {
+                if (!have_uw) {
+                    double y[3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    mm[j] = live ? fma(rd[j], rw[j], two_level ? yw[3 * myagg + j] : 0.0) : 0.0;   // m = M^-1 w
-                    q[j] = rr[j] * ru[j];                                                    // gamma = r . u
-                    q[3 + j] = rw[j] * ru[j];                                                // delta = w . u
-                    q[6] = fma(rr[j] * rd[j] * rr[j], ctl[8 + j], q[6]);                     // Jacobi-norm residual (stop test)
-                }
-                ++ph; publish(mm);
-                OC2_STAMP(1);
-                if (a.nbr) {
-                    if (!oc_announce_and_wait_neighbours<false>(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; }
-                } else {   // more than 64 neighbour blocks somewhere: a grid barrier orders the exchange
-                    ++be;
-                    if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
-                }
-                OC2_STAMP(2);
-                halo_and_rows(mm, rn);                                                       // n = A m
-                OC2_STAMP(3);
-                ++be;
-                const int par = (int)(be & 1u);
-                publish_record(q, two_level ? rn : nullptr, par);
-                OC2_STAMP(4);
-                if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
-                OC2_STAMP(5);
-                if (two_level) reduce_and_coarse(par, 7, ar);                                // the sums, and ycur = Ac^-1 P^T n
-                else reduce_records(par, 7);
-                OC2_STAMP(6);
-                if (wv == 0) {
-                    const int j = lane < 3 ? lane : 0;
-                    const double g = bc[j], d = bc[3 + j], rs = bc[6];
-                    const unsigned long long m3 = 7ull;
-                    const bool finite = (__ballot(g < 1e290 && g >= 0.0 && d < 1e290) & m3) == m3 && rs < 1e290 && !(rs > 1e16 * rho_best);
-                    int act = 0;
-                    if (!finite) act = 2;
-                    else if (rs <= kOcTrig * a.tol2) act = 1;
-                    else if (lane < 3) {
-                        double alpha, beta;
-                        if (fresh) { beta = 0.0; alpha = (d > 0.0) ? g / d : 0.0; }
-                        else {
-                            const double gp = sc[j], ap = sc[3 + j];
-                            beta = (gp > 0.0) ? g / gp : 0.0;
-                            const double den = (ap != 0.0) ? d - beta * g / ap : d;
-                            alpha = (den > 0.0) ? g / den : 0.0;
-                        }
-                        sc[j] = g; sc[3 + j] = alpha; glast[j] = g;
-                        ctl[2 + j] = alpha; ctl[5 + j] = beta;
+                    for (int j = 0; j < 3; ++j) rr[j] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
+                    if (two_level) {
+                        if (!coarse_apply(rr, y)) return false;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) ru[j] += y[j];
                     }
-                    rho_best = fmin(rho_best, rs);
-                    if (lane == 0) ictl[2] = act;
+                    ++ph; ++be; publish(ru);
+                    if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return false;
+                    halo_and_rows(ru, rw);
+                    __syncthreads();
                 }
-                const int act = action();
-                if (act == 2) { entry_restart = true; go_classic = true; break; }
-                if (act == 1) {
-                    const int v = verify();
-                    if (v < 0) { aborted = true; break; }
-                    if (v == 1) { conv = true; break; }
-                    go_classic = true; fresh = true;     // the true residual replaces the recursive one: restart (beta = 0)
-                    break;
+                if (two_level) {
+                    double y[3];
+                    if (!coarse_apply(rw, y)) return false;
+                    if (tid < 3 * kOcSubK) { yw[tid] = ycur[tid]; yz[tid] = 0.0; }
+                    __syncthreads();
                 }
+                return true;
+            };
+            int passes = 0;
+            double pass_start = 0.0;     // sum over the axes of r . D^-1 r / b . D^-1 b at the start of the pass
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double alpha = ctl[2 + j], beta = ctl[5 + j];
-                    rz[j] = fma(beta, rz[j], rn[j]);
-                    rq[j] = fma(beta, rq[j], mm[j]);
-                    rsv[j] = fma(beta, rsv[j], rw[j]);
-                    rp[j] = fma(beta, rp[j], ru[j]);
-                    rx[j] = fma(alpha, rp[j], rx[j]);
-                    rr[j] = fma(-alpha, rsv[j], rr[j]);
-                    ru[j] = fma(-alpha, rq[j], ru[j]);
-                    rw[j] = fma(-alpha, rz[j], rw[j]);
+            for (int j = 0; j < 3; ++j) pass_start = fma(bc[j], ctl[8 + j], pass_start);
+            bool have_uw = true;         // the start phase above left u = M^-1 r and w = A u
+            while (!aborted && !conv && !go_classic && iters < a.max_iters) {
+                if (!start_pass(have_uw)) { aborted = true; break; }
+                have_uw = false;
+                const double target = fmax(kOcTrig * a.tol2, kOcPipeFloor * pass_start);
+                double rho_best = 1e300;
+                int since = 0;
+                bool next_pass = false;
+                while (iters < a.max_iters) {
+                    OC2_STAMP(0);
+                    double mm[3], rn[3], q[7];
+                    q[6] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        mm[j] = live ? fma(rd[j], rw[j], two_level ? yw[3 * myagg + j] : 0.0) : 0.0;   // m = M^-1 w
+                        q[j] = rr[j] * ru[j];                                                    // gamma = r . u
+                        q[3 + j] = rw[j] * ru[j];                                                // delta = w . u
+                        q[6] = fma(rr[j] * rd[j] * rr[j], ctl[8 + j], q[6]);                     // Jacobi-norm residual (stop test)
+                    }
+                    ++ph; publish(mm);
+                    OC2_STAMP(1);
+                    if (a.nbr) {
+                        if (!oc_announce_and_wait_neighbours<false>(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; }
+                    } else {   // more than 64 neighbour blocks somewhere: a grid barrier orders the exchange
+                        ++be;
+                        if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    }
+                    OC2_STAMP(2);
+                    halo_and_rows(mm, rn);                                                       // n = A m
+                    OC2_STAMP(3);
+                    ++be;
+                    const int par = (int)(be & 1u);
+                    publish_record(q, two_level ? rn : nullptr, par);
+                    OC2_STAMP(4);
+                    if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    OC2_STAMP(5);
+                    if (two_level) reduce_and_coarse(par, 7, ar);                                // the sums, and ycur = Ac^-1 P^T n
+                    else reduce_records(par, 7);
+                    OC2_STAMP(6);
+                    if (wv == 0) {
+                        const int j = lane < 3 ? lane : 0;
+                        const double g = bc[j], d = bc[3 + j], rs = bc[6];
+                        const unsigned long long m3 = 7ull;
+                        const bool finite = (__ballot(g < 1e290 && g >= 0.0 && d < 1e290) & m3) == m3 && rs < 1e290 && !(rs > 1e16 * rho_best);
+                        since = rs < rho_best ? 0 : since + 1;
+                        int act = 0;
+                        if (!finite) act = 2;
+                        else if (rs <= target || since >= kOcStagnation) act = 1;
+                        else if (lane < 3) {
+                            double alpha, beta;
+                            if (fresh) { beta = 0.0; alpha = (d > 0.0) ? g / d : 0.0; }
+                            else {
+                                const double gp = sc[j], ap = sc[3 + j];
+                                beta = (gp > 0.0) ? g / gp : 0.0;
+                                const double den = (ap != 0.0) ? d - beta * g / ap : d;
+                                alpha = (den > 0.0) ? g / den : 0.0;
+                            }
+                            sc[j] = g; sc[3 + j] = alpha; glast[j] = g;
+                            ctl[2 + j] = alpha; ctl[5 + j] = beta;
+                        }
+                        rho_best = fmin(rho_best, rs);
+                        if (lane == 0) ictl[2] = act;
+                    }
+                    const int act = action();
+                    if (act == 2) { entry_restart = true; go_classic = true; break; }
+                    if (act == 1) {
+                        const int v = verify();      // leaves u = D^-1 (true residual)
+                        if (v < 0) { aborted = true; break; }
+                        if (v == 1) { conv = true; break; }
+                        fresh = true;                // the true residual replaces the recursive one: beta = 0
+                        if (++passes >= 4) { go_classic = true; break; }
+                        pass_start = 3.0 * ctl[1];   // (the largest axis ratio of the verification, as a bound of the sum)
+                        next_pass = true;
+                        break;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double alpha = ctl[2 + j], beta = ctl[5 + j];
+                        rz[j] = fma(beta, rz[j], rn[j]);
+                        rq[j] = fma(beta, rq[j], mm[j]);
+                        rsv[j] = fma(beta, rsv[j], rw[j]);
+                        rp[j] = fma(beta, rp[j], ru[j]);
+                        rx[j] = fma(alpha, rp[j], rx[j]);
+                        rr[j] = fma(-alpha, rsv[j], rr[j]);
+                        ru[j] = fma(-alpha, rq[j], ru[j]);
+                        rw[j] = fma(-alpha, rz[j], rw[j]);
+                    }
+                    if (two_level && tid < 3 * kOcSubK) {
+                        const int j = tid % 3;
+                        const double zz = fma(ctl[5 + j], yz[tid], ycur[tid]);
+                        yz[tid] = zz;
+                        yw[tid] = fma(-ctl[2 + j], zz, yw[tid]);
+                    }
+                    __syncthreads();   // yw is read, ctl / bc / ycur / the local vector are rewritten by the next iteration
+                    ++iters; ++pipe_iters; fresh = false;
+                    OC2_STAMP(7);
+                    if (prof) ++prof_n;
                 }
-                if (two_level && tid < 3 * kOcSubK) {
-                    const int j = tid % 3;
-                    const double zz = fma(ctl[5 + j], yz[tid], ycur[tid]);
-                    yz[tid] = zz;
-                    yw[tid] = fma(-ctl[2 + j], zz, yw[tid]);
-                }
-                __syncthreads();   // yw is read, ctl / bc / ycur / the local vector are rewritten by the next iteration
-                ++iters; ++pipe_iters; fresh = false;
-                OC2_STAMP(7);
-                if (prof) ++prof_n;
+                if (!next_pass) break;
             }
             if (!conv && !go_classic && !aborted) {   // iteration cap: leave u = D^-1 r behind (epilogue, recycled pair)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) ru[j] = rd[j] * rr[j];
             }
             if (aborted || conv || !go_classic) break;
-        } else {   // tolerances below the pipelined floor: classic form from the start; u = D^-1 r
-#pragma unroll
-            for (int j = 0; j < 3; ++j) ru[j] = rd[j] * rr[j];
         }
         // ---- classic (Hestenes-Stiefel) CG with the Jacobi preconditioner, three synchronisations per iteration: gamma =
         // r . u, then p, s = A p and delta = p . s computed directly (stable end game on ill-conditioned systems) ----

@@ -39,6 +39,10 @@ WORKLOADS = {
     # pulling triangulation, carved by an implicit bunny-like surface; valences 3..26), randomly numbered like a mesh file
     # and renumbered by renumber_for_locality like the samples do; NH / StVK by slab, feet pinned
     "blob1m_mix": dict(n=118, kinds="blob", linsolver=0, admm_iters=20),
+    # UzawaCG with ACTIVE constraints at scale (src/UzawaCG.hpp:92-120): the n=26 cube (105 456 tets, NH) dropped on a Floor,
+    # no pins; every ADMM iteration detects, builds C and runs the Schur-complement CG whose every iteration is one on-chip
+    # PCG solve.  Steady contact: ~700 constrained vertices.
+    "cube100k_uzawa_floor": dict(n=26, kinds="nh_floor", linsolver=2, admm_iters=20),
     "cube1m_linear": dict(n=55, kinds="linear", linsolver=0, admm_iters=20),   # diagnostic: cheapest prox
     "cube1m_stvk": dict(n=55, kinds="stvk", linsolver=0, admm_iters=20),
 }
@@ -56,6 +60,12 @@ def build_scene(w, n_override=None):
     if w["kinds"] == "blob":
         sc = scenes.blob_scene(n, admm_iters=w["admm_iters"], linsolver=w["linsolver"])
         return sc, sum(len(t[1]) for t in sc.tets), len(sc.x)
+    if w["kinds"] == "nh_floor":
+        sc = scenes.cube_scene(n, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=w["admm_iters"], linsolver=w["linsolver"])
+        sc.pins.clear()
+        sc.obstacles.append((0, [-0.02, 0.0, 0.0, 0.0]))
+        sc.settings.update(gravity=-9.8, timestep_s=1.0 / 24.0)
+        return sc, len(sc.tets[0][1]), len(sc.x)
     verts, tets = meshes.kuhn_cube(n)
     sc = scenes.Scene()
     sc.x = verts
@@ -233,6 +243,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload + (" (n=%d override)" % args.n if args.n else ""), "elements": nt, "verts": nv,
                    "admm_iters_per_step": iters, "global_solver": "multicolor-GS(30 sweeps)" if w["linsolver"] == 1 else
+                   "UzawaCG (Schur-complement CG, <= 20 iterations, stop decided on the device) over the on-chip PCG tol=%g" % args.pcg_tol if w["linsolver"] == 2 else
                    "PCG (one persistent on-chip launch per solve: two-level preconditioned pipelined CG, matrix and vectors in LDS) tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters),
                    "parallelism": "element-block x%d" % world if world > 1 else "single-gpu"},
         "ms_per_frame": ms_per_step,
@@ -249,7 +260,7 @@ def main():
             from admm_elastic_amd import meshes as _m
             tets_all = np.concatenate([t[1] + t[4] for t in sc.tets])
             out["config"]["vertex_valence"] = _m.valence_stats(nv, tets_all)   # edges per vertex (row of Ahat = valence + 1)
-        if not args.no_roofline and w["linsolver"] != 1 and world == 1:
+        if not args.no_roofline and w["linsolver"] == 0 and world == 1:
             # The time-dominant kernel: the whole PCG solve is ONE persistent launch whose matrix and vectors stay in LDS /
             # registers, so it has no HBM roofline; an iteration is two dependent synchronisations -- the vector exchange
             # between neighbour blocks and the all-to-all of the block records behind one grid barrier.  Their latency floor

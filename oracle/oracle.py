@@ -539,10 +539,11 @@ class OracleSolver:
         curr = x_bar.copy()
         z = np.zeros(self.R); u = np.zeros(self.R)                # :70-71 (z = D x is a dead store)
         self.inner_iters = 0
-        for _ in range(self.admm_iters):
+        for it_ in range(self.admm_iters):
             self.local_step(curr, z, u)                           # :84-87
-            self._hits = self.detect_passive(curr) if self.linsolver != 1 else []   # :92-93
-            self._dhits = self.detect_dynamic(curr)
+            if it_ == 0 or not getattr(self, "freeze_active", False):   # (freeze_active: test mode, one detect per step)
+                self._hits = self.detect_passive(curr) if self.linsolver != 1 else []   # :92-93
+                self._dhits = self.detect_dynamic(curr)
             b = self.rhs(Mxbar, z, u)                             # :98
             curr, it = self.global_solve(curr, b)                 # :99
             self.inner_iters += it

@@ -395,6 +395,33 @@ def test_step_uzawa_collisions_loose():
     assert s.runtime_data().inner_iters > 8
 
 
+@pytest.mark.parametrize("what", ["cloth_floor", "cube_floor"])
+def test_step_uzawa_frozen_active_set_is_tight(what, monkeypatch):
+    """Whole UzawaCG steps with contact, with the chaos taken out: both sides run Collider::detect only in the FIRST ADMM
+    iteration of a step and keep those rows for the rest of it (GPU: ADMM_HIP_UZ_FREEZE=1, oracle: freeze_active) -- the
+    rest of the contact step (rows of C, multiplier warm start, Schur CG on the GPU PCG, local steps) then agrees with
+    the oracle as tightly as the contact-free steps do."""
+    if what == "cloth_floor":
+        sc = scenes.cloth_scene(8, floor=0.4613, admm_iters=8, linsolver=2)
+    else:
+        sc = scenes.cube_scene(3, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=8, linsolver=2, size=0.5)
+        for k in list(sc.pins):
+            del sc.pins[k]
+        sc.obstacles.append((0, [-0.0217, 0.0, 0.0, 0.0]))
+    monkeypatch.setenv("ADMM_HIP_UZ_FREEZE", "1")
+    s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=600)
+    monkeypatch.delenv("ADMM_HIP_UZ_FREEZE")
+    o = sc.make_oracle(mode=1)
+    o.freeze_active = True
+    hit_frames = 0
+    for _ in range(8):
+        s.step(); o.step()
+        hit_frames += 1 if len(o._hits) else 0
+    assert hit_frames >= 3, "scene meant to collide"
+    assert s.runtime_data().inner_iters > 8
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7, scenes.rel_err(s.m_x, o.x)
+
+
 def test_step_parity_beams_config1():
     """BASELINE configs[0] / samples/sca2016/beams.cpp: three 12x3x3-cell beams (1 944 tets), linear / NH /
     StVK, soft rubber, scaled to 1 m height and spread along y (beams.cpp:43-90), pins = all vertices within
@@ -523,17 +550,19 @@ def test_big_translation_equivariance(big):
 
 
 # ------------------------------------------------------------------------------------------------------
-# On-chip PCG (pcg_onchip.hpp: one persistent launch per solve) against the two-kernels-per-iteration path
-# and the exact solve.  Both paths run the same recurrence; only the summation order of the dot products
-# differs, so iteration counts agree to a few iterations and solutions to the solve tolerance.
-def _solve_both(sc, b, x0, **kw):
+# On-chip PCG (pcg_onchip2.hpp: one persistent launch per solve) against the two-kernels-per-iteration path
+# and the exact solve: same system, same stop rule on the true residual, solutions agree to the solve tolerance.
+def _solve_both(sc, b, x0, env=None, **kw):
     out = []
     for launches in ("0", "1"):
         os.environ["ADMM_HIP_PCG_LAUNCHES"] = launches
+        os.environ.update(env or {})
         try:
             s = sc.make_solver(**kw)
         finally:
             os.environ.pop("ADMM_HIP_PCG_LAUNCHES", None)
+            for k in (env or {}):
+                os.environ.pop(k, None)
         x, it = s.global_solve(b, x0)
         x2, it2 = s.global_solve(b, x0)          # the persistent state (barrier words, u buffer) is reusable
         assert it2 == it and np.array_equal(x, x2)   # and the solve is deterministic
@@ -548,7 +577,9 @@ def test_onchip_pcg_matches_launch_path_and_exact(n, kind):
     rng = np.random.default_rng(77 + n)
     b = o.A @ rng.standard_normal(o.dof)
     (x_oc, it_oc), (x_l, it_l) = _solve_both(sc, b, np.zeros(o.dof), pcg_tol=1e-12, pcg_max_iters=2000)
-    assert 0 < it_oc < 2000 and abs(it_oc - it_l) <= max(3, it_l // 20), (it_oc, it_l)
+    # (the launch path is Jacobi-preconditioned; the on-chip kernel's two-level preconditioner needs fewer iterations, and
+    # never more than a few above it on systems too small for a coarse space to matter)
+    assert 0 < it_oc < 2000 and it_oc <= it_l + max(3, it_l // 20), (it_oc, it_l)
     xo = o.solve_ldlt(b)
     assert np.linalg.norm(x_oc - xo) <= 1e-8 * np.linalg.norm(xo)
     assert np.linalg.norm(x_oc - x_l) <= 1e-9 * np.linalg.norm(xo)
@@ -559,13 +590,16 @@ def test_onchip_pcg_unconverged_and_cloth():
     sc = scenes.cloth_scene(40)
     o = sc.make_oracle()
     b = o.A @ np.random.default_rng(3).standard_normal(o.dof)
-    (x_oc, it_oc), (x_l, it_l) = _solve_both(sc, b, np.zeros(o.dof), pcg_tol=1e-12, pcg_max_iters=7)
+    # with the same (Jacobi) preconditioner the two paths are the same Krylov method: same iterate after 7 iterations
+    (x_oc, it_oc), (x_l, it_l) = _solve_both(sc, b, np.zeros(o.dof), env={"ADMM_HIP_OC_COARSE": "0"}, pcg_tol=1e-12, pcg_max_iters=7)
     assert it_oc == 7 and it_l == 7
     assert np.linalg.norm(x_oc - x_l) <= 1e-9 * np.linalg.norm(x_l)
+    (x_oc, it_oc), (x_l, it_l) = _solve_both(sc, b, np.zeros(o.dof), pcg_tol=1e-12, pcg_max_iters=7)
+    assert it_oc == 7 and it_l == 7                        # two-level: also stopped by the cap, reported as such
     (x_oc, it_oc), (x_l, it_l) = _solve_both(sc, b, np.zeros(o.dof), pcg_tol=1e-11, pcg_max_iters=5000)
     xo = o.solve_ldlt(b)
     assert np.linalg.norm(x_oc - xo) <= 1e-7 * np.linalg.norm(xo)
-    assert abs(it_oc - it_l) <= max(3, it_l // 20), (it_oc, it_l)
+    assert 0 < it_oc <= it_l + max(3, it_l // 20), (it_oc, it_l)
 
 
 def _free_stiff_bodies(cells=3):
@@ -728,7 +762,7 @@ def test_onchip_pcg_1024_thread_variant_and_global_columns():
         x, it = s.global_solve(b, np.zeros(3 * nv))
         res.append((x, it)); s.close()
     (x_oc, it_oc), (x_l, it_l) = res
-    assert 0 < it_oc < 3000 and abs(it_oc - it_l) <= max(3, it_l // 20), (it_oc, it_l)
+    assert 0 < it_oc < 3000 and it_oc <= it_l + max(3, it_l // 20), (it_oc, it_l)   # (two-level on chip, Jacobi on the launch path)
     X = x_oc.reshape(-1, 3)
     r = b.reshape(-1, 3) - (m * X + Ah @ X)
     dinv = 1.0 / (m + Ah.diagonal()[:, None])
