@@ -362,6 +362,10 @@ int oc_diagnostics(admm_hip_ctx *c, int seq) {
     if (c->oc_plan) {   // k_pcg2: eight stamps per pipelined iteration
         fprintf(stderr, "[oc_prof] seq %d: LDS fill %.2f  start phase %.2f  loop + end game %.2f  epilogue %.2f us\n", seq, us(63 * 8 + 1, 63 * 8), us(63 * 8 + 2, 63 * 8 + 1),
                 us(63 * 8 + 3, 63 * 8 + 2), us(63 * 8 + 4, 63 * 8 + 3));
+        if (h[62 * 8 + 6] > h[62 * 8])
+            fprintf(stderr, "[oc_prof] start: entry residual %.2f  recycled sums %.2f  barrier %.2f  reduce + Cholesky %.2f  coarse(r) %.2f  u exchange + rows %.2f  record %.2f  barrier + reduce + coarse(w) %.2f us\n",
+                    us(62 * 8, 63 * 8 + 1), us(62 * 8 + 1, 62 * 8), us(62 * 8 + 2, 62 * 8 + 1), us(62 * 8 + 3, 62 * 8 + 2), us(62 * 8 + 4, 62 * 8 + 3),
+                    us(62 * 8 + 5, 62 * 8 + 4), us(62 * 8 + 6, 62 * 8 + 5), us(63 * 8 + 2, 62 * 8 + 6));
         double d[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int n = 0;
         for (int it = 0; it + 1 < 62 && h[(it + 1) * 8] > h[it * 8 + 7] && h[it * 8 + 7] > h[it * 8]; ++it, ++n) {
             for (int k = 0; k < 7; ++k) d[k] += us(it * 8 + k + 1, it * 8 + k);

@@ -297,8 +297,9 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
     // leaves r . D^-1 r (and optionally b . D^-1 b) in q[0..5]
     auto true_residual = [&](bool with_bnorm, double *q, double *ri_out) -> bool {
         double ax[3];
-        ++ph; ++be; publish(rx);
-        if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return false;
+        ++ph; publish(rx);
+        if (a.nbr) { if (!oc_announce_and_wait_neighbours<false>(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) return false; }
+        else { ++be; if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return false; }
         halo_and_rows(rx, ax);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                         r[jj][ax] = on ? a.rc.R[jj][3 * (size_t)row + ax] : 0.0;
                     }
                 if (!true_residual(true, q, ri)) { aborted = true; break; }
+                if (prof) a.prof[62 * 8 + 0] = wall_clock64();
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     bj[j] = live ? a.b[3 * (size_t)vi + j] : 0.0;
@@ -355,14 +357,39 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                         block_sums24(q24);
                         if (tid < 24) oc_store_sc1(rs_r, ((24 * g24 + tid) * a.G + (int)blockIdx.x) * 8, res24[tid]);
                     }
+                    if (prof) a.prof[62 * 8 + 1] = wall_clock64();
                     ++be;
                     if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    if (prof) a.prof[62 * 8 + 2] = wall_clock64();
                     double *sums = (double *)(smem + kOc2Scratch);   // [3 kRcQ + 2 + 3 kRc] in the (idle) local vector
-                    for (int k = wv; k < 3 * kRcQ; k += nw) {
-                        double sm = 0.0;
-                        for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_r, (k * a.G + g) * 8);
-                        sm = wave_sum(sm);
-                        if (lane == 0) sums[k] = sm;
+                    {   // every block adds the G partials of every sum in the same order; wave wv takes sums wv, wv + nw, ...:
+                        // all loads first, one round trip
+                        double v[6][4];
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) {
+                            const int k = wv + nw * t;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int g = lane + 64 * j;
+                                v[t][j] = (k < 3 * kRcQ && g < a.G) ? oc_load_sc1_f64(rs_r, (k * a.G + g) * 8) : 0.0;
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < 6; ++t) {
+                            const int k = wv + nw * t;
+                            if (k < 3 * kRcQ) {
+                                double sm = ((v[t][0] + v[t][1]) + v[t][2]) + v[t][3];
+                                for (int g = lane + 256; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_r, (k * a.G + g) * 8);
+                                sm = wave_sum(sm);
+                                if (lane == 0) sums[k] = sm;
+                            }
+                        }
+                        for (int k = wv + 6 * nw; k < 3 * kRcQ; k += nw) {   // blocks with fewer than 11 waves
+                            double sm = 0.0;
+                            for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_r, (k * a.G + g) * 8);
+                            sm = wave_sum(sm);
+                            if (lane == 0) sums[k] = sm;
+                        }
                     }
                     __syncthreads();
                     double *coefL = sums + 3 * kRcQ + 2;   // [3][kRc]
@@ -393,6 +420,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                 }
             }
             // r explicitly; u = M^-1 r (q stays the Jacobi norm)
+            if (prof) a.prof[62 * 8 + 3] = wall_clock64();
 #pragma unroll
             for (int j = 0; j < 3; ++j) rr[j] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
             if (two_level) {
@@ -401,12 +429,26 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) ru[j] += y[j];
             }
-            ++ph; ++be; publish(ru);
-            publish_record(q, nullptr, (int)(be & 1u));
+            // u to the neighbours (hand-off, no barrier), w = A u, then ONE record: the stop-test sums and P^T w
+            if (prof) a.prof[62 * 8 + 4] = wall_clock64();
+            ++ph; publish(ru);
+            if (a.nbr) { if (!oc_announce_and_wait_neighbours<false>(bar, a.flags, a.nbr, (unsigned)a.seq, ph, ok_lds, a.sig)) { aborted = true; break; } }
+            else { ++be; if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; } }
+            halo_and_rows(ru, rw);                   // w = A u
+            if (prof) a.prof[62 * 8 + 5] = wall_clock64();
+            ++be;
+            publish_record(q, two_level ? rw : nullptr, (int)(be & 1u));
+            if (prof) a.prof[62 * 8 + 6] = wall_clock64();
         }
-        if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
-        halo_and_rows(ru, rw);                       // w = A u
-        reduce_records((int)(be & 1u), 6);
+        {
+            AinvRows ar0;
+            if (two_level) ainv_prefetch(ar0);
+            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            if (two_level) {
+                reduce_and_coarse((int)(be & 1u), 6, ar0);      // ... and y_w = Ac^-1 P^T w for the first pass
+                if (tid < 3 * kOcSubK) { yw[tid] = ycur[tid]; yz[tid] = 0.0; }
+            } else reduce_records((int)(be & 1u), 6);
+        }
         if (tid == 0) {
             // The three axes are independent systems with their own b . D^-1 b.  An axis whose right-hand side vanishes or is
             // > 15 orders below the largest one is measured against the largest one.  b = 0 altogether: the solution is x = 0.
@@ -473,7 +515,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
         //      (UzawaCG's inner solves) still run in this form.  Anything irregular hands over to the classic form below ----
         {
             // u = M^-1 r, w = A u, y_w from the residual in rr / ru = D^-1 r (the state a pass starts from)
-            auto start_pass = [&](bool have_uw) -> bool {
+            auto start_pass = [&](bool have_uw) -> bool {   // (have_uw: the start phase left u, w and y_w behind)
                 if (!have_uw) {
                     double y[3];
 #pragma unroll
@@ -488,7 +530,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                     halo_and_rows(ru, rw);
                     __syncthreads();
                 }
-                if (two_level) {
+                if (two_level && !have_uw) {
                     double y[3];
                     if (!coarse_apply(rw, y)) return false;
                     if (tid < 3 * kOcSubK) { yw[tid] = ycur[tid]; yz[tid] = 0.0; }
