@@ -21,6 +21,13 @@ def run(name, sc, frames, **kw):
     return ok and unconv == 0
 
 good = True
+sc, nt, nv = bench.build_scene(bench.WORKLOADS["blob1m_mix"], None)
+good &= run("blob1m_mix pcg 1e-8", sc, int(sys.argv[1]) if len(sys.argv) > 1 else 40, pcg_tol=1e-8, pcg_max_iters=2000)
+sc, nt, nv = bench.build_scene(bench.WORKLOADS["blob1m_mix"], 50)
+good &= run("blob77k pcg 1e-12, asynchronous steps", sc, 150, pcg_tol=1e-12, pcg_max_iters=3000)
+for n in (7, 13, 31, 47):     # block counts / waves per block around the plan's break points
+    sc, nt, nv = bench.build_scene(bench.WORKLOADS["cube1m_mix"], n)
+    good &= run("cube n=%d pcg 1e-10" % n, sc, 30, pcg_tol=1e-10, pcg_max_iters=3000)
 sc, nt, nv = bench.build_scene(bench.WORKLOADS["cube1m_mix"], None)
 good &= run("cube1m_mix pcg 1e-8", sc, int(sys.argv[1]) if len(sys.argv) > 1 else 40, pcg_tol=1e-8, pcg_max_iters=2000)
 sc, nt, nv = bench.build_scene(bench.WORKLOADS["cube1m_mix"], 20)
