@@ -69,6 +69,7 @@ SYMBOLS = [
     ("admm_hip_local_step", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
     ("admm_hip_global_solve", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int_p]),
     ("admm_hip_num_rows", C.c_int, [C.c_void_p]),
+    ("admm_hip_solve_totals", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("admm_hip_probe_sync", C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
     ("admm_hip_get_matrix", C.c_int, [C.c_void_p, c_int_p, c_int_p, c_double_p, c_int_p]),
     ("admm_hip_get_colors", C.c_int, [C.c_void_p, c_int_p, c_int_p]),
@@ -81,6 +82,7 @@ SYMBOLS = [
     ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     ("admm_host_greedy_coloring", C.c_int, [C.c_int32, c_int_p, c_int_p, c_int_p]),
     ("admm_host_locality_order", None, [C.c_int32, C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, c_double_p]),
+    ("admm_host_block_order", None, [C.c_int32, C.c_int32, C.c_int32, c_int_p, C.c_int32, c_int_p]),
     ("admm_host_oc_plan", C.c_int, [C.POINTER(Desc), C.c_int32, C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, C.POINTER(C.c_int64)]),
 ]
 
@@ -168,6 +170,14 @@ def locality_order(n_verts, elems):
     sb, sa = C.c_double(0), C.c_double(0)
     lib().admm_host_locality_order(n_verts, elems.shape[0], elems.shape[1], iptr(elems), iptr(new_id), C.byref(sb), C.byref(sa))
     return new_id, sb.value, sa.value
+
+
+def block_order(n_verts, elems, leaf=256):
+    """admm_host_block_order: new_id[n_verts] (hierarchical block order) for tets [n,4] or triangles [n,3]."""
+    elems = i32(elems)
+    new_id = np.zeros(n_verts, np.int32)
+    lib().admm_host_block_order(n_verts, elems.shape[0], elems.shape[1], iptr(elems), leaf, iptr(new_id))
+    return new_id
 
 
 def partition(n_items, world_size, rank):

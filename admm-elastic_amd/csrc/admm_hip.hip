@@ -1258,7 +1258,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->cg_p.zero()); HIP_TRY(c->cg_s.zero());
     HIP_TRY(c->part.alloc(6 * (size_t)c->NB)); HIP_TRY(c->part_b.alloc(3 * (size_t)c->NB));
     HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
-    HIP_TRY(c->counters.alloc(8 + 64)); HIP_TRY(c->counters.zero());
+    HIP_TRY(c->counters.alloc(8 + 64 + 8)); HIP_TRY(c->counters.zero());   // [72..74]: totals since create (on-chip PCG)
     if (d->linsolver != 1) HIP_TRY(plan_pcg_onchip(c));
     if (d->linsolver != 1) {
         const char *env = getenv("ADMM_HIP_NO_RECYCLE");
@@ -1795,6 +1795,20 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     return ADMM_HIP_OK;
 }
 
+int admm_hip_solve_totals(admm_hip_ctx *c, int64_t *solves, int64_t *converged, int64_t *inner_iters) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "solve_totals: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = settle(c)) return rc;
+    int h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(h, c->counters.p + 72, sizeof(h), hipMemcpyDeviceToHost));
+    const bool counted = c->oc_enabled && c->oc_plan;     // only the general-mesh on-chip PCG keeps these totals
+    if (solves) *solves = counted ? h[0] : -1;
+    if (converged) *converged = counted ? h[1] : -1;
+    if (inner_iters) *inner_iters = counted ? h[2] : -1;
+    return ADMM_HIP_OK;
+}
+
 int admm_hip_probe_sync(admm_hip_ctx *c, int32_t n, double *us_all_to_all, double *us_exchange, int64_t *plan_stats) {
     if (!c || n < 1) return fail(ADMM_HIP_ERR_ARG, "probe_sync: bad input");
     if (us_all_to_all) *us_all_to_all = 0.0;
@@ -1939,6 +1953,10 @@ void admm_host_lame(double youngs, double poisson, double *mu, double *lambda, d
 }
 int admm_host_greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color) {
     return admm_host::greedy_coloring(n, rowptr, col, color);
+}
+
+void admm_host_block_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t leaf, int32_t *new_id) {
+    admm_host::block_order(n_verts, n_elems, corners, idx, leaf, new_id);
 }
 
 void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id,

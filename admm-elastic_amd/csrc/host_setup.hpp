@@ -105,6 +105,10 @@ struct OcPlan {
 // A = Ahat (mass not included), mass3 [3 n]; lds_bytes = LDS one block may spend on its local vector and matrix slab
 OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_bytes, bool want_coarse);
 
+// Hierarchical block order of mesh vertices (oc_plan.cpp): compact leaves of ~leaf vertices from a recursive graph
+// bisection, leaves in recursion-tree order, breadth-first inside a leaf.  new_id[v] = position of vertex v.
+void block_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t leaf, int32_t *new_id);
+
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
 int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
 void lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);

@@ -143,6 +143,46 @@ bool spd_inverse(int n, std::vector<double> &a) {
 
 } // namespace
 
+// Hierarchical block order of mesh vertices (mesh preprocessing, admm_host_block_order): the vertices are split into compact
+// leaves of ~`leaf` vertices by the same recursive graph bisection the on-chip PCG uses for its blocks, leaves numbered in the
+// order of the recursion tree (neighbouring leaves are siblings), vertices inside a leaf breadth-first.  Against reverse
+// Cuthill-McKee the "active window" of a gather -- the span of indices the neighbours of a run of consecutive vertices touch
+// -- shrinks from a level-set front (thousands of vertices on an unstructured 1 M-tet body) to a few leaves.
+void block_order(int32_t nv, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t leaf, int32_t *new_id) {
+    Graph g;
+    {
+        std::vector<std::vector<int32_t> > adj(nv);
+        for (int e = 0; e < n_elems; ++e)
+            for (int a = 0; a < corners; ++a)
+                for (int b = 0; b < corners; ++b)
+                    if (a != b) adj[idx[(size_t)corners * e + a]].push_back(idx[(size_t)corners * e + b]);
+        g.ptr.assign(nv + 1, 0);
+        for (int32_t v = 0; v < nv; ++v) {
+            std::sort(adj[v].begin(), adj[v].end());
+            adj[v].erase(std::unique(adj[v].begin(), adj[v].end()), adj[v].end());
+            g.ptr[v + 1] = g.ptr[v] + (int32_t)adj[v].size();
+        }
+        g.adj.reserve(g.ptr[nv]);
+        for (int32_t v = 0; v < nv; ++v) g.adj.insert(g.adj.end(), adj[v].begin(), adj[v].end());
+    }
+    const int L = std::max(1, (nv + std::max(leaf, 1) - 1) / std::max(leaf, 1));
+    std::vector<int32_t> sizes(L), members(nv), part_of(nv, 0), mark(nv, 0);
+    for (int b = 0; b < L; ++b) sizes[b] = (int32_t)(((int64_t)nv * (b + 1)) / L - ((int64_t)nv * b) / L);
+    std::iota(members.begin(), members.end(), 0);
+    std::vector<char> seen(nv, 0);
+    int32_t next_id = 1;
+    bisect(g, members, sizes.data(), L, 0, mark, next_id, seen, part_of);
+    std::vector<std::vector<int32_t> > leaves(L);
+    for (int32_t v = 0; v < nv; ++v) leaves[part_of[v]].push_back(v);
+    int32_t next = 0;
+    std::vector<int32_t> order;
+    for (int b = 0; b < L; ++b) {
+        if (leaves[b].empty()) continue;
+        bfs_order(g, leaves[b], mark, mark[leaves[b][0]], leaves[b][0], seen, order);
+        for (int32_t v : order) new_id[v] = next++;
+    }
+}
+
 OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_bytes, bool want_coarse) {
     OcPlan P;
     const int32_t nv = A.n;

@@ -751,6 +751,8 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
             atomicMax(a.counters + 3, iters);
             a.counters[8 + (a.seq & 63)] = iters;
         }
+        // totals since admm_hip_create (never reset: admm_hip_solve_totals)
+        atomicAdd(a.counters + 72, 1); atomicAdd(a.counters + 73, o.converged); atomicAdd(a.counters + 74, iters);
         if (prof) a.prof[63 * 8 + 4] = wall_clock64();
     }
 }

@@ -103,13 +103,18 @@ def lumped_masses_tris(verts, tris, density=1.0):
     return m
 
 
-def renumber_for_locality(verts, elems, force=False):
-    """Vertex numbering with locality (capi.locality_order, reverse Cuthill-McKee) for a mesh whose numbering has none:
-    returns (verts, elems, new_id) renumbered when the mean edge span shrinks by more than 2x (or force), else unchanged
-    with new_id = identity.  Everything indexed by vertex (pins, surface lists) goes through new_id."""
+def renumber_for_locality(verts, elems, force=False, method="rcm", leaf=256):
+    """Vertex numbering with locality for a mesh whose numbering has none: method "rcm" = capi.locality_order (reverse
+    Cuthill-McKee), "blocks" = capi.block_order (compact leaves from a recursive graph bisection: the smaller active window
+    for the gathers on unstructured meshes).  Returns (verts, elems, new_id) renumbered when the mean edge span shrinks by more
+    than 2x (or force), else unchanged with new_id = identity.  Everything indexed by vertex (pins, surface lists) goes through
+    new_id."""
     from . import capi
     verts = np.asarray(verts); elems = np.asarray(elems, dtype=np.int32)
     new_id, before, after = capi.locality_order(len(verts), elems)
+    if method == "blocks":
+        new_id = capi.block_order(len(verts), elems, leaf)
+        after = 0.0 if force else after
     if not force and not (after < 0.5 * before):
         return verts, elems, np.arange(len(verts), dtype=np.int32)
     out = np.empty_like(verts); out[new_id] = verts

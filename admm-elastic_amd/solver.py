@@ -360,6 +360,13 @@ class Solver:
         dist.broadcast_object_list(obj, src=0)
         check(lib().admm_hip_comm_init(self._ctx, obj[0], s.rank, s.world_size))
 
+    def solve_totals(self):
+        """admm_hip_solve_totals: (solves, converged solves, inner iterations) of the on-chip PCG since initialize."""
+        self._need_ctx()
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(lib().admm_hip_solve_totals(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def probe_sync(self, n=200):
         """admm_hip_probe_sync: (us per all-to-all, us per vector exchange, plan statistics dict) of the on-chip PCG."""
         self._need_ctx()

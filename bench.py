@@ -58,7 +58,7 @@ def build_scene(w, n_override=None):
         sc = scenes.cloth_scene(n, limits=(0.95, 1.05), floor=0.3, admm_iters=w["admm_iters"], linsolver=w["linsolver"])
         return sc, len(sc.tris[0][1]), len(sc.x)
     if w["kinds"] == "blob":
-        sc = scenes.blob_scene(n, admm_iters=w["admm_iters"], linsolver=w["linsolver"])
+        sc = scenes.blob_scene(n, admm_iters=w["admm_iters"], linsolver=w["linsolver"], order=os.environ.get("ADMM_BENCH_ORDER", "rcm"))
         return sc, sum(len(t[1]) for t in sc.tets), len(sc.x)
     if w["kinds"] == "nh_floor":
         sc = scenes.cube_scene(n, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=w["admm_iters"], linsolver=w["linsolver"])
@@ -205,19 +205,35 @@ def main():
     for _ in range(args.warmup):
         s.step_device(stats=True)
     sync()
-    # Timed region.  Every step also records HIP events (on the context's own stream) around its
-    # prox kernels; reading them back costs one stream sync per frame, which is inside the timing.
+    # Timed region: EXACTLY `steps` frames.  With the on-chip PCG the frames are issued without per-step statistics (no
+    # events between the kernels, no host synchronisation between frames: +2-3 %) and the solver's own totals say afterwards
+    # whether every solve of the region converged; the per-phase split, the event-pair duration of the prox kernels and the
+    # iteration counts then come from `steps` more frames run with statistics OUTSIDE the timed region.  Other solvers: the
+    # statistics frames are the timed ones, as in round 1.
     local_ms = rhs_ms = global_ms = lk_ms = 0.0
     inner = unconv = 0
+    tot0 = s.solve_totals() if w["linsolver"] == 0 else (-1, -1, -1)
+    lean = tot0[0] >= 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        s.step_device(stats=True)
-        rd = s.runtime_data()
-        local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms; inner += rd.inner_iters
-        lk_ms += rd.local_kernel_ms
-        unconv += rd.unconverged_solves
+        s.step_device(stats=not lean)
+        if not lean:
+            rd = s.runtime_data()
+            local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms; inner += rd.inner_iters
+            lk_ms += rd.local_kernel_ms
+            unconv += rd.unconverged_solves
     sync()
     elapsed = time.perf_counter() - t0
+    if lean:
+        tot1 = s.solve_totals()
+        unconv = (tot1[0] - tot0[0]) - (tot1[1] - tot0[1])
+        assert tot1[0] - tot0[0] == iters * args.steps, (tot0, tot1)
+        for _ in range(args.steps):
+            s.step_device(stats=True)
+            rd = s.runtime_data()
+            local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms; inner += rd.inner_iters
+            lk_ms += rd.local_kernel_ms
+        sync()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,6 +266,7 @@ def main():
         "split_ms_per_admm_iter": {"local": local_ms / (iters * args.steps), "rhs": rhs_ms / (iters * args.steps),
                                    "global": global_ms / (iters * args.steps)},
         "inner_iters_per_admm_iter": inner / (iters * args.steps), "unconverged_solves_in_timed_region": unconv,
+        "timed_region": "frames issued without per-step statistics; split / iteration counts from as many frames with statistics right after" if lean else "frames with per-step statistics",
         # mean time of one inner (PCG / GS) iteration incl. the per-solve overheads: (global - rhs) / inner iterations.
         # The PCG kernel keeps matrix and vectors on chip; its iteration is bound by one grid barrier, not by HBM.
         "us_per_inner_iter": 1e3 * (global_ms - rhs_ms) / max(inner, 1),

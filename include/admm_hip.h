@@ -206,6 +206,12 @@ int admm_hip_local_step(admm_hip_ctx *ctx, const double *x, double *u_inout, dou
  * through *iters.  Uses the context's linsolver, pins and obstacles. */
 int admm_hip_global_solve(admm_hip_ctx *ctx, const double *b, double *x_inout, int32_t *iters);
 
+/* Totals of the on-chip PCG since admm_hip_create (no reference counterpart): solves launched, solves that met pcg_tol,
+ * inner iterations.  Synchronises the context's stream.  Lets a caller run admm_hip_step WITHOUT per-step statistics
+ * (asynchronously, no events between the kernels) and still check afterwards that every solve converged.  -1 when the context
+ * does not use the general-mesh on-chip PCG. */
+int admm_hip_solve_totals(admm_hip_ctx *ctx, int64_t *solves, int64_t *converged, int64_t *inner_iters);
+
 /* Diagnostics of the on-chip PCG (linsolver 0 / 2; no reference counterpart): the latency floor of the two
  * synchronisations one CG iteration consists of, measured on this context's grid with the kernel's own primitives and
  * payloads but no arithmetic, as microseconds per repetition over n repetitions: the all-to-all (block record -> grid barrier
@@ -269,6 +275,14 @@ void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners,
  * off), largest halo list, LDS slab columns used.  lds_bytes = LDS a block may spend on its local vector and matrix slab. */
 int admm_host_oc_plan(const admm_hip_desc *desc, int32_t n_blocks, int32_t slices_per_block, int32_t lds_bytes,
                       int32_t *row_vertex, int32_t *row_aggregate, double *coarse_inv, int64_t *stats);
+
+/* Mesh preprocessing, second ordering (no counterpart in the reference): hierarchical BLOCK order.  The vertices are split
+ * into compact leaves of about `leaf` vertices by recursive graph bisection (the method the on-chip PCG uses for its blocks),
+ * leaves numbered in recursion-tree order, vertices breadth-first inside a leaf.  Reverse Cuthill-McKee minimises the
+ * bandwidth, i.e. the index distance of neighbours; this order minimises the ACTIVE WINDOW of the per-vertex gathers (corner
+ * forces, positions): on an unstructured 1 M-tet body the right-hand-side gather fetches 2x less.  Same contract as
+ * admm_host_locality_order: new_id[v] = new index of vertex v, the caller renumbers its mesh before building the solver. */
+void admm_host_block_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t leaf, int32_t *new_id);
 
 #ifdef __cplusplus
 }

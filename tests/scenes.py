@@ -169,13 +169,13 @@ def rel_err(a, b, x_ref=None):
     return np.linalg.norm(a - b, axis=1).max() / max(diag, 1e-300)
 
 
-def blob_scene(n, jitter=0.15, seed=0, **settings):
+def blob_scene(n, jitter=0.15, seed=0, order="rcm", **settings):
     """BASELINE configs[2] on an UNSTRUCTURED body: meshes.unstructured_blob (valences 3..26, not 2-colourable, no exact
     zeros in Ahat), numbered randomly like a mesh file and renumbered for locality as the samples do; Neo-Hookean / StVK
     by z-slab, soft rubber, the feet (y < 0.1) pinned."""
     sc = Scene()
     verts, tets = meshes.unstructured_blob(n, jitter=jitter, seed=seed)
-    verts, tets, _ = meshes.renumber_for_locality(verts, tets, force=True)
+    verts, tets, _ = meshes.renumber_for_locality(verts, tets, force=True, method=order)
     cz = verts[tets].mean(axis=1)[:, 2]
     slab = (cz * 8).astype(int) % 2
     sc.x = verts; sc.m = meshes.lumped_masses_tets(verts, tets)

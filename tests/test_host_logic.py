@@ -128,3 +128,14 @@ def test_locality_order_is_a_permutation_that_shrinks_the_span():
     tris = meshes.cloth_grid(10)[1]
     nid_t, _, _ = capi.locality_order(121, tris)                     # triangles too
     assert sorted(nid_t) == list(range(121))
+    # the hierarchical block order (admm_host_block_order): a permutation; consecutive runs of `leaf` vertices are compact
+    # (few distinct neighbour leaves), which is what bounds the active window of the per-vertex gathers
+    nid_b = capi.block_order(nv, t2, 64)
+    assert sorted(int(i) for i in nid_b) == list(range(nv))
+    leaf_of = nid_b // 64
+    e = np.concatenate([t2[:, [a, b]] for a in range(4) for b in range(a + 1, 4)])
+    pairs = np.unique(np.sort(leaf_of[e], axis=1), axis=0)
+    nbr = np.bincount(pairs[pairs[:, 0] != pairs[:, 1]].ravel(), minlength=leaf_of.max() + 1)
+    assert nbr.max() <= 26 and nbr.mean() < 14, (nbr.max(), nbr.mean())
+    v5, t5, nid5 = meshes.renumber_for_locality(v2, t2, force=True, method="blocks", leaf=64)
+    assert np.array_equal(v5[t5], v2[t2]) and np.array_equal(nid5, nid_b)
