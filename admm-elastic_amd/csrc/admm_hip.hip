@@ -986,9 +986,9 @@ int validate(const admm_hip_desc *d) {
     if (d->n_tets < 0 || d->n_tris < 0 || d->n_pins < 0) return fail(ADMM_HIP_ERR_ARG, "negative count");
     // the kernels address the per-element SoA arrays and the node vectors with 32-bit byte offsets (buffer instructions):
     // the largest array of a context, cf[12][n + 1] doubles, and the node vectors must stay below 2^31 bytes
-    if ((int64_t)96 * ((int64_t)d->n_tets + 1) >= ((int64_t)1 << 31) || (int64_t)96 * ((int64_t)d->n_tris + 1) >= ((int64_t)1 << 31) ||
+    if ((int64_t)128 * ((int64_t)d->n_tets + 1) >= ((int64_t)1 << 31) || (int64_t)96 * ((int64_t)d->n_tris + 1) >= ((int64_t)1 << 31) ||
         (int64_t)24 * d->n_verts >= ((int64_t)1 << 31))
-        return fail(ADMM_HIP_ERR_ARG, "scene too large for one context (limit: 22.3 M tets / tris, 89 M vertices per rank)");
+        return fail(ADMM_HIP_ERR_ARG, "scene too large for one context (limit: 16.7 M tets, 22.3 M tris, 89 M vertices per rank)");
     if (d->n_tets && (!d->tet_idx || !d->tet_Binv || !d->tet_weight || !d->tet_kind || !d->tet_mu || !d->tet_lambda || !d->tet_k))
         return fail(ADMM_HIP_ERR_ARG, "tet arrays missing");
     if (d->n_tris && (!d->tri_idx || !d->tri_rest || !d->tri_weight || !d->tri_limit_min || !d->tri_limit_max))
@@ -1130,7 +1130,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->t_mat.upload(mat)); HIP_TRY(c->mats.upload(mats));
         HIP_TRY(c->t_u.alloc((size_t)9 * ld)); HIP_TRY(c->t_u.zero());
         HIP_TRY(c->t_z.alloc((size_t)9 * ld)); HIP_TRY(c->t_z.zero());
-        HIP_TRY(c->t_cf.alloc((size_t)12 * ld)); HIP_TRY(c->t_cf.zero());
+        HIP_TRY(c->t_cf.alloc((size_t)(ADMM_CF_AOS ? 16 : 12) * ld)); HIP_TRY(c->t_cf.zero());   // corner forces (kernels.hpp: kCfStride)
         // incidence on the permuted numbering
         std::vector<int32_t> pidx((size_t)4 * nt);
         for (int n = 0; n < nt; ++n) { pidx[4 * n] = idx[n].x; pidx[4 * n + 1] = idx[n].y; pidx[4 * n + 2] = idx[n].z; pidx[4 * n + 3] = idx[n].w; }

@@ -236,8 +236,20 @@ __device__ __forceinline__ void tet_gather(const TetArgs &a, const int4 id, TetP
 }
 
 // prox + dual update + corner forces of one tet from its loaded inputs
+// Corner forces: SoA cf[12][ld] (default).  ADMM_CF_AOS=1 (A/B, measured and NOT kept): one 128-byte record per tet (corner c
+// at doubles [3 c, 3 c + 3)), so that the right-hand-side gather reads the 24 bytes of an incidence from ONE sector instead of
+// three 8-byte elements of three SoA arrays (on the unstructured 1 M-tet body the SoA gather fetches 3.3x its algorithmic
+// bytes), written through a wave-private transposition in LDS -- the wave's own columns of the rows that parked Binv / V -- so
+// that every store instruction covers whole sectors.  Same box, 1 M tets: unstructured body local step 69.4 -> 76.3 us, gather
+// 83.0 -> 67.5 us (+1.6 % ADMM it/s); Kuhn cube 69.3 -> 74.6 us and 51.6 -> 66.2 us (-2.4 %): the staged stores cost the local
+// step more than the gather gains, and on the cube the SoA gather was the coalesced one.
+#ifndef ADMM_CF_AOS
+#define ADMM_CF_AOS 0
+#endif
+constexpr int kCfStride = ADMM_CF_AOS ? 16 : 1;   // doubles between the records of consecutive tets (AoS) / elements (SoA)
+
 template <int KIND, bool WRITE_Z>
-__device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, const TetIn &in, const TetPos &x, double (*sBi)[256], double (*sV)[256]) {
+__device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, int t_end, bool valid, const TetIn &in, const TetPos &x, double (*sBi)[256], double (*sV)[256]) {
     const int ld8 = a.ld * 8, t8 = t * 8;
     const __amdgpu_buffer_rsrc_t ru = soa_rsrc(a.u), rcf = soa_rsrc(a.cf);
     const Mat *__restrict__ mats = a.mats;
@@ -300,9 +312,11 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, const
         for (int i = 0; i < 3; ++i) { du[i] = S0[i] - S1[i]; dg[i] = s * (2.0 * S1[i] - S0[i]); }
         double un[9];
         usvt(U, du, V, un);
+        if (valid) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) buf_st_stream(ru, t8, c * ld8, un[c]);
-        if (WRITE_Z) {
+            for (int c = 0; c < 9; ++c) buf_st_stream(ru, t8, c * ld8, un[c]);
+        }
+        if (WRITE_Z && valid) {
             double zi[9];
             usvt(U, S1, V, zi);
             const __amdgpu_buffer_rsrc_t rz = soa_rsrc(a.z);
@@ -312,30 +326,64 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, const
         usvt(U, dg, V, G);
     }
     // corner forces: H(j,m) = sum_r G(j,r) Binv(m,r); corner m+1 gets H(:,m), corner 0 gets -sum_m H(:,m).
-    // SoA cf[12][ld] (an AoS-per-tet layout was measured slower for both this kernel and the gather: with a
-    // locality-preserving element order the SoA accesses coalesce across lanes).
-    double f0[3] = {0.0, 0.0, 0.0};
+    double f[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const double b0 = sBi[0 + m][threadIdx.x], b1 = sBi[3 + m][threadIdx.x], b2 = sBi[6 + m][threadIdx.x];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const double h = fma(G[j], b0, fma(G[3 + j], b1, G[6 + j] * b2));
-            buf_st_stream(rcf, t8, (3 * (m + 1) + j) * ld8, h);
-            f0[j] -= h;
+            f[3 * (m + 1) + j] = h;
+            f[j] -= h;
         }
     }
+#if ADMM_CF_AOS
+    {
+        // rows 0..11 of the LDS block (sBi rows 0..8, then sV rows 0..2): this wave's 64 columns are its staging area.  Component c
+        // of lane l goes to column (l + 4 c) mod 64 of row c: the transposed reads below then hit distinct banks.
+        const int lane = (int)threadIdx.x & 63, wb = (int)threadIdx.x & ~63;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) buf_st_stream(rcf, t8, j * ld8, f0[j]);
+        for (int c = 0; c < 12; ++c) {
+            double *rowp = c < 9 ? sBi[c] : sV[c - 9];
+            rowp[wb + ((lane + 4 * c) & 63)] = f[c];
+        }
+        // store round k: lane covers bytes [1024 k + 16 lane, + 16) of the wave's 64 x 128-byte records = record 8 k + lane / 8,
+        // doubles 2 (lane % 8), + 1; the fourth sector of a record (lane % 8 >= 6) is never written or read
+        const int pr = lane & 7, j8 = lane >> 3;
+        const int tw = t - lane;                 // first tet of this wave
+        if (pr < 6) {
+            const double *r0 = (2 * pr) < 9 ? sBi[2 * pr] : sV[2 * pr - 9];
+            const double *r1 = (2 * pr + 1) < 9 ? sBi[2 * pr + 1] : sV[2 * pr + 1 - 9];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int tau = 8 * k + j8;
+                const double v0 = r0[wb + ((tau + 8 * pr) & 63)], v1 = r1[wb + ((tau + 8 * pr + 4) & 63)];
+                if (tw + tau < t_end) {
+                    union { double d[2]; bv4u v; } pk; pk.d[0] = v0; pk.d[1] = v1;
+                    __builtin_amdgcn_raw_buffer_store_b128(pk.v, rcf, (tw + tau) * 128 + pr * 16, 0, ADMM_STREAM_ST_AUX);
+                }
+            }
+        }
+    }
+#else
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) buf_st_stream(rcf, t8, c * ld8, f[c]);
+    }
+#endif
 }
 
+// t_end = end of this constitutive model's tet range.  The whole wave takes part (the corner-force records are stored by the
+// wave together): lanes past the end redo the last tet of the range and store nothing.
 template <int KIND, bool WRITE_Z>
-__device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, double (*sBi)[256], double (*sV)[256]) {
+__device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, int t_end, double (*sBi)[256], double (*sV)[256]) {
     TetIn in; TetPos x;
-    const int4 id = tet_load_idx(a, t);
-    tet_load<KIND>(a, t, in);
+    const bool valid = t < t_end;
+    const int tl = valid ? t : t_end - 1;
+    const int4 id = tet_load_idx(a, tl);
+    tet_load<KIND>(a, tl, in);
     tet_gather(a, id, x);
-    tet_compute_store<KIND, WRITE_Z>(a, t, in, x, sBi, sV);
+    tet_compute_store<KIND, WRITE_Z>(a, t, t_end, valid, in, x, sBi, sV);
 }
 
 // one constitutive model per launch (used when a scene has a single model, and by the parity entry point)
@@ -344,11 +392,11 @@ template <int KIND, bool WRITE_Z>
 #define ADMM_NH_WAVES 3
 #endif
 __global__ __launch_bounds__(256, (KIND == 1 ? ADMM_NH_WAVES : KIND == 4 ? 2 : 4)) void k_local_tets(int t0, int t1, TetArgs a) {
-    __shared__ double sBi[9][256];
-    __shared__ double sV[(KIND == 2 || ADMM_PARK_V_NH != 0) ? 9 : 1][256];
+    __shared__ double sL[(KIND == 2 || ADMM_PARK_V_NH != 0) ? 18 : 12][256];     // rows 0..8: Binv; 9..: V (parked) / staging
+    double (*sBi)[256] = sL, (*sV)[256] = sL + 9;
     const int t = t0 + xcd_block() * 256 + threadIdx.x;
     ts_enter(a);
-    if (t < t1) local_tet_body<KIND, WRITE_Z>(a, t, sBi, sV);
+    if (t - (int)(threadIdx.x & 63) < t1) local_tet_body<KIND, WRITE_Z>(a, t, t1, sBi, sV);
     ts_exit(a);
 }
 
@@ -356,19 +404,20 @@ __global__ __launch_bounds__(256, (KIND == 1 ? ADMM_NH_WAVES : KIND == 4 ? 2 : 4
 // Avoids the ramp-down / ramp-up between per-model launches of a mixed scene.
 template <bool WRITE_Z>
 __global__ __launch_bounds__(256, ADMM_NH_WAVES) void k_local_tets_fused(int b0, int b1, int b2, int b3, int nb0, int nb1, TetArgs a) {
-    __shared__ double sBi[9][256];
-    __shared__ double sV[9][256];
+    __shared__ double sL[18][256];
+    double (*sBi)[256] = sL, (*sV)[256] = sL + 9;
     const int blk = xcd_block();
+    const int l0 = (int)(threadIdx.x & 63);
     ts_enter(a);
     if (blk < nb0) {
         const int t = b0 + blk * 256 + threadIdx.x;
-        if (t < b1) local_tet_body<0, WRITE_Z>(a, t, sBi, sV);
+        if (t - l0 < b1) local_tet_body<0, WRITE_Z>(a, t, b1, sBi, sV);
     } else if (blk < nb1) {
         const int t = b1 + (blk - nb0) * 256 + threadIdx.x;
-        if (t < b2) local_tet_body<1, WRITE_Z>(a, t, sBi, sV);
+        if (t - l0 < b2) local_tet_body<1, WRITE_Z>(a, t, b2, sBi, sV);
     } else {
         const int t = b2 + (blk - nb1) * 256 + threadIdx.x;
-        if (t < b3) local_tet_body<2, WRITE_Z>(a, t, sBi, sV);
+        if (t - l0 < b3) local_tet_body<2, WRITE_Z>(a, t, b3, sBi, sV);
     }
     ts_exit(a);
 }
@@ -437,8 +486,11 @@ struct GatherArgs {
 
 // sum of the corner forces incident to this lane's vertex (incidence widths are multiples of 8; padding
 // points at the all-zero dummy element ld-1).  Software-pipelined, 8 incidences (24 gathers) per round.
+template <bool AOS>
 __device__ __forceinline__ void gather_corners(const int *__restrict__ inc, int w, const double *__restrict__ cf, int ld, double *acc) {
     constexpr int R = 8;
+    // element (tet e >> 2, corner e & 3): AoS = doubles [16 (e >> 2) + 3 (e & 3), + 3) of the tet's record; SoA = cf[3 c + j][tet]
+    const size_t js = AOS ? 1 : (size_t)ld;
     int e[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) e[i] = inc[64 * i];
@@ -449,8 +501,8 @@ __device__ __forceinline__ void gather_corners(const int *__restrict__ inc, int 
         double g[3 * R];
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const double *p = cf + (size_t)(3 * (e[i] & 3)) * ld + (e[i] >> 2);
-            g[3 * i] = p[0]; g[3 * i + 1] = p[ld]; g[3 * i + 2] = p[2 * (size_t)ld];
+            const double *p = AOS ? cf + (size_t)(e[i] >> 2) * 16 + 3 * (e[i] & 3) : cf + (size_t)(3 * (e[i] & 3)) * ld + (e[i] >> 2);
+            g[3 * i] = p[0]; g[3 * i + 1] = p[js]; g[3 * i + 2] = p[2 * js];
         }
 #pragma unroll
         for (int i = 0; i < R; ++i) { acc[0] += g[3 * i]; acc[1] += g[3 * i + 1]; acc[2] += g[3 * i + 2]; e[i] = en[i]; }
@@ -458,8 +510,8 @@ __device__ __forceinline__ void gather_corners(const int *__restrict__ inc, int 
     double g[3 * R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-        const double *p = cf + (size_t)(3 * (e[i] & 3)) * ld + (e[i] >> 2);
-        g[3 * i] = p[0]; g[3 * i + 1] = p[ld]; g[3 * i + 2] = p[2 * (size_t)ld];
+        const double *p = AOS ? cf + (size_t)(e[i] >> 2) * 16 + 3 * (e[i] & 3) : cf + (size_t)(3 * (e[i] & 3)) * ld + (e[i] >> 2);
+        g[3 * i] = p[0]; g[3 * i + 1] = p[js]; g[3 * i + 2] = p[2 * js];
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) { acc[0] += g[3 * i]; acc[1] += g[3 * i + 1]; acc[2] += g[3 * i + 2]; }
@@ -473,8 +525,8 @@ __global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
         const int r = s * 64 + lane;
         const int v = r < a.nv ? a.order[r] : a.nv;
         double acc[3] = {0.0, 0.0, 0.0};
-        if (a.t_inc) gather_corners(a.t_inc + a.t_ptr[s] + lane, a.t_w[s], a.t_cf, a.t_ld, acc);
-        if (a.r_inc) gather_corners(a.r_inc + a.r_ptr[s] + lane, a.r_w[s], a.r_cf, a.r_ld, acc);
+        if (a.t_inc) gather_corners<ADMM_CF_AOS != 0>(a.t_inc + a.t_ptr[s] + lane, a.t_w[s], a.t_cf, a.t_ld, acc);
+        if (a.r_inc) gather_corners<false>(a.r_inc + a.r_ptr[s] + lane, a.r_w[s], a.r_cf, a.r_ld, acc);
         if (v < a.nv) {
             if (a.vert_pin) {
                 const int pi = a.vert_pin[v];
