@@ -189,6 +189,8 @@ class Solver:
         pin_in_place = points is None or len(points) != n
         if (self.m_x.size == 0 and pin_in_place) or (pin_in_place and points is not None and len(points) > 0):
             raise AdmmHipError(-1, "**Solver::set_pins Error: Bad input.")
+        if pin_in_place and self.initialized and self._ctx:
+            self.download()     # the reference pins at the CURRENT m_x: after device-resident stepping the host copy is stale
         self._pins = {}
         for i, idx in enumerate(inds):
             self._pins[idx] = self.m_x[3 * idx:3 * idx + 3].copy() if pin_in_place else f64(points[i]).copy()

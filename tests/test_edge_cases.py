@@ -141,3 +141,22 @@ def test_barrier_timeout_falls_back_and_replays(monkeypatch):
     for _ in range(4):
         s2.step()
     assert scenes.rel_err(s2.m_x, ref.m_x) < 1e-8
+
+
+@pytest.mark.gpu
+def test_pin_in_place_after_device_resident_steps_uses_the_current_positions():
+    """ADVICE round 1: Solver::set_pins(inds) without points pins at the CURRENT m_x (src/Solver.cpp:121-125); after
+    step_device() the host copy is stale, so the binding has to fetch the device state first."""
+    import scenes
+    sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, admm_iters=5, linsolver=1)
+    s = sc.make_solver()
+    s.upload()
+    for _ in range(5):
+        s.step_device()
+    stale = s.m_x.copy()
+    free = [i for i in range(len(sc.x)) if i not in sc.pins][:3]
+    s.set_pins(list(sc.pins.keys()) + free)
+    now = s.m_x.reshape(-1, 3)
+    assert np.abs(s.m_x - stale).max() > 1e-4          # the body moved while the host copy was stale
+    for v in free:
+        assert np.array_equal(s._pins[v], now[v])

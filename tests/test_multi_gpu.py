@@ -190,3 +190,23 @@ def test_two_ranks_two_gpus_match_single_context():
         assert unconv == 0
         assert scenes.rel_err(x, ref.m_x) < 1e-9, (rank, scenes.rel_err(x, ref.m_x))   # summation order of the partial RHS differs
     assert np.array_equal(res[0][1], res[1][1])      # the replicated solves see the same all-reduced right-hand side
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus N` ignored the flag (one rank, "n_gpus": 1).  It now starts N ranks itself
+    when no launcher did (the driver's `python -m torch.distributed.run --nproc-per-node N` line), and a mismatch between
+    --gpus and WORLD_SIZE is an error.  Without GPUs every rank fails loudly: the hot path has no CPU fallback."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if pkg.device_count() > 0:
+        pytest.skip("CPU-only check of the launcher")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert "rank 0 needs HIP device 0" in out and "rank 1 needs HIP device 1" in out, out[-2000:]     # two ranks were started
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in (r.stdout + r.stderr)
