@@ -63,6 +63,7 @@ SYMBOLS = [
     ("admm_hip_get_state", C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     ("admm_hip_set_pins", C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_double_p]),
     ("admm_hip_set_surface_inds", C.c_int, [C.c_void_p, C.c_int32, c_int_p]),
+    ("admm_hip_set_wind", C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_double_p]),
     ("admm_hip_add_dynamic_tetmesh", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, C.c_int32, c_int_p, C.c_int32, c_int_p]),
     ("admm_hip_detect_dynamic", C.c_int, [C.c_void_p, c_double_p, C.c_int32, c_int_p, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_hip_step", C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(Stats)]),

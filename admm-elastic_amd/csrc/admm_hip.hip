@@ -190,6 +190,8 @@ struct admm_hip_ctx {
     // good is kept, with the steps issued since; a timed-out barrier (detected at the next synchronisation) switches the
     // context to the launch-per-iteration PCG for good, restores that state and replays the steps.
     DevBuf<double> bk_x, bk_v; std::vector<std::pair<int, double> > pending; bool oc_gave_up = false;
+    // WindForce on the device (admm_hip_set_wind): triangles, their vertex incidence, per-triangle forces
+    int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
     int test_abort_seq = 0;   // tests only (ADMM_HIP_TEST_ABORT_SOLVE=k): the k-th on-chip solve of the context finds its barrier aborted
     int n3i = 0;   // length of the solver-internal scratch vectors (recycled pairs): max(n3, 3 * oc_rows)
     int solve_seq = 0;
@@ -249,7 +251,7 @@ struct admm_hip_ctx {
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release();
         oc_A.release(); oc_orig.release(); oc_ldsoff.release(); oc_wls.release(); oc_haloptr.release(); oc_halosrc.release(); oc_col16.release();
         oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release();
-        bk_x.release(); bk_v.release();
+        bk_x.release(); bk_v.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
@@ -1410,6 +1412,24 @@ int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const dou
     return ADMM_HIP_OK;
 }
 
+// Solver::ext_forces.push_back(std::make_shared<WindForce>(tris)) + WindForce::direction (src/ExplicitForce.hpp:39-46)
+int admm_hip_set_wind(admm_hip_ctx *c, int32_t n_tris, const int32_t *tris, const double *direction) {
+    if (!c || n_tris < 0 || (n_tris > 0 && (!tris || !direction))) return fail(ADMM_HIP_ERR_ARG, "set_wind: bad input");
+    for (int64_t i = 0; i < (int64_t)3 * n_tris; ++i)
+        if (tris[i] < 0 || tris[i] >= c->nv) return fail(ADMM_HIP_ERR_ARG, "set_wind: triangle index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = settle(c)) return rc;
+    c->wind_tris.release(); c->wind_inc.release(); c->wind_force.release();
+    c->wind_n = n_tris;
+    if (n_tris == 0) return ADMM_HIP_OK;
+    for (int j = 0; j < 3; ++j) c->wind_dir[j] = direction[j];
+    HIP_TRY(c->wind_tris.upload(std::vector<int>(tris, tris + 3 * (size_t)n_tris)));
+    HIP_TRY(c->wind_inc.upload(admm_host::incidence_sell(c->nv, n_tris, 3, tris, n_tris * 4)));
+    HIP_TRY(c->wind_force.alloc(3 * ((size_t)n_tris + 1))); HIP_TRY(c->wind_force.zero());
+    return ADMM_HIP_OK;
+}
+
 // Solver::surface_inds (src/Solver.hpp:70): the vertices Collider::detect looks at (Collider.hpp:157,163)
 int admm_hip_set_surface_inds(admm_hip_ctx *c, int32_t n, const int32_t *inds) {
     if (!c || n < 0 || (n > 0 && !inds)) return fail(ADMM_HIP_ERR_ARG, "set_surface_inds: bad input");
@@ -1587,6 +1607,12 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     c->uz_iters_step = 0; c->uz_detected = false;
     c->rc_prev_valid = c->rc_iter; c->rc_frame += 1; c->rc_iter = 0;   // this frame's pairs become "previous frame"
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
+    if (c->wind_n > 0) {   // ExplicitForce::project of the wind, Solver.cpp:54 (before gravity and the prediction)
+        hipLaunchKernelGGL(k_wind_tris, dim3(blocks_for(c->wind_n)), dim3(256), 0, st, c->wind_n, c->wind_tris.p, c->x.p, c->v.p,
+                           c->wind_dir[0], c->wind_dir[1], c->wind_dir[2], c->dt, c->wind_force.p);
+        hipLaunchKernelGGL(k_wind_nodes, dim3((c->wind_inc.n_slices + 3) / 4), dim3(256), 0, st, c->nv, c->wind_n, c->wind_inc.ptr.p,
+                           c->wind_inc.w.p, c->wind_inc.idx.p, c->wind_force.p, c->v.p);
+    }
     hipLaunchKernelGGL(k_predict, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, c->dt, gravity, c->x.p, c->v.p, c->m.p,
                        c->Mxbar.p, c->curr.p);
     // curr_u = 0 (Solver.cpp:71); curr_z = D x is a dead store in the reference (:70)

@@ -115,6 +115,56 @@ __global__ __launch_bounds__(256) void k_predict(int n3, double dt, double gravi
     curr[i] = xb;
 }
 
+// WindForce::project (src/ExplicitForce.cpp:47-104; Wejchert & Haumann 1991) on the device, for device-resident stepping:
+// per triangle the force -alpha_n area v_n |v_n| n (alpha_n = 1000) from the velocity relative to the wind along the unit normal,
+// times 0.33 dt ...
+__global__ __launch_bounds__(256) void k_wind_tris(int n, const int *__restrict__ tris, const double *__restrict__ x,
+                                                   const double *__restrict__ v, double dx, double dy, double dz, double dt,
+                                                   double *__restrict__ force /* [3][n + 1], entry n stays zero */) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int i0 = 3 * tris[3 * t], i1 = 3 * tris[3 * t + 1], i2 = 3 * tris[3 * t + 2];
+    const double vr[3] = {(v[i0] + v[i1] + v[i2]) * (1.0 / 3.0) - dx, (v[i0 + 1] + v[i1 + 1] + v[i2 + 1]) * (1.0 / 3.0) - dy,
+                          (v[i0 + 2] + v[i1 + 2] + v[i2 + 2]) * (1.0 / 3.0) - dz};
+    const double a[3] = {x[i1] - x[i0], x[i1 + 1] - x[i0 + 1], x[i1 + 2] - x[i0 + 2]};
+    const double b[3] = {x[i2] - x[i0], x[i2 + 1] - x[i0 + 1], x[i2 + 2] - x[i0 + 2]};
+    double nn[3];
+    cross3(a, b, nn);
+    const double len = sqrt(dot3(nn, nn));
+    double f[3] = {0.0, 0.0, 0.0};
+    if (len > 0.0) {    // (degenerate triangle: no area, no force)
+        const double il = 1.0 / len;
+        const double un[3] = {nn[0] * il, nn[1] * il, nn[2] * il};
+        const double vn = dot3(un, vr);
+        const double sc = -1000.0 * (0.5 * len) * vn * fabs(vn) * 0.33 * dt;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) f[j] = sc * un[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) force[(size_t)j * (n + 1) + t] = f[j];
+}
+// ... ADDED TO THE VELOCITY of the triangle's three nodes (the reference does not divide by the node mass; kept): a gather over
+// the vertex -> triangle incidence lists, no atomics.  Every triangle sees the velocities of the start of the step (the
+// reference's OpenMP loop reads whatever its critical sections have already written: order-dependent there).
+__global__ __launch_bounds__(256) void k_wind_nodes(int nv, int n_tris, const int *__restrict__ ptr, const int *__restrict__ w,
+                                                    const int *__restrict__ inc, const double *__restrict__ force, double *__restrict__ v) {
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (s * 64 >= nv) return;
+    const int vtx = s * 64 + lane;
+    const int *il = inc + ptr[s] + lane;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int k = 0; k < w[s]; ++k) {
+        const int t = il[64 * k] >> 2;      // (element, corner) code of incidence_sell; padding = the all-zero entry n_tris
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] += force[(size_t)j * (n_tris + 1) + t];
+    }
+    if (vtx < nv) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[3 * (size_t)vtx + j] += acc[j];
+    }
+}
+
 // Solver::step epilogue (src/Solver.cpp:105-106)
 __global__ __launch_bounds__(256) void k_finish(int n3, double inv_dt, double *__restrict__ x, double *__restrict__ v,
                                                 const double *__restrict__ curr) {

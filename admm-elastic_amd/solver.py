@@ -203,6 +203,14 @@ class Solver:
         """Solver::add_obstacle (src/Solver.cpp:159-161)."""
         self._obstacles.append(obj)
 
+    def set_wind(self, tris, direction):
+        """ext_forces.push_back(WindForce(tris)) with WindForce::direction (src/ExplicitForce.hpp:39-46), applied on the device
+        at the start of every step.  tris [n,3] node indices; empty = no wind.  After initialize."""
+        self._need_ctx()
+        t = i32(tris, (-1, 3)) if len(tris) else np.zeros((0, 3), np.int32)
+        d = f64(direction).ravel().copy()
+        check(lib().admm_hip_set_wind(self._ctx, t.shape[0], iptr(t), dptr(d)))
+
     def add_dynamic_collider(self, obj):
         """Solver::add_dynamic_collider (src/Solver.cpp:163-165)."""
         self._dynamic.append(obj)

@@ -165,6 +165,14 @@ int admm_hip_get_state(admm_hip_ctx *ctx, double *x, double *v);
  * at Solver.cpp:147-151); all other pins become inactive.  linsolver 1: the set is replaced freely. */
 int admm_hip_set_pins(admm_hip_ctx *ctx, int32_t n, const int32_t *vert, const double *xyz);
 
+/* Solver::ext_forces with a WindForce (src/ExplicitForce.hpp:39-46, src/ExplicitForce.cpp:47-104), applied on the DEVICE at the
+ * start of every admm_hip_step, where Solver::step calls ExplicitForce::project (src/Solver.cpp:54): tris [3*n_tris] = the node
+ * indices of the triangles the wind acts on (WindForce's constructor argument), direction [3] = WindForce::direction.  Every
+ * triangle sees the velocities of the start of the step (the reference's OpenMP loop reads whatever its critical sections have
+ * already written).  n_tris = 0 removes the force.  For callers that keep m_x / m_v on the host the C++ mirror applies the same
+ * force on the host, like the reference. */
+int admm_hip_set_wind(admm_hip_ctx *ctx, int32_t n_tris, const int32_t *tris, const double *direction);
+
 /* Solver::surface_inds (src/Solver.hpp:70; filled by binding::add_tetmesh, samples/utils/AddMeshes.hpp:131-137): the
  * vertices Collider::detect tests (src/Collider.hpp:157,163).  n = 0 -> every vertex (the reference's rule for an
  * empty list).  Applies to passive detection of the UzawaCG path and to dynamic detection. */

@@ -801,3 +801,39 @@ def test_gs_two_colour_scheme_equals_three_kernel_scheme(floor):
         if floor is None:
             assert (it2 < mx) == (tol > 1e-9)      # the loose tolerances stop early, the tight one runs out of sweeps
         assert np.array_equal(x2, x3), (tol, np.abs(x2 - x3).max())
+
+
+def test_wind_force_on_the_device():
+    """WindForce::project (src/ExplicitForce.cpp:47-104) applied on the device at the start of a step: against the formula
+    evaluated in numpy with every triangle reading the start-of-step velocities (the documented order of the device version;
+    the reference's own loop is order-dependent), through one cloth step with the ADMM loop switched off (0 iterations:
+    x_new = x + dt v, v_new = v)."""
+    sc = scenes.cloth_scene(6, limits=None, admm_iters=0, linsolver=0)
+    sc.pins.clear()
+    sc.settings["gravity"] = 0.0
+    s = sc.make_solver()
+    verts, tris, _, _ = sc.tris[0]
+    rng = np.random.default_rng(4)
+    x0 = (sc.x + 0.05 * rng.standard_normal(sc.x.shape)).ravel()
+    v0 = 0.3 * rng.standard_normal(x0.size)
+    wind = np.array([1.5, -0.2, 0.7])
+    sel = tris[::2]                                    # the wind acts on a subset of the triangles
+    s.m_x = x0.copy(); s.m_v = v0.copy()
+    s.set_wind(sel, wind)
+    dt = sc.settings["timestep_s"]
+    s.step()
+    X = x0.reshape(-1, 3); V = v0.reshape(-1, 3)
+    add = np.zeros_like(V)
+    for t in sel:
+        vr = V[t].mean(axis=0) - wind
+        n = np.cross(X[t[1]] - X[t[0]], X[t[2]] - X[t[0]]); ln = np.linalg.norm(n); un = n / ln
+        vn = un @ vr
+        add[t] += -1000.0 * (0.5 * ln) * vn * abs(vn) * un * 0.33 * dt
+    v_exp = (V + add).ravel()
+    assert np.abs(s.m_v - v_exp).max() <= 1e-12 * max(1.0, np.abs(v_exp).max())
+    assert np.abs(s.m_x - (x0 + dt * v_exp)).max() <= 1e-12
+    assert np.abs(add).max() > 1e-3
+    s.set_wind([], wind)                               # removed again
+    s.m_x = x0.copy(); s.m_v = v0.copy()
+    s.step()
+    assert np.abs(s.m_v - v0).max() <= 1e-14
