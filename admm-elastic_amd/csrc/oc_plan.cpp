@@ -206,7 +206,7 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
     P.pos.assign(nv, -1);
     std::vector<int32_t> len(nv, 0);
     for (int32_t r = 0; r < nv; ++r) len[r] = g.ptr[r + 1] - g.ptr[r];
-    std::vector<int32_t> agg_part(nv, 0);
+    std::vector<int32_t> agg_part(nv, 0), bfs_rank(nv, 0);
     for (int b = 0; b < G; ++b) {
         std::vector<int32_t> &mem = blocks[b];
         const int32_t nb = (int32_t)mem.size();
@@ -223,12 +223,19 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
             bisect(g, copy, sizes, nnz, 0, mark, next_id, seen, agg_part);
             for (int32_t v : mem) agg_part[v] = nz_map[agg_part[v]];
         }
-        // rows of the block: longest first (ties: aggregate, vertex) -> the 64 rows of a wavefront have similar lengths
+        // rows of the block: longest first -> the 64 rows of a wavefront have similar lengths; rows of equal length in
+        // breadth-first order of the block's graph, so that neighbouring lanes read neighbouring entries of the local vector
         std::vector<int32_t> rows(mem);
+        if (nb > 0) {
+            const int32_t idb2 = next_id++;
+            for (int32_t v : mem) mark[v] = idb2;
+            std::vector<int32_t> bfs;
+            bfs_order(g, mem, mark, idb2, mem[0], seen, bfs);
+            for (int32_t i = 0; i < nb; ++i) bfs_rank[bfs[i]] = i;
+        }
         std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) {
             if (len[x] != len[y]) return len[x] > len[y];
-            if (agg_part[x] != agg_part[y]) return agg_part[x] < agg_part[y];
-            return x < y;
+            return bfs_rank[x] < bfs_rank[y];
         });
         int32_t slot = b * T;
         for (int32_t v : rows) { P.orig[slot] = v; P.pos[v] = slot; ++slot; }
