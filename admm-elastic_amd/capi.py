@@ -84,6 +84,7 @@ SYMBOLS = [
     ("admm_host_greedy_coloring", C.c_int, [C.c_int32, c_int_p, c_int_p, c_int_p]),
     ("admm_host_locality_order", None, [C.c_int32, C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, c_double_p]),
     ("admm_host_block_order", None, [C.c_int32, C.c_int32, C.c_int32, c_int_p, C.c_int32, c_int_p]),
+    ("admm_host_chunk_reduce", C.c_int, [C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
     ("admm_host_oc_plan", C.c_int, [C.POINTER(Desc), C.c_int32, C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, C.POINTER(C.c_int64)]),
 ]
 
@@ -179,6 +180,15 @@ def block_order(n_verts, elems, leaf=256):
     new_id = np.zeros(n_verts, np.int32)
     lib().admm_host_block_order(n_verts, elems.shape[0], elems.shape[1], iptr(elems), leaf, iptr(new_id))
     return new_id
+
+
+def chunk_reduce(n_verts, tets, kind_begin, corner_forces):
+    """admm_host_chunk_reduce: the local step's block-level reduction of corner forces [n,4,3] run on the host -> (vertex sums
+    [n_verts,3], dict of plan statistics)."""
+    tets = i32(tets); kb = i32(kind_begin); cf = f64(corner_forces)
+    out = np.zeros((n_verts, 3)); st = (C.c_int64 * 8)()
+    check(lib().admm_host_chunk_reduce(n_verts, tets.shape[0], iptr(tets), iptr(kb), dptr(cf), dptr(out), st))
+    return out, dict(chunks=st[0], records=st[1], max_passes=st[2], max_list=st[3], stored=st[4])
 
 
 def partition(n_items, world_size, rank):

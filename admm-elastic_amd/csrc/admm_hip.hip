@@ -131,11 +131,13 @@ struct admm_hip_ctx {
     DevBuf<double> x, v, m, Mxbar, curr, b, dinv;
     // tets (sorted by constitutive model; perm[new] = caller's index)
     int nt = 0, ldt = 0;
+    int n_rec = 0;
     int kind_begin[6] = {0, 0, 0, 0, 0, 0}; // [linear | NH (+ NH spline) | StVK (+ StVK spline) | co-rotated spline | splines with kappa != 0 | end]
     std::vector<int> tet_perm;
     std::vector<int> tri_perm;        // device slot -> caller's triangle index (sorted like the tets: lowest vertex first)
     DevBuf<int4> t_idx;
-    DevBuf<double> t_Binv, t_u, t_z, t_sc, t_cf;
+    DevBuf<double> t_Binv, t_u, t_z, t_sc, t_rec;     // t_rec: per-chunk partial sums of the corner forces, [n_rec + 1][4]
+    DevBuf<unsigned short> ch_ent; DevBuf<int> ch_group, ch_rec; int chunk_base[6] = {0, 0, 0, 0, 0, 0};   // host_setup.hpp: TetChunks
     DevBuf<int> t_mat;
     DevBuf<Mat> mats;
     SellDev t_inc; DevBuf<int> g_order;   // incidence lists, and the vertex every row of them gathers for
@@ -240,7 +242,7 @@ struct admm_hip_ctx {
         (void)hipSetDevice(device);
         if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
         x.release(); v.release(); m.release(); Mxbar.release(); curr.release(); b.release(); dinv.release();
-        t_idx.release(); t_Binv.release(); t_u.release(); t_z.release(); t_sc.release(); t_cf.release();
+        t_idx.release(); t_Binv.release(); t_u.release(); t_z.release(); t_sc.release(); t_rec.release(); ch_ent.release(); ch_group.release(); ch_rec.release();
         t_mat.release(); mats.release(); t_inc.release(); g_order.release();
         r_idx.release(); r_rest.release(); r_u.release(); r_z.release(); r_sc.release(); r_cf.release();
         r_lmin.release(); r_lmax.release(); r_inc.release();
@@ -286,7 +288,8 @@ void launch_local(admm_hip_ctx *c) {
     hipStream_t st = c->stream;
     if (c->nt > 0) {
         const int b0 = c->kind_begin[0], b1 = c->kind_begin[1], b2 = c->kind_begin[2], b3 = c->kind_begin[3];
-        TetArgs a{c->ldt, c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_cf.p, nullptr, 0};
+        TetArgs a{c->ldt, c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p,
+                  c->ch_ent.p, c->ch_group.p, c->ch_rec.p, c->t_rec.p, 0, nullptr, 0};
         auto stamp = [&]() {   // the next launch gets its own pair of stamp arrays
             if (c->timing && c->lk_launch < c->lk_cap) { a.ts = c->lk_ts.p + (size_t)c->lk_launch * 2 * c->lk_tsn; a.ts_n = c->lk_tsn; c->lk_launch += 1; }
             else a.ts = nullptr;
@@ -294,13 +297,14 @@ void launch_local(admm_hip_ctx *c) {
         const int b4 = c->kind_begin[4], b5 = c->kind_begin[5];
         const int kinds = (b1 > b0) + (b2 > b1) + (b3 > b2);
         if (b5 > b4) {    // SplineTet splines with a compression term: their own launch
-            stamp();
+            stamp(); a.chunk0 = c->chunk_base[4];
             hipLaunchKernelGGL((k_local_tets<4, WRITE_Z>), dim3(blocks_for(b5 - b4)), dim3(256), 0, st, b4, b5, a);
         }
-        if (b4 > b3) stamp();
+        if (b4 > b3) { stamp(); a.chunk0 = c->chunk_base[3]; }
         if (b4 > b3)      // co-rotated spline tets: their own launch (no BASELINE config mixes them in)
             hipLaunchKernelGGL((k_local_tets<3, WRITE_Z>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, b3, b4, a);
         if (b3 > b0) stamp();
+        a.chunk0 = b1 > b0 ? 0 : b2 > b1 ? c->chunk_base[1] : c->chunk_base[2];   // (fused: chunks 0 .. of the models it covers)
         if (kinds >= 2) { // mixed scene: one launch over all models
             const int n0 = blocks_for(b1 - b0), n1 = blocks_for(b2 - b1), n2 = blocks_for(b3 - b2);
             hipLaunchKernelGGL((k_local_tets_fused<WRITE_Z>), dim3(n0 + n1 + n2), dim3(256), 0, st, b0, b1, b2, b3, n0, n0 + n1, a);
@@ -320,7 +324,7 @@ void launch_local(admm_hip_ctx *c) {
 void launch_gather(admm_hip_ctx *c) {
     GatherArgs a{};
     a.nv = c->nv; a.n_slices = (c->nv + 63) / 64;
-    if (c->nt > 0) { a.t_ptr = c->t_inc.ptr.p; a.t_w = c->t_inc.w.p; a.t_inc = c->t_inc.idx.p; a.t_cf = c->t_cf.p; a.t_ld = c->ldt; }
+    if (c->nt > 0) { a.t_ptr = c->t_inc.ptr.p; a.t_w = c->t_inc.w.p; a.t_inc = c->t_inc.idx.p; a.t_rec = c->t_rec.p; }
     if (c->ntri > 0) { a.r_ptr = c->r_inc.ptr.p; a.r_w = c->r_inc.w.p; a.r_inc = c->r_inc.idx.p; a.r_cf = c->r_cf.p; a.r_ld = c->ldr; }
     if (c->npin_terms > 0) {
         a.vert_pin = c->vert_pin.p; a.pin_xyz = c->pin_xyz.p; a.pin_active = c->pin_active.p;
@@ -1132,11 +1136,19 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->t_mat.upload(mat)); HIP_TRY(c->mats.upload(mats));
         HIP_TRY(c->t_u.alloc((size_t)9 * ld)); HIP_TRY(c->t_u.zero());
         HIP_TRY(c->t_z.alloc((size_t)9 * ld)); HIP_TRY(c->t_z.zero());
-        HIP_TRY(c->t_cf.alloc((size_t)(ADMM_CF_AOS ? 16 : 12) * ld)); HIP_TRY(c->t_cf.zero());   // corner forces (kernels.hpp: kCfStride)
-        // incidence on the permuted numbering
+        // the chunks' reduction lists and the vertex -> records incidence, on the permuted numbering
+        static_assert(kChunkFanK == admm_host::kChunkFan && kChunkLdK == admm_host::kChunkLd, "kernels.hpp and host_setup.hpp disagree on the chunk layout");
         std::vector<int32_t> pidx((size_t)4 * nt);
         for (int n = 0; n < nt; ++n) { pidx[4 * n] = idx[n].x; pidx[4 * n + 1] = idx[n].y; pidx[4 * n + 2] = idx[n].z; pidx[4 * n + 3] = idx[n].w; }
-        HIP_TRY(c->t_inc.upload(admm_host::incidence_sell(nv, nt, 4, pidx.data(), nt * 4, g_order.data())));
+        const admm_host::TetChunks ch = admm_host::tet_chunks(nt, pidx.data(), c->kind_begin);
+        if ((size_t)ch.n_rec * 32 + 32 >= (size_t)1 << 31) return fail(ADMM_HIP_ERR_ARG, "too many corner-force records for 32-bit offsets");
+        c->chunk_base[0] = 0;
+        for (int gI = 0; gI < 5; ++gI) c->chunk_base[gI + 1] = c->chunk_base[gI] + blocks_for(cnt[gI]);
+        HIP_TRY(c->ch_ent.upload(ch.ent)); HIP_TRY(c->ch_group.upload(std::vector<int>(ch.group_base.begin(), ch.group_base.end())));
+        HIP_TRY(c->ch_rec.upload(std::vector<int>(ch.rec_base.begin(), ch.rec_base.end())));
+        HIP_TRY(c->t_rec.alloc((size_t)4 * (ch.n_rec + 1))); HIP_TRY(c->t_rec.zero());     // record n_rec stays zero: the padding of the incidence lists
+        HIP_TRY(c->t_inc.upload(admm_host::record_incidence(nv, ch.n_rec, ch.rec_vertex.data(), ch.n_rec, g_order.data())));
+        c->n_rec = ch.n_rec;
     }
     // ---- tris ----
     c->ntri = re - rb; c->ldr = c->ntri + 1;
@@ -1983,6 +1995,48 @@ int admm_host_greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *c
 
 void admm_host_block_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t leaf, int32_t *new_id) {
     admm_host::block_order(n_verts, n_elems, corners, idx, leaf, new_id);
+}
+
+int admm_host_chunk_reduce(int32_t n_verts, int32_t n_tets, const int32_t *tet_idx, const int32_t *kind_begin, const double *corner_forces,
+                           double *vertex_sums, int64_t *stats) {
+    if (n_verts < 1 || n_tets < 0 || !tet_idx || !kind_begin || !corner_forces || !vertex_sums) return fail(ADMM_HIP_ERR_ARG, "chunk_reduce: bad input");
+    const admm_host::TetChunks ch = admm_host::tet_chunks(n_tets, tet_idx, kind_begin);
+    const admm_host::Sell inc = admm_host::record_incidence(n_verts, ch.n_rec, ch.rec_vertex.data(), ch.n_rec);
+    // the block's LDS image: rows of kChunkLd doubles, row 3 c + j = component j of corner c, column = tet of the chunk, column 256 = 0
+    std::vector<double> lds((size_t)12 * admm_host::kChunkLd), rec((size_t)4 * (ch.n_rec + 1), 0.0);
+    int32_t chunk = 0;
+    int64_t max_groups = 0;
+    for (int k = 0; k < 5; ++k)
+        for (int32_t t0 = kind_begin[k]; t0 < kind_begin[k + 1]; t0 += 256, ++chunk) {
+            std::fill(lds.begin(), lds.end(), 0.0);
+            for (int32_t t = t0; t < std::min(kind_begin[k + 1], t0 + 256); ++t)
+                for (int c = 0; c < 12; ++c) lds[(size_t)c * admm_host::kChunkLd + (t - t0)] = corner_forces[12 * (size_t)t + c];
+            const int32_t nrec = ch.rec_base[chunk + 1] - ch.rec_base[chunk];
+            max_groups = std::max<int64_t>(max_groups, ch.group_base[chunk + 1] - ch.group_base[chunk]);
+            for (int32_t g = ch.group_base[chunk]; g < ch.group_base[chunk + 1]; ++g)
+                for (int tid = 0; tid < 256; ++tid) {
+                    double sum[3] = {0.0, 0.0, 0.0};
+                    for (int i = 0; i < admm_host::kChunkFan; ++i) {
+                        const size_t w = ch.ent[((size_t)g * 256 + tid) * admm_host::kChunkFan + i] / 8;
+                        for (int j = 0; j < 3; ++j) sum[j] += lds[w + (size_t)j * admm_host::kChunkLd];
+                    }
+                    const int32_t j = (g - ch.group_base[chunk]) * 256 + tid;
+                    if (j < nrec) for (int q = 0; q < 3; ++q) rec[4 * (size_t)(ch.rec_base[chunk] + j) + q] = sum[q];
+                }
+        }
+    int64_t max_w = 0;
+    for (int32_t v = 0; v < n_verts; ++v) {
+        const int32_t s = v / 64, l = v % 64;
+        double sum[3] = {0.0, 0.0, 0.0};
+        for (int32_t kk = 0; kk < inc.slice_width[s]; ++kk) {
+            const int32_t e = inc.idx[(size_t)inc.slice_ptr[s] + 64 * kk + l];
+            for (int q = 0; q < 3; ++q) sum[q] += rec[4 * (size_t)e + q];
+        }
+        max_w = std::max<int64_t>(max_w, inc.slice_width[s]);
+        for (int q = 0; q < 3; ++q) vertex_sums[3 * (size_t)v + q] = sum[q];
+    }
+    if (stats) { stats[0] = ch.n_chunks; stats[1] = ch.n_rec; stats[2] = max_groups; stats[3] = max_w; stats[4] = (int64_t)inc.idx.size(); }
+    return ADMM_HIP_OK;
 }
 
 void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id,

@@ -20,6 +20,12 @@
 namespace admm_dev {
 
 #define ADMM_M3(A, r, c) ((A)[(c) * 3 + (r)])
+#ifndef ADMM_COUNT
+#define ADMM_COUNT(slot)      // experiments/hostmath counts sweeps / rotations through this; nothing on the device
+#endif
+#ifndef ADMM_RECORD
+#define ADMM_RECORD(slot, value)
+#endif
 
 __device__ __forceinline__ double dot3(const double *a, const double *b) {
     return fma(a[0], b[0], fma(a[1], b[1], a[2] * b[2]));
@@ -45,41 +51,13 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return y;
 }
 
-// One Jacobi rotation annihilating a_pq of a symmetric 3x3; r is the third index.
-// vp, vq: the two affected eigenvector columns.  t = sgn(a) b / (|a| + sqrt(a^2 + b^2)), a = aqq-app, b = 2 apq.
-__device__ __forceinline__ bool jacobi_rotate(double &app, double &aqq, double &apq, double &arp, double &arq,
-                                              double *vp, double *vq) {
-    const double scale = fabs(app) + fabs(aqq);
-    if (!(fabs(apq) > 1e-17 * scale)) { return false; }
-    const double a = aqq - app, b = 2.0 * apq;
-    const double h2 = fma(a, a, b * b);
-    const double h = h2 * fast_rsqrt(h2);
-    const double t = copysign(1.0, a) * b * fast_rcp(fabs(a) + h);
-    const double c = fast_rsqrt(fma(t, t, 1.0));
-    const double s = t * c;
-    app = fma(-t, apq, app);
-    aqq = fma(t, apq, aqq);
-    apq = 0.0;
-    const double rp = arp, rq = arq;
-    arp = c * rp - s * rq;
-    arq = s * rp + c * rq;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double x = vp[i], y = vq[i];
-        vp[i] = c * x - s * y;
-        vq[i] = s * x + c * y;
-    }
-    return true;
-}
-
-// FP32 version used only to SEED the eigenvectors (quarter-rate hardware rcp/sqrt/rsq, 2-cycle VALU)
+// FP32 rotation used only to SEED the eigenvectors (quarter-rate hardware rcp/sqrt/rsq).  Unconditional: with b = 0 it is
+// the identity (t = 0, c = 1), so there is no branch whose two sides the compiler would have to merge with register copies.
 __device__ __forceinline__ void jacobi_rotate_f32(float &app, float &aqq, float &apq, float &arp, float &arq,
                                                   float *vp, float *vq) {
-    const float a = aqq - app, b = 2.0f * apq;
-    const float h2 = fmaf(a, a, b * b);
-    if (!(h2 > 1e-30f) || !(fabsf(b) > 1e-9f * (fabsf(app) + fabsf(aqq)))) return;
-    const float h = __builtin_amdgcn_sqrtf(h2);
-    const float t = copysignf(1.0f, a) * b * __builtin_amdgcn_rcpf(fabsf(a) + h);
+    const float a = aqq - app, b = apq + apq;
+    const float h = __builtin_amdgcn_sqrtf(fmaxf(fmaf(a, a, b * b), 1e-36f));
+    const float t = b * __builtin_amdgcn_rcpf(a + copysignf(h, a));      // sgn(a) b / (|a| + h)
     const float c = __builtin_amdgcn_rsqf(fmaf(t, t, 1.0f));
     const float s = t * c;
     app = fmaf(-t, apq, app);
@@ -87,73 +65,93 @@ __device__ __forceinline__ void jacobi_rotate_f32(float &app, float &aqq, float 
     apq = 0.0f;
     const float rp = arp, rq = arq;
     arp = c * rp - s * rq;
-    arq = s * rp + c * rq;
+    arq = fmaf(s, rp, c * rq);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const float x = vp[i], y = vq[i];
         vp[i] = c * x - s * y;
-        vq[i] = s * x + c * y;
+        vq[i] = fmaf(s, x, c * y);
     }
 }
 
-// Signed SVD  F = U diag(S) V^T,  U,V in SO(3),  S[0] >= S[1] >= |S[2]|, sign(S[2]) = sign(det F).
-// F, U, V column-major.
-// Mixed precision, full FP64 accuracy: (1) 4 cyclic Jacobi sweeps on F^T F in FP32 give V to ~1e-7;
-// (2) V is re-orthonormalised in FP64 and C' = V^T C V formed in FP64 (off-diagonals ~1e-7 |C|);
-// (3) FP64 Jacobi sweeps finish the job -- Jacobi converges quadratically, so one sweep (rarely two)
-// reaches round-off; the loop still runs to convergence, so the result does not depend on step (1).
+// One-sided (Hestenes) Jacobi rotation in FP64: rotates columns p, q of B = F V (and of V) so that b_p . b_q = 0.
+// al = |b_p|^2, be = |b_q|^2, ga = b_p . b_q.  Same angle as the two-sided rotation of F^T F: t = sgn(a) b / (|a| + sqrt(a^2 + b^2)).
+// t only steers the convergence (one Newton step on the 2^-24 hardware seeds); c decides the orthogonality of V (two steps).
+__device__ __forceinline__ void hestenes_rotate(double *bp, double *bq, double *vp, double *vq, double al, double be, double ga) {
+    ADMM_COUNT(2);
+    const double a = be - al, b = ga + ga;
+    const double h2 = fmax(fma(a, a, b * b), 1e-300);
+    double y = __builtin_amdgcn_rsq(h2);
+    y = fma(y, fma(-0.5 * h2 * y, y, 0.5), y);
+    const double den = fma(h2, y, fabs(a));
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(r, fma(-den, r, 1.0), r);
+    const double t = copysign(b, a * b) * r;        // sgn(a) b / den   (a = 0: the sign of b, i.e. a 45 degree rotation)
+    const double c = fast_rsqrt(fma(t, t, 1.0));
+    const double s = t * c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double x = bp[i], z = bq[i];
+        bp[i] = c * x - s * z;
+        bq[i] = fma(s, x, c * z);
+        const double vx = vp[i], vz = vq[i];
+        vp[i] = c * vx - s * vz;
+        vq[i] = fma(s, vx, c * vz);
+    }
+}
+
+// Signed SVD  F = U diag(S) V^T with U, V in SO(3).  S is NOT sorted (every energy of the library is a symmetric function of
+// the stretches; the reference sorts, src/FastSVD.hpp:43-68); at most one entry is negative, and then it is the one of
+// smallest magnitude (the reference's convention: the sign of det F goes to the smallest stretch).
+// F, U, V column-major.  Mixed precision, FP64 result:
+//  (1) FP32 cyclic Jacobi on the DEVIATORIC part of F^T F, scaled to unit norm: the eigenvectors are those of F^T F, and an
+//      element at strain 1e-6 is resolved as well as one at strain 1 (on the trace-normalised matrix the FP32 phase stalled at
+//      1e-7 / strain and the FP64 phase paid for it with extra sweeps).  Three sweeps, a fourth if some lane of the wave is not
+//      at the FP32 floor yet (wave-uniform decisions: straight-line code, no merges).
+//  (2) V is re-orthonormalised in FP64, B = F V.
+//  (3) ONE one-sided (Hestenes) FP64 Jacobi sweep on the columns of B -- Jacobi converges quadratically, so the 1e-7 of the seed
+//      becomes round-off; further sweeps only while some pair of columns of some lane is not orthogonal to 3e-14 (cosine).
+//  (4) U by Gram-Schmidt on B: U in SO(3) by construction, the last stretch u2 . b2 carries the sign of det F; if it is negative
+//      and not the smallest, the sign is moved by flipping two columns of U (no sorting, no special case for flat elements).
 __device__ __forceinline__ void signed_svd3(const double *F, double *U, double *S, double *V) {
-    // C = F^T F
-    double c00 = dot3(F + 0, F + 0), c01 = dot3(F + 0, F + 3), c02 = dot3(F + 0, F + 6);
-    double c11 = dot3(F + 3, F + 3), c12 = dot3(F + 3, F + 6), c22 = dot3(F + 6, F + 6);
-    double v0[3] = {1, 0, 0}, v1[3] = {0, 1, 0}, v2[3] = {0, 0, 1};
-    const double tr = c00 + c11 + c22;
-    if (tr > 1e-280) {
-        // (1) FP32 seed on the trace-normalised matrix
-        const double itr = fast_rcp(tr);
-        float a00 = (float)(c00 * itr), a01 = (float)(c01 * itr), a02 = (float)(c02 * itr);
-        float a11 = (float)(c11 * itr), a12 = (float)(c12 * itr), a22 = (float)(c22 * itr);
+    double v0[3], v1[3], v2[3];
+    const double c00 = dot3(F + 0, F + 0), c01 = dot3(F + 0, F + 3), c02 = dot3(F + 0, F + 6);
+    const double c11 = dot3(F + 3, F + 3), c12 = dot3(F + 3, F + 6), c22 = dot3(F + 6, F + 6);
+    const double m = (c00 + c11 + c22) * (1.0 / 3.0);
+    const double d0 = c00 - m, d1 = c11 - m, d2 = c22 - m;
+    const double o2 = fma(c01, c01, fma(c02, c02, c12 * c12));
+    const double nd2 = fma(d0, d0, fma(d1, d1, fma(d2, d2, o2 + o2)));
+    const bool seeded = nd2 > 1e-30 * m * m && nd2 > 1e-280;     // else: a multiple of the identity to round-off, V = I
+    {
+        const double inv = seeded ? __builtin_amdgcn_rsq(nd2) : 0.0;
+        float a00 = (float)(d0 * inv), a01 = (float)(c01 * inv), a02 = (float)(c02 * inv);
+        float a11 = (float)(d1 * inv), a12 = (float)(c12 * inv), a22 = (float)(d2 * inv);
         float w0[3] = {1.f, 0.f, 0.f}, w1[3] = {0.f, 1.f, 0.f}, w2[3] = {0.f, 0.f, 1.f};
-#pragma unroll 1
-#ifndef ADMM_F32_SWEEPS
-#define ADMM_F32_SWEEPS 4
+#ifndef ADMM_F32_OFF2
+#define ADMM_F32_OFF2 2e-13f
 #endif
-        for (int sweep = 0; sweep < ADMM_F32_SWEEPS; ++sweep) {
-            jacobi_rotate_f32(a00, a11, a01, a02, a12, w0, w1);
-            jacobi_rotate_f32(a00, a22, a02, a01, a12, w0, w2);
-            jacobi_rotate_f32(a11, a22, a12, a01, a02, w1, w2);
-        }
-        // (2) orthonormalise in FP64 (Gram-Schmidt; v2 = v0 x v1) and rotate C into that basis
+#define ADMM_F32_SWEEP() { ADMM_COUNT(0); jacobi_rotate_f32(a00, a11, a01, a02, a12, w0, w1); jacobi_rotate_f32(a00, a22, a02, a01, a12, w0, w2); \
+                           jacobi_rotate_f32(a11, a22, a12, a01, a02, w1, w2); }
+        ADMM_F32_SWEEP(); ADMM_F32_SWEEP(); ADMM_F32_SWEEP();
+        if (__any(fmaf(a01, a01, fmaf(a02, a02, a12 * a12)) > ADMM_F32_OFF2)) ADMM_F32_SWEEP();
+#undef ADMM_F32_SWEEP
+        // (2) orthonormalise in FP64 (Gram-Schmidt; the columns are unit vectors to 1e-7: 1/sqrt(1 + e) by its series)
 #pragma unroll
         for (int i = 0; i < 3; ++i) { v0[i] = (double)w0[i]; v1[i] = (double)w1[i]; }
-        double n = fast_rsqrt(dot3(v0, v0));
+        double e = dot3(v0, v0) - 1.0;
+        double n = fma(e, fma(e, 0.375, -0.5), 1.0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) v0[i] *= n;
         const double pr01 = dot3(v0, v1);
 #pragma unroll
         for (int i = 0; i < 3; ++i) v1[i] = fma(-pr01, v0[i], v1[i]);
-        n = fast_rsqrt(dot3(v1, v1));
+        e = dot3(v1, v1) - 1.0;
+        n = fma(e, fma(e, 0.375, -0.5), 1.0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) v1[i] *= n;
         cross3(v0, v1, v2);
-        // W = C V (columns), then C' = V^T W (symmetric)
-        double x0[3], x1[3], x2[3];
-        x0[0] = fma(c00, v0[0], fma(c01, v0[1], c02 * v0[2])); x0[1] = fma(c01, v0[0], fma(c11, v0[1], c12 * v0[2])); x0[2] = fma(c02, v0[0], fma(c12, v0[1], c22 * v0[2]));
-        x1[0] = fma(c00, v1[0], fma(c01, v1[1], c02 * v1[2])); x1[1] = fma(c01, v1[0], fma(c11, v1[1], c12 * v1[2])); x1[2] = fma(c02, v1[0], fma(c12, v1[1], c22 * v1[2]));
-        x2[0] = fma(c00, v2[0], fma(c01, v2[1], c02 * v2[2])); x2[1] = fma(c01, v2[0], fma(c11, v2[1], c12 * v2[2])); x2[2] = fma(c02, v2[0], fma(c12, v2[1], c22 * v2[2]));
-        c00 = dot3(v0, x0); c01 = dot3(v0, x1); c02 = dot3(v0, x2);
-        c11 = dot3(v1, x1); c12 = dot3(v1, x2); c22 = dot3(v2, x2);
     }
-    // (3) FP64 sweeps to convergence
-#pragma unroll 1
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        bool any = false;
-        any |= jacobi_rotate(c00, c11, c01, c02, c12, v0, v1);
-        any |= jacobi_rotate(c00, c22, c02, c01, c12, v0, v2);
-        any |= jacobi_rotate(c11, c22, c12, c01, c02, v1, v2);
-        if (!any) break;
-    }
-    // B = F V ; stretches are the column norms (more accurate than sqrt of the eigenvalues)
+    // B = F V
     double b0[3], b1[3], b2[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -161,21 +159,34 @@ __device__ __forceinline__ void signed_svd3(const double *F, double *U, double *
         b1[r] = fma(F[r], v1[0], fma(F[3 + r], v1[1], F[6 + r] * v1[2]));
         b2[r] = fma(F[r], v2[0], fma(F[3 + r], v2[1], F[6 + r] * v2[2]));
     }
-    double n0 = dot3(b0, b0), n1 = dot3(b1, b1), n2 = dot3(b2, b2);
-    // sort descending (swap b and v columns together)
-#define ADMM_SWAP3(x, y) { _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) { double t_ = x[i_]; x[i_] = y[i_]; y[i_] = t_; } }
-    if (n0 < n1) { ADMM_SWAP3(b0, b1); ADMM_SWAP3(v0, v1); double t = n0; n0 = n1; n1 = t; }
-    if (n0 < n2) { ADMM_SWAP3(b0, b2); ADMM_SWAP3(v0, v2); double t = n0; n0 = n2; n2 = t; }
-    if (n1 < n2) { ADMM_SWAP3(b1, b2); ADMM_SWAP3(v1, v2); double t = n1; n1 = n2; n2 = t; }
-#undef ADMM_SWAP3
-    // make V a rotation: v2 = v0 x v1 (equals +-v2); flip b2 with it
-    double vx[3];
-    cross3(v0, v1, vx);
-    if (dot3(vx, v2) < 0.0) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { v2[i] = -v2[i]; b2[i] = -b2[i]; }
+    // (3) FP64 one-sided sweeps until every pair of columns is orthogonal: cos^2 <= ADMM_SVD_TOL2.  Then F = U diag(S) V^T to
+    // ~3e-14 |F| whatever the order of the columns in the Gram-Schmidt below.
+#ifndef ADMM_SVD_TOL2
+#define ADMM_SVD_TOL2 1e-27
+#endif
+    double n0, n1, n2;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        hestenes_rotate(b0, b1, v0, v1, dot3(b0, b0), dot3(b1, b1), dot3(b0, b1));
+        hestenes_rotate(b0, b2, v0, v2, dot3(b0, b0), dot3(b2, b2), dot3(b0, b2));
+        hestenes_rotate(b1, b2, v1, v2, dot3(b1, b1), dot3(b2, b2), dot3(b1, b2));
+        ADMM_COUNT(1);
+        n0 = dot3(b0, b0); n1 = dot3(b1, b1); n2 = dot3(b2, b2);
+        const double g01 = dot3(b0, b1), g02 = dot3(b0, b2), g12 = dot3(b1, b2);
+        ADMM_RECORD(8 + sweep, fmax(g01 * g01 / fmax(n0 * n1, 1e-300), fmax(g02 * g02 / fmax(n0 * n2, 1e-300), g12 * g12 / fmax(n1 * n2, 1e-300))));
+        const bool open = g01 * g01 > ADMM_SVD_TOL2 * n0 * n1 || g02 * g02 > ADMM_SVD_TOL2 * n0 * n2 || g12 * g12 > ADMM_SVD_TOL2 * n1 * n2;
+        if (!__any(open)) break;
     }
-    // U by Gram-Schmidt on b0, b1; u2 = u0 x u1
+    // (4) U by Gram-Schmidt on b0, b1; u2 = u0 x u1.  A column that is round-off (flat or collapsed element) must not be one
+    // of the two the basis is built from: only then (rare, whole waves skip it) sort the columns by norm.  Every swap is a
+    // rotation (the moved column changes sign), so V stays in SO(3) and F = B V^T.
+    if (fmin(n0, fmin(n1, n2)) <= 1e-28 * fmax(n0, fmax(n1, n2))) {
+#define ADMM_SWAPNEG3(x, y) { _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) { const double t_ = x[i_]; x[i_] = y[i_]; y[i_] = -t_; } }
+        if (n0 < n1) { ADMM_SWAPNEG3(b0, b1); ADMM_SWAPNEG3(v0, v1); const double t = n0; n0 = n1; n1 = t; }
+        if (n0 < n2) { ADMM_SWAPNEG3(b0, b2); ADMM_SWAPNEG3(v0, v2); const double t = n0; n0 = n2; n2 = t; }
+        if (n1 < n2) { ADMM_SWAPNEG3(b1, b2); ADMM_SWAPNEG3(v1, v2); const double t = n1; n1 = n2; n2 = t; }
+#undef ADMM_SWAPNEG3
+    }
     double u0[3], u1[3], u2[3];
     double s0 = 0.0;
     if (n0 > 1e-300) {
@@ -189,10 +200,10 @@ __device__ __forceinline__ void signed_svd3(const double *F, double *U, double *
     double wn = dot3(w, w);
     if (!(wn > 1e-30 * n0) || !(wn > 1e-300)) {
         // rank <= 1: any unit vector orthogonal to u0
-        double e[3] = {0.0, 0.0, 0.0};
+        double ee[3] = {0.0, 0.0, 0.0};
         const double a0 = fabs(u0[0]), a1 = fabs(u0[1]), a2 = fabs(u0[2]);
-        if (a0 <= a1 && a0 <= a2) e[0] = 1.0; else if (a1 <= a2) e[1] = 1.0; else e[2] = 1.0;
-        cross3(u0, e, w);
+        if (a0 <= a1 && a0 <= a2) ee[0] = 1.0; else if (a1 <= a2) ee[1] = 1.0; else ee[2] = 1.0;
+        cross3(u0, ee, w);
         wn = dot3(w, w);
     }
     {
@@ -201,12 +212,14 @@ __device__ __forceinline__ void signed_svd3(const double *F, double *U, double *
         for (int i = 0; i < 3; ++i) u1[i] = w[i] * inv;
     }
     cross3(u0, u1, u2);
-    S[0] = s0;
-    S[1] = dot3(u1, b1);
-    S[2] = dot3(u2, b2);
+    double s1 = dot3(u1, b1), s2 = dot3(u2, b2);
+    // the sign of det F sits on s2; the convention wants it on the smallest stretch: flip u2 and that column of U
+    const bool f0 = s2 < 0.0 && s0 < -s2 && s0 <= s1, f1 = s2 < 0.0 && s1 < -s2 && !f0;
+    const double g0 = f0 ? -1.0 : 1.0, g1 = f1 ? -1.0 : 1.0, g2 = (f0 || f1) ? -1.0 : 1.0;
+    S[0] = s0 * g0; S[1] = s1 * g1; S[2] = s2 * g2;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        U[i] = u0[i]; U[3 + i] = u1[i]; U[6 + i] = u2[i];
+        U[i] = u0[i] * g0; U[3 + i] = u1[i] * g1; U[6 + i] = u2[i] * g2;
         V[i] = v0[i]; V[3 + i] = v1[i]; V[6 + i] = v2[i];
     }
 }
@@ -324,6 +337,57 @@ struct StretchModel {
     }
 };
 
+// Newton direction at (s, g, D, w): Sherman-Morrison solve with |D| floored, frozen components on the s = 0 boundary (StVK),
+// scaled steepest descent if the rank-one part makes it no descent direction.  Returns false at a zero (reduced) gradient.
+// pure = the exact Newton step (no floored / flipped curvature, no frozen component).
+template <int KIND, typename T>
+__device__ __forceinline__ bool newton_direction(const StretchModel<KIND, T> &m, const T *s, const T *g, const T *D, const T *w,
+                                                 T *d, T &gd, bool &pure) {
+    const T floorD = T(1e-8) * (t_abs(m.k) + t_abs(m.mu)) + T(1e-30);
+    T a[3], y[3];
+    T wDg = T(0), wDw = T(0);
+    pure = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T Di = t_max(t_abs(D[i]), floorD);
+        const bool active = (KIND >= 2) && (s[i] <= T(0)) && (g[i] > T(0));
+        pure = pure && !active && (D[i] >= floorD);
+        a[i] = active ? T(0) : t_rcp(Di);
+        y[i] = g[i] * a[i];
+        wDg = t_fma(w[i], y[i], wDg);
+        wDw = t_fma(w[i] * w[i], a[i], wDw);
+    }
+    const T den = t_fma(m.la, wDw, T(1));
+    const T coef = (den > T(1e-6)) ? m.la * wDg * t_rcp(den) : T(0);
+    pure = pure && (den > T(1e-6));
+    gd = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        d[i] = -(y[i] - coef * w[i] * a[i]);
+        gd = t_fma(g[i], d[i], gd);
+    }
+    if (!(gd < T(0))) { // not a descent direction (indefinite rank-one part): scaled steepest descent
+        gd = T(0); pure = false;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { d[i] = -y[i]; gd = t_fma(g[i], d[i], gd); }
+        if (!(gd < T(0))) return false;
+    }
+    return true;
+}
+// Is the step d small enough to be applied without re-evaluation (quadratic convergence: the remaining error is ~ step^2)?
+// That error is ~ step^2 times (third / second derivative) ~ step^2 / s_min near the barrier / the s = 0 boundary: the
+// threshold scales with min(1, s_min)^2, never below the 1e-9 the FP64 callers tolerate; and the estimate only holds for
+// an exact Newton step.
+template <typename T>
+__device__ __forceinline__ bool newton_step_is_final(const T *s, const T *d, bool pure, T tol_final) {
+    T dmax = T(0), mag = T(1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { dmax = t_max(dmax, t_abs(d[i])); mag = t_max(mag, t_abs(s[i])); }
+    const T smin = t_max(T(0), t_min(T(1), t_min(s[0], t_min(s[1], s[2]))));
+    const T tol_floor = sizeof(T) == 4 ? tol_final * T(0.03) : T(1e-9);
+    return dmax <= (pure ? t_max(tol_final * smin * smin, tol_floor) : tol_floor) * mag;
+}
+
 // Safeguarded Newton for argmin_s Psi(s) + k/2 |s - x0|^2, started from s (in/out); returns iterations.
 //  - Hessian = diag(D) + la w w^T  -> Sherman-Morrison solve, |D| floored to stay positive definite
 //  - NH: the log barrier keeps iterates strictly positive.  StVK: the feasible set is s >= 0 and for
@@ -331,52 +395,34 @@ struct StretchModel {
 //    with an outward gradient are frozen, trial points are projected back)
 //  - Armijo backtracking on the objective, evaluated once per trial point (value+gradient+Hessian)
 //  - a predicted step below tol_final is applied without re-evaluation and ends the iteration
-//    (quadratic convergence: the remaining error is ~ step^2)
+//  - the common case -- the FIRST step is already that final step in every lane of the wave (the callers start close) --
+//    is straight-line code under a wave-uniform branch; the general loop follows only for waves that need it
 template <int KIND, typename T>
 __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T *s, int max_it, T tol_final, T noise, int max_ls) {
     T g[3], D[3], w[3];
     T f = m.eval(s, g, D, w);
+    {
+        T d[3], gd, sn[3];
+        bool pure;
+        const bool desc = newton_direction<KIND, T>(m, s, g, D, w, d, gd, pure);
+        bool fin = desc && newton_step_is_final<T>(s, d, pure, tol_final);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (KIND >= 2) sn[i] = t_max(sn[i], T(0)); }
+        fin = fin && m.feasible(sn);
+        if (__all(fin)) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s[i] = sn[i];
+            return 1;
+        }
+    }
     const T fscale = T(4) * (t_abs(m.mu) + t_abs(m.la) + t_abs(m.k));
     int it = 0;
 #pragma unroll 1
     for (; it < max_it; ++it) {
-        const T floorD = T(1e-8) * (t_abs(m.k) + t_abs(m.mu)) + T(1e-30);
-        T a[3], y[3];
-        T wDg = T(0), wDw = T(0);
-        bool pure = true;   // the step below is the exact Newton step (no floored / flipped curvature, no frozen component)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const T Di = t_max(t_abs(D[i]), floorD);
-            const bool active = (KIND >= 2) && (s[i] <= T(0)) && (g[i] > T(0));
-            pure = pure && !active && (D[i] >= floorD);
-            a[i] = active ? T(0) : t_rcp(Di);
-            y[i] = g[i] * a[i];
-            wDg = t_fma(w[i], y[i], wDg);
-            wDw = t_fma(w[i] * w[i], a[i], wDw);
-        }
-        const T den = t_fma(m.la, wDw, T(1));
-        const T coef = (den > T(1e-6)) ? m.la * wDg * t_rcp(den) : T(0);
-        pure = pure && (den > T(1e-6));
-        T d[3], gd = T(0), dmax = T(0), mag = T(1);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            d[i] = -(y[i] - coef * w[i] * a[i]);
-            gd = t_fma(g[i], d[i], gd);
-        }
-        if (!(gd < T(0))) { // not a descent direction (indefinite rank-one part): scaled steepest descent
-            gd = T(0); pure = false;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) { d[i] = -y[i]; gd = t_fma(g[i], d[i], gd); }
-            if (!(gd < T(0))) break; // zero (reduced) gradient
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { dmax = t_max(dmax, t_abs(d[i])); mag = t_max(mag, t_abs(s[i])); }
-        // the error left by an un-re-evaluated step is ~ step^2 * |f'''/f''| ~ step^2 / s_min near the barrier /
-        // the s = 0 boundary: scale the threshold by min(1, s_min)^2, never below the 1e-9 the FP64 callers tolerate;
-        // and that estimate only holds for an exact Newton step (quadratic convergence)
-        const T smin = t_max(T(0), t_min(T(1), t_min(s[0], t_min(s[1], s[2]))));
-        const T tol_floor = sizeof(T) == 4 ? tol_final * T(0.03) : T(1e-9);
-        if (dmax <= (pure ? t_max(tol_final * smin * smin, tol_floor) : tol_floor) * mag) { // final correction: apply and stop
+        T d[3], gd;
+        bool pure;
+        if (!newton_direction<KIND, T>(m, s, g, D, w, d, gd, pure)) break;
+        if (newton_step_is_final<T>(s, d, pure, tol_final)) { // final correction: apply and stop
             T sn[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (KIND >= 2) sn[i] = t_max(sn[i], T(0)); }
@@ -573,7 +619,7 @@ __device__ __forceinline__ void prox_stretches_kappa(int type, double mu, double
     m.x0[0] = S[0]; m.x0[1] = S[1]; m.x0[2] = S[2];       // :124 set_x0 (before the fix-ups)
     const double eps = 1e-6;
     if (fabs(S[0]) < eps && fabs(S[1]) < eps && fabs(S[2]) < eps) { S[0] = eps; S[1] = eps; S[2] = eps; } // :128-131
-    if (S[2] < 0.0) S[2] = -S[2];                           // :133
+    S[0] = fabs(S[0]); S[1] = fabs(S[1]); S[2] = fabs(S[2]);   // :133
     if (type == 0) { S[0] = fmax(S[0], 1e-12); S[1] = fmax(S[1], 1e-12); S[2] = fmax(S[2], 1e-12); }
     newton_stretch_dense(m, S, 200);
 }
@@ -588,7 +634,7 @@ __device__ __forceinline__ void prox_stretches(double mu, double la, double k, d
     double x0[3] = {S[0], S[1], S[2]};                      // :124 set_x0 (before the fix-ups)
     const double eps = 1e-6;
     if (fabs(S[0]) < eps && fabs(S[1]) < eps && fabs(S[2]) < eps) { S[0] = eps; S[1] = eps; S[2] = eps; } // :128-131
-    if (S[2] < 0.0) S[2] = -S[2];                           // :133
+    S[0] = fabs(S[0]); S[1] = fabs(S[1]); S[2] = fabs(S[2]);   // :133 (flips the signed smallest stretch, wherever signed_svd3 left it)
     if (KIND == 1) { // keep the start strictly inside the log barrier
         S[0] = fmax(S[0], 1e-12); S[1] = fmax(S[1], 1e-12); S[2] = fmax(S[2], 1e-12);
     }

@@ -165,6 +165,72 @@ Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int
     return S;
 }
 
+TetChunks tet_chunks(int32_t n_tets, const int32_t *tet_idx, const int32_t kind_begin[6]) {
+    TetChunks C;
+    C.group_base.push_back(0); C.rec_base.push_back(0);
+    std::vector<std::pair<int32_t, int32_t>> vc;      // (vertex, tl * 4 + corner) of one chunk
+    for (int k = 0; k < 5; ++k) {
+        for (int32_t t0 = kind_begin[k]; t0 < kind_begin[k + 1]; t0 += 256) {
+            const int32_t t1 = std::min(kind_begin[k + 1], t0 + 256);
+            vc.clear();
+            for (int32_t t = t0; t < t1; ++t)
+                for (int c = 0; c < 4; ++c) vc.emplace_back(tet_idx[4 * (size_t)t + c], (t - t0) * 4 + c);
+            std::sort(vc.begin(), vc.end());
+            // records: runs of one vertex, cut after kChunkFan entries
+            const size_t g0 = C.ent.size();
+            int32_t nrec = 0;
+            for (size_t i = 0; i < vc.size();) {
+                size_t j = i;
+                while (j < vc.size() && vc[j].first == vc[i].first && j - i < (size_t)kChunkFan) ++j;
+                for (size_t e = i; e < i + kChunkFan; ++e) {
+                    uint16_t off = kChunkPad;
+                    if (e < j) { const int32_t tl = vc[e].second >> 2, c = vc[e].second & 3; off = (uint16_t)(((3 * c) * kChunkLd + tl) * 8); }
+                    C.ent.push_back(off);
+                }
+                C.rec_vertex.push_back(vc[i].first);
+                ++nrec;
+                i = j;
+            }
+            const int32_t groups = std::max(1, (nrec + 255) / 256);
+            C.ent.resize(g0 + (size_t)groups * 256 * kChunkFan, kChunkPad);
+            C.group_base.push_back(C.group_base.back() + groups);
+            C.rec_base.push_back(C.rec_base.back() + nrec);
+            C.n_chunks += 1;
+        }
+    }
+    C.n_rec = C.rec_base.back();
+    (void)n_tets;
+    return C;
+}
+
+Sell record_incidence(int32_t n_verts, int32_t n_rec, const int32_t *rec_vertex, int32_t pad_code, const int32_t *row_vertex) {
+    std::vector<int32_t> cnt(n_verts + 1, 0);
+    for (int32_t i = 0; i < n_rec; ++i) cnt[rec_vertex[i] + 1]++;
+    for (int32_t i = 0; i < n_verts; ++i) cnt[i + 1] += cnt[i];
+    std::vector<int32_t> lst(cnt[n_verts]);
+    std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
+    for (int32_t e = 0; e < n_rec; ++e) lst[pos[rec_vertex[e]]++] = e;
+    Sell S;
+    S.n_rows = n_verts;
+    S.n_slices = (n_verts + 63) / 64;
+    S.slice_ptr.assign(S.n_slices + 1, 0);
+    S.slice_width.assign(S.n_slices, 0);
+    auto vert = [&](int32_t r) { return row_vertex ? row_vertex[r] : r; };
+    for (int32_t s = 0; s < S.n_slices; ++s) {
+        int32_t w = 0;
+        for (int32_t r = 64 * s; r < std::min(n_verts, 64 * s + 64); ++r) w = std::max(w, cnt[vert(r) + 1] - cnt[vert(r)]);
+        w = std::max(4, (w + 3) / 4 * 4);   // the gather consumes 4 records per pipelined round
+        S.slice_width[s] = w;
+        S.slice_ptr[s + 1] = S.slice_ptr[s] + 64 * w;
+    }
+    S.idx.assign(S.slice_ptr[S.n_slices], pad_code);
+    for (int32_t r = 0; r < n_verts; ++r) {
+        const int32_t s = r / 64, l = r % 64, v = vert(r);
+        for (int32_t k = 0; k < cnt[v + 1] - cnt[v]; ++k) S.idx[(size_t)S.slice_ptr[s] + 64 * k + l] = lst[cnt[v] + k];
+    }
+    return S;
+}
+
 // Row order of the incidence lists: inside every window of 512 consecutive vertices the vertices with the most incident
 // elements come first, so the 64 rows of a slice have similar lengths (unstructured 1 M-tet body: 2.17x -> 1.24x stored
 // per real incidence) while a slice still gathers from one neighbourhood of the mesh.

@@ -40,6 +40,24 @@ Sell csr_to_sell(const Csr &A);
 // vertex -> list of (element, corner) codes, code = elem * stride + corner; padding = pad_code
 // row_vertex (optional, a permutation of the vertices): row r of the SELL holds the list of vertex row_vertex[r]
 Sell incidence_sell(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t pad_code, const int32_t *row_vertex = nullptr);
+// Block-level reduction of the tet corner forces (kernels.hpp: tet_compute_store).  A CHUNK = the 256 consecutive tets one
+// block of the local step works on (chunks never straddle two constitutive models).  The block parks its 1024 corner forces in
+// LDS and sums them per vertex into RECORDS of at most kChunkFan corner forces each (a vertex with more incident corners in the
+// chunk gets several records), one record per thread and pass: the right-hand-side gather then reads ~3-4 records per vertex
+// instead of ~24 corner forces, and the local step writes ~25 instead of 96 bytes per tet.
+constexpr int kChunkFan = 8;            // corner forces per record = 16-byte entry list per thread
+constexpr int kChunkLd = 257;           // doubles between two rows of the LDS block (column 256 = the all-zero padding column)
+constexpr uint16_t kChunkPad = 256 * 8; // LDS byte offset of the padding entry
+struct TetChunks {
+    int32_t n_chunks = 0, n_rec = 0;
+    std::vector<uint16_t> ent;          // [n_groups][256][kChunkFan]: LDS byte offsets (x component) of the corner forces of record (group, thread)
+    std::vector<int32_t> group_base;    // [n_chunks + 1]: first 256-record group of a chunk (one group per chunk for tets in a vertex-coherent order)
+    std::vector<int32_t> rec_base;      // [n_chunks + 1]: first record of a chunk
+    std::vector<int32_t> rec_vertex;    // [n_rec]
+};
+TetChunks tet_chunks(int32_t n_tets, const int32_t *tet_idx, const int32_t kind_begin[6]);
+// vertex -> records incidence lists (row r gathers for vertex row_vertex[r]); widths are multiples of 4, padding = pad_code
+Sell record_incidence(int32_t n_verts, int32_t n_rec, const int32_t *rec_vertex, int32_t pad_code, const int32_t *row_vertex = nullptr);
 std::vector<int32_t> incidence_row_order(int32_t n_verts, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int32_t window);
 
 int greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color);

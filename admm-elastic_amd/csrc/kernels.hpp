@@ -177,13 +177,17 @@ __global__ __launch_bounds__(256) void k_finish(int n3, double inv_dt, double *_
 
 // ---------------------------------------------------------------------------------------------------
 // LOCAL STEP, tets: EnergyTerm::update (src/EnergyTerm.hpp:130-140) for every tet of one constitutive
-// model, fused with the element's contribution to dt^2 D^T W^2 (z - u) (src/Solver.cpp:98), written as
-// 4 corner force vectors cf[12][ld] that k_gather_rhs sums per vertex (no atomics, deterministic).
+// model, fused with the element's contribution to dt^2 D^T W^2 (z - u) (src/Solver.cpp:98): the block (= CHUNK of 256
+// consecutive tets) parks its 4 x 256 corner force vectors in LDS and sums them per vertex into RECORDS (host_setup.hpp:
+// TetChunks; fixed order, no atomics, deterministic) that k_gather_rhs sums per vertex -- ~25 B per tet written and ~4
+// sectors per vertex gathered instead of 96 B per tet and ~24 scattered corner forces per vertex.
 //   F = [x1-x0, x2-x0, x3-x0] Binv  ==  D_i x   (D-block of src/TetEnergyTerm.cpp:50-71)
+constexpr int kChunkFanK = 8, kChunkLdK = 257;   // == admm_host::kChunkFan, kChunkLd (checked in admm_hip.hip)
 struct TetArgs {
     int ld;
     const int4 *idx; const double *Binv; double *u; double *z; const double *sc; const int *mat_id; const Mat *mats;
-    const double *x; double *cf;
+    const double *x;
+    const unsigned short *ch_ent; const int *ch_group, *ch_rec; double *rec; int chunk0;   // chunk plan, records [n_rec + 1][4], first chunk of this launch
     // kernel-level timing (stats only): every wave stores the device wall clock at entry in ts[wave slot] and at exit in
     // ts[ts_n + wave slot]; nullptr = off.  max(exit) - min(entry) is the launch's
     // duration as rocprofv3 reports it, without the dispatch gaps an event pair around the launch also counts.
@@ -286,22 +290,15 @@ __device__ __forceinline__ void tet_gather(const TetArgs &a, const int4 id, TetP
 }
 
 // prox + dual update + corner forces of one tet from its loaded inputs
-// Corner forces: SoA cf[12][ld] (default).  ADMM_CF_AOS=1 (A/B, measured and NOT kept): one 128-byte record per tet (corner c
-// at doubles [3 c, 3 c + 3)), so that the right-hand-side gather reads the 24 bytes of an incidence from ONE sector instead of
-// three 8-byte elements of three SoA arrays (on the unstructured 1 M-tet body the SoA gather fetches 3.3x its algorithmic
-// bytes), written through a wave-private transposition in LDS -- the wave's own columns of the rows that parked Binv / V -- so
-// that every store instruction covers whole sectors.  Same box, 1 M tets: unstructured body local step 69.4 -> 76.3 us, gather
-// 83.0 -> 67.5 us (+1.6 % ADMM it/s); Kuhn cube 69.3 -> 74.6 us and 51.6 -> 66.2 us (-2.4 %): the staged stores cost the local
-// step more than the gather gains, and on the cube the SoA gather was the coalesced one.
-#ifndef ADMM_CF_AOS
-#define ADMM_CF_AOS 0
-#endif
-constexpr int kCfStride = ADMM_CF_AOS ? 16 : 1;   // doubles between the records of consecutive tets (AoS) / elements (SoA)
-
+// LDS block of the local step: rows of kChunkLdK doubles, one column per thread (thread-private, conflict-free 8-byte
+// accesses) plus the all-zero padding column 256.  Rows 0..8 park Binv across the prox, rows 9..17 V (StVK); after the prox
+// rows 0..11 hold the thread's four corner forces for the chunk's reduction.
+typedef __attribute__((address_space(3))) double LdsDk;
 template <int KIND, bool WRITE_Z>
-__device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, int t_end, bool valid, const TetIn &in, const TetPos &x, double (*sBi)[256], double (*sV)[256]) {
+__device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool valid, int chunk, const TetIn &in, const TetPos &x, LdsDk *sL) {
     const int ld8 = a.ld * 8, t8 = t * 8;
-    const __amdgpu_buffer_rsrc_t ru = soa_rsrc(a.u), rcf = soa_rsrc(a.cf);
+    const __amdgpu_buffer_rsrc_t ru = soa_rsrc(a.u);
+    LdsDk *sBi = sL + threadIdx.x, *sV = sL + 9 * kChunkLdK + threadIdx.x;     // row c of this thread: [c * kChunkLdK]
     const Mat *__restrict__ mats = a.mats;
     // Binv is needed twice (F = Ds Binv before the prox, corner forces after it).  It is parked in LDS (sBi) in
     // between: thread-private slots, [c][tid] layout (bank-conflict-free 8-B accesses), no VGPRs held
@@ -323,7 +320,7 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, int t
                 for (int j = 0; j < 3; ++j)   // EnergyTerm.hpp:133-135  zi = D_i x + u_i
                     q[r * 3 + j] = fma(Ds[j], in.Bi[r * 3 + 0], fma(Ds[3 + j], in.Bi[r * 3 + 1], fma(Ds[6 + j], in.Bi[r * 3 + 2], in.ui[r * 3 + j])));
 #pragma unroll
-            for (int c = 0; c < 9; ++c) sBi[c][threadIdx.x] = in.Bi[c];
+            for (int c = 0; c < 9; ++c) sBi[c * kChunkLdK] = in.Bi[c];
         }
         signed_svd3(q, U, S0, V);   // q = U diag(S0) V^T to round-off: q itself is not needed any more
     }
@@ -343,13 +340,13 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, int t
         constexpr bool kParkV = (KIND == 2) || (ADMM_PARK_V_NH != 0);
         if (kParkV) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) sV[c][threadIdx.x] = V[c];
+            for (int c = 0; c < 9; ++c) sV[c * kChunkLdK] = V[c];
         }
         const Mat mt = mats[in.mid];
         prox_stretches<KIND>(mt.mu, mt.la, mt.k, S1);
         if (kParkV) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) V[c] = sV[c][threadIdx.x];
+            for (int c = 0; c < 9; ++c) V[c] = sV[c * kChunkLdK];
         }
     }
     // z = U diag(S1) V^T ; u_new = u + D_i x - z = q - z = U diag(S0 - S1) V^T   (EnergyTerm.hpp:137)
@@ -379,7 +376,7 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, int t
     double f[12] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-        const double b0 = sBi[0 + m][threadIdx.x], b1 = sBi[3 + m][threadIdx.x], b2 = sBi[6 + m][threadIdx.x];
+        const double b0 = sBi[(0 + m) * kChunkLdK], b1 = sBi[(3 + m) * kChunkLdK], b2 = sBi[(6 + m) * kChunkLdK];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const double h = fma(G[j], b0, fma(G[3 + j], b1, G[6 + j] * b2));
@@ -387,53 +384,49 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, int t
             f[j] -= h;
         }
     }
-#if ADMM_CF_AOS
+    // The chunk's reduction: every thread parks its corner forces (its own column: nobody else has touched it), then thread j
+    // of pass p sums the <= 8 corner forces of record 256 p + j (16 bytes of LDS offsets, host-built) and stores the record as
+    // one 32-byte sector.  Lanes past the end of the model's tet range park values no list refers to.
+#pragma unroll
+    for (int c = 0; c < 12; ++c) sBi[c * kChunkLdK] = f[c];
+    __syncthreads();
     {
-        // rows 0..11 of the LDS block (sBi rows 0..8, then sV rows 0..2): this wave's 64 columns are its staging area.  Component c
-        // of lane l goes to column (l + 4 c) mod 64 of row c: the transposed reads below then hit distinct banks.
-        const int lane = (int)threadIdx.x & 63, wb = (int)threadIdx.x & ~63;
+        const int g0 = __builtin_amdgcn_readfirstlane(a.ch_group[chunk]), g1 = __builtin_amdgcn_readfirstlane(a.ch_group[chunk + 1]);
+        const int r0 = __builtin_amdgcn_readfirstlane(a.ch_rec[chunk]), nrec = __builtin_amdgcn_readfirstlane(a.ch_rec[chunk + 1]) - r0;
+        const __amdgpu_buffer_rsrc_t re = soa_rsrc(a.ch_ent), rr = soa_rsrc(a.rec);
+        const LdsDk *base = sL;
+        for (int g = g0; g < g1; ++g) {
+            union { bv4u v; unsigned short h[8]; } e;
+            e.v = __builtin_amdgcn_raw_buffer_load_b128(re, (g * 256 + (int)threadIdx.x) * 16, 0, ADMM_STREAM_LD_AUX);
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int c = 0; c < 12; ++c) {
-            double *rowp = c < 9 ? sBi[c] : sV[c - 9];
-            rowp[wb + ((lane + 4 * c) & 63)] = f[c];
-        }
-        // store round k: lane covers bytes [1024 k + 16 lane, + 16) of the wave's 64 x 128-byte records = record 8 k + lane / 8,
-        // doubles 2 (lane % 8), + 1; the fourth sector of a record (lane % 8 >= 6) is never written or read
-        const int pr = lane & 7, j8 = lane >> 3;
-        const int tw = t - lane;                 // first tet of this wave
-        if (pr < 6) {
-            const double *r0 = (2 * pr) < 9 ? sBi[2 * pr] : sV[2 * pr - 9];
-            const double *r1 = (2 * pr + 1) < 9 ? sBi[2 * pr + 1] : sV[2 * pr + 1 - 9];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int tau = 8 * k + j8;
-                const double v0 = r0[wb + ((tau + 8 * pr) & 63)], v1 = r1[wb + ((tau + 8 * pr + 4) & 63)];
-                if (tw + tau < t_end) {
-                    union { double d[2]; bv4u v; } pk; pk.d[0] = v0; pk.d[1] = v1;
-                    __builtin_amdgcn_raw_buffer_store_b128(pk.v, rcf, (tw + tau) * 128 + pr * 16, 0, ADMM_STREAM_ST_AUX);
-                }
+            for (int i = 0; i < kChunkFanK; ++i) {
+                const LdsDk *q = (const LdsDk *)((const __attribute__((address_space(3))) char *)base + e.h[i]);
+                s0 += q[0]; s1 += q[kChunkLdK]; s2 += q[2 * kChunkLdK];
+            }
+            const int j = (g - g0) * 256 + (int)threadIdx.x;
+            if (j < nrec) {
+                union { double d[2]; bv4u v; } p0; p0.d[0] = s0; p0.d[1] = s1;
+                union { double d; bv2u v; } p1; p1.d = s2;
+                __builtin_amdgcn_raw_buffer_store_b128(p0.v, rr, (r0 + j) * 32, 0, ADMM_STREAM_ST_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(p1.v, rr, (r0 + j) * 32 + 16, 0, ADMM_STREAM_ST_AUX);
             }
         }
     }
-#else
-    if (valid) {
-#pragma unroll
-        for (int c = 0; c < 12; ++c) buf_st_stream(rcf, t8, c * ld8, f[c]);
-    }
-#endif
 }
 
-// t_end = end of this constitutive model's tet range.  The whole wave takes part (the corner-force records are stored by the
-// wave together): lanes past the end redo the last tet of the range and store nothing.
+// t_end = end of this constitutive model's tet range.  The whole block takes part (the chunk's reduction synchronises it):
+// lanes past the end redo the last tet of the range and store nothing of their own.
 template <int KIND, bool WRITE_Z>
-__device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, int t_end, double (*sBi)[256], double (*sV)[256]) {
+__device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, int t_end, int chunk, LdsDk *sL) {
     TetIn in; TetPos x;
     const bool valid = t < t_end;
     const int tl = valid ? t : t_end - 1;
     const int4 id = tet_load_idx(a, tl);
     tet_load<KIND>(a, tl, in);
     tet_gather(a, id, x);
-    tet_compute_store<KIND, WRITE_Z>(a, t, t_end, valid, in, x, sBi, sV);
+    if (threadIdx.x < 3) sL[threadIdx.x * kChunkLdK + 256] = 0.0;     // the padding column of the reduction lists
+    tet_compute_store<KIND, WRITE_Z>(a, t, valid, chunk, in, x, sL);
 }
 
 // one constitutive model per launch (used when a scene has a single model, and by the parity entry point)
@@ -442,32 +435,29 @@ template <int KIND, bool WRITE_Z>
 #define ADMM_NH_WAVES 3
 #endif
 __global__ __launch_bounds__(256, (KIND == 1 ? ADMM_NH_WAVES : KIND == 4 ? 2 : 4)) void k_local_tets(int t0, int t1, TetArgs a) {
-    __shared__ double sL[(KIND == 2 || ADMM_PARK_V_NH != 0) ? 18 : 12][256];     // rows 0..8: Binv; 9..: V (parked) / staging
-    double (*sBi)[256] = sL, (*sV)[256] = sL + 9;
-    const int t = t0 + xcd_block() * 256 + threadIdx.x;
+    __shared__ double sLm[((KIND == 2 || ADMM_PARK_V_NH != 0) ? 18 : 12) * kChunkLdK];     // rows 0..8: Binv; 9..: V (parked); 0..11: corner forces
+    LdsDk *sL = (LdsDk *)sLm;
+    const int blk = xcd_block();
     ts_enter(a);
-    if (t - (int)(threadIdx.x & 63) < t1) local_tet_body<KIND, WRITE_Z>(a, t, t1, sBi, sV);
+    local_tet_body<KIND, WRITE_Z>(a, t0 + blk * 256 + (int)threadIdx.x, t1, a.chunk0 + blk, sL);
     ts_exit(a);
 }
 
 // all models in ONE launch: block ranges [0,nb0) linear, [nb0,nb1) NH, [nb1,nb2) StVK (wave-uniform branch).
-// Avoids the ramp-down / ramp-up between per-model launches of a mixed scene.
+// Avoids the ramp-down / ramp-up between per-model launches of a mixed scene.  (Chunks are numbered model by model in this
+// order, so the block index is the chunk index.)
 template <bool WRITE_Z>
 __global__ __launch_bounds__(256, ADMM_NH_WAVES) void k_local_tets_fused(int b0, int b1, int b2, int b3, int nb0, int nb1, TetArgs a) {
-    __shared__ double sL[18][256];
-    double (*sBi)[256] = sL, (*sV)[256] = sL + 9;
+    __shared__ double sLm[18 * kChunkLdK];
+    LdsDk *sL = (LdsDk *)sLm;
     const int blk = xcd_block();
-    const int l0 = (int)(threadIdx.x & 63);
     ts_enter(a);
     if (blk < nb0) {
-        const int t = b0 + blk * 256 + threadIdx.x;
-        if (t - l0 < b1) local_tet_body<0, WRITE_Z>(a, t, b1, sBi, sV);
+        local_tet_body<0, WRITE_Z>(a, b0 + blk * 256 + (int)threadIdx.x, b1, a.chunk0 + blk, sL);
     } else if (blk < nb1) {
-        const int t = b1 + (blk - nb0) * 256 + threadIdx.x;
-        if (t - l0 < b2) local_tet_body<1, WRITE_Z>(a, t, b2, sBi, sV);
+        local_tet_body<1, WRITE_Z>(a, b1 + (blk - nb0) * 256 + (int)threadIdx.x, b2, a.chunk0 + blk, sL);
     } else {
-        const int t = b2 + (blk - nb1) * 256 + threadIdx.x;
-        if (t - l0 < b3) local_tet_body<2, WRITE_Z>(a, t, b3, sBi, sV);
+        local_tet_body<2, WRITE_Z>(a, b2 + (blk - nb1) * 256 + (int)threadIdx.x, b3, a.chunk0 + blk, sL);
     }
     ts_exit(a);
 }
@@ -523,7 +513,7 @@ __global__ __launch_bounds__(256) void k_local_tris(int n, int ld, const int4 *_
 // forces, plus the SpringPin terms (src/SpringEnergyTerm.hpp:54-61), whose local step is done here.
 struct GatherArgs {
     int nv, n_slices;
-    const int *t_ptr, *t_w, *t_inc; const double *t_cf; int t_ld;  // tets (t_inc == nullptr -> none)
+    const int *t_ptr, *t_w, *t_inc; const double *t_rec;           // tets: lists of records [.][4] (t_inc == nullptr -> none)
     const int *r_ptr, *r_w, *r_inc; const double *r_cf; int r_ld;  // tris
     const int *vert_pin;       // [nv] pin term index or -1 (nullptr -> no pin terms)
     const double *pin_xyz; const int *pin_active; double *pin_u, *pin_z; double pin_sc; // dt^2 w_pin^2
@@ -536,6 +526,31 @@ struct GatherArgs {
 
 // sum of the corner forces incident to this lane's vertex (incidence widths are multiples of 8; padding
 // points at the all-zero dummy element ld-1).  Software-pipelined, 8 incidences (24 gathers) per round.
+// sum of the records (partial sums of a chunk of tets, one 32-byte sector each) of this lane's vertex; widths are multiples of
+// 4, padding points at the all-zero record.  Software-pipelined, 4 records per round.
+__device__ __forceinline__ void gather_records(const int *__restrict__ inc, int w, const double *__restrict__ rec, double *acc) {
+    constexpr int R = 4;
+    const __amdgpu_buffer_rsrc_t rr = soa_rsrc(rec);
+    int e[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) e[i] = inc[64 * i];
+    for (int k = R; k <= w; k += R) {
+        int en[R];
+        if (k < w) {
+#pragma unroll
+            for (int i = 0; i < R; ++i) en[i] = inc[64 * (k + i)];
+        }
+        union { double d[2]; bv4u v; } g0[R]; union { double d; bv2u v; } g1[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            g0[i].v = __builtin_amdgcn_raw_buffer_load_b128(rr, e[i] * 32, 0, 0);
+            g1[i].v = __builtin_amdgcn_raw_buffer_load_b64(rr, e[i] * 32 + 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) { acc[0] += g0[i].d[0]; acc[1] += g0[i].d[1]; acc[2] += g1[i].d; if (k < w) e[i] = en[i]; }
+    }
+}
+
 template <bool AOS>
 __device__ __forceinline__ void gather_corners(const int *__restrict__ inc, int w, const double *__restrict__ cf, int ld, double *acc) {
     constexpr int R = 8;
@@ -575,7 +590,7 @@ __global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
         const int r = s * 64 + lane;
         const int v = r < a.nv ? a.order[r] : a.nv;
         double acc[3] = {0.0, 0.0, 0.0};
-        if (a.t_inc) gather_corners<ADMM_CF_AOS != 0>(a.t_inc + a.t_ptr[s] + lane, a.t_w[s], a.t_cf, a.t_ld, acc);
+        if (a.t_inc) gather_records(a.t_inc + a.t_ptr[s] + lane, a.t_w[s], a.t_rec, acc);
         if (a.r_inc) gather_corners<false>(a.r_inc + a.r_ptr[s] + lane, a.r_w[s], a.r_cf, a.r_ld, acc);
         if (v < a.nv) {
             if (a.vert_pin) {

@@ -292,6 +292,15 @@ int admm_host_oc_plan(const admm_hip_desc *desc, int32_t n_blocks, int32_t slice
  * admm_host_locality_order: new_id[v] = new index of vertex v, the caller renumbers its mesh before building the solver. */
 void admm_host_block_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t leaf, int32_t *new_id);
 
+/* Test hook for the host-side plan of the local step's block-level reduction (csrc/host_setup.hpp: TetChunks; no counterpart
+ * in the reference, whose right-hand side is the sparse product D^T W^2 (z - u), src/Solver.cpp:98).  Runs the plan on the host
+ * exactly as the kernels do: every chunk of 256 consecutive tets (chunks do not straddle kind_begin[k], the starts of the five
+ * constitutive-model groups, kind_begin[5] = n_tets) sums its corner forces [n_tets][4][3] per vertex into records of at most 8
+ * corner forces, the per-vertex lists of records are summed into vertex_sums [n_verts][3].
+ * stats[0..4] = chunks, records, most 256-record passes of a chunk, widest record list, stored list entries. */
+int admm_host_chunk_reduce(int32_t n_verts, int32_t n_tets, const int32_t *tet_idx, const int32_t *kind_begin, const double *corner_forces,
+                           double *vertex_sums, int64_t *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -139,3 +139,41 @@ def test_locality_order_is_a_permutation_that_shrinks_the_span():
     assert nbr.max() <= 26 and nbr.mean() < 14, (nbr.max(), nbr.mean())
     v5, t5, nid5 = meshes.renumber_for_locality(v2, t2, force=True, method="blocks", leaf=64)
     assert np.array_equal(v5[t5], v2[t2]) and np.array_equal(nid5, nid_b)
+
+
+@pytest.mark.parametrize("case", ["cube", "blob", "shuffled", "tiny", "kinds"])
+def test_chunk_reduction_plan_sums_every_corner_force_once(case):
+    """The host-built plan of the local step's block-level reduction (chunks of 256 tets -> records of <= 8 corner forces ->
+    per-vertex lists of records), run on the host as the kernels run it, equals the plain scatter-add of the corner forces:
+    every (tet, corner) is counted exactly once, in chunks that straddle nothing, with padding that adds nothing."""
+    rng = np.random.default_rng(3)
+    if case == "cube":
+        verts, tets = meshes.kuhn_cube(9)
+    elif case == "blob":
+        verts, tets = meshes.unstructured_blob(14)
+    elif case == "shuffled":        # vertex-incoherent tets: a chunk sees ~1000 distinct vertices -> several 256-record passes
+        verts, tets = meshes.kuhn_cube(9)
+        tets = rng.integers(0, len(verts), tets.shape).astype(np.int32)
+    elif case == "tiny":
+        verts, tets = meshes.kuhn_cube(1)
+    else:
+        verts, tets = meshes.kuhn_cube(7)
+    nt, nv = len(tets), len(verts)
+    if case in ("cube", "blob"):    # the order the library puts the tets of one model in: by lowest vertex, then index sum
+        tets = tets[np.lexsort((tets.sum(1), tets.min(1)))]
+    if case == "kinds":             # five constitutive-model groups of uneven sizes, one of them empty
+        cuts = sorted(rng.choice(np.arange(1, nt), 3, replace=False).tolist())
+        kb = [0, cuts[0], cuts[1], cuts[1], cuts[2], nt]
+    else:
+        kb = [0, 0, nt, nt, nt, nt]
+    cf = rng.standard_normal((nt, 4, 3))
+    got, st = capi.chunk_reduce(nv, tets, kb, cf)
+    want = np.zeros((nv, 3))
+    np.add.at(want, tets.reshape(-1), cf.reshape(-1, 3))
+    assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    n_chunks = sum((kb[k + 1] - kb[k] + 255) // 256 for k in range(5))
+    assert st["chunks"] == n_chunks and st["records"] >= len(np.unique(tets))
+    if case in ("cube", "blob"):    # vertex-coherent tets: one or two passes per chunk, a handful of records per vertex
+        assert st["max_passes"] <= 2 and st["records"] < 0.3 * 4 * nt and st["max_list"] <= 16, st
+    if case == "shuffled":
+        assert st["max_passes"] > 1, st
