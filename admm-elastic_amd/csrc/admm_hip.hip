@@ -2039,6 +2039,18 @@ int admm_host_chunk_reduce(int32_t n_verts, int32_t n_tets, const int32_t *tet_i
     return ADMM_HIP_OK;
 }
 
+#ifdef ADMM_LOCAL_PHASES
+// experiments only (not declared in include/admm_hip.h): phase ticks of the local-step waves since the last call
+int admm_debug_local_phases(unsigned long long *out8) {
+    std::vector<unsigned long long> all((size_t)8 * admm_k::kPhaseWaves);
+    if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(admm_k::g_local_phase), all.size() * sizeof(unsigned long long)) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) out8[k] = 0;
+    for (size_t i = 0; i < all.size(); ++i) out8[i & 7] += all[i];
+    std::fill(all.begin(), all.end(), 0ull);
+    return hipMemcpyToSymbol(HIP_SYMBOL(admm_k::g_local_phase), all.data(), all.size() * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t *new_id,
                               double *span_before, double *span_after) {
     admm_host::locality_order(n_verts, n_elems, corners, idx, new_id, span_before, span_after);

@@ -388,6 +388,10 @@ __device__ __forceinline__ bool newton_step_is_final(const T *s, const T *d, boo
     return dmax <= (pure ? t_max(tol_final * smin * smin, tol_floor) : tol_floor) * mag;
 }
 
+// (everything by value: an array whose address is passed to a real call lives in scratch memory for its whole life)
+template <typename T> struct NewtonIO { T s[3], g[3], D[3], w[3], f; int it; };
+template <int KIND, typename T>
+__device__ __attribute__((noinline)) NewtonIO<T> newton_stretch_general(StretchModel<KIND, T> m, NewtonIO<T> io, int max_it, T tol_final, T noise, int max_ls);
 // Safeguarded Newton for argmin_s Psi(s) + k/2 |s - x0|^2, started from s (in/out); returns iterations.
 //  - Hessian = diag(D) + la w w^T  -> Sherman-Morrison solve, |D| floored to stay positive definite
 //  - NH: the log barrier keeps iterates strictly positive.  StVK: the feasible set is s >= 0 and for
@@ -415,6 +419,22 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
             return 1;
         }
     }
+    NewtonIO<T> io;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { io.s[i] = s[i]; io.g[i] = g[i]; io.D[i] = D[i]; io.w[i] = w[i]; }
+    io.f = f; io.it = 0;
+    io = newton_stretch_general<KIND, T>(m, io, max_it, tol_final, noise, max_ls);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[i] = io.s[i];
+    return io.it;
+}
+// the general loop, OUTLINED (noinline): it is the rare path (waves whose first step is not final in every lane) but it is the
+// part with the most values alive -- inlined, it dictated the register allocation of the whole local-step kernel
+template <int KIND, typename T>
+__device__ __attribute__((noinline)) NewtonIO<T> newton_stretch_general(StretchModel<KIND, T> m, NewtonIO<T> io, int max_it, T tol_final, T noise, int max_ls) {
+    T s[3], g[3], D[3], w[3], f = io.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s[i] = io.s[i]; g[i] = io.g[i]; D[i] = io.D[i]; w[i] = io.w[i]; }
     const T fscale = T(4) * (t_abs(m.mu) + t_abs(m.la) + t_abs(m.k));
     int it = 0;
 #pragma unroll 1
@@ -457,7 +477,10 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
 #pragma unroll
         for (int i = 0; i < 3; ++i) { s[i] = sn[i]; g[i] = gn[i]; D[i] = Dn[i]; w[i] = wn[i]; }
     }
-    return it;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) io.s[i] = s[i];
+    io.it = it;
+    return io;
 }
 
 // mixed-precision driver: FP32 iterations, then FP64 polish.  Parameters are normalised by k so the

@@ -294,11 +294,31 @@ __device__ __forceinline__ void tet_gather(const TetArgs &a, const int4 id, TetP
 // accesses) plus the all-zero padding column 256.  Rows 0..8 park Binv across the prox, rows 9..17 V (StVK); after the prox
 // rows 0..11 hold the thread's four corner forces for the chunk's reduction.
 typedef __attribute__((address_space(3))) double LdsDk;
+// -DADMM_LOCAL_PHASES (experiments only): every wave adds the wall-clock ticks (100 MHz) it spent between the marks of
+// tet_compute_store to g_local_phase[]; [7] counts the waves.  experiments/local_phases.py reads them.
+#ifdef ADMM_LOCAL_PHASES
+constexpr int kPhaseWaves = 1 << 16;
+__device__ unsigned long long g_local_phase[8 * kPhaseWaves];      // [wave of the launch][mark]: private slots, no atomics
+#define ADMM_PHASE_SLOT() (g_local_phase + 8 * (((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) & (kPhaseWaves - 1)))
+#define ADMM_PHASE_MARK(k) { const unsigned long long now_ = wall_clock64(); if ((threadIdx.x & 63) == 0) ADMM_PHASE_SLOT()[k] += now_ - ph_t_; ph_t_ = now_; }
+#define ADMM_PHASE_BEGIN() unsigned long long ph_t_ = wall_clock64(); if ((threadIdx.x & 63) == 0) ADMM_PHASE_SLOT()[7] += 1ull;
+#else
+#define ADMM_PHASE_MARK(k)
+#define ADMM_PHASE_BEGIN()
+#endif
 template <int KIND, bool WRITE_Z>
-__device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool valid, int chunk, const TetIn &in, const TetPos &x, LdsDk *sL) {
+__device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool valid, int chunk, const TetIn &in, const TetPos &x, LdsDk *sL
+#ifdef ADMM_LOCAL_PHASES
+                                                  , unsigned long long ph_t_
+#endif
+                                                  ) {
     const int ld8 = a.ld * 8, t8 = t * 8;
     const __amdgpu_buffer_rsrc_t ru = soa_rsrc(a.u);
     LdsDk *sBi = sL + threadIdx.x, *sV = sL + 9 * kChunkLdK + threadIdx.x;     // row c of this thread: [c * kChunkLdK]
+#ifdef ADMM_LOCAL_PHASES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the marks below then separate the wait for the loads from the math)
+#endif
+    ADMM_PHASE_MARK(0);
     const Mat *__restrict__ mats = a.mats;
     // Binv is needed twice (F = Ds Binv before the prox, corner forces after it).  It is parked in LDS (sBi) in
     // between: thread-private slots, [c][tid] layout (bank-conflict-free 8-B accesses), no VGPRs held
@@ -324,6 +344,13 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
         }
         signed_svd3(q, U, S0, V);   // q = U diag(S0) V^T to round-off: q itself is not needed any more
     }
+    ADMM_PHASE_MARK(1);
+    // the reduction list of this thread's record (first pass): in flight across the prox instead of after the block barrier
+    const int g0 = __builtin_amdgcn_readfirstlane(a.ch_group[chunk]), g1 = __builtin_amdgcn_readfirstlane(a.ch_group[chunk + 1]);
+    const int r0 = __builtin_amdgcn_readfirstlane(a.ch_rec[chunk]), nrec = __builtin_amdgcn_readfirstlane(a.ch_rec[chunk + 1]) - r0;
+    const __amdgpu_buffer_rsrc_t re = soa_rsrc(a.ch_ent);
+    union { bv4u v; unsigned short h[8]; } e;
+    e.v = __builtin_amdgcn_raw_buffer_load_b128(re, (g0 * 256 + (int)threadIdx.x) * 16, 0, ADMM_STREAM_LD_AUX);
 #pragma unroll
     for (int i = 0; i < 3; ++i) S1[i] = S0[i];
     if (KIND == 0) {
@@ -332,12 +359,14 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
         const Mat mt = mats[in.mid];
         prox_stretches_kappa(mt.type, mt.mu, mt.la, mt.k, mt.kappa, S1);
     } else {
-        // StVK fits 4 waves/SIMD (128 VGPRs) only with V out of the way; NH needs 3 waves/SIMD either way
-        // (measured: forcing 128 VGPRs spills and is slower), so it keeps V in registers.
+        // NH, StVK and the co-rotated spline fit 4 waves/SIMD (128 VGPRs) with V out of the way during the stretch
+        // minimisation AND the general Newton loop outlined (device_math.hpp: newton_stretch_general) -- inlined, that rare
+        // path dictated 166 VGPRs = 3 waves/SIMD; forcing 128 then spilled on the common path and was slower (measured in both
+        // rounds).  Same box, 1 M tets: 3 waves 68.4 us, 4 waves with spills 71.8 us, 4 waves + V parked + outlined loop 65.4 us.
 #ifndef ADMM_PARK_V_NH
-#define ADMM_PARK_V_NH 0
+#define ADMM_PARK_V_NH 1
 #endif
-        constexpr bool kParkV = (KIND == 2) || (ADMM_PARK_V_NH != 0);
+        constexpr bool kParkV = (KIND == 2) || (KIND == 3) || (KIND == 1 && ADMM_PARK_V_NH != 0);
         if (kParkV) {
 #pragma unroll
             for (int c = 0; c < 9; ++c) sV[c * kChunkLdK] = V[c];
@@ -349,6 +378,7 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
             for (int c = 0; c < 9; ++c) V[c] = sV[c * kChunkLdK];
         }
     }
+    ADMM_PHASE_MARK(2);
     // z = U diag(S1) V^T ; u_new = u + D_i x - z = q - z = U diag(S0 - S1) V^T   (EnergyTerm.hpp:137)
     // G = dt^2 w^2 (z - u_new) = s U diag(2 S1 - S0) V^T
     const double s = in.s;
@@ -389,15 +419,14 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
     // one 32-byte sector.  Lanes past the end of the model's tet range park values no list refers to.
 #pragma unroll
     for (int c = 0; c < 12; ++c) sBi[c * kChunkLdK] = f[c];
+    ADMM_PHASE_MARK(3);
     __syncthreads();
+    ADMM_PHASE_MARK(4);
     {
-        const int g0 = __builtin_amdgcn_readfirstlane(a.ch_group[chunk]), g1 = __builtin_amdgcn_readfirstlane(a.ch_group[chunk + 1]);
-        const int r0 = __builtin_amdgcn_readfirstlane(a.ch_rec[chunk]), nrec = __builtin_amdgcn_readfirstlane(a.ch_rec[chunk + 1]) - r0;
-        const __amdgpu_buffer_rsrc_t re = soa_rsrc(a.ch_ent), rr = soa_rsrc(a.rec);
+        const __amdgpu_buffer_rsrc_t rr = soa_rsrc(a.rec);
         const LdsDk *base = sL;
         for (int g = g0; g < g1; ++g) {
-            union { bv4u v; unsigned short h[8]; } e;
-            e.v = __builtin_amdgcn_raw_buffer_load_b128(re, (g * 256 + (int)threadIdx.x) * 16, 0, ADMM_STREAM_LD_AUX);
+            if (g > g0) e.v = __builtin_amdgcn_raw_buffer_load_b128(re, (g * 256 + (int)threadIdx.x) * 16, 0, ADMM_STREAM_LD_AUX);
             double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int i = 0; i < kChunkFanK; ++i) {
@@ -413,6 +442,11 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
             }
         }
     }
+    ADMM_PHASE_MARK(5);
+#ifdef ADMM_LOCAL_PHASES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ADMM_PHASE_MARK(6);
+#endif
 }
 
 // t_end = end of this constitutive model's tet range.  The whole block takes part (the chunk's reduction synchronises it):
@@ -420,22 +454,27 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
 template <int KIND, bool WRITE_Z>
 __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, int t_end, int chunk, LdsDk *sL) {
     TetIn in; TetPos x;
+    ADMM_PHASE_BEGIN();
     const bool valid = t < t_end;
     const int tl = valid ? t : t_end - 1;
     const int4 id = tet_load_idx(a, tl);
     tet_load<KIND>(a, tl, in);
     tet_gather(a, id, x);
     if (threadIdx.x < 3) sL[threadIdx.x * kChunkLdK + 256] = 0.0;     // the padding column of the reduction lists
+#ifdef ADMM_LOCAL_PHASES
+    tet_compute_store<KIND, WRITE_Z>(a, t, valid, chunk, in, x, sL, ph_t_);
+#else
     tet_compute_store<KIND, WRITE_Z>(a, t, valid, chunk, in, x, sL);
+#endif
 }
 
 // one constitutive model per launch (used when a scene has a single model, and by the parity entry point)
 template <int KIND, bool WRITE_Z>
 #ifndef ADMM_NH_WAVES
-#define ADMM_NH_WAVES 3
+#define ADMM_NH_WAVES 4
 #endif
 __global__ __launch_bounds__(256, (KIND == 1 ? ADMM_NH_WAVES : KIND == 4 ? 2 : 4)) void k_local_tets(int t0, int t1, TetArgs a) {
-    __shared__ double sLm[((KIND == 2 || ADMM_PARK_V_NH != 0) ? 18 : 12) * kChunkLdK];     // rows 0..8: Binv; 9..: V (parked); 0..11: corner forces
+    __shared__ double sLm[((KIND == 2 || KIND == 3 || (KIND == 1 && ADMM_PARK_V_NH != 0)) ? 18 : 12) * kChunkLdK];     // rows 0..8: Binv; 9..: V (parked); 0..11: corner forces
     LdsDk *sL = (LdsDk *)sLm;
     const int blk = xcd_block();
     ts_enter(a);
