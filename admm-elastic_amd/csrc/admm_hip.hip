@@ -183,6 +183,7 @@ struct admm_hip_ctx {
     DevBuf<unsigned long long> oc_prof;   // diagnosis (ADMM_HIP_OC_PROF=1)
     bool oc_debug = false; int oc_prof_block = 0;
     // general-mesh plan of the on-chip PCG (oc_plan.cpp): internal row order, its SELL, slab shares, two-level data
+    double oc_sm_ab = 0.0, oc_sm_b = 0.0, oc_lam_bb = 0.0;   // block-local smoother of k_pcg2 (pcg_onchip2.hpp: smooth)
     bool oc_plan = false, oc_coarse = false; int oc_rows = 0, oc_bcols = 0, oc_nc = 0, oc_ncp = 0, oc_veclen = 0;
     SellDev oc_A; DevBuf<int> oc_orig, oc_ldsoff, oc_wls, oc_haloptr, oc_halosrc; DevBuf<unsigned short> oc_col16;
     DevBuf<double> oc_mdiag, oc_ainv, oc_cbuf;
@@ -422,6 +423,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.rc_part = c->oc_rc_part.p;
     if (c->oc_coarse) { a.ainv = c->oc_ainv.p; a.cbuf = c->oc_cbuf.p; a.nc = c->oc_nc; a.ncp = c->oc_ncp; }
     a.skip = rc.skip;
+    a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b;
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg2<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     c->last_launched_iters = 0;
@@ -532,6 +534,18 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
                     if ((e = c->oc_ainv.upload(plan.ainv)) != hipSuccess) return e;
                     if ((e = c->oc_cbuf.alloc((size_t)2 * 3 * plan.ncp)) != hipSuccess) return e;
                     if ((e = c->oc_cbuf.zero()) != hipSuccess) return e;
+                }
+                {   // block-local smoother: degree-2 Chebyshev polynomial of D^-1 A_bb on [hi / ratio, hi], hi = the plan's estimate
+                    // of lambda_max + 10 % (the polynomial stays positive up to 1.125 hi); ADMM_HIP_OC_CHEB=0: plain Jacobi
+                    const char *ch = getenv("ADMM_HIP_OC_CHEB"), *cr = getenv("ADMM_HIP_OC_CHEB_RATIO");
+                    c->oc_sm_ab = 0.0; c->oc_sm_b = 0.0; c->oc_lam_bb = plan.lam_bb;
+                    if (!(ch && ch[0] == '0') && plan.lam_bb > 0.0) {
+                        const double ratio = cr ? std::max(1.5, atof(cr)) : 16.0;
+                        const double hi = 1.1 * plan.lam_bb, lo = hi / ratio, th = 0.5 * (hi + lo), de = 0.5 * (hi - lo);
+                        const double sg = th / de, r0 = 1.0 / sg, r1 = 1.0 / (2.0 * sg - r0);
+                        const double al = (1.0 + r1 * r0) / th + 2.0 * r1 / de, be = 2.0 * r1 / (de * th);
+                        c->oc_sm_ab = al - be; c->oc_sm_b = be;
+                    }
                 }
                 c->oc_stat[0] = plan.stat_nnz; c->oc_stat[1] = plan.stat_stored; c->oc_stat[2] = plan.stat_onchip; c->oc_stat[3] = plan.stat_local;
                 c->oc_stat[4] = plan.nbr_max; c->oc_stat[5] = c->oc_coarse ? plan.nc : 0;

@@ -118,6 +118,7 @@ struct OcPlan {
     int nc = 0, ncp = 0;                // coarse unknowns (G * kOcSub), padded row length of ainv
     bool coarse_ok = false;
     std::vector<double> ainv;           // [nc][ncp] (P^T A P)^-1
+    double lam_bb = 0.0;                // estimate of lambda_max(D^-1 A_bb), A_bb = the block-diagonal part of M + Ahat (power iteration)
     int64_t stat_nnz = 0, stat_stored = 0, stat_onchip = 0, stat_local = 0;
 };
 // A = Ahat (mass not included), mass3 [3 n]; lds_bytes = LDS one block may spend on its local vector and matrix slab

@@ -384,6 +384,42 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
         }
     }
     P.ok = true;
+    // ---- largest eigenvalue of D^-1 A_bb (A_bb = entries of M + Ahat inside one block, D = its diagonal; the smallest of the
+    // three axes' masses makes the bound safe for all of them): the block-local Chebyshev smoother of k_pcg2 needs an upper
+    // bound.  Power iteration on the symmetrised operator, deterministic start, 40 steps (the estimate approaches from below;
+    // the caller adds its margin).
+    {
+        std::vector<double> dis(nv);
+        for (int32_t v = 0; v < nv; ++v) {
+            double aii = 0.0;
+            for (int32_t k = A.rowptr[v]; k < A.rowptr[v + 1]; ++k) if (A.col[k] == v) aii += A.val[k];
+            const double mm = std::min(mass3[3 * (size_t)v], std::min(mass3[3 * (size_t)v + 1], mass3[3 * (size_t)v + 2]));
+            dis[v] = 1.0 / std::sqrt(mm + aii);
+        }
+        std::vector<double> x(nv), y(nv);
+        for (int32_t v = 0; v < nv; ++v) x[v] = 1.0 + 0.5 * std::sin(0.7 * v + 0.3);
+        double lam = 0.0;
+        for (int it = 0; it < 40; ++it) {
+            double nrm = 0.0;
+            for (int32_t v = 0; v < nv; ++v) nrm += x[v] * x[v];
+            nrm = 1.0 / std::sqrt(nrm);
+            for (int32_t v = 0; v < nv; ++v) x[v] *= nrm;
+            double rq = 0.0;
+            for (int32_t v = 0; v < nv; ++v) {
+                double acc = 0.0;
+                const int32_t bv = part_of[v];
+                for (int32_t k = A.rowptr[v]; k < A.rowptr[v + 1]; ++k) {
+                    const int32_t c = A.col[k];
+                    if (c != v && part_of[c] == bv) acc += A.val[k] * dis[c] * x[c];
+                }
+                y[v] = x[v] + dis[v] * acc;        // (unit diagonal of the scaled operator)
+                rq += x[v] * y[v];
+            }
+            lam = rq;
+            x.swap(y);
+        }
+        P.lam_bb = lam;
+    }
     return P;
 }
 

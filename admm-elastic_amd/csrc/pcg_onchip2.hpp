@@ -34,6 +34,7 @@ struct Oc2Args {
     const double *val;               // entry (s, k, lane) at ptr[s] + 64 k + lane
     const unsigned short *col16;     // its local column at ptr[s] + ((k / 4) 64 + lane) 4 + k % 4
     const int *lds_off, *wl_s;       // per slice: slab offset (columns) and columns held in LDS
+    double sm_ab, sm_b;              // block-local smoother S v = D^-1 (sm_ab v - sm_b offdiag(A_bb) D^-1 v); sm_b = 0: S = D^-1
     int bcols;                       // slab columns per block
     const int *orig;                 // [n_rows] vertex | aggregate << 28 (-1 = dummy row)
     const int *halo_ptr, *halo_src;  // [G + 1]; internal rows of the halo entries (sorted per block)
@@ -57,6 +58,13 @@ struct Oc2Args {
 
 constexpr int kOc2Scratch = 4096;   // bytes of LDS scratch ahead of the local vector and the matrix slab
 typedef __attribute__((address_space(3))) unsigned long long LdsU64;
+
+// first half of oc_barrier: drain this block's stores and arrive; oc_barrier_wait (pcg_onchip.hpp) is the second half
+__device__ __forceinline__ void oc2_barrier_arrive(unsigned *bar) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(bar + 16 * ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
@@ -112,6 +120,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
     __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void *)a.cbuf, 0, a.cbuf ? 2 * 3 * a.ncp * 8 : 0, 0x00020000);
 
     double rx[3], ru[3], rw[3], rp[3], rsv[3], rz[3], rq[3], rr[3], rd[3], rm[3];
+    double sw[3] = {0.0, 0.0, 0.0}, sz[3] = {0.0, 0.0, 0.0};     // S w and S z (S = block-local part of M^-1), by recurrence
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         rx[j] = live ? a.x[3 * (size_t)vi + j] : 0.0; rd[j] = live ? a.dinv[3 * (size_t)vi + j] : 0.0;
@@ -140,18 +149,8 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
         oc_store_sc1(rs_u, bo, a0, a1);
         oc_store_sc1(rs_u, bo + 1024, b0, b1);
     };
-    // after the synchronisation of phase ph: halo entries -> local vector, then out = A v from LDS
-    auto halo_and_rows = [&](const double *self, double *out) {
-        const int vb = (int)(ph & 1u) * ub;
-        for (int h = tid, it = 0; h < nh; h += T, ++it) {
-            const int src = it == 0 ? hs0 : it == 1 ? hs1 : a.halo_src[hp0 + h];
-            union { double d[2]; v4u v; } g0, g1;
-            g0.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, vb + src * 32, 0, 16);
-            g1.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, vb + src * 32 + 16, 0, 16);
-            vec[T + h] = g0.d[0]; vec[NV + T + h] = g0.d[1]; vec[2 * NV + T + h] = g1.d[0];
-        }
-        __syncthreads();
-        double acc[3] = {0.0, 0.0, 0.0};
+    // this thread's row (off-diagonal part) times the local vector
+    auto row_times_local_vector = [&](double *acc) {
         for (int k = 0; k < w; k += 4) {
             unsigned long long cc; double vv[4];
             if (k < wl_s) {
@@ -169,8 +168,45 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                 acc[0] = fma(vv[i], vec[c], acc[0]); acc[1] = fma(vv[i], vec[NV + c], acc[1]); acc[2] = fma(vv[i], vec[2 * NV + c], acc[2]);
             }
         }
+    };
+    // after the synchronisation of phase ph: halo entries -> local vector, then out = A v from LDS
+    auto halo_and_rows = [&](const double *self, double *out) {
+        const int vb = (int)(ph & 1u) * ub;
+        for (int h = tid, it = 0; h < nh; h += T, ++it) {
+            const int src = it == 0 ? hs0 : it == 1 ? hs1 : a.halo_src[hp0 + h];
+            union { double d[2]; v4u v; } g0, g1;
+            g0.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, vb + src * 32, 0, 16);
+            g1.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, vb + src * 32 + 16, 0, 16);
+            vec[T + h] = g0.d[0]; vec[NV + T + h] = g0.d[1]; vec[2 * NV + T + h] = g1.d[0];
+        }
+        __syncthreads();
+        double acc[3] = {0.0, 0.0, 0.0};
+        row_times_local_vector(acc);
 #pragma unroll
         for (int j = 0; j < 3; ++j) out[j] = fma(rm[j], self[j], acc[j]);
+    };
+    // The block-local part of the preconditioner: a degree-2 Chebyshev polynomial in D^-1 A_bb, A_bb = the entries of A whose
+    // row AND column sit in this block -- data the block holds in LDS, no exchange (experiments/block_cheb_proto.py: 114 ->
+    // 81 iterations next to the coarse space on the 1 M-tet body; the exact block solve would give 63).  In closed form
+    // S v = D^-1 (sm_ab v - sm_b offdiag(A_bb) D^-1 v): D^-1 v goes into the local vector with the halo part zeroed, the
+    // ordinary row loop does the rest.  S is symmetric positive definite as long as lambda_max(D^-1 A_bb) stays below the
+    // bound the host derived the coefficients from (oc_plan.cpp: power iteration + margin).
+    const bool smoothing = a.sm_b != 0.0;
+    auto smooth = [&](const double *v, double *out) {
+        if (!smoothing) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) out[j] = rd[j] * v[j];
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vec[j * NV + tid] = rd[j] * v[j];
+        for (int h = tid; h < nh; h += T) { vec[T + h] = 0.0; vec[NV + T + h] = 0.0; vec[2 * NV + T + h] = 0.0; }
+        __syncthreads();
+        double acc[3] = {0.0, 0.0, 0.0};
+        row_times_local_vector(acc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[j] = rd[j] * fma(-a.sm_b, acc[j], a.sm_ab * v[j]);
+        __syncthreads();   // the local vector is rewritten by the next publish
     };
     // block totals of 8 NG quantities -> res24 (valid after the call for all threads); fixed order -> deterministic
     auto block_sums = [&](const double *q24, auto ng_tag) {
@@ -423,6 +459,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
             if (prof) a.prof[62 * 8 + 3] = wall_clock64();
 #pragma unroll
             for (int j = 0; j < 3; ++j) rr[j] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
+            smooth(rr, ru);
             if (two_level) {
                 double y[3];
                 if (!coarse_apply(rr, y)) { aborted = true; break; }
@@ -520,6 +557,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                     double y[3];
 #pragma unroll
                     for (int j = 0; j < 3; ++j) rr[j] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
+                    smooth(rr, ru);
                     if (two_level) {
                         if (!coarse_apply(rr, y)) return false;
 #pragma unroll
@@ -536,6 +574,9 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                     if (tid < 3 * kOcSubK) { yw[tid] = ycur[tid]; yz[tid] = 0.0; }
                     __syncthreads();
                 }
+                smooth(rw, sw);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) sz[j] = 0.0;
                 return true;
             };
             int passes = 0;
@@ -552,11 +593,11 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                 bool next_pass = false;
                 while (iters < a.max_iters) {
                     OC2_STAMP(0);
-                    double mm[3], rn[3], q[7];
+                    double mm[3], rn[3], sn[3], q[7];
                     q[6] = 0.0;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
-                        mm[j] = live ? fma(rd[j], rw[j], two_level ? yw[3 * myagg + j] : 0.0) : 0.0;   // m = M^-1 w
+                        mm[j] = live ? sw[j] + (two_level ? yw[3 * myagg + j] : 0.0) : 0.0;      // m = M^-1 w = S w + P Ac^-1 P^T w
                         q[j] = rr[j] * ru[j];                                                    // gamma = r . u
                         q[3 + j] = rw[j] * ru[j];                                                // delta = w . u
                         q[6] = fma(rr[j] * rd[j] * rr[j], ctl[8 + j], q[6]);                     // Jacobi-norm residual (stop test)
@@ -576,7 +617,11 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                     const int par = (int)(be & 1u);
                     publish_record(q, two_level ? rn : nullptr, par);
                     OC2_STAMP(4);
-                    if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+                    // S n (the block-local part of M^-1 n, data of this block only) behind the latency of the grid barrier:
+                    // S w is then carried by the recurrences below like w itself, no smoothing on the critical path
+                    oc2_barrier_arrive(bar);
+                    smooth(rn, sn);
+                    if (!oc_barrier_wait(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
                     OC2_STAMP(5);
                     if (two_level) reduce_and_coarse(par, 7, ar);                                // the sums, and ycur = Ac^-1 P^T n
                     else reduce_records(par, 7);
@@ -621,6 +666,8 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                     for (int j = 0; j < 3; ++j) {
                         const double alpha = ctl[2 + j], beta = ctl[5 + j];
                         rz[j] = fma(beta, rz[j], rn[j]);
+                        sz[j] = fma(beta, sz[j], sn[j]);
+                        sw[j] = fma(-alpha, sz[j], sw[j]);
                         rq[j] = fma(beta, rq[j], mm[j]);
                         rsv[j] = fma(beta, rsv[j], rw[j]);
                         rp[j] = fma(beta, rp[j], ru[j]);
