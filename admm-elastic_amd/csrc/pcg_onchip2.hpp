@@ -232,19 +232,22 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
     };
     auto block_sums24 = [&](const double *q24) { block_sums(q24, std::integral_constant<int, 3>()); };
     // this block's record: q7[0..6] -> part (parity par) and, two-level, P^T v -> cbuf (parity par)
-    auto publish_record = [&](const double *q7, const double *v, int par) {
+    // (with_v is a flag, not "v or nullptr": an array whose address is selected against nullptr stays in scratch memory -- the
+    // n of every iteration did, and came back through twelve conditional scratch loads)
+    const double zero3[3] = {0.0, 0.0, 0.0};
+    auto publish_record = [&](const double *q7, const double *v, bool with_v, int par) {
         double q24[24];
 #pragma unroll
         for (int i = 0; i < 8; ++i) q24[i] = i < 7 ? q7[i] : 0.0;
 #pragma unroll
         for (int ag = 0; ag < kOcSubK; ++ag)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) q24[8 + 3 * ag + j] = (v != nullptr && live && myagg == ag) ? v[j] : 0.0;
+            for (int j = 0; j < 3; ++j) q24[8 + 3 * ag + j] = (with_v && live && myagg == ag) ? v[j] : 0.0;
 #pragma unroll
         for (int i = 8 + 3 * kOcSubK; i < 24; ++i) q24[i] = 0.0;
         block_sums24(q24);
         if (tid < 7) oc_store_sc1(rs_p, ((par * 8 + tid) * a.G + (int)blockIdx.x) * 8, res24[tid]);
-        else if (v != nullptr && tid >= 8 && tid < 8 + 3 * kOcSubK) {
+        else if (with_v && tid >= 8 && tid < 8 + 3 * kOcSubK) {
             const int ag = (tid - 8) / 3, j = (tid - 8) - 3 * ag;
             oc_store_sc1(rs_c, ((par * 3 + j) * a.ncp + (int)blockIdx.x * kOcSubK + ag) * 8, res24[tid]);
         }
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
         ++be;
         const int par = (int)(be & 1u);
         const double z7[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        publish_record(z7, v, par);
+        publish_record(z7, v, true, par);
         AinvRows ar;
         ainv_prefetch(ar);
         if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return false;
@@ -474,7 +477,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
             halo_and_rows(ru, rw);                   // w = A u
             if (prof) a.prof[62 * 8 + 5] = wall_clock64();
             ++be;
-            publish_record(q, two_level ? rw : nullptr, (int)(be & 1u));
+            publish_record(q, rw, two_level, (int)(be & 1u));
             if (prof) a.prof[62 * 8 + 6] = wall_clock64();
         }
         {
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
             double q[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (!true_residual(false, q, nullptr)) return -1;
             ++be;
-            publish_record(q, nullptr, (int)(be & 1u));
+            publish_record(q, zero3, false, (int)(be & 1u));
             if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return -1;
             reduce_records((int)(be & 1u), 3);
             if (tid == 0) {
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                     OC2_STAMP(3);
                     ++be;
                     const int par = (int)(be & 1u);
-                    publish_record(q, two_level ? rn : nullptr, par);
+                    publish_record(q, rn, two_level, par);
                     OC2_STAMP(4);
                     // S n (the block-local part of M^-1 n, data of this block only) behind the latency of the grid barrier:
                     // S w is then carried by the recurrences below like w itself, no smoothing on the critical path
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) q[j] = (live ? ru[j] * ru[j] * fast_rcp(rd[j]) : 0.0);
             ++be;
-            publish_record(q, nullptr, (int)(be & 1u));
+            publish_record(q, zero3, false, (int)(be & 1u));
             if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
             reduce_records((int)(be & 1u), 3);
             if (wv == 0) {   // lanes 0..2 = one axis each
@@ -757,7 +760,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) { q[j] = 0.0; q[3 + j] = rp[j] * rsv[j]; }
             ++be;
-            publish_record(q, nullptr, (int)(be & 1u));
+            publish_record(q, zero3, false, (int)(be & 1u));
             if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
             reduce_records((int)(be & 1u), 6);
 #pragma unroll
