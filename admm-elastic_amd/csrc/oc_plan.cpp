@@ -363,7 +363,8 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
     bool uniform_mass = true;
     for (int32_t v = 0; v < nv && uniform_mass; ++v)
         uniform_mass = mass3[3 * (size_t)v] == mass3[3 * (size_t)v + 1] && mass3[3 * (size_t)v] == mass3[3 * (size_t)v + 2];
-    if (want_coarse && uniform_mass && P.nc <= 2048) {
+    if (!uniform_mass) { P.ok = false; return P; }   // k_pcg2 keeps ONE diagonal value per row (the launch path serves such a system)
+    if (want_coarse && P.nc <= 2048) {
         const int nc = P.nc;
         std::vector<int32_t> agg(nv);
         for (int32_t v = 0; v < nv; ++v) agg[v] = part_of[v] * kOcSub + agg_part[v];

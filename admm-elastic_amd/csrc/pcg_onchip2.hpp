@@ -119,12 +119,16 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
     const bool two_level = a.ainv != nullptr && a.nc <= 2 * T;
     __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void *)a.cbuf, 0, a.cbuf ? 2 * 3 * a.ncp * 8 : 0, 0x00020000);
 
-    double rx[3], ru[3], rw[3], rp[3], rsv[3], rz[3], rq[3], rr[3], rd[3], rm[3];
+    double rx[3], ru[3], rw[3], rp[3], rsv[3], rz[3], rq[3], rr[3];
     double sw[3] = {0.0, 0.0, 0.0}, sz[3] = {0.0, 0.0, 0.0};     // S w and S z (S = block-local part of M^-1), by recurrence
+    // The plan only exists for masses that are the same on the three axes of a vertex (oc_plan.cpp; the reference has no others:
+    // m_masses[3 i + j] = mass of vertex i): the diagonal and its inverse are ONE value per row, not three -- the kernel sits
+    // on the edge of its register budget, these are 8 VGPRs.
+    const double rd0 = live ? a.dinv[3 * (size_t)vi] : 0.0, rm0 = live ? a.mdiag[3 * (size_t)row] : 0.0;
+    const double rd[3] = {rd0, rd0, rd0}, rm[3] = {rm0, rm0, rm0};
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        rx[j] = live ? a.x[3 * (size_t)vi + j] : 0.0; rd[j] = live ? a.dinv[3 * (size_t)vi + j] : 0.0;
-        rm[j] = live ? a.mdiag[3 * (size_t)row + j] : 0.0;
+        rx[j] = live ? a.x[3 * (size_t)vi + j] : 0.0;
         ru[j] = rw[j] = rp[j] = rsv[j] = rz[j] = rq[j] = rr[j] = 0.0;
     }
     unsigned *const bar = a.bar + 32 * 16 * (a.seq & 1);
@@ -267,13 +271,13 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
     };
     // The rows of Ac^-1 of this block's aggregates, columns tid and tid + T: constant over the solve, fetched (L2) ahead
     // of the grid barrier so that their latency hides behind it
-    struct AinvRows { double v[2][kOcSubK]; };
+    struct AinvRows { float v[2][kOcSubK]; };   // (a preconditioner: single precision, applied the same way every time, is exact enough)
     auto ainv_prefetch = [&](AinvRows &ar) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int c = tid + it * T;
 #pragma unroll
-            for (int ag = 0; ag < kOcSubK; ++ag) ar.v[it][ag] = c < a.nc ? a.ainv[(size_t)((int)blockIdx.x * kOcSubK + ag) * a.ncp + c] : 0.0;
+            for (int ag = 0; ag < kOcSubK; ++ag) ar.v[it][ag] = c < a.nc ? (float)a.ainv[(size_t)((int)blockIdx.x * kOcSubK + ag) * a.ncp + c] : 0.0f;
         }
     };
     // after the grid barrier: bc[0..nsum) = global sums of the records, ycur = (rows of Ac^-1 of this block's aggregates) x
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
 #pragma unroll
             for (int ag = 0; ag < kOcSubK; ++ag)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) q16[3 * ag + j] = fma(ar.v[it][ag], cn[it][j], q16[3 * ag + j]);
+                for (int j = 0; j < 3; ++j) q16[3 * ag + j] = fma((double)ar.v[it][ag], cn[it][j], q16[3 * ag + j]);
         block_sums(q16, std::integral_constant<int, 2>());
         if (tid < 3 * kOcSubK) ycur[tid] = res24[tid];
         __syncthreads();
@@ -596,15 +600,9 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                 bool next_pass = false;
                 while (iters < a.max_iters) {
                     OC2_STAMP(0);
-                    double mm[3], rn[3], sn[3], q[7];
-                    q[6] = 0.0;
+                    double mm[3], rn[3], sn[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        mm[j] = live ? sw[j] + (two_level ? yw[3 * myagg + j] : 0.0) : 0.0;      // m = M^-1 w = S w + P Ac^-1 P^T w
-                        q[j] = rr[j] * ru[j];                                                    // gamma = r . u
-                        q[3 + j] = rw[j] * ru[j];                                                // delta = w . u
-                        q[6] = fma(rr[j] * rd[j] * rr[j], ctl[8 + j], q[6]);                     // Jacobi-norm residual (stop test)
-                    }
+                    for (int j = 0; j < 3; ++j) mm[j] = live ? sw[j] + (two_level ? yw[3 * myagg + j] : 0.0) : 0.0;   // m = M^-1 w = S w + P Ac^-1 P^T w
                     ++ph; publish(mm);
                     OC2_STAMP(1);
                     if (a.nbr) {
@@ -618,7 +616,17 @@ __global__ __launch_bounds__(MAXT) void k_pcg2(Oc2Args a) {
                     OC2_STAMP(3);
                     ++be;
                     const int par = (int)(be & 1u);
-                    publish_record(q, rn, two_level, par);
+                    {   // (the sums just before their record, not across the exchange and the row loop: 14 VGPRs)
+                        double q[7];
+                        q[6] = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            q[j] = rr[j] * ru[j];                                                // gamma = r . u
+                            q[3 + j] = rw[j] * ru[j];                                            // delta = w . u
+                            q[6] = fma(rr[j] * rd[j] * rr[j], ctl[8 + j], q[6]);                 // Jacobi-norm residual (stop test)
+                        }
+                        publish_record(q, rn, two_level, par);
+                    }
                     OC2_STAMP(4);
                     // S n (the block-local part of M^-1 n, data of this block only) behind the latency of the grid barrier:
                     // S w is then carried by the recurrences below like w itself, no smoothing on the critical path
