@@ -344,22 +344,46 @@ template <int KIND, typename T>
 __device__ __forceinline__ bool newton_direction(const StretchModel<KIND, T> &m, const T *s, const T *g, const T *D, const T *w,
                                                  T *d, T &gd, bool &pure) {
     const T floorD = T(1e-8) * (t_abs(m.k) + t_abs(m.mu)) + T(1e-30);
+    // H = diag(D) + la w w^T.  Every D_i > 0: positive definite.  Exactly ONE D_i < 0: still positive definite iff
+    // 1 + la sum w_i^2 / D_i < 0 (det H = prod D_i (1 + la sum w_i^2 / D_i); Cauchy interlacing settles the other minors) --
+    // the case of a strongly compressed stretch next to strongly extended ones (NH: log J > 0 turns a diagonal entry negative
+    // while the rank-one barrier term keeps the Hessian convex).  In both cases the Sherman-Morrison solve with the SIGNED
+    // diagonal is the exact Newton step.  Otherwise |D| is floored: a convexified model, linear convergence (it used to
+    // serve the second case too, and elements at stretches like (4.9, 2.9, 2.4) then stopped at the iteration cap 5e-5 short
+    // of the minimiser).
     T a[3], y[3];
-    T wDg = T(0), wDw = T(0);
-    pure = true;
+    int nneg = 0;
+    bool okD = true, act[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const T Di = t_max(t_abs(D[i]), floorD);
-        const bool active = (KIND >= 2) && (s[i] <= T(0)) && (g[i] > T(0));
-        pure = pure && !active && (D[i] >= floorD);
-        a[i] = active ? T(0) : t_rcp(Di);
-        y[i] = g[i] * a[i];
-        wDg = t_fma(w[i], y[i], wDg);
+        act[i] = (KIND >= 2) && (s[i] <= T(0)) && (g[i] > T(0));
+        okD = okD && !act[i] && (t_abs(D[i]) >= floorD);
+        nneg += (D[i] < T(0)) ? 1 : 0;
+    }
+    T wDw = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a[i] = t_rcp(okD ? D[i] : T(1));
         wDw = t_fma(w[i] * w[i], a[i], wDw);
     }
-    const T den = t_fma(m.la, wDw, T(1));
-    const T coef = (den > T(1e-6)) ? m.la * wDg * t_rcp(den) : T(0);
-    pure = pure && (den > T(1e-6));
+    T den = t_fma(m.la, wDw, T(1));
+    pure = okD && (nneg == 0 ? den > T(1e-6) : (nneg == 1 && den < T(-1e-6)));
+    if (!pure) {
+        wDw = T(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            a[i] = act[i] ? T(0) : t_rcp(t_max(t_abs(D[i]), floorD));
+            wDw = t_fma(w[i] * w[i], a[i], wDw);
+        }
+        den = t_fma(m.la, wDw, T(1));
+    }
+    T wDg = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        y[i] = g[i] * a[i];
+        wDg = t_fma(w[i], y[i], wDg);
+    }
+    const T coef = (pure || den > T(1e-6)) ? m.la * wDg * t_rcp(den) : T(0);
     gd = T(0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -373,6 +397,34 @@ __device__ __forceinline__ bool newton_direction(const StretchModel<KIND, T> &m,
         if (!(gd < T(0))) return false;
     }
     return true;
+}
+// The lean version for the common case: the EXACT Newton step, or false if the Hessian is not positive definite by the test
+// above / a bound is active / the step is no descent direction -- the caller then leaves the element to the general loop.
+template <int KIND, typename T>
+__device__ __forceinline__ bool newton_direction_exact(const StretchModel<KIND, T> &m, const T *s, const T *g, const T *D, const T *w, T *d) {
+    const T floorD = T(1e-8) * (t_abs(m.k) + t_abs(m.mu)) + T(1e-30);
+    T a[3];
+    int nneg = 0;
+    bool okD = true;
+    T wDw = T(0), wDg = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        okD = okD && !((KIND >= 2) && (s[i] <= T(0)) && (g[i] > T(0))) && (t_abs(D[i]) >= floorD);
+        nneg += (D[i] < T(0)) ? 1 : 0;
+        a[i] = t_rcp(D[i]);
+        wDw = t_fma(w[i] * w[i], a[i], wDw);
+        wDg = t_fma(w[i], g[i] * a[i], wDg);
+    }
+    const T den = t_fma(m.la, wDw, T(1));
+    const bool pd = okD && (nneg == 0 ? den > T(1e-6) : (nneg == 1 && den < T(-1e-6)));
+    const T coef = m.la * wDg * t_rcp(den);
+    T gd = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        d[i] = -(g[i] - coef * w[i]) * a[i];
+        gd = t_fma(g[i], d[i], gd);
+    }
+    return pd && gd < T(0);
 }
 // Is the step d small enough to be applied without re-evaluation (quadratic convergence: the remaining error is ~ step^2)?
 // That error is ~ step^2 times (third / second derivative) ~ step^2 / s_min near the barrier / the s = 0 boundary: the
@@ -406,10 +458,9 @@ __device__ __forceinline__ int newton_stretch(const StretchModel<KIND, T> &m, T 
     T g[3], D[3], w[3];
     T f = m.eval(s, g, D, w);
     {
-        T d[3], gd, sn[3];
-        bool pure;
-        const bool desc = newton_direction<KIND, T>(m, s, g, D, w, d, gd, pure);
-        bool fin = desc && newton_step_is_final<T>(s, d, pure, tol_final);
+        T d[3], sn[3];
+        const bool exact = newton_direction_exact<KIND, T>(m, s, g, D, w, d);
+        bool fin = exact && newton_step_is_final<T>(s, d, true, tol_final);
 #pragma unroll
         for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (KIND >= 2) sn[i] = t_max(sn[i], T(0)); }
         fin = fin && m.feasible(sn);

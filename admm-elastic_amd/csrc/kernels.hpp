@@ -263,7 +263,7 @@ __device__ __forceinline__ void buf_st(__amdgpu_buffer_rsrc_t rs, int voff, int 
 
 // What one tet reads: loaded by tet_load (streams: Binv, u, scale, material id) and tet_gather (the four vertex
 // positions); all loads of a tet are issued before any of its arithmetic.
-struct TetIn { double Bi[9], ui[9], s; int mid; };
+struct TetIn { double Bi[9], ui[9]; int mid; };
 struct TetPos { double p[12]; };
 
 __device__ __forceinline__ int4 tet_load_idx(const TetArgs &a, int t) {
@@ -277,7 +277,6 @@ __device__ __forceinline__ void tet_load(const TetArgs &a, int t, TetIn &in) {
     const __amdgpu_buffer_rsrc_t rBinv = soa_rsrc(a.Binv), ru = soa_rsrc(a.u);
 #pragma unroll
     for (int c = 0; c < 9; ++c) { in.Bi[c] = buf_ld_stream(rBinv, t8, c * ld8); in.ui[c] = buf_ld_stream(ru, t8, c * ld8); }
-    in.s = buf_ld_stream(soa_rsrc(a.sc), t8, 0);
     in.mid = (KIND == 0) ? 0 : __builtin_amdgcn_raw_buffer_load_b32(soa_rsrc(a.mat_id), t * 4, 0, 0);
 }
 __device__ __forceinline__ void tet_gather(const TetArgs &a, const int4 id, TetPos &x) {
@@ -351,6 +350,9 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
     const __amdgpu_buffer_rsrc_t re = soa_rsrc(a.ch_ent);
     union { bv4u v; unsigned short h[8]; } e;
     e.v = __builtin_amdgcn_raw_buffer_load_b128(re, (g0 * 256 + (int)threadIdx.x) * 16, 0, ADMM_STREAM_LD_AUX);
+    // dt^2 w^2 of this tet: needed after the prox, fetched across it like the list (two registers less across the SVD: the fused
+    // kernel sits exactly on its 128)
+    const double s = buf_ld_stream(soa_rsrc(a.sc), valid ? t8 : 0, 0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) S1[i] = S0[i];
     if (KIND == 0) {
@@ -381,7 +383,6 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
     ADMM_PHASE_MARK(2);
     // z = U diag(S1) V^T ; u_new = u + D_i x - z = q - z = U diag(S0 - S1) V^T   (EnergyTerm.hpp:137)
     // G = dt^2 w^2 (z - u_new) = s U diag(2 S1 - S0) V^T
-    const double s = in.s;
     double G[9];
     {
         double du[3], dg[3];

@@ -110,7 +110,11 @@ def test_stretch_minimisation_meets_the_oracles_optimality_condition(hm, kind):
     for k in (0.1 * mu, mu, 30.0 * mu):
         n = 3000
         x0 = np.concatenate([1.0 + 0.05 * rng.standard_normal((n, 3)), rng.uniform(0.3, 2.5, (n, 3)),
-                             np.abs(1.0 + 0.3 * rng.standard_normal((n, 3))) * np.array([1, 1, -1.0])])      # near rest, large strain, inverted
+                             np.abs(1.0 + 0.3 * rng.standard_normal((n, 3))) * np.array([1, 1, -1.0]),
+                             rng.uniform(0.15, 6.0, (n, 3)),                                                   # extreme: det up to 200
+                             np.array([[4.91949492, 2.87407946, 2.38054277]])])      # near rest, large strain, inverted, extreme,
+        # and the element that exposed the convexified Hessian model (one negative diagonal entry, Hessian still convex): the
+        # Newton then crawled to its iteration cap 5e-5 short of the minimiser
         s = np.ascontiguousarray(x0.copy())
         hm.hm_prox(kind, len(s), mu, la, k, s.ctypes.data_as(dp))
         assert np.isfinite(s).all()
