@@ -408,6 +408,7 @@ static int newton3(const prox_problem *p, double *x, int max_iters) {
         }
         double t = 1.0, xn[3];
         int ok = 0;
+        const double fscale = (fabs(p->mu) + fabs(p->lambda) + fabs(p->k)) * (1.0 + x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
         for (int ls = 0; ls < 60; ++ls) {
             double gs = 0.0;
             for (int c = 0; c < 3; ++c) {
@@ -416,7 +417,10 @@ static int newton3(const prox_problem *p, double *x, int max_iters) {
                 gs += g[c] * (xn[c] - x[c]);
             }
             int feas = proj ? 1 : feasible(p, xn);
-            if (feas && prox_value(p, xn) <= f + 1e-4 * gs + 1e-14 * fabs(f)) { ok = 1; break; }
+            /* round-off in f is absolute: O(mu + lambda + k) terms cancel to O(strain^2), so the allowance is measured against
+             * the size of the terms, not against |f| -- with 1e-14 |f| the search refused the last Newton steps and the polish
+             * stalled ~1e-8 away from the minimiser (the GPU path, checked with this file's own gradient, was closer) */
+            if (feas && prox_value(p, xn) <= f + 1e-4 * gs + 1e-15 * (fabs(f) + fscale)) { ok = 1; break; }
             t *= 0.5;
         }
         if (!ok) break;

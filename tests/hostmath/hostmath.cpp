@@ -26,6 +26,7 @@ void hm_prox(int kind, int n, double mu, double la, double k, double *S) {
     for (int i = 0; i < n; ++i) {
         if (kind == 1) prox_stretches<1>(mu, la, k, S + 3 * i);
         else if (kind == 2) prox_stretches<2>(mu, la, k, S + 3 * i);
+        else if (kind == 3) prox_stretches<3>(mu, la, k, S + 3 * i);
         else if (kind == 0) prox_stretches<0>(mu, la, k, S + 3 * i);
     }
 }

@@ -26,7 +26,7 @@ def deformed(sc, amp, seed):
 
 
 @pytest.mark.parametrize("kind", list(KINDS))
-@pytest.mark.parametrize("amp", [0.0, 0.01, 0.12])   # 0.12 on a 1/4 grid inverts a few tets
+@pytest.mark.parametrize("amp", [0.0, 0.01, 0.12, 0.3])   # 0.12 on a 1/4 grid inverts a few tets, 0.3 many (stretches up to 5)
 def test_local_step_tets(kind, amp):
     sc = scenes.cube_scene(4, KINDS[kind], pin_face=False)
     s = sc.make_solver()
@@ -37,10 +37,12 @@ def test_local_step_tets(kind, amp):
     z, u = s.local_step(x, u0)
     zo = np.zeros(R); uo = u0.copy()
     o.local_step(x, zo, uo)
-    tol = 1e-11 if kind == "linear" else 2e-8
+    # (hyperelastic: both sides are exact minimisers -- the device's Newton and the oracle's polished L-BFGS meet at ~5e-13,
+    # measured; up to round 2 the oracle's polish stalled 1e-8 short and the bound had to be 2e-8)
+    tol = 1e-11 if kind == "linear" else 1e-10
     assert np.abs(z - zo).max() < tol, np.abs(z - zo).max()
     assert np.abs(u - uo).max() < tol
-    if amp == 0.12:
+    if amp >= 0.12:
         F = (uo - u0 + zo).reshape(-1, 3, 3)
         assert (np.linalg.det(F) < 0).any(), "case meant to contain inverted elements"
 
@@ -55,7 +57,7 @@ def test_local_step_mixed_materials_and_rhs():
     z, u, b = s.local_step(x, u0, Mxbar)
     zo = np.zeros(o.R); uo = u0.copy()
     o.local_step(x, zo, uo)
-    assert np.abs(z - zo).max() < 2e-8 and np.abs(u - uo).max() < 2e-8
+    assert np.abs(z - zo).max() < 1e-10 and np.abs(u - uo).max() < 1e-10, (np.abs(z - zo).max(), np.abs(u - uo).max())
     bo = o.rhs(Mxbar, zo, uo)
     assert np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
 
@@ -241,7 +243,7 @@ def test_spline_tets_with_compression_term(kind):
     z, u = s.local_step(x.ravel(), u0)
     zo = np.zeros(o.R); uo = u0.copy()
     o.local_step(x.ravel(), zo, uo)
-    assert np.abs(z - zo).max() < 5e-8 and np.abs(u - uo).max() < 5e-8, (np.abs(z - zo).max(), np.abs(u - uo).max())
+    assert np.abs(z - zo).max() < 1e-9 and np.abs(u - uo).max() < 1e-9, (np.abs(z - zo).max(), np.abs(u - uo).max())
     z0, _ = s0.local_step(x.ravel(), u0)
     assert np.abs(z - z0).max() > 1e-4                # the compression term is not a no-op
     for _ in range(3):
