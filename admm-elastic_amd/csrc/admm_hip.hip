@@ -211,7 +211,7 @@ struct admm_hip_ctx {
     double *rc_E(int s) { return rc_buf.p + ((size_t)(s % kRcSlots) * 2 + 0) * (size_t)n3i; }
     double *rc_R(int s) { return rc_buf.p + ((size_t)(s % kRcSlots) * 2 + 1) * (size_t)n3i; }
     // UzawaCG (per-vertex constraint rows)
-    DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part;
+    DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part, uz_dmax; DevBuf<long long> uz_dacc;   // uz_dacc / uz_dmax: dyn_collide.hpp, k_uz_ct_dyn
     DevBuf<UzScal> uz_scal;
     int uz_prev_hits = -1, uz_last_hits = 0, NBU = 1, uz_iters_step = 0, uz_prev_iters = 0;
     bool uz_freeze = false, uz_detected = false;   // tests (ADMM_HIP_UZ_FREEZE=1): Collider::detect only in the first ADMM iteration of a step
@@ -257,7 +257,7 @@ struct admm_hip_ctx {
         bk_x.release(); bk_v.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
-        uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release();
+        uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
         gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
         lk_ts.release(); lk_out.release(); oc_color.release();
@@ -700,6 +700,15 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     return rc;
 }
 
+// face-vertex part of C^T v for the dynamic rows (dyn_collide.hpp): largest magnitude, integer scatter, apply
+static void launch_ct_dyn(admm_hip_ctx *c, int nq, const int *qlist, int mode, const double *v, const int *dface, const double *dbary, double *out) {
+    hipStream_t st = c->stream;
+    const int gq = blocks_for(nq);
+    hipLaunchKernelGGL(k_uz_ct_dyn_max, dim3(gq), dim3(256), 0, st, nq, qlist, c->uz_cn.p, v, dface, dbary, c->uz_dmax.p);
+    hipLaunchKernelGGL(k_uz_ct_dyn, dim3(gq), dim3(256), 0, st, nq, qlist, mode, c->uz_cn.p, v, dface, dbary, c->uz_dmax.p, c->uz_dacc.p);
+    hipLaunchKernelGGL(k_uz_ct_dyn_apply, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, c->uz_dmax.p, c->uz_dacc.p, out);
+}
+
 // Collider::detect, dynamic objects (src/Collider.hpp:166-168,192-201): refit every tet tree at x, then query the
 // candidates against the objects in add_dynamic_collider order.  Payloads land in dyn_face / dyn_bary / dyn_n / dyn_dx.
 int enqueue_dyn_detect(admm_hip_ctx *c, const double *x) {
@@ -760,7 +769,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     }
     if (nh == 0) return launch_pcg_recycled(c, b, x); // no constraints: one prefactored solve (:78-81)
     hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 0, b, c->uz_cn.p, c->uz_y.p, c->uz_q1.p);       // q1 = b - C^T y
-    if (dyn) hipLaunchKernelGGL(k_uz_ct_dyn, dim3(gq), dim3(256), 0, st, nq, qlist, 0, c->uz_cn.p, c->uz_y.p, dface, dbary, c->uz_q1.p);
+    if (dyn) launch_ct_dyn(c, nq, qlist, 0, c->uz_y.p, dface, dbary, c->uz_q1.p);
     if (launch_pcg(c, c->uz_q1.p, x, c->pcg_max_iters)) return -1;                                               // x = A^-1 q1
     hipLaunchKernelGGL(k_uz_resid, dim3(gv), dim3(256), 0, st, nv, x, c->uz_cn.p, c->uz_cc.p, c->uz_r.p, c->uz_d.p, dface, dbary);
     if (hipMemsetAsync(c->uz_scal.p, 0, sizeof(UzScal), st) != hipSuccess) return -1;
@@ -777,7 +786,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
         const int n = std::min(chunk, c->uz_max_iters - launched);
         for (int it = 0; it < n; ++it) {
             hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 1, b, c->uz_cn.p, c->uz_d.p, c->uz_q1.p);   // q1 = C^T d
-            if (dyn) hipLaunchKernelGGL(k_uz_ct_dyn, dim3(gq), dim3(256), 0, st, nq, qlist, 1, c->uz_cn.p, c->uz_d.p, dface, dbary, c->uz_q1.p);
+            if (dyn) launch_ct_dyn(c, nq, qlist, 1, c->uz_d.p, dface, dbary, c->uz_q1.p);
             if (hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) return -1;
             if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, c->pcg_max_iters, stop_flag)) return -1;                       // q2 = A^-1 q1
             hipLaunchKernelGGL(k_uz_dots, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_q2.p, c->uz_cn.p, c->uz_d.p, c->uz_r.p, c->uz_q3.p,
@@ -1350,6 +1359,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         c->NBU = std::max(1, std::min((nv + 255) / 256, 256));
         HIP_TRY(c->uz_cn.alloc(c->n3)); HIP_TRY(c->uz_cn.zero());
         HIP_TRY(c->uz_q1.alloc(c->n3)); HIP_TRY(c->uz_q2.alloc(c->n3)); HIP_TRY(c->uz_q2.zero());
+        HIP_TRY(c->uz_dmax.alloc(2)); HIP_TRY(c->uz_dmax.zero()); HIP_TRY(c->uz_dacc.alloc(c->n3)); HIP_TRY(c->uz_dacc.zero());
         HIP_TRY(c->uz_cc.alloc(nv)); HIP_TRY(c->uz_y.alloc(nv)); HIP_TRY(c->uz_y.zero());
         HIP_TRY(c->uz_r.alloc(nv)); HIP_TRY(c->uz_d.alloc(nv)); HIP_TRY(c->uz_q3.alloc(nv));
         HIP_TRY(c->uz_part.alloc(2 * (size_t)c->NBU)); HIP_TRY(c->uz_scal.alloc(1)); HIP_TRY(c->uz_scal.zero());

@@ -308,23 +308,64 @@ __global__ __launch_bounds__(256) void k_dyn_rows(int nq, const int *__restrict_
     cc[v] = 0.0;
 }
 
-// the face-vertex part of C^T y: out += s * ck n bary_j y_v at face vertex j, s = +1 for (base - C^T y), -1 for C^T y.
-// Several rows may share a face vertex: FP64 atomic adds (the only atomics on data in this library; their order is
-// the only source of run-to-run round-off differences, and only while dynamic rows exist).
-__global__ __launch_bounds__(256) void k_uz_ct_dyn(int nq, const int *__restrict__ query, int mode, const double *__restrict__ cn,
-                                                   const double *__restrict__ y, const int *__restrict__ dface,
-                                                   const double *__restrict__ dbary, double *__restrict__ out) {
+// The face-vertex part of C^T y: out += s * ck n bary_j y_v at face vertex j, s = +1 for (base - C^T y), -1 for C^T y.
+// Several rows may share a face vertex.  No FP64 atomics (their order would make contact runs differ in the last bits from run
+// to run): the contributions are summed as 64-bit INTEGERS in a fixed-point format chosen from their largest magnitude --
+// integer addition is associative, so the sum does not depend on the order, and with 2^-50 of the largest contribution as the
+// unit it is as accurate as the FP64 sum.  Three small launches: (1) the largest magnitude (atomicMax on the bit pattern of a
+// non-negative double is order-independent too), (2) the scatter with integer atomic adds, (3) out += sum / scale, clearing the
+// accumulator behind itself.  dmax[0] must be 0 on entry of (1); (3) leaves it 0 again.
+__device__ __forceinline__ double uz_dyn_scale(double m) {      // 2^(50 - e) for m = f 2^e, f in [0.5, 1)
+    const int e = (int)((__double2hiint(m) >> 20) & 0x7ff) - 1022;
+    return __hiloint2double((1023 + 50 - e) << 20, 0);
+}
+__global__ __launch_bounds__(256) void k_uz_ct_dyn_max(int nq, const int *__restrict__ query, const double *__restrict__ cn,
+                                                       const double *__restrict__ y, const int *__restrict__ dface,
+                                                       const double *__restrict__ dbary, double *__restrict__ dmax) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nq) return;
     const int v = query ? query[q] : q;
     if (dface[3 * (size_t)v] < 0) return;
+    const double c = fmax(fabs(cn[3 * (size_t)v]), fmax(fabs(cn[3 * (size_t)v + 1]), fabs(cn[3 * (size_t)v + 2])));
+    const double b = fmax(fabs(dbary[3 * (size_t)v]), fmax(fabs(dbary[3 * (size_t)v + 1]), fabs(dbary[3 * (size_t)v + 2])));
+    const double m = fabs(y[v]) * b * c;
+    if (m > 0.0 && m < 1e300) atomicMax((unsigned long long *)dmax, (unsigned long long)__double_as_longlong(m));
+}
+__global__ __launch_bounds__(256) void k_uz_ct_dyn(int nq, const int *__restrict__ query, int mode, const double *__restrict__ cn,
+                                                   const double *__restrict__ y, const int *__restrict__ dface,
+                                                   const double *__restrict__ dbary, const double *__restrict__ dmax,
+                                                   long long *__restrict__ acc) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const int v = query ? query[q] : q;
+    if (dface[3 * (size_t)v] < 0) return;
+    const double m = dmax[0];
+    if (!(m > 0.0)) return;
+    const double scale = uz_dyn_scale(m);
     const double s = (mode == 0 ? 1.0 : -1.0) * y[v];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int f = dface[3 * (size_t)v + j];
         const double w = s * dbary[3 * (size_t)v + j];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) atomicAdd(out + 3 * (size_t)f + a, w * cn[3 * (size_t)v + a]);
+        for (int a = 0; a < 3; ++a) {
+            const long long k = __double2ll_rn(w * cn[3 * (size_t)v + a] * scale);
+            if (k != 0) atomicAdd((unsigned long long *)(acc + 3 * (size_t)f + a), (unsigned long long)k);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_uz_ct_dyn_apply(int n3, double *__restrict__ dmax, long long *__restrict__ acc, double *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double m = dmax[0];
+    if (i < n3 && m > 0.0) {
+        const long long k = acc[i];
+        if (k != 0) { out[i] += (double)k / uz_dyn_scale(m); acc[i] = 0; }
+    }
+    // (every thread has read dmax above; the last block to pass clears it for the next use)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd((unsigned int *)(dmax + 1), 1u) == gridDim.x - 1) { dmax[0] = 0.0; ((unsigned int *)(dmax + 1))[0] = 0u; }
     }
 }
 

@@ -223,6 +223,24 @@ def test_step_with_self_collision():
     assert X[nvb:, 1].min() > X[:nvb, 1].mean()
 
 
+@pytest.mark.gpu
+def test_self_collision_steps_are_bit_reproducible():
+    """C^T y of the dynamic rows scatters to face vertices that several rows share; it is summed in fixed-point integers
+    (csrc/dyn_collide.hpp: k_uz_ct_dyn), so two runs of a colliding scene are identical to the last bit -- with FP64 atomic
+    adds (rounds 1 and 2a) they differed by round-off and, the active set being chaotic, soon by more."""
+    runs = []
+    for rep in range(2):
+        sc = scenes.two_blocks_scene(3, floor=-0.3)
+        s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=600)
+        hits = 0
+        for _ in range(6):
+            s.step()
+            hits += s.runtime_data().inner_iters
+        runs.append(s.m_x.copy()); s.close()
+        assert hits > 5
+    assert np.array_equal(runs[0], runs[1])
+
+
 def _gs_pair(n, floor, **kw):
     """GPU solver + oracle on the two-blocks scene with the multi-colour GS, sharing the base colouring"""
     sc = scenes.two_blocks_scene(n, floor=floor, linsolver=1, **kw)
