@@ -547,6 +547,9 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
                         c->oc_sm_ab = al - be; c->oc_sm_b = be;
                     }
                 }
+                if (getenv("ADMM_HIP_OC_DIAG"))
+                    fprintf(stderr, "[oc_plan] lanes on the busiest LDS bank pair per half-wave column: %.2f by index, %.2f as placed; lambda_max(D^-1 A_bb) ~ %.3f\n",
+                            plan.stat_bank_sorted, plan.stat_bank_placed, plan.lam_bb);
                 c->oc_stat[0] = plan.stat_nnz; c->oc_stat[1] = plan.stat_stored; c->oc_stat[2] = plan.stat_onchip; c->oc_stat[3] = plan.stat_local;
                 c->oc_stat[4] = plan.nbr_max; c->oc_stat[5] = c->oc_coarse ? plan.nc : 0;
             }

@@ -118,6 +118,7 @@ struct OcPlan {
     int nc = 0, ncp = 0;                // coarse unknowns (G * kOcSub), padded row length of ainv
     bool coarse_ok = false;
     std::vector<double> ainv;           // [nc][ncp] (P^T A P)^-1
+    double stat_bank_sorted = 0.0, stat_bank_placed = 0.0;   // lanes on the busiest LDS bank pair per (half wavefront, column): entries by index / as placed
     double lam_bb = 0.0;                // estimate of lambda_max(D^-1 A_bb), A_bb = the block-diagonal part of M + Ahat (power iteration)
     int64_t stat_nnz = 0, stat_stored = 0, stat_onchip = 0, stat_local = 0;
 };

@@ -17,6 +17,7 @@
 #include "host_setup.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -274,38 +275,96 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
     S.val.assign(S.slice_ptr[S.n_slices], 0.0);
     P.col16.assign(S.slice_ptr[S.n_slices], 0);
     P.mdiag.assign(3 * (size_t)P.n_rows, 0.0);
+    // Entries of a row may stand in any order: they are placed so that the 32 lanes of a half wavefront -- the group one
+    // ds_read_b64 serves per LDS cycle -- read DISTINCT bank pairs of the local vector in every column (bank pair of entry c =
+    // c mod 32: the vector starts on a 256-byte boundary).  Placed by increasing column index, a column had ~3.5 lanes on its
+    // busiest bank pair, i.e. the random reads of the vector -- 12 of the 17 LDS instructions of four entries -- ran at less
+    // than a third of the LDS rate.  Greedy, column by column: rows with the most entries left choose first, each the entry
+    // whose bank pair is least used in this column so far; rows without entries left pad with a zero times an own entry of
+    // the least used bank pair.
+    int64_t conflict_sorted = 0, conflict_placed = 0, columns_total = 0;
+    const bool place_by_bank = [] { const char *e = getenv("ADMM_HIP_OC_BANKS"); return !(e && e[0] == '0'); }();
     for (int32_t s = 0; s < S.n_slices; ++s) {
         const int b = s / spb;
         const std::vector<int32_t> &h = halo[b];
+        const int32_t w = S.slice_width[s];
+        std::vector<std::pair<int32_t, double> > ent[64];   // (local index, value), increasing local index
         for (int l = 0; l < 64; ++l) {
             const int32_t r = 64 * s + l, v = P.orig[r];
-            const uint16_t self = (uint16_t)(r - b * T);
-            int32_t k = 0;
-            auto put = [&](uint16_t c, double x) {
-                S.val[(size_t)S.slice_ptr[s] + 64 * k + l] = x;
-                P.col16[(size_t)S.slice_ptr[s] + ((size_t)(k >> 2) * 64 + l) * 4 + (k & 3)] = c;
-                ++k;
-            };
-            if (v >= 0) {
-                std::vector<std::pair<int32_t, double> > ent;   // (local index, value), increasing local index
-                double diag = 0.0;
-                for (int32_t q = A.rowptr[v]; q < A.rowptr[v + 1]; ++q) {
-                    const int32_t cv = A.col[q];
-                    if (cv == v) { diag = A.val[q]; continue; }
-                    if (A.val[q] == 0.0) continue;
-                    const int32_t pr = P.pos[cv];
-                    int32_t lc;
-                    if (part_of[cv] == b) lc = pr - b * T;
-                    else lc = T + (int32_t)(std::lower_bound(h.begin(), h.end(), pr) - h.begin());
-                    ent.emplace_back(lc, A.val[q]);
-                }
-                std::sort(ent.begin(), ent.end());
-                for (auto &e : ent) put((uint16_t)e.first, e.second);
-                for (int j = 0; j < 3; ++j) P.mdiag[3 * (size_t)r + j] = mass3[3 * (size_t)v + j] + diag;
+            if (v < 0) continue;
+            double diag = 0.0;
+            for (int32_t q = A.rowptr[v]; q < A.rowptr[v + 1]; ++q) {
+                const int32_t cv = A.col[q];
+                if (cv == v) { diag = A.val[q]; continue; }
+                if (A.val[q] == 0.0) continue;
+                const int32_t pr = P.pos[cv];
+                int32_t lc;
+                if (part_of[cv] == b) lc = pr - b * T;
+                else lc = T + (int32_t)(std::lower_bound(h.begin(), h.end(), pr) - h.begin());
+                ent[l].emplace_back(lc, A.val[q]);
             }
-            while (k < S.slice_width[s]) put(self, 0.0);   // padding: zero times the row's own entry
+            std::sort(ent[l].begin(), ent[l].end());
+            for (int j = 0; j < 3; ++j) P.mdiag[3 * (size_t)r + j] = mass3[3 * (size_t)v + j] + diag;
+        }
+        auto put = [&](int l, int32_t k, uint16_t c, double x) {
+            S.val[(size_t)S.slice_ptr[s] + 64 * k + l] = x;
+            P.col16[(size_t)S.slice_ptr[s] + ((size_t)(k >> 2) * 64 + l) * 4 + (k & 3)] = c;
+        };
+        for (int half = 0; half < 2; ++half) {
+            const int l0 = 32 * half;
+            {   // what the order by column index would cost (statistics)
+                for (int32_t k = 0; k < w; ++k) {
+                    int load[32] = {0}, mx = 0;
+                    for (int l = l0; l < l0 + 32; ++l) {
+                        const int32_t c = k < (int32_t)ent[l].size() ? ent[l][k].first : (int32_t)(64 * s + l - b * T);
+                        mx = std::max(mx, ++load[c & 31]);
+                    }
+                    conflict_sorted += mx; ++columns_total;
+                }
+            }
+            if (!place_by_bank) {
+                for (int l = l0; l < l0 + 32; ++l)
+                    for (int32_t k = 0; k < w; ++k) {
+                        if (k < (int32_t)ent[l].size()) put(l, k, (uint16_t)ent[l][k].first, ent[l][k].second);
+                        else put(l, k, (uint16_t)(64 * s + l - b * T), 0.0);
+                    }
+                continue;
+            }
+            std::vector<char> used[32];
+            for (int l = l0; l < l0 + 32; ++l) used[l - l0].assign(ent[l].size(), 0);
+            int rem[32];
+            for (int l = l0; l < l0 + 32; ++l) rem[l - l0] = (int)ent[l].size();
+            for (int32_t k = 0; k < w; ++k) {
+                int load[32] = {0};
+                int order[32];
+                std::iota(order, order + 32, 0);
+                std::stable_sort(order, order + 32, [&](int x, int y) { return rem[x] > rem[y]; });
+                int mx = 0;
+                for (int oi = 0; oi < 32; ++oi) {
+                    const int i = order[oi], l = l0 + i;
+                    if (rem[i] > 0) {
+                        int best = -1, best_load = 1 << 30;
+                        for (int e = 0; e < (int)ent[l].size(); ++e)
+                            if (!used[i][e]) {
+                                const int ld = load[ent[l][e].first & 31];
+                                if (ld < best_load) { best_load = ld; best = e; }
+                            }
+                        used[i][best] = 1; --rem[i];
+                        mx = std::max(mx, ++load[ent[l][best].first & 31]);
+                        put(l, k, (uint16_t)ent[l][best].first, ent[l][best].second);
+                    } else {
+                        int bc = 0;
+                        for (int c = 1; c < 32; ++c) if (load[c] < load[bc]) bc = c;
+                        mx = std::max(mx, ++load[bc]);
+                        put(l, k, (uint16_t)bc, 0.0);      // zero times own entry bc of the block (T >= 64: it exists and is finite)
+                    }
+                }
+                conflict_placed += mx;
+            }
         }
     }
+    P.stat_bank_sorted = columns_total ? (double)conflict_sorted / (double)columns_total : 0.0;
+    P.stat_bank_placed = columns_total ? (double)(place_by_bank ? conflict_placed : conflict_sorted) / (double)columns_total : 0.0;
     // ---- LDS: the block's local vector (3 axes x (T + halo)) and the slab (10 bytes per entry) ----
     P.vec_len = T + P.nh_cap;
     const int lds_cols = std::max(0, (lds_bytes - 3 * 8 * P.vec_len) / (64 * 10)) / 4 * 4;
