@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import admm_elastic_amd as pkg
-from admm_elastic_amd import meshes
+from admm_elastic_amd import capi, meshes
 from admm_elastic_amd.solver import Lame
 from oracle import oracle as orc
 import scenes
@@ -45,6 +45,38 @@ def test_local_step_tets(kind, amp):
     if amp >= 0.12:
         F = (uo - u0 + zo).reshape(-1, 3, 3)
         assert (np.linalg.det(F) < 0).any(), "case meant to contain inverted elements"
+
+
+def test_local_step_and_rhs_with_randomly_numbered_vertices():
+    """A mesh whose vertex numbering has no locality (a mesh file as it comes): a chunk of 256 tets then touches ~800 different
+    vertices, its block-level reduction of the corner forces runs several 256-record passes and the record lists get long --
+    same z, u and right-hand side as the oracle, and the whole step too."""
+    verts, tets = meshes.kuhn_cube(12)
+    rng = np.random.default_rng(31)
+    perm = rng.permutation(len(verts))                  # new index of old vertex i
+    v2 = np.zeros_like(verts); v2[perm] = verts
+    t2 = perm[tets].astype(np.int32)[rng.permutation(len(tets))]
+    sc = scenes.Scene()
+    sc.add_tet_mesh(v2, t2, Lame.soft_rubber(), pkg.TET_NEOHOOKEAN)
+    for i in np.nonzero(v2[:, 0] < 1e-9)[0]:
+        sc.pins[int(i)] = v2[i].copy()
+    sc.settings.update(admm_iters=5, linsolver=0)
+    _, st = capi.chunk_reduce(len(v2), t2[np.lexsort((t2.sum(1), t2.min(1)))], [0, 0, len(t2), len(t2), len(t2), len(t2)], np.zeros((len(t2), 4, 3)))
+    assert st["max_passes"] >= 2, st                    # the case this test is about
+    s = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=600)
+    o = sc.make_oracle(mode=1)
+    x = deformed(sc, 0.02, 5)
+    u0 = 0.02 * np.random.default_rng(6).standard_normal(o.R)
+    Mxbar = np.random.default_rng(7).standard_normal(x.size)
+    z, u, b = s.local_step(x, u0, Mxbar)
+    zo = np.zeros(o.R); uo = u0.copy()
+    o.local_step(x, zo, uo)
+    assert np.abs(z - zo).max() < 1e-10 and np.abs(u - uo).max() < 1e-10
+    bo = o.rhs(Mxbar, zo, uo)
+    assert np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+    for _ in range(2):
+        s.step(); o.step()
+    assert scenes.rel_err(s.m_x, o.x) < 1e-7, scenes.rel_err(s.m_x, o.x)
 
 
 def test_local_step_mixed_materials_and_rhs():
