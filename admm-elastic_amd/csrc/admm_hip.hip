@@ -1997,6 +1997,7 @@ int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int
     if (stats) {
         stats[0] = P.stat_nnz; stats[1] = P.stat_stored; stats[2] = P.stat_onchip; stats[3] = P.stat_local;
         stats[4] = P.nbr_ok ? P.nbr_max : -1; stats[5] = P.coarse_ok ? P.nc : 0; stats[6] = P.nh_max; stats[7] = P.bcols;
+        stats[8] = (int64_t)llround(1e9 * P.lam_bb); stats[9] = (int64_t)llround(1e6 * P.stat_bank_sorted); stats[10] = (int64_t)llround(1e6 * P.stat_bank_placed);
     }
     return ADMM_HIP_OK;
 }

@@ -297,10 +297,12 @@ class Solver:
         rv = np.zeros(n, np.int32); ra = np.zeros(n, np.int32)
         nc = 4 * n_blocks
         ci = np.zeros((nc, nc)) if coarse else None
-        st = (C.c_int64 * 8)()
+        st = (C.c_int64 * 11)()
         check(lib().admm_host_oc_plan(C.byref(d), n_blocks, slices_per_block, lds_bytes, iptr(rv), iptr(ra), dptr(ci) if coarse else None, st))
         keys = ("nnz", "stored", "on_chip", "block_local", "max_neighbour_blocks", "coarse_unknowns", "max_halo", "lds_cols")
-        return dict(row_vertex=rv, row_aggregate=ra, coarse_inv=ci, stats=dict(zip(keys, list(st))))
+        stats = dict(zip(keys, list(st)[:8]))
+        stats.update(lambda_bb=st[8] * 1e-9, bank_load_by_index=st[9] * 1e-6, bank_load_placed=st[10] * 1e-6)
+        return dict(row_vertex=rv, row_aggregate=ra, coarse_inv=ci, stats=stats)
 
     def initialize(self, settings=None):
         s = settings if settings is not None else Settings()

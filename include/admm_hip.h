@@ -278,9 +278,11 @@ void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners,
  * split into 4 compact aggregates that carry the coarse space of the two-level preconditioner
  * M^-1 = D^-1 + P (P^T A P)^-1 P^T.  row_vertex [64 * n_blocks * slices_per_block]: vertex of every internal row (-1 =
  * unused slot); row_aggregate (same length): coarse unknown of the row (block * 4 + aggregate); coarse_inv [nc * nc], nc =
- * 4 * n_blocks: (P^T A P)^-1, row-major (NULL to skip); stats [8]: off-diagonal non-zeros, stored SELL entries, entries
+ * 4 * n_blocks: (P^T A P)^-1, row-major (NULL to skip); stats [11]: off-diagonal non-zeros, stored SELL entries, entries
  * held in LDS, block-local non-zeros, most neighbour blocks of a block (-1: more than 64), coarse unknowns (0 = two-level
- * off), largest halo list, LDS slab columns used.  lds_bytes = LDS a block may spend on its local vector and matrix slab. */
+ * off), largest halo list, LDS slab columns used, 1e9 x the estimate of lambda_max(D^-1 A_bb) the block-local smoother is built
+ * on (A_bb = entries of M + Ahat inside one block), 1e6 x the lanes on the busiest LDS bank pair per half-wavefront column with the
+ * entries in index order / as placed.  lds_bytes = LDS a block may spend on its local vector and matrix slab. */
 int admm_host_oc_plan(const admm_hip_desc *desc, int32_t n_blocks, int32_t slices_per_block, int32_t lds_bytes,
                       int32_t *row_vertex, int32_t *row_aggregate, double *coarse_inv, int64_t *stats);
 

@@ -57,6 +57,25 @@ def _check_plan(sc, G, spb):
     x0, it_j = _pcg(A, b, lambda r: dinv * r, tol=1e-11)
     x1, it_2 = _pcg(A, b, lambda r: dinv * r + P @ (plan["coarse_inv"] @ (P.T @ r)), tol=1e-11)
     assert np.abs(x1 - x0).max() <= 1e-7 * np.abs(x0).max()
+    # the block-local Chebyshev smoother of the kernel is built on the plan's estimate of lambda_max(D^-1 A_bb): it must not
+    # underestimate by more than the kernel's margin (coefficients from 1.1 x the estimate, polynomial positive up to 1.125 x
+    # that), and S + coarse must beat D^-1 + coarse
+    import scipy.sparse.linalg as spla
+    blk = agg // 4
+    coo = A.tocoo(); keep = blk[coo.row] == blk[coo.col]
+    Ab = sp.csr_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=A.shape)
+    Sb = sp.diags(np.sqrt(dinv)) @ Ab @ sp.diags(np.sqrt(dinv))
+    lam = spla.eigsh(Sb, k=1, which="LA", return_eigenvectors=False)[0]
+    assert 0.9 * lam <= st["lambda_bb"] <= 1.0001 * lam, (lam, st["lambda_bb"])
+    hi = 1.1 * st["lambda_bb"]; lo = hi / 16.0; th, de = 0.5 * (hi + lo), 0.5 * (hi - lo)
+    sg = th / de; r0 = 1.0 / sg; r1 = 1.0 / (2.0 * sg - r0)
+    al = (1.0 + r1 * r0) / th + 2.0 * r1 / de; be = 2.0 * r1 / (de * th)          # admm_hip.hip: oc_sm_ab = al - be, oc_sm_b = be
+    assert al - be * lam > 0.0                                                     # q(lambda) > 0 on the whole spectrum: S is SPD
+    Aoff = Ab - sp.diags(Ab.diagonal())
+    S = lambda r: dinv * ((al - be) * r - be * (Aoff @ (dinv * r)))
+    x2, it_3 = _pcg(A, b, lambda r: S(r) + P @ (plan["coarse_inv"] @ (P.T @ r)), tol=1e-11)
+    assert np.abs(x2 - x0).max() <= 1e-7 * np.abs(x0).max() and it_3 < 0.9 * it_2, (it_2, it_3)
+    assert st["bank_load_placed"] <= st["bank_load_by_index"] + 1e-9
     return it_j, it_2, st
 
 
