@@ -682,7 +682,8 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     RcBasis B{};
     // basis: the (up to) kRc most recent pairs of THIS frame.  (Adding the previous frame's pair at the same
     // index was measured: it does not help the first solves of a frame.)
-    for (int j = 1; j <= kRc && s - j >= 0; ++j) { B.E[B.cnt] = c->rc_E(s - j); B.R[B.cnt] = c->rc_R(s - j); ++B.cnt; }
+    static const int rc_pairs = [] { const char *e = getenv("ADMM_HIP_RC_PAIRS"); return e ? std::max(0, std::min(kRc, atoi(e))) : kRc; }();   // (A/B: fewer pairs)
+    for (int j = 1; j <= rc_pairs && s - j >= 0; ++j) { B.E[B.cnt] = c->rc_E(s - j); B.R[B.cnt] = c->rc_R(s - j); ++B.cnt; }
     static const bool rc_kernels = getenv("ADMM_HIP_RC_KERNELS") && getenv("ADMM_HIP_RC_KERNELS")[0] == '1';   // A/B: separate k_rc_* launches
     if (c->oc_enabled && (!rc_kernels || c->oc_plan)) {   // (the plan's pairs live in its internal row order: k_rc_* cannot read them)   // projection, solve and the new pair in ONE persistent launch
         OcRc rc; rc.on = true; rc.B = B; rc.Eslot = c->rc_E(s); rc.Rslot = c->rc_R(s);
