@@ -11,6 +11,13 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 lib_path = os.path.join(HERE, "libadmm_hip.so")
+# Experiments only: ADMM_HIP_LIB=<path> loads another build of the library (a same-box A/B of kernel variants) WITHOUT
+# touching the in-tree one; it is announced on stderr so that a number can never silently come from a variant.
+_variant = os.environ.get("ADMM_HIP_LIB")
+if _variant:
+    import sys as _sys
+    lib_path = os.path.abspath(_variant)
+    print("[admm_hip] ADMM_HIP_LIB set: loading the library VARIANT %s" % lib_path, file=_sys.stderr)
 
 
 class AdmmHipError(RuntimeError):

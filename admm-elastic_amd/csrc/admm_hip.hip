@@ -181,7 +181,7 @@ struct admm_hip_ctx {
     DevBuf<unsigned> oc_bar;
     DevBuf<int> oc_nbr; DevBuf<unsigned long long> oc_flags;   // neighbour hand-off of the pipelined iteration
     DevBuf<unsigned long long> oc_prof;   // diagnosis (ADMM_HIP_OC_PROF=1)
-    bool oc_debug = false; int oc_prof_block = 0;
+    bool oc_debug = false, oc_always_verify = false; int oc_prof_block = 0;
     // general-mesh plan of the on-chip PCG (oc_plan.cpp): internal row order, its SELL, slab shares, two-level data
     double oc_sm_ab = 0.0, oc_sm_b = 0.0, oc_lam_bb = 0.0;   // block-local smoother of k_pcg2 (pcg_onchip2.hpp: smooth)
     bool oc_plan = false, oc_coarse = false; int oc_rows = 0, oc_bcols = 0, oc_nc = 0, oc_ncp = 0, oc_veclen = 0;
@@ -423,6 +423,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.rc_part = c->oc_rc_part.p;
     if (c->oc_coarse) { a.ainv = c->oc_ainv.p; a.cbuf = c->oc_cbuf.p; a.nc = c->oc_nc; a.ncp = c->oc_ncp; }
     a.skip = rc.skip;
+    a.trust_short = c->oc_always_verify ? 0 : 1;
     a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b;
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg2<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
@@ -579,6 +580,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     {   // diagnosis switches, read once
         const char *pe = getenv("ADMM_HIP_OC_PROF"), *pb = getenv("ADMM_HIP_OC_PROF_BLOCK"), *pd = getenv("ADMM_HIP_OC_DEBUG");
         c->oc_debug = pd && pd[0] == '1';
+        { const char *ve = getenv("ADMM_HIP_OC_VERIFY"); c->oc_always_verify = ve && ve[0] == '1'; }   // A/B, tests: verify every pass (pcg_onchip2.hpp: kOc2TrustIters)
         c->oc_prof_block = pb ? atoi(pb) : 0;
         if (pe && pe[0] == '1') { if ((e = c->oc_prof.alloc(64 * 8)) != hipSuccess) return e; if ((e = c->oc_prof.zero()) != hipSuccess) return e; }
     }

@@ -769,6 +769,134 @@ def test_onchip_pcg_big_system_residual(big):
     assert np.abs(X - xt).max() < 1e-6
 
 
+def test_short_pass_needs_no_verification(monkeypatch):
+    """pcg_onchip2.hpp, kOc2TrustIters: a first pass that reaches a tolerance >= 1e-9 within 40 pipelined iterations is believed
+    without the verification exchange.  The iterate is the one the verified solve returns (the verification never changes
+    x), its TRUE residual -- formed here on the host -- meets the stop rule, and it agrees with the exact solve; cold and warm
+    starts, structured and unstructured mesh.  ADMM_HIP_OC_VERIFY=1 is the old behaviour."""
+    import scipy.sparse as sp
+    for sc in (scenes.blob_scene(44, admm_iters=5, linsolver=0), scenes.cube_scene(26, KINDS["neohookean"])):
+        o = sc.make_oracle(big=True)
+        rng = np.random.default_rng(4)
+        b = o.A @ rng.standard_normal(o.dof)
+        xe = o.solve_ldlt(b)
+        dinv = 1.0 / o.A.diagonal()
+        for start in (xe + 1e-4 * rng.standard_normal(o.dof), np.zeros(o.dof)):
+            res = {}
+            for verify in ("0", "1"):
+                monkeypatch.setenv("ADMM_HIP_OC_VERIFY", verify)
+                s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=600)
+                res[verify] = s.global_solve(b, start)
+                s.close()
+            monkeypatch.delenv("ADMM_HIP_OC_VERIFY")
+            (x0, it0), (x1, it1) = res["0"], res["1"]
+            assert it0 == it1 and 0 < it0 < 600
+            assert np.abs(x0 - x1).max() <= 1e-13 * np.abs(x1).max()      # (same iterate; the code generation of the two paths may differ in the last bit)
+            r = (b - o.A @ x0).reshape(-1, 3); B = b.reshape(-1, 3); D = dinv.reshape(-1, 3)
+            assert ((r ** 2 * D).sum(axis=0) <= 1.0001e-16 * (B ** 2 * D).sum(axis=0)).all()     # the true residual meets the rule
+            assert np.abs(x0 - xe).max() <= 1e-5 * np.abs(xe).max()       # (a residual of 1e-8 is an error of up to cond x 1e-8)
+
+
+# ---- configs[2] AS BENCHMARKED: the unstructured 1 M-tet body of bench.py (blob1m_mix, n = 118) at full size ----------------
+@pytest.fixture(scope="module")
+def big_blob():
+    import bench
+    n = int(os.environ.get("ADMM_TEST_BIG_BLOB_N", "118"))
+    sc, nt, nv = bench.build_scene(bench.WORKLOADS["blob1m_mix"], n)
+    if n == 118:
+        assert nt == 1012608 and nv == 183844
+    return sc
+
+
+def test_big_blob_rotation_is_a_fixed_point_of_the_prox(big_blob):
+    """The twin of test_big_rotation_is_a_fixed_point_of_the_prox on the mesh the driver benchmarks: F = R for every tet => z = R,
+    u = 0 and b = M x_bar + Ahat x -- SVD, prox, the block-level reduction of the corner forces (24 tets per vertex here), the
+    record gather and the host-assembled matrix on 1 012 608 unstructured tets."""
+    import scipy.sparse as sp
+    sc = big_blob
+    st = dict(sc.settings); sc.settings.update(admm_iters=3, gravity=0.0)
+    s = sc.make_solver(pcg_tol=1e-10, pcg_max_iters=60)
+    sc.settings.update(st)
+    Rm = np.linalg.qr(np.random.default_rng(15).standard_normal((3, 3)))[0]
+    if np.linalg.det(Rm) < 0:
+        Rm[:, 2] *= -1
+    x = (sc.x @ Rm.T + np.array([0.3, -0.2, 0.1])).ravel()
+    Mx = np.random.default_rng(16).standard_normal(x.size)
+    z, u, b = s.local_step(x, np.zeros(s.num_rows()), Mx)
+    nt = sum(len(t[1]) for t in sc.tets)
+    assert len(z) == 9 * nt + 6 * len(sc.pins)
+    Z = z[:9 * nt].reshape(-1, 3, 3).transpose(0, 2, 1)
+    assert np.abs(Z - Rm).max() < 1e-9
+    assert np.abs(u[:9 * nt]).max() < 1e-9
+    rp, ci, va = s.system_matrix()
+    nv = len(sc.x)
+    Ah = sp.csr_matrix((va, ci, rp), shape=(nv, nv))
+    # the pinned feet: their SpringPin terms pull towards the pin positions (z = pin, u = x - pin); the tet part must equal
+    # Ahat_tets x = (Ahat - w_pin^2 dt^2 on the pinned diagonal) x
+    pins = np.array(sorted(sc.pins), dtype=np.int64)
+    free = np.ones(nv, bool); free[pins] = False
+    Ax = (Ah @ x.reshape(-1, 3))
+    resid = (b - Mx).reshape(-1, 3) - Ax
+    assert np.abs(resid[free]).max() < 1e-9 * np.abs(Ax).max()
+    assert np.abs(Ax).max() > 1.0
+    s.close()
+
+
+def test_big_blob_bench_tolerance_vs_tight_solve(big_blob):
+    """The driver's workload, the driver's settings (pcg_tol 1e-8, recycled warm start, short passes unverified) against the
+    same path converged to 1e-12 and verified after every pass: <= 1e-5 of the bounding box (the north-star bar) after two frames."""
+    sc = big_blob
+    xs = []
+    for tol, mx, env in ((1e-12, 1500, "1"), (1e-8, 600, "0")):
+        os.environ["ADMM_HIP_OC_VERIFY"] = env
+        try:
+            s = sc.make_solver(pcg_tol=tol, pcg_max_iters=mx)
+        finally:
+            os.environ.pop("ADMM_HIP_OC_VERIFY", None)
+        for _ in range(2):
+            s.step()
+        assert s.runtime_data().unconverged_solves == 0
+        xs.append(s.m_x.copy()); s.close()
+    err = scenes.rel_err(xs[1], xs[0])
+    assert err < 1e-5, err
+    assert err < 3e-6, err          # measured ~1e-6
+    assert np.abs(xs[0] - sc.x.ravel()).max() > 1e-3
+
+
+def test_big_blob_onchip_pcg_residual_and_uzawa_frame(big_blob):
+    """(i) the returned x of a cold 1e-10 solve on the 183 844-vertex unstructured system satisfies the stop rule on the host-formed
+    true residual; (ii) configs[2] names UzawaCG: with no active constraints its solve IS the prefactored solve
+    (src/UzawaCG.hpp:78-81) -- one frame with linsolver 2 equals the frame with linsolver 0."""
+    import scipy.sparse as sp
+    sc = big_blob
+    s = sc.make_solver(pcg_tol=1e-10, pcg_max_iters=3000)
+    rp, ci, va = s.system_matrix()
+    nv = len(sc.x)
+    Ah = sp.csr_matrix((va, ci, rp), shape=(nv, nv))
+    m = np.asarray(s.m_masses).reshape(-1, 3)
+    xt = np.random.default_rng(18).standard_normal((nv, 3))
+    b = (m * xt + Ah @ xt).ravel()
+    x, it = s.global_solve(b, np.zeros(3 * nv))
+    assert 0 < it < 3000
+    X = x.reshape(-1, 3)
+    r = b.reshape(-1, 3) - (m * X + Ah @ X)
+    dinv = 1.0 / (m + Ah.diagonal()[:, None])
+    for j in range(3):
+        assert np.sum(r[:, j] ** 2 * dinv[:, j]) <= 1.05e-20 * np.sum(b.reshape(-1, 3)[:, j] ** 2 * dinv[:, j])
+    assert np.abs(X - xt).max() < 1e-6
+    s.close()
+    frames = []
+    for ls in (0, 2):
+        st = dict(sc.settings); sc.settings.update(linsolver=ls)
+        s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=600)
+        sc.settings.update(st)
+        s.step()
+        assert s.runtime_data().unconverged_solves == 0 or ls == 2
+        frames.append(s.m_x.copy()); s.close()
+    assert scenes.rel_err(frames[1], frames[0]) < 1e-9
+    assert np.abs(frames[0] - sc.x.ravel()).max() > 1e-4
+
+
 def test_onchip_pcg_1024_thread_variant_and_global_columns():
     """n = 60 Kuhn cube (226 981 vertices): 14 slices per CU -> the 1024-thread kernel variant, whose LDS slab
     holds only the first 8 of the 16 matrix columns (the rest is read from global memory every iteration).
