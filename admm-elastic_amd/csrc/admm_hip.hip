@@ -186,7 +186,8 @@ struct admm_hip_ctx {
     double oc_sm_ab = 0.0, oc_sm_b = 0.0, oc_lam_bb = 0.0;   // block-local smoother of k_pcg2 (pcg_onchip2.hpp: smooth)
     bool oc_plan = false, oc_coarse = false; int oc_rows = 0, oc_bcols = 0, oc_nc = 0, oc_ncp = 0, oc_veclen = 0;
     SellDev oc_A; DevBuf<int> oc_orig, oc_ldsoff, oc_wls, oc_haloptr, oc_halosrc; DevBuf<unsigned short> oc_col16;
-    DevBuf<double> oc_mdiag, oc_ainv, oc_cbuf;
+    DevBuf<double> oc_mdiag, oc_ainv, oc_cbuf; DevBuf<float> oc_cwt; bool oc_affine = false;
+    const double *create_xyz = nullptr;   // desc.vert_xyz, valid during admm_hip_create only (coarse space of the plan)
     int64_t oc_stat[6] = {0, 0, 0, 0, 0, 0};   // nnz, stored, on chip, block-local, max neighbour blocks, coarse unknowns
     // Recovery from a grid barrier that cannot complete (the persistent PCG kernel needs all its blocks resident at once:
     // another persistent kernel, a second context or CU masking can break that).  The state at the last point known to be
@@ -253,7 +254,7 @@ struct admm_hip_ctx {
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release();
         oc_A.release(); oc_orig.release(); oc_ldsoff.release(); oc_wls.release(); oc_haloptr.release(); oc_halosrc.release(); oc_col16.release();
-        oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release();
+        oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release(); oc_cwt.release();
         bk_x.release(); bk_v.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
@@ -422,6 +423,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.rc_on = rc.on ? 1 : 0; a.rc = rc.B; a.rc_xs = c->rc_xs.p; a.rc_r0 = c->rc_r0.p; a.rc_Eslot = rc.Eslot; a.rc_Rslot = rc.Rslot;
     a.rc_part = c->oc_rc_part.p;
     if (c->oc_coarse) { a.ainv = c->oc_ainv.p; a.cbuf = c->oc_cbuf.p; a.nc = c->oc_nc; a.ncp = c->oc_ncp; }
+    a.cwt = c->oc_cwt.p;
     a.skip = rc.skip;
     a.trust_short = c->oc_always_verify ? 0 : 1;
     a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b;
@@ -508,7 +510,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
         if (!(pe && pe[0] == '0') && c->oc_poly_m < 2) {
             std::vector<double> mass(c->n3);
             if ((e = hipMemcpy(mass.data(), c->m.p, mass.size() * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return e;
-            plan = admm_host::build_oc_plan(c->Ahat, mass.data(), G, spb, (int)lds_max - kOc2Scratch, !(ce && ce[0] == '0'));
+            plan = admm_host::build_oc_plan(c->Ahat, mass.data(), G, spb, (int)lds_max - kOc2Scratch, !(ce && ce[0] == '0'), c->create_xyz);
             if (plan.ok && plan.bcols >= 4) {
                 c->oc_plan = true;
                 c->oc_rows = plan.n_rows; c->oc_bcols = plan.bcols; c->oc_veclen = plan.vec_len;
@@ -530,6 +532,8 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
                 }
                 if ((e = c->oc_mdiag.upload(plan.mdiag)) != hipSuccess) return e;
                 c->oc_coarse = plan.coarse_ok && plan.nc <= 2 * T;
+                c->oc_affine = plan.affine;
+                if ((e = c->oc_cwt.upload(plan.cwt)) != hipSuccess) return e;
                 if (c->oc_coarse) {
                     c->oc_nc = plan.nc; c->oc_ncp = plan.ncp;
                     if ((e = c->oc_ainv.upload(plan.ainv)) != hipSuccess) return e;
@@ -1302,7 +1306,9 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->part.alloc(6 * (size_t)c->NB)); HIP_TRY(c->part_b.alloc(3 * (size_t)c->NB));
     HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
     HIP_TRY(c->counters.alloc(8 + 64 + 8)); HIP_TRY(c->counters.zero());   // [72..74]: totals since create (on-chip PCG)
+    c->create_xyz = d->vert_xyz;
     if (d->linsolver != 1) HIP_TRY(plan_pcg_onchip(c));
+    c->create_xyz = nullptr;
     if (d->linsolver != 1) {
         const char *env = getenv("ADMM_HIP_NO_RECYCLE");
         c->rc_enabled = !(env && env[0] == '1');
@@ -1976,7 +1982,7 @@ int admm_host_assemble_matrix(const admm_hip_desc *d, int32_t *rowptr, int32_t *
     return ADMM_HIP_OK;
 }
 int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int32_t lds_bytes, int32_t *row_vertex,
-                      int32_t *row_aggregate, double *coarse_inv, int64_t *stats) {
+                      int32_t *row_aggregate, double *coarse_inv, int64_t *stats, float *row_weights) {
     int rc = validate(d);
     if (rc) return rc;
     if (n_blocks < 1 || spb < 1 || spb > 16 || (int64_t)n_blocks * spb * 64 < d->n_verts) return fail(ADMM_HIP_ERR_ARG, "oc_plan: blocks x slices do not hold the vertices");
@@ -1987,9 +1993,10 @@ int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int
     const bool pins_as_terms = (d->linsolver == 0 || d->linsolver == 2);
     const admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
                                                       d->tri_idx, d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, pw);
-    const admm_host::OcPlan P = admm_host::build_oc_plan(A, d->masses, n_blocks, spb, lds_bytes, coarse_inv != nullptr);
+    const admm_host::OcPlan P = admm_host::build_oc_plan(A, d->masses, n_blocks, spb, lds_bytes, coarse_inv != nullptr, d->vert_xyz);
     if (!P.ok) return fail(ADMM_HIP_ERR_ARG, "oc_plan: a block does not fit its slots");
     if (row_vertex) std::copy(P.orig.begin(), P.orig.end(), row_vertex);
+    if (row_weights) std::copy(P.cwt.begin(), P.cwt.end(), row_weights);
     if (row_aggregate)
         for (int32_t r = 0; r < P.n_rows; ++r)
             row_aggregate[r] = P.orig[r] < 0 ? -1 : (r / (64 * spb)) * admm_host::kOcSub + P.row_agg[r];

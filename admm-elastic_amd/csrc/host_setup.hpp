@@ -118,12 +118,15 @@ struct OcPlan {
     int nc = 0, ncp = 0;                // coarse unknowns (G * kOcSub), padded row length of ainv
     bool coarse_ok = false;
     std::vector<double> ainv;           // [nc][ncp] (P^T A P)^-1
+    std::vector<float> cwt;             // [4 n_rows] row r of P: weights of the row in the kOcSub coarse functions of its block
+    bool affine = false;                // coarse functions {1, x, y, z} per block (coordinates given) instead of kOcSub constants
     double stat_bank_sorted = 0.0, stat_bank_placed = 0.0;   // lanes on the busiest LDS bank pair per (half wavefront, column): entries by index / as placed
     double lam_bb = 0.0;                // estimate of lambda_max(D^-1 A_bb), A_bb = the block-diagonal part of M + Ahat (power iteration)
     int64_t stat_nnz = 0, stat_stored = 0, stat_onchip = 0, stat_local = 0;
 };
 // A = Ahat (mass not included), mass3 [3 n]; lds_bytes = LDS one block may spend on its local vector and matrix slab
-OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_bytes, bool want_coarse);
+// xyz (optional, [3 n]): smooth vertex coordinates for the affine coarse space
+OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_bytes, bool want_coarse, const double *xyz = nullptr);
 
 // Hierarchical block order of mesh vertices (oc_plan.cpp): compact leaves of ~leaf vertices from a recursive graph
 // bisection, leaves in recursion-tree order, breadth-first inside a leaf.  new_id[v] = position of vertex v.

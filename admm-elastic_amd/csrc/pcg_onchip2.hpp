@@ -52,6 +52,8 @@ struct Oc2Args {
     double tol2;
     int rc_on; RcBasis rc; double *rc_xs, *rc_r0, *rc_Eslot, *rc_Rslot, *rc_part;   // recycled warm start (internal rows)
     const double *ainv; double *cbuf; int nc, ncp;   // two-level: [nc][ncp] coarse inverse, [2][3][ncp] published aggregate sums
+    const float *cwt;    // [n_rows][kOcSubK] row r of P: the row's weights in the coarse functions of its block (one-hot on its aggregate,
+                         // or (1, x, y, z) per block: oc_plan.cpp)
     int trust_short;     // 1: a short first pass needs no verification of its residual (see kOc2TrustIters)
     const int *skip;     // optional: *skip != 0 (set by an earlier kernel of the stream, e.g. UzawaCG's stop flag) makes the
                          // launch a no-op -- lets the host enqueue outer iterations ahead without synchronising
@@ -115,6 +117,20 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     const bool live = oa >= 0;
     const int vi = live ? (oa & 0x0fffffff) : 0;       // the vertex this row belongs to
     const int myagg = live ? (oa >> 28) & 3 : 0;
+    // (cvt_here: the float -> double conversion as a volatile instruction.  Left to the compiler it is hoisted out of the
+    // iteration loop, single-precision constants then occupy twice the registers in a loop that has none to spare, and most of
+    // them are spilled and come back from scratch memory every iteration.)
+    auto cvt_here = [](float f) -> double { double d; asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(d) : "v"(f)); return d; };
+    float cw[kOcSubK];   // this row of P (zero for dummy rows)
+    {
+        const float4 t = *(const float4 *)(a.cwt + 4 * (size_t)row);
+        cw[0] = t.x; cw[1] = t.y; cw[2] = t.z; cw[3] = t.w;
+    }
+    static_assert(kOcSubK == 4, "four coarse functions per block");
+    // (P y)_row for a [kOcSubK][3] coarse vector in LDS
+    auto prolong = [&](const double *y, int j) -> double {
+        return fma(cvt_here(cw[0]), y[j], fma(cvt_here(cw[1]), y[3 + j], fma(cvt_here(cw[2]), y[6 + j], cvt_here(cw[3]) * y[9 + j])));
+    };
     const int w = __builtin_amdgcn_readfirstlane(a.w[s]);
     const int base = __builtin_amdgcn_readfirstlane(a.ptr[s]);
     const int wl_s = __builtin_amdgcn_readfirstlane(a.wl_s[s]);
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                 if (f < 8) q8[i] = f < 7 ? q7[f < 7 ? f : 0] : 0.0;
                 else if (f < 8 + 3 * kOcSubK) {
                     const int ag = (f - 8) / 3, j = (f - 8) % 3;
-                    q8[i] = (with_v && ((opq(oa) >> 28) == ag)) ? v[j] : 0.0;      // (dummy rows: oa = -1, no aggregate; v = 0 there anyway)
+                    q8[i] = with_v ? cvt_here(cw[ag]) * v[j] : 0.0;                 // (P^T v)_(ag, j): this row's share
                 } else q8[i] = 0.0;
             }
         }, std::integral_constant<int, 3>());
@@ -331,10 +347,6 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     };
     // The rows of Ac^-1 of this block's aggregates, columns tid and tid + T: constant over the solve, fetched (L2) ahead
     // of the grid barrier so that their latency hides behind it
-    // (cvt_here: the float -> double conversion as a volatile instruction.  Left to the compiler it is hoisted out of the
-    // iteration loop, the eight rows then occupy SIXTEEN registers of a loop that has none to spare, and most of them are spilled
-    // and come back from scratch memory every iteration.)
-    auto cvt_here = [](float f) -> double { double d; asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(d) : "v"(f)); return d; };
     struct AinvRows { float v[2][kOcSubK]; };   // (a preconditioner: single precision, applied the same way every time, is exact enough)
     auto ainv_prefetch = [&](AinvRows &ar) {
         const int tid = otid();
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) return false;
         reduce_and_coarse(par, 0, ar);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) y[j] = live ? ycur[3 * myagg + j] : 0.0;     // (start of a pass only)
+        for (int j = 0; j < 3; ++j) y[j] = prolong(ycur, j);                     // (start of a pass only)
         return true;
     };
     int iters = 0, pipe_iters = 0;
@@ -678,7 +690,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                         double mm[3];
                         const int oa_ = opq(oa);
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) mm[j] = oa_ >= 0 ? sw[j] + (two_level ? yw[ywp + 3 * ((oa_ >> 28) & 3) + j] : 0.0) : 0.0;   // m = M^-1 w = S w + P Ac^-1 P^T w
+                        for (int j = 0; j < 3; ++j) mm[j] = oa_ >= 0 ? sw[j] + (two_level ? prolong(yw + ywp, j) : 0.0) : 0.0;   // m = M^-1 w = S w + P Ac^-1 P^T w
                         ++ph; publish(mm);
                     }
                     OC2_STAMP(1);
@@ -764,7 +776,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                         // (m is formed again from S w and y_w, bit for bit what was published, instead of being held across the
                         // exchange, the row loops and the reductions: 6 VGPRs; y_w is double-buffered by iteration parity so that
                         // its update by threads 0..11 below cannot overtake these reads)
-                        const double mmj = oa_ >= 0 ? sw[j] + (two_level ? yw[ywp + 3 * ((oa_ >> 28) & 3) + j] : 0.0) : 0.0;
+                        const double mmj = oa_ >= 0 ? sw[j] + (two_level ? prolong(yw + ywp, j) : 0.0) : 0.0;
                         rz[j] = fma(beta, rz[j], rn[j]);
                         sz[j] = fma(beta, sz[j], sn[j]);
                         sw[j] = fma(-alpha, sz[j], sw[j]);

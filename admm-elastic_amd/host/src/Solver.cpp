@@ -345,6 +345,7 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
     std::memset(&d, 0, sizeof(d));
     d.struct_size = sizeof(d); d.device = device;
     d.n_verts = dof / 3; d.masses = m_masses.data(); d.dt = m_settings.timestep_s;
+    d.vert_xyz = m_x.data();      // smooth coordinates for the coarse space of the on-chip PCG (the solve does not depend on them)
     flat.fill(d);
     // pins that are not energy terms (linsolver 1) go through the in-sweep pin list
     std::vector<int32_t> gs_v; std::vector<double> gs_p;

@@ -262,6 +262,8 @@ class Solver:
         d.tet_idx, d.tet_Binv, d.tet_weight = iptr(f["tet_idx"]), dptr(f["tet_Binv"]), dptr(f["tet_weight"])
         d.tet_kind, d.tet_mu, d.tet_lambda, d.tet_k = iptr(f["tet_kind"]), dptr(f["tet_mu"]), dptr(f["tet_lambda"]), dptr(f["tet_k"])
         d.tet_kappa = dptr(f["tet_kappa"]) if f["tet_kappa"].any() else None
+        self._xyz_c = f64(self.m_x).copy()           # smooth coordinates for the coarse space of the on-chip PCG (desc.vert_xyz)
+        d.vert_xyz = dptr(self._xyz_c) if self._xyz_c.size == dof else None
         d.n_tris = f["tri_idx"].shape[0]
         d.tri_idx, d.tri_rest, d.tri_weight = iptr(f["tri_idx"]), dptr(f["tri_rest"]), dptr(f["tri_weight"])
         d.tri_limit_min, d.tri_limit_max = dptr(f["tri_limit_min"]), dptr(f["tri_limit_max"])
@@ -298,11 +300,13 @@ class Solver:
         nc = 4 * n_blocks
         ci = np.zeros((nc, nc)) if coarse else None
         st = (C.c_int64 * 11)()
-        check(lib().admm_host_oc_plan(C.byref(d), n_blocks, slices_per_block, lds_bytes, iptr(rv), iptr(ra), dptr(ci) if coarse else None, st))
+        wt = np.zeros((n, 4), np.float32)
+        check(lib().admm_host_oc_plan(C.byref(d), n_blocks, slices_per_block, lds_bytes, iptr(rv), iptr(ra), dptr(ci) if coarse else None, st,
+                                      wt.ctypes.data_as(C.POINTER(C.c_float))))
         keys = ("nnz", "stored", "on_chip", "block_local", "max_neighbour_blocks", "coarse_unknowns", "max_halo", "lds_cols")
         stats = dict(zip(keys, list(st)[:8]))
         stats.update(lambda_bb=st[8] * 1e-9, bank_load_by_index=st[9] * 1e-6, bank_load_placed=st[10] * 1e-6)
-        return dict(row_vertex=rv, row_aggregate=ra, coarse_inv=ci, stats=stats)
+        return dict(row_vertex=rv, row_aggregate=ra, coarse_inv=ci, stats=stats, row_weights=wt)
 
     def initialize(self, settings=None):
         s = settings if settings is not None else Settings()

@@ -132,6 +132,76 @@ def cpu_baseline(w, budget_s=12.0):
                        "(L-BFGS, reference stop rule) + %s; host has %d hardware threads" % (nt, shape, n_s, iters, dt, solver, cores))
 
 
+CALIBRATION_FILE = os.path.join(ROOT, "profiles", "r03_cpu_calibration.json")
+
+
+def cpu_calibration(out_path=CALIBRATION_FILE):
+    """the oracle PORT (what `cpu_baseline` times on the GPU box, where /root/reference does not exist) against
+    the REAL reference code that compiles here (oracle/_ref: TriEnergyTerm.cpp + EnergyTerm::update, Eigen::SimplicialLDLT as
+    LDLTSolver uses it), same inputs, same host, same thread count -- so that "x the port" can be read as "x the reference".
+    Run in the build container (`python bench.py --calibrate-cpu-baseline`); the result is committed under profiles/ and quoted
+    by `cpu_baseline.calibration`.  The tet prox of the reference needs the absent mcloptlib and cannot be timed."""
+    import ctypes
+    import platform
+    from oracle import oracle as orc
+    import scenes
+    R = orc.ref_lib()
+    if R is None or not hasattr(R, "ref_time_tri_local_step"):
+        raise SystemExit("calibration needs oracle/_ref built from /root/reference (make -C oracle)")
+    L = orc.lib()
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except OSError:
+        pass
+    res = {"host": platform.processor() or platform.machine(), "hardware_threads": os.cpu_count(), "omp_threads": threads, "cases": []}
+    # (1) triangle local step: the cloth of configs[4] at 200 x 200 cells (80 000 triangles), strain limits on
+    sc = scenes.cloth_scene(200, limits=(0.95, 1.05), admm_iters=5, linsolver=0)
+    o = sc.make_oracle(mode=0, big=True)
+    verts, tris, lame, off = sc.tris[0]
+    rng = np.random.default_rng(0)
+    x = (sc.x + 0.01 * rng.standard_normal(sc.x.shape)).ravel()
+    idx = np.ascontiguousarray(tris, dtype=np.int32)
+    t_ref = R.ref_time_tri_local_step(len(idx), orc._i(idx), len(sc.x), orc._p(np.ascontiguousarray(verts, dtype=np.float64)),
+                                      lame.mu, lame.lambda_, lame.limit_min, lame.limit_max, orc._p(np.ascontiguousarray(x)), 5)
+    z = np.zeros(o.R); u = np.zeros(o.R)
+    t_port = 1e300
+    for _ in range(5):
+        t0 = time.perf_counter(); o.local_step(x, z, u); t_port = min(t_port, time.perf_counter() - t0)
+    res["cases"].append({"what": "triangle local step (TriEnergyTerm::update over all terms, src/Solver.cpp:84-87), %d triangles, strain limits 0.95/1.05" % len(idx),
+                         "reference_s": t_ref, "port_s": t_port, "reference_over_port": t_ref / t_port})
+    # (2) prefactored solve: the bench's CPU sample (48 000-tet cube, 27 783 dof) and the 105 456-tet cube of configs[1]
+    for n in (20, 26):
+        scn = scenes.cube_scene(n, pkg_kind("neohookean"), admm_iters=5, linsolver=0)
+        on = scn.make_oracle(mode=0, big=True)
+        Ah = on.A[0::3, :][:, 0::3].tocsr(); Ah.sort_indices()
+        m3 = np.ascontiguousarray(on.m)
+        Ahat = (Ah - __import__("scipy.sparse", fromlist=["diags"]).diags(m3[0::3])).tocsr(); Ahat.sort_indices()
+        b = np.ascontiguousarray(on.A @ rng.standard_normal(on.dof))
+        fs, ss = ctypes.c_double(0), ctypes.c_double(0)
+        rc = R.ref_time_ldlt(on.nv, orc._i(np.ascontiguousarray(Ahat.indptr, dtype=np.int32)), orc._i(np.ascontiguousarray(Ahat.indices, dtype=np.int32)),
+                             orc._p(np.ascontiguousarray(Ahat.data)), orc._p(m3), orc._p(b), 3, ctypes.byref(fs), ctypes.byref(ss))
+        assert rc == 0, rc
+        t_port = 1e300
+        for _ in range(3):
+            t0 = time.perf_counter(); on.solve_ldlt(b); t_port = min(t_port, time.perf_counter() - t0)
+        res["cases"].append({"what": "one prefactored solve (Eigen::SimplicialLDLT as LDLTSolver, src/LinearSolver.hpp:79-90, vs the port's SuperLU), Kuhn cube n=%d, %d dof" % (n, on.dof),
+                             "reference_s": ss.value, "reference_factor_s": fs.value, "port_s": t_port, "reference_over_port": ss.value / t_port})
+    res["summary"] = {"local_step_reference_over_port": res["cases"][0]["reference_over_port"],
+                      "solve_reference_over_port": res["cases"][1]["reference_over_port"],
+                      "note": "ratio > 1: the reference is slower than the port on this host, i.e. 'x the port' UNDERSTATES 'x the reference'; the "
+                              "reference's tet prox (mcloptlib L-BFGS, absent) is not timed -- the port runs the reference's stop rule with its own minimiser"}
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res["summary"]))
+    return res
+
+
+def pkg_kind(name):
+    import admm_elastic_amd as pkg
+    return {"neohookean": pkg.TET_NEOHOOKEAN, "linear": pkg.TET_LINEAR, "stvk": pkg.TET_STVK}[name]
+
+
 def pmc_traffic(workload, key="local_step_bytes_per_launch"):
     """HBM/fabric bytes per launch of the local-step kernels from the committed rocprofv3 PMC passes
     (profiles/*pmc*.json: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs; FETCH_SIZE doubled per
@@ -160,7 +230,11 @@ def main():
     ap.add_argument("--pcg-max-iters", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--calibrate-cpu-baseline", action="store_true", help="build container only: time the oracle port against the compiled reference pieces -> profiles/")
     args = ap.parse_args()
+    if args.calibrate_cpu_baseline:
+        cpu_calibration()
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks here, exactly as the driver's

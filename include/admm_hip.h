@@ -123,6 +123,14 @@ typedef struct {
      * xu::StVK / xu::CoRotated): [n_tets] or NULL (= 0 everywhere, what the reference's own SplineTet constructors pass,
      * src/TetEnergyTerm.hpp:194).  Read for the ADMM_TET_SPLINE_* kinds only. */
     const double *tet_kappa;
+
+    /* Optional [3 * n_verts]: any SMOOTH coordinates of the vertices -- Solver::m_x as it stands at Solver::initialize
+     * (src/Solver.cpp:167), which is what both host mirrors pass.  Used ONLY to build the coarse space of the on-chip PCG's
+     * two-level preconditioner: with coordinates every block carries the four functions {1, x, y, z} (the low-energy modes of
+     * the Laplacian-like Ahat) instead of four piecewise-constant aggregates -- same 4 unknowns per block, the smooth error
+     * modes that dominate the POSITION error of an iterate are represented to second order.  NULL = piecewise constants.
+     * The solution of the system does not depend on it (a preconditioner). */
+    const double *vert_xyz;
 } admm_hip_desc;
 
 /* Maps 1:1 onto Solver::RuntimeData (src/Solver.hpp:54-61) plus GPU-side extras. */
@@ -277,14 +285,16 @@ void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners,
  * caller's numbering is kept at the API): n_blocks compact blocks (one per CU) of slices_per_block wavefronts, every block
  * split into 4 compact aggregates that carry the coarse space of the two-level preconditioner
  * M^-1 = D^-1 + P (P^T A P)^-1 P^T.  row_vertex [64 * n_blocks * slices_per_block]: vertex of every internal row (-1 =
- * unused slot); row_aggregate (same length): coarse unknown of the row (block * 4 + aggregate); coarse_inv [nc * nc], nc =
+ * unused slot); row_aggregate (same length): coarse unknown of the row (block * 4 + aggregate); row_weights (NULL to skip)
+ * [4 * rows]: the row's weights in the four coarse functions of its block, i.e. row r of P -- one-hot on the aggregate
+ * without desc.vert_xyz, (1, x, y, z) centred and scaled per block with it; coarse_inv [nc * nc], nc =
  * 4 * n_blocks: (P^T A P)^-1, row-major (NULL to skip); stats [11]: off-diagonal non-zeros, stored SELL entries, entries
  * held in LDS, block-local non-zeros, most neighbour blocks of a block (-1: more than 64), coarse unknowns (0 = two-level
  * off), largest halo list, LDS slab columns used, 1e9 x the estimate of lambda_max(D^-1 A_bb) the block-local smoother is built
  * on (A_bb = entries of M + Ahat inside one block), 1e6 x the lanes on the busiest LDS bank pair per half-wavefront column with the
  * entries in index order / as placed.  lds_bytes = LDS a block may spend on its local vector and matrix slab. */
 int admm_host_oc_plan(const admm_hip_desc *desc, int32_t n_blocks, int32_t slices_per_block, int32_t lds_bytes,
-                      int32_t *row_vertex, int32_t *row_aggregate, double *coarse_inv, int64_t *stats);
+                      int32_t *row_vertex, int32_t *row_aggregate, double *coarse_inv, int64_t *stats, float *row_weights);
 
 /* Mesh preprocessing, second ordering (no counterpart in the reference): hierarchical BLOCK order.  The vertices are split
  * into compact leaves of about `leaf` vertices by recursive graph bisection (the method the on-chip PCG uses for its blocks),

@@ -113,6 +113,11 @@ def ref_lib():
     L.ref_ldlt_solve.argtypes = [C.c_int, ip, ip, dp, C.c_int, dp, dp]
     L.ref_ldlt_solve.restype = C.c_int
     L.ref_xu_spline.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp]
+    if hasattr(L, "ref_time_tri_local_step"):      # (a prebuilt library of an earlier round has no timing entry points)
+        L.ref_time_tri_local_step.argtypes = [C.c_int, ip, C.c_int, dp, C.c_double, C.c_double, C.c_double, C.c_double, dp, C.c_int]
+        L.ref_time_tri_local_step.restype = C.c_double
+        L.ref_time_ldlt.argtypes = [C.c_int, ip, ip, dp, dp, dp, C.c_int, dp, dp]
+        L.ref_time_ldlt.restype = C.c_int
     return L
 
 

@@ -23,6 +23,7 @@
 #include <vector>
 #include <memory>
 #include <cstring>
+#include <chrono>
 #include <stdexcept>
 #include <Eigen/Dense>
 #include <Eigen/Sparse>
@@ -169,6 +170,62 @@ int ref_ldlt_solve(int n, const int *rp, const int *ci, const double *val, int n
         xo = xx;
     }
     return 0;
+}
+
+// ---- timing of the real reference pieces (bench.py --calibrate-cpu-baseline: SURVEY 8d (ii), the oracle port's times are
+// cross-calibrated against the reference code that compiles here).  Same loops as above, the set-up outside the clock. ----
+// The reference's local loop over triangle terms (src/Solver.cpp:84-87: `for energyterms: update(D, x, z, u)`; its `omp parallel for`
+// is kept, threads = OMP_NUM_THREADS): seconds per pass over all terms, best of `reps`.
+double ref_time_tri_local_step(int n_tris, const int *inds, int nv, const double *verts_rest, double mu, double lambda,
+                               double limit_min, double limit_max, const double *x_in, int reps) {
+    try {
+        admm::Lame lame; lame.mu = mu; lame.lambda = lambda; lame.limit_min = limit_min; lame.limit_max = limit_max;
+        std::vector<std::shared_ptr<admm::EnergyTerm> > terms;
+        admm::create_tris_from_mesh<double, admm::TriEnergyTerm>(terms, verts_rest, inds, n_tris, lame, 0);
+        std::vector<Triplet<double> > trips; std::vector<double> w;
+        for (size_t i = 0; i < terms.size(); ++i) terms[i]->get_reduction(trips, w);
+        SparseMat D(w.size(), nv * 3);
+        D.setFromTriplets(trips.begin(), trips.end());
+        VecX x = Map<const VecX>(x_in, nv * 3);
+        VecX zz = VecX::Zero(w.size()), uu = VecX::Zero(w.size());
+        const int n = (int)terms.size();
+        double best = 1e300;
+        for (int r = 0; r < reps; ++r) {
+            const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for
+            for (int i = 0; i < n; ++i) terms[i]->update(D, x, zz, uu);
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt < best) best = dt;
+        }
+        return best;
+    } catch (std::exception &e) { return -1.0; }
+}
+// LDLTSolver::update_system + solve (src/LinearSolver.hpp:79-90) on the dof x dof matrix A = diag(m) + Ahat (x) I3 the reference
+// factors (Ahat given in CSR, masses per dof): seconds of the factorisation and of one solve (best of `reps`).
+int ref_time_ldlt(int nv, const int *rp, const int *ci, const double *val, const double *mass3, const double *b3, int reps,
+                  double *factor_s, double *solve_s) {
+    const int n = 3 * nv;
+    std::vector<Triplet<double> > trips;
+    for (int i = 0; i < nv; ++i)
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+            for (int j = 0; j < 3; ++j) trips.emplace_back(3 * i + j, 3 * ci[k] + j, val[k] + (ci[k] == i ? mass3[3 * i + j] : 0.0));
+    SparseMat A(n, n);
+    A.setFromTriplets(trips.begin(), trips.end());
+    SimplicialLDLT<SparseMatrix<double> > chol;
+    auto t0 = std::chrono::steady_clock::now();
+    chol.compute(A);
+    *factor_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (chol.info() != Success) return -1;
+    VecX bb = Map<const VecX>(b3, n), xx(n);
+    double best = 1e300;
+    for (int r = 0; r < reps; ++r) {
+        t0 = std::chrono::steady_clock::now();
+        xx = chol.solve(bb);
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dt < best) best = dt;
+    }
+    *solve_s = best;
+    return xx.allFinite() ? 0 : -2;
 }
 
 // xu splines: which 0 NeoHookean, 1 StVK, 2 CoRotated; out = f,g,h,df,dg,dh at x
