@@ -111,6 +111,7 @@ struct admm_hip_ctx {
     DevBuf<signed char> oc_color; bool oc_bssor = false;             // block-local symmetric GS preconditioner (2-colourable Ahat)
     DevBuf<unsigned long long> lk_ts, lk_out; int lk_tsn = 0, lk_launch = 0, lk_cap = 0; double lk_tick_ms = 0.0;
     std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration (+1) when stats are requested
+    bool lt_on = false; std::vector<hipEvent_t> lt_ev; size_t lt_used = 0;   // admm_hip_time_local_launches: event pairs of the lean steps
 
     int nv = 0, n3 = 0;
     double dt = 1.0 / 24.0;
@@ -264,6 +265,7 @@ struct admm_hip_ctx {
         lk_ts.release(); lk_out.release(); oc_color.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
+        for (hipEvent_t e : lt_ev) (void)hipEventDestroy(e);
         if (gs_exec) (void)hipGraphExecDestroy(gs_exec);
         if (h_sig) (void)hipHostFree(h_sig);
         if (ev_coll0) (void)hipEventDestroy(ev_coll0);
@@ -1669,7 +1671,13 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     if (c->npin_terms) HIP_TRY(hipMemsetAsync(c->pin_u.p, 0, c->pin_u.n * sizeof(double), st));
     for (int s = 0; s < admm_iters; ++s) {
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s], st));
+        const bool lt = !timed && c->lt_on;
+        if (lt) {
+            while (c->lt_ev.size() < c->lt_used + 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->lt_ev.push_back(e); }
+            HIP_TRY(hipEventRecord(c->lt_ev[c->lt_used], st));
+        }
         launch_local<false>(c);                 // Solver.cpp:84-87
+        if (lt) { HIP_TRY(hipEventRecord(c->lt_ev[c->lt_used + 1], st)); c->lt_used += 2; }
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 1], st));
         // passive collisions are resolved inside the GS sweeps (linsolver 1, Solver.cpp:76)
         if (int rr = launch_rhs(c))             // Solver.cpp:98
@@ -1916,6 +1924,28 @@ int admm_hip_probe_sync(admm_hip_ctx *c, int32_t n, double *us_all_to_all, doubl
     if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "probe_sync: a grid barrier timed out"); }
     if (us_all_to_all) *us_all_to_all = out[0];
     if (us_exchange) *us_exchange = out[1];
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_time_local_launches(admm_hip_ctx *c, int32_t on) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "time_local_launches: NULL context");
+    c->lt_on = on != 0;
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_local_launch_times(admm_hip_ctx *c, int64_t *n_pairs, double *sum_ms) {
+    if (!c || !n_pairs || !sum_ms) return fail(ADMM_HIP_ERR_ARG, "local_launch_times: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = settle(c)) return rc;
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < c->lt_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->lt_ev[i], c->lt_ev[i + 1]));
+        sum += ms;
+    }
+    *n_pairs = (int64_t)(c->lt_used / 2); *sum_ms = sum;
+    c->lt_used = 0;
     return ADMM_HIP_OK;
 }
 

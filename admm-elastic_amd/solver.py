@@ -391,6 +391,18 @@ class Solver:
         keys = ("nnz", "stored", "on_chip", "block_local", "max_neighbour_blocks", "coarse_unknowns")
         return a.value, b.value, dict(zip(keys, list(st)))
 
+    def time_local_launches(self, on=True):
+        """admm_hip_time_local_launches: event pairs around the local-step launches of the steps issued without statistics."""
+        self._need_ctx()
+        check(lib().admm_hip_time_local_launches(self._ctx, 1 if on else 0))
+
+    def local_launch_times(self):
+        """admm_hip_local_launch_times: (pairs recorded since the last call, sum of their intervals in ms)."""
+        self._need_ctx()
+        n = C.c_int64(0); ms = C.c_double(0.0)
+        check(lib().admm_hip_local_launch_times(self._ctx, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def runtime_data(self):
         return self._runtime
 

@@ -189,7 +189,7 @@ def cpu_calibration(out_path=CALIBRATION_FILE):
                              "reference_s": ss.value, "reference_factor_s": fs.value, "port_s": t_port, "reference_over_port": ss.value / t_port})
     res["summary"] = {"local_step_reference_over_port": res["cases"][0]["reference_over_port"],
                       "solve_reference_over_port": res["cases"][1]["reference_over_port"],
-                      "note": "ratio > 1: the reference is slower than the port on this host, i.e. 'x the port' UNDERSTATES 'x the reference'; the "
+                      "note": "reference_over_port = time of the REAL reference code / time of the oracle port, same inputs, host, threads.  < 1: the reference is FASTER than the port, so x-the-port OVERSTATES x-the-reference by 1 / ratio; the "
                               "reference's tet prox (mcloptlib L-BFGS, absent) is not timed -- the port runs the reference's stop rule with its own minimiser"}
     with open(out_path, "w") as f:
         json.dump(res, f, indent=1)
@@ -288,6 +288,10 @@ def main():
     inner = unconv = 0
     tot0 = s.solve_totals() if w["linsolver"] == 0 else (-1, -1, -1)
     lean = tot0[0] >= 0
+    lt_pairs, lt_ms = 0, 0.0       # the local-step launches of the TIMED region: event pairs, read after it
+    if lean:
+        s.time_local_launches(True)
+        s.local_launch_times()     # (clears what the warm-up recorded)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         s.step_device(stats=not lean)
@@ -298,16 +302,23 @@ def main():
             unconv += rd.unconverged_solves
     sync()
     elapsed = time.perf_counter() - t0
+    stats_elapsed = elapsed
     if lean:
+        lt_pairs, lt_ms = s.local_launch_times()
+        s.time_local_launches(False)
         tot1 = s.solve_totals()
         unconv = (tot1[0] - tot0[0]) - (tot1[1] - tot0[1])
         assert tot1[0] - tot0[0] == iters * args.steps, (tot0, tot1)
+        t1s = time.perf_counter()
         for _ in range(args.steps):
             s.step_device(stats=True)
             rd = s.runtime_data()
             local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms; inner += rd.inner_iters
             lk_ms += rd.local_kernel_ms
         sync()
+        stats_elapsed = time.perf_counter() - t1s
+    else:
+        lt_pairs, lt_ms = iters * args.steps, local_ms
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -340,7 +351,10 @@ def main():
         "split_ms_per_admm_iter": {"local": local_ms / (iters * args.steps), "rhs": rhs_ms / (iters * args.steps),
                                    "global": global_ms / (iters * args.steps)},
         "inner_iters_per_admm_iter": inner / (iters * args.steps), "unconverged_solves_in_timed_region": unconv,
-        "timed_region": "frames issued without per-step statistics; split / iteration counts from as many frames with statistics right after" if lean else "frames with per-step statistics",
+        "timed_region": ("frames issued without per-step statistics (one hipEvent pair around every local-step launch is the only instrumentation: "
+                         "`roofline`); split / iteration counts from as many STATISTICS FRAMES right after, which take %.3f x the time of the timed ones "
+                         "(`stats_frames_ms_per_step`)" % (stats_elapsed / elapsed)) if lean else "frames with per-step statistics",
+        "stats_frames_ms_per_step": 1e3 * stats_elapsed / max(args.steps, 1),
         # mean time of one inner (PCG / GS) iteration incl. the per-solve overheads: (global - rhs) / inner iterations.
         # The PCG kernel keeps matrix and vectors on chip; its iteration is bound by one grid barrier, not by HBM.
         "us_per_inner_iter": 1e3 * (global_ms - rhs_ms) / max(inner, 1),
@@ -362,6 +376,8 @@ def main():
             solve_us = 1e3 * (global_ms - rhs_ms) / max(n_solves, 1)
             us_it = solve_us / max(it_per_solve, 1e-9)
             out["roofline_global"] = {
+                "role": "TIME-DOMINANT kernel: %.0f %% of a statistics frame" % (100.0 * (global_ms - rhs_ms) / max(local_ms + global_ms, 1e-30)),
+                "measured_in": "statistics frames (event pairs between the phases), not the timed region",
                 "kernel": "k_pcg2 (whole two-level PCG solve, one persistent launch per ADMM iteration)",
                 "bound": "synchronisation latency (grid barrier + neighbour exchange); data on chip",
                 "iterations_per_solve": it_per_solve, "solve_us": solve_us, "us_per_iteration_incl_solve_overhead": us_it,
@@ -370,9 +386,10 @@ def main():
                 "plan": pst, "pmc_bytes_per_iteration": pmc_traffic(args.workload, "pcg_bytes_per_iteration"),
             }
         if not args.no_roofline:
-            # dominant single kernel = the per-tet prox kernel (local step).  ALGORITHMIC bytes per tet per
-            # ADMM iteration: 16 idx + 72 Binv + 72 u read + 72 u write + 72 z write + 24 nv/nt.
-            launches = iters * args.steps
+            # The HBM-bound kernel the north-star names: the per-tet prox kernel (local step) -- second by time behind the
+            # persistent PCG launch (`roofline_global`).  ALGORITHMIC bytes per tet per ADMM iteration: 16 idx +
+            # 72 Binv + 72 u read + 72 u write + 72 z write + 24 nv/nt.
+            launches = max(lt_pairs, 1)
             # (with N ranks, rank 0 times its own element block: nt / N elements per launch)
             bytes_per_launch = ((188.0 if w["kinds"] == "cloth" else 304.0) + 24.0 * nv / nt) * nt / world
             # Duration of one launch, measured live in the timed region on the context's own stream, three ways that bracket
@@ -382,16 +399,26 @@ def main():
             # cost the launch ~2 %): every wave stamps the device wall clock at entry and exit -- max exit - min entry is
             # another 2-3 us shorter than rocprofv3 (it misses the dispatch ramp-up, the drain of the last stores and the
             # end-of-kernel cache release).
-            avg_s = 1e-3 * local_ms / launches
+            avg_s = 1e-3 * lt_ms / launches
             achieved = bytes_per_launch / avg_s / 1e9
-            out["roofline"] = {"kernel": "k_local_tris" if w["kinds"] == "cloth" else "k_local_tets (all constitutive models of one ADMM iteration)", "bound": "hbm",
+            out["roofline"] = {"role": "the HBM-bound kernel the north-star names (local step): %.0f %% of a statistics frame, second by time behind `roofline_global`"
+                                       % (100.0 * local_ms / max(local_ms + global_ms, 1e-30)),
+                               "measured_in": ("the TIMED region: %d hipEvent pairs, one around every local-step launch" % lt_pairs) if lean else "the timed region (statistics frames)",
+                               "kernel": "k_local_tris" if w["kinds"] == "cloth" else "k_local_tets (all constitutive models of one ADMM iteration)", "bound": "hbm",
                                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": pmc_traffic(args.workload), "avg_launch_us": 1e6 * avg_s,
                                "timing": "hipEventRecord pair around the launch, context stream",
-                               "kernel_us_device_clock": (1e3 * lk_ms / launches) if lk_ms > 0 else None,
+                               "kernel_us_device_clock": (1e3 * lk_ms / (iters * args.steps)) if lk_ms > 0 else None,
+                               "avg_launch_us_statistics_frames": 1e3 * local_ms / (iters * args.steps) if lean else None,
                                "algorithmic_bytes_per_launch": bytes_per_launch}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
+            try:    # the port against the real reference pieces, measured in the build container (bench.py --calibrate-cpu-baseline)
+                cal = json.load(open(CALIBRATION_FILE))
+                out["cpu_baseline"]["calibration"] = dict(cal["summary"], file=os.path.relpath(CALIBRATION_FILE, ROOT), host=cal.get("host"),
+                                                          omp_threads=cal.get("omp_threads"))
+            except Exception:
+                out["cpu_baseline"]["calibration"] = None
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

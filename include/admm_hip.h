@@ -236,6 +236,14 @@ int admm_hip_solve_totals(admm_hip_ctx *ctx, int64_t *solves, int64_t *converged
  * LDS, block-local non-zeros, most neighbour blocks of a block, coarse unknowns of the two-level preconditioner. */
 int admm_hip_probe_sync(admm_hip_ctx *ctx, int32_t n, double *us_all_to_all, double *us_exchange, int64_t *plan_stats);
 
+/* Measurement only (bench.py `roofline`; no counterpart in the reference, whose MicroTimer brackets the whole local loop,
+ * src/Solver.cpp:83-88).  on = 1: every later admm_hip_step WITHOUT statistics records a hipEvent pair around the launches of
+ * its local step (all constitutive models of one ADMM iteration) on the context's stream -- nothing else changes, no
+ * synchronisation is added.  admm_hip_local_launch_times synchronises the stream and returns the number of pairs recorded since
+ * the last call and the sum of their intervals in milliseconds (kernel + the two dispatch gaps of the pair). */
+int admm_hip_time_local_launches(admm_hip_ctx *ctx, int32_t on);
+int admm_hip_local_launch_times(admm_hip_ctx *ctx, int64_t *n_pairs, double *sum_ms);
+
 /* Sizes: R = rows of D (9*n_tets + 6*n_tris + 6*n_pin_terms). */
 int admm_hip_num_rows(const admm_hip_ctx *ctx);
 
