@@ -88,6 +88,7 @@ SYMBOLS = [
     ("admm_hip_comm_init", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     ("admm_host_assemble_matrix", C.c_int, [C.POINTER(Desc), c_int_p, c_int_p, c_double_p, c_int_p]),
     ("admm_host_partition", None, [C.c_int32, C.c_int, C.c_int, c_int_p, c_int_p]),
+    ("admm_host_component_partition", C.c_int32, [C.POINTER(Desc), C.c_int, c_int_p]),
     ("admm_host_tet_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_tri_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),

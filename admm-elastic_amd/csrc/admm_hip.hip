@@ -128,6 +128,13 @@ struct admm_hip_ctx {
     int nt_total = 0, ntri_total = 0; // element counts of the whole scene (row layout of z/u)
     int tri_begin = 0;                // first triangle owned by this rank
 
+    // COMPONENT-AWARE partition (admm_hip_create with world_size > 1 on a scene of >= world_size connected components, SURVEY 8e
+    // "element / vertex blocks" taken at the one place a mesh cuts for free): this context then holds ONLY the bodies assigned to
+    // its rank, renumbered locally, and steps them like a single-GPU scene -- no exchange inside a step, the solve is the block
+    // of the block-diagonal Ahat that belongs to these bodies.  The caller's arrays keep the GLOBAL numbering; admm_hip_get_state
+    // merges the ranks' parts over RCCL when a communicator was given (cm_comm; never used inside a step).
+    struct CompMode { bool on = false; int rank = 0, world = 1; int nv_global = 0, n_components = 0; std::vector<int32_t> l2g, g2l; } cm;
+    ncclComm_t cm_comm = nullptr; DevBuf<double> cm_buf;
     // node vectors
     DevBuf<double> x, v, m, Mxbar, curr, b, dinv;
     // tets (sorted by constitutive model; perm[new] = caller's index)
@@ -244,6 +251,8 @@ struct admm_hip_ctx {
     ~admm_hip_ctx() {
         (void)hipSetDevice(device);
         if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+        if (cm_comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(cm_comm);
+        cm_buf.release();
         x.release(); v.release(); m.release(); Mxbar.release(); curr.release(); b.release(); dinv.release();
         t_idx.release(); t_Binv.release(); t_u.release(); t_z.release(); t_sc.release(); t_rec.release(); ch_ent.release(); ch_group.release(); ch_rec.release();
         t_mat.release(); mats.release(); t_inc.release(); g_order.release();
@@ -548,7 +557,10 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
                     c->oc_sm_ab = 0.0; c->oc_sm_b = 0.0; c->oc_lam_bb = plan.lam_bb;
                     if (!(ch && ch[0] == '0') && plan.lam_bb > 0.0) {
                         const double ratio = cr ? std::max(1.5, atof(cr)) : 16.0;
-                        const double hi = 1.1 * plan.lam_bb, lo = hi / ratio, th = 0.5 * (hi + lo), de = 0.5 * (hi - lo);
+                        // upper end of the interval: the plan's estimate of lambda_max(D^-1 A_bb) (power iterations from three
+                        // starts, run until they stagnate) + 10 %, never above the plan's rigorous Gershgorin bound; the polynomial
+                        // stays positive up to 1.125 x this value
+                        const double hi = std::min(1.1 * plan.lam_bb, std::max(plan.lam_bb_gersh, 1.0)), lo = hi / ratio, th = 0.5 * (hi + lo), de = 0.5 * (hi - lo);
                         const double sg = th / de, r0 = 1.0 / sg, r1 = 1.0 / (2.0 * sg - r0);
                         const double al = (1.0 + r1 * r0) / th + 2.0 * r1 / de, be = 2.0 * r1 / (de * th);
                         c->oc_sm_ab = al - be; c->oc_sm_b = be;
@@ -571,8 +583,9 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_sync_probe<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T > 768 && (e = hipFuncSetAttribute((const void *)k_sync_probe<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    int per_cu = 0;
-    if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
+    int per_cu = 0;     // (the kernel that will actually be launched with this LDS size)
+    if (c->oc_plan) e = T <= 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<768>, T, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<1024>, T, lds);
+    else if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
     else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<1024>, T, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1 || G > cus) return hipSuccess; // one block per CU keeps every block resident whatever the LDS split
@@ -794,6 +807,10 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     const int *stop_flag = &c->uz_scal.p->stop;
     int launched = 0;
     int chunk = std::max(1, std::min(c->uz_max_iters, c->uz_prev_iters > 0 ? c->uz_prev_iters + 1 : 4));
+    // Only the general-mesh persistent kernel (k_pcg2) honours the device-side stop flag; on the other inner-solve paths (launch
+    // per iteration, round-1 kernel) an iteration enqueued behind the stop would run a full dead solve: one at a time there.
+    const bool skip_honoured = c->oc_enabled && c->oc_plan;
+    if (!skip_honoured) chunk = 1;
     while (launched < c->uz_max_iters) {
         const int n = std::min(chunk, c->uz_max_iters - launched);
         for (int it = 0; it < n; ++it) {
@@ -813,7 +830,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
         if (hipMemcpyAsync(&h, c->uz_scal.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         if (h.stop) break;
-        chunk = 2;
+        chunk = skip_honoured ? 2 : 1;
     }
     c->uz_prev_iters = h.iters;
     *iters = h.iters;
@@ -1072,7 +1089,70 @@ int admm_hip_device_count(void) {
     return n;
 }
 
+static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out);
+
+// world_size > 1: whole bodies per rank when the scene has enough of them (see admm_hip_ctx::CompMode), element blocks otherwise
+// (ADMM_HIP_PARTITION=elements forces the latter; =components insists on the former and fails if the scene does not split).
 int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
+    if (!out) return fail(ADMM_HIP_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (int rc = validate(d)) return rc;
+    const char *pm = getenv("ADMM_HIP_PARTITION");
+    const bool force_el = pm && !strcmp(pm, "elements"), force_co = pm && !strcmp(pm, "components");
+    if (d->world_size <= 1 || force_el) return create_impl(d, out);
+    const int world = d->world_size, rank = d->rank, nv = d->n_verts;
+    std::vector<int32_t> vrank(nv);
+    const int32_t ncomp = admm_host::component_partition(nv, d->n_tets, d->tet_idx, d->n_tris, d->tri_idx, world, vrank.data());
+    if (ncomp < world) {
+        if (force_co) return fail(ADMM_HIP_ERR_ARG, "ADMM_HIP_PARTITION=components: the scene has fewer connected components than ranks");
+        return create_impl(d, out);
+    }
+    // ---- the sub-scene of this rank, locally numbered ----
+    std::vector<int32_t> l2g, g2l(nv, -1);
+    for (int32_t v = 0; v < nv; ++v) if (vrank[v] == rank) { g2l[v] = (int32_t)l2g.size(); l2g.push_back(v); }
+    const int32_t nl = (int32_t)l2g.size();
+    std::vector<double> masses(3 * (size_t)nl), xyz;
+    for (int32_t i = 0; i < nl; ++i) for (int j = 0; j < 3; ++j) masses[3 * (size_t)i + j] = d->masses[3 * (size_t)l2g[i] + j];
+    if (d->vert_xyz) { xyz.resize(3 * (size_t)nl); for (int32_t i = 0; i < nl; ++i) for (int j = 0; j < 3; ++j) xyz[3 * (size_t)i + j] = d->vert_xyz[3 * (size_t)l2g[i] + j]; }
+    std::vector<int32_t> t_idx, t_kind, r_idx, p_vert, p_act, colors;
+    std::vector<double> t_Binv, t_w, t_mu, t_la, t_k, t_kap, r_rest, r_w, r_lmin, r_lmax, p_xyz;
+    for (int32_t t = 0; t < d->n_tets; ++t) {
+        if (vrank[d->tet_idx[4 * (size_t)t]] != rank) continue;
+        for (int k = 0; k < 4; ++k) t_idx.push_back(g2l[d->tet_idx[4 * (size_t)t + k]]);
+        for (int k = 0; k < 9; ++k) t_Binv.push_back(d->tet_Binv[9 * (size_t)t + k]);
+        t_w.push_back(d->tet_weight[t]); t_kind.push_back(d->tet_kind[t]); t_mu.push_back(d->tet_mu[t]); t_la.push_back(d->tet_lambda[t]); t_k.push_back(d->tet_k[t]);
+        if (d->tet_kappa) t_kap.push_back(d->tet_kappa[t]);
+    }
+    for (int32_t t = 0; t < d->n_tris; ++t) {
+        if (vrank[d->tri_idx[3 * (size_t)t]] != rank) continue;
+        for (int k = 0; k < 3; ++k) r_idx.push_back(g2l[d->tri_idx[3 * (size_t)t + k]]);
+        for (int k = 0; k < 4; ++k) r_rest.push_back(d->tri_rest[4 * (size_t)t + k]);
+        r_w.push_back(d->tri_weight[t]); r_lmin.push_back(d->tri_limit_min[t]); r_lmax.push_back(d->tri_limit_max[t]);
+    }
+    for (int32_t p = 0; p < d->n_pins; ++p) {
+        if (vrank[d->pin_vert[p]] != rank) continue;
+        p_vert.push_back(g2l[d->pin_vert[p]]);
+        for (int j = 0; j < 3; ++j) p_xyz.push_back(d->pin_xyz[3 * (size_t)p + j]);
+        if (d->pin_active) p_act.push_back(d->pin_active[p]);
+    }
+    if (d->gs_colors) { colors.resize(nl); for (int32_t i = 0; i < nl; ++i) colors[i] = d->gs_colors[l2g[i]]; }
+    admm_hip_desc sub = *d;
+    sub.n_verts = nl; sub.masses = masses.data(); sub.vert_xyz = d->vert_xyz ? xyz.data() : nullptr;
+    sub.n_tets = (int32_t)t_w.size(); sub.tet_idx = t_idx.data(); sub.tet_Binv = t_Binv.data(); sub.tet_weight = t_w.data(); sub.tet_kind = t_kind.data();
+    sub.tet_mu = t_mu.data(); sub.tet_lambda = t_la.data(); sub.tet_k = t_k.data(); sub.tet_kappa = d->tet_kappa ? t_kap.data() : nullptr;
+    sub.n_tris = (int32_t)r_w.size(); sub.tri_idx = r_idx.data(); sub.tri_rest = r_rest.data(); sub.tri_weight = r_w.data();
+    sub.tri_limit_min = r_lmin.data(); sub.tri_limit_max = r_lmax.data();
+    sub.n_pins = (int32_t)p_vert.size(); sub.pin_vert = p_vert.data(); sub.pin_xyz = p_xyz.data(); sub.pin_active = d->pin_active ? p_act.data() : nullptr;
+    sub.gs_colors = d->gs_colors ? colors.data() : nullptr;
+    sub.rank = 0; sub.world_size = 0;
+    if (int rc = create_impl(&sub, out)) return rc;
+    admm_hip_ctx *c = *out;
+    c->cm.on = true; c->cm.rank = rank; c->cm.world = world; c->cm.nv_global = nv; c->cm.n_components = ncomp;
+    c->cm.l2g = std::move(l2g); c->cm.g2l = std::move(g2l);
+    return ADMM_HIP_OK;
+}
+
+static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     if (!out) return fail(ADMM_HIP_ERR_ARG, "out is NULL");
     *out = nullptr;
     int rc = validate(d);
@@ -1387,7 +1467,49 @@ void admm_hip_destroy(admm_hip_ctx *ctx) { delete ctx; }
 
 int admm_hip_num_rows(const admm_hip_ctx *c) { return c ? 9 * c->nt_total + 6 * c->ntri_total + 6 * c->npin_terms : 0; }
 
+static int set_state_impl(admm_hip_ctx *c, const double *x, const double *v);
+static int get_state_impl(admm_hip_ctx *c, double *x, double *v);
+
 int admm_hip_set_state(admm_hip_ctx *c, const double *x, const double *v) {
+    if (!c || !x) return fail(ADMM_HIP_ERR_ARG, "set_state: NULL argument");
+    if (!c->cm.on) return set_state_impl(c, x, v);
+    // component partition: the caller's arrays are numbered globally; this rank takes its bodies
+    std::vector<double> xl(c->n3), vl(v ? c->n3 : 0);
+    for (int i = 0; i < c->nv; ++i)
+        for (int j = 0; j < 3; ++j) { xl[3 * (size_t)i + j] = x[3 * (size_t)c->cm.l2g[i] + j]; if (v) vl[3 * (size_t)i + j] = v[3 * (size_t)c->cm.l2g[i] + j]; }
+    return set_state_impl(c, xl.data(), v ? vl.data() : nullptr);
+}
+
+// component partition: this rank's entries go into the caller's globally numbered arrays; with a communicator the parts of all
+// ranks are merged (one sum all-reduce of a vector that is zero outside the rank's own entries), without one the other ranks'
+// entries are left as they are
+int admm_hip_get_state(admm_hip_ctx *c, double *x, double *v) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "get_state: NULL context");
+    if (!c->cm.on) return get_state_impl(c, x, v);
+    std::vector<double> xl(x ? c->n3 : 0), vl(v ? c->n3 : 0);
+    if (int rc = get_state_impl(c, x ? xl.data() : nullptr, v ? vl.data() : nullptr)) return rc;
+    const size_t n3g = 3 * (size_t)c->cm.nv_global;
+    for (int pass = 0; pass < 2; ++pass) {
+        double *dst = pass == 0 ? x : v;
+        const std::vector<double> &src = pass == 0 ? xl : vl;
+        if (!dst) continue;
+        if (!c->cm_comm) {
+            for (int i = 0; i < c->nv; ++i) for (int j = 0; j < 3; ++j) dst[3 * (size_t)c->cm.l2g[i] + j] = src[3 * (size_t)i + j];
+            continue;
+        }
+        std::vector<double> full(n3g, 0.0);
+        for (int i = 0; i < c->nv; ++i) for (int j = 0; j < 3; ++j) full[3 * (size_t)c->cm.l2g[i] + j] = src[3 * (size_t)i + j];
+        if (c->cm_buf.n < n3g) { c->cm_buf.release(); HIP_TRY(c->cm_buf.alloc(n3g)); }
+        HIP_TRY(hipMemcpyAsync(c->cm_buf.p, full.data(), n3g * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        if (g_rccl.AllReduce(c->cm_buf.p, c->cm_buf.p, n3g, ncclDouble, ncclSum, c->cm_comm, c->stream) != ncclSuccess)
+            return fail(ADMM_HIP_ERR_COMM, "get_state: ncclAllReduce (merge of the ranks' bodies) failed");
+        HIP_TRY(hipMemcpyAsync(dst, c->cm_buf.p, n3g * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ADMM_HIP_OK;
+}
+
+static int set_state_impl(admm_hip_ctx *c, const double *x, const double *v) {
     if (!c || !x) return fail(ADMM_HIP_ERR_ARG, "set_state: NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->x.p, x, c->n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -1406,7 +1528,7 @@ int admm_hip_set_state(admm_hip_ctx *c, const double *x, const double *v) {
     return ADMM_HIP_OK;
 }
 
-int admm_hip_get_state(admm_hip_ctx *c, double *x, double *v) {
+static int get_state_impl(admm_hip_ctx *c, double *x, double *v) {
     if (!c) return fail(ADMM_HIP_ERR_ARG, "get_state: NULL context");
     HIP_TRY(hipSetDevice(c->device));
     if (x) HIP_TRY(hipMemcpyAsync(x, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -1421,7 +1543,20 @@ int admm_hip_get_state(admm_hip_ctx *c, double *x, double *v) {
     return ADMM_HIP_OK;
 }
 
+static int set_pins_impl(admm_hip_ctx *c, int32_t n, const int32_t *vert, const double *xyz);
 int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const double *xyz) {
+    if (!c || n < 0 || (n > 0 && (!vert || !xyz))) return fail(ADMM_HIP_ERR_ARG, "set_pins: Bad input (Solver.cpp:118-120)");
+    if (!c->cm.on) return set_pins_impl(c, n, vert, xyz);
+    std::vector<int32_t> vl; std::vector<double> pl;        // component partition: the pins of this rank's bodies
+    for (int i = 0; i < n; ++i) {
+        if (vert[i] < 0 || vert[i] >= c->cm.nv_global) return fail(ADMM_HIP_ERR_ARG, "set_pins: index out of range");
+        const int32_t l = c->cm.g2l[vert[i]];
+        if (l < 0) continue;
+        vl.push_back(l); for (int j = 0; j < 3; ++j) pl.push_back(xyz[3 * (size_t)i + j]);
+    }
+    return set_pins_impl(c, (int32_t)vl.size(), vl.data(), pl.data());
+}
+static int set_pins_impl(admm_hip_ctx *c, int32_t n, const int32_t *vert, const double *xyz) {
     if (!c || n < 0 || (n > 0 && (!vert || !xyz))) return fail(ADMM_HIP_ERR_ARG, "set_pins: Bad input (Solver.cpp:118-120)");
     HIP_TRY(hipSetDevice(c->device));
     // admm_hip_step without stats returns while its kernels are still in flight on the context's (non-blocking)
@@ -1463,7 +1598,23 @@ int admm_hip_set_pins(admm_hip_ctx *c, int32_t n, const int32_t *vert, const dou
 }
 
 // Solver::ext_forces.push_back(std::make_shared<WindForce>(tris)) + WindForce::direction (src/ExplicitForce.hpp:39-46)
+static int set_wind_impl(admm_hip_ctx *c, int32_t n_tris, const int32_t *tris, const double *direction);
 int admm_hip_set_wind(admm_hip_ctx *c, int32_t n_tris, const int32_t *tris, const double *direction) {
+    if (!c || n_tris < 0 || (n_tris > 0 && (!tris || !direction))) return fail(ADMM_HIP_ERR_ARG, "set_wind: bad input");
+    if (!c->cm.on) return set_wind_impl(c, n_tris, tris, direction);
+    std::vector<int32_t> tl;                                  // component partition: the triangles of this rank's bodies
+    for (int64_t t = 0; t < n_tris; ++t) {
+        int32_t l[3];
+        for (int k = 0; k < 3; ++k) {
+            const int32_t g = tris[3 * t + k];
+            if (g < 0 || g >= c->cm.nv_global) return fail(ADMM_HIP_ERR_ARG, "set_wind: triangle index out of range");
+            l[k] = c->cm.g2l[g];
+        }
+        if (l[0] >= 0 && l[1] >= 0 && l[2] >= 0) for (int k = 0; k < 3; ++k) tl.push_back(l[k]);
+    }
+    return set_wind_impl(c, (int32_t)(tl.size() / 3), tl.data(), direction);
+}
+static int set_wind_impl(admm_hip_ctx *c, int32_t n_tris, const int32_t *tris, const double *direction) {
     if (!c || n_tris < 0 || (n_tris > 0 && (!tris || !direction))) return fail(ADMM_HIP_ERR_ARG, "set_wind: bad input");
     for (int64_t i = 0; i < (int64_t)3 * n_tris; ++i)
         if (tris[i] < 0 || tris[i] >= c->nv) return fail(ADMM_HIP_ERR_ARG, "set_wind: triangle index out of range");
@@ -1481,10 +1632,32 @@ int admm_hip_set_wind(admm_hip_ctx *c, int32_t n_tris, const int32_t *tris, cons
 }
 
 // Solver::surface_inds (src/Solver.hpp:70): the vertices Collider::detect looks at (Collider.hpp:157,163)
+static int set_surface_inds_impl(admm_hip_ctx *c, int32_t n, const int32_t *inds);
 int admm_hip_set_surface_inds(admm_hip_ctx *c, int32_t n, const int32_t *inds) {
+    if (!c || n < 0 || (n > 0 && !inds)) return fail(ADMM_HIP_ERR_ARG, "set_surface_inds: bad input");
+    if (!c->cm.on) return set_surface_inds_impl(c, n, inds);
+    std::vector<int32_t> il;
+    for (int i = 0; i < n; ++i) {
+        if (inds[i] < 0 || inds[i] >= c->cm.nv_global) return fail(ADMM_HIP_ERR_ARG, "set_surface_inds: index out of range");
+        if (c->cm.g2l[inds[i]] >= 0) il.push_back(c->cm.g2l[inds[i]]);
+    }
+    if (n > 0 && il.empty()) {     // a list none of whose vertices is ours must not turn into "every vertex": an all-zero candidate mask
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (int rc = settle(c)) return rc;
+        c->surf_list.release(); c->surf_mask.release();
+        c->n_surf = 1;             // (the list itself only serves the dynamic queries, which a component-partitioned context does not run)
+        HIP_TRY(c->surf_list.upload(std::vector<int>(1, 0)));
+        HIP_TRY(c->surf_mask.upload(std::vector<unsigned char>(c->nv, 0)));
+        return ADMM_HIP_OK;
+    }
+    return set_surface_inds_impl(c, (int32_t)il.size(), il.data());
+}
+static int set_surface_inds_impl(admm_hip_ctx *c, int32_t n, const int32_t *inds) {
     if (!c || n < 0 || (n > 0 && !inds)) return fail(ADMM_HIP_ERR_ARG, "set_surface_inds: bad input");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));   // a step may still be in flight (see admm_hip_set_pins)
+    if (int rc = settle(c)) return rc;          // (steps that hit a barrier time-out are replayed with the OLD surface list)
     std::vector<int> list;
     std::vector<unsigned char> mask(c->nv, 0);
     for (int i = 0; i < n; ++i) {
@@ -1502,6 +1675,7 @@ int admm_hip_set_surface_inds(admm_hip_ctx *c, int32_t n, const int32_t *inds) {
 // Solver::add_dynamic_collider(TetMeshCollision(mesh, v_offset)) -- src/Solver.cpp:163-165, src/DynamicObject.hpp:45-64
 int admm_hip_add_dynamic_tetmesh(admm_hip_ctx *c, int32_t vert_offset, int32_t n_verts, const double *rest_verts,
                                  int32_t n_tets, const int32_t *tets, int32_t n_faces, const int32_t *faces) {
+    if (c && c->cm.on) return fail(ADMM_HIP_ERR_STATE, "add_dynamic_tetmesh: dynamic colliders couple the bodies -- create the rank contexts with ADMM_HIP_PARTITION=elements");
     if (!c || !rest_verts || !tets || n_verts <= 0 || n_tets <= 0 || vert_offset < 0 || vert_offset + n_verts > c->nv)
         return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: bad input");
     if (n_faces <= 0 || !faces) return fail(ADMM_HIP_ERR_ARG, "**TetMeshCollision Error: TetMesh needs surface faces");
@@ -1510,6 +1684,7 @@ int admm_hip_add_dynamic_tetmesh(admm_hip_ctx *c, int32_t vert_offset, int32_t n
     for (int i = 0; i < 3 * n_faces; ++i) if (faces[i] < 0 || faces[i] >= n_verts) return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: face index out of range");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));   // a step may still be in flight (see admm_hip_set_pins)
+    if (int rc = settle(c)) return rc;          // (pending steps are replayed, if need be, without the new collider)
     auto fill_levels = [](const admm_host::OctTree &T, OctLevels &L) {
         L.n_levels = T.n_levels;
         for (int l = 0; l < T.n_levels; ++l) { L.off[l] = T.level_off[l]; L.n[l] = T.level_n[l]; }
@@ -1747,7 +1922,10 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
 // good state and replay.  Single-GPU contexts only (a replay on one rank would issue all-reduces the others do not).
 static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
     c->h_sig[2] = 0;
-    if (c->world > 1 || c->comm || c->pending.empty() || !c->bk_x.p)
+    if (c->world > 1 || c->comm)     // a replay on one rank would issue all-reduces the other ranks do not: the step is lost, cleanly
+        return fail(ADMM_HIP_ERR_COMM, "PCG: a grid barrier of the on-chip solve timed out on a rank of a multi-GPU job; the step cannot be replayed under a "
+                                       "communicator -- restore the state on every rank (admm_hip_set_state) and continue");
+    if (c->pending.empty() || !c->bk_x.p)
         return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)");
     if (!c->oc_gave_up) fprintf(stderr, "[admm_hip] on-chip PCG: a grid barrier timed out (blocks not co-resident?) -- falling back to the launch-per-iteration PCG and replaying %d step(s)\n", (int)c->pending.size());
     c->oc_gave_up = true; c->oc_enabled = false;
@@ -1822,6 +2000,7 @@ static void dev_to_rows(const admm_hip_ctx *c, const std::vector<double> &tu, co
 
 int admm_hip_local_step(admm_hip_ctx *c, const double *x, double *u_inout, double *z_out, const double *Mxbar, double *b_out) {
     if (!c || !x || !u_inout || !z_out) return fail(ADMM_HIP_ERR_ARG, "local_step: NULL argument");
+    if (c->cm.on) return fail(ADMM_HIP_ERR_STATE, "local_step: kernel-level entry points work on the rows of the whole scene; this context holds only its rank's bodies (ADMM_HIP_PARTITION=elements)");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     std::vector<double> tu, ru, pu;
@@ -1859,6 +2038,7 @@ int admm_hip_local_step(admm_hip_ctx *c, const double *x, double *u_inout, doubl
 
 int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int32_t *iters) {
     if (!c || !b || !x_inout) return fail(ADMM_HIP_ERR_ARG, "global_solve: NULL argument");
+    if (c->cm.on) return fail(ADMM_HIP_ERR_STATE, "global_solve: kernel-level entry points work on the whole scene; this context holds only its rank's bodies (ADMM_HIP_PARTITION=elements)");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(c->b.p, b, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1951,6 +2131,7 @@ int admm_hip_local_launch_times(admm_hip_ctx *c, int64_t *n_pairs, double *sum_m
 
 int admm_hip_get_matrix(const admm_hip_ctx *c, int32_t *rowptr, int32_t *col, double *val, int32_t *nnz) {
     if (!c) return fail(ADMM_HIP_ERR_ARG, "get_matrix: NULL context");
+    if (c->cm.on) return fail(ADMM_HIP_ERR_STATE, "get_matrix: this context holds only its rank's bodies (admm_host_assemble_matrix gives the whole matrix)");
     if (nnz) *nnz = (int32_t)c->Ahat.col.size();
     if (rowptr) std::copy(c->Ahat.rowptr.begin(), c->Ahat.rowptr.end(), rowptr);
     if (col) std::copy(c->Ahat.col.begin(), c->Ahat.col.end(), col);
@@ -1979,6 +2160,16 @@ int admm_hip_comm_unique_id(char *id128) {
 
 int admm_hip_comm_init(admm_hip_ctx *c, const char *id128, int rank, int world_size) {
     if (!c || !id128) return fail(ADMM_HIP_ERR_ARG, "comm_init: NULL argument");
+    if (c->cm.on) {     // component partition: the communicator only merges the ranks' parts in admm_hip_get_state
+        if (rank != c->cm.rank || world_size != c->cm.world) return fail(ADMM_HIP_ERR_ARG, "comm_init: rank/world_size differ from the ones the context was created with");
+        if (!g_rccl.load()) return fail(ADMM_HIP_ERR_COMM, "cannot load librccl");
+        HIP_TRY(hipSetDevice(c->device));
+        ncclUniqueId idc;
+        std::memcpy(&idc, id128, sizeof(idc));
+        ncclResult_t rr = g_rccl.CommInitRank(&c->cm_comm, world_size, idc, rank);
+        if (rr != ncclSuccess) return fail(ADMM_HIP_ERR_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rr));
+        return ADMM_HIP_OK;
+    }
     if (rank != c->rank || world_size != c->world)
         return fail(ADMM_HIP_ERR_ARG, "comm_init: rank/world_size differ from the ones the context was created with");
     // a world of one needs no communicator; ADMM_HIP_FORCE_COMM=1 builds (and uses) one anyway so that the RCCL
@@ -2043,6 +2234,10 @@ int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int
 }
 void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end) {
     admm_host::partition(n_items, world_size, rank, begin, end);
+}
+int32_t admm_host_component_partition(const admm_hip_desc *d, int world_size, int32_t *vertex_rank) {
+    if (!d || !vertex_rank || d->n_verts < 1) return -1;
+    return admm_host::component_partition(d->n_verts, d->n_tets, d->tet_idx, d->n_tris, d->tri_idx, std::max(world_size, 1), vertex_rank);
 }
 int admm_host_tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol) {
     int r = admm_host::tet_rest(n, idx, verts, Binv, vol);

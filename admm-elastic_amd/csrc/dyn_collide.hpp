@@ -329,7 +329,8 @@ __global__ __launch_bounds__(256) void k_uz_ct_dyn_max(int nq, const int *__rest
     const double c = fmax(fabs(cn[3 * (size_t)v]), fmax(fabs(cn[3 * (size_t)v + 1]), fabs(cn[3 * (size_t)v + 2])));
     const double b = fmax(fabs(dbary[3 * (size_t)v]), fmax(fabs(dbary[3 * (size_t)v + 1]), fabs(dbary[3 * (size_t)v + 2])));
     const double m = fabs(y[v]) * b * c;
-    if (m > 0.0 && m < 1e300) atomicMax((unsigned long long *)dmax, (unsigned long long)__double_as_longlong(m));
+    // (below 1e-280 the contributions are zero for every purpose, and 2^(50 - e) would leave the exponent range of a double)
+    if (m > 1e-280 && m < 1e300) atomicMax((unsigned long long *)dmax, (unsigned long long)__double_as_longlong(m));
 }
 __global__ __launch_bounds__(256) void k_uz_ct_dyn(int nq, const int *__restrict__ query, int mode, const double *__restrict__ cn,
                                                    const double *__restrict__ y, const int *__restrict__ dface,

@@ -231,6 +231,31 @@ Sell record_incidence(int32_t n_verts, int32_t n_rec, const int32_t *rec_vertex,
     return S;
 }
 
+int32_t component_partition(int32_t nv, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int world, int32_t *vertex_rank) {
+    std::vector<int32_t> parent(nv);
+    std::iota(parent.begin(), parent.end(), 0);
+    auto find = [&](int32_t a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+    auto unite = [&](int32_t a, int32_t b) { a = find(a); b = find(b); if (a != b) parent[std::max(a, b)] = std::min(a, b); };   // root = lowest vertex
+    for (int32_t t = 0; t < n_tets; ++t) for (int k = 1; k < 4; ++k) unite(tet_idx[4 * (size_t)t], tet_idx[4 * (size_t)t + k]);
+    for (int32_t t = 0; t < n_tris; ++t) for (int k = 1; k < 3; ++k) unite(tri_idx[3 * (size_t)t], tri_idx[3 * (size_t)t + k]);
+    std::vector<int64_t> load_of_root(nv, 0);
+    for (int32_t t = 0; t < n_tets; ++t) load_of_root[find(tet_idx[4 * (size_t)t])] += 1;
+    for (int32_t t = 0; t < n_tris; ++t) load_of_root[find(tri_idx[3 * (size_t)t])] += 1;
+    std::vector<int32_t> roots;
+    for (int32_t v = 0; v < nv; ++v) if (find(v) == v) roots.push_back(v);
+    std::stable_sort(roots.begin(), roots.end(), [&](int32_t a, int32_t b) { return load_of_root[a] != load_of_root[b] ? load_of_root[a] > load_of_root[b] : a < b; });
+    std::vector<int64_t> load(std::max(world, 1), 0);
+    std::vector<int32_t> rank_of_root(nv, 0);
+    for (int32_t r : roots) {
+        int best = 0;
+        for (int k = 1; k < world; ++k) if (load[k] < load[best]) best = k;
+        rank_of_root[r] = best;
+        load[best] += std::max<int64_t>(load_of_root[r], 1);      // (a loose vertex still counts as something)
+    }
+    for (int32_t v = 0; v < nv; ++v) vertex_rank[v] = rank_of_root[find(v)];
+    return (int32_t)roots.size();
+}
+
 // Row order of the incidence lists: inside every window of 512 consecutive vertices the vertices with the most incident
 // elements come first, so the 64 rows of a slice have similar lengths (unstructured 1 M-tet body: 2.17x -> 1.24x stored
 // per real incidence) while a slice still gathers from one neighbourhood of the mesh.

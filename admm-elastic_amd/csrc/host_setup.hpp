@@ -122,6 +122,7 @@ struct OcPlan {
     bool affine = false;                // coarse functions {1, x, y, z} per block (coordinates given) instead of kOcSub constants
     double stat_bank_sorted = 0.0, stat_bank_placed = 0.0;   // lanes on the busiest LDS bank pair per (half wavefront, column): entries by index / as placed
     double lam_bb = 0.0;                // estimate of lambda_max(D^-1 A_bb), A_bb = the block-diagonal part of M + Ahat (power iteration)
+    double lam_bb_gersh = 0.0;          // rigorous upper bound of the same (Gershgorin on D^-1/2 A_bb D^-1/2)
     int64_t stat_nnz = 0, stat_stored = 0, stat_onchip = 0, stat_local = 0;
 };
 // A = Ahat (mass not included), mass3 [3 n]; lds_bytes = LDS one block may spend on its local vector and matrix slab
@@ -131,6 +132,12 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
 // Hierarchical block order of mesh vertices (oc_plan.cpp): compact leaves of ~leaf vertices from a recursive graph
 // bisection, leaves in recursion-tree order, breadth-first inside a leaf.  new_id[v] = position of vertex v.
 void block_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t leaf, int32_t *new_id);
+
+// Connected components of the scene (vertices joined by tets / triangles) and their assignment to `world` ranks: components by
+// decreasing element count (ties: lowest vertex first), each to the least loaded rank so far (ties: lowest rank).  Returns the
+// number of components; vertex_rank[v] = owning rank.  The multi-GPU partition that needs NO exchange inside a step.
+int32_t component_partition(int32_t n_verts, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int world,
+                            int32_t *vertex_rank);
 
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
 int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);

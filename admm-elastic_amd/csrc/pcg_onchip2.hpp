@@ -254,7 +254,10 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     // S v = D^-1 (sm_ab v - sm_b offdiag(A_bb) D^-1 v): D^-1 v goes into the local vector with the halo part zeroed, the
     // ordinary row loop does the rest.  S is symmetric positive definite as long as lambda_max(D^-1 A_bb) stays below the
     // bound the host derived the coefficients from (oc_plan.cpp: power iteration + margin).
-    const bool smoothing = a.sm_b != 0.0;
+    // (counters[75]: set for good by a solve whose pipelined pass broke off with non-finite or negative sums -- the sign of a
+    // preconditioner that is not positive definite, e.g. a bound of the smoother's interval that was too low; later solves of the
+    // context then run with S = D^-1)
+    const bool smoothing = a.sm_b != 0.0 && __builtin_amdgcn_readfirstlane(a.counters[75]) == 0;
     auto smooth = [&](const double *v, double *out) {
         if (!smoothing) {
 #pragma unroll
@@ -753,7 +756,10 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                         if (lane == 0) ictl[2] = act;
                     }
                     const int act = action();
-                    if (act == 2) { entry_restart = true; go_classic = true; break; }
+                    if (act == 2) {
+                        if (blockIdx.x == 0 && otid() == 0 && smoothing) a.counters[75] = 1;
+                        entry_restart = true; go_classic = true; break;
+                    }
                     if (act == 4) {                  // converged by the recursive residual of a short first pass: no verification
 #pragma unroll
                         for (int j = 0; j < 3; ++j) ru[j] = rd[j] * rr[j];

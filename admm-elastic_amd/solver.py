@@ -376,6 +376,14 @@ class Solver:
         dist.broadcast_object_list(obj, src=0)
         check(lib().admm_hip_comm_init(self._ctx, obj[0], s.rank, s.world_size))
 
+    def component_partition(self, world_size, settings=None):
+        """admm_host_component_partition: (number of connected components, owning rank of every vertex) -- the multi-GPU
+        partition admm_hip_create uses when the scene has at least world_size bodies."""
+        d = self.make_desc(settings if settings is not None else self._settings)
+        vr = np.zeros(self.m_x.size // 3, np.int32)
+        n = lib().admm_host_component_partition(C.byref(d), world_size, iptr(vr))
+        return n, vr
+
     def solve_totals(self):
         """admm_hip_solve_totals: (solves, converged solves, inner iterations) of the on-chip PCG since initialize."""
         self._need_ctx()

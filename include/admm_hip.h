@@ -226,7 +226,7 @@ int admm_hip_global_solve(admm_hip_ctx *ctx, const double *b, double *x_inout, i
  * inner iterations.  Synchronises the context's stream.  Lets a caller run admm_hip_step WITHOUT per-step statistics
  * (asynchronously, no events between the kernels) and still check afterwards that every solve converged.  -1 when the context
  * does not use the general-mesh on-chip PCG. */
-int admm_hip_solve_totals(admm_hip_ctx *ctx, int64_t *solves, int64_t *converged, int64_t *inner_iters);
+int admm_hip_solve_totals(admm_hip_ctx *ctx, int64_t *solves, int64_t *converged, int64_t *inner_iters);   /* returns ADMM_HIP_OK; the three values are -1 when this context's solver keeps no totals */
 
 /* Diagnostics of the on-chip PCG (linsolver 0 / 2; no reference counterpart): the latency floor of the two
  * synchronisations one CG iteration consists of, measured on this context's grid with the kernel's own primitives and
@@ -261,6 +261,16 @@ int admm_hip_get_colors(const admm_hip_ctx *ctx, int32_t *color, int32_t *n_colo
 int admm_hip_comm_unique_id(char *id128);                                   /* ncclGetUniqueId */
 int admm_hip_comm_init(admm_hip_ctx *ctx, const char *id128, int rank, int world_size);
 void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end);
+
+/* Multi-GPU, component-aware partition (the reference has no distributed layer).  When a scene has at least
+ * world_size connected components (bodies that share no vertex), admm_hip_create gives every rank WHOLE bodies: its context
+ * holds only them, renumbered locally, and steps them like a single-GPU scene -- no exchange inside a step, the global solve
+ * is the rank's block of the block-diagonal system matrix.  The caller keeps the global numbering (set_state / get_state /
+ * set_pins translate; admm_hip_get_state merges the ranks' parts over RCCL when admm_hip_comm_init was called).  Components go
+ * to ranks by decreasing element count, each to the least loaded rank so far.  Otherwise (a single body, or
+ * ADMM_HIP_PARTITION=elements) the element-block partition above is used.  This host-only function returns the number of
+ * components and, in vertex_rank [n_verts], the rank that would own every vertex. */
+int32_t admm_host_component_partition(const admm_hip_desc *desc, int world_size, int32_t *vertex_rank);
 
 /* ---- host-side set-up arithmetic (no GPU) ---- */
 /* The matrix admm_hip_create would assemble for this description (same code path), without a GPU:

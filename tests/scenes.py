@@ -169,6 +169,22 @@ def rel_err(a, b, x_ref=None):
     return np.linalg.norm(a - b, axis=1).max() / max(diag, 1e-300)
 
 
+def bodies_scene(cells, kinds=None, gap=1.6, **settings):
+    """Several SEPARATE bodies in one Solver (the reference's boxes.cpp / beams.cpp shape): Kuhn cubes of `cells[i]` cells per edge
+    side by side along x, each with its own constitutive model, each pinned on its x-min face.  The system matrix is block
+    diagonal by body -- the scene the component-aware multi-GPU partition cuts for free."""
+    sc = Scene()
+    kinds = kinds or [pkg.TET_NEOHOOKEAN, pkg.TET_STVK, pkg.TET_LINEAR]
+    for i, n in enumerate(cells):
+        verts, tets = meshes.kuhn_cube(n)
+        verts = verts + np.array([gap * i, 0.0, 0.0])
+        off = sc.add_tet_mesh(verts, tets, Lame.soft_rubber(), kinds[i % len(kinds)])
+        for v in np.nonzero(verts[:, 0] < gap * i + 1e-9)[0]:
+            sc.pins[int(v) + off] = verts[v].copy()
+    sc.settings.update(settings)
+    return sc
+
+
 def blob_scene(n, jitter=0.15, seed=0, order="rcm", **settings):
     """BASELINE configs[2] on an UNSTRUCTURED body: meshes.unstructured_blob (valences 3..26, not 2-colourable, no exact
     zeros in Ahat), numbered randomly like a mesh file and renumbered for locality as the samples do; Neo-Hookean / StVK

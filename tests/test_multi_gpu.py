@@ -192,6 +192,182 @@ def test_two_ranks_two_gpus_match_single_context():
     assert np.array_equal(res[0][1], res[1][1])      # the replicated solves see the same all-reduced right-hand side
 
 
+# ---- component-aware partition: whole bodies per rank, no exchange inside a step (admm_hip_ctx::CompMode) -------------------
+def test_component_partition_assigns_whole_bodies():
+    """admm_host_component_partition: bodies by decreasing element count to the least loaded rank; a body is never cut; a
+    single body gives one component (then admm_hip_create falls back to element blocks)."""
+    sc = scenes.bodies_scene([3, 5, 2, 4, 3], linsolver=0)
+    s = sc.make_solver(init=False)
+    body = np.concatenate([np.full(len(t[0]), i) for i, t in enumerate(sc.tets)])      # body of every vertex
+    ntet = np.array([len(t[1]) for t in sc.tets])
+    for world in (1, 2, 3, 5):
+        n, vr = s.component_partition(world, sc.product_settings)
+        assert n == 5
+        for b in range(5):
+            assert len(set(vr[body == b])) == 1                                        # whole bodies
+        rank_of_body = np.array([vr[body == b][0] for b in range(5)])
+        load = np.array([ntet[rank_of_body == r].sum() for r in range(world)])
+        assert (load > 0).all() and load.max() <= ntet.sum() / world + ntet.max()       # nobody idle, greedy balance
+        n2, vr2 = s.component_partition(world, sc.product_settings)
+        assert n2 == n and np.array_equal(vr, vr2)                                      # deterministic
+    # largest body first to rank 0, the next to rank 1, ...
+    n, vr = s.component_partition(2, sc.product_settings)
+    assert vr[body == 1][0] == 0 and vr[body == 3][0] == 1
+    one = scenes.mixed_cube_scene(4, linsolver=0).make_solver(init=False)
+    n, vr = one.component_partition(4, scenes.mixed_cube_scene(4, linsolver=0).make_solver(init=False)._settings)
+    assert n == 1 and (vr == 0).all()
+
+
+def _component_worker(rank, world, port, frames, q):
+    """One rank of the component-partitioned job on the CPU: the oracle steps ONLY the bodies admm_host_component_partition gives
+    this rank (a sub-scene with its own exact solve -- the rank's block of the block-diagonal system); positions are merged by
+    an all-gather at the end, as admm_hip_get_state does with its communicator."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = scenes.bodies_scene([3, 4, 2], admm_iters=6, linsolver=0)
+    n, vr = sc.make_solver(init=False).component_partition(world)
+    own = np.nonzero(vr == rank)[0]
+    g2l = -np.ones(len(sc.x), np.int64); g2l[own] = np.arange(len(own))
+    sub = scenes.Scene()
+    sub.x = sc.x[own]; sub.m = sc.m[own]
+    for verts, tets, lame, kind, off in sc.tets:
+        if vr[off] == rank:
+            sub.tets.append((sub.x, g2l[tets + off].astype(np.int32), lame, kind, 0))
+    sub.pins = {int(g2l[k]): p for k, p in sc.pins.items() if vr[k] == rank}
+    sub.settings.update(sc.settings)
+    o = sub.make_oracle(mode=1)
+    for _ in range(frames):
+        o.step()
+    mine = np.zeros(3 * len(sc.x)); mine.reshape(-1, 3)[own] = o.x.reshape(-1, 3)
+    t = torch.from_numpy(mine)
+    dist.all_reduce(t)                      # merge (every vertex has exactly one owner)
+    if rank == 0:
+        q.put(t.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_component_partition_matches_single_rank_gloo():
+    import torch.multiprocessing as mp
+    frames, world = 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_component_worker, args=(r, world, port, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    x_merged = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc = scenes.bodies_scene([3, 4, 2], admm_iters=6, linsolver=0)
+    o = sc.make_oracle(mode=1)
+    for _ in range(frames):
+        o.step()
+    assert scenes.rel_err(x_merged, o.x) < 1e-10      # exact solves of the blocks of a block-diagonal system = the exact solve
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_component_rank_contexts_reproduce_single_context(world):
+    """World-N rank contexts on ONE GPU (no communicator): every context holds its rank's bodies only, steps them without any
+    exchange, and the merged trajectory is the single context's (to the solve tolerance: the ranks' PCG solves are the blocks of
+    the single context's solve).  Pins moved through the global numbering; the kernel-level entry points refuse."""
+    sc = scenes.bodies_scene([4, 6, 3, 5], admm_iters=8, linsolver=0)
+    frames = 3
+    moved = {k: p + np.array([0.02, 0.0, 0.01]) for k, p in sc.pins.items()}
+    ref = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=2000)
+    for f in range(frames):
+        ref.step()
+        if f == 0:
+            ref.set_pins(list(moved.keys()), list(moved.values()))
+    n, vr = ref.component_partition(world)
+    assert n == 4
+    merged = np.zeros_like(ref.m_x)
+    for r in range(world):
+        s = sc.make_solver(rank=r, world_size=world, pcg_tol=1e-11, pcg_max_iters=2000)
+        x0 = s.m_x.copy()
+        for f in range(frames):
+            s.step()
+            if f == 0:
+                s.set_pins(list(moved.keys()), list(moved.values()))
+        own = np.repeat(vr == r, 3)
+        assert np.array_equal(s.m_x[~own], x0[~own])              # the other ranks' bodies are not touched
+        assert s.runtime_data().unconverged_solves == 0
+        merged[own] = s.m_x[own]
+        with pytest.raises(pkg.AdmmHipError):
+            s.local_step(s.m_x, np.zeros(s.num_rows()))
+        s.close()
+    assert scenes.rel_err(merged, ref.m_x) < 1e-9, scenes.rel_err(merged, ref.m_x)
+    assert np.abs(ref.m_x - sc.x.ravel()).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_component_partition_merges_over_rccl_on_one_gpu(monkeypatch):
+    """The RCCL leg of the component partition on one GPU: a world of ONE with ADMM_HIP_PARTITION=components and a communicator:
+    admm_hip_get_state runs its merging all-reduce (the identity here) and returns the single-context trajectory bit for bit."""
+    import ctypes as C
+    sc = scenes.bodies_scene([4, 3], admm_iters=6, linsolver=0)
+    ref = sc.make_solver(pcg_tol=1e-10, pcg_max_iters=500)
+    for _ in range(3):
+        ref.step()
+    monkeypatch.setenv("ADMM_HIP_PARTITION", "components")
+    s = sc.make_solver(rank=0, world_size=2, pcg_tol=1e-10, pcg_max_iters=500)      # rank 0 of 2: the larger body
+    monkeypatch.delenv("ADMM_HIP_PARTITION")
+    for _ in range(3):
+        s.step()
+    n, vr = ref.component_partition(2)
+    own = np.repeat(vr == 0, 3)
+    single_body = scenes.bodies_scene([4], admm_iters=6, linsolver=0).make_solver(pcg_tol=1e-10, pcg_max_iters=500)
+    for _ in range(3):
+        single_body.step()
+    assert np.array_equal(s.m_x[own], single_body.m_x)        # the rank's context IS the single-GPU solver of its bodies
+
+
+@pytest.mark.gpu
+def test_barrier_timeout_under_a_communicator_is_a_clean_comm_error(monkeypatch):
+    """A grid barrier of the persistent PCG kernel that cannot complete is recovered by a replay on a single GPU
+    (tests/test_edge_cases.py); under a communicator a replay on one rank would issue all-reduces the others do not, so the
+    step fails with ADMM_HIP_ERR_COMM and a message that says what to do -- never a hang, never a wrong state."""
+    import ctypes as C
+    sc = scenes.mixed_cube_scene(6, admm_iters=6, linsolver=0)
+    monkeypatch.setenv("ADMM_HIP_TEST_ABORT_SOLVE", "8")
+    s = sc.make_solver(pcg_tol=1e-10, pcg_max_iters=500)
+    monkeypatch.delenv("ADMM_HIP_TEST_ABORT_SOLVE")
+    monkeypatch.setenv("ADMM_HIP_FORCE_COMM", "1")
+    buf = C.create_string_buffer(128)
+    capi.check(capi.lib().admm_hip_comm_unique_id(buf))
+    capi.check(capi.lib().admm_hip_comm_init(s._ctx, bytes(buf.raw), 0, 1))
+    monkeypatch.delenv("ADMM_HIP_FORCE_COMM")
+    s.step()
+    with pytest.raises(pkg.AdmmHipError) as ei:
+        s.step()                                   # solve 8 is in the second frame
+    assert ei.value.code == -5 and "communicator" in str(ei.value)
+    s.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_functional():
+    """`python bench.py --gpus 2` end to end on a one-GPU box (ADMM_BENCH_SHARE_GPU=1: both ranks on device 0, gloo): the weak-scaling
+    default workload (one body per rank), the component-aware partition, the barrier + max-over-ranks timing and the JSON line.
+    A functional check of the N-rank code path -- the two ranks time-share the device, the number means nothing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_N="30")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["workload"].startswith("blobs_1m_per_gpu")
+    assert d["unconverged_solves_in_timed_region"] == 0 and d["finite"] and d["value"] > 0
+    assert "whole bodies per rank x2" in d["config"]["parallelism"] and d["expected_speedup"]["vs_one_gpu"] == 2.0
+
+
 def test_bench_gpus_flag_starts_that_many_ranks():
     """`python bench.py --gpus N` ignored the flag (one rank, "n_gpus": 1).  It now starts N ranks itself
     when no launcher did (the driver's `python -m torch.distributed.run --nproc-per-node N` line), and a mismatch between
