@@ -49,6 +49,7 @@ class Desc(C.Structure):
         ("rank", C.c_int32), ("world_size", C.c_int32),
         ("tet_kappa", c_double_p),
         ("vert_xyz", c_double_p),
+        ("n_spline_tables", C.c_int32), ("spline_tables", c_double_p), ("tet_spline", c_int_p),
     ]
 
 
@@ -60,6 +61,9 @@ class Stats(C.Structure):
         ("local_kernel_ms", C.c_double),
     ]
 
+
+SPLINE_TABLE_DOUBLES = 9228     # ADMM_SPLINE_TABLE_DOUBLES
+SPLINE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_double)     # admm_spline_fn
 
 # every symbol include/admm_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -89,6 +93,8 @@ SYMBOLS = [
     ("admm_host_assemble_matrix", C.c_int, [C.POINTER(Desc), c_int_p, c_int_p, c_double_p, c_int_p]),
     ("admm_host_partition", None, [C.c_int32, C.c_int, C.c_int, c_int_p, c_int_p]),
     ("admm_host_component_partition", C.c_int32, [C.POINTER(Desc), C.c_int, c_int_p]),
+    ("admm_host_tabulate_spline", C.c_int, [SPLINE_FN, C.c_void_p, C.c_double, C.c_double, c_double_p]),
+    ("admm_host_spline_table_eval", None, [c_double_p, C.c_int, C.c_double, c_double_p]),
     ("admm_host_tet_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_tri_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),

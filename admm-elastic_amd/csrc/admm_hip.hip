@@ -147,7 +147,7 @@ struct admm_hip_ctx {
     DevBuf<double> t_Binv, t_u, t_z, t_sc, t_rec;     // t_rec: per-chunk partial sums of the corner forces, [n_rec + 1][4]
     DevBuf<unsigned short> ch_ent; DevBuf<int> ch_group, ch_rec; int chunk_base[6] = {0, 0, 0, 0, 0, 0};   // host_setup.hpp: TetChunks
     DevBuf<int> t_mat;
-    DevBuf<Mat> mats;
+    DevBuf<Mat> mats; DevBuf<double> spl_tab;   // tabulated user splines (ADMM_TET_SPLINE_TABLE)
     SellDev t_inc; DevBuf<int> g_order;   // incidence lists, and the vertex every row of them gathers for
     // tris
     int ntri = 0, ldr = 0;
@@ -255,7 +255,7 @@ struct admm_hip_ctx {
         cm_buf.release();
         x.release(); v.release(); m.release(); Mxbar.release(); curr.release(); b.release(); dinv.release();
         t_idx.release(); t_Binv.release(); t_u.release(); t_z.release(); t_sc.release(); t_rec.release(); ch_ent.release(); ch_group.release(); ch_rec.release();
-        t_mat.release(); mats.release(); t_inc.release(); g_order.release();
+        t_mat.release(); mats.release(); spl_tab.release(); t_inc.release(); g_order.release();
         r_idx.release(); r_rest.release(); r_u.release(); r_z.release(); r_sc.release(); r_cf.release();
         r_lmin.release(); r_lmax.release(); r_inc.release();
         vert_pin.release(); pin_active.release(); pin_xyz.release(); pin_u.release(); pin_z.release();
@@ -302,7 +302,7 @@ void launch_local(admm_hip_ctx *c) {
     if (c->nt > 0) {
         const int b0 = c->kind_begin[0], b1 = c->kind_begin[1], b2 = c->kind_begin[2], b3 = c->kind_begin[3];
         TetArgs a{c->ldt, c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p,
-                  c->ch_ent.p, c->ch_group.p, c->ch_rec.p, c->t_rec.p, 0, nullptr, 0};
+                  c->ch_ent.p, c->ch_group.p, c->ch_rec.p, c->t_rec.p, 0, c->spl_tab.p, nullptr, 0};
         auto stamp = [&]() {   // the next launch gets its own pair of stamp arrays
             if (c->timing && c->lk_launch < c->lk_cap) { a.ts = c->lk_ts.p + (size_t)c->lk_launch * 2 * c->lk_tsn; a.ts_n = c->lk_tsn; c->lk_launch += 1; }
             else a.ts = nullptr;
@@ -1065,7 +1065,10 @@ int validate(const admm_hip_desc *d) {
         if (d->tri_idx[i] < 0 || d->tri_idx[i] >= d->n_verts) return fail(ADMM_HIP_ERR_ARG, "tri index out of range");
     for (int i = 0; i < d->n_tets; ++i) {
         if (!(d->tet_weight[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "Some weight leq 0 (EnergyTerm.hpp:124-126)");
-        if (d->tet_kind[i] < 0 || d->tet_kind[i] > ADMM_TET_SPLINE_COROTATED) return fail(ADMM_HIP_ERR_ARG, "unknown tet kind");
+        if (d->tet_kind[i] < 0 || d->tet_kind[i] > ADMM_TET_SPLINE_TABLE) return fail(ADMM_HIP_ERR_ARG, "unknown tet kind");
+        if (d->tet_kind[i] == ADMM_TET_SPLINE_TABLE &&
+            (!d->spline_tables || !d->tet_spline || d->tet_spline[i] < 0 || d->tet_spline[i] >= d->n_spline_tables))
+            return fail(ADMM_HIP_ERR_ARG, "SplineTet with a user-defined spline: its table (admm_host_tabulate_spline) is missing");
     }
     for (int i = 0; i < d->n_tris; ++i) {
         if (!(d->tri_weight[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "Some weight leq 0 (EnergyTerm.hpp:124-126)");
@@ -1114,7 +1117,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     std::vector<double> masses(3 * (size_t)nl), xyz;
     for (int32_t i = 0; i < nl; ++i) for (int j = 0; j < 3; ++j) masses[3 * (size_t)i + j] = d->masses[3 * (size_t)l2g[i] + j];
     if (d->vert_xyz) { xyz.resize(3 * (size_t)nl); for (int32_t i = 0; i < nl; ++i) for (int j = 0; j < 3; ++j) xyz[3 * (size_t)i + j] = d->vert_xyz[3 * (size_t)l2g[i] + j]; }
-    std::vector<int32_t> t_idx, t_kind, r_idx, p_vert, p_act, colors;
+    std::vector<int32_t> t_idx, t_kind, r_idx, p_vert, p_act, colors, t_spl;
     std::vector<double> t_Binv, t_w, t_mu, t_la, t_k, t_kap, r_rest, r_w, r_lmin, r_lmax, p_xyz;
     for (int32_t t = 0; t < d->n_tets; ++t) {
         if (vrank[d->tet_idx[4 * (size_t)t]] != rank) continue;
@@ -1122,6 +1125,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         for (int k = 0; k < 9; ++k) t_Binv.push_back(d->tet_Binv[9 * (size_t)t + k]);
         t_w.push_back(d->tet_weight[t]); t_kind.push_back(d->tet_kind[t]); t_mu.push_back(d->tet_mu[t]); t_la.push_back(d->tet_lambda[t]); t_k.push_back(d->tet_k[t]);
         if (d->tet_kappa) t_kap.push_back(d->tet_kappa[t]);
+        if (d->tet_spline) t_spl.push_back(d->tet_spline[t]);
     }
     for (int32_t t = 0; t < d->n_tris; ++t) {
         if (vrank[d->tri_idx[3 * (size_t)t]] != rank) continue;
@@ -1140,6 +1144,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     sub.n_verts = nl; sub.masses = masses.data(); sub.vert_xyz = d->vert_xyz ? xyz.data() : nullptr;
     sub.n_tets = (int32_t)t_w.size(); sub.tet_idx = t_idx.data(); sub.tet_Binv = t_Binv.data(); sub.tet_weight = t_w.data(); sub.tet_kind = t_kind.data();
     sub.tet_mu = t_mu.data(); sub.tet_lambda = t_la.data(); sub.tet_k = t_k.data(); sub.tet_kappa = d->tet_kappa ? t_kap.data() : nullptr;
+    sub.tet_spline = d->tet_spline ? t_spl.data() : nullptr;
     sub.n_tris = (int32_t)r_w.size(); sub.tri_idx = r_idx.data(); sub.tri_rest = r_rest.data(); sub.tri_weight = r_w.data();
     sub.tri_limit_min = r_lmin.data(); sub.tri_limit_max = r_lmax.data();
     sub.n_pins = (int32_t)p_vert.size(); sub.pin_vert = p_vert.data(); sub.pin_xyz = p_xyz.data(); sub.pin_active = d->pin_active ? p_act.data() : nullptr;
@@ -1210,7 +1215,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         auto kap = [&](int t) { return (d->tet_kappa && d->tet_kind[t] >= ADMM_TET_SPLINE_NH) ? d->tet_kappa[t] : 0.0; };
         auto grp_t = [&](int t) {   // xu::NeoHookean / xu::StVK splines with kappa = 0 ARE the NH / StVK models
             const int k = d->tet_kind[t];
-            if (kap(t) != 0.0) return 4;
+            if (kap(t) != 0.0 || k == ADMM_TET_SPLINE_TABLE) return 4;
             return k == ADMM_TET_LINEAR ? 0 : (k == ADMM_TET_STVK || k == ADMM_TET_SPLINE_STVK) ? 2 : k == ADMM_TET_SPLINE_COROTATED ? 3 : 1;
         };
         c->tet_perm.resize(nt);
@@ -1231,7 +1236,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         for (int t = tb; t < te; ++t) cnt[grp_t(t)]++;
         c->kind_begin[0] = 0;
         for (int gI = 0; gI < 5; ++gI) c->kind_begin[gI + 1] = c->kind_begin[gI] + cnt[gI];
-        std::map<std::tuple<double, double, double, double, int>, int> mat_map;
+        std::map<std::tuple<double, double, double, double, int, int>, int> mat_map;
         std::vector<Mat> mats;
         std::vector<int4> idx(nt);
         std::vector<double> Binv((size_t)9 * ld, 0.0), sc(ld, 0.0);
@@ -1241,14 +1246,20 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
             idx[n] = make_int4(d->tet_idx[4 * o], d->tet_idx[4 * o + 1], d->tet_idx[4 * o + 2], d->tet_idx[4 * o + 3]);
             for (int k = 0; k < 9; ++k) Binv[(size_t)k * ld + n] = d->tet_Binv[9 * (size_t)o + k];
             sc[n] = dt2 * d->tet_weight[o] * d->tet_weight[o];
-            const int stype = d->tet_kind[o] == ADMM_TET_SPLINE_STVK ? 1 : d->tet_kind[o] == ADMM_TET_SPLINE_COROTATED ? 2 : 0;
-            auto key = std::make_tuple(d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), kap(o) != 0.0 ? stype : 0);
+            const bool tabulated = d->tet_kind[o] == ADMM_TET_SPLINE_TABLE;
+            const int stype = tabulated ? 3 : d->tet_kind[o] == ADMM_TET_SPLINE_STVK ? 1 : d->tet_kind[o] == ADMM_TET_SPLINE_COROTATED ? 2 : 0;
+            const int table = tabulated ? d->tet_spline[o] : 0;
+            auto key = std::make_tuple(d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), (kap(o) != 0.0 || tabulated) ? stype : 0, table);
             auto it = mat_map.find(key);
-            if (it == mat_map.end()) { it = mat_map.emplace(key, (int)mats.size()).first; mats.push_back(Mat{d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), stype, 0}); }
+            if (it == mat_map.end()) { it = mat_map.emplace(key, (int)mats.size()).first; mats.push_back(Mat{d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), stype, table}); }
             mat[n] = it->second;
         }
         HIP_TRY(c->t_idx.upload(idx)); HIP_TRY(c->t_Binv.upload(Binv)); HIP_TRY(c->t_sc.upload(sc));
         HIP_TRY(c->t_mat.upload(mat)); HIP_TRY(c->mats.upload(mats));
+        if (d->n_spline_tables > 0 && d->spline_tables) {
+            static_assert(kSplineTableDoubles == ADMM_SPLINE_TABLE_DOUBLES && kSplineTableDoubles == admm_host::kSplineTableDoublesH, "spline table layout");
+            HIP_TRY(c->spl_tab.upload(std::vector<double>(d->spline_tables, d->spline_tables + (size_t)d->n_spline_tables * ADMM_SPLINE_TABLE_DOUBLES)));
+        }
         HIP_TRY(c->t_u.alloc((size_t)9 * ld)); HIP_TRY(c->t_u.zero());
         HIP_TRY(c->t_z.alloc((size_t)9 * ld)); HIP_TRY(c->t_z.zero());
         // the chunks' reduction lists and the vertex -> records incidence, on the permuted numbering
@@ -2239,6 +2250,13 @@ int32_t admm_host_component_partition(const admm_hip_desc *d, int world_size, in
     if (!d || !vertex_rank || d->n_verts < 1) return -1;
     return admm_host::component_partition(d->n_verts, d->n_tets, d->tet_idx, d->n_tris, d->tri_idx, std::max(world_size, 1), vertex_rank);
 }
+int admm_host_tabulate_spline(admm_spline_fn fn, void *user, double s_min, double s_max, double *table_out) {
+    const int r = admm_host::tabulate_spline(fn, user, s_min, s_max, table_out);
+    if (r == -1) return fail(ADMM_HIP_ERR_ARG, "tabulate_spline: need a function, a table and 0 < s_min < s_max");
+    if (r == -2) return fail(ADMM_HIP_ERR_ARG, "tabulate_spline: the spline returned a non-finite value inside [s_min, s_max] (and their products)");
+    return ADMM_HIP_OK;
+}
+void admm_host_spline_table_eval(const double *table, int which, double x, double *out3) { admm_host::spline_table_eval(table, which, x, out3); }
 int admm_host_tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol) {
     int r = admm_host::tet_rest(n, idx, verts, Binv, vol);
     if (r) return fail(ADMM_HIP_ERR_GEOMETRY, "TetEnergyTerm Error: Inverted initial tet " + std::to_string(-r - 1));

@@ -586,6 +586,7 @@ __device__ __forceinline__ int minimize_stretch(double mu, double la, double k, 
 struct SplineKappaModel {
     int type;
     double mu, la, k, kappa, x0[3];
+    __device__ __forceinline__ double lower() const { return 0.0; }
     __device__ __forceinline__ bool feasible(const double *s) const {
         if (type == 0) return s[0] > 0.0 && s[1] > 0.0 && s[2] > 0.0;
         return s[0] >= 0.0 && s[1] >= 0.0 && s[2] >= 0.0;
@@ -610,7 +611,8 @@ struct SplineKappaModel {
 };
 // argmin_s Psi(s) + c(J) + k/2 |s - x0|^2: projected, safeguarded Newton with the dense Hessian (Cholesky of the free block,
 // scaled steepest descent when it is not positive definite), Armijo backtracking; iterated until the step is below 1e-9.
-__device__ __forceinline__ int newton_stretch_dense(const SplineKappaModel &m, double *s, int max_it) {
+template <class MODEL>
+__device__ __forceinline__ int newton_stretch_dense(const MODEL &m, double *s, int max_it) {
     double g[3], H[6];
     double f = m.eval(s, g, H);
     const double fscale = 4.0 * (fabs(m.mu) + fabs(m.la) + fabs(m.k));
@@ -619,7 +621,7 @@ __device__ __forceinline__ int newton_stretch_dense(const SplineKappaModel &m, d
     for (; it < max_it; ++it) {
         bool fr[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) fr[i] = !(m.type != 0 && s[i] <= 0.0 && g[i] > 0.0);   // components held at the bound
+        for (int i = 0; i < 3; ++i) fr[i] = !(m.type != 0 && s[i] <= m.lower() && g[i] > 0.0);   // components held at the bound
         // frozen components: unit row / column, zero right-hand side
         const double a00 = fr[0] ? H[0] : 1.0, a11 = fr[1] ? H[3] : 1.0, a22 = fr[2] ? H[5] : 1.0;
         const double a01 = (fr[0] && fr[1]) ? H[1] : 0.0, a02 = (fr[0] && fr[2]) ? H[2] : 0.0, a12 = (fr[1] && fr[2]) ? H[4] : 0.0;
@@ -654,7 +656,7 @@ __device__ __forceinline__ int newton_stretch_dense(const SplineKappaModel &m, d
         if (dmax <= 1e-9 * mag) {   // final correction: apply and stop
             double sn[3];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (m.type != 0) sn[i] = fmax(sn[i], 0.0); }
+            for (int i = 0; i < 3; ++i) { sn[i] = s[i] + d[i]; if (m.type != 0) sn[i] = fmax(sn[i], m.lower()); }
             if (m.feasible(sn)) { s[0] = sn[0]; s[1] = sn[1]; s[2] = sn[2]; }
             ++it;
             break;
@@ -667,7 +669,7 @@ __device__ __forceinline__ int newton_stretch_dense(const SplineKappaModel &m, d
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 sn[i] = fma(t, d[i], s[i]);
-                if (m.type != 0) sn[i] = fmax(sn[i], 0.0);
+                if (m.type != 0) sn[i] = fmax(sn[i], m.lower());
                 gs = fma(g[i], sn[i] - s[i], gs);
             }
             if (m.feasible(sn)) {
@@ -684,6 +686,106 @@ __device__ __forceinline__ int newton_stretch_dense(const SplineKappaModel &m, d
         for (int i = 0; i < 6; ++i) H[i] = Hn[i];
     }
     return it;
+}
+// ---- USER-DEFINED xu::Spline (src/XuSpline.hpp:34-46: any object with f, g, h, df, dg, dh; src/TetEnergyTerm.hpp:197-204) ----
+// The host samples the six functions once (admm_host_tabulate_spline) and the device evaluates the TABLES.  One table per
+// function F in {f, g, h}: kSplineNodes nodes, uniform in t = ln x over [x_lo, x_hi] (stretches are positive and the relative
+// resolution is what matters: f lives on stretches, g on products of two, h on J), per node (F, dF/dt, d2F/dt2) with dF/dt =
+// x F'(x) from the spline's own derivative and the second derivative from central differences of it.  Between nodes: the
+// QUINTIC Hermite interpolant -- C2, so value, gradient and Hessian of the interpolated energy are derivatives of ONE function
+// and the safeguarded Newton iteration above converges on it exactly as on a closed form.  Interpolation error of the gradient:
+// O(dt^5) ~ 1e-10 relative at 1024 nodes.  Outside the table the end node's Taylor quadratic in x continues the function (finite
+// down to x = 0: the polynomial splines are reproduced there to O(x_lo^3); a spline that is singular at 0 is not, and does not
+// need to be -- its minimiser stays away from 0).
+constexpr int kSplineNodes = 1024;
+constexpr int kSplineFnDoubles = 4 + 3 * kSplineNodes;          // {t0, dt, 1 / dt, n} + nodes
+constexpr int kSplineTableDoubles = 3 * kSplineFnDoubles;       // f, g, h
+// F(x), F'(x), F''(x) from one function's table
+__device__ __forceinline__ void spline_table_eval(const double *tab, double x, double &F, double &F1, double &F2) {
+    const double t0 = tab[0], dt = tab[1], idt = tab[2];
+    const int n = (int)tab[3];
+    const double t = t_log(fmax(x, 1e-300));
+    double r = (t - t0) * idt;
+    int i = (int)floor(r);
+    i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+    double u = r - (double)i;
+    const double *a = tab + 4 + 3 * i;
+    double p, pt, ptt;
+    if (u < 0.0 || u > 1.0) {      // outside the table: the Taylor quadratic IN x of the nearest end node (finite down to x = 0)
+        const double *e = u < 0.0 ? a : a + 3;
+        const double xe = exp(u < 0.0 ? t0 : fma(dt, (double)(n - 1), t0)), ixe = 1.0 / xe;
+        const double d1 = e[1] * ixe, d2 = (e[2] - e[1]) * ixe * ixe, dx = x - xe;
+        F = fma(dx, fma(0.5 * dx, d2, d1), e[0]); F1 = fma(dx, d2, d1); F2 = d2;
+        return;
+    } else {
+        const double F0 = a[0], G0 = a[1] * dt, H0 = a[2] * dt * dt, F1n = a[3], G1 = a[4] * dt, H1 = a[5] * dt * dt;
+        // quintic Hermite: p(u) = c0 + c1 u + c2 u^2 + c3 u^3 + c4 u^4 + c5 u^5
+        const double c0 = F0, c1 = G0, c2 = 0.5 * H0;
+        const double dF = F1n - F0;
+        const double c3 = 10.0 * dF - 6.0 * G0 - 4.0 * G1 - 1.5 * H0 + 0.5 * H1;
+        const double c4 = -15.0 * dF + 8.0 * G0 + 7.0 * G1 + 1.5 * H0 - H1;
+        const double c5 = 6.0 * dF - 3.0 * (G0 + G1) - 0.5 * H0 + 0.5 * H1;
+        p = fma(u, fma(u, fma(u, fma(u, fma(u, c5, c4), c3), c2), c1), c0);
+        pt = fma(u, fma(u, fma(u, fma(u, 5.0 * c5, 4.0 * c4), 3.0 * c3), 2.0 * c2), c1) * idt;
+        ptt = fma(u, fma(u, fma(u, 20.0 * c5, 12.0 * c4), 6.0 * c3), 2.0 * c2) * idt * idt;
+    }
+    const double ix = fast_rcp(fmax(x, 1e-300));
+    F = p; F1 = pt * ix; F2 = (ptt - pt) * ix * ix;
+}
+struct SplineTableModel {
+    int type;                 // 1: stretches are kept at or above the table's lower end (projected steps)
+    const double *tab;        // [3][kSplineFnDoubles]
+    double mu, la, k, x0[3], lo;
+    __device__ __forceinline__ double lower() const { return lo; }
+    __device__ __forceinline__ bool feasible(const double *s) const { return s[0] >= lo && s[1] >= lo && s[2] >= lo; }
+    // Psi = sum f(s_i) + sum_{i<j} g(s_i s_j) + h(s_0 s_1 s_2) + k/2 |s - x0|^2 (src/TetEnergyTerm.cpp:243-265), dense Hessian
+    __device__ __forceinline__ double eval(const double *s, double *g, double *H) const {
+        double val = 0.0;
+        const double *tf = tab, *tg = tab + kSplineFnDoubles, *th = tab + 2 * kSplineFnDoubles;
+        double f0, f1, f2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            spline_table_eval(tf, s[i], f0, f1, f2);
+            const double dx = s[i] - x0[i];
+            val += f0 + 0.5 * k * dx * dx;
+            g[i] = fma(k, dx, f1);
+            H[i == 0 ? 0 : i == 1 ? 3 : 5] = f2 + k;
+        }
+        H[1] = 0.0; H[2] = 0.0; H[4] = 0.0;
+        // pairs (0,1), (0,2), (1,2)
+        const int pi[3] = {0, 0, 1}, pj[3] = {1, 2, 2}, ph[3] = {1, 2, 4};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int i = pi[q], j = pj[q];
+            spline_table_eval(tg, s[i] * s[j], f0, f1, f2);
+            val += f0;
+            g[i] = fma(f1, s[j], g[i]); g[j] = fma(f1, s[i], g[j]);
+            H[i == 0 ? 0 : 3] = fma(f2 * s[j], s[j], H[i == 0 ? 0 : 3]);
+            H[j == 1 ? 3 : 5] = fma(f2 * s[i], s[i], H[j == 1 ? 3 : 5]);
+            H[ph[q]] = fma(f2 * s[i], s[j], H[ph[q]]) + f1;
+        }
+        const double J = s[0] * s[1] * s[2];
+        spline_table_eval(th, J, f0, f1, f2);
+        val += f0;
+        const double dJ[3] = {s[1] * s[2], s[2] * s[0], s[0] * s[1]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) g[i] = fma(f1, dJ[i], g[i]);
+        H[0] = fma(f2 * dJ[0], dJ[0], H[0]); H[3] = fma(f2 * dJ[1], dJ[1], H[3]); H[5] = fma(f2 * dJ[2], dJ[2], H[5]);
+        H[1] += fma(f2 * dJ[0], dJ[1], f1 * s[2]); H[2] += fma(f2 * dJ[0], dJ[2], f1 * s[1]); H[4] += fma(f2 * dJ[1], dJ[2], f1 * s[0]);
+        return val;
+    }
+};
+// HyperElasticTet::prox on the stretches (src/TetEnergyTerm.cpp:124-135) for a tabulated (user-defined) spline.  k_scale = a
+// stiffness of the order of the spline's own (the tet's k) for the solver's round-off thresholds.
+__device__ __forceinline__ void prox_stretches_table(const double *tab, double k, double *S) {
+    SplineTableModel m;
+    m.type = 1; m.tab = tab; m.k = k; m.mu = k; m.la = k;
+    m.lo = 0.0;                                           // stretches stay >= 0 (the reference's objective is infinite below, src/TetEnergyTerm.cpp:211-214)
+    m.x0[0] = S[0]; m.x0[1] = S[1]; m.x0[2] = S[2];       // :124 set_x0 (before the fix-ups)
+    const double eps = 1e-6;
+    if (fabs(S[0]) < eps && fabs(S[1]) < eps && fabs(S[2]) < eps) { S[0] = eps; S[1] = eps; S[2] = eps; } // :128-131
+    S[0] = fabs(S[0]); S[1] = fabs(S[1]); S[2] = fabs(S[2]);   // :133
+    newton_stretch_dense(m, S, 200);
 }
 // HyperElasticTet::prox on the stretches (src/TetEnergyTerm.cpp:124-135) for a spline with kappa != 0
 __device__ __forceinline__ void prox_stretches_kappa(int type, double mu, double la, double k, double kappa, double *S) {

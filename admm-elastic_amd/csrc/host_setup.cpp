@@ -256,6 +256,58 @@ int32_t component_partition(int32_t nv, int32_t n_tets, const int32_t *tet_idx, 
     return (int32_t)roots.size();
 }
 
+// ---- tabulated user splines --------------------------------------------------------------------------------------------------
+int tabulate_spline(spline_fn fn, void *user, double s_min, double s_max, double *out) {
+    if (!fn || !out || !(s_min > 0.0) || !(s_max > s_min) || !(s_max < 1e100)) return -1;
+    for (int which = 0; which < 3; ++which) {       // f on stretches, g on products of two, h on products of three
+        const double lo = std::pow(s_min, which + 1), hi = std::pow(s_max, which + 1);
+        double *tab = out + (size_t)which * kSplineFnDoublesH;
+        const double t0 = std::log(lo), dt = (std::log(hi) - t0) / (kSplineNodesH - 1);
+        tab[0] = t0; tab[1] = dt; tab[2] = 1.0 / dt; tab[3] = (double)kSplineNodesH;
+        for (int i = 0; i < kSplineNodesH; ++i) {
+            const double x = std::exp(t0 + dt * i);
+            const double F = fn(user, which, x), d1 = fn(user, which + 3, x);
+            const double e = 1e-5;                  // second derivative: central difference of the spline's own first derivative
+            const double d2 = (fn(user, which + 3, x * (1.0 + e)) - fn(user, which + 3, x * (1.0 - e))) / (2.0 * e * x);
+            if (!std::isfinite(F) || !std::isfinite(d1) || !std::isfinite(d2)) return -2;
+            tab[4 + 3 * i] = F;                     // F(e^t)
+            tab[4 + 3 * i + 1] = x * d1;            // dF/dt   = x F'
+            tab[4 + 3 * i + 2] = x * x * d2 + x * d1;   // d2F/dt2 = x^2 F'' + x F'
+        }
+    }
+    return 0;
+}
+void spline_table_eval(const double *table, int which, double x, double *out3) {
+    const double *tab = table + (size_t)which * kSplineFnDoublesH;
+    const double t0 = tab[0], dt = tab[1], idt = tab[2];
+    const int n = (int)tab[3];
+    const double t = std::log(std::max(x, 1e-300));
+    const double r = (t - t0) * idt;
+    int i = (int)std::floor(r);
+    i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+    const double u = r - (double)i;
+    const double *a = tab + 4 + 3 * i;
+    double p, pt, ptt;
+    if (u < 0.0 || u > 1.0) {      // outside the table: the Taylor quadratic in x of the nearest end node
+        const double *e = u < 0.0 ? a : a + 3;
+        const double xe = std::exp(u < 0.0 ? t0 : t0 + dt * (n - 1));
+        const double d1 = e[1] / xe, d2 = (e[2] - e[1]) / (xe * xe), dx = x - xe;
+        out3[0] = e[0] + dx * (d1 + 0.5 * dx * d2); out3[1] = d1 + dx * d2; out3[2] = d2;
+        return;
+    } else {
+        const double F0 = a[0], G0 = a[1] * dt, H0 = a[2] * dt * dt, F1 = a[3], G1 = a[4] * dt, H1 = a[5] * dt * dt, dF = F1 - F0;
+        const double c0 = F0, c1 = G0, c2 = 0.5 * H0;
+        const double c3 = 10.0 * dF - 6.0 * G0 - 4.0 * G1 - 1.5 * H0 + 0.5 * H1;
+        const double c4 = -15.0 * dF + 8.0 * G0 + 7.0 * G1 + 1.5 * H0 - H1;
+        const double c5 = 6.0 * dF - 3.0 * (G0 + G1) - 0.5 * H0 + 0.5 * H1;
+        p = c0 + u * (c1 + u * (c2 + u * (c3 + u * (c4 + u * c5))));
+        pt = (c1 + u * (2.0 * c2 + u * (3.0 * c3 + u * (4.0 * c4 + u * 5.0 * c5)))) * idt;
+        ptt = (2.0 * c2 + u * (6.0 * c3 + u * (12.0 * c4 + u * 20.0 * c5))) * idt * idt;
+    }
+    const double xx = std::max(x, 1e-300);
+    out3[0] = p; out3[1] = pt / xx; out3[2] = (ptt - pt) / (xx * xx);
+}
+
 // Row order of the incidence lists: inside every window of 512 consecutive vertices the vertices with the most incident
 // elements come first, so the 64 rows of a slice have similar lengths (unstructured 1 M-tet body: 2.17x -> 1.24x stored
 // per real incidence) while a slice still gathers from one neighbourhood of the mesh.

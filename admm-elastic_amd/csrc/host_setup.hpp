@@ -139,6 +139,12 @@ void block_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_
 int32_t component_partition(int32_t n_verts, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int world,
                             int32_t *vertex_rank);
 
+// tabulated user splines (device_math.hpp: spline_table_eval; layout: 3 functions x {t0, dt, 1/dt, n, n x (F, dF/dt, d2F/dt2)})
+constexpr int kSplineNodesH = 1024, kSplineFnDoublesH = 4 + 3 * kSplineNodesH, kSplineTableDoublesH = 3 * kSplineFnDoublesH;
+typedef double (*spline_fn)(void *user, int which, double x);
+int tabulate_spline(spline_fn fn, void *user, double s_min, double s_max, double *table_out);
+void spline_table_eval(const double *table, int which, double x, double *out3);
+
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
 int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
 void lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);

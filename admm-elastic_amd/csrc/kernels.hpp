@@ -19,7 +19,7 @@ namespace admm_k {
 
 using namespace admm_dev;
 
-struct Mat { double mu, la, k, kappa; int type, pad_; };   // kappa / type: SplineTet splines with a compression term (KIND 4)
+struct Mat { double mu, la, k, kappa; int type, table; };   // KIND 4: type 0..2 = xu:: spline with a compression term kappa; type 3 = tabulated (user-defined) spline `table`
 
 constexpr int kMaxObst = 8;
 struct Obstacles {
@@ -188,6 +188,7 @@ struct TetArgs {
     const int4 *idx; const double *Binv; double *u; double *z; const double *sc; const int *mat_id; const Mat *mats;
     const double *x;
     const unsigned short *ch_ent; const int *ch_group, *ch_rec; double *rec; int chunk0;   // chunk plan, records [n_rec + 1][4], first chunk of this launch
+    const double *spl;        // tabulated user splines (device_math.hpp: kSplineTableDoubles each), KIND 4 / Mat::type 3
     // kernel-level timing (stats only): every wave stores the device wall clock at entry in ts[wave slot] and at exit in
     // ts[ts_n + wave slot]; nullptr = off.  max(exit) - min(entry) is the launch's
     // duration as rocprofv3 reports it, without the dispatch gaps an event pair around the launch also counts.
@@ -359,7 +360,8 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
         prox_stretches<0>(0.0, 0.0, 0.0, S1);
     } else if (KIND == 4) {   // xu:: spline with kappa != 0 (dense-Hessian Newton; rare, not tuned)
         const Mat mt = mats[in.mid];
-        prox_stretches_kappa(mt.type, mt.mu, mt.la, mt.k, mt.kappa, S1);
+        if (mt.type == 3) prox_stretches_table(a.spl + (size_t)mt.table * kSplineTableDoubles, mt.k, S1);
+        else prox_stretches_kappa(mt.type, mt.mu, mt.la, mt.k, mt.kappa, S1);
     } else {
         // NH, StVK and the co-rotated spline fit 4 waves/SIMD (128 VGPRs) with V out of the way during the stretch
         // minimisation AND the general Newton loop outlined (device_math.hpp: newton_stretch_general) -- inlined, that rare

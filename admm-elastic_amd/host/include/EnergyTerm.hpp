@@ -37,6 +37,7 @@ struct FlatTerm {
     int kind;           // ADMM_TET_*
     double mu, lambda, k, limit_min, limit_max;
     double kappa = 0.0; // SplineTet: compression term of the xu:: spline (src/XuSpline.hpp:43-45)
+    const void *user_spline = nullptr;   // SplineTet with a user-defined xu::Spline (kind ADMM_TET_SPLINE_TABLE): the object to tabulate
     double pin[3];
     int active;
 };

@@ -45,15 +45,15 @@ protected:
 };
 
 // src/TetEnergyTerm.hpp:176-206.  Defaults to xu::NeoHookean(mu, lambda, 0) like the reference (:191-195); the second
-// constructor takes one of the reference's splines (XuSpline.hpp), with or without compression term.  A user-defined
-// spline has no GPU kernel: flatten() returns false and Solver::initialize says so.
+// constructor takes any xu::Spline (XuSpline.hpp): the reference's three with or without compression term run closed-form
+// kernels, a user-defined one is tabulated by Solver::initialize and runs the table kernel (ADMM_TET_SPLINE_TABLE).
 class SplineTet : public NeoHookeanTet {
 public:
     SplineTet(const Vec4i &tet, const std::vector<Vec3> &verts, const Lame &lame)
         : NeoHookeanTet(tet, verts, lame), spline(std::make_shared<xu::NeoHookean>(lame.mu, lame.lambda, 0.0)) {}
     SplineTet(const Vec4i &tet, const std::vector<Vec3> &verts, const Lame &lame, std::shared_ptr<xu::Spline> spline_)
         : NeoHookeanTet(tet, verts, lame), spline(spline_) {}
-    int kind() const { int kd = 3; double m, l, kp; spline->flatten(kd, m, l, kp); return kd; }
+    int kind() const { int kd = 3; double m, l, kp; return spline->flatten(kd, m, l, kp) ? kd : 6; }
     bool flatten(FlatTerm &out) const;
     std::shared_ptr<xu::Spline> spline;
 protected:

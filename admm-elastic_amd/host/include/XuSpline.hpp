@@ -3,8 +3,9 @@
 // The interface (xu::Spline with f / g / h and their derivatives) and the three named splines keep the reference's
 // names and constructor arguments.  On the GPU each named spline with kappa = 0 IS one of the closed-form stretch models
 // (NeoHookean -> NH, StVK -> StVK, CoRotated -> co-rotated linear), which is how SplineTet::flatten hands it to the
-// kernels; the host-side f / g / h below only serve EnergyTerm::energy.  A spline with kappa != 0, or a user-defined
-// subclass, has no kernel: Solver::initialize rejects it (no CPU fallback).
+// kernels; the host-side f / g / h below only serve EnergyTerm::energy.  A USER-DEFINED subclass (any object with the six
+// functions, as in the reference) is sampled once by Solver::initialize (admm_host_tabulate_spline over stretches in
+// [table_min, table_max]) and evaluated on the device from its tables: no CPU fallback, no restriction to the three named splines.
 #ifndef ADMM_XUSPLINE_HPP
 #define ADMM_XUSPLINE_HPP 1
 
@@ -25,11 +26,13 @@ public:
     // compression term of the paper's Eq. 16 and its derivative as the reference evaluates them (src/XuSpline.hpp:44-45)
     static double compress_term(double kappa, double x) { const double t = (1.0 - x) / 6.0; return kappa * t * t * t / 12.0; }
     static double d_compress_term(double kappa, double x) { const double t = (1.0 - x) / 6.0; return -kappa * t * t / 24.0; }
-    // GPU description: ADMM_TET_SPLINE_* kind, the spline's Lame constants and compression term; false = no kernel for this
-    // (user-defined) spline
+    // GPU description: ADMM_TET_SPLINE_* kind, the spline's Lame constants and compression term; false = not one of the named
+    // splines: the solver tabulates it (ADMM_TET_SPLINE_TABLE)
     virtual bool flatten(int &kind, double &mu_out, double &lambda_out, double &kappa_out) const {
         (void)kind; (void)mu_out; (void)lambda_out; (void)kappa_out; return false;
     }
+    // range of principal stretches the table of a user-defined spline covers (outside it the end nodes' quadratics continue)
+    double table_min = 0.02, table_max = 50.0;
 };
 
 namespace detail {

@@ -6,6 +6,7 @@
 #include "TriEnergyTerm.hpp"
 #include "../../../include/admm_hip.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -21,7 +22,9 @@ void check(int rc, const char *what) {
 
 // gathers flat arrays for admm_hip_desc
 struct Flat {
-    std::vector<int32_t> tet_idx, tet_kind, tri_idx, pin_vert, pin_active;
+    std::vector<int32_t> tet_idx, tet_kind, tri_idx, pin_vert, pin_active, tet_spline;
+    std::vector<const void *> splines;      // distinct user-defined splines, in order of first use
+    std::vector<double> spline_tables;
     std::vector<double> tet_Binv, tet_w, tet_mu, tet_la, tet_k, tet_kappa, tri_rest, tri_w, tri_lmin, tri_lmax, pin_xyz;
     double pin_weight = 0.0;
     void add(const FlatTerm &t) {
@@ -30,6 +33,12 @@ struct Flat {
             for (int i = 0; i < 9; ++i) tet_Binv.push_back(t.mat[i]);
             tet_w.push_back(t.weight); tet_kind.push_back(t.kind); tet_mu.push_back(t.mu); tet_la.push_back(t.lambda); tet_k.push_back(t.k);
             tet_kappa.push_back(t.kappa);
+            int tab = 0;
+            if (t.kind == ADMM_TET_SPLINE_TABLE) {
+                tab = (int)(std::find(splines.begin(), splines.end(), t.user_spline) - splines.begin());
+                if (tab == (int)splines.size()) splines.push_back(t.user_spline);
+            }
+            tet_spline.push_back(tab);
         } else if (t.type == FlatTerm::TRI) {
             for (int i = 0; i < 3; ++i) tri_idx.push_back(t.idx[i]);
             for (int i = 0; i < 4; ++i) tri_rest.push_back(t.mat[i]);
@@ -40,10 +49,24 @@ struct Flat {
             pin_active.push_back(t.active); pin_weight = t.weight;
         }
     }
+    // samples every distinct user-defined spline (src/XuSpline.hpp:34-46) into its device table
+    void tabulate() {
+        spline_tables.assign(splines.size() * (size_t)ADMM_SPLINE_TABLE_DOUBLES, 0.0);
+        for (size_t i = 0; i < splines.size(); ++i) {
+            const xu::Spline *sp = (const xu::Spline *)splines[i];
+            auto cb = [](void *user, int which, double x) -> double {
+                const xu::Spline *q = (const xu::Spline *)user;
+                return which == 0 ? q->f(x) : which == 1 ? q->g(x) : which == 2 ? q->h(x) : which == 3 ? q->df(x) : which == 4 ? q->dg(x) : q->dh(x);
+            };
+            if (admm_host_tabulate_spline(cb, (void *)sp, sp->table_min, sp->table_max, &spline_tables[i * (size_t)ADMM_SPLINE_TABLE_DOUBLES]) != ADMM_HIP_OK)
+                throw std::runtime_error(std::string("Solver::initialize: ") + admm_hip_last_error());
+        }
+    }
     void fill(admm_hip_desc &d) const {
         d.n_tets = (int32_t)tet_w.size();
         d.tet_idx = tet_idx.data(); d.tet_Binv = tet_Binv.data(); d.tet_weight = tet_w.data(); d.tet_kind = tet_kind.data();
         d.tet_mu = tet_mu.data(); d.tet_lambda = tet_la.data(); d.tet_k = tet_k.data(); d.tet_kappa = tet_kappa.data();
+        d.n_spline_tables = (int32_t)splines.size(); d.spline_tables = spline_tables.data(); d.tet_spline = tet_spline.data();
         d.n_tris = (int32_t)tri_w.size();
         d.tri_idx = tri_idx.data(); d.tri_rest = tri_rest.data(); d.tri_weight = tri_w.data();
         d.tri_limit_min = tri_lmin.data(); d.tri_limit_max = tri_lmax.data();
@@ -84,6 +107,7 @@ void EnergyTerm::update(const SparseMat &D, const VecX &x, VecX &z, VecX &u) {
         admm_hip_desc d;
         std::memset(&d, 0, sizeof(d));
         d.struct_size = sizeof(d); d.n_verts = nv; d.masses = masses.data(); d.dt = 1.0; d.linsolver = 0; d.gs_tol = -1.0;
+        f.tabulate();
         f.fill(d);
         admm_hip_ctx *ctx = nullptr;
         check(admm_hip_create(&d, &ctx), "EnergyTerm::update");
@@ -202,7 +226,11 @@ double StVKTet::energy(const VecX &F) { // src/TetEnergyTerm.cpp:220-226
 bool SplineTet::flatten(FlatTerm &o) const {
     if (!TetEnergyTerm::flatten(o)) return false;
     int kd = 0; double m = 0, l = 0, kp = 0;
-    if (!spline || !spline->flatten(kd, m, l, kp)) return false;   // a user-defined spline: no kernel
+    if (!spline) return false;
+    if (!spline->flatten(kd, m, l, kp)) {     // a user-defined spline: Solver::initialize tabulates the object
+        o.kind = ADMM_TET_SPLINE_TABLE; o.user_spline = spline.get(); o.kappa = 0.0;
+        return true;
+    }
     o.kind = kd; o.mu = m; o.lambda = l; o.kappa = kp;             // the spline's constants; k stays the tet's (TetEnergyTerm.hpp:192-204)
     return true;
 }
@@ -346,6 +374,7 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
     d.struct_size = sizeof(d); d.device = device;
     d.n_verts = dof / 3; d.masses = m_masses.data(); d.dt = m_settings.timestep_s;
     d.vert_xyz = m_x.data();      // smooth coordinates for the coarse space of the on-chip PCG (the solve does not depend on them)
+    flat.tabulate();              // user-defined xu::Spline objects -> device tables
     flat.fill(d);
     // pins that are not energy terms (linsolver 1) go through the in-sweep pin list
     std::vector<int32_t> gs_v; std::vector<double> gs_p;

@@ -11,7 +11,7 @@ import numpy as np
 from . import capi
 from .capi import AdmmHipError, Desc, Stats, check, dptr, f64, i32, iptr, lib
 
-TET_LINEAR, TET_NEOHOOKEAN, TET_STVK, TET_SPLINE_NH, TET_SPLINE_STVK, TET_SPLINE_COROTATED = 0, 1, 2, 3, 4, 5
+TET_LINEAR, TET_NEOHOOKEAN, TET_STVK, TET_SPLINE_NH, TET_SPLINE_STVK, TET_SPLINE_COROTATED, TET_SPLINE_TABLE = 0, 1, 2, 3, 4, 5, 6
 LS_LDLT, LS_NCMCGS, LS_UZAWACG = 0, 1, 2
 
 
@@ -120,7 +120,8 @@ class Solver:
         self.m_x = np.zeros(0)
         self.m_v = np.zeros(0)
         self.m_masses = np.zeros(0)
-        self._tets = []   # (idx[n,4], Binv[n,9], weight[n], kind[n], mu[n], la[n], k[n])
+        self._tets = []   # (idx[n,4], Binv[n,9], weight[n], kind[n], mu[n], la[n], k[n], kappa[n], spline table[n])
+        self._user_splines = []   # user-defined xu::Spline objects (TET_SPLINE_TABLE), in order of first use
         self._tris = []   # (idx[n,3], rest[n,4], weight[n], lmin[n], lmax[n])
         self._pins = {}   # vertex -> xyz   (ConstraintSet::pins)
         self._obstacles = []
@@ -164,9 +165,21 @@ class Solver:
         k = lame.bulk_modulus()
         n = inds.shape[0]
         w = np.sqrt(k * vol)
-        sp = spline if spline is not None else lame
+        table = 0
+        if kind == TET_SPLINE_TABLE:
+            # SplineTet(tet, verts, lame, shared_ptr<xu::Spline>) with a USER-DEFINED spline (src/TetEnergyTerm.hpp:197-204): any
+            # object with f, g, h, df, dg, dh (src/XuSpline.hpp:34-46); sampled once into a device table
+            if spline is None or not all(hasattr(spline, a) for a in ("f", "g", "h", "df", "dg", "dh")):
+                raise AdmmHipError(-1, "TET_SPLINE_TABLE needs a spline object with f, g, h, df, dg, dh")
+            if not any(spline is sp for sp in self._user_splines):
+                self._user_splines.append(spline)
+            table = [i for i, sp in enumerate(self._user_splines) if sp is spline][0]
+            sp = lame
+        else:
+            sp = spline if spline is not None else lame
         self._tets.append((inds + vertex_offset, Binv, w, np.full(n, kind, np.int32), np.full(n, sp.mu),
-                           np.full(n, sp.lambda_), np.full(n, k), np.full(n, float(kappa) if kind >= TET_SPLINE_NH else 0.0)))
+                           np.full(n, sp.lambda_), np.full(n, k), np.full(n, float(kappa) if TET_SPLINE_NH <= kind <= TET_SPLINE_COROTATED else 0.0),
+                           np.full(n, table, np.int32)))
         return n
 
     def add_tris(self, verts, inds, lame, vertex_offset=0):
@@ -239,7 +252,7 @@ class Solver:
         out = dict(
             tet_idx=cat(T, 0, (0, 4), np.int32), tet_Binv=cat(T, 1, (0, 9), np.float64), tet_weight=cat(T, 2, (0,), np.float64),
             tet_kind=cat(T, 3, (0,), np.int32), tet_mu=cat(T, 4, (0,), np.float64), tet_lambda=cat(T, 5, (0,), np.float64),
-            tet_k=cat(T, 6, (0,), np.float64), tet_kappa=cat(T, 7, (0,), np.float64),
+            tet_k=cat(T, 6, (0,), np.float64), tet_kappa=cat(T, 7, (0,), np.float64), tet_spline=cat(T, 8, (0,), np.int32),
             tri_idx=cat(R, 0, (0, 3), np.int32), tri_rest=cat(R, 1, (0, 4), np.float64), tri_weight=cat(R, 2, (0,), np.float64),
             tri_limit_min=cat(R, 3, (0,), np.float64), tri_limit_max=cat(R, 4, (0,), np.float64),
             pin_vert=i32(list(self._pins.keys())),
@@ -262,6 +275,17 @@ class Solver:
         d.tet_idx, d.tet_Binv, d.tet_weight = iptr(f["tet_idx"]), dptr(f["tet_Binv"]), dptr(f["tet_weight"])
         d.tet_kind, d.tet_mu, d.tet_lambda, d.tet_k = iptr(f["tet_kind"]), dptr(f["tet_mu"]), dptr(f["tet_lambda"]), dptr(f["tet_k"])
         d.tet_kappa = dptr(f["tet_kappa"]) if f["tet_kappa"].any() else None
+        if self._user_splines:          # tabulate every user-defined spline (admm_host_tabulate_spline)
+            nd = capi.SPLINE_TABLE_DOUBLES
+            self._spline_tables = np.zeros((len(self._user_splines), nd))
+            for i, sp in enumerate(self._user_splines):
+                fns = (sp.f, sp.g, sp.h, sp.df, sp.dg, sp.dh)
+                cb = capi.SPLINE_FN(lambda user, which, x, fns=fns: float(fns[which](x)))
+                check(lib().admm_host_tabulate_spline(cb, None, float(getattr(sp, "table_min", 0.02)), float(getattr(sp, "table_max", 50.0)),
+                                                      dptr(self._spline_tables[i])))
+            d.n_spline_tables = len(self._user_splines)
+            d.spline_tables = dptr(self._spline_tables)
+            d.tet_spline = iptr(f["tet_spline"])
         self._xyz_c = f64(self.m_x).copy()           # smooth coordinates for the coarse space of the on-chip PCG (desc.vert_xyz)
         d.vert_xyz = dptr(self._xyz_c) if self._xyz_c.size == dof else None
         d.n_tris = f["tri_idx"].shape[0]

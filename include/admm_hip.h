@@ -45,7 +45,10 @@ typedef enum {
  * the SPLINE's constants, tet_kappa its compression term (src/XuSpline.hpp:44-45; 0 = none), tet_k the tet's bulk modulus
  * (src/TetEnergyTerm.hpp:192-204).  User-defined splines have no kernel. */
 enum { ADMM_TET_LINEAR = 0, ADMM_TET_NEOHOOKEAN = 1, ADMM_TET_STVK = 2, ADMM_TET_SPLINE_NH = 3, ADMM_TET_SPLINE_STVK = 4,
-       ADMM_TET_SPLINE_COROTATED = 5 };
+       ADMM_TET_SPLINE_COROTATED = 5,
+       ADMM_TET_SPLINE_TABLE = 6 };   /* SplineTet with a USER-DEFINED xu::Spline (src/TetEnergyTerm.hpp:197-204, src/XuSpline.hpp:34-46):
+                                       * the spline's six functions sampled by admm_host_tabulate_spline, desc.tet_spline = its table */
+#define ADMM_SPLINE_TABLE_DOUBLES 9228   /* doubles of one table: 3 functions x (4 header + 3 x 1024 node values) */
 
 /* global solvers -- Solver::Settings::linsolver, src/Solver.hpp:46 ("0=LDLT, 1=NCMCGS, 2=UzawaCG").
  * 0: the prefactored LDLT (src/LinearSolver.hpp:59-92) is replaced by a preconditioned CG (Jacobi, or a block-local
@@ -131,6 +134,13 @@ typedef struct {
      * modes that dominate the POSITION error of an iterate are represented to second order.  NULL = piecewise constants.
      * The solution of the system does not depend on it (a preconditioner). */
     const double *vert_xyz;
+
+    /* Tabulated user splines (ADMM_TET_SPLINE_TABLE): n_spline_tables tables of ADMM_SPLINE_TABLE_DOUBLES doubles each, made by
+     * admm_host_tabulate_spline; tet_spline [n_tets]: table of every tet (read for that kind only).  tet_mu / tet_lambda of such
+     * tets are not used; tet_k is the tet's bulk modulus as for every kind. */
+    int32_t n_spline_tables;
+    const double *spline_tables;
+    const int32_t *tet_spline;
 } admm_hip_desc;
 
 /* Maps 1:1 onto Solver::RuntimeData (src/Solver.hpp:54-61) plus GPU-side extras. */
@@ -261,6 +271,17 @@ int admm_hip_get_colors(const admm_hip_ctx *ctx, int32_t *color, int32_t *n_colo
 int admm_hip_comm_unique_id(char *id128);                                   /* ncclGetUniqueId */
 int admm_hip_comm_init(admm_hip_ctx *ctx, const char *id128, int rank, int world_size);
 void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end);
+
+/* A user-defined xu::Spline on the device (src/XuSpline.hpp:34-46 is an interface of six virtual functions; the reference calls them
+ * inside its L-BFGS, src/TetEnergyTerm.cpp:243-265).  `fn(user, which, x)` returns f, g, h, df, dg, dh (which = 0..5) at x > 0;
+ * the functions are sampled over stretches in [s_min, s_max] (f), their pairwise products (g) and triple products (h) on grids
+ * uniform in ln x, second derivatives by central differences of df / dg / dh, into table_out [ADMM_SPLINE_TABLE_DOUBLES].  The
+ * kernels evaluate the C2 quintic Hermite interpolant (relative error of the energy gradient ~1e-10 for splines as smooth as
+ * the reference's).  Returns ADMM_HIP_ERR_ARG for a bad range or a non-finite sample.  admm_host_spline_table_eval evaluates a
+ * table as the device does: out3 = {F, F', F''} of function which (0 f, 1 g, 2 h) at x (tests). */
+typedef double (*admm_spline_fn)(void *user, int which, double x);
+int admm_host_tabulate_spline(admm_spline_fn fn, void *user, double s_min, double s_max, double *table_out);
+void admm_host_spline_table_eval(const double *table, int which, double x, double *out3);
 
 /* Multi-GPU, component-aware partition (the reference has no distributed layer).  When a scene has at least
  * world_size connected components (bodies that share no vertex), admm_hip_create gives every rank WHOLE bodies: its context

@@ -283,6 +283,83 @@ def test_spline_tets_with_compression_term(kind):
     assert scenes.rel_err(s.m_x, o.x) < 1e-7, scenes.rel_err(s.m_x, o.x)
 
 
+class _UserSpline:
+    """An xu::Spline the library knows nothing about (src/XuSpline.hpp:34-46): the six functions of one of the reference's splines
+    WITH its compression term, re-stated in Python -- so the oracle can evaluate the same spline analytically."""
+    def __init__(self, which, mu, la, kappa):
+        self.which, self.mu, self.la, self.kappa = which, mu, la, kappa
+
+    def _c(self, x):
+        t = (1.0 - x) / 6.0
+        return self.kappa * t ** 3 / 12.0
+
+    def _dc(self, x):
+        t = (1.0 - x) / 6.0
+        return -self.kappa * t * t / 24.0
+
+    def f(self, s):
+        mu, la = self.mu, self.la
+        return [mu * (s * s - 1) / 2, la * (s ** 4 - 6 * s * s + 5) / 8 + mu * (s * s - 1) ** 2 / 4, la * (s * s - 6 * s + 5) / 2 + mu * (s - 1) ** 2][self.which]
+
+    def df(self, s):
+        mu, la = self.mu, self.la
+        return [mu * s, la * (s ** 3 - 3 * s) / 2 + mu * s * (s * s - 1), la * (s - 3) + 2 * mu * (s - 1)][self.which]
+
+    def g(self, p):
+        return [0.0, self.la * (p * p - 1) / 4, self.la * (p - 1)][self.which]
+
+    def dg(self, p):
+        return [0.0, self.la * p / 2, self.la][self.which]
+
+    def h(self, J):
+        v = self._c(J)
+        if self.which == 0:
+            lJ = np.log(J); v += lJ * (self.la * lJ / 2 - self.mu)
+        return v
+
+    def dh(self, J):
+        v = self._dc(J)
+        if self.which == 0:
+            v += (self.la * np.log(J) - self.mu) / J
+        return v
+
+
+@pytest.mark.parametrize("which", [0, 1, 2])
+def test_user_defined_spline_tets(which):
+    """SplineTet with a USER-DEFINED xu::Spline (src/TetEnergyTerm.hpp:197-204): the six functions are sampled into device tables
+    (admm_host_tabulate_spline; C2 quintic Hermite in ln x) and minimised by the dense-Hessian Newton of the kappa splines.
+    Against the oracle evaluating the SAME spline analytically (kinds TET_SPLINE_* with kappa): kernel-level local step on
+    stretched, compressed and inverted tets, and whole steps.  Tolerance = the table's: the interpolated energy gradient is
+    accurate to ~1e-10 relative, the minimiser to ~1e-8 of a stretch (stated, not hidden)."""
+    kd = [pkg.TET_SPLINE_NH, pkg.TET_SPLINE_STVK, pkg.TET_SPLINE_COROTATED][which]
+    sc = scenes.cube_scene(4, kd, admm_iters=10, linsolver=0)
+    verts, tets, lame, _, off = sc.tets[0]
+    spl = Lame(2.0e7, 0.3)
+    kappa = 40.0 * spl.mu
+    user = _UserSpline(which, spl.mu, spl.lambda_, kappa)
+    s = pkg.Solver()
+    s.add_nodes(sc.x, sc.masses3())
+    s.add_tets(verts, tets, lame, pkg.TET_SPLINE_TABLE, spline=user)
+    s.set_pins(list(sc.pins.keys()), [sc.pins[k] for k in sc.pins])
+    st = scenes.Settings(**sc.settings); st.pcg_tol = 1e-11; st.pcg_max_iters = 400
+    assert s.initialize(st)
+    o = orc.OracleSolver(sc.x, sc.masses3(), admm_iters=10, linsolver=0, pins=sc.pins, mode=1,
+                         tets=dict(idx=tets, verts=sc.x, kind=np.full(len(tets), kd, np.int32), mu=spl.mu, la=spl.lambda_,
+                                   k=lame.bulk_modulus(), kappa=kappa))
+    rng = np.random.default_rng(12)
+    x = (sc.x * np.array([0.7, 1.2, 0.8]) + 0.03 * rng.standard_normal(sc.x.shape))
+    x[5] = x[5] + np.array([0.9, -0.4, 0.3])          # drags its tets through inversion
+    u0 = np.zeros(s.num_rows()); u0[:9 * len(tets)] = 0.02 * rng.standard_normal(9 * len(tets))
+    z, u = s.local_step(x.ravel(), u0)
+    zo = np.zeros(o.R); uo = u0.copy()
+    o.local_step(x.ravel(), zo, uo)
+    assert np.abs(z - zo).max() < 2e-7 and np.abs(u - uo).max() < 2e-7, (np.abs(z - zo).max(), np.abs(u - uo).max())
+    for _ in range(3):
+        s.step(); o.step()
+    assert scenes.rel_err(s.m_x, o.x) < 1e-6, scenes.rel_err(s.m_x, o.x)
+    assert np.abs(s.m_x - sc.x.ravel()).max() > 1e-3
+
+
 def test_tet_order_does_not_matter():
     """The library sorts the tets it is given (by model, then by lowest vertex index: memory-coherent gathers whatever
     order a mesh file lists them in); outputs keep the CALLER's row order.  Shuffled input = same z / u rows, same step."""

@@ -177,3 +177,35 @@ def test_chunk_reduction_plan_sums_every_corner_force_once(case):
         assert st["max_passes"] <= 2 and st["records"] < 0.3 * 4 * nt and st["max_list"] <= 16, st
     if case == "shuffled":
         assert st["max_passes"] > 1, st
+
+
+def test_spline_tables_reproduce_the_spline():
+    """admm_host_tabulate_spline / admm_host_spline_table_eval (the device evaluates the same interpolant, csrc/device_math.hpp:
+    spline_table_eval): a user-defined xu::Spline (here xu::StVK with a compression term, re-stated) is reproduced by its tables --
+    value to 1e-11, first derivative to 1e-9, second (from central differences of the first) to 1e-5, relative to the spline's
+    stiffness, over the whole table range; a quadratic continues the function outside; bad ranges and non-finite samples refuse."""
+    import ctypes as C
+    import pytest
+    L = capi.lib()
+    mu, la, kap = 3.0e5, 7.0e5, 2.0e5
+    fns = [lambda s: la * (s ** 4 - 6 * s * s + 5) / 8 + mu * (s * s - 1) ** 2 / 4, lambda p: la * (p * p - 1) / 4, lambda J: kap * ((1 - J) / 6) ** 3 / 12,
+           lambda s: la * (s ** 3 - 3 * s) / 2 + mu * s * (s * s - 1), lambda p: la * p / 2, lambda J: -kap * ((1 - J) / 6) ** 2 / 24]
+    d2 = [lambda s: la * (3 * s * s - 3) / 2 + mu * (3 * s * s - 1), lambda p: la / 2, lambda J: kap * ((1 - J) / 6) / 72]
+    cb = capi.SPLINE_FN(lambda u, w, x: float(fns[w](x)))
+    tab = np.zeros(capi.SPLINE_TABLE_DOUBLES)
+    capi.check(L.admm_host_tabulate_spline(cb, None, 0.02, 50.0, capi.dptr(tab)))
+    out = np.zeros(3); worst = np.zeros(3)
+    rng = np.random.default_rng(0)
+    for which in range(3):
+        for x in np.exp(rng.uniform(np.log(0.02 ** (which + 1)), np.log(50.0 ** (which + 1)), 1500)):
+            L.admm_host_spline_table_eval(capi.dptr(tab), which, float(x), capi.dptr(out))
+            ref = np.array([fns[which](x), fns[which + 3](x), d2[which](x)])
+            worst = np.maximum(worst, np.abs(out - ref) / (np.abs(ref) + mu))
+    assert worst[0] < 1e-11 and worst[1] < 1e-9 and worst[2] < 1e-5, worst
+    L.admm_host_spline_table_eval(capi.dptr(tab), 0, 60.0, capi.dptr(out))          # beyond the table: C1 continuation, finite
+    assert np.isfinite(out).all() and abs(out[1] - fns[3](60.0)) < 0.2 * abs(fns[3](60.0))
+    with pytest.raises(capi.AdmmHipError):
+        capi.check(L.admm_host_tabulate_spline(cb, None, 2.0, 1.0, capi.dptr(tab)))
+    bad = capi.SPLINE_FN(lambda u, w, x: float("nan"))
+    with pytest.raises(capi.AdmmHipError):
+        capi.check(L.admm_host_tabulate_spline(bad, None, 0.02, 50.0, capi.dptr(tab)))
