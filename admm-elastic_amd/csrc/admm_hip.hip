@@ -217,8 +217,14 @@ struct admm_hip_ctx {
     DevBuf<double> rc_buf, rc_r0, rc_xs, rc_part, rc_coef;
     int rc_iter = 0, rc_frame = 0, rc_prev_valid = 0, NBR = 1; // pairs of the previous frame valid for s < rc_prev_valid
     bool rc_enabled = true;
-    double *rc_E(int s) { return rc_buf.p + ((size_t)(s % kRcSlots) * 2 + 0) * (size_t)n3i; }
-    double *rc_R(int s) { return rc_buf.p + ((size_t)(s % kRcSlots) * 2 + 1) * (size_t)n3i; }
+    // Slots: the pairs of the FIRST kRc solves of a frame have slots of their own (0 .. kRc - 1), later solves share a ring of
+    // kRcSlots behind them.  Slot j < kRc therefore keeps "the most recent pair of solve index j" across the frame boundary: when
+    // solve s < kRc of the next frame starts, slots 0 .. s - 1 hold this frame's pairs and slots s .. kRc - 1 still the PREVIOUS
+    // frame's -- which it projects on as well (launch_pcg_recycled).
+    static constexpr int kRcAllSlots = kRc + kRcSlots;
+    static int rc_slot(int s) { return s < kRc ? s : kRc + (s - kRc) % kRcSlots; }
+    double *rc_E(int s) { return rc_buf.p + ((size_t)rc_slot(s) * 2 + 0) * (size_t)n3i; }
+    double *rc_R(int s) { return rc_buf.p + ((size_t)rc_slot(s) * 2 + 1) * (size_t)n3i; }
     // UzawaCG (per-vertex constraint rows)
     DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part, uz_dmax; DevBuf<long long> uz_dacc;   // uz_dacc / uz_dmax: dyn_collide.hpp, k_uz_ct_dyn
     DevBuf<UzScal> uz_scal;
@@ -705,6 +711,15 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     // index was measured: it does not help the first solves of a frame.)
     static const int rc_pairs = [] { const char *e = getenv("ADMM_HIP_RC_PAIRS"); return e ? std::max(0, std::min(kRc, atoi(e))) : kRc; }();   // (A/B: fewer pairs)
     for (int j = 1; j <= rc_pairs && s - j >= 0; ++j) { B.E[B.cnt] = c->rc_E(s - j); B.R[B.cnt] = c->rc_R(s - j); ++B.cnt; }
+    // The first solves of a frame have few pairs of their own (the very first none: 85 of the 194 PCG iterations of a blob1m_mix
+    // frame were its).  The free places of the basis go to the PREVIOUS frame's pairs of the same and the following solve indices
+    // (slots s .. kRc - 1, not yet overwritten): in steady motion the first corrections of consecutive frames are nearly
+    // parallel.  (E, A E) pairs stay exact whatever the state does -- the matrix of a scene never changes -- so this can only
+    // help or do nothing.  Round 1 measured "no gain" for this with the Jacobi preconditioner; with the two-level one the CPU
+    // prototype (experiments/first_solve_proto.py) gives 53 -> 19..26 iterations for the first solve, 30 -> 11..17 for the second.
+    static const bool rc_prev = [] { const char *e = getenv("ADMM_HIP_RC_PREV"); return !(e && e[0] == '0'); }();
+    if (rc_prev)
+        for (int q = s; q < kRc && q < c->rc_prev_valid && B.cnt < rc_pairs; ++q) { B.E[B.cnt] = c->rc_E(q); B.R[B.cnt] = c->rc_R(q); ++B.cnt; }
     static const bool rc_kernels = getenv("ADMM_HIP_RC_KERNELS") && getenv("ADMM_HIP_RC_KERNELS")[0] == '1';   // A/B: separate k_rc_* launches
     if (c->oc_enabled && (!rc_kernels || c->oc_plan)) {   // (the plan's pairs live in its internal row order: k_rc_* cannot read them)   // projection, solve and the new pair in ONE persistent launch
         OcRc rc; rc.on = true; rc.B = B; rc.Eslot = c->rc_E(s); rc.Rslot = c->rc_R(s);
@@ -1408,7 +1423,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         c->NBR = std::max(1, std::min((nv + 255) / 256, 256));
         c->n3i = std::max(c->n3, 3 * c->oc_rows);
         if (c->rc_enabled) {
-            HIP_TRY(c->rc_buf.alloc((size_t)admm_hip_ctx::kRcSlots * 2 * c->n3i));
+            HIP_TRY(c->rc_buf.alloc((size_t)admm_hip_ctx::kRcAllSlots * 2 * c->n3i));
             HIP_TRY(c->rc_r0.alloc(c->n3i)); HIP_TRY(c->rc_xs.alloc(c->n3i));
             HIP_TRY(c->rc_part.alloc((size_t)3 * kRcQ * c->NBR)); HIP_TRY(c->rc_coef.alloc(3 * kRc)); HIP_TRY(c->rc_coef.zero());
         }
@@ -1528,7 +1543,7 @@ static int set_state_impl(admm_hip_ctx *c, const double *x, const double *v) {
     else HIP_TRY(hipMemsetAsync(c->v.p, 0, c->n3 * sizeof(double), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->h_sig && c->h_sig[2]) {   // the steps before this call hit a barrier time-out; their result is overwritten anyway
-        c->h_sig[2] = 0; c->oc_gave_up = true; c->oc_enabled = false;
+        c->h_sig[2] = 0; c->oc_gave_up = true; c->oc_enabled = false; c->rc_iter = 0;
         if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
         HIP_TRY(hipMemcpy(c->x.p, x, c->n3 * sizeof(double), hipMemcpyHostToDevice));
         if (v) HIP_TRY(hipMemcpy(c->v.p, v, c->n3 * sizeof(double), hipMemcpyHostToDevice));
@@ -1940,6 +1955,7 @@ static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
         return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)");
     if (!c->oc_gave_up) fprintf(stderr, "[admm_hip] on-chip PCG: a grid barrier timed out (blocks not co-resident?) -- falling back to the launch-per-iteration PCG and replaying %d step(s)\n", (int)c->pending.size());
     c->oc_gave_up = true; c->oc_enabled = false;
+    c->rc_iter = 0;      // (the stored pairs are in the on-chip kernel's internal row order: the launch path must not project on them)
     if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
     HIP_TRY(hipMemcpyAsync(c->x.p, c->bk_x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->v.p, c->bk_v.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

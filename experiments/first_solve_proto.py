@@ -1,0 +1,51 @@
+"""The FIRST solve of a frame takes 85 of the 194 PCG iterations of a blob1m_mix frame (no recycled pairs yet, start = x_bar).
+Does projecting on the PREVIOUS frame's pairs help it with the two-level preconditioner?  CPU oracle + scipy PCG (affine coarse
+space, Jacobi smoother), per frame: iterations of solves 0..3 with (a) this frame's pairs only (what the kernel does), (b) also the
+previous frame's first K pairs for the solves that have fewer than 4 of their own.  python experiments/first_solve_proto.py [n] [G]"""
+import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'experiments')
+import numpy as np, scipy.sparse as sp, scipy.sparse.csgraph as csg
+import bench, scenes
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 44
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+sc, nt, nv = bench.build_scene(bench.WORKLOADS["blob1m_mix"], n)
+o = sc.make_oracle(mode=1, big=True)
+Ah = o.A[0::3, :][:, 0::3].tocsr(); dinv = 1.0 / Ah.diagonal()
+s = sc.make_solver(init=False)
+plan = s.host_oc_plan(G, 4, settings=sc.product_settings)
+rv, wt = plan["row_vertex"], plan["row_weights"]; live = rv >= 0
+blk = np.arange(len(rv)) // 256
+rr = np.repeat(np.nonzero(live)[0], 4)
+P = sp.csr_matrix((wt[live].ravel().astype(float), (np.repeat(rv[live], 4), 4 * blk[rr] + np.tile(np.arange(4), live.sum()))), shape=(nv, 4 * G))
+Ai = plan["coarse_inv"]
+prec = lambda R: dinv[:, None] * R + P @ (Ai @ (P.T @ R))
+def solve(B, X0, pairs, tol=1e-8, maxit=400):
+    X = X0.copy(); R = B - Ah @ X
+    for ax in range(3):
+        if pairs:
+            E = np.stack([p[0][:, ax] for p in pairs], 1); AE = np.stack([p[1][:, ax] for p in pairs], 1)
+            c = np.linalg.lstsq(E.T @ AE, E.T @ R[:, ax], rcond=None)[0]
+            X[:, ax] += E @ c; R[:, ax] -= AE @ c
+    b2 = (B * dinv[:, None] * B).sum(0)
+    Z = prec(R); Pd = Z.copy(); rz = (R * Z).sum(0)
+    for it in range(maxit):
+        if ((R * dinv[:, None] * R).sum(0) <= tol * tol * b2).all(): return it
+        AP = Ah @ Pd; al = rz / (Pd * AP).sum(0); X += al * Pd; R -= al * AP
+        Z = prec(R); rz2 = (R * Z).sum(0); Pd = Z + (rz2 / rz) * Pd; rz = rz2
+    return maxit
+prev = []
+for f in range(5):
+    o.v[1::3] += o.dt * o.gravity
+    x_bar = o.x + o.dt * o.v; Mxbar = o.m * x_bar
+    curr = x_bar.copy(); z = np.zeros(o.R); u = np.zeros(o.R)
+    pairs = []; its_a = []; its_b = []
+    for si in range(o.admm_iters):
+        o.local_step(curr, z, u); b = o.rhs(Mxbar, z, u); xs = o.solve_ldlt(b)
+        if si < 4:
+            B = b.reshape(-1, 3); X0 = curr.reshape(-1, 3)
+            its_a.append(solve(B, X0, pairs[-4:]))
+            extra = prev[:max(0, 4 - len(pairs))] if si < 4 else []
+            its_b.append(solve(B, X0, (extra + pairs)[-4:] if not pairs else pairs[-4:] + extra))
+        e = (xs - curr).reshape(-1, 3); pairs.append((e, Ah @ e)); curr = xs
+    o.v = (curr - o.x) / o.dt; o.x = curr
+    print("frame", f, "own pairs only:", its_a, "| + previous frame's first pairs:", its_b, flush=True)
+    prev = pairs[:4]
