@@ -40,12 +40,15 @@ for f in range(5):
     pairs = []; its_a = []; its_b = []
     for si in range(o.admm_iters):
         o.local_step(curr, z, u); b = o.rhs(Mxbar, z, u); xs = o.solve_ldlt(b)
-        if si < 4:
+        if si < 5:
             B = b.reshape(-1, 3); X0 = curr.reshape(-1, 3)
             its_a.append(solve(B, X0, pairs[-4:]))
-            extra = prev[:max(0, 4 - len(pairs))] if si < 4 else []
-            its_b.append(solve(B, X0, (extra + pairs)[-4:] if not pairs else pairs[-4:] + extra))
+            K = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+            mode = sys.argv[3] if len(sys.argv) > 3 else "first"
+            free = max(0, K - len(pairs))
+            extra = (prev[:free] if mode == "first" else prev[si:si + free] if mode == "same" else prev[max(0, si - 1):max(0, si - 1) + free]) if prev else []
+            its_b.append(solve(B, X0, pairs[-K:] + extra))
         e = (xs - curr).reshape(-1, 3); pairs.append((e, Ah @ e)); curr = xs
     o.v = (curr - o.x) / o.dt; o.x = curr
     print("frame", f, "own pairs only:", its_a, "| + previous frame's first pairs:", its_b, flush=True)
-    prev = pairs[:4]
+    prev = pairs[:6]
