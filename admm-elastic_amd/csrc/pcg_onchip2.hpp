@@ -921,8 +921,8 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         }
         // totals since admm_hip_create (never reset: admm_hip_solve_totals)
         atomicAdd(a.counters + 72, 1); atomicAdd(a.counters + 73, o.converged); atomicAdd(a.counters + 74, iters);
-        if (prof) a.prof[63 * 8 + 4] = wall_clock64();
     }
+    if (prof) a.prof[63 * 8 + 4] = wall_clock64();     // (the profiled block's own epilogue)
 }
 
 // Latency floor of the two synchronisations an iteration of k_pcg2 is made of, measured on the same grid with the same
