@@ -96,6 +96,8 @@ SYMBOLS = [
     ("admm_host_tabulate_spline", C.c_int, [SPLINE_FN, C.c_void_p, C.c_double, C.c_double, c_double_p]),
     ("admm_host_spline_table_eval", None, [c_double_p, C.c_int, C.c_double, c_double_p]),
     ("admm_host_tet_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
+    ("admm_host_tet_rest_positions", C.c_int, [C.c_int32, C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
+    ("admm_hip_tet_rest_mode", C.c_int, [C.c_void_p]),
     ("admm_host_tri_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     ("admm_host_greedy_coloring", C.c_int, [C.c_int32, c_int_p, c_int_p, c_int_p]),
@@ -158,6 +160,15 @@ def tet_rest(verts, tets):
     Binv = np.empty((n, 9)); vol = np.empty(n)
     check(lib().admm_host_tet_rest(n, iptr(tets), dptr(verts), dptr(Binv), dptr(vol)))
     return Binv, vol
+
+
+def tet_rest_positions(n_verts, tets, Binv, candidate=None):
+    """admm_host_tet_rest_positions: (mode, x0) -- mode 1 candidate accepted, 2 propagated through the tets, 0 none."""
+    tets = i32(tets, (-1, 4)); Binv = f64(Binv, (-1, 9))
+    x0 = np.zeros((n_verts, 3))
+    cand = None if candidate is None else f64(candidate, (-1, 3))
+    mode = lib().admm_host_tet_rest_positions(n_verts, tets.shape[0], iptr(tets), dptr(Binv), None if cand is None else dptr(cand), dptr(x0))
+    return mode, x0
 
 
 def tri_rest(verts, tris):

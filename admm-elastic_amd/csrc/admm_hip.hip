@@ -144,6 +144,8 @@ struct admm_hip_ctx {
     std::vector<int> tet_perm;
     std::vector<int> tri_perm;        // device slot -> caller's triangle index (sorted like the tets: lowest vertex first)
     DevBuf<int4> t_idx;
+    DevBuf<double> t_x0;      // rest positions [nv][3] when the tets' Binv is recomputed from them (tet_rest_mode != 0; t_Binv is then empty)
+    int tet_rest_mode = 0;    // 0 streamed Binv, 1 rest positions = desc.vert_xyz, 2 rest positions propagated through the tets
     DevBuf<double> t_Binv, t_u, t_z, t_sc, t_rec;     // t_rec: per-chunk partial sums of the corner forces, [n_rec + 1][4]
     DevBuf<unsigned short> ch_ent; DevBuf<int> ch_group, ch_rec; int chunk_base[6] = {0, 0, 0, 0, 0, 0};   // host_setup.hpp: TetChunks
     DevBuf<int> t_mat;
@@ -302,12 +304,12 @@ inline int blocks_for(int n) { return (n + 255) / 256; }
 SellA sell_arg(const SellDev &S) { return SellA{S.n_rows, S.n_slices, S.ptr.p, S.w.p, S.idx.p, S.val.p}; }
 
 // ---- launch helpers (all on ctx->stream) -------------------------------------------------------------
-template <bool WRITE_Z>
-void launch_local(admm_hip_ctx *c) {
+template <bool WRITE_Z, bool REST>
+void launch_local_impl(admm_hip_ctx *c) {
     hipStream_t st = c->stream;
     if (c->nt > 0) {
         const int b0 = c->kind_begin[0], b1 = c->kind_begin[1], b2 = c->kind_begin[2], b3 = c->kind_begin[3];
-        TetArgs a{c->ldt, c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p,
+        TetArgs a{c->ldt, c->t_idx.p, c->t_Binv.p, c->t_u.p, c->t_z.p, c->t_sc.p, c->t_mat.p, c->mats.p, c->curr.p, c->t_x0.p,
                   c->ch_ent.p, c->ch_group.p, c->ch_rec.p, c->t_rec.p, 0, c->spl_tab.p, nullptr, 0};
         auto stamp = [&]() {   // the next launch gets its own pair of stamp arrays
             if (c->timing && c->lk_launch < c->lk_cap) { a.ts = c->lk_ts.p + (size_t)c->lk_launch * 2 * c->lk_tsn; a.ts_n = c->lk_tsn; c->lk_launch += 1; }
@@ -317,27 +319,32 @@ void launch_local(admm_hip_ctx *c) {
         const int kinds = (b1 > b0) + (b2 > b1) + (b3 > b2);
         if (b5 > b4) {    // SplineTet splines with a compression term: their own launch
             stamp(); a.chunk0 = c->chunk_base[4];
-            hipLaunchKernelGGL((k_local_tets<4, WRITE_Z>), dim3(blocks_for(b5 - b4)), dim3(256), 0, st, b4, b5, a);
+            hipLaunchKernelGGL((k_local_tets<4, WRITE_Z, REST>), dim3(blocks_for(b5 - b4)), dim3(256), 0, st, b4, b5, a);
         }
         if (b4 > b3) { stamp(); a.chunk0 = c->chunk_base[3]; }
         if (b4 > b3)      // co-rotated spline tets: their own launch (no BASELINE config mixes them in)
-            hipLaunchKernelGGL((k_local_tets<3, WRITE_Z>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, b3, b4, a);
+            hipLaunchKernelGGL((k_local_tets<3, WRITE_Z, REST>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, b3, b4, a);
         if (b3 > b0) stamp();
         a.chunk0 = b1 > b0 ? 0 : b2 > b1 ? c->chunk_base[1] : c->chunk_base[2];   // (fused: chunks 0 .. of the models it covers)
         if (kinds >= 2) { // mixed scene: one launch over all models
             const int n0 = blocks_for(b1 - b0), n1 = blocks_for(b2 - b1), n2 = blocks_for(b3 - b2);
-            hipLaunchKernelGGL((k_local_tets_fused<WRITE_Z>), dim3(n0 + n1 + n2), dim3(256), 0, st, b0, b1, b2, b3, n0, n0 + n1, a);
+            hipLaunchKernelGGL((k_local_tets_fused<WRITE_Z, REST>), dim3(n0 + n1 + n2), dim3(256), 0, st, b0, b1, b2, b3, n0, n0 + n1, a);
         } else if (b1 > b0) {
-            hipLaunchKernelGGL((k_local_tets<0, WRITE_Z>), dim3(blocks_for(b1 - b0)), dim3(256), 0, st, b0, b1, a);
+            hipLaunchKernelGGL((k_local_tets<0, WRITE_Z, REST>), dim3(blocks_for(b1 - b0)), dim3(256), 0, st, b0, b1, a);
         } else if (b2 > b1) {
-            hipLaunchKernelGGL((k_local_tets<1, WRITE_Z>), dim3(blocks_for(b2 - b1)), dim3(256), 0, st, b1, b2, a);
+            hipLaunchKernelGGL((k_local_tets<1, WRITE_Z, REST>), dim3(blocks_for(b2 - b1)), dim3(256), 0, st, b1, b2, a);
         } else if (b3 > b2) {
-            hipLaunchKernelGGL((k_local_tets<2, WRITE_Z>), dim3(blocks_for(b3 - b2)), dim3(256), 0, st, b2, b3, a);
+            hipLaunchKernelGGL((k_local_tets<2, WRITE_Z, REST>), dim3(blocks_for(b3 - b2)), dim3(256), 0, st, b2, b3, a);
         }
     }
     if (c->ntri > 0)
         hipLaunchKernelGGL((k_local_tris<WRITE_Z>), dim3(blocks_for(c->ntri)), dim3(256), 0, st, c->ntri, c->ldr, c->r_idx.p,
                            c->r_rest.p, c->r_u.p, c->r_z.p, c->r_sc.p, c->r_lmin.p, c->r_lmax.p, c->curr.p, c->r_cf.p);
+}
+template <bool WRITE_Z>
+void launch_local(admm_hip_ctx *c) {      // Binv recomputed from the rest positions / streamed: decided once, in admm_hip_create
+    if (c->tet_rest_mode) launch_local_impl<WRITE_Z, true>(c);
+    else launch_local_impl<WRITE_Z, false>(c);
 }
 
 void launch_gather(admm_hip_ctx *c) {
@@ -1269,7 +1276,15 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
             if (it == mat_map.end()) { it = mat_map.emplace(key, (int)mats.size()).first; mats.push_back(Mat{d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), stype, table}); }
             mat[n] = it->second;
         }
-        HIP_TRY(c->t_idx.upload(idx)); HIP_TRY(c->t_Binv.upload(Binv)); HIP_TRY(c->t_sc.upload(sc));
+        HIP_TRY(c->t_idx.upload(idx)); HIP_TRY(c->t_sc.upload(sc));
+        {   // Binv: recomputed by the local step from the rest positions when the tets come from one set of positions (they do
+            // when TetEnergyTerm's constructor made them), streamed otherwise.  ADMM_HIP_TET_REST=0: always streamed (A/B, tests).
+            const char *e = getenv("ADMM_HIP_TET_REST");
+            std::vector<double> x0((size_t)3 * nv);
+            c->tet_rest_mode = (e && e[0] == '0') ? 0 : admm_host::tet_rest_positions(nv, nt, d->tet_idx + 4 * (size_t)tb, d->tet_Binv + 9 * (size_t)tb, d->vert_xyz, x0.data());   // (this rank's tets)
+            if (c->tet_rest_mode) HIP_TRY(c->t_x0.upload(x0));
+            else HIP_TRY(c->t_Binv.upload(Binv));
+        }
         HIP_TRY(c->t_mat.upload(mat)); HIP_TRY(c->mats.upload(mats));
         if (d->n_spline_tables > 0 && d->spline_tables) {
             static_assert(kSplineTableDoubles == ADMM_SPLINE_TABLE_DOUBLES && kSplineTableDoubles == admm_host::kSplineTableDoublesH, "spline table layout");
@@ -2273,6 +2288,11 @@ int admm_host_tabulate_spline(admm_spline_fn fn, void *user, double s_min, doubl
     return ADMM_HIP_OK;
 }
 void admm_host_spline_table_eval(const double *table, int which, double x, double *out3) { admm_host::spline_table_eval(table, which, x, out3); }
+int admm_host_tet_rest_positions(int32_t n_verts, int32_t n_tets, const int32_t *idx, const double *Binv, const double *candidate, double *x0_out) {
+    if (n_verts <= 0 || n_tets < 0 || !idx || !Binv || !x0_out) return -1;
+    return admm_host::tet_rest_positions(n_verts, n_tets, idx, Binv, candidate, x0_out);
+}
+int admm_hip_tet_rest_mode(const admm_hip_ctx *c) { return c ? c->tet_rest_mode : -1; }
 int admm_host_tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol) {
     int r = admm_host::tet_rest(n, idx, verts, Binv, vol);
     if (r) return fail(ADMM_HIP_ERR_GEOMETRY, "TetEnergyTerm Error: Inverted initial tet " + std::to_string(-r - 1));

@@ -3,6 +3,7 @@
 #include "host_setup.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <limits>
 #include <utility>
 #include <numeric>
@@ -455,6 +456,72 @@ int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, d
         o[2 * 3 + 2] =  (B[0][0] * B[1][1] - B[0][1] * B[1][0]) * id;
     }
     return 0;
+}
+
+// Rest POSITIONS behind the tets' edges_inv (TetEnergyTerm's constructor inverts the rest edge matrix of the vertex positions
+// it is given, src/TetEnergyTerm.cpp:31-48; all tets of a mesh are built from ONE set of positions).  With them the local step
+// recomputes Binv from 4 gathered positions (vertex data: cache-resident) instead of streaming 72 bytes per tet and launch.
+// Candidates: `cand` (the caller's coordinates: exact when the solver is initialised in its rest state), else positions
+// propagated from tet to tet through inv(Binv) (defined up to a translation per connected component, which no kernel sees).
+// A candidate is accepted only if EVERY tet's recomputed Binv equals the given one to 1e-11 of its largest entry (the kernels then
+// reproduce the streamed-Binv results to ~1e-13); 0 = the tets do not come from one set of positions: Binv stays streamed.
+static bool rest_positions_match(int32_t nt, const int32_t *idx, const double *Binv, const double *x) {
+    for (int32_t t = 0; t < nt; ++t) {
+        double B[9], vol;
+        if (tet_rest(1, idx + 4 * (size_t)t, x, B, &vol) != 0) return false;
+        double big = 0.0, dif = 0.0;
+        for (int k = 0; k < 9; ++k) {
+            big = std::max(big, std::fabs(Binv[9 * (size_t)t + k]));
+            dif = std::max(dif, std::fabs(Binv[9 * (size_t)t + k] - B[k]));
+        }
+        if (!(dif <= 1e-11 * big)) return false;      // (also catches NaN)
+    }
+    return true;
+}
+int tet_rest_positions(int32_t nv, int32_t nt, const int32_t *idx, const double *Binv, const double *cand, double *x0) {
+    if (nt <= 0) return 0;
+    for (size_t i = 0; i < (size_t)4 * nt; ++i) if (idx[i] < 0 || idx[i] >= nv) return 0;
+    if (cand && rest_positions_match(nt, idx, Binv, cand)) { std::memcpy(x0, cand, sizeof(double) * 3 * (size_t)nv); return 1; }
+    // vertex -> tets
+    std::vector<int32_t> ptr((size_t)nv + 1, 0), inc((size_t)4 * nt);
+    for (size_t i = 0; i < (size_t)4 * nt; ++i) ptr[idx[i] + 1]++;
+    for (int32_t v = 0; v < nv; ++v) ptr[v + 1] += ptr[v];
+    { std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1); for (int32_t t = 0; t < nt; ++t) for (int k = 0; k < 4; ++k) inc[fill[idx[4 * (size_t)t + k]]++] = t; }
+    std::vector<char> known(nv, 0), seen(nt, 0);
+    std::fill(x0, x0 + 3 * (size_t)nv, 0.0);
+    std::vector<int32_t> queue; queue.reserve(nt);
+    for (int32_t seed = 0; seed < nt; ++seed) {
+        if (seen[seed]) continue;
+        known[idx[4 * (size_t)seed]] = 1;               // the component's translation: this vertex at the origin
+        seen[seed] = 1; queue.clear(); queue.push_back(seed);
+        for (size_t h = 0; h < queue.size(); ++h) {
+            const int32_t t = queue[h];
+            const int32_t *id = idx + 4 * (size_t)t;
+            const double *b = Binv + 9 * (size_t)t;     // column-major b[c * 3 + r]
+            // E = Binv^-1 (columns = edges x1 - x0, x2 - x0, x3 - x0), in long double
+            long double m[3][3], e[3][3];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) m[r][c] = b[c * 3 + r];
+            const long double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+                                  + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+            if (!(det > 0.0L) && !(det < 0.0L)) return 0;
+            e[0][0] =  (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; e[0][1] = -(m[0][1] * m[2][2] - m[0][2] * m[2][1]) / det; e[0][2] =  (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+            e[1][0] = -(m[1][0] * m[2][2] - m[1][2] * m[2][0]) / det; e[1][1] =  (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; e[1][2] = -(m[0][0] * m[1][2] - m[0][2] * m[1][0]) / det;
+            e[2][0] =  (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; e[2][1] = -(m[0][0] * m[2][1] - m[0][1] * m[2][0]) / det; e[2][2] =  (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+            int a = -1;
+            for (int k = 0; k < 4; ++k) if (known[id[k]]) { a = k; break; }
+            if (a < 0) return 0;                        // (cannot happen: a tet is queued through a known vertex)
+            long double rel[4][3];                      // corner k relative to corner 0
+            for (int j = 0; j < 3; ++j) { rel[0][j] = 0.0L; for (int k = 1; k < 4; ++k) rel[k][j] = e[j][k - 1]; }
+            for (int k = 0; k < 4; ++k) {
+                if (known[id[k]]) continue;
+                for (int j = 0; j < 3; ++j) x0[3 * (size_t)id[k] + j] = (double)((long double)x0[3 * (size_t)id[a] + j] + (rel[k][j] - rel[a][j]));
+                known[id[k]] = 1;
+            }
+            for (int k = 0; k < 4; ++k)
+                for (int32_t q = ptr[id[k]]; q < ptr[id[k] + 1]; ++q) if (!seen[inc[q]]) { seen[inc[q]] = 1; queue.push_back(inc[q]); }
+        }
+    }
+    return rest_positions_match(nt, idx, Binv, x0) ? 2 : 0;
 }
 
 // src/TriEnergyTerm.cpp:29-52

@@ -146,6 +146,8 @@ int tabulate_spline(spline_fn fn, void *user, double s_min, double s_max, double
 void spline_table_eval(const double *table, int which, double x, double *out3);
 
 int tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
+// rest positions [3 nv] behind the tets' Binv: 1 = `cand` reproduces every Binv, 2 = propagated from tet to tet, 0 = none (host_setup.cpp)
+int tet_rest_positions(int32_t nv, int32_t nt, const int32_t *idx, const double *Binv, const double *cand, double *x0);
 int tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
 void lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);
 void partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end);

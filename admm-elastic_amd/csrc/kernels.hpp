@@ -187,6 +187,7 @@ struct TetArgs {
     int ld;
     const int4 *idx; const double *Binv; double *u; double *z; const double *sc; const int *mat_id; const Mat *mats;
     const double *x;
+    const double *x0;         // rest positions [nv][3] (the tets' Binv is then recomputed per launch instead of streamed), or nullptr
     const unsigned short *ch_ent; const int *ch_group, *ch_rec; double *rec; int chunk0;   // chunk plan, records [n_rec + 1][4], first chunk of this launch
     const double *spl;        // tabulated user splines (device_math.hpp: kSplineTableDoubles each), KIND 4 / Mat::type 3
     // kernel-level timing (stats only): every wave stores the device wall clock at entry in ts[wave slot] and at exit in
@@ -272,13 +273,36 @@ __device__ __forceinline__ int4 tet_load_idx(const TetArgs &a, int t) {
     q4.v = __builtin_amdgcn_raw_buffer_load_b128(soa_rsrc(a.idx), t * 16, 0, 0);
     return q4.i;
 }
-template <int KIND>
+template <int KIND, bool REST>
 __device__ __forceinline__ void tet_load(const TetArgs &a, int t, TetIn &in) {
     const int ld8 = a.ld * 8, t8 = t * 8;   // bytes between two components of an SoA array (the largest offset, 12 ld 8 for cf, stays < 2^31: admm_hip_create rejects more than 22.3 M elements)
     const __amdgpu_buffer_rsrc_t rBinv = soa_rsrc(a.Binv), ru = soa_rsrc(a.u);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) { in.Bi[c] = buf_ld_stream(rBinv, t8, c * ld8); in.ui[c] = buf_ld_stream(ru, t8, c * ld8); }
+    for (int c = 0; c < 9; ++c) {
+        if (!REST) in.Bi[c] = buf_ld_stream(rBinv, t8, c * ld8);      // REST: Binv comes from the rest positions (tet_rest_binv)
+        in.ui[c] = buf_ld_stream(ru, t8, c * ld8);
+    }
     in.mid = (KIND == 0) ? 0 : __builtin_amdgcn_raw_buffer_load_b32(soa_rsrc(a.mat_id), t * 4, 0, 0);
+}
+// Binv = [x1 - x0, x2 - x0, x3 - x0]^-1 of the REST positions (src/TetEnergyTerm.cpp:31-48), recomputed per launch: four
+// 24-byte gathers of vertex data (4.4 MB at 1 M tets: L2-resident, next to the same gathers of x) and ~45 FP64 operations
+// instead of 72 streamed bytes per tet -- a quarter of the kernel's HBM traffic.  admm_hip_create switches this on only when
+// every tet's recomputed Binv reproduces the caller's (host_setup.cpp: tet_rest_positions).
+__device__ __forceinline__ void tet_rest_binv(const TetArgs &a, const int4 id, TetIn &in) {
+    const __amdgpu_buffer_rsrc_t r0 = soa_rsrc(a.x0);
+    const int o[4] = {id.x * 24, id.y * 24, id.z * 24, id.w * 24};
+    double p[12];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) p[3 * v + j] = buf_ld(r0, o[v] + 8 * j, 0);
+    double e0[3], e1[3], e2[3], c0[3], c1[3], c2[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { e0[j] = p[3 + j] - p[j]; e1[j] = p[6 + j] - p[j]; e2[j] = p[9 + j] - p[j]; }
+    cross3(e1, e2, c0); cross3(e2, e0, c1); cross3(e0, e1, c2);
+    const double idet = fast_rcp(fma(e0[0], c0[0], fma(e0[1], c0[1], e0[2] * c0[2])));
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { in.Bi[r * 3 + 0] = c0[r] * idet; in.Bi[r * 3 + 1] = c1[r] * idet; in.Bi[r * 3 + 2] = c2[r] * idet; }
 }
 __device__ __forceinline__ void tet_gather(const TetArgs &a, const int4 id, TetPos &x) {
     const __amdgpu_buffer_rsrc_t rx = soa_rsrc(a.x);
@@ -454,14 +478,15 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
 
 // t_end = end of this constitutive model's tet range.  The whole block takes part (the chunk's reduction synchronises it):
 // lanes past the end redo the last tet of the range and store nothing of their own.
-template <int KIND, bool WRITE_Z>
+template <int KIND, bool WRITE_Z, bool REST>
 __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, int t_end, int chunk, LdsDk *sL) {
     TetIn in; TetPos x;
     ADMM_PHASE_BEGIN();
     const bool valid = t < t_end;
     const int tl = valid ? t : t_end - 1;
     const int4 id = tet_load_idx(a, tl);
-    tet_load<KIND>(a, tl, in);
+    tet_load<KIND, REST>(a, tl, in);
+    if (REST) tet_rest_binv(a, id, in);
     tet_gather(a, id, x);
     if (threadIdx.x < 3) sL[threadIdx.x * kChunkLdK + 256] = 0.0;     // the padding column of the reduction lists
 #ifdef ADMM_LOCAL_PHASES
@@ -472,7 +497,7 @@ __device__ __forceinline__ void local_tet_body(const TetArgs &a, int t, int t_en
 }
 
 // one constitutive model per launch (used when a scene has a single model, and by the parity entry point)
-template <int KIND, bool WRITE_Z>
+template <int KIND, bool WRITE_Z, bool REST>
 #ifndef ADMM_NH_WAVES
 #define ADMM_NH_WAVES 4
 #endif
@@ -481,25 +506,25 @@ __global__ __launch_bounds__(256, (KIND == 1 ? ADMM_NH_WAVES : KIND == 4 ? 2 : 4
     LdsDk *sL = (LdsDk *)sLm;
     const int blk = xcd_block();
     ts_enter(a);
-    local_tet_body<KIND, WRITE_Z>(a, t0 + blk * 256 + (int)threadIdx.x, t1, a.chunk0 + blk, sL);
+    local_tet_body<KIND, WRITE_Z, REST>(a, t0 + blk * 256 + (int)threadIdx.x, t1, a.chunk0 + blk, sL);
     ts_exit(a);
 }
 
 // all models in ONE launch: block ranges [0,nb0) linear, [nb0,nb1) NH, [nb1,nb2) StVK (wave-uniform branch).
 // Avoids the ramp-down / ramp-up between per-model launches of a mixed scene.  (Chunks are numbered model by model in this
 // order, so the block index is the chunk index.)
-template <bool WRITE_Z>
+template <bool WRITE_Z, bool REST>
 __global__ __launch_bounds__(256, ADMM_NH_WAVES) void k_local_tets_fused(int b0, int b1, int b2, int b3, int nb0, int nb1, TetArgs a) {
     __shared__ double sLm[18 * kChunkLdK];
     LdsDk *sL = (LdsDk *)sLm;
     const int blk = xcd_block();
     ts_enter(a);
     if (blk < nb0) {
-        local_tet_body<0, WRITE_Z>(a, b0 + blk * 256 + (int)threadIdx.x, b1, a.chunk0 + blk, sL);
+        local_tet_body<0, WRITE_Z, REST>(a, b0 + blk * 256 + (int)threadIdx.x, b1, a.chunk0 + blk, sL);
     } else if (blk < nb1) {
-        local_tet_body<1, WRITE_Z>(a, b1 + (blk - nb0) * 256 + (int)threadIdx.x, b2, a.chunk0 + blk, sL);
+        local_tet_body<1, WRITE_Z, REST>(a, b1 + (blk - nb0) * 256 + (int)threadIdx.x, b2, a.chunk0 + blk, sL);
     } else {
-        local_tet_body<2, WRITE_Z>(a, b2 + (blk - nb1) * 256 + (int)threadIdx.x, b3, a.chunk0 + blk, sL);
+        local_tet_body<2, WRITE_Z, REST>(a, b2 + (blk - nb1) * 256 + (int)threadIdx.x, b3, a.chunk0 + blk, sL);
     }
     ts_exit(a);
 }

@@ -435,6 +435,11 @@ class Solver:
         check(lib().admm_hip_local_launch_times(self._ctx, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def tet_rest_mode(self):
+        """admm_hip_tet_rest_mode: 0 = the local step streams Binv, 1 / 2 = it recomputes Binv from gathered rest positions."""
+        self._need_ctx()
+        return lib().admm_hip_tet_rest_mode(self._ctx)
+
     def runtime_data(self):
         return self._runtime
 

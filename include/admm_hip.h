@@ -300,6 +300,17 @@ int admm_host_assemble_matrix(const admm_hip_desc *desc, int32_t *rowptr, int32_
 /* TetEnergyTerm ctor (src/TetEnergyTerm.cpp:31-48): Binv [9*n], vol [n]; ADMM_HIP_ERR_GEOMETRY if a
  * rest volume is negative.  verts [3*nv], idx [4*n]. */
 int admm_host_tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol);
+/* Rest positions behind a set of edges_inv (no reference counterpart; src/TetEnergyTerm.cpp:31-48 builds every Binv from the
+ * vertex positions it is handed).  admm_hip_create calls this on the tets it is given: when ONE set of vertex positions
+ * reproduces every tet's Binv to 1e-11, the local step gathers those positions (vertex data, cache-resident) and recomputes
+ * Binv instead of streaming 72 bytes per tet and launch.  candidate [3*n_verts] or NULL is tried first (admm_hip_create
+ * passes desc.vert_xyz); otherwise positions are propagated from tet to tet through inv(Binv), one translation per connected
+ * component.  Returns 1 (candidate), 2 (propagated), 0 (the tets do not share one set of rest positions: Binv is streamed),
+ * -1 bad arguments; x0_out [3*n_verts].  ADMM_HIP_TET_REST=0 in the environment keeps Binv streamed (A/B, tests). */
+int admm_host_tet_rest_positions(int32_t n_verts, int32_t n_tets, const int32_t *idx, const double *Binv,
+                                 const double *candidate, double *x0_out);
+/* which of the above this context's local step uses: 0 streamed Binv, 1 / 2 rest positions; -1 NULL context */
+int admm_hip_tet_rest_mode(const admm_hip_ctx *ctx);
 /* TriEnergyTerm ctor (src/TriEnergyTerm.cpp:29-52): rest [4*n], area [n]. */
 int admm_host_tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
 /* Lame (src/EnergyTerm.hpp:34-59) */

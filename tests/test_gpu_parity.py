@@ -47,6 +47,57 @@ def test_local_step_tets(kind, amp):
         assert (np.linalg.det(F) < 0).any(), "case meant to contain inverted elements"
 
 
+def test_local_step_binv_from_rest_positions_or_streamed(monkeypatch):
+    """The local step recomputes Binv from gathered rest positions whenever the tets share one set of them (mode 1: the solver
+    is initialised at rest; mode 2: initialised deformed, positions propagated through the tets), streams it otherwise (mode 0:
+    a pre-strained element, or ADMM_HIP_TET_REST=0).  Same z, u and right-hand side in every mode, each against the oracle."""
+    def run(sc, x, solver_x=None):
+        o = sc.make_oracle(mode=1)
+        rest = sc.x
+        if solver_x is not None:
+            sc.x = solver_x                         # Solver::m_x at initialize is not the rest state
+        s = sc.make_solver()
+        sc.x = rest
+        u0 = 0.05 * np.random.default_rng(12).standard_normal(o.R)
+        Mxbar = np.random.default_rng(7).standard_normal(x.size)
+        z, u, b = s.local_step(x, u0, Mxbar)
+        zo = np.zeros(o.R); uo = u0.copy()
+        o.local_step(x, zo, uo)
+        assert np.abs(z - zo).max() < 1e-10 and np.abs(u - uo).max() < 1e-10
+        bo = o.rhs(Mxbar, zo, uo)
+        assert np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+        return s.tet_rest_mode(), z, u, b
+    sc = scenes.cube_scene(5, pkg.TET_NEOHOOKEAN, pin_face=True)
+    x = deformed(sc, 0.05, 3)
+    m1, z1, u1, b1 = run(sc, x)
+    assert m1 == 1
+    monkeypatch.setenv("ADMM_HIP_TET_REST", "0")
+    m0, z0, u0_, b0 = run(sc, x)
+    monkeypatch.delenv("ADMM_HIP_TET_REST")
+    assert m0 == 0
+    assert np.abs(z1 - z0).max() < 1e-12 and np.abs(u1 - u0_).max() < 1e-12 and np.abs(b1 - b0).max() <= 1e-11 * np.abs(b0).max()
+    # initialised in a deformed state: the caller's coordinates are not the rest positions
+    sc2 = scenes.cube_scene(5, pkg.TET_STVK, pin_face=True)
+    assert run(sc2, deformed(sc2, 0.05, 5), solver_x=deformed(sc2, 0.03, 4).reshape(-1, 3))[0] == 2
+    # a pre-strained element (built from other rest positions than its neighbours): no common rest state, Binv stays streamed;
+    # checked against two oracles, one for the body and one for that element
+    verts, tets = meshes.kuhn_cube(5)
+    sc3 = scenes.Scene()
+    sc3.add_tet_mesh(verts, tets, Lame.soft_rubber(), pkg.TET_NEOHOOKEAN)
+    sc3.tets = [(verts, tets[1:], Lame.soft_rubber(), pkg.TET_NEOHOOKEAN, 0), (verts * 1.01, tets[:1], Lame.soft_rubber(), pkg.TET_NEOHOOKEAN, 0)]
+    s = sc3.make_solver()
+    assert s.tet_rest_mode() == 0
+    sa = scenes.Scene(); sa.add_tet_mesh(verts, tets[1:], Lame.soft_rubber(), pkg.TET_NEOHOOKEAN)
+    sb = scenes.Scene(); sb.add_tet_mesh(verts * 1.01, tets[:1], Lame.soft_rubber(), pkg.TET_NEOHOOKEAN)
+    sa.m[:] = 1.0; sb.m[:] = 1.0                    # (vertices outside the oracles' tets: any mass, only their local steps are used)
+    oa, ob = sa.make_oracle(mode=1), sb.make_oracle(mode=1)
+    u0 = 0.05 * np.random.default_rng(12).standard_normal(oa.R + ob.R)
+    z, u = s.local_step(x, u0)
+    za = np.zeros(oa.R); ua = u0[:oa.R].copy(); oa.local_step(x, za, ua)
+    zb = np.zeros(ob.R); ub = u0[oa.R:].copy(); ob.local_step(x, zb, ub)
+    assert np.abs(z - np.concatenate([za, zb])).max() < 1e-10 and np.abs(u - np.concatenate([ua, ub])).max() < 1e-10
+
+
 def test_local_step_and_rhs_with_randomly_numbered_vertices():
     """A mesh whose vertex numbering has no locality (a mesh file as it comes): a chunk of 256 tets then touches ~800 different
     vertices, its block-level reduction of the corner forces runs several 256-record passes and the record lists get long --

@@ -209,3 +209,30 @@ def test_spline_tables_reproduce_the_spline():
     bad = capi.SPLINE_FN(lambda u, w, x: float("nan"))
     with pytest.raises(capi.AdmmHipError):
         capi.check(L.admm_host_tabulate_spline(bad, None, 0.02, 50.0, capi.dptr(tab)))
+
+
+def test_rest_positions_behind_the_tets_binv():
+    """admm_host_tet_rest_positions (what admm_hip_create decides the local step's Binv source with): the mesh's own positions
+    are accepted as they are; without them (or with a deformed candidate) positions propagated from tet to tet reproduce every
+    Binv; tets that do not come from one set of positions are refused."""
+    verts, tets = meshes.unstructured_blob(14)[:2]
+    Binv, _ = capi.tet_rest(verts, tets)
+    mode, x0 = capi.tet_rest_positions(len(verts), tets, Binv, verts)
+    assert mode == 1 and np.array_equal(x0, verts)
+    for cand in (None, verts * 1.05 + 0.01 * np.random.default_rng(0).standard_normal(verts.shape)):
+        mode, x0 = capi.tet_rest_positions(len(verts), tets, Binv, cand)
+        assert mode == 2
+        B2, _ = capi.tet_rest(x0, tets)
+        assert np.abs(B2 - Binv).max() <= 1e-12 * np.abs(Binv).max()
+        used = np.unique(tets)
+        d = x0[used] - verts[used]                       # one translation for the (single) component
+        assert np.abs(d - d[0]).max() < 1e-12
+    # two separate bodies: a translation each
+    v2 = np.vstack([verts, verts + 3.0]); t2 = np.vstack([tets, tets + len(verts)]).astype(np.int32)
+    B2, _ = capi.tet_rest(v2, t2)
+    mode, x0 = capi.tet_rest_positions(len(v2), t2, B2, None)
+    assert mode == 2 and np.abs(capi.tet_rest(x0, t2)[0] - B2).max() <= 1e-12 * np.abs(B2).max()
+    # one tet built from other rest positions than its neighbours (a pre-strained element): no common rest state
+    Bb = Binv.copy(); Bb[7] *= 1.001
+    assert capi.tet_rest_positions(len(verts), tets, Bb, verts)[0] == 0
+    assert capi.tet_rest_positions(len(verts), tets, Bb, None)[0] == 0
