@@ -231,6 +231,12 @@ struct admm_hip_ctx {
     DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part, uz_dmax; DevBuf<long long> uz_dacc;   // uz_dacc / uz_dmax: dyn_collide.hpp, k_uz_ct_dyn
     DevBuf<UzScal> uz_scal;
     int uz_prev_hits = -1, uz_last_hits = 0, NBU = 1, uz_iters_step = 0, uz_prev_iters = 0;
+    // cached columns of K^-1 for the Schur iterations (kernels.hpp: k_uz_cols_apply).  uzc_slot_h[v] = column slot of vertex v or -1.
+    bool uzc_on = false, uzc_usable = false;
+    size_t uzc_cap = 0; int uzc_n = 0, uzc_n_act = 0;
+    DevBuf<double> uzc_cols; DevBuf<int> uzc_slot, uzc_act, uzc_miss, uzc_info; DevBuf<unsigned char> uzc_flag;
+    std::vector<int> uzc_slot_h;
+    long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0;
     bool uz_freeze = false, uz_detected = false;   // tests (ADMM_HIP_UZ_FREEZE=1): Collider::detect only in the first ADMM iteration of a step
     // GS: the whole solve (colours x sweeps + residual tests, ~500 tiny launches) is captured once into a
     // hipGraph and replayed -- the per-colour kernels are far below the host launch rate
@@ -278,6 +284,7 @@ struct admm_hip_ctx {
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
+        uzc_cols.release(); uzc_slot.release(); uzc_act.release(); uzc_miss.release(); uzc_info.release(); uzc_flag.release();
         gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
         lk_ts.release(); lk_out.release(); oc_color.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
@@ -775,6 +782,38 @@ int enqueue_dyn_detect(admm_hip_ctx *c, const double *x) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Columns of K^-1 for the vertices listed in uzc_miss (n_missing of them): three per PCG launch (one per axis), at a tolerance two
+// orders below the context's.  1 = every active vertex now has its column, 0 = the cache is full (this solve uses the PCG), -1 error.
+int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
+    if (n_missing <= 0) return 1;
+    hipStream_t st = c->stream;
+    const int nv = c->nv;
+    if ((size_t)c->uzc_n + (size_t)n_missing > c->uzc_cap) return 0;
+    if (!c->uzc_cols.p && c->uzc_cols.alloc(c->uzc_cap * (size_t)nv) != hipSuccess) { (void)hipGetLastError(); c->uzc_on = false; return 0; }
+    std::vector<int> miss(n_missing);
+    if (hipMemcpy(miss.data(), c->uzc_miss.p, sizeof(int) * (size_t)n_missing, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const double keep_tol = c->pcg_tol;
+    c->pcg_tol = std::min(1e-2 * keep_tol, 1e-10);
+    int rc = 1;
+    for (int k = 0; k < n_missing && rc == 1; k += 3) {
+        int v[3], sl[3];
+        for (int j = 0; j < 3; ++j) { v[j] = k + j < n_missing ? miss[k + j] : -1; sl[j] = v[j] >= 0 ? c->uzc_n + k + j : -1; }
+        if (hipMemsetAsync(c->uz_q1.p, 0, c->n3 * sizeof(double), st) != hipSuccess || hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) { rc = -1; break; }
+        hipLaunchKernelGGL(k_uz_unit_rhs, dim3(1), dim3(1), 0, st, v[0], v[1], v[2], c->uz_q1.p);
+        if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, std::max(c->pcg_max_iters, 2000))) { rc = -1; break; }
+        hipLaunchKernelGGL(k_uz_store_cols, dim3(blocks_for(nv)), dim3(256), 0, st, nv, c->uz_q2.p, c->uzc_cols.p, sl[0], sl[1], sl[2]);
+        c->uzc_col_solves += 1;
+    }
+    c->pcg_tol = keep_tol;
+    if (rc == 1 && hipStreamSynchronize(st) != hipSuccess) rc = -1;
+    if (rc == 1 && c->h_sig && c->h_sig[2]) rc = -1;     // a grid barrier of one of the solves timed out: nothing is committed
+    if (rc != 1) return rc;
+    for (int k = 0; k < n_missing; ++k) c->uzc_slot_h[miss[k]] = c->uzc_n + k;
+    c->uzc_n += n_missing;
+    if (hipMemcpy(c->uzc_slot.p, c->uzc_slot_h.data(), sizeof(int) * (size_t)nv, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    return 1;
+}
+
 // UzawaCG::solve (src/UzawaCG.hpp:57-125).  Host-driven outer loop (one stream sync per Schur-CG
 // iteration, negligible next to the inner solves); returns the reference's iteration count via *iters.
 int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
@@ -805,8 +844,20 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
                                c->counters.p + 6);
         }
         if (c->timing && hipEventRecord(c->ev_coll1, st) != hipSuccess) return -1;
+        int info[2] = {0, 0};
+        if (c->uzc_on) {   // the vertices C^T touches (ascending), and those without a cached column
+            if (hipMemsetAsync(c->uzc_flag.p, 0, nv, st) != hipSuccess) return -1;
+            hipLaunchKernelGGL(k_uz_act_flags, dim3(gv), dim3(256), 0, st, nv, c->uz_cn.p, dface, c->uzc_flag.p);
+            hipLaunchKernelGGL(k_uz_act_compact, dim3(1), dim3(1024), 0, st, nv, c->uzc_flag.p, c->uzc_slot.p, c->uzc_act.p, c->uzc_miss.p, c->uzc_info.p);
+            if (hipMemcpyAsync(info, c->uzc_info.p, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+        }
         if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (c->uzc_on) {
+            c->uzc_n_act = info[0];
+            c->uzc_usable = false;
+            if (nh > 0) { const int rc = uz_ensure_columns(c, info[1]); if (rc < 0) return -1; c->uzc_usable = rc == 1; }
+        }
         if (c->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_coll0, c->ev_coll1) == hipSuccess) c->coll_ms_step += ms; }
     }
     c->uz_last_hits = nh;
@@ -831,15 +882,23 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     int chunk = std::max(1, std::min(c->uz_max_iters, c->uz_prev_iters > 0 ? c->uz_prev_iters + 1 : 4));
     // Only the general-mesh persistent kernel (k_pcg2) honours the device-side stop flag; on the other inner-solve paths (launch
     // per iteration, round-1 kernel) an iteration enqueued behind the stop would run a full dead solve: one at a time there.
-    const bool skip_honoured = c->oc_enabled && c->oc_plan;
+    const bool use_cols = c->uzc_on && c->uzc_usable;      // every active vertex has its column of K^-1: no inner solves
+    const bool skip_honoured = use_cols || (c->oc_enabled && c->oc_plan);
     if (!skip_honoured) chunk = 1;
     while (launched < c->uz_max_iters) {
         const int n = std::min(chunk, c->uz_max_iters - launched);
         for (int it = 0; it < n; ++it) {
             hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 1, b, c->uz_cn.p, c->uz_d.p, c->uz_q1.p);   // q1 = C^T d
             if (dyn) launch_ct_dyn(c, nq, qlist, 1, c->uz_d.p, dface, dbary, c->uz_q1.p);
-            if (hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) return -1;
-            if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, c->pcg_max_iters, stop_flag)) return -1;                       // q2 = A^-1 q1
+            if (use_cols) {                                                                                          // q2 = A^-1 q1
+                hipLaunchKernelGGL(k_uz_cols_apply, dim3((nv + 63) / 64), dim3(256), 0, st, nv, c->uzc_n_act, c->uzc_act.p, c->uzc_slot.p,
+                                   c->uzc_cols.p, c->uz_q1.p, c->uz_q2.p, stop_flag);
+                c->uzc_applies += 1;
+            } else {
+                if (hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) return -1;
+                if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, c->pcg_max_iters, stop_flag)) return -1;
+                c->uzc_pcg_solves += 1;
+            }
             hipLaunchKernelGGL(k_uz_dots, dim3(c->NBU), dim3(256), 0, st, nv, c->uz_q2.p, c->uz_cn.p, c->uz_d.p, c->uz_r.p, c->uz_q3.p,
                                c->uz_part.p, c->NBU, dface, dbary);
             hipLaunchKernelGGL(k_uz_alpha, dim3(1), dim3(256), 0, st, c->uz_part.p, c->NBU, c->uz_scal.p);
@@ -1498,6 +1557,22 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->uz_cc.alloc(nv)); HIP_TRY(c->uz_y.alloc(nv)); HIP_TRY(c->uz_y.zero());
         HIP_TRY(c->uz_r.alloc(nv)); HIP_TRY(c->uz_d.alloc(nv)); HIP_TRY(c->uz_q3.alloc(nv));
         HIP_TRY(c->uz_part.alloc(2 * (size_t)c->NBU)); HIP_TRY(c->uz_scal.alloc(1)); HIP_TRY(c->uz_scal.zero());
+        {   // column cache of the Schur iterations: needs A = K (x) I3 (per-vertex masses, which is all the reference has).
+            // ADMM_HIP_UZ_CACHE=0 switches it off (every Schur iteration is then an on-chip PCG solve, as in rounds 1-2),
+            // ADMM_HIP_UZ_CACHE_MB bounds its HBM (default 16 GiB of the 288; allocated at the first contact).
+            const char *e = getenv("ADMM_HIP_UZ_CACHE"), *mb = getenv("ADMM_HIP_UZ_CACHE_MB");
+            bool per_vertex = true;
+            for (int v = 0; v < nv && per_vertex; ++v)
+                per_vertex = d->masses[3 * (size_t)v] == d->masses[3 * (size_t)v + 1] && d->masses[3 * (size_t)v] == d->masses[3 * (size_t)v + 2];
+            const double bytes = (mb ? atof(mb) : 16384.0) * 1048576.0;
+            c->uzc_cap = (size_t)std::min<double>((double)nv, std::floor(bytes / (8.0 * nv)));
+            c->uzc_on = !(e && e[0] == '0') && per_vertex && c->uzc_cap >= 3;
+            if (c->uzc_on) {
+                c->uzc_slot_h.assign(nv, -1);
+                HIP_TRY(c->uzc_slot.upload(c->uzc_slot_h)); HIP_TRY(c->uzc_act.alloc(nv)); HIP_TRY(c->uzc_miss.alloc(nv));
+                HIP_TRY(c->uzc_info.alloc(2)); HIP_TRY(c->uzc_info.zero()); HIP_TRY(c->uzc_flag.alloc(nv));
+            }
+        }
     }
     HIP_TRY(hipDeviceSynchronize());
     *out = guard.release();
@@ -2291,6 +2366,14 @@ void admm_host_spline_table_eval(const double *table, int which, double x, doubl
 int admm_host_tet_rest_positions(int32_t n_verts, int32_t n_tets, const int32_t *idx, const double *Binv, const double *candidate, double *x0_out) {
     if (n_verts <= 0 || n_tets < 0 || !idx || !Binv || !x0_out) return -1;
     return admm_host::tet_rest_positions(n_verts, n_tets, idx, Binv, candidate, x0_out);
+}
+int admm_hip_uzawa_cache_stats(admm_hip_ctx *c, int64_t *columns, int64_t *column_solves, int64_t *schur_from_columns, int64_t *schur_by_pcg) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "uzawa_cache_stats: NULL context");
+    if (columns) *columns = c->uzc_on ? c->uzc_n : -1;
+    if (column_solves) *column_solves = c->uzc_col_solves;
+    if (schur_from_columns) *schur_from_columns = c->uzc_applies;
+    if (schur_by_pcg) *schur_by_pcg = c->uzc_pcg_solves;
+    return ADMM_HIP_OK;
 }
 int admm_hip_tet_rest_mode(const admm_hip_ctx *c) { return c ? c->tet_rest_mode : -1; }
 int admm_host_tet_rest(int32_t n, const int32_t *idx, const double *verts, double *Binv, double *vol) {

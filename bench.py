@@ -324,6 +324,7 @@ def main():
     if lean:
         s.time_local_launches(True)
         s.local_launch_times()     # (clears what the warm-up recorded)
+    uz0 = s.uzawa_cache_stats() if w["linsolver"] == 2 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         s.step_device(stats=not lean)
@@ -335,6 +336,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     stats_elapsed = elapsed
+    uz1 = s.uzawa_cache_stats() if w["linsolver"] == 2 else None
     if lean:
         lt_pairs, lt_ms = s.local_launch_times()
         s.time_local_launches(False)
@@ -389,6 +391,12 @@ def main():
                          "`roofline`); split / iteration counts from as many STATISTICS FRAMES right after, which take %.3f x the time of the timed ones "
                          "(`stats_frames_ms_per_step`)" % (stats_elapsed / elapsed)) if lean else "frames with per-step statistics",
         "stats_frames_ms_per_step": 1e3 * stats_elapsed / max(args.steps, 1),
+        # UzawaCG: how the Schur iterations of the timed region applied A^-1 (cached columns of K^-1 / inner PCG solves), and the
+        # PCG launches the region spent on new columns (vertices that touched an obstacle for the first time)
+        "uzawa": None if uz0 is None else {"cached_columns": uz1["columns"],
+                                           "schur_iterations_from_columns": uz1["schur_from_columns"] - uz0["schur_from_columns"],
+                                           "schur_iterations_by_pcg": uz1["schur_by_pcg"] - uz0["schur_by_pcg"],
+                                           "column_solves_in_timed_region": uz1["column_solves"] - uz0["column_solves"]},
         # mean time of one inner (PCG / GS) iteration incl. the per-solve overheads: (global - rhs) / inner iterations.
         # The PCG kernel keeps matrix and vectors on chip; its iteration is bound by one grid barrier, not by HBM.
         "us_per_inner_iter": 1e3 * (global_ms - rhs_ms) / max(inner, 1),

@@ -539,6 +539,40 @@ def test_global_solve_uzawa_collisions(what):
         assert np.abs(X[hv, 1] - sc.obstacles[0][1][0]).max() < 1e-6
 
 
+def test_uzawa_cached_columns_equal_inner_solves(monkeypatch):
+    """The Schur iterations apply A^-1 through cached columns of K^-1 (one pass over the active columns) instead of one PCG solve
+    each: same Schur CG, same result as with the inner solves (ADMM_HIP_UZ_CACHE=0) and as the oracle; a vertex's column is solved
+    for once; a cache that cannot hold the active set falls back to the inner solves."""
+    sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=8, linsolver=2, size=0.5)
+    sc.obstacles.append((0, [0.03, 0.0, 0.0, 0.0]))
+    o = sc.make_oracle(mode=1)
+    rng = np.random.default_rng(1)
+    x = sc.x.copy(); x[:, 1] -= 0.02 + 0.03 * rng.random(len(x)); x = x.ravel()
+    b = o.A @ (x + 0.001 * rng.standard_normal(x.size))
+    hits = o.detect_passive(x)
+    xo, ito = o.solve_uzawa(x, b, hits)
+    s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+    xg, itg = s.global_solve(b, x)
+    st = s.uzawa_cache_stats()
+    assert st["columns"] == len(hits) and st["column_solves"] == (len(hits) + 2) // 3, (st, len(hits))
+    assert st["schur_from_columns"] >= itg - 1 > 0 and st["schur_by_pcg"] == 0, (st, itg)    # (launched; those behind the stop are no-ops)
+    xg2, _ = s.global_solve(b, x)                      # same active set: no new columns
+    assert s.uzawa_cache_stats()["column_solves"] == st["column_solves"]
+    monkeypatch.setenv("ADMM_HIP_UZ_CACHE", "0")
+    s0 = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+    monkeypatch.delenv("ADMM_HIP_UZ_CACHE")
+    x0, it0 = s0.global_solve(b, x)
+    st0 = s0.uzawa_cache_stats()
+    assert st0["columns"] == -1 and st0["schur_from_columns"] == 0 and st0["schur_by_pcg"] >= it0 - 1
+    assert np.abs(xg - x0).max() < 1e-9 and np.abs(xg - xo).max() < 1e-7 and abs(itg - it0) <= 2
+    monkeypatch.setenv("ADMM_HIP_UZ_CACHE_MB", "%g" % (8.0 * len(sc.x) * (len(hits) - 1) / 1048576.0))   # one column short
+    s1 = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+    monkeypatch.delenv("ADMM_HIP_UZ_CACHE_MB")
+    x1, it1 = s1.global_solve(b, x)
+    st1 = s1.uzawa_cache_stats()
+    assert st1["columns"] == 0 and st1["schur_from_columns"] == 0 and st1["schur_by_pcg"] >= it1 - 1 and np.abs(x1 - x0).max() < 1e-9
+
+
 def test_step_uzawa_collisions_loose():
     """Whole steps with contact.  The reference's active set is chaotic by construction: a vertex resting
     on the floor at y0 +- 1e-10 is or is not a hit in the next ADMM iteration (dx < 0, Collider.hpp:181),
