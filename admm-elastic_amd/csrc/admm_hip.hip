@@ -18,7 +18,6 @@
 #include "../../include/admm_hip.h"
 #include "host_setup.hpp"
 #include "kernels.hpp"
-#include "pcg_onchip.hpp"
 #include "pcg_onchip2.hpp"
 
 using namespace admm_k;
@@ -107,8 +106,6 @@ struct admm_hip_ctx {
     hipEvent_t ev_coll0 = nullptr, ev_coll1 = nullptr;   // around Collider::detect (UzawaCG path), when stats are requested
     bool timing = false; double coll_ms_step = 0.0;
     // kernel-level timing of the tet local-step launches (device wall clock, kernels.hpp: ts_enter / ts_exit)
-    int oc_poly_m = 0; double oc_lmax = 2.0, oc_poly_ratio = 30.0;   // Chebyshev preconditioner of the on-chip PCG
-    DevBuf<signed char> oc_color; bool oc_bssor = false;             // block-local symmetric GS preconditioner (2-colourable Ahat)
     DevBuf<unsigned long long> lk_ts, lk_out; int lk_tsn = 0, lk_launch = 0, lk_cap = 0; double lk_tick_ms = 0.0;
     std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration (+1) when stats are requested
     bool lt_on = false; std::vector<hipEvent_t> lt_ev; size_t lt_used = 0;   // admm_hip_time_local_launches: event pairs of the lean steps
@@ -184,7 +181,7 @@ struct admm_hip_ctx {
     // launching as soon as a solve has converged -- without ever synchronising the stream.
     int *h_sig = nullptr;         // pinned + mapped: [0] seq of the last converged solve, [1] closed chunks
     int *d_sig = nullptr;         // device alias of h_sig
-    // on-chip PCG (pcg_onchip.hpp): one persistent launch per solve when the system fits the chip
+    // on-chip PCG (pcg_onchip2.hpp): one persistent launch per solve when the system fits the chip
     bool oc_enabled = false;
     int oc_G = 0, oc_spb = 0, oc_T = 0, oc_wl = 0; size_t oc_lds = 0;
     DevBuf<double> oc_ubuf, oc_part, oc_rc_part;
@@ -286,7 +283,7 @@ struct admm_hip_ctx {
         uz_q2.release(); uz_part.release(); uz_scal.release();
         uzc_cols.release(); uzc_slot.release(); uzc_act.release(); uzc_miss.release(); uzc_info.release(); uzc_flag.release();
         gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
-        lk_ts.release(); lk_out.release(); oc_color.release();
+        lk_ts.release(); lk_out.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
         for (hipEvent_t e : lt_ev) (void)hipEventDestroy(e);
@@ -466,42 +463,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
 }
 
 int launch_pcg_onchip(admm_hip_ctx *c, const double *b, double *x, int max_iters, const OcRc &rc = OcRc()) {
-    if (c->oc_plan) return launch_pcg2(c, b, x, max_iters, rc);
-    hipStream_t st = c->stream;
-    OcArgs a{};
-    a.n_rows = c->A.n_rows; a.n_slices = c->A.n_slices;
-    a.ptr = c->A.ptr.p; a.w = c->A.w.p; a.col = c->A.idx.p; a.val = c->A.val.p;
-    a.m = c->m.p; a.dinv = c->dinv.p; a.b = b; a.x = x; a.u_out = c->cg_u.p;
-    a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.bar = c->oc_bar.p;
-    a.nbr = c->oc_nbr.p; a.flags = c->oc_flags.p;
-    a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
-    a.spb = c->oc_spb; a.wl = c->oc_wl; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
-    a.tol2 = c->pcg_tol * c->pcg_tol;
-    a.poly_m = c->oc_poly_m;
-    if (a.poly_m >= 2) {   // Chebyshev coefficients on [lmax / ratio, lmax]
-        const double hi = c->oc_lmax, lo = hi / c->oc_poly_ratio;
-        const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo), sigma = theta / delta;
-        double rho = 1.0 / sigma;
-        a.cheb_inv_theta = 1.0 / theta;
-        for (int k = 0; k < 8; ++k) {
-            const double rn = 1.0 / (2.0 * sigma - rho);
-            a.cheb_c1[k] = rn * rho; a.cheb_c2[k] = 2.0 * rn / delta;
-            rho = rn;
-        }
-    }
-    a.rc_on = rc.on ? 1 : 0; a.rc = rc.B; a.rc_xs = c->rc_xs.p; a.rc_r0 = c->rc_r0.p; a.rc_Eslot = rc.Eslot; a.rc_Rslot = rc.Rslot;
-    a.rc_part = c->oc_rc_part.p;
-    a.prof = c->oc_prof.p;
-    a.prof_block = c->oc_prof_block;
-    a.row_color = c->oc_bssor ? c->oc_color.p : nullptr;
-    if (a.row_color && c->oc_nbr.p && c->oc_T <= 768 && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<768, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
-    else if (a.row_color && c->oc_nbr.p && a.poly_m < 2) hipLaunchKernelGGL((k_pcg_onchip<1024, 2>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
-    else if (a.poly_m >= 2 && c->oc_nbr.p && c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768, 1>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
-    else if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg_onchip<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
-    else hipLaunchKernelGGL((k_pcg_onchip<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
-    c->last_launched_iters = 0; // the verdict of the solve is written to cg_scal[0]
-    if (c->oc_debug || c->oc_prof.p) return oc_diagnostics(c, a.seq);
-    return 0;
+    return launch_pcg2(c, b, x, max_iters, rc);      // (oc_enabled implies the plan)
 }
 
 // Decide whether the system fits the chip: one SELL slice per wave, <= 16 waves per block, one block per CU.
@@ -517,28 +479,23 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     int G = std::min(cus, ns);
     int spb = (ns + G - 1) / G;
     if (spb > 16) return hipSuccess;
-    {   // general-mesh plan: the two-level preconditioner lets every thread handle two coarse unknowns (4 G <= 2 x 64 spb);
-        // small systems therefore use fewer, larger blocks (which also makes their grid barrier cheaper)
+    {   // ADMM_HIP_OC_PLAN=0: no on-chip solve (A/B against the launch-per-iteration path, like ADMM_HIP_PCG_LAUNCHES=1)
         const char *pe = getenv("ADMM_HIP_OC_PLAN");
-        if (!(pe && pe[0] == '0'))
-            while (spb < 16 && (ns + spb - 1) / spb > 32 * spb) ++spb;
+        if (pe && pe[0] == '0') return hipSuccess;
     }
+    // the two-level preconditioner lets every thread handle two coarse unknowns (4 G <= 2 x 64 spb); small systems therefore
+    // use fewer, larger blocks (which also makes their grid barrier cheaper)
+    while (spb < 16 && (ns + spb - 1) / spb > 32 * spb) ++spb;
     G = (ns + spb - 1) / spb;
     const int T = 64 * spb;
-    const int wmax = c->A_wmax;
     const size_t lds_max = std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
-    const size_t fixed = (size_t)kOcScratch + (size_t)spb * kOcStage;
-    if (lds_max < fixed + (size_t)T * 4 * 12) return hipSuccess;
-    int wl = (int)((lds_max - fixed) / ((size_t)T * 12)) & ~3;
-    wl = std::min(wl, wmax);
-    size_t lds = fixed + (size_t)T * wl * 12;
-    // General-mesh plan (default; ADMM_HIP_OC_PLAN=0 keeps the rows in the caller's order and the round-1 kernel,
-    // pcg_onchip.hpp): compact blocks by graph bisection, rows sorted by length, local vector + halo list + slab in LDS,
+    size_t lds = 0;
+    // The plan: compact blocks by graph bisection, rows sorted by length, local vector + halo list + slab in LDS,
     // two-level preconditioner (ADMM_HIP_OC_COARSE=0: Jacobi on the same layout) -- oc_plan.cpp, pcg_onchip2.hpp.
     admm_host::OcPlan plan;
     {
-        const char *pe = getenv("ADMM_HIP_OC_PLAN"), *ce = getenv("ADMM_HIP_OC_COARSE");
-        if (!(pe && pe[0] == '0') && c->oc_poly_m < 2) {
+        const char *ce = getenv("ADMM_HIP_OC_COARSE");
+        {
             std::vector<double> mass(c->n3);
             if ((e = hipMemcpy(mass.data(), c->m.p, mass.size() * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) return e;
             plan = admm_host::build_oc_plan(c->Ahat, mass.data(), G, spb, (int)lds_max - kOc2Scratch, !(ce && ce[0] == '0'), c->create_xyz);
@@ -594,23 +551,17 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
             }
         }
     }
-    const void *fn = T <= 768 ? (const void *)k_pcg_onchip<768> : (const void *)k_pcg_onchip<1024>;
-    if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<768, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg_onchip<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    if (!c->oc_plan) return hipSuccess;      // no plan (halo too large for 16-bit columns, per-dof masses, ...): the launch path serves the system
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_pcg2<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T > 768 && (e = hipFuncSetAttribute((const void *)k_pcg2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T <= 768 && (e = hipFuncSetAttribute((const void *)k_sync_probe<768>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     if (T > 768 && (e = hipFuncSetAttribute((const void *)k_sync_probe<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
     int per_cu = 0;     // (the kernel that will actually be launched with this LDS size)
-    if (c->oc_plan) e = T <= 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<768>, T, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<1024>, T, lds);
-    else if (T <= 768) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<768>, T, lds);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_onchip<1024>, T, lds);
+    e = T <= 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<768>, T, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<1024>, T, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1 || G > cus) return hipSuccess; // one block per CU keeps every block resident whatever the LDS split
-    c->oc_G = G; c->oc_spb = spb; c->oc_T = T; c->oc_wl = wl; c->oc_lds = lds;
-    if ((e = c->oc_ubuf.alloc((size_t)2 * (c->oc_plan ? G * spb : ns) * 64 * (c->oc_plan ? 4 : 3))) != hipSuccess) return e;
+    c->oc_G = G; c->oc_spb = spb; c->oc_T = T; c->oc_lds = lds;
+    if ((e = c->oc_ubuf.alloc((size_t)2 * G * spb * 64 * 4)) != hipSuccess) return e;
     if ((e = c->oc_part.alloc((size_t)2 * 8 * G)) != hipSuccess) return e;
     if ((e = c->oc_rc_part.alloc((size_t)72 * G)) != hipSuccess) return e;
     if ((e = c->oc_bar.alloc(2 * 32 * 16)) != hipSuccess) return e;
@@ -623,53 +574,12 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
         c->oc_prof_block = pb ? atoi(pb) : 0;
         if (pe && pe[0] == '1') { if ((e = c->oc_prof.alloc(64 * 8)) != hipSuccess) return e; if ((e = c->oc_prof.zero()) != hipSuccess) return e; }
     }
-    {   // which blocks does every block gather from?  (rows of block b: [64 spb b, 64 spb (b + 1)))
+    {   // which blocks does every block gather from?  (ADMM_HIP_OC_NO_NBR=1: every gather waits for a grid barrier instead)
         const char *off = getenv("ADMM_HIP_OC_NO_NBR");
-        const int rows_pb = 64 * spb;
-        std::vector<int> nbr((size_t)G * 64, -1);
-        bool fits = !(off && off[0] == '1');
-        if (c->oc_plan) { fits = fits && plan.nbr_ok; if (fits) nbr = plan.nbr; }
-        for (int b = 0; b < G && fits && !c->oc_plan; ++b) {
-            std::vector<char> seen(G, 0);
-            int n = 0;
-            const int r1 = std::min(c->Ahat.n, rows_pb * (b + 1));
-            for (int r = rows_pb * b; r < r1 && fits; ++r)
-                for (int k = c->Ahat.rowptr[r]; k < c->Ahat.rowptr[r + 1]; ++k) {
-                    if (c->Ahat.val[k] == 0.0) continue;            // exact zeros are not in the SELL matrix
-                    const int bj = c->Ahat.col[k] / rows_pb;
-                    if (bj == b || seen[bj]) continue;
-                    seen[bj] = 1;
-                    if (n == 64) { fits = false; break; }
-                    nbr[(size_t)b * 64 + n++] = bj;
-                }
-        }
-        if (fits) {
-            if ((e = c->oc_nbr.upload(nbr)) != hipSuccess) return e;
+        if (!(off && off[0] == '1') && plan.nbr_ok) {
+            if ((e = c->oc_nbr.upload(plan.nbr)) != hipSuccess) return e;
             if ((e = c->oc_flags.alloc((size_t)8 * G)) != hipSuccess) return e;
             if ((e = c->oc_flags.zero()) != hipSuccess) return e;
-        }
-    }
-    {   // block-local symmetric Gauss-Seidel preconditioner: needs a 2-colouring of the non-zero pattern of Ahat
-        const char *bs = getenv("ADMM_HIP_OC_BSSOR");
-        c->oc_bssor = false;
-        // on by default; ADMM_HIP_OC_BSSOR=0 = plain Jacobi (A/B).  Rows wider than the 32-bit local-entry mask would make
-        // the sweep unsymmetric: such meshes keep Jacobi.
-        if (!(bs && bs[0] == '0') && c->oc_nbr.p && c->A_wmax <= 32 && !c->oc_plan) {
-            const int nv = c->Ahat.n;
-            std::vector<int32_t> rp(nv + 1, 0), ci;
-            for (int i = 0; i < nv; ++i) {
-                for (int k = c->Ahat.rowptr[i]; k < c->Ahat.rowptr[i + 1]; ++k)
-                    if (c->Ahat.val[k] != 0.0 || c->Ahat.col[k] == i) ci.push_back(c->Ahat.col[k]);
-                rp[i + 1] = (int32_t)ci.size();
-            }
-            std::vector<int32_t> col(nv, 0);
-            const int nc = admm_host::greedy_coloring(nv, rp.data(), ci.data(), col.data());
-            if (nc <= 2) {
-                std::vector<signed char> c8(nv);
-                for (int i = 0; i < nv; ++i) c8[i] = (signed char)col[i];
-                if ((e = c->oc_color.upload(c8)) != hipSuccess) return e;
-                c->oc_bssor = true;
-            }
         }
     }
     c->oc_enabled = true;
@@ -1457,23 +1367,6 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
             for (int j = 0; j < 3; ++j) dinv[3 * (size_t)vtx + j] = 1.0 / (mass[3 * (size_t)vtx + j] + diag);
         }
         HIP_TRY(c->m.upload(mass)); HIP_TRY(c->dinv.upload(dinv));
-        // rigorous upper bound of the spectrum of D^-1 A (Gershgorin on D^-1/2 A D^-1/2, per axis): the interval of the
-        // Chebyshev preconditioner of the on-chip PCG must contain the largest eigenvalue
-        double lmax = 1.0;
-        for (int vtx = 0; vtx < nv; ++vtx)
-            for (int j = 0; j < 3; ++j) {
-                const double di = dinv[3 * (size_t)vtx + j];
-                double row = 1.0;
-                for (int k = c->Ahat.rowptr[vtx]; k < c->Ahat.rowptr[vtx + 1]; ++k) {
-                    const int col = c->Ahat.col[k];
-                    if (col != vtx) row += std::fabs(c->Ahat.val[k]) * std::sqrt(di * dinv[3 * (size_t)col + j]);
-                }
-                lmax = std::max(lmax, row);
-            }
-        c->oc_lmax = lmax;
-        const char *pm = getenv("ADMM_HIP_OC_POLY"), *pr = getenv("ADMM_HIP_OC_POLY_RATIO");
-        c->oc_poly_m = pm ? std::max(0, std::min(8, atoi(pm))) : 0;
-        if (pr && atof(pr) > 1.0) c->oc_poly_ratio = atof(pr);
     }
     HIP_TRY(c->x.alloc(c->n3)); HIP_TRY(c->x.zero());
     HIP_TRY(c->v.alloc(c->n3)); HIP_TRY(c->v.zero());

@@ -1,4 +1,4 @@
-// oc_plan.cpp -- host-side plan of the on-chip PCG (pcg_onchip.hpp) for GENERAL meshes.  No GPU calls.
+// oc_plan.cpp -- host-side plan of the on-chip PCG (pcg_onchip2.hpp).  No GPU calls.
 //
 // The persistent PCG kernel gives every CU one block of rows.  Which rows, and in which order, decides (i) how much of a
 // matrix-vector product stays inside a block, (ii) how many other blocks a block waits for, (iii) how well the rows fill

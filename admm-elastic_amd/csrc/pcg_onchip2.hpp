@@ -1,30 +1,51 @@
-// pcg_onchip2.hpp -- the global solve of the ADMM step for GENERAL meshes: one persistent launch, two-level preconditioned
+// pcg_onchip2.hpp -- the global solve of the ADMM step: one persistent launch per solve for ANY mesh, two-level preconditioned
 // pipelined CG, every matrix-vector product out of LDS.
 //
-// Replaces the prefactored LDLT solve of src/LinearSolver.hpp:87-90 (same system, stop rule on the TRUE residual
-// r . D^-1 r <= tol^2 b . D^-1 b as in pcg_onchip.hpp, whose synchronisation primitives, safeguards and end game this
-// kernel shares).  What is new against pcg_onchip.hpp (kept as the A/B reference, ADMM_HIP_OC_PLAN=0):
-//   * the rows live in the plan's internal order (oc_plan.cpp): block = one CU = a COMPACT patch of the mesh (recursive
-//     graph bisection), 81 % of the non-zeros of the unstructured 1 M-tet body are block-local (index strips: 46 %);
-//   * a block keeps a LOCAL VECTOR in LDS: its own 64 spb entries plus its halo list -- the rows of other blocks its
-//     matrix rows reference, each fetched ONCE per product (one 8-byte sc1 load per axis) instead of once per referencing
-//     non-zero.  The product itself then runs entirely out of LDS: values (8 B) + 16-bit local columns, four columns per
-//     8-byte word.  On the unstructured body the gather of pcg_onchip.hpp issued 40 global loads per row and product
-//     (25 us per iteration); here a block issues ~3 per halo entry (~1 per row);
-//   * two-level preconditioner  M^-1 = D^-1 + P (P^T A P)^-1 P^T  with P = indicator vectors of kOcSub compact aggregates
-//     per block (<= 1024 coarse unknowns; the dense inverse is formed once on the host -- the system matrix of a scene
-//     never changes, src/Solver.cpp:225-226).  Jacobi needs 131 (cube) / 55 (unstructured body) iterations per solve of the
-//     1 M-tet benches, the block-local Gauss-Seidel sweep of pcg_onchip.hpp 85 / --, this 35 / 11.  The coarse part needs
-//     P^T v of ALL blocks: an all-to-all of 12 numbers per block.  It costs no extra synchronisation: m = M^-1 w is carried
-//     like w itself -- with y_w = Ac^-1 P^T w and y_z = Ac^-1 P^T z (this block's 4 x 3 entries), n = A m gives
-//     y_n = Ac^-1 P^T n after one all-to-all of the aggregate sums of n, then y_z = y_n + beta y_z, y_w -= alpha y_z --
-//     and that all-to-all rides on the iteration's one grid barrier next to the partial dot products.  An iteration is:
-//     publish m; neighbour hand-off (flags, no barrier); halo fetch; n = A m out of LDS; publish {P^T n, dots}; ONE grid
-//     barrier; reduce; coarse rows; update.
+// Replaces the prefactored LDLT solve of src/LinearSolver.hpp:87-90 (same system; stop rule on the TRUE residual,
+// r . D^-1 r <= tol^2 b . D^-1 b, the rule of the launch-per-iteration path in kernels.hpp, which stays as the fallback for
+// systems that do not fit the chip).  Why: at the BASELINE sizes one CG iteration of that path moves ~90 MB through L2 /
+// Infinity Cache although the whole problem fits ON CHIP: 256 CUs x (160 KB LDS + 512 KB VGPRs).
+//   * block = one CU = a COMPACT patch of the mesh in the plan's internal row order (oc_plan.cpp: recursive graph bisection;
+//     79 % of the non-zeros of the unstructured 1 M-tet body are block-local), wave = one 64-row SELL slice, thread = one
+//     vertex (3 dofs); the thread's matrix row lives in LDS for the whole solve, its vector entries in registers;
+//   * a block keeps a LOCAL VECTOR in LDS: its own 64 spb entries plus its halo list -- the rows of other blocks its matrix
+//     rows reference, each fetched ONCE per product.  The product itself runs entirely out of LDS: values (8 B) + 16-bit
+//     local columns, four columns per 8-byte word;
+//   * two-level preconditioner  M^-1 = S + P (P^T A P)^-1 P^T : P = kOcSub functions per block (the affine functions
+//     {1, x, y, z} of the block's vertices, energy-orthonormalised; or indicator vectors of compact aggregates), <= 1024
+//     coarse unknowns, dense inverse formed once on the host (the system matrix of a scene never changes,
+//     src/Solver.cpp:225-226); S = a degree-2 Chebyshev polynomial of the block-diagonal part of A (all of it in this
+//     block's LDS), applied behind the grid barrier's latency and carried by recurrence.  The coarse part needs P^T v of ALL
+//     blocks: an all-to-all of 12 numbers per block.  It costs no extra synchronisation: m = M^-1 w is carried like w
+//     itself -- with y_w = Ac^-1 P^T w and y_z = Ac^-1 P^T z (this block's 4 x 3 entries), n = A m gives
+//     y_n = Ac^-1 P^T n after one all-to-all of the coarse sums of n, then y_z = y_n + beta y_z, y_w -= alpha y_z -- and that
+//     all-to-all rides on the iteration's one grid barrier next to the partial dot products;
+//   * ONE grid barrier per iteration: the recurrences are those of pipelined CG (Ghysels & Vanroose 2014, general form with r
+//     and q = M^-1 s carried explicitly), whose dot products use vectors that exist BEFORE the product n = A m.  An
+//     iteration is: publish m; neighbour hand-off (flags, no barrier: oc_sync.hpp); halo fetch; n = A m out of LDS; publish
+//     {P^T n, dots}; ONE grid barrier (S n inside its latency); reduce; coarse rows; update;
+//   * the recycled (Galerkin) warm start of the ADMM loop is the first phase of the same launch and the new (correction,
+//     A correction) pair is written in its epilogue;
+//   * pipelined CG carries w = A u by recurrence, so its recursive residual can drift from the true one.  When the recurrence
+//     reports convergence the kernel recomputes r = b - A x, applies the stop rule to it, and starts the next PASS from that
+//     true residual if the test fails (a pass is trusted for nine orders of magnitude, kOcPipeFloor); a first pass of
+//     <= kOc2TrustIters iterations at a tolerance >= 1e-9 is not verified (its deviation is far below the tolerance).  After
+//     four passes, or when a pass stagnates near the FP64 floor, the kernel continues SEAMLESSLY (same x, u, p, gamma) in the
+//     CLASSIC Hestenes-Stiefel form (p = u + beta p, s = A p, alpha = gamma / (p . s): three synchronisations per iteration,
+//     but p . A p is computed directly -- the Chronopoulos-Gear form's alpha is a difference of nearly equal numbers near
+//     the floor and sent x to 1e254 on free nearly incompressible bodies).  A verification that fails twice without a 4x
+//     improvement means the FP64 floor has been reached: the solve stops as converged;
+//   * the three axes are independent systems (A = Ahat (x) I3) with their own b . M^-1 b; an axis whose right-hand side
+//     vanishes (C^T d of a floor contact has no x / z part) is measured against the largest axis, b = 0 returns x = 0;
+//   * sums that turn non-finite, or grow 1e8x above the best residual seen, send the solve back to the ENTRY x (still in
+//     global memory: x is written once, in the epilogue) and on in the classic form; a second failure returns the entry x,
+//     reported as unconverged -- never a non-finite vector;
+//   * every block reduces the partial records in the same fixed order, so all blocks take the same decisions and the result
+//     is deterministic run to run.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels.hpp"
-#include "pcg_onchip.hpp"
+#include "oc_sync.hpp"
 
 namespace admm_k {
 
@@ -44,7 +65,7 @@ struct Oc2Args {
     double *ubuf;                    // [2][n_rows][4] published vector (x, y, z, pad: one 32-byte sector per row, so a halo
                                      // entry is ONE request), double-buffered by phase parity
     double *part;                    // [2][8][G] per-block partial sums, double-buffered by barrier parity
-    unsigned *bar;                   // barrier words (see pcg_onchip.hpp)
+    unsigned *bar;                   // barrier words (see oc_sync.hpp)
     const int *nbr; unsigned long long *flags;
     int *counters; CgScal *scal; int *sig;
     unsigned long long *prof; int prof_block;
@@ -72,7 +93,7 @@ constexpr int kOc2Scratch = 4096;
 constexpr int kOc2TrustIters = 40;  // pipelined iterations of a first pass whose recursive residual is believed without verification   // bytes of LDS scratch ahead of the local vector and the matrix slab
 typedef __attribute__((address_space(3))) unsigned long long LdsU64;
 
-// first half of oc_barrier: drain this block's stores and arrive; oc_barrier_wait (pcg_onchip.hpp) is the second half
+// first half of oc_barrier: drain this block's stores and arrive; oc_barrier_wait (oc_sync.hpp) is the second half
 __device__ __forceinline__ void oc2_barrier_arrive(unsigned *bar) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -442,7 +463,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
             double q[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (!a.rc_on) { if (!true_residual(true, q, nullptr)) { aborted = true; break; } }
             else {
-                // recycled warm start (see pcg_onchip.hpp / k_rc_* in kernels.hpp): A-orthogonal projection of the initial
+                // recycled warm start (see k_rc_* in kernels.hpp): A-orthogonal projection of the initial
                 // error on the stored exact pairs (E_j, R_j = A E_j): per axis G c = g, x += E c, r0 -= R c
                 double ri[3], bj[3];
                 const int cnt = a.rc.cnt;
