@@ -232,6 +232,8 @@ struct admm_hip_ctx {
     bool uzc_on = false, uzc_usable = false;
     size_t uzc_cap = 0; int uzc_n = 0, uzc_n_act = 0;
     DevBuf<double> uzc_cols; DevBuf<int> uzc_slot, uzc_act, uzc_miss, uzc_info; DevBuf<unsigned char> uzc_flag;
+    DevBuf<double> uzc_G, uzc_part, uzc_gq, uz_y0; DevBuf<int> uzc_pos;   // Schur iterations on the active vertices (kernels.hpp: k_uzc_*)
+    bool uzc_compact = true;
     std::vector<int> uzc_slot_h;
     long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0;
     bool uz_freeze = false, uz_detected = false;   // tests (ADMM_HIP_UZ_FREEZE=1): Collider::detect only in the first ADMM iteration of a step
@@ -282,6 +284,7 @@ struct admm_hip_ctx {
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
         uzc_cols.release(); uzc_slot.release(); uzc_act.release(); uzc_miss.release(); uzc_info.release(); uzc_flag.release();
+        uzc_G.release(); uzc_part.release(); uzc_gq.release(); uz_y0.release(); uzc_pos.release();
         gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
         lk_ts.release(); lk_out.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
@@ -698,8 +701,17 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     if (n_missing <= 0) return 1;
     hipStream_t st = c->stream;
     const int nv = c->nv;
-    if ((size_t)c->uzc_n + (size_t)n_missing > c->uzc_cap) return 0;
-    if (!c->uzc_cols.p && c->uzc_cols.alloc(c->uzc_cap * (size_t)nv) != hipSuccess) { (void)hipGetLastError(); c->uzc_on = false; return 0; }
+    const size_t need = (size_t)c->uzc_n + (size_t)n_missing;
+    if (need > c->uzc_cap) return 0;
+    if (need * (size_t)nv > c->uzc_cols.n) {     // grow (doubling, at least 64 columns, never beyond the cap); the columns move once
+        const size_t have = c->uzc_cols.n / (size_t)nv, cols = std::min(c->uzc_cap, std::max<size_t>(need, std::max<size_t>(64, 2 * have)));
+        DevBuf<double> nb;
+        if (nb.alloc(cols * (size_t)nv) != hipSuccess) { (void)hipGetLastError(); return 0; }      // no room: this solve uses the PCG
+        if (hipStreamSynchronize(st) != hipSuccess) { nb.release(); return -1; }
+        if (c->uzc_n > 0 && hipMemcpy(nb.p, c->uzc_cols.p, sizeof(double) * (size_t)c->uzc_n * nv, hipMemcpyDeviceToDevice) != hipSuccess) { nb.release(); return -1; }
+        c->uzc_cols.release();
+        c->uzc_cols = nb;
+    }
     std::vector<int> miss(n_missing);
     if (hipMemcpy(miss.data(), c->uzc_miss.p, sizeof(int) * (size_t)n_missing, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     const double keep_tol = c->pcg_tol;
@@ -758,7 +770,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
         if (c->uzc_on) {   // the vertices C^T touches (ascending), and those without a cached column
             if (hipMemsetAsync(c->uzc_flag.p, 0, nv, st) != hipSuccess) return -1;
             hipLaunchKernelGGL(k_uz_act_flags, dim3(gv), dim3(256), 0, st, nv, c->uz_cn.p, dface, c->uzc_flag.p);
-            hipLaunchKernelGGL(k_uz_act_compact, dim3(1), dim3(1024), 0, st, nv, c->uzc_flag.p, c->uzc_slot.p, c->uzc_act.p, c->uzc_miss.p, c->uzc_info.p);
+            hipLaunchKernelGGL(k_uz_act_compact, dim3(1), dim3(1024), 0, st, nv, c->uzc_flag.p, c->uzc_slot.p, c->uzc_act.p, c->uzc_miss.p, c->uzc_pos.p, c->uzc_info.p);
             if (hipMemcpyAsync(info, c->uzc_info.p, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         }
         if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
@@ -778,7 +790,10 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     if (nh == 0) return launch_pcg_recycled(c, b, x); // no constraints: one prefactored solve (:78-81)
     hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 0, b, c->uz_cn.p, c->uz_y.p, c->uz_q1.p);       // q1 = b - C^T y
     if (dyn) launch_ct_dyn(c, nq, qlist, 0, c->uz_y.p, dface, dbary, c->uz_q1.p);
-    if (launch_pcg(c, c->uz_q1.p, x, c->pcg_max_iters)) return -1;                                               // x = A^-1 q1
+    // x = A^-1 q1, warm-started from the current x and -- like the contact-free solves -- projected on the recycled pairs first
+    // (ADMM_HIP_UZ_RECYCLE=0: plain warm start, as in rounds 1-2)
+    static const bool uz_rc = [] { const char *e = getenv("ADMM_HIP_UZ_RECYCLE"); return !(e && e[0] == '0'); }();
+    if (uz_rc ? launch_pcg_recycled(c, c->uz_q1.p, x) : launch_pcg(c, c->uz_q1.p, x, c->pcg_max_iters)) return -1;
     hipLaunchKernelGGL(k_uz_resid, dim3(gv), dim3(256), 0, st, nv, x, c->uz_cn.p, c->uz_cc.p, c->uz_r.p, c->uz_d.p, dface, dbary);
     if (hipMemsetAsync(c->uz_scal.p, 0, sizeof(UzScal), st) != hipSuccess) return -1;
     const double tol2 = c->uz_tol * c->uz_tol;
@@ -793,11 +808,45 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     // Only the general-mesh persistent kernel (k_pcg2) honours the device-side stop flag; on the other inner-solve paths (launch
     // per iteration, round-1 kernel) an iteration enqueued behind the stop would run a full dead solve: one at a time there.
     const bool use_cols = c->uzc_on && c->uzc_usable;      // every active vertex has its column of K^-1: no inner solves
+    // ... and the iterations themselves run on the active vertices only (k_uzc_*): the active x active block of K^-1 is extracted
+    // once per solve, x is updated once after the loop from the multiplier update y - y0
+    const int n_act = c->uzc_n_act, ldG = (n_act + 63) & ~63;
+    bool compact = use_cols && c->uzc_compact && n_act > 0 && n_act <= 8192;
+    int nseg = 1, seg_len = n_act;
+    if (compact) {
+        const int nbi = (n_act + 63) / 64;
+        nseg = std::max(1, std::min(std::min(16, nbi), 256 / nbi));
+        seg_len = (n_act + nseg - 1) / nseg;
+        const size_t needG = (size_t)n_act * ldG, needP = (size_t)nseg * n_act * 3;
+        if (c->uzc_G.n < needG) { c->uzc_G.release(); if (c->uzc_G.alloc(needG + needG / 4) != hipSuccess) { (void)hipGetLastError(); c->uzc_G.n = 0; c->uzc_G.p = nullptr; compact = false; } }
+        if (compact && c->uzc_part.n < needP) { c->uzc_part.release(); if (c->uzc_part.alloc(2 * needP) != hipSuccess) return -1; }
+        if (compact && c->uzc_gq.n < (size_t)3 * n_act) { c->uzc_gq.release(); if (c->uzc_gq.alloc((size_t)6 * n_act) != hipSuccess) return -1; }
+    }
+    if (compact) {
+        if (hipMemcpyAsync(c->uz_y0.p, c->uz_y.p, nv * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+        hipLaunchKernelGGL(k_uzc_extract, dim3((n_act + 255) / 256, n_act), dim3(256), 0, st, nv, n_act, ldG, c->uzc_act.p, c->uzc_slot.p, c->uzc_cols.p, c->uzc_G.p);
+    }
     const bool skip_honoured = use_cols || (c->oc_enabled && c->oc_plan);
     if (!skip_honoured) chunk = 1;
     while (launched < c->uz_max_iters) {
         const int n = std::min(chunk, c->uz_max_iters - launched);
         for (int it = 0; it < n; ++it) {
+            if (compact) {      // one Schur iteration on the active vertices: two launches (+ C^T d by the dense kernels if rows share face vertices)
+                if (dyn) {
+                    hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 1, b, c->uz_cn.p, c->uz_d.p, c->uz_q1.p);
+                    launch_ct_dyn(c, nq, qlist, 1, c->uz_d.p, dface, dbary, c->uz_q1.p);
+                }
+                hipLaunchKernelGGL(k_uzc_matvec, dim3((n_act + 63) / 64, nseg), dim3(256), 0, st, n_act, ldG, seg_len, c->uzc_act.p, c->uzc_G.p,
+                                   c->uz_cn.p, c->uz_d.p, dyn ? c->uz_q1.p : (const double *)nullptr, c->uzc_part.p, stop_flag);
+                if (n_act <= 1024)
+                    hipLaunchKernelGGL((k_uzc_rows<true>), dim3(1), dim3(1024), 0, st, n_act, nseg, c->uzc_act.p, c->uzc_pos.p, c->uzc_part.p, c->uzc_gq.p,
+                                       c->uz_cn.p, dface, dbary, c->uz_d.p, c->uz_r.p, c->uz_y.p, c->uz_q3.p, tol2, c->uz_scal.p);
+                else
+                    hipLaunchKernelGGL((k_uzc_rows<false>), dim3(1), dim3(1024), 0, st, n_act, nseg, c->uzc_act.p, c->uzc_pos.p, c->uzc_part.p, c->uzc_gq.p,
+                                       c->uz_cn.p, dface, dbary, c->uz_d.p, c->uz_r.p, c->uz_y.p, c->uz_q3.p, tol2, c->uz_scal.p);
+                c->uzc_applies += 1;
+                continue;
+            }
             hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 1, b, c->uz_cn.p, c->uz_d.p, c->uz_q1.p);   // q1 = C^T d
             if (dyn) launch_ct_dyn(c, nq, qlist, 1, c->uz_d.p, dface, dbary, c->uz_q1.p);
             if (use_cols) {                                                                                          // q2 = A^-1 q1
@@ -822,6 +871,14 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         if (h.stop) break;
         chunk = skip_honoured ? 2 : 1;
+    }
+    if (compact) {      // x = x0 - A^-1 C^T (y - y0): one pass over the full columns
+        hipLaunchKernelGGL(k_uzc_dy, dim3(gv), dim3(256), 0, st, nv, c->uz_y.p, c->uz_y0.p, c->uz_q3.p);
+        hipLaunchKernelGGL(k_uz_ct, dim3(gv), dim3(256), 0, st, nv, 1, b, c->uz_cn.p, c->uz_q3.p, c->uz_q1.p);
+        if (dyn) launch_ct_dyn(c, nq, qlist, 1, c->uz_q3.p, dface, dbary, c->uz_q1.p);
+        hipLaunchKernelGGL(k_uz_cols_apply, dim3((nv + 63) / 64), dim3(256), 0, st, nv, n_act, c->uzc_act.p, c->uzc_slot.p, c->uzc_cols.p,
+                           c->uz_q1.p, c->uz_q2.p, (const int *)nullptr);
+        hipLaunchKernelGGL(k_uzc_xsub, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, x, c->uz_q2.p);
     }
     c->uz_prev_iters = h.iters;
     *iters = h.iters;
@@ -1464,6 +1521,8 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 c->uzc_slot_h.assign(nv, -1);
                 HIP_TRY(c->uzc_slot.upload(c->uzc_slot_h)); HIP_TRY(c->uzc_act.alloc(nv)); HIP_TRY(c->uzc_miss.alloc(nv));
                 HIP_TRY(c->uzc_info.alloc(2)); HIP_TRY(c->uzc_info.zero()); HIP_TRY(c->uzc_flag.alloc(nv));
+                HIP_TRY(c->uzc_pos.alloc(nv)); HIP_TRY(c->uz_y0.alloc(nv));
+                { const char *ce = getenv("ADMM_HIP_UZ_COMPACT"); c->uzc_compact = !(ce && ce[0] == '0'); }   // 0: full-height column pass in every Schur iteration (A/B)
             }
         }
     }

@@ -1523,26 +1523,42 @@ __global__ __launch_bounds__(256) void k_uz_act_flags(int nv, const double *__re
     if (dface != nullptr && dface[3 * (size_t)v] >= 0)
         for (int j = 0; j < 3; ++j) flag[dface[3 * (size_t)v + j]] = 1;      // (several rows may share a face vertex: same value)
 }
-// One block: the flagged vertices in ascending order (the order of the sums in k_uz_cols_apply: deterministic), and those of them
-// that have no column yet.  info[0] = active vertices, info[1] = missing columns.
+// One block: the flagged vertices in ascending order (the order of the sums in k_uz_cols_apply / k_uzc_matvec: deterministic),
+// those of them that have no column yet, and the inverse map pos[v] = place of v in the list (-1: not active).
+// info[0] = active vertices, info[1] = missing columns.  Four consecutive vertices per thread and pass.
 __global__ __launch_bounds__(1024) void k_uz_act_compact(int nv, const unsigned char *__restrict__ flag, const int *__restrict__ slot,
-                                                         int *__restrict__ act, int *__restrict__ miss, int *__restrict__ info) {
+                                                         int *__restrict__ act, int *__restrict__ miss, int *__restrict__ pos, int *__restrict__ info) {
     __shared__ int wsum[2][16], base[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 2) base[tid] = 0;
     __syncthreads();
-    for (int v0 = 0; v0 < nv; v0 += 1024) {
-        const int v = v0 + tid;
-        const bool a = v < nv && flag[v] != 0;
-        const bool m = a && slot[v] < 0;
-        const unsigned long long ba = __ballot(a), bm = __ballot(m);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (lane == 0) { wsum[0][wv] = __popcll(ba); wsum[1][wv] = __popcll(bm); }
+    for (int v0 = 0; v0 < nv; v0 += 4096) {
+        const int vb = v0 + 4 * tid;
+        bool a[4], m[4];
+        int na = 0, nm = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = vb + k < nv && flag[vb + k] != 0;
+            m[k] = a[k] && slot[vb + k] < 0;
+            na += a[k] ? 1 : 0; nm += m[k] ? 1 : 0;
+        }
+        // exclusive prefix over the wave (lanes in vertex order), then over the waves
+        int pa = na, pm = nm;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int ta = __shfl_up(pa, o), tm = __shfl_up(pm, o);
+            if (lane >= o) { pa += ta; pm += tm; }
+        }
+        if (lane == 63) { wsum[0][wv] = pa; wsum[1][wv] = pm; }
         __syncthreads();
-        int oa = base[0], om = base[1];
+        int oa = base[0] + pa - na, om = base[1] + pm - nm;
         for (int w = 0; w < wv; ++w) { oa += wsum[0][w]; om += wsum[1][w]; }
-        if (a) act[oa + __popcll(ba & below)] = v;
-        if (m) miss[om + __popcll(bm & below)] = v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (vb + k < nv) pos[vb + k] = a[k] ? oa : -1;
+            if (a[k]) act[oa++] = vb + k;
+            if (m[k]) miss[om++] = vb + k;
+        }
         __syncthreads();
         if (tid == 0) { int ta = 0, tm = 0; for (int w = 0; w < 16; ++w) { ta += wsum[0][w]; tm += wsum[1][w]; } base[0] += ta; base[1] += tm; }
         __syncthreads();
@@ -1607,6 +1623,197 @@ __global__ __launch_bounds__(256) void k_uz_cols_apply(int nv, int n_act, const 
         const int ii = blockIdx.x * 64 + lane;
         if (ii < nv) q2[3 * (size_t)ii + c] = ((part[c][0][lane] + part[c][1][lane]) + part[c][2][lane]) + part[c][3][lane];
     }
+}
+
+// ---- the Schur iterations on the ACTIVE vertices only -----------------------------------------------------------------
+// Inside the Schur CG only C A^-1 C^T d is needed (r -= alpha C q2), i.e. q2 = A^-1 C^T d at the active vertices: the active x
+// active block of K^-1, extracted once per solve from the cached columns (k_uzc_extract: G[j][i] = (K^-1 e_(act_j))[act_i],
+// n_act^2 doubles: 4 MB at 729 active vertices against 115 MB for the full-height columns).  An iteration is then two launches:
+// k_uzc_matvec (g = G t with t = (C^T d) at the active vertices, segments of the j range in parallel) and k_uzc_rows (ONE block:
+// sums the segments, q3 = C g, alpha, y += alpha d, r -= alpha q3, the stop test, beta, d = r - beta d: UzawaCG.hpp:96-118, the
+// arithmetic of k_uz_dots / alpha / step / beta / dir on the active rows).  x is not touched inside the loop:
+// x = x0 - A^-1 C^T (y - y0) is applied once after it through the full columns (k_uz_cols_apply).
+__global__ __launch_bounds__(256) void k_uzc_extract(int nv, int n_act, int ld, const int *__restrict__ act, const int *__restrict__ slot,
+                                                     const double *__restrict__ cols, double *__restrict__ G) {
+    const int j = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_act) G[(size_t)j * ld + i] = cols[(size_t)slot[act[j]] * nv + act[i]];
+}
+// part[s][i][:] = sum over the j of segment s of G[j][i] t_j; t_j = q1[act_j] (q1 = C^T d formed by the dense kernels: scenes with
+// dynamic rows) or cn[act_j] d[act_j] (passive rows only: q1 == nullptr).  Block = 64 i x 4 waves (wave w: j = w, w + 4, ...).
+__global__ __launch_bounds__(256) void k_uzc_matvec(int n_act, int ld, int seg_len, const int *__restrict__ act, const double *__restrict__ G,
+                                                    const double *__restrict__ cn, const double *__restrict__ d, const double *__restrict__ q1,
+                                                    double *__restrict__ part, const int *__restrict__ stop) {
+    if (stop && *stop) return;
+    __shared__ double red[3][4][64];
+    __shared__ double tq[3][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane, ic = i < n_act ? i : n_act - 1;
+    const int j0 = blockIdx.y * seg_len, j1 = min(n_act, j0 + seg_len);
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    for (int a0 = j0; a0 < j1; a0 += 256) {
+        const int na = min(256, j1 - a0);
+        __syncthreads();
+        if ((int)threadIdx.x < na) {
+            const int v = act[a0 + threadIdx.x];
+            if (q1) { tq[0][threadIdx.x] = q1[3 * (size_t)v]; tq[1][threadIdx.x] = q1[3 * (size_t)v + 1]; tq[2][threadIdx.x] = q1[3 * (size_t)v + 2]; }
+            else { const double dv = d[v]; tq[0][threadIdx.x] = cn[3 * (size_t)v] * dv; tq[1][threadIdx.x] = cn[3 * (size_t)v + 1] * dv; tq[2][threadIdx.x] = cn[3 * (size_t)v + 2] * dv; }
+        }
+        __syncthreads();
+        const double *Gp = G + (size_t)a0 * ld + ic;
+        int k = wv;
+        for (; k + 28 < na; k += 32) {
+            double g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = Gp[(size_t)(k + 4 * u) * ld];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc0 = fma(g[u], tq[0][k + 4 * u], acc0); acc1 = fma(g[u], tq[1][k + 4 * u], acc1); acc2 = fma(g[u], tq[2][k + 4 * u], acc2);
+            }
+        }
+        for (; k < na; k += 4) {
+            const double g = Gp[(size_t)k * ld];
+            acc0 = fma(g, tq[0][k], acc0); acc1 = fma(g, tq[1][k], acc1); acc2 = fma(g, tq[2][k], acc2);
+        }
+    }
+    red[0][wv][lane] = acc0; red[1][wv][lane] = acc1; red[2][wv][lane] = acc2;
+    __syncthreads();
+    if (threadIdx.x < 192) {
+        const int c = threadIdx.x >> 6;
+        if (i < n_act) part[((size_t)blockIdx.y * n_act + i) * 3 + c] = ((red[c][0][lane] + red[c][1][lane]) + red[c][2][lane]) + red[c][3][lane];
+    }
+}
+// sum of two quantities over a block of 1024 threads, fixed order; result in all threads
+__device__ __forceinline__ void block_sum2_1024(double &a, double &b, double *lds /* [32] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const double sa = wave_sum(a), sb = wave_sum(b);
+    __syncthreads();
+    if (lane == 0) { lds[wv] = sa; lds[16 + wv] = sb; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < 16; ++w) { ta += lds[w]; tb += lds[16 + w]; }
+    a = ta; b = tb;
+}
+// ONE: n_act <= 1024, one active vertex per thread: everything it needs is loaded once (all loads in flight together) and stays
+// in registers / LDS across the phases -- the kernel is a chain of dependent global latencies otherwise.
+template <bool ONE>
+__global__ __launch_bounds__(1024) void k_uzc_rows(int n_act, int nseg, const int *__restrict__ act, const int *__restrict__ pos,
+                                                   const double *__restrict__ part, double *__restrict__ gq, const double *__restrict__ cn,
+                                                   const int *__restrict__ dface, const double *__restrict__ dbary, double *__restrict__ d,
+                                                   double *__restrict__ r, double *__restrict__ y, double *__restrict__ q3, double tol2,
+                                                   UzScal *__restrict__ sc) {
+    __shared__ double lds[32];
+    __shared__ double s_alpha, s_beta;
+    __shared__ int s_stop;
+    __shared__ double sg[ONE ? 3 * 1024 : 3];
+    if (sc->stop) return;
+    const int tid = threadIdx.x;
+    if (ONE) {
+        const bool on = tid < n_act;
+        const int v = on ? act[tid] : 0;
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0, dv = 0.0, rv = 0.0, yv = 0.0, g[3] = {0.0, 0.0, 0.0}, bw[3] = {0.0, 0.0, 0.0};
+        int fp[3] = {-1, -1, -1};
+        if (on) {
+            c0 = cn[3 * (size_t)v]; c1 = cn[3 * (size_t)v + 1]; c2 = cn[3 * (size_t)v + 2];
+            dv = d[v]; rv = r[v]; yv = y[v];
+            if (dface != nullptr) {
+                const int f0 = dface[3 * (size_t)v];
+                if (f0 >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { fp[j] = pos[dface[3 * (size_t)v + j]]; bw[j] = dbary[3 * (size_t)v + j]; }
+                }
+            }
+            for (int s = 0; s < nseg; ++s)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] += part[((size_t)s * n_act + tid) * 3 + c];
+        }
+        sg[3 * tid] = g[0]; sg[3 * tid + 1] = g[1]; sg[3 * tid + 2] = g[2];
+        __syncthreads();
+        double t = c0 * g[0] + c1 * g[1] + c2 * g[2];
+        if (fp[0] >= 0 && (c0 != 0.0 || c1 != 0.0 || c2 != 0.0)) {
+            double rr = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) rr -= bw[j] * (c0 * sg[3 * fp[j]] + c1 * sg[3 * fp[j] + 1] + c2 * sg[3 * fp[j] + 2]);
+            t += rr;
+        }
+        double s0 = dv * t, s1 = dv * rv;
+        block_sum2_1024(s0, s1, lds);
+        const double denom = s0;
+        if (fabs(denom) < 2.2250738585072014e-308) { if (tid == 0) { sc->denom = denom; sc->stop = 1; sc->alpha = 0.0; } return; }
+        const double al = s1 / denom;
+        yv += al * dv; rv -= al * t;
+        s0 = rv * rv; s1 = rv * t;
+        block_sum2_1024(s0, s1, lds);
+        if (on) { y[v] = yv; r[v] = rv; q3[v] = t; }
+        if (s0 < tol2) { if (tid == 0) { sc->denom = denom; sc->alpha = al; sc->rr = s0; sc->stop = 1; } return; }
+        const double be = s1 / denom;
+        if (on) d[v] = rv - be * dv;
+        if (tid == 0) { sc->denom = denom; sc->alpha = al; sc->rr = s0; sc->beta = be; sc->iters += 1; }
+        return;
+    }
+    for (int a = tid; a < n_act; a += 1024)                   // g = sum of the segments (fixed order)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double g = 0.0;
+            for (int s = 0; s < nseg; ++s) g += part[((size_t)s * n_act + a) * 3 + c];
+            gq[3 * (size_t)a + c] = g;
+        }
+    __syncthreads();
+    double s0 = 0.0, s1 = 0.0;
+    for (int a = tid; a < n_act; a += 1024) {                 // q3 = C g on the rows; d.q3, d.r   (k_uz_dots)
+        const int v = act[a];
+        const double c0 = cn[3 * (size_t)v], c1 = cn[3 * (size_t)v + 1], c2 = cn[3 * (size_t)v + 2];
+        double t = c0 * gq[3 * (size_t)a] + c1 * gq[3 * (size_t)a + 1] + c2 * gq[3 * (size_t)a + 2];
+        if (dface != nullptr && dface[3 * (size_t)v] >= 0 && (c0 != 0.0 || c1 != 0.0 || c2 != 0.0)) {
+            double rr = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int f = pos[dface[3 * (size_t)v + j]];
+                rr -= dbary[3 * (size_t)v + j] * (c0 * gq[3 * (size_t)f] + c1 * gq[3 * (size_t)f + 1] + c2 * gq[3 * (size_t)f + 2]);
+            }
+            t += rr;
+        }
+        q3[v] = t;
+        s0 = fma(d[v], t, s0);
+        s1 = fma(d[v], r[v], s1);
+    }
+    block_sum2_1024(s0, s1, lds);
+    if (tid == 0) {                                           // k_uz_alpha
+        sc->denom = s0;
+        s_stop = 0;
+        if (fabs(s0) < 2.2250738585072014e-308) { sc->stop = 1; sc->alpha = 0.0; s_stop = 1; s_alpha = 0.0; }
+        else { s_alpha = s1 / s0; sc->alpha = s_alpha; }
+    }
+    __syncthreads();
+    if (s_stop) return;
+    const double al = s_alpha;
+    s0 = 0.0; s1 = 0.0;
+    for (int a = tid; a < n_act; a += 1024) {                 // y += alpha d; r -= alpha q3; r.r, r.q3   (k_uz_step without x)
+        const int v = act[a];
+        y[v] += al * d[v];
+        const double rv = r[v] - al * q3[v];
+        r[v] = rv;
+        s0 = fma(rv, rv, s0);
+        s1 = fma(rv, q3[v], s1);
+    }
+    block_sum2_1024(s0, s1, lds);
+    if (tid == 0) {                                           // k_uz_beta
+        sc->rr = s0;
+        if (s0 < tol2) { sc->stop = 1; s_stop = 1; }
+        else { s_beta = s1 / sc->denom; sc->beta = s_beta; sc->iters += 1; }
+    }
+    __syncthreads();
+    if (s_stop) return;
+    const double be = s_beta;
+    for (int a = tid; a < n_act; a += 1024) { const int v = act[a]; d[v] = r[v] - be * d[v]; }   // k_uz_dir
+}
+// w = y - y0 (the multiplier update of the whole Schur CG), and x -= q2
+__global__ __launch_bounds__(256) void k_uzc_dy(int nv, const double *__restrict__ y, const double *__restrict__ y0, double *__restrict__ w) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v < nv) w[v] = y[v] - y0[v];
+}
+__global__ __launch_bounds__(256) void k_uzc_xsub(int n3, double *__restrict__ x, const double *__restrict__ q2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n3) x[i] -= q2[i];
 }
 
 } // namespace admm_k

@@ -540,9 +540,10 @@ def test_global_solve_uzawa_collisions(what):
 
 
 def test_uzawa_cached_columns_equal_inner_solves(monkeypatch):
-    """The Schur iterations apply A^-1 through cached columns of K^-1 (one pass over the active columns) instead of one PCG solve
-    each: same Schur CG, same result as with the inner solves (ADMM_HIP_UZ_CACHE=0) and as the oracle; a vertex's column is solved
-    for once; a cache that cannot hold the active set falls back to the inner solves."""
+    """The Schur iterations apply A^-1 through cached columns of K^-1 instead of one PCG solve each -- on the active vertices only
+    (the active x active block of K^-1, x updated once after the loop), or as a full-height column pass per iteration
+    (ADMM_HIP_UZ_COMPACT=0): same Schur CG, same result as with the inner solves (ADMM_HIP_UZ_CACHE=0) and as the oracle; a vertex's
+    column is solved for once; a cache that cannot hold the active set falls back to the inner solves."""
     sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=8, linsolver=2, size=0.5)
     sc.obstacles.append((0, [0.03, 0.0, 0.0, 0.0]))
     o = sc.make_oracle(mode=1)
@@ -565,6 +566,11 @@ def test_uzawa_cached_columns_equal_inner_solves(monkeypatch):
     st0 = s0.uzawa_cache_stats()
     assert st0["columns"] == -1 and st0["schur_from_columns"] == 0 and st0["schur_by_pcg"] >= it0 - 1
     assert np.abs(xg - x0).max() < 1e-9 and np.abs(xg - xo).max() < 1e-7 and abs(itg - it0) <= 2
+    monkeypatch.setenv("ADMM_HIP_UZ_COMPACT", "0")     # full-height column pass and the dense row kernels in every Schur iteration
+    s2 = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+    monkeypatch.delenv("ADMM_HIP_UZ_COMPACT")
+    x2, it2 = s2.global_solve(b, x)
+    assert np.abs(x2 - xg).max() < 1e-10 and it2 == itg, (np.abs(x2 - xg).max(), it2, itg)
     monkeypatch.setenv("ADMM_HIP_UZ_CACHE_MB", "%g" % (8.0 * len(sc.x) * (len(hits) - 1) / 1048576.0))   # one column short
     s1 = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
     monkeypatch.delenv("ADMM_HIP_UZ_CACHE_MB")
