@@ -312,8 +312,9 @@ int admm_host_tet_rest_positions(int32_t n_verts, int32_t n_tets, const int32_t 
 /* UzawaCG's Schur iterations (src/UzawaCG.hpp:92-120) apply A^-1 to C^T d.  A never changes after initialize and C^T d is
  * non-zero only at constrained vertices, so the library keeps the columns of K^-1 (A = K (x) I3) of every vertex that has ever
  * carried a constraint row: solved once by the on-chip PCG at 1e-2 x pcg_tol (<= 1e-10), three per launch, kept in HBM
- * (ADMM_HIP_UZ_CACHE_MB, default 16384); a Schur iteration is then one pass over the active columns instead of a PCG solve.
- * ADMM_HIP_UZ_CACHE=0: every Schur iteration is a PCG solve.  columns: cached columns (-1: cache off); column_solves: PCG
+ * (grown on demand up to ADMM_HIP_UZ_CACHE_MB, default 16384).  The Schur iterations then run on the active vertices only (the
+ * active x active block of K^-1; ADMM_HIP_UZ_COMPACT=0: one pass over the full-height active columns per iteration) and x is
+ * updated once from the multiplier update.  ADMM_HIP_UZ_CACHE=0: every Schur iteration is a PCG solve.  columns: cached columns (-1: cache off); column_solves: PCG
  * launches spent on columns; schur_from_columns / schur_by_pcg: Schur iterations served either way since create. */
 int admm_hip_uzawa_cache_stats(admm_hip_ctx *ctx, int64_t *columns, int64_t *column_solves, int64_t *schur_from_columns,
                                int64_t *schur_by_pcg);
