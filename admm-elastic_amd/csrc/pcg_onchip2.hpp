@@ -211,14 +211,24 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     // own entries -> local vector and -> this wave's 64 sectors of ubuf: two 16-byte write-through stores per lane, each
     // instruction covering 1 KB of whole sectors (lane pairs write the two halves of a row's sector: half-written sectors
     // from a row-per-lane layout measured 3x slower to drain); transposed through the local vector
+    // layout of the local vector: component j of entry c.  ADMM_OC2_AOS: the three components of an entry side by side (24-byte
+    // stride: the row loop's three reads per matrix entry become one ds_read2_b64 + one ds_read_b64); 0: per-axis arrays
+#ifndef ADMM_OC2_AOS
+#define ADMM_OC2_AOS 0
+#endif
+#if ADMM_OC2_AOS
+#define OC2_VX(c, j) (3 * (c) + (j))
+#else
+#define OC2_VX(c, j) ((j) * NV + (c))
+#endif
     auto publish = [&](const double *v) {
         const int tid = otid(), lane = tid & 63;
-        LdsD *o = vec + (tid & ~63);
-        o[lane] = v[0]; o[NV + lane] = v[1]; o[2 * NV + lane] = v[2];
+        const int wb = tid & ~63;
+        vec[OC2_VX(wb + lane, 0)] = v[0]; vec[OC2_VX(wb + lane, 1)] = v[1]; vec[OC2_VX(wb + lane, 2)] = v[2];
         const int r0 = lane >> 1, hi = lane & 1;
         const int bo = (int)(ph & 1u) * ub + s * 2048 + lane * 16;
-        const double a0 = o[(hi ? 2 * NV : 0) + r0], a1 = hi ? 0.0 : o[NV + r0];
-        const double b0 = o[(hi ? 2 * NV : 0) + 32 + r0], b1 = hi ? 0.0 : o[NV + 32 + r0];
+        const double a0 = vec[OC2_VX(wb + r0, hi ? 2 : 0)], a1 = hi ? 0.0 : vec[OC2_VX(wb + r0, 1)];
+        const double b0 = vec[OC2_VX(wb + 32 + r0, hi ? 2 : 0)], b1 = hi ? 0.0 : vec[OC2_VX(wb + 32 + r0, 1)];
         oc_store_sc1(rs_u, bo, a0, a1);
         oc_store_sc1(rs_u, bo + 1024, b0, b1);
     };
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = (int)((cc >> (16 * i)) & 0xffffull);
-                acc[0] = fma(vv[i], vec[c], acc[0]); acc[1] = fma(vv[i], vec[NV + c], acc[1]); acc[2] = fma(vv[i], vec[2 * NV + c], acc[2]);
+                acc[0] = fma(vv[i], vec[OC2_VX(c, 0)], acc[0]); acc[1] = fma(vv[i], vec[OC2_VX(c, 1)], acc[1]); acc[2] = fma(vv[i], vec[OC2_VX(c, 2)], acc[2]);
             }
         }
     };
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
             union { double d[2]; v4u v; } g0, g1;
             g0.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, vb + src * 32, 0, 16);
             g1.v = __builtin_amdgcn_raw_buffer_load_b128(rs_u, vb + src * 32 + 16, 0, 16);
-            vec[T + h] = g0.d[0]; vec[NV + T + h] = g0.d[1]; vec[2 * NV + T + h] = g1.d[0];
+            vec[OC2_VX(T + h, 0)] = g0.d[0]; vec[OC2_VX(T + h, 1)] = g0.d[1]; vec[OC2_VX(T + h, 2)] = g1.d[0];
         }
         __syncthreads();
         double acc[3] = {0.0, 0.0, 0.0};
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     };
     auto halo_and_rows_self_from_vec = [&](double *out) {
         const int tid = otid();
-        const double self[3] = {vec[tid], vec[NV + tid], vec[2 * NV + tid]};    // written by this thread in publish()
+        const double self[3] = {vec[OC2_VX(tid, 0)], vec[OC2_VX(tid, 1)], vec[OC2_VX(tid, 2)]};    // written by this thread in publish()
         halo_and_rows(self, out);
     };
     // The block-local part of the preconditioner: a degree-2 Chebyshev polynomial in D^-1 A_bb, A_bb = the entries of A whose
@@ -287,8 +297,8 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         }
         const int tid = otid();
 #pragma unroll
-        for (int j = 0; j < 3; ++j) vec[j * NV + tid] = rd[j] * v[j];
-        for (int h = tid; h < nh; h += T) { vec[T + h] = 0.0; vec[NV + T + h] = 0.0; vec[2 * NV + T + h] = 0.0; }
+        for (int j = 0; j < 3; ++j) vec[OC2_VX(tid, j)] = rd[j] * v[j];
+        for (int h = tid; h < nh; h += T) { vec[OC2_VX(T + h, 0)] = 0.0; vec[OC2_VX(T + h, 1)] = 0.0; vec[OC2_VX(T + h, 2)] = 0.0; }
         __syncthreads();
         double acc[3] = {0.0, 0.0, 0.0};
         row_times_local_vector(acc);
