@@ -233,7 +233,7 @@ struct admm_hip_ctx {
     size_t uzc_cap = 0; int uzc_n = 0, uzc_n_act = 0;
     DevBuf<double> uzc_cols; DevBuf<int> uzc_slot, uzc_act, uzc_miss, uzc_info; DevBuf<unsigned char> uzc_flag;
     DevBuf<double> uzc_G, uzc_part, uzc_gq, uz_y0; DevBuf<int> uzc_pos;   // Schur iterations on the active vertices (kernels.hpp: k_uzc_*)
-    bool uzc_compact = true;
+    bool uzc_compact = true; int uzc_one_max = 1024, uzc_compact_max = 8192;   // (the limits are lowered by tests to reach the general paths on small scenes)
     std::vector<int> uzc_slot_h;
     long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0;
     bool uz_freeze = false, uz_detected = false;   // tests (ADMM_HIP_UZ_FREEZE=1): Collider::detect only in the first ADMM iteration of a step
@@ -811,7 +811,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     // ... and the iterations themselves run on the active vertices only (k_uzc_*): the active x active block of K^-1 is extracted
     // once per solve, x is updated once after the loop from the multiplier update y - y0
     const int n_act = c->uzc_n_act, ldG = (n_act + 63) & ~63;
-    bool compact = use_cols && c->uzc_compact && n_act > 0 && n_act <= 8192;
+    bool compact = use_cols && c->uzc_compact && n_act > 0 && n_act <= c->uzc_compact_max;      // (G is n_act^2 doubles: 512 MB at the limit)
     int nseg = 1, seg_len = n_act;
     if (compact) {
         const int nbi = (n_act + 63) / 64;
@@ -838,7 +838,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
                 }
                 hipLaunchKernelGGL(k_uzc_matvec, dim3((n_act + 63) / 64, nseg), dim3(256), 0, st, n_act, ldG, seg_len, c->uzc_act.p, c->uzc_G.p,
                                    c->uz_cn.p, c->uz_d.p, dyn ? c->uz_q1.p : (const double *)nullptr, c->uzc_part.p, stop_flag);
-                if (n_act <= 1024)
+                if (n_act <= c->uzc_one_max)
                     hipLaunchKernelGGL((k_uzc_rows<true>), dim3(1), dim3(1024), 0, st, n_act, nseg, c->uzc_act.p, c->uzc_pos.p, c->uzc_part.p, c->uzc_gq.p,
                                        c->uz_cn.p, dface, dbary, c->uz_d.p, c->uz_r.p, c->uz_y.p, c->uz_q3.p, tol2, c->uz_scal.p);
                 else
@@ -1523,6 +1523,8 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 HIP_TRY(c->uzc_info.alloc(2)); HIP_TRY(c->uzc_info.zero()); HIP_TRY(c->uzc_flag.alloc(nv));
                 HIP_TRY(c->uzc_pos.alloc(nv)); HIP_TRY(c->uz_y0.alloc(nv));
                 { const char *ce = getenv("ADMM_HIP_UZ_COMPACT"); c->uzc_compact = !(ce && ce[0] == '0'); }   // 0: full-height column pass in every Schur iteration (A/B)
+                { const char *e1 = getenv("ADMM_HIP_UZ_ONE_MAX"), *e2 = getenv("ADMM_HIP_UZ_COMPACT_MAX");      // test hooks
+                  if (e1) c->uzc_one_max = std::max(0, std::min(1024, atoi(e1))); if (e2) c->uzc_compact_max = std::max(0, atoi(e2)); }
             }
         }
     }
