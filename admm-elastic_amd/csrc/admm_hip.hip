@@ -183,7 +183,7 @@ struct admm_hip_ctx {
     int *d_sig = nullptr;         // device alias of h_sig
     // on-chip PCG (pcg_onchip2.hpp): one persistent launch per solve when the system fits the chip
     bool oc_enabled = false;
-    int oc_G = 0, oc_spb = 0, oc_T = 0, oc_wl = 0; size_t oc_lds = 0;
+    int oc_G = 0, oc_spb = 0, oc_T = 0; size_t oc_lds = 0;
     DevBuf<double> oc_ubuf, oc_part, oc_rc_part;
     DevBuf<unsigned> oc_bar;
     DevBuf<int> oc_nbr; DevBuf<unsigned long long> oc_flags;   // neighbour hand-off of the pipelined iteration
@@ -736,8 +736,9 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     return 1;
 }
 
-// UzawaCG::solve (src/UzawaCG.hpp:57-125).  Host-driven outer loop (one stream sync per Schur-CG
-// iteration, negligible next to the inner solves); returns the reference's iteration count via *iters.
+// UzawaCG::solve (src/UzawaCG.hpp:57-125).  The Schur-CG loop is enqueued in chunks, its stop decision is taken on the device; A^-1 of
+// every iteration through cached columns of K^-1 (kernels.hpp: k_uz_cols_apply, k_uzc_*) or, without them, an on-chip PCG solve.
+// Returns the reference's iteration count via *iters.
 int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     hipStream_t st = c->stream;
     const int nv = c->nv, gv = blocks_for(nv);
@@ -805,8 +806,8 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     const int *stop_flag = &c->uz_scal.p->stop;
     int launched = 0;
     int chunk = std::max(1, std::min(c->uz_max_iters, c->uz_prev_iters > 0 ? c->uz_prev_iters + 1 : 4));
-    // Only the general-mesh persistent kernel (k_pcg2) honours the device-side stop flag; on the other inner-solve paths (launch
-    // per iteration, round-1 kernel) an iteration enqueued behind the stop would run a full dead solve: one at a time there.
+    // Only the persistent kernel (k_pcg2) and the column kernels honour the device-side stop flag; on the launch-per-iteration
+    // inner-solve path an iteration enqueued behind the stop would run a full dead solve: one at a time there.
     const bool use_cols = c->uzc_on && c->uzc_usable;      // every active vertex has its column of K^-1: no inner solves
     // ... and the iterations themselves run on the active vertices only (k_uzc_*): the active x active block of K^-1 is extracted
     // once per solve, x is updated once after the loop from the multiplier update y - y0

@@ -3,9 +3,12 @@
 // Data layout in HBM (FP64, int32 indices):
 //   node vectors  x, v, m, Mxbar, curr, b, r, p, ...   [n_verts][3] interleaved (the API's layout)
 //   per-tet       idx  int4[nt]            one 16-B load per lane, coalesced
-//                 Binv [9][ld], u [9][ld], z [9][ld], cf [12][ld]   SoA, ld = nt + 1: lane t reads
-//                 component c at c*ld + t -> every load/store of a wave is one contiguous 512-B run
-//                 sc [ld] = dt^2 w^2, mat int[nt] -> Mat table {mu, lambda, k}
+//                 u [9][ld], z [9][ld]   SoA, ld = nt + 1: lane t reads component c at c*ld + t -> every load/store of a
+//                 wave is one contiguous 512-B run; Binv [9][ld] likewise, but only when the tets do not share one set of rest
+//                 positions -- otherwise x0 [n_verts][3] is gathered next to x and Binv recomputed (tet_rest_binv)
+//                 sc [ld] = dt^2 w^2, mat int[nt] -> Mat table {mu, lambda, k, kappa, type, table}
+//                 corner forces: not stored per tet -- summed per vertex over the block's 256 tets in LDS, one 32-byte record per
+//                 (block, vertex) in rec [n_rec + 1][4] (host_setup.hpp: TetChunks)
 //   per-tri       idx int4[n], rest [4][ld], u/z [6][ld], cf [9][ld], sc, limits
 //   Ahat / vertex->corner incidence: SELL-64 (slice = one wavefront, see host_setup.hpp)
 // One lane owns one element (local step) or one vertex row (gather, SpMV): the SoA layout makes all
