@@ -215,6 +215,7 @@ struct admm_hip_ctx {
     static constexpr int kRcSlots = kRc + 1;
     DevBuf<double> rc_buf, rc_r0, rc_xs, rc_part, rc_coef;
     int rc_iter = 0, rc_frame = 0, rc_prev_valid = 0, NBR = 1; // pairs of the previous frame valid for s < rc_prev_valid
+    int rc_pairs = kRc; bool rc_adapt = false, rc_decided = false; long long rc_snap[2] = {0, 0};   // pairs per projection: see step_impl
     bool rc_enabled = true;
     // Slots: the pairs of the FIRST kRc solves of a frame have slots of their own (0 .. kRc - 1), later solves share a ring of
     // kRcSlots behind them.  Slot j < kRc therefore keeps "the most recent pair of solve index j" across the frame boundary: when
@@ -636,7 +637,7 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     RcBasis B{};
     // basis: the (up to) kRc most recent pairs of THIS frame.  (Adding the previous frame's pair at the same
     // index was measured: it does not help the first solves of a frame.)
-    static const int rc_pairs = [] { const char *e = getenv("ADMM_HIP_RC_PAIRS"); return e ? std::max(0, std::min(kRc, atoi(e))) : kRc; }();   // (A/B: fewer pairs)
+    const int rc_pairs = c->rc_pairs;
     for (int j = 1; j <= rc_pairs && s - j >= 0; ++j) { B.E[B.cnt] = c->rc_E(s - j); B.R[B.cnt] = c->rc_R(s - j); ++B.cnt; }
     // The first solves of a frame have few pairs of their own (the very first none: 85 of the 194 PCG iterations of a blob1m_mix
     // frame were its).  The free places of the basis go to the PREVIOUS frame's pairs of the same and the following solve indices
@@ -1445,6 +1446,12 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     if (d->linsolver != 1) {
         const char *env = getenv("ADMM_HIP_NO_RECYCLE");
         c->rc_enabled = !(env && env[0] == '1');
+        {   // pairs per projection: ADMM_HIP_RC_PAIRS=n fixes the count; otherwise four until the scene has shown how many iterations its
+            // solves need (step_impl).  ADMM_HIP_RC_ADAPT=0: always four.
+            const char *pe = getenv("ADMM_HIP_RC_PAIRS"), *ae = getenv("ADMM_HIP_RC_ADAPT");
+            c->rc_pairs = pe ? std::max(0, std::min(kRc, atoi(pe))) : kRc;
+            c->rc_adapt = !pe && !(ae && ae[0] == '0');
+        }
         c->NBR = std::max(1, std::min((nv + 255) / 256, 256));
         c->n3i = std::max(c->n3, 3 * c->oc_rows);
         if (c->rc_enabled) {
@@ -1902,6 +1909,21 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     // counters[5] (closed chunks) must stay monotone across steps: only [0..4] are reset
     c->uz_iters_step = 0; c->uz_detected = false;
     c->rc_prev_valid = c->rc_iter; c->rc_frame += 1; c->rc_iter = 0;   // this frame's pairs become "previous frame"
+    // How many pairs a projection uses is decided ONCE per context, from the scene's own behaviour: four pairs cost ~4 us per solve
+    // more than three (8.8 MB of reads, 20 block sums) and pay when solves need many iterations (Kuhn cube: 17.4 -> 13.9 per solve),
+    // not when they need few (unstructured body: 4.25 vs 4.35).  The fourth frame is measured with four pairs (two stream
+    // synchronisations in the life of a context), then the count is fixed: deterministic.  ADMM_HIP_RC_PAIRS=n fixes it from the start.
+    if (c->rc_adapt && !c->rc_decided && c->linsolver == 0 && c->oc_enabled && c->oc_plan && (c->rc_frame == 4 || c->rc_frame == 5)) {
+        int h[3] = {0, 0, 0};
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h, c->counters.p + 72, sizeof(h), hipMemcpyDeviceToHost));
+        if (c->rc_frame == 4) { c->rc_snap[0] = h[0]; c->rc_snap[1] = h[2]; }
+        else {
+            const long long solves = h[0] - c->rc_snap[0], its = h[2] - c->rc_snap[1];
+            if (solves >= 8) c->rc_pairs = (double)its <= 7.0 * (double)solves ? 3 : kRc;
+            c->rc_decided = true;
+        }
+    }
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
     if (c->wind_n > 0) {   // ExplicitForce::project of the wind, Solver.cpp:54 (before gravity and the prediction)
         hipLaunchKernelGGL(k_wind_tris, dim3(blocks_for(c->wind_n)), dim3(256), 0, st, c->wind_n, c->wind_tris.p, c->x.p, c->v.p,
