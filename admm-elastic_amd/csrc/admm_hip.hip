@@ -1911,13 +1911,13 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     c->rc_prev_valid = c->rc_iter; c->rc_frame += 1; c->rc_iter = 0;   // this frame's pairs become "previous frame"
     // How many pairs a projection uses is decided ONCE per context, from the scene's own behaviour: four pairs cost ~4 us per solve
     // more than three (8.8 MB of reads, 20 block sums) and pay when solves need many iterations (Kuhn cube: 17.4 -> 13.9 per solve),
-    // not when they need few (unstructured body: 4.25 vs 4.35).  The fourth frame is measured with four pairs (two stream
+    // not when they need few (unstructured body: 4.25 vs 4.35).  The third frame is measured with four pairs (two stream
     // synchronisations in the life of a context), then the count is fixed: deterministic.  ADMM_HIP_RC_PAIRS=n fixes it from the start.
-    if (c->rc_adapt && !c->rc_decided && c->linsolver == 0 && c->oc_enabled && c->oc_plan && (c->rc_frame == 4 || c->rc_frame == 5)) {
+    if (c->rc_adapt && !c->rc_decided && c->linsolver == 0 && c->oc_enabled && c->oc_plan && (c->rc_frame == 3 || c->rc_frame == 4)) {
         int h[3] = {0, 0, 0};
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h, c->counters.p + 72, sizeof(h), hipMemcpyDeviceToHost));
-        if (c->rc_frame == 4) { c->rc_snap[0] = h[0]; c->rc_snap[1] = h[2]; }
+        if (c->rc_frame == 3) { c->rc_snap[0] = h[0]; c->rc_snap[1] = h[2]; }
         else {
             const long long solves = h[0] - c->rc_snap[0], its = h[2] - c->rc_snap[1];
             if (solves >= 8) c->rc_pairs = (double)its <= 7.0 * (double)solves ? 3 : kRc;

@@ -241,7 +241,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=4)     # (the recycled projection settles its pair count in frames 3-4)
     ap.add_argument("--workload", default=None, choices=list(WORKLOADS),
                     help="default: blob1m_mix on one GPU, blobs_1m_per_gpu (weak scaling, one 1 M-tet body per GPU) on several")
     ap.add_argument("--n", type=int, default=0, help="override cells per edge (testing only)")
