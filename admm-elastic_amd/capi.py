@@ -98,7 +98,7 @@ SYMBOLS = [
     ("admm_host_tet_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_tet_rest_positions", C.c_int, [C.c_int32, C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_hip_tet_rest_mode", C.c_int, [C.c_void_p]),
-    ("admm_hip_uzawa_cache_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("admm_hip_uzawa_cache_stats", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 5),
     ("admm_host_tri_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     ("admm_host_greedy_coloring", C.c_int, [C.c_int32, c_int_p, c_int_p, c_int_p]),

@@ -236,7 +236,7 @@ struct admm_hip_ctx {
     DevBuf<double> uzc_G, uzc_part, uzc_gq, uz_y0; DevBuf<int> uzc_pos;   // Schur iterations on the active vertices (kernels.hpp: k_uzc_*)
     bool uzc_compact = true; int uzc_one_max = 1024, uzc_compact_max = 8192;   // (the limits are lowered by tests to reach the general paths on small scenes)
     std::vector<int> uzc_slot_h;
-    long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0;
+    long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0, uzc_evictions = 0;
     bool uz_freeze = false, uz_detected = false;   // tests (ADMM_HIP_UZ_FREEZE=1): Collider::detect only in the first ADMM iteration of a step
     // GS: the whole solve (colours x sweeps + residual tests, ~500 tiny launches) is captured once into a
     // hipGraph and replayed -- the per-colour kernels are far below the host launch rate
@@ -702,10 +702,24 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     if (n_missing <= 0) return 1;
     hipStream_t st = c->stream;
     const int nv = c->nv;
-    const size_t need = (size_t)c->uzc_n + (size_t)n_missing;
-    if (need > c->uzc_cap) return 0;
-    if (need * (size_t)nv > c->uzc_cols.n) {     // grow (doubling, at least 64 columns, never beyond the cap); the columns move once
-        const size_t have = c->uzc_cols.n / (size_t)nv, cols = std::min(c->uzc_cap, std::max<size_t>(need, std::max<size_t>(64, 2 * have)));
+    // slots for the new columns: fresh ones while the cache has room; a FULL cache gives up the columns of every vertex that is not
+    // active in this solve (contacts that moved on -- a rolling or sliding body -- must not pin the cache for good)
+    std::vector<int> slots;
+    const size_t fresh = std::min<size_t>((size_t)n_missing, c->uzc_cap - (size_t)c->uzc_n);
+    for (size_t k = 0; k < fresh; ++k) slots.push_back(c->uzc_n + (int)k);
+    std::vector<int> evicted;       // vertices whose columns are given up (committed only if the solves succeed)
+    if (slots.size() < (size_t)n_missing) {
+        std::vector<int> act(c->uzc_n_act);
+        if (c->uzc_n_act > 0 && hipMemcpy(act.data(), c->uzc_act.p, sizeof(int) * (size_t)c->uzc_n_act, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        std::vector<char> is_act(nv, 0);
+        for (int v : act) is_act[v] = 1;
+        for (int v = 0; v < nv && slots.size() < (size_t)n_missing; ++v)
+            if (c->uzc_slot_h[v] >= 0 && !is_act[v]) { slots.push_back(c->uzc_slot_h[v]); evicted.push_back(v); }
+        if (slots.size() < (size_t)n_missing) return 0;      // the active set itself does not fit: this solve uses the PCG
+    }
+    const size_t top = (size_t)*std::max_element(slots.begin(), slots.end()) + 1;
+    if (top * (size_t)nv > c->uzc_cols.n) {     // grow (doubling, at least 64 columns, never beyond the cap); the columns move once
+        const size_t have = c->uzc_cols.n / (size_t)nv, cols = std::min(c->uzc_cap, std::max<size_t>(top, std::max<size_t>(64, 2 * have)));
         DevBuf<double> nb;
         if (nb.alloc(cols * (size_t)nv) != hipSuccess) { (void)hipGetLastError(); return 0; }      // no room: this solve uses the PCG
         if (hipStreamSynchronize(st) != hipSuccess) { nb.release(); return -1; }
@@ -720,7 +734,7 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     int rc = 1;
     for (int k = 0; k < n_missing && rc == 1; k += 3) {
         int v[3], sl[3];
-        for (int j = 0; j < 3; ++j) { v[j] = k + j < n_missing ? miss[k + j] : -1; sl[j] = v[j] >= 0 ? c->uzc_n + k + j : -1; }
+        for (int j = 0; j < 3; ++j) { v[j] = k + j < n_missing ? miss[k + j] : -1; sl[j] = v[j] >= 0 ? slots[k + j] : -1; }
         if (hipMemsetAsync(c->uz_q1.p, 0, c->n3 * sizeof(double), st) != hipSuccess || hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) { rc = -1; break; }
         hipLaunchKernelGGL(k_uz_unit_rhs, dim3(1), dim3(1), 0, st, v[0], v[1], v[2], c->uz_q1.p);
         if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, std::max(c->pcg_max_iters, 2000))) { rc = -1; break; }
@@ -729,12 +743,16 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     }
     c->pcg_tol = keep_tol;
     if (rc == 1 && hipStreamSynchronize(st) != hipSuccess) rc = -1;
-    if (rc == 1 && c->h_sig && c->h_sig[2]) rc = -1;     // a grid barrier of one of the solves timed out: nothing is committed
-    if (rc != 1) return rc;
-    for (int k = 0; k < n_missing; ++k) c->uzc_slot_h[miss[k]] = c->uzc_n + k;
-    c->uzc_n += n_missing;
+    const bool aborted = c->h_sig && c->h_sig[2];     // a grid barrier of one of the solves timed out
+    // (the evicted vertices' slots may have been overwritten whatever happened: they are given up in every case)
+    for (int v : evicted) c->uzc_slot_h[v] = -1;
+    if (rc == 1 && !aborted) {
+        for (int k = 0; k < n_missing; ++k) c->uzc_slot_h[miss[k]] = slots[k];
+        c->uzc_n += (int)fresh;
+    } else rc = -1;
     if (hipMemcpy(c->uzc_slot.p, c->uzc_slot_h.data(), sizeof(int) * (size_t)nv, hipMemcpyHostToDevice) != hipSuccess) return -1;
-    return 1;
+    c->uzc_evictions += (long long)evicted.size();
+    return rc;
 }
 
 // UzawaCG::solve (src/UzawaCG.hpp:57-125).  The Schur-CG loop is enqueued in chunks, its stop decision is taken on the device; A^-1 of
@@ -2344,12 +2362,17 @@ int admm_host_tet_rest_positions(int32_t n_verts, int32_t n_tets, const int32_t 
     if (n_verts <= 0 || n_tets < 0 || !idx || !Binv || !x0_out) return -1;
     return admm_host::tet_rest_positions(n_verts, n_tets, idx, Binv, candidate, x0_out);
 }
-int admm_hip_uzawa_cache_stats(admm_hip_ctx *c, int64_t *columns, int64_t *column_solves, int64_t *schur_from_columns, int64_t *schur_by_pcg) {
+int admm_hip_uzawa_cache_stats(admm_hip_ctx *c, int64_t *columns, int64_t *column_solves, int64_t *schur_from_columns, int64_t *schur_by_pcg,
+                               int64_t *evicted) {
     if (!c) return fail(ADMM_HIP_ERR_ARG, "uzawa_cache_stats: NULL context");
-    if (columns) *columns = c->uzc_on ? c->uzc_n : -1;
+    if (columns) {
+        *columns = -1;
+        if (c->uzc_on) { int64_t n = 0; for (int s : c->uzc_slot_h) n += s >= 0 ? 1 : 0; *columns = n; }
+    }
     if (column_solves) *column_solves = c->uzc_col_solves;
     if (schur_from_columns) *schur_from_columns = c->uzc_applies;
     if (schur_by_pcg) *schur_by_pcg = c->uzc_pcg_solves;
+    if (evicted) *evicted = c->uzc_evictions;
     return ADMM_HIP_OK;
 }
 int admm_hip_tet_rest_mode(const admm_hip_ctx *c) { return c ? c->tet_rest_mode : -1; }

@@ -436,11 +436,11 @@ class Solver:
         return n.value, ms.value
 
     def uzawa_cache_stats(self):
-        """admm_hip_uzawa_cache_stats: dict(columns, column_solves, schur_from_columns, schur_by_pcg)."""
+        """admm_hip_uzawa_cache_stats: dict(columns, column_solves, schur_from_columns, schur_by_pcg, evicted)."""
         self._need_ctx()
-        a = [C.c_int64(0) for _ in range(4)]
+        a = [C.c_int64(0) for _ in range(5)]
         check(lib().admm_hip_uzawa_cache_stats(self._ctx, *[C.byref(x) for x in a]))
-        return dict(zip(("columns", "column_solves", "schur_from_columns", "schur_by_pcg"), (x.value for x in a)))
+        return dict(zip(("columns", "column_solves", "schur_from_columns", "schur_by_pcg", "evicted"), (x.value for x in a)))
 
     def tet_rest_mode(self):
         """admm_hip_tet_rest_mode: 0 = the local step streams Binv, 1 / 2 = it recomputes Binv from gathered rest positions."""

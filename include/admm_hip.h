@@ -315,9 +315,10 @@ int admm_host_tet_rest_positions(int32_t n_verts, int32_t n_tets, const int32_t 
  * (grown on demand up to ADMM_HIP_UZ_CACHE_MB, default 16384).  The Schur iterations then run on the active vertices only (the
  * active x active block of K^-1; ADMM_HIP_UZ_COMPACT=0: one pass over the full-height active columns per iteration) and x is
  * updated once from the multiplier update.  ADMM_HIP_UZ_CACHE=0: every Schur iteration is a PCG solve.  columns: cached columns (-1: cache off); column_solves: PCG
- * launches spent on columns; schur_from_columns / schur_by_pcg: Schur iterations served either way since create. */
+ * launches spent on columns; schur_from_columns / schur_by_pcg: Schur iterations served either way since create; evicted:
+ * columns given up because the cache was full (it then drops the columns of every vertex that is not active in the current solve). */
 int admm_hip_uzawa_cache_stats(admm_hip_ctx *ctx, int64_t *columns, int64_t *column_solves, int64_t *schur_from_columns,
-                               int64_t *schur_by_pcg);
+                               int64_t *schur_by_pcg, int64_t *evicted);
 /* which of the above this context's local step uses: 0 streamed Binv, 1 / 2 rest positions; -1 NULL context */
 int admm_hip_tet_rest_mode(const admm_hip_ctx *ctx);
 /* TriEnergyTerm ctor (src/TriEnergyTerm.cpp:29-52): rest [4*n], area [n]. */

@@ -585,6 +585,35 @@ def test_uzawa_cached_columns_equal_inner_solves(monkeypatch):
     assert st1["columns"] == 0 and st1["schur_from_columns"] == 0 and st1["schur_by_pcg"] >= it1 - 1 and np.abs(x1 - x0).max() < 1e-9
 
 
+def test_uzawa_column_cache_evicts_inactive_columns(monkeypatch):
+    """A full cache gives up the columns of vertices that are not active in the current solve (contacts that moved on): a second solve
+    with another set of touching vertices still runs from columns, and agrees with the inner-solve path."""
+    sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=8, linsolver=2, size=0.5)
+    sc.obstacles.append((0, [0.03, 0.0, 0.0, 0.0]))
+    o = sc.make_oracle(mode=1)
+    rng = np.random.default_rng(5)
+    low = np.nonzero(sc.x[:, 1] < 1e-9)[0]                                  # the bottom face
+    xa = sc.x.copy(); xa[low[: len(low) // 2], 1] -= 0.05; xa[:, 1] += 0.04  # its first half dips under the floor ...
+    xb = sc.x.copy(); xb[low[len(low) // 2:], 1] -= 0.05; xb[:, 1] += 0.04   # ... then its second half
+    ha, hb = o.detect_passive(xa.ravel()), o.detect_passive(xb.ravel())
+    va, vb = set(h[0] for h in ha), set(h[0] for h in hb)
+    assert len(va) > 3 and len(vb) > 3 and not (va & vb)
+    b = o.A @ (sc.x.ravel() + 0.001 * rng.standard_normal(sc.x.size))
+    monkeypatch.setenv("ADMM_HIP_UZ_CACHE_MB", "%g" % (8.0 * len(sc.x) * (max(len(va), len(vb)) + 1) / 1048576.0))
+    s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+    monkeypatch.delenv("ADMM_HIP_UZ_CACHE_MB")
+    monkeypatch.setenv("ADMM_HIP_UZ_CACHE", "0")
+    s0 = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+    monkeypatch.delenv("ADMM_HIP_UZ_CACHE")
+    for k, (x, hv) in enumerate(((xa, va), (xb, vb), (xa, va))):
+        xg, itg = s.global_solve(b, x.ravel())
+        x0, it0 = s0.global_solve(b, x.ravel())
+        st = s.uzawa_cache_stats()
+        assert st["schur_by_pcg"] == 0 and st["columns"] <= max(len(va), len(vb)) + 1, (k, st)
+        assert np.abs(xg - x0).max() < 1e-9 and abs(itg - it0) <= 2, (k, np.abs(xg - x0).max(), itg, it0)
+    assert st["evicted"] >= len(va) - 1 and st["column_solves"] > (len(va) + 2) // 3 + (len(vb) + 2) // 3, st
+
+
 def test_step_uzawa_collisions_loose():
     """Whole steps with contact.  The reference's active set is chaotic by construction: a vertex resting
     on the floor at y0 +- 1e-10 is or is not a hit in the next ADMM iteration (dx < 0, Collider.hpp:181),
