@@ -247,6 +247,7 @@ struct admm_hip_ctx {
     DevBuf<int> color_nodes;
     SellDev gs_sell; DevBuf<int> gs_slot_node; DevBuf<double> gs_diag; std::vector<int> gs_color_slice;
     DevBuf<double> gs_xb, gs_part2;   // two-colour scheme (k_gs_color2): roll-back copy, partial sums
+    DevBuf<unsigned char> gs_low; bool gs_fusedN = false;   // >= 3 colours: residual test fused into the colour kernels (k_gs_colorN)
     Obstacles obst{};
     // dynamic (self-)collision (dyn_collide.hpp): one entry per TetMeshCollision, payload arrays per vertex
     struct DynDev {
@@ -276,7 +277,7 @@ struct admm_hip_ctx {
         gs_pin_flag.release(); gs_pin_xyz.release();
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
         cg_r.release(); cg_u.release(); cg_w.release(); cg_p.release(); cg_s.release(); part.release(); part_b.release();
-        cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release();
+        cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release(); gs_low.release();
         oc_A.release(); oc_orig.release(); oc_ldsoff.release(); oc_wls.release(); oc_haloptr.release(); oc_halosrc.release(); oc_col16.release();
         oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release(); oc_cwt.release();
         bk_x.release(); bk_v.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
@@ -930,6 +931,28 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
         hipLaunchKernelGGL(k_gs_check2, dim3(1), dim3(256), 0, st, a2, (c->gs_max_iters - 1) & 1);
         return;
     }
+    if (check && c->gs_fusedN && c->gs_max_iters > 0) {
+        // three and more colours: the residual test rides on the colour kernels too (k_gs_colorN), one launch per colour and sweep
+        const int C = c->n_colors, sL = c->gs_color_slice[C - 1], nsL = c->gs_color_slice[C] - sL, nbL = (nsL + 3) / 4;
+        int nE = 0;
+        std::vector<int> off(C, 0);
+        for (int k = 0; k + 1 < C; ++k) { off[k] = nE; nE += (c->gs_color_slice[k + 1] - c->gs_color_slice[k] + 3) / 4; }
+        GsNArgs aN{a, c->gs_xb.p, c->gs_part2.p, c->gs_part2.p + 4 * (size_t)nbL, nbL, nE, c->gs_color_slice[0], sL - c->gs_color_slice[0], c->gs_low.p};
+        for (int it = 0; it < c->gs_max_iters; ++it) {
+            const int par = it & 1;
+            for (int k = 0; k + 1 < C; ++k) {
+                const int s0 = c->gs_color_slice[k], ns = c->gs_color_slice[k + 1] - s0, nb = (ns + 3) / 4;
+                if (nb == 0) continue;
+                if (it == 0) hipLaunchKernelGGL((k_gs_colorN<0, false, true>), dim3(nb), dim3(256), 0, st, aN, s0, ns, c->obst, 0, par, off[k], k);
+                else hipLaunchKernelGGL((k_gs_colorN<0, true, true>), dim3(nb), dim3(256), 0, st, aN, s0, ns, c->obst, 0, par, off[k], k);
+            }
+            hipLaunchKernelGGL((k_gs_colorN<2, false, true>), dim3(nbL), dim3(256), 0, st, aN, sL, nsL, c->obst, it > 0 ? 1 : 0, par, 0, C - 1);
+        }
+        // the last sweep: residuals of the earlier colours in one pass (nothing moves any more), then the verdict
+        hipLaunchKernelGGL((k_gs_colorN<0, true, false>), dim3(nE), dim3(256), 0, st, aN, aN.s0_early, aN.ns_early, c->obst, 0, 0, 0, 1);
+        hipLaunchKernelGGL(k_gs_checkN, dim3(1), dim3(256), 0, st, aN, (c->gs_max_iters - 1) & 1);
+        return;
+    }
     for (int it = 0; it < c->gs_max_iters; ++it) {
         bool first = true;
         for (int col = 0; col < c->n_colors; ++col) {
@@ -1521,6 +1544,33 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 const int nbB = (c->gs_color_slice[1] - c->gs_color_slice[0] + 3) / 4, nbA = (c->gs_color_slice[2] - c->gs_color_slice[1] + 3) / 4;
                 HIP_TRY(c->gs_xb.alloc(c->n3)); HIP_TRY(c->gs_xb.zero());
                 HIP_TRY(c->gs_part2.alloc(4 * (size_t)nbA + 2 * (size_t)nbB)); HIP_TRY(c->gs_part2.zero());
+            }
+            // three colours (triangulated cloth): the same, generalised (k_gs_colorN): no residual SpMV per sweep.  Every colour kernel
+            // pays ~1.3 us for its share of the residual, the SpMV launch it replaces cost 5.6 us: beyond three or four colours the plain
+            // sequence is faster (ADMM_HIP_GS_FUSED_MAX=n raises the limit: tests).
+            const char *fm = getenv("ADMM_HIP_GS_FUSED_MAX");
+            const int fused_max = fm ? atoi(fm) : 3;
+            if (c->n_colors >= 3 && c->n_colors <= fused_max && !(g3 && g3[0] == '1')) {
+                int nE = 0;
+                for (int k = 0; k + 1 < c->n_colors; ++k) nE += (c->gs_color_slice[k + 1] - c->gs_color_slice[k] + 3) / 4;
+                const int nbL = (c->gs_color_slice[c->n_colors] - c->gs_color_slice[c->n_colors - 1] + 3) / 4;
+                // per SELL entry: is the column's colour below the row's?  (padding entries: no)
+                std::vector<unsigned char> low(g.sell.idx.size(), 0);
+                for (int32_t sl = 0; sl < g.sell.n_slices; ++sl)
+                    for (int l = 0; l < 64; ++l) {
+                        const int32_t row = g.slot_node[(size_t)64 * sl + l];
+                        if (row < 0) continue;
+                        for (int32_t k = 0; k < g.sell.slice_width[sl]; ++k) {
+                            const size_t e = (size_t)g.sell.slice_ptr[sl] + 64 * (size_t)k + l;
+                            if (g.sell.val[e] != 0.0 && c->color_h[g.sell.idx[e]] < c->color_h[row]) low[e] = 1;
+                        }
+                    }
+                if (nE > 0 && nbL > 0) {
+                    HIP_TRY(c->gs_low.upload(low));
+                    HIP_TRY(c->gs_xb.alloc(c->n3)); HIP_TRY(c->gs_xb.zero());
+                    HIP_TRY(c->gs_part2.alloc(4 * (size_t)nbL + 2 * (size_t)nE)); HIP_TRY(c->gs_part2.zero());
+                    c->gs_fusedN = true;
+                }
             }
         }
     }

@@ -1316,6 +1316,180 @@ __global__ __launch_bounds__(256) void k_gs_check2(Gs2Args a2, int parity) {
     }
 }
 
+// THREE AND MORE COLOURS: the same idea as k_gs_color2 -- no residual SpMV of its own, one launch per colour and sweep.  After sweep
+// k the rows of the LAST colour see only final neighbour values: their residuals are taken right after their update (POST, as in
+// the two-colour scheme).  The rows of every EARLIER colour c are untouched until their kernel of sweep k+1, which takes their
+// sweep-k residuals before it updates them -- but by then the rows of the colours before c have already moved on to sweep k+1, so
+// every such kernel keeps the old value of its rows in `xb` before overwriting it, and colour c sums its residual rows with xb for
+// neighbours of a colour < c and x for the others (sell_row_mixed: one more pass over the row; the first colour needs none).  The test
+// of sweep k is settled by the LAST-colour kernel of sweep k+1; if the sweep had converged, the speculative updates of the earlier
+// colours are rolled back from xb and the solve stops exactly where the reference stops (NodalMultiColorGS.hpp:136-140).
+struct GsNArgs {
+    GsArgs g;
+    double *xb;                  // [3 nv] values of the rows of colours 0 .. C-2 before their update of the current sweep
+    double *partL;               // [2 (sweep parity)][2][nbL] last-colour partials (|r|^2, |b|^2)
+    double *partE;               // [2][nE] partials of the earlier colours' kernels, concatenated (block nbE_off + blockIdx.x)
+    int nbL, nE;
+    int s0_early, ns_early;      // slices of the colours 0 .. C-2 (contiguous in the colour-ordered SELL: roll-back, final pass)
+    const unsigned char *low;    // per SELL entry: the column's colour is below the row's (its value of the previous sweep is in xb)
+};
+// cur = sum_k Ahat(row,k) x_col and old = sum_k Ahat(row,k) xo_col in ONE pass: xo = xb for the columns flagged `low` (their colour is
+// below the row's: already updated in this sweep), x otherwise.  The flags stand next to the entries (same index as col / val), so
+// the second sum adds gathers, not a dependent memory stage.
+__device__ __forceinline__ void sell_row_both(const SellA &A, const unsigned char *__restrict__ low, int s, int lane, const double *__restrict__ x,
+                                              const double *__restrict__ xb, double *cur, double *old) {
+    const int w = A.w[s];
+    const int *__restrict__ cp = A.col + A.ptr[s] + lane;
+    const double *__restrict__ vp = A.val + A.ptr[s] + lane;
+    const unsigned char *__restrict__ lp = low + A.ptr[s] + lane;
+    cur[0] = cur[1] = cur[2] = 0.0; old[0] = old[1] = old[2] = 0.0;
+    for (int k = 0; k < w; k += 4) {
+        int col[4]; double a[4]; unsigned char lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { col[i] = cp[64 * (k + i)]; a[i] = vp[64 * (k + i)]; lo[i] = lp[64 * (k + i)]; }
+        double g[12], h[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double *p = x + 3 * (size_t)col[i];
+            g[3 * i] = p[0]; g[3 * i + 1] = p[1]; g[3 * i + 2] = p[2];
+            h[3 * i] = g[3 * i]; h[3 * i + 1] = g[3 * i + 1]; h[3 * i + 2] = g[3 * i + 2];
+            if (lo[i]) { const double *q = xb + 3 * (size_t)col[i]; h[3 * i] = q[0]; h[3 * i + 1] = q[1]; h[3 * i + 2] = q[2]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cur[0] = fma(a[i], g[3 * i], cur[0]); cur[1] = fma(a[i], g[3 * i + 1], cur[1]); cur[2] = fma(a[i], g[3 * i + 2], cur[2]);
+            old[0] = fma(a[i], h[3 * i], old[0]); old[1] = fma(a[i], h[3 * i + 1], old[1]); old[2] = fma(a[i], h[3 * i + 2], old[2]);
+        }
+    }
+}
+// ROLE 0: an earlier colour (my_color = 0 .. C-2), ROLE 2: the last colour.  RESID (ROLE 0): there is a previous sweep whose residual
+// this kernel contributes to.  UPDATE = false: the residual pass that settles the LAST sweep (all earlier colours in one launch).
+template <int ROLE, bool RESID, bool UPDATE>
+__global__ __launch_bounds__(256) void k_gs_colorN(GsNArgs aN, int slice0, int nslices, Obstacles ob, int decide, int parity, int part_off,
+                                                   int my_color) {
+    const GsArgs &a = aN.g;
+    __shared__ double lds[8];
+    const int done_flag = *a.done;
+    const int lane = threadIdx.x & 63;
+    if (ROLE == 2 && decide) {   // last colour of sweep k+1: was sweep k converged?
+        if (done_flag) return;
+        double q[2] = {0.0, 0.0};
+        const double *pL = aN.partL + (size_t)(parity ^ 1) * 2 * aN.nbL;
+        for (int i = threadIdx.x; i < aN.nbL; i += 256) { q[0] += pL[i]; q[1] += pL[aN.nbL + i]; }
+        for (int i = threadIdx.x; i < aN.nE; i += 256) { q[0] += aN.partE[i]; q[1] += aN.partE[aN.nE + i]; }
+        block_sum<2>(q, lds);
+        const bool conv = q[0] / q[1] < a.tol2;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (conv) *a.done = 1; else { atomicAdd(a.sweeps, 1); atomicAdd(a.total, 1); }
+        }
+        if (conv) {   // undo the speculative updates of the earlier colours of this sweep
+            for (int ws = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); ws < aN.ns_early; ws += (int)gridDim.x * 4) {
+                const int v = a.slot_node[(size_t)64 * (aN.s0_early + ws) + lane];
+                if (v >= 0) {
+#pragma unroll
+                    for (int q3 = 0; q3 < 3; ++q3) a.x[3 * (size_t)v + q3] = aN.xb[3 * (size_t)v + q3];
+                }
+            }
+            return;
+        }
+    }
+    const int ws = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    double rs[2] = {0.0, 0.0};
+    if (ws < nslices) {
+        const int s = slice0 + ws;
+        const int v = a.slot_node[(size_t)64 * s + lane];
+        double LUx[3], LUo[3];
+        if (ROLE == 0 && RESID && UPDATE && my_color > 0) sell_row_both(a.S, aN.low, s, lane, a.x, aN.xb, LUx, LUo);
+        else {
+            sell_row(a.S, s, lane, a.x, LUx);       // (first colour: nothing has moved yet in this sweep; final pass: every neighbour is final)
+            LUo[0] = LUx[0]; LUo[1] = LUx[1]; LUo[2] = LUx[2];
+        }
+        if (v >= 0) {
+            const double ad = a.diag[(size_t)64 * s + lane];
+            const bool pinned = a.pin_flag && a.pin_flag[v];
+            double aii[3], cx[3], bi[3], nx[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                aii[q] = ad + a.m[3 * (size_t)v + q];
+                cx[q] = a.x[3 * (size_t)v + q];
+                bi[q] = a.b[3 * (size_t)v + q];
+                nx[q] = cx[q];
+            }
+            if (ROLE == 0 && RESID) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double r = bi[q] - fma(aii[q], cx[q], LUo[q]);
+                    rs[0] = fma(r, r, rs[0]); rs[1] = fma(bi[q], bi[q], rs[1]);
+                }
+            }
+            if (ROLE == 0 && UPDATE && !done_flag) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) aN.xb[3 * (size_t)v + q] = cx[q];
+            }
+            if (UPDATE && !done_flag) {
+                if (pinned) { // :111-117
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
+                } else {
+                    double jac[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        jac[q] = (bi[q] - LUx[q]) / aii[q];
+                        nx[q] = (1.0 - a.omega) * cx[q] + a.omega * jac[q]; // :210
+                    }
+                    double n[3], p[3];
+                    if (ob.n > 0 && passive_hit(ob, nx, n, p)) { // constrained_segment_update :218-262
+                        double dx[3] = {jac[0] - p[0], jac[1] - p[1], jac[2] - p[2]};
+                        double nn[3] = {0.0, 0.0, 0.0}, uu[3], vv[3];
+                        if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0; // orthoG :171-177
+                        cross3(nn, n, uu);
+                        double il = 1.0 / sqrt(dot3(uu, uu));
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) uu[q] *= il;
+                        cross3(n, uu, vv);
+                        il = 1.0 / sqrt(dot3(vv, vv));
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) vv[q] *= il;
+                        const double t0 = dot3(uu, dx), t1 = dot3(vv, dx);
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) nx[q] = uu[q] * t0 + vv[q] * t1 + p[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
+            }
+            if (ROLE == 2) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double r = bi[q] - fma(aii[q], nx[q], LUx[q]);
+                    rs[0] = fma(r, r, rs[0]); rs[1] = fma(bi[q], bi[q], rs[1]);
+                }
+            }
+        }
+    }
+    if (ROLE == 2 || RESID) {
+        block_sum<2>(rs, lds);
+        if (threadIdx.x == 0 && !done_flag) {
+            if (ROLE == 2) { double *pL = aN.partL + (size_t)parity * 2 * aN.nbL; pL[blockIdx.x] = rs[0]; pL[aN.nbL + blockIdx.x] = rs[1]; }
+            else { aN.partE[part_off + blockIdx.x] = rs[0]; aN.partE[aN.nE + part_off + blockIdx.x] = rs[1]; }
+        }
+    }
+}
+// settles the LAST sweep of the scheme (the earlier colours' residuals come from one UPDATE = false pass over all of them)
+__global__ __launch_bounds__(256) void k_gs_checkN(GsNArgs aN, int parity) {
+    __shared__ double lds[8];
+    const GsArgs &a = aN.g;
+    if (*a.done) return;
+    double q[2] = {0.0, 0.0};
+    const double *pL = aN.partL + (size_t)parity * 2 * aN.nbL;
+    for (int i = threadIdx.x; i < aN.nbL; i += 256) { q[0] += pL[i]; q[1] += pL[aN.nbL + i]; }
+    for (int i = threadIdx.x; i < aN.nE; i += 256) { q[0] += aN.partE[i]; q[1] += aN.partE[aN.nE + i]; }
+    block_sum<2>(q, lds);
+    if (threadIdx.x == 0) {
+        if (q[0] / q[1] < a.tol2) *a.done = 1; else { atomicAdd(a.sweeps, 1); atomicAdd(a.total, 1); }
+    }
+}
+
 // residual test of one sweep (:136-140): partial sums of |b - A x|^2 and |b|^2
 __global__ __launch_bounds__(256) void k_gs_resid(SellA A, const double *__restrict__ m, const double *__restrict__ b,
                                                   const double *__restrict__ x, double *__restrict__ part, int NB,

@@ -1172,6 +1172,41 @@ def test_gs_two_colour_scheme_equals_three_kernel_scheme(floor):
         assert np.array_equal(x2, x3), (tol, np.abs(x2 - x3).max())
 
 
+@pytest.mark.parametrize("what", ["cloth", "cloth_floor", "blob"])
+def test_gs_fused_residual_scheme_with_more_colours_equals_plain_scheme(what):
+    """Three and more colours (triangulated cloth: 3, unstructured body: 8+): the per-sweep residual test rides on the colour kernels
+    as well (k_gs_colorN: every earlier colour keeps its rows' old values, sums its sweep-k residuals in its kernel of sweep k+1 with
+    the old values of the colours that have already moved on, and is rolled back if sweep k had converged) -- same sweep count and
+    bit-identical x as the plain colour ... colour / residual-SpMV sequence, for solves that stop early, late, and not at all."""
+    if what == "blob":
+        sc = scenes.blob_scene(14, admm_iters=4, linsolver=1)
+    else:
+        sc = scenes.cloth_scene(10, floor=0.46 if what == "cloth_floor" else None, admm_iters=4, linsolver=1)
+    o = sc.make_oracle()
+    rng = np.random.default_rng(17)
+    xt = sc.x + 0.01 * rng.standard_normal(sc.x.shape)
+    for v, p in sc.pins.items():
+        xt[v] = p
+    b = o.A @ xt.ravel()
+    for tol, mx in ((1e-2, 300), (1e-4, 600), (1e-10, 12)):
+        res = []
+        for three in ("0", "1"):
+            os.environ["ADMM_HIP_GS_THREE_KERNELS"] = three
+            os.environ["ADMM_HIP_GS_FUSED_MAX"] = "64"      # (by default only three-colour meshes use the fused scheme: it pays there)
+            try:
+                s = sc.make_solver(gs_tol=tol, gs_max_iters=mx)
+            finally:
+                os.environ.pop("ADMM_HIP_GS_THREE_KERNELS", None); os.environ.pop("ADMM_HIP_GS_FUSED_MAX", None)
+            assert s.gs_colors()[1] >= 3
+            x, it = s.global_solve(b, sc.x.ravel().copy())
+            res.append((x, it)); s.close()
+        (xf, itf), (xp, itp) = res
+        assert itf == itp, (tol, itf, itp)
+        assert np.array_equal(xf, xp), (tol, np.abs(xf - xp).max())
+        if what == "cloth":
+            assert (itf < mx) == (tol > 1e-9), (tol, itf)
+
+
 def test_wind_force_on_the_device():
     """WindForce::project (src/ExplicitForce.cpp:47-104) applied on the device at the start of a step: against the formula
     evaluated in numpy with every triangle reading the start-of-step velocities (the documented order of the device version;
