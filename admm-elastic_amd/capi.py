@@ -64,6 +64,7 @@ class Stats(C.Structure):
 
 SPLINE_TABLE_DOUBLES = 9228     # ADMM_SPLINE_TABLE_DOUBLES
 SPLINE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_double)     # admm_spline_fn
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)     # admm_allreduce_fn
 
 # every symbol include/admm_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -90,6 +91,7 @@ SYMBOLS = [
     ("admm_hip_get_colors", C.c_int, [C.c_void_p, c_int_p, c_int_p]),
     ("admm_hip_comm_unique_id", C.c_int, [C.c_char_p]),
     ("admm_hip_comm_init", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    ("admm_hip_set_rhs_allreduce", C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     ("admm_host_assemble_matrix", C.c_int, [C.POINTER(Desc), c_int_p, c_int_p, c_double_p, c_int_p]),
     ("admm_host_partition", None, [C.c_int32, C.c_int, C.c_int, c_int_p, c_int_p]),
     ("admm_host_component_partition", C.c_int32, [C.POINTER(Desc), C.c_int, c_int_p]),

@@ -19,6 +19,7 @@
 #include "host_setup.hpp"
 #include "kernels.hpp"
 #include "pcg_onchip2.hpp"
+#include "gs_persist.hpp"
 
 using namespace admm_k;
 
@@ -115,6 +116,7 @@ struct admm_hip_ctx {
     int linsolver = 0;
     double constraint_w = 1.0;
     int pcg_max_iters = 500; double pcg_tol = 1e-10;
+    double tol_last = 0.0; int tol_last_n = 0;      // experiments: see step_impl
     int gs_max_iters = 30; double gs_tol = 1e-10, gs_omega = 1.9;
     int uz_max_iters = 20; double uz_tol = 1e-10;
     bool state_set = false;
@@ -122,6 +124,7 @@ struct admm_hip_ctx {
 
     // multi-GPU (element-block partition, replicated global solve, RCCL all-reduce of the partial RHS)
     ncclComm_t comm = nullptr;
+    admm_allreduce_fn ar_fn = nullptr; void *ar_user = nullptr; double *ar_host = nullptr;   // admm_hip_set_rhs_allreduce: the caller's own transport
     int nt_total = 0, ntri_total = 0; // element counts of the whole scene (row layout of z/u)
     int tri_begin = 0;                // first triangle owned by this rank
 
@@ -248,6 +251,10 @@ struct admm_hip_ctx {
     SellDev gs_sell; DevBuf<int> gs_slot_node; DevBuf<double> gs_diag; std::vector<int> gs_color_slice;
     DevBuf<double> gs_xb, gs_part2;   // two-colour scheme (k_gs_color2): roll-back copy, partial sums
     DevBuf<unsigned char> gs_low; bool gs_fusedN = false;   // >= 3 colours: residual test fused into the colour kernels (k_gs_colorN)
+    // persistent multi-colour GS (gs_persist.hpp): one launch per solve on the plan of oc_plan.cpp: build_gs_plan
+    bool gsp_enabled = false; int gsp_G = 0, gsp_C = 0; size_t gsp_lds = 0; int64_t gsp_stat[6] = {0, 0, 0, 0, 0, 0};
+    DevBuf<int> gsp_hdr, gsp_orig, gsp_out, gsp_hbox, gsp_horig; DevBuf<double> gsp_diag, gsp_vals; DevBuf<unsigned short> gsp_cols;
+    DevBuf<uint4> gsp_box, gsp_part, gsp_meet; DevBuf<unsigned> gsp_abort;
     Obstacles obst{};
     // dynamic (self-)collision (dyn_collide.hpp): one entry per TetMeshCollision, payload arrays per vertex
     struct DynDev {
@@ -282,6 +289,8 @@ struct admm_hip_ctx {
         oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release(); oc_cwt.release();
         bk_x.release(); bk_v.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
+        gsp_hdr.release(); gsp_orig.release(); gsp_out.release(); gsp_hbox.release(); gsp_horig.release(); gsp_diag.release(); gsp_vals.release(); gsp_cols.release();
+        gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -294,6 +303,7 @@ struct admm_hip_ctx {
         for (hipEvent_t e : lt_ev) (void)hipEventDestroy(e);
         if (gs_exec) (void)hipGraphExecDestroy(gs_exec);
         if (h_sig) (void)hipHostFree(h_sig);
+        if (ar_host) (void)hipHostFree(ar_host);
         if (ev_coll0) (void)hipEventDestroy(ev_coll0);
         if (ev_coll1) (void)hipEventDestroy(ev_coll1);
         if (ev_step0) (void)hipEventDestroy(ev_step0);
@@ -376,9 +386,15 @@ void launch_gather(admm_hip_ctx *c) {
 int launch_rhs(admm_hip_ctx *c) {
     launch_gather(c);
     if (c->world > 1 || c->comm) {
-        if (!c->comm) return -2;
-        ncclResult_t r = g_rccl.AllReduce(c->b.p, c->b.p, (size_t)c->n3, ncclDouble, ncclSum, c->comm, c->stream);
-        if (r != ncclSuccess) return -3;
+        if (c->comm) {
+            ncclResult_t r = g_rccl.AllReduce(c->b.p, c->b.p, (size_t)c->n3, ncclDouble, ncclSum, c->comm, c->stream);
+            if (r != ncclSuccess) return -3;
+        } else if (c->ar_fn) {     // the caller's transport, staged through pinned host memory (two copies + a stream synchronisation per ADMM iteration)
+            if (hipMemcpyAsync(c->ar_host, c->b.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) return -3;
+            if (c->ar_fn(c->ar_user, c->ar_host, (int64_t)c->n3) != 0) return -3;
+            if (hipMemcpyAsync(c->b.p, c->ar_host, c->n3 * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return -3;
+        } else return -2;
     }
     return 0;
 }
@@ -925,7 +941,7 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
             const int par = it & 1;
             if (it == 0) hipLaunchKernelGGL((k_gs_color2<false, true, false>), dim3(nbB), dim3(256), 0, st, a2, s00, ns0, c->obst, 0, par);
             else hipLaunchKernelGGL((k_gs_color2<true, true, false>), dim3(nbB), dim3(256), 0, st, a2, s00, ns0, c->obst, 0, par);
-            hipLaunchKernelGGL((k_gs_color2<false, true, true>), dim3(nbA), dim3(256), 0, st, a2, s01, ns1, c->obst, it > 0 ? 1 : 0, par);
+            hipLaunchKernelGGL((k_gs_color2<false, true, true>), dim3(nbA), dim3(256), 0, st, a2, s01, ns1, c->obst, it /* 0: nothing to settle; else the launch's stamp */, par);
         }
         hipLaunchKernelGGL((k_gs_color2<true, false, false>), dim3(nbB), dim3(256), 0, st, a2, s00, ns0, c->obst, 0, 0);
         hipLaunchKernelGGL(k_gs_check2, dim3(1), dim3(256), 0, st, a2, (c->gs_max_iters - 1) & 1);
@@ -946,7 +962,7 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
                 if (it == 0) hipLaunchKernelGGL((k_gs_colorN<0, false, true>), dim3(nb), dim3(256), 0, st, aN, s0, ns, c->obst, 0, par, off[k], k);
                 else hipLaunchKernelGGL((k_gs_colorN<0, true, true>), dim3(nb), dim3(256), 0, st, aN, s0, ns, c->obst, 0, par, off[k], k);
             }
-            hipLaunchKernelGGL((k_gs_colorN<2, false, true>), dim3(nbL), dim3(256), 0, st, aN, sL, nsL, c->obst, it > 0 ? 1 : 0, par, 0, C - 1);
+            hipLaunchKernelGGL((k_gs_colorN<2, false, true>), dim3(nbL), dim3(256), 0, st, aN, sL, nsL, c->obst, it /* the launch's stamp */, par, 0, C - 1);
         }
         // the last sweep: residuals of the earlier colours in one pass (nothing moves any more), then the verdict
         hipLaunchKernelGGL((k_gs_colorN<0, true, false>), dim3(nE), dim3(256), 0, st, aN, aN.s0_early, aN.ns_early, c->obst, 0, 0, 0, 1);
@@ -972,7 +988,71 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
                        c->counters.p + 2, c->counters.p, check);
 }
 
+// the whole solve as ONE persistent launch (gs_persist.hpp)
+void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
+    hipStream_t st = c->stream;
+    (void)hipMemsetAsync(c->counters.p + 1, 0, 2 * sizeof(int), st);
+    GspArgs a{};
+    a.G = c->gsp_G; a.C = c->gsp_C;
+    a.hdr = c->gsp_hdr.p; a.orig = c->gsp_orig.p; a.out_idx = c->gsp_out.p; a.halo_box = c->gsp_hbox.p; a.halo_orig = c->gsp_horig.p;
+    a.diag = c->gsp_diag.p; a.vals = c->gsp_vals.p; a.cols = c->gsp_cols.p;
+    a.m = c->m.p; a.b = b; a.x = x;
+    a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p;
+    a.omega = c->gs_omega; a.tol2 = c->gs_tol * c->gs_tol; a.max_sweeps = c->gs_max_iters; a.check = c->gs_tol > 0.0 ? 1 : 0;
+    a.seq = (unsigned)++c->solve_seq;
+    a.box = (v4u *)c->gsp_box.p; a.part = (v4u *)c->gsp_part.p; a.meet = (v4u *)c->gsp_meet.p; a.abort_word = c->gsp_abort.p;
+    a.done = c->counters.p + 1; a.sweeps = c->counters.p + 2; a.total = c->counters.p; a.sig = c->d_sig;
+    hipLaunchKernelGGL(k_gs_persist, dim3(c->gsp_G), dim3(kGspT), c->gsp_lds, st, a, c->obst);
+}
+
+// Plan + buffers of the persistent GS kernel; leaves gsp_enabled = false when the scene does not fit (the colour kernels serve it).
+hipError_t plan_gs_persist(admm_hip_ctx *c) {
+    c->gsp_enabled = false;
+    const char *env = getenv("ADMM_HIP_GS_PERSIST");
+    if (env && env[0] == '0') return hipSuccess;
+    static_assert(kGspMaxCK == admm_host::kGspMaxC && kGspHdrK == admm_host::kGspHdr, "gs_persist.hpp and host_setup.hpp disagree on the plan layout");
+    if (c->n_colors < 1 || c->n_colors > kGspMaxCK || (int64_t)c->gs_max_iters * c->n_colors >= 2000) return hipSuccess;   // (stamp space of one solve)
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, c->device);
+    if (e != hipSuccess) return e;
+    const int cus = prop.multiProcessorCount;
+    const int lds_max = (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
+    const char *rt = getenv("ADMM_HIP_GS_ROWS");
+    const int rows_target = rt ? std::max(32, atoi(rt)) : 384;
+    std::vector<int32_t> col32(c->color_h.begin(), c->color_h.end());
+    admm_host::GsPlan P = admm_host::build_gs_plan(c->Ahat, c->n_colors, col32.data(), cus, rows_target, lds_max);
+    if (!P.ok) return hipSuccess;
+    if ((e = hipFuncSetAttribute((const void *)k_gs_persist, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes)) != hipSuccess) return e;
+    int per_cu = 0;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gs_persist, kGspT, P.lds_bytes)) != hipSuccess) return e;
+    if (per_cu < 1 || P.G > cus) return hipSuccess;      // every block must be resident at once
+    if ((e = c->gsp_hdr.upload(std::vector<int>(P.hdr.begin(), P.hdr.end()))) != hipSuccess) return e;
+    if ((e = c->gsp_orig.upload(std::vector<int>(P.orig.begin(), P.orig.end()))) != hipSuccess) return e;
+    if ((e = c->gsp_out.upload(std::vector<int>(P.out_idx.begin(), P.out_idx.end()))) != hipSuccess) return e;
+    if ((e = c->gsp_hbox.upload(std::vector<int>(P.halo_box.begin(), P.halo_box.end()))) != hipSuccess) return e;
+    if ((e = c->gsp_horig.upload(std::vector<int>(P.halo_orig.begin(), P.halo_orig.end()))) != hipSuccess) return e;
+    if ((e = c->gsp_diag.upload(P.diag)) != hipSuccess) return e;
+    if ((e = c->gsp_vals.upload(P.vals)) != hipSuccess) return e;
+    if ((e = c->gsp_cols.upload(P.cols)) != hipSuccess) return e;
+    if ((e = c->gsp_box.alloc((size_t)std::max(P.ob_total, 1) * 6)) != hipSuccess) return e;
+    if ((e = c->gsp_box.zero()) != hipSuccess) return e;
+    if ((e = c->gsp_part.alloc((size_t)P.G * 8)) != hipSuccess) return e;
+    if ((e = c->gsp_part.zero()) != hipSuccess) return e;
+    if ((e = c->gsp_meet.alloc((size_t)P.G)) != hipSuccess) return e;
+    if ((e = c->gsp_meet.zero()) != hipSuccess) return e;
+    if ((e = c->gsp_abort.alloc(16)) != hipSuccess) return e;
+    if ((e = c->gsp_abort.zero()) != hipSuccess) return e;
+    c->gsp_G = P.G; c->gsp_C = P.C; c->gsp_lds = (size_t)P.lds_bytes;
+    c->gsp_stat[0] = P.G; c->gsp_stat[1] = P.max_rows; c->gsp_stat[2] = P.max_halo; c->gsp_stat[3] = P.max_nbr; c->gsp_stat[4] = P.ob_total; c->gsp_stat[5] = P.lds_bytes;
+    if (getenv("ADMM_HIP_OC_DIAG"))
+        fprintf(stderr, "[gs_plan] %d blocks x %d threads, <= %d rows and %d halo entries per block, <= %d neighbour blocks, %d outbox nodes, %d bytes of LDS\n",
+                P.G, kGspT, P.max_rows, P.max_halo, P.max_nbr, P.ob_total, P.lds_bytes);
+    c->gsp_enabled = true;
+    return hipSuccess;
+}
+
 void launch_gs(admm_hip_ctx *c, const double *b, double *x) {
+    if (c->gsp_enabled) { launch_gs_persist(c, b, x); return; }
     if (c->gs_exec && (c->gs_graph_b != b || c->gs_graph_x != x)) { (void)hipGraphExecDestroy(c->gs_exec); c->gs_exec = nullptr; }
     if (!c->gs_exec) {
         hipGraph_t g = nullptr;
@@ -1267,6 +1347,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     c->linsolver = d->linsolver;
     c->pcg_max_iters = d->pcg_max_iters > 0 ? d->pcg_max_iters : 500;
     c->pcg_tol = d->pcg_tol > 0 ? d->pcg_tol : 1e-10;
+    { const char *e1 = getenv("ADMM_HIP_TOL_LAST"), *e2 = getenv("ADMM_HIP_TOL_LAST_N"); c->tol_last = e1 ? atof(e1) : 0.0; c->tol_last_n = e2 ? atoi(e2) : 0; }
     c->gs_max_iters = d->gs_max_iters > 0 ? d->gs_max_iters : 30;
     c->gs_tol = d->gs_tol >= 0 ? d->gs_tol : 1e-10;
     c->gs_omega = d->gs_omega > 0 ? d->gs_omega : 1.9;
@@ -1574,6 +1655,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
             }
         }
     }
+    if (d->linsolver == 1) HIP_TRY(plan_gs_persist(c));
     if (d->linsolver == 2) {
         { const char *fz = getenv("ADMM_HIP_UZ_FREEZE"); c->uz_freeze = fz && fz[0] == '1'; }
         c->NBU = std::max(1, std::min((nv + 255) / 256, 256));
@@ -1663,8 +1745,9 @@ static int set_state_impl(admm_hip_ctx *c, const double *x, const double *v) {
     else HIP_TRY(hipMemsetAsync(c->v.p, 0, c->n3 * sizeof(double), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->h_sig && c->h_sig[2]) {   // the steps before this call hit a barrier time-out; their result is overwritten anyway
-        c->h_sig[2] = 0; c->oc_gave_up = true; c->oc_enabled = false; c->rc_iter = 0;
+        c->h_sig[2] = 0; c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false; c->rc_iter = 0;
         if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
+        if (c->gsp_abort.p) HIP_TRY(c->gsp_abort.zero());
         HIP_TRY(hipMemcpy(c->x.p, x, c->n3 * sizeof(double), hipMemcpyHostToDevice));
         if (v) HIP_TRY(hipMemcpy(c->v.p, v, c->n3 * sizeof(double), hipMemcpyHostToDevice));
         else HIP_TRY(hipMemset(c->v.p, 0, c->n3 * sizeof(double)));
@@ -1981,7 +2064,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     // more than three (8.8 MB of reads, 20 block sums) and pay when solves need many iterations (Kuhn cube: 17.4 -> 13.9 per solve),
     // not when they need few (unstructured body: 4.25 vs 4.35).  The third frame is measured with four pairs (two stream
     // synchronisations in the life of a context), then the count is fixed: deterministic.  ADMM_HIP_RC_PAIRS=n fixes it from the start.
-    if (c->rc_adapt && !c->rc_decided && c->linsolver == 0 && c->oc_enabled && c->oc_plan && (c->rc_frame == 3 || c->rc_frame == 4)) {
+    if (c->rc_adapt && !c->rc_decided && c->linsolver != 1 && c->oc_enabled && c->oc_plan && (c->rc_frame == 3 || c->rc_frame == 4)) {
         int h[3] = {0, 0, 0};
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h, c->counters.p + 72, sizeof(h), hipMemcpyDeviceToHost));
@@ -2017,10 +2100,14 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 1], st));
         // passive collisions are resolved inside the GS sweeps (linsolver 1, Solver.cpp:76)
         if (int rr = launch_rhs(c))             // Solver.cpp:98
-            return fail(rr == -2 ? ADMM_HIP_ERR_STATE : ADMM_HIP_ERR_COMM, rr == -2 ? "step: world_size > 1 but admm_hip_comm_init was not called" : "ncclAllReduce failed");
+            return fail(rr == -2 ? ADMM_HIP_ERR_STATE : ADMM_HIP_ERR_COMM, rr == -2 ? "step: world_size > 1 but neither admm_hip_comm_init nor admm_hip_set_rhs_allreduce was called" : "all-reduce of the right-hand side failed");
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 2], st));
-        if (launch_global(c, c->b.p, c->curr.p))   // Solver.cpp:99
-            return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
+        // experiments (ADMM_HIP_TOL_LAST=tol, ADMM_HIP_TOL_LAST_N=k): the last k solves of a step at another tolerance
+        const double keep_tol = c->pcg_tol;
+        if (c->tol_last > 0.0 && s >= admm_iters - c->tol_last_n) c->pcg_tol = c->tol_last;
+        const int grc = launch_global(c, c->b.p, c->curr.p);   // Solver.cpp:99
+        c->pcg_tol = keep_tol;
+        if (grc) return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     }
     c->timing = false;
     if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * admm_iters], st));
@@ -2056,7 +2143,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         CgScal sc[2];
         HIP_TRY(hipMemcpy(sc, c->cg_scal.p, sizeof(sc), hipMemcpyDeviceToHost));
         stats->admm_iters = admm_iters;
-        if (c->linsolver == 1) { stats->inner_iters = h[0]; stats->last_solve_converged = h[1]; }
+        if (c->linsolver == 1) { stats->inner_iters = h[0]; stats->last_solve_converged = h[1] != 0; }   // (the done word carries the stamp of the launch that raised it)
         else if (c->linsolver == 2) {
             stats->inner_iters = c->uz_iters_step; // the reference counts Schur-CG iterations (UzawaCG.hpp:124)
             stats->n_constraints = c->uz_last_hits;
@@ -2083,13 +2170,14 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
 // good state and replay.  Single-GPU contexts only (a replay on one rank would issue all-reduces the others do not).
 static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
     c->h_sig[2] = 0;
-    if (c->world > 1 || c->comm)     // a replay on one rank would issue all-reduces the other ranks do not: the step is lost, cleanly
+    if (c->world > 1 || c->comm || c->ar_fn)     // a replay on one rank would issue all-reduces the other ranks do not: the step is lost, cleanly
         return fail(ADMM_HIP_ERR_COMM, "PCG: a grid barrier of the on-chip solve timed out on a rank of a multi-GPU job; the step cannot be replayed under a "
                                        "communicator -- restore the state on every rank (admm_hip_set_state) and continue");
     if (c->pending.empty() || !c->bk_x.p)
         return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)");
     if (!c->oc_gave_up) fprintf(stderr, "[admm_hip] on-chip PCG: a grid barrier timed out (blocks not co-resident?) -- falling back to the launch-per-iteration PCG and replaying %d step(s)\n", (int)c->pending.size());
-    c->oc_gave_up = true; c->oc_enabled = false;
+    c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false;
+    if (c->gsp_abort.p) HIP_TRY(c->gsp_abort.zero());
     c->rc_iter = 0;      // (the stored pairs are in the on-chip kernel's internal row order: the launch path must not project on them)
     if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
     HIP_TRY(hipMemcpyAsync(c->x.p, c->bk_x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -2115,7 +2203,7 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
     if (!c->state_set) return fail(ADMM_HIP_ERR_STATE, "step: call admm_hip_set_state first");
     if (admm_iters < 0) return fail(ADMM_HIP_ERR_ARG, "step: admm_iters < 0");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->oc_enabled && c->linsolver != 1 && c->world == 1 && !c->comm) {
+    if (((c->oc_enabled && c->linsolver != 1) || (c->gsp_enabled && c->linsolver == 1)) && c->world == 1 && !c->comm && !c->ar_fn) {
         if (c->pending.empty()) {   // the state every later replay starts from
             if (!c->bk_x.p) { HIP_TRY(c->bk_x.alloc(c->n3)); HIP_TRY(c->bk_v.alloc(c->n3)); }
             HIP_TRY(hipMemcpyAsync(c->bk_x.p, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -2175,7 +2263,7 @@ int admm_hip_local_step(admm_hip_ctx *c, const double *x, double *u_inout, doubl
     else HIP_TRY(hipMemsetAsync(c->Mxbar.p, 0, c->n3 * sizeof(double), st));
     launch_local<true>(c);
     // multi-GPU contexts without a communicator return their PARTIAL right-hand side (parity tests sum them)
-    if (c->world > 1 && !c->comm) launch_gather(c);
+    if (c->world > 1 && !c->comm && !c->ar_fn) launch_gather(c);
     else if (launch_rhs(c)) return fail(ADMM_HIP_ERR_COMM, "local_step: ncclAllReduce failed");
     HIP_TRY(hipGetLastError());
     std::vector<double> tz((size_t)9 * c->ldt), rz((size_t)6 * c->ldr), pz(3 * (size_t)c->npin_terms);
@@ -2344,6 +2432,16 @@ int admm_hip_comm_init(admm_hip_ctx *c, const char *id128, int rank, int world_s
     std::memcpy(&id, id128, sizeof(id));
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world_size, id, rank);
     if (r != ncclSuccess) return fail(ADMM_HIP_ERR_COMM, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r));
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_set_rhs_allreduce(admm_hip_ctx *c, admm_allreduce_fn fn, void *user) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "set_rhs_allreduce: NULL context");
+    if (c->cm.on) return fail(ADMM_HIP_ERR_STATE, "set_rhs_allreduce: the component partition exchanges nothing inside a step");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (fn && !c->ar_host) HIP_TRY(hipHostMalloc((void **)&c->ar_host, (size_t)c->n3 * sizeof(double), hipHostMallocDefault));
+    c->ar_fn = fn; c->ar_user = user;
     return ADMM_HIP_OK;
 }
 

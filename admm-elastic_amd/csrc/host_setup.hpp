@@ -129,6 +129,49 @@ struct OcPlan {
 // xyz (optional, [3 n]): smooth vertex coordinates for the affine coarse space
 OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_bytes, bool want_coarse, const double *xyz = nullptr);
 
+// Plan of the PERSISTENT multi-colour Gauss-Seidel kernel (oc_plan.cpp: build_gs_plan; kernels: gs_persist.hpp).  The vertices are
+// split into G compact blocks (one per CU, the recursive bisection of the on-chip PCG); a block keeps its rows' matrix entries,
+// its part of x and the values of the rows of other blocks it references (its halo) in LDS for the whole solve, and a colour phase
+// only exchanges the boundary rows of that colour with the neighbouring blocks (tagged granules in an outbox per block).
+//   own rows of a block: by colour, inside a colour boundary rows (referenced by another block) first
+//   local column index : own row -> its position, halo entry h -> n_own + h (halo entries by colour as well)
+//   matrix entries     : per (block, colour) an ELL of that colour's rows, width W = longest row, entry (k, row i) at
+//                        ent_base + eoff[c] + k * n_c + i; the entries of a row keep their CSR order (ascending original column), so
+//                        the row sums are bit-identical to the colour kernels' (padding: value 0 on the row's own index)
+constexpr int kGspMaxC = 12;       // colours a plan supports
+constexpr int kGspHdr = 64;        // ints per block header:
+//   0 n_own, 1 n_halo, 2 row_base (into orig / out_idx / diag), 3 halo_base (into halo_box / halo_orig), 4 ent_base (into vals / cols),
+//   5 ob_base (first outbox node of the block), 6 n_out, 7 ent_count, 8.. cs[C + 1] (own rows of colour c: [cs[c], cs[c + 1])),
+//   21.. hs[C + 1] (halo entries of colour c), 34.. W[C], 46.. eoff[C]
+struct GsPlan {
+    bool ok = false;
+    int G = 0, C = 0;
+    std::vector<int32_t> hdr;         // [G][kGspHdr]
+    std::vector<int32_t> orig;        // [rows]  vertex of every own row
+    std::vector<int32_t> out_idx;     // [rows]  outbox node of the row inside its block, -1 = no other block reads it
+    std::vector<double> diag;         // [rows]  Ahat(v, v)
+    std::vector<int32_t> halo_box;    // [halo]  global outbox node the entry is read from
+    std::vector<int32_t> halo_orig;   // [halo]  its vertex (initial value)
+    std::vector<double> vals; std::vector<uint16_t> cols;
+    int32_t ob_total = 0;             // outbox nodes of all blocks
+    int32_t lds_bytes = 0;            // LDS the fullest block needs
+    int32_t max_nbr = 0, max_halo = 0, max_rows = 0;
+};
+GsPlan build_gs_plan(const Csr &A, int n_colors, const int32_t *color, int max_blocks, int rows_target, int lds_limit);
+// bytes of LDS a block with these counts needs (shared with the kernel: gs_persist.hpp computes the same offsets)
+inline int32_t gsp_lds_bytes(int32_t n_own, int32_t n_halo, int32_t ent_count) {
+    const int32_t L = n_own + n_halo;
+    int32_t o = 1024;                         // scratch: reductions, control words
+    o += 24 * L;                              // x [L][3]
+    o += 48 * n_own;                          // b, a_ii [n_own][3]
+    o += 8 * ent_count;                       // values
+    o += (2 * ent_count + 7) / 8 * 8;         // 16-bit local columns
+    o += (4 * n_own + 7) / 8 * 8;             // outbox node of every own row
+    o += (4 * n_halo + 7) / 8 * 8;            // source of every halo entry
+    o += (n_own + 7) / 8 * 8;                 // pin flags
+    return o;
+}
+
 // Hierarchical block order of mesh vertices (oc_plan.cpp): compact leaves of ~leaf vertices from a recursive graph
 // bisection, leaves in recursion-tree order, breadth-first inside a leaf.  new_id[v] = position of vertex v.
 void block_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_t *idx, int32_t leaf, int32_t *new_id);

@@ -1101,6 +1101,38 @@ __device__ __forceinline__ bool passive_hit(const Obstacles &ob, const double *x
     return false;
 }
 
+// One node of one colour of a sweep: over-relaxed Jacobi value (:210), or -- when the relaxed point would be inside a passive
+// obstacle -- the constrained segment update of :218-262 (projection of the UNRELAXED value onto the tangent plane at the contact
+// point, no over-relaxation).  One definition with every product-sum written as an explicit fma, shared by all sweep kernels
+// (k_gs_color, k_gs_color2, k_gs_colorN, k_gs_persist): their results are bit-identical by construction, not by the compiler's
+// contraction choices.
+__device__ __forceinline__ void gs_relax(const Obstacles &ob, double omega, const double *bi, const double *LUx, const double *aii,
+                                         const double *cx, double *nx) {
+    double jac[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        jac[q] = (bi[q] - LUx[q]) / aii[q];
+        nx[q] = fma(omega, jac[q], (1.0 - omega) * cx[q]); // :210
+    }
+    double n[3], p[3];
+    if (ob.n > 0 && passive_hit(ob, nx, n, p)) { // constrained_segment_update :218-262
+        const double dx[3] = {jac[0] - p[0], jac[1] - p[1], jac[2] - p[2]};
+        double nn[3] = {0.0, 0.0, 0.0}, uu[3], vv[3];
+        if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0; // orthoG :171-177
+        uu[0] = fma(nn[1], n[2], -(nn[2] * n[1])); uu[1] = fma(nn[2], n[0], -(nn[0] * n[2])); uu[2] = fma(nn[0], n[1], -(nn[1] * n[0]));
+        double il = 1.0 / sqrt(fma(uu[2], uu[2], fma(uu[1], uu[1], uu[0] * uu[0])));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) uu[q] *= il;
+        vv[0] = fma(n[1], uu[2], -(n[2] * uu[1])); vv[1] = fma(n[2], uu[0], -(n[0] * uu[2])); vv[2] = fma(n[0], uu[1], -(n[1] * uu[0]));
+        il = 1.0 / sqrt(fma(vv[2], vv[2], fma(vv[1], vv[1], vv[0] * vv[0])));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) vv[q] *= il;
+        const double t0 = fma(uu[2], dx[2], fma(uu[1], dx[1], uu[0] * dx[0])), t1 = fma(vv[2], dx[2], fma(vv[1], dx[1], vv[0] * dx[0]));
+#pragma unroll
+        for (int q = 0; q < 3; ++q) nx[q] = fma(uu[q], t0, fma(vv[q], t1, p[q]));
+    }
+}
+
 struct GsArgs {
     SellA S;                    // colour-ordered SELL of the off-diagonal non-zeros (host_setup.hpp: GsSell)
     const int *slot_node;       // node of every SELL lane, -1 = padding
@@ -1149,31 +1181,10 @@ __global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nsli
         return;
     }
     const double ad = a.diag[(size_t)64 * s + lane];
-    double jac[3], nx[3];
+    double aii[3], cx[3], bi[3], nx[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const double aii = ad + a.m[3 * (size_t)v + q];
-        const double cx = a.x[3 * (size_t)v + q];
-        jac[q] = (a.b[3 * (size_t)v + q] - LUx[q]) / aii;
-        nx[q] = (1.0 - a.omega) * cx + a.omega * jac[q]; // :210
-    }
-    double n[3], p[3];
-    if (ob.n > 0 && passive_hit(ob, nx, n, p)) { // constrained_segment_update :218-262
-        double dx[3] = {jac[0] - p[0], jac[1] - p[1], jac[2] - p[2]};
-        double nn[3] = {0.0, 0.0, 0.0}, uu[3], vv[3];
-        if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0; // orthoG :171-177
-        cross3(nn, n, uu);
-        double il = 1.0 / sqrt(dot3(uu, uu));
-#pragma unroll
-        for (int q = 0; q < 3; ++q) uu[q] *= il;
-        cross3(n, uu, vv);
-        il = 1.0 / sqrt(dot3(vv, vv));
-#pragma unroll
-        for (int q = 0; q < 3; ++q) vv[q] *= il;
-        const double t0 = dot3(uu, dx), t1 = dot3(vv, dx);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) nx[q] = uu[q] * t0 + vv[q] * t1 + p[q];
-    }
+    for (int q = 0; q < 3; ++q) { aii[q] = ad + a.m[3 * (size_t)v + q]; cx[q] = a.x[3 * (size_t)v + q]; bi[q] = a.b[3 * (size_t)v + q]; }
+    gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
 #pragma unroll
     for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
 }
@@ -1203,8 +1214,11 @@ __global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int n
     // standing in front of it (these kernels are a few microseconds of pure latency)
     const int done_flag = *a.done;
     const int lane = threadIdx.x & 63;
-    if (decide) {   // last colour of sweep k+1: was sweep k converged?
-        if (done_flag) return;
+    if (decide) {   // last colour of sweep k+1 (decide = k+1, the stamp of this launch): was sweep k converged?
+        // `done` set by an EARLIER launch: nothing to do.  Block 0 of THIS launch raises it with this launch's stamp, and a block that
+        // is scheduled after that store must still do its grid-strided share of the roll-back below -- it re-derives the verdict from
+        // the partials like every other block.
+        if (done_flag && done_flag != decide) return;
         double q[2] = {0.0, 0.0};
         const double *pA = a2.partA + (size_t)(parity ^ 1) * 2 * a2.nbA;
         for (int i = threadIdx.x; i < a2.nbA; i += 256) { q[0] += pA[i]; q[1] += pA[a2.nbA + i]; }
@@ -1212,7 +1226,7 @@ __global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int n
         block_sum<2>(q, lds);
         const bool conv = q[0] / q[1] < a.tol2;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            if (conv) *a.done = 1; else { atomicAdd(a.sweeps, 1); atomicAdd(a.total, 1); }
+            if (conv) *a.done = decide; else { atomicAdd(a.sweeps, 1); atomicAdd(a.total, 1); }
         }
         if (conv) {   // undo the speculative first-colour update of this sweep
             for (int ws = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); ws < a2.ns_first; ws += (int)gridDim.x * 4) {
@@ -1255,31 +1269,7 @@ __global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int n
                 if (pinned) { // :111-117
 #pragma unroll
                     for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
-                } else {
-                    double jac[3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        jac[q] = (bi[q] - LUx[q]) / aii[q];
-                        nx[q] = (1.0 - a.omega) * cx[q] + a.omega * jac[q]; // :210
-                    }
-                    double n[3], p[3];
-                    if (ob.n > 0 && passive_hit(ob, nx, n, p)) { // constrained_segment_update :218-262
-                        double dx[3] = {jac[0] - p[0], jac[1] - p[1], jac[2] - p[2]};
-                        double nn[3] = {0.0, 0.0, 0.0}, uu[3], vv[3];
-                        if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0; // orthoG :171-177
-                        cross3(nn, n, uu);
-                        double il = 1.0 / sqrt(dot3(uu, uu));
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) uu[q] *= il;
-                        cross3(n, uu, vv);
-                        il = 1.0 / sqrt(dot3(vv, vv));
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) vv[q] *= il;
-                        const double t0 = dot3(uu, dx), t1 = dot3(vv, dx);
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) nx[q] = uu[q] * t0 + vv[q] * t1 + p[q];
-                    }
-                }
+                } else gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
             }
@@ -1371,8 +1361,8 @@ __global__ __launch_bounds__(256) void k_gs_colorN(GsNArgs aN, int slice0, int n
     __shared__ double lds[8];
     const int done_flag = *a.done;
     const int lane = threadIdx.x & 63;
-    if (ROLE == 2 && decide) {   // last colour of sweep k+1: was sweep k converged?
-        if (done_flag) return;
+    if (ROLE == 2 && decide) {   // last colour of sweep k+1 (decide = k+1, the stamp of this launch): was sweep k converged?
+        if (done_flag && done_flag != decide) return;   // raised by an earlier launch (see k_gs_color2: a block must not skip its roll-back share)
         double q[2] = {0.0, 0.0};
         const double *pL = aN.partL + (size_t)(parity ^ 1) * 2 * aN.nbL;
         for (int i = threadIdx.x; i < aN.nbL; i += 256) { q[0] += pL[i]; q[1] += pL[aN.nbL + i]; }
@@ -1380,7 +1370,7 @@ __global__ __launch_bounds__(256) void k_gs_colorN(GsNArgs aN, int slice0, int n
         block_sum<2>(q, lds);
         const bool conv = q[0] / q[1] < a.tol2;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            if (conv) *a.done = 1; else { atomicAdd(a.sweeps, 1); atomicAdd(a.total, 1); }
+            if (conv) *a.done = decide; else { atomicAdd(a.sweeps, 1); atomicAdd(a.total, 1); }
         }
         if (conv) {   // undo the speculative updates of the earlier colours of this sweep
             for (int ws = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); ws < aN.ns_early; ws += (int)gridDim.x * 4) {
@@ -1430,31 +1420,7 @@ __global__ __launch_bounds__(256) void k_gs_colorN(GsNArgs aN, int slice0, int n
                 if (pinned) { // :111-117
 #pragma unroll
                     for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
-                } else {
-                    double jac[3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        jac[q] = (bi[q] - LUx[q]) / aii[q];
-                        nx[q] = (1.0 - a.omega) * cx[q] + a.omega * jac[q]; // :210
-                    }
-                    double n[3], p[3];
-                    if (ob.n > 0 && passive_hit(ob, nx, n, p)) { // constrained_segment_update :218-262
-                        double dx[3] = {jac[0] - p[0], jac[1] - p[1], jac[2] - p[2]};
-                        double nn[3] = {0.0, 0.0, 0.0}, uu[3], vv[3];
-                        if (n[0] > 0.999) nn[2] = 1.0; else nn[0] = 1.0; // orthoG :171-177
-                        cross3(nn, n, uu);
-                        double il = 1.0 / sqrt(dot3(uu, uu));
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) uu[q] *= il;
-                        cross3(n, uu, vv);
-                        il = 1.0 / sqrt(dot3(vv, vv));
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) vv[q] *= il;
-                        const double t0 = dot3(uu, dx), t1 = dot3(vv, dx);
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) nx[q] = uu[q] * t0 + vv[q] * t1 + p[q];
-                    }
-                }
+                } else gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
             }

@@ -613,4 +613,139 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
     return P;
 }
 
+
+// ---- plan of the persistent multi-colour GS kernel (host_setup.hpp: GsPlan) -------------------------------------------------------
+GsPlan build_gs_plan(const Csr &A, int n_colors, const int32_t *color, int max_blocks, int rows_target, int lds_limit) {
+    GsPlan P;
+    const int32_t nv = A.n;
+    const int C = n_colors;
+    if (C < 1 || C > kGspMaxC || nv < 1 || max_blocks < 1) return P;
+    const int G = std::max(1, std::min(max_blocks, (nv + std::max(rows_target, 1) - 1) / std::max(rows_target, 1)));
+    P.G = G; P.C = C;
+    const Graph g = coupling_graph(A);
+    std::vector<int32_t> part_of(nv, 0), mark(nv, 0);
+    {
+        std::vector<char> seen(nv, 0);
+        std::vector<int32_t> sizes(G), members(nv);
+        for (int b = 0; b < G; ++b) sizes[b] = (int32_t)(((int64_t)nv * (b + 1)) / G - ((int64_t)nv * b) / G);
+        std::iota(members.begin(), members.end(), 0);
+        int32_t next_id = 1;
+        bisect(g, members, sizes.data(), G, 0, mark, next_id, seen, part_of);
+    }
+    // boundary rows: referenced by a row of another block
+    std::vector<char> boundary(nv, 0);
+    for (int32_t v = 0; v < nv; ++v)
+        for (int32_t k = g.ptr[v]; k < g.ptr[v + 1]; ++k)
+            if (part_of[g.adj[k]] != part_of[v]) { boundary[v] = 1; break; }
+    // own rows per block: by colour, boundary rows first, then by vertex index
+    std::vector<std::vector<int32_t> > rows(G);
+    for (int32_t v = 0; v < nv; ++v) rows[part_of[v]].push_back(v);
+    std::vector<int32_t> local(nv, -1), ob_of(nv, -1);
+    P.hdr.assign((size_t)G * kGspHdr, 0);
+    int32_t row_base = 0, ob_base = 0;
+    for (int b = 0; b < G; ++b) {
+        std::vector<int32_t> &r = rows[b];
+        std::stable_sort(r.begin(), r.end(), [&](int32_t x, int32_t y) {
+            if (color[x] != color[y]) return color[x] < color[y];
+            if (boundary[x] != boundary[y]) return boundary[x] > boundary[y];
+            return x < y;
+        });
+        int32_t *h = &P.hdr[(size_t)b * kGspHdr];
+        h[0] = (int32_t)r.size(); h[2] = row_base; h[5] = ob_base;
+        int32_t n_out = 0;
+        for (size_t i = 0; i < r.size(); ++i) {
+            local[r[i]] = (int32_t)i;
+            h[8 + color[r[i]] + 1] += 1;
+            if (boundary[r[i]]) ob_of[r[i]] = n_out++;
+        }
+        for (int c = 0; c < C; ++c) h[8 + c + 1] += h[8 + c];
+        h[6] = n_out;
+        for (int32_t v : r) { P.orig.push_back(v); P.out_idx.push_back(ob_of[v]); }
+        row_base += (int32_t)r.size(); ob_base += n_out;
+        P.max_rows = std::max(P.max_rows, (int32_t)r.size());
+    }
+    P.ob_total = ob_base;
+    P.diag.assign(P.orig.size(), 0.0);
+    // halo lists per block: by colour, then by (source block, source row)
+    int32_t halo_base = 0; int64_t ent_base = 0;
+    for (int b = 0; b < G; ++b) {
+        int32_t *h = &P.hdr[(size_t)b * kGspHdr];
+        std::vector<int32_t> halo;
+        for (int32_t v : rows[b])
+            for (int32_t k = g.ptr[v]; k < g.ptr[v + 1]; ++k)
+                if (part_of[g.adj[k]] != b) halo.push_back(g.adj[k]);
+        std::sort(halo.begin(), halo.end());
+        halo.erase(std::unique(halo.begin(), halo.end()), halo.end());
+        std::stable_sort(halo.begin(), halo.end(), [&](int32_t x, int32_t y) {
+            if (color[x] != color[y]) return color[x] < color[y];
+            if (part_of[x] != part_of[y]) return part_of[x] < part_of[y];
+            return local[x] < local[y];
+        });
+        const int32_t n_own = h[0], n_halo = (int32_t)halo.size();
+        if (n_own + n_halo > 65535) return P;
+        h[1] = n_halo; h[3] = halo_base;
+        std::vector<int32_t> hloc(n_halo);
+        {
+            std::vector<int32_t> nb;
+            for (int32_t i = 0; i < n_halo; ++i) {
+                const int32_t v = halo[i];
+                h[21 + color[v] + 1] += 1;
+                P.halo_box.push_back(P.hdr[(size_t)part_of[v] * kGspHdr + 5] + ob_of[v]);
+                P.halo_orig.push_back(v);
+                nb.push_back(part_of[v]);
+            }
+            std::sort(nb.begin(), nb.end()); nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+            P.max_nbr = std::max(P.max_nbr, (int32_t)nb.size());
+        }
+        for (int c = 0; c < C; ++c) h[21 + c + 1] += h[21 + c];
+        P.max_halo = std::max(P.max_halo, n_halo);
+        // local index of a halo vertex: binary search would need the sort key; a map through a scratch array instead
+        std::vector<std::pair<int32_t, int32_t> > hmap(n_halo);
+        for (int32_t i = 0; i < n_halo; ++i) hmap[i] = std::make_pair(halo[i], n_own + i);
+        std::sort(hmap.begin(), hmap.end());
+        auto loc_of = [&](int32_t v) -> int32_t {
+            if (part_of[v] == b) return local[v];
+            return std::lower_bound(hmap.begin(), hmap.end(), std::make_pair(v, (int32_t)-1))->second;
+        };
+        // entries: per colour an ELL of the colour's rows
+        h[4] = (int32_t)ent_base;
+        int32_t eoff = 0;
+        for (int c = 0; c < C; ++c) {
+            const int32_t r0 = h[8 + c], n_c = h[8 + c + 1] - r0;
+            int32_t W = 0;
+            for (int32_t i = 0; i < n_c; ++i) {
+                const int32_t v = rows[b][r0 + i];
+                int32_t len = 0;
+                for (int32_t q = A.rowptr[v]; q < A.rowptr[v + 1]; ++q) len += (A.col[q] != v && A.val[q] != 0.0) ? 1 : 0;
+                W = std::max(W, len);
+            }
+            h[34 + c] = W; h[46 + c] = eoff;
+            const size_t base = P.vals.size();
+            P.vals.resize(base + (size_t)W * n_c, 0.0);
+            P.cols.resize(base + (size_t)W * n_c, 0);
+            for (int32_t i = 0; i < n_c; ++i) {
+                const int32_t v = rows[b][r0 + i];
+                int32_t k = 0;
+                for (int32_t q = A.rowptr[v]; q < A.rowptr[v + 1]; ++q) {
+                    if (A.col[q] == v) { P.diag[(size_t)h[2] + r0 + i] = A.val[q]; continue; }
+                    if (A.val[q] == 0.0) continue;
+                    P.vals[base + (size_t)k * n_c + i] = A.val[q];
+                    P.cols[base + (size_t)k * n_c + i] = (uint16_t)loc_of(A.col[q]);
+                    ++k;
+                }
+                for (; k < W; ++k) P.cols[base + (size_t)k * n_c + i] = (uint16_t)(r0 + i);      // padding: 0 x own value
+            }
+            eoff += W * n_c;
+        }
+        h[7] = eoff;
+        ent_base += eoff; halo_base += n_halo;
+        if (ent_base > (int64_t)1 << 30) return P;
+        P.lds_bytes = std::max(P.lds_bytes, gsp_lds_bytes(n_own, n_halo, eoff));
+    }
+    if (P.vals.empty()) { P.vals.push_back(0.0); P.cols.push_back(0); }
+    if (P.halo_box.empty()) { P.halo_box.push_back(0); P.halo_orig.push_back(0); }
+    P.ok = P.lds_bytes <= lds_limit;
+    return P;
+}
+
 } // namespace admm_host

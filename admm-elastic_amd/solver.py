@@ -400,6 +400,24 @@ class Solver:
         dist.broadcast_object_list(obj, src=0)
         check(lib().admm_hip_comm_init(self._ctx, obj[0], s.rank, s.world_size))
 
+    def set_rhs_allreduce(self, fn):
+        """admm_hip_set_rhs_allreduce: the multi-GPU exchange over the caller's own transport instead of RCCL.  fn(buf) must sum
+        the numpy array `buf` (a view of the library's pinned host buffer, [3 n_verts]) IN PLACE over all ranks; None removes it."""
+        self._need_ctx()
+        if fn is None:
+            self._ar_cb = capi.ALLREDUCE_FN(0)
+        else:
+            def cb(user, ptr, n):
+                try:
+                    fn(np.ctypeslib.as_array(ptr, shape=(n,)))
+                    return 0
+                except Exception:        # a Python exception must not unwind through the C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._ar_cb = capi.ALLREDUCE_FN(cb)      # (kept alive as long as the context may call it)
+        check(lib().admm_hip_set_rhs_allreduce(self._ctx, self._ar_cb, None))
+
     def component_partition(self, world_size, settings=None):
         """admm_host_component_partition: (number of connected components, owning rank of every vertex) -- the multi-GPU
         partition admm_hip_create uses when the scene has at least world_size bodies."""

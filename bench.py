@@ -8,8 +8,10 @@ global solve} on a device-resident state (no host<->device traffic inside the ti
 Workloads (BASELINE.json `configs`):
   blob1m_mix   configs[2] as named ("1M-tet synthetic bunny/dragon, StVK + Neo-Hookean mix"): the DEFAULT.  Unstructured
                body (meshes.unstructured_blob, 1 012 608 tets / 183 844 verts, valences 3..26), soft rubber, feet pinned,
-               g=-9.8, dt=1/24, 20 ADMM iters/step, global solve = GPU PCG (the "UzawaCG" config has no active
-               constraints, so its solve IS the prefactored solve)
+               g=-9.8, dt=1/24, 20 ADMM iters/step, global solve = UzawaCG (linsolver 2; no obstacle in the scene, so every
+               solve is the prefactored solve of src/UzawaCG.hpp:78-81 = the recycled on-chip PCG).  With --gpus N > 1 the SAME
+               body at fixed tet count: element-block partition, one RCCL all-reduce of the right-hand side per ADMM iteration
+               (BASELINE configs[3], "scaling": "strong"); the weak series (one body per GPU) rides along as `weak_value`
   cube1m_mix   the same config on the n=55 Kuhn cube (998 250 tets; round 1's headline mesh), x=0 face pinned
   cube1m_nh    same mesh, all Neo-Hookean (the north-star's target mesh)
   cube100k_gs  configs[1]: n=26 (105 456 tets), Neo-Hookean, multi-colour GS global step
@@ -38,7 +40,10 @@ WORKLOADS = {
     # configs[2] as named ("synthetic bunny/dragon"): unstructured body (meshes.unstructured_blob: jittered lattice, random
     # pulling triangulation, carved by an implicit bunny-like surface; valences 3..26), randomly numbered like a mesh file
     # and renumbered by renumber_for_locality like the samples do; NH / StVK by slab, feet pinned
-    "blob1m_mix": dict(n=118, kinds="blob", linsolver=0, admm_iters=20),
+    # BASELINE configs[2] names "UzawaCG global step": linsolver 2.  The scene has no obstacle, so every UzawaCG::solve is the one
+    # prefactored solve of src/UzawaCG.hpp:78-81 -- on the GPU the recycled on-chip PCG (equality with linsolver 0 at full size:
+    # tests/test_gpu_parity.py::test_big_blob_onchip_pcg_residual_and_uzawa_frame)
+    "blob1m_mix": dict(n=118, kinds="blob", linsolver=2, admm_iters=20),
     # UzawaCG with ACTIVE constraints at scale (src/UzawaCG.hpp:92-120): the n=26 cube (105 456 tets, NH) dropped on a Floor,
     # no pins; every ADMM iteration detects, builds C and runs the Schur-complement CG whose every iteration is one on-chip
     # PCG solve.  Steady contact: ~700 constrained vertices.
@@ -150,6 +155,36 @@ def cpu_baseline(w, budget_s=12.0):
                        "(L-BFGS, reference stop rule) + %s; host has %d hardware threads" % (nt, shape, n_s, iters, dt, solver, cores))
 
 
+def cpu_baseline_full_size(w, threads, budget_s=8.0):
+    """The CPU leg AT THE BENCHMARKED SIZE, with the solver family that is the fair CPU baseline there (at
+    1 M tets the reference's LDLT needs a 31-minute factorisation and then 0.47 ADMM it/s, its multi-colour GS 2.0-2.4 with no
+    set-up): the oracle's OpenMP local step + 30 SOR sweeps on the full mesh, `threads` OpenMP threads, whole ADMM iterations
+    timed until the budget is spent (at least two)."""
+    import ctypes
+    from admm_elastic_amd import capi
+    wf = dict(w, linsolver=1)
+    t0 = time.perf_counter()
+    sc, nt, nv = build_scene(wf)
+    sc.settings["admm_iters"] = 1
+    s = sc.make_solver(init=False)
+    rp, ci, _ = s.host_matrix(sc.product_settings)
+    colors, nc = capi.greedy_coloring(rp, ci)
+    o = sc.make_oracle(mode=0, gs_colors=colors, big=True)
+    setup_s = time.perf_counter() - t0
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(threads)
+    except OSError:
+        pass
+    o.step()                                   # (first touch)
+    t0 = time.perf_counter(); n = 0
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 200):
+        o.step(); n += 1
+    dt = time.perf_counter() - t0
+    return dict(admm_iters_per_s=n / dt, elements=nt, colours=nc, cores=threads, admm_iterations_timed=n, seconds=dt, setup_seconds=setup_s,
+                what="oracle (port) at the benchmarked size: OpenMP local step (L-BFGS, reference stop rule) + 30 multi-colour SOR sweeps "
+                     "(src/NodalMultiColorGS.hpp; tol 1e-10 is never met, like the reference's 600 inner iterations per frame)")
+
+
 CALIBRATION_FILE = os.path.join(ROOT, "profiles", "r03_cpu_calibration.json")
 
 
@@ -243,7 +278,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=4)     # (the recycled projection settles its pair count in frames 3-4)
     ap.add_argument("--workload", default=None, choices=list(WORKLOADS),
-                    help="default: blob1m_mix on one GPU, blobs_1m_per_gpu (weak scaling, one 1 M-tet body per GPU) on several")
+                    help="default: blob1m_mix -- on several GPUs the same body at fixed tet count (strong scaling, BASELINE configs[3]); "
+                         "blobs_1m_per_gpu = one 1 M-tet body per GPU (weak scaling) as the whole line")
     ap.add_argument("--n", type=int, default=0, help="override cells per edge (testing only)")
     ap.add_argument("--pcg-tol", type=float, default=1e-8)
     ap.add_argument("--pcg-max-iters", type=int, default=600)
@@ -255,7 +291,7 @@ def main():
         args.n = int(os.environ["ADMM_BENCH_N"])
     default_workload = args.workload is None
     if args.workload is None:
-        args.workload = "blob1m_mix" if args.gpus <= 1 else "blobs_1m_per_gpu"
+        args.workload = "blob1m_mix"
     if args.calibrate_cpu_baseline:
         cpu_calibration()
         return
@@ -301,6 +337,10 @@ def main():
     s = sc.make_solver(device=local_rank, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters, rank=rank, world_size=world)
     if world > 1 and not share:
         s.comm_init(dist)
+    elif world > 1 and not weak:
+        # one-GPU functional check of the element partition: RCCL cannot put two ranks on one device, so the partial right-hand
+        # sides are summed by the caller's own transport (admm_hip_set_rhs_allreduce: here gloo on a host buffer)
+        s.set_rhs_allreduce(lambda buf: dist.all_reduce(torch.from_numpy(buf)))
     s.upload()
 
     def sync():
@@ -319,7 +359,9 @@ def main():
     # statistics frames are the timed ones, as in round 1.
     local_ms = rhs_ms = global_ms = lk_ms = 0.0
     inner = unconv = 0
-    tot0 = s.solve_totals() if w["linsolver"] == 0 else (-1, -1, -1)
+    # contact-free scenes on the on-chip PCG (linsolver 0, or UzawaCG without obstacles: one prefactored solve per ADMM iteration)
+    contact_free = w["linsolver"] == 0 or (w["linsolver"] == 2 and not sc.obstacles and not sc.dynamic)
+    tot0 = s.solve_totals() if contact_free else (-1, -1, -1)
     lean = tot0[0] >= 0
     lt_pairs, lt_ms = 0, 0.0       # the local-step launches of the TIMED region: event pairs, read after it
     if lean:
@@ -348,10 +390,13 @@ def main():
         for _ in range(args.steps):
             s.step_device(stats=True)
             rd = s.runtime_data()
-            local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms; inner += rd.inner_iters
+            local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms
             lk_ms += rd.local_kernel_ms
         sync()
         stats_elapsed = time.perf_counter() - t1s
+        tot2 = s.solve_totals()
+        inner = tot2[2] - tot1[2]            # PCG iterations of the statistics frames (UzawaCG's own count is 1 per contact-free solve)
+        unconv += (tot2[0] - tot1[0]) - (tot2[1] - tot1[1])
     else:
         lt_pairs, lt_ms = iters * args.steps, local_ms
     if dist is not None:
@@ -361,6 +406,31 @@ def main():
     ms_per_step = 1e3 * elapsed / max(args.steps, 1)
     # weak scaling: every rank steps its own body, the job's rate is the bodies' ADMM iterations per second, summed
     value = (world if weak else 1) * iters * args.steps / elapsed
+    # The WEAK series rides along on the strong default line (`weak_value`): every rank steps ONE whole body of its own (a
+    # single-GPU context of the same scene -- what blobs_1m_per_gpu gives each rank), same warm-up, same K frames, barriers,
+    # max over ranks; N bodies' ADMM iterations per second, summed.
+    weak_value = weak_ms = one = None
+    if world > 1 and not weak and default_workload:
+        sw = sc.make_solver(device=local_rank, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters)
+        sw.upload()
+        for _ in range(args.warmup):
+            sw.step_device(stats=True)
+        sync()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            sw.step_device(stats=False)
+        sync()
+        tw = time.perf_counter() - tw
+        t = torch.tensor([tw], dtype=torch.float64, device="cpu" if share else "cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        weak_ms = 1e3 * float(t.item()) / max(args.steps, 1)
+        weak_value = world * iters * args.steps / float(t.item())
+        one = [0.0, 0.0, 0.0]                # split of the single-GPU context (three statistics frames): the inputs of `expected_speedup`
+        for _ in range(3):
+            sw.step_device(stats=True)
+            r1 = sw.runtime_data()
+            one[0] += r1.local_ms / (3 * iters); one[1] += r1.rhs_ms / (3 * iters); one[2] += r1.global_ms / (3 * iters)
+        sw.close()
 
     rd = s.runtime_data()
     s.download()
@@ -377,11 +447,13 @@ def main():
     out = {
         "metric": "ADMM iterations/sec", "value": value, "unit": "ADMM it/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        # the DEFAULT lines of --gpus 1, 2, 4, 8 form one weak-scaling series: one 1 M-tet body per GPU (blob1m_mix IS that body)
-        "scaling": "weak" if (weak or (default_workload and world == 1)) else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        # the DEFAULT lines of --gpus 1, 2, 4, 8 are BASELINE's series: ONE 1 M-tet body at fixed tet count (configs[3]); the weak
+        # series (one such body per GPU) is `weak_value` of the same lines
+        "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload + (" (n=%d override)" % args.n if args.n else ""), "elements": nt, "verts": nv,
                    "admm_iters_per_step": iters, "global_solver": "multicolor-GS(30 sweeps)" if w["linsolver"] == 1 else
-                   "UzawaCG (Schur-complement CG, <= 20 iterations, stop decided on the device) over the on-chip PCG tol=%g" % args.pcg_tol if w["linsolver"] == 2 else
+                   ("UzawaCG, no active constraints: every solve is the prefactored solve (src/UzawaCG.hpp:78-81) = one persistent on-chip two-level pipelined PCG launch, tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters)
+                    if contact_free else "UzawaCG (Schur-complement CG, <= 20 iterations, stop decided on the device) over the on-chip PCG tol=%g" % args.pcg_tol) if w["linsolver"] == 2 else
                    "PCG (one persistent on-chip launch per solve: two-level preconditioned pipelined CG, matrix and vectors in LDS) tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters),
                    "parallelism": ("whole bodies per rank x%d (component-aware partition, no exchange inside a step)" % world if weak else
                                    "element-block x%d (RCCL all-reduce of the right-hand side, replicated solve)" % world) if world > 1 else "single-gpu"},
@@ -404,12 +476,22 @@ def main():
         "us_per_inner_iter": 1e3 * (global_ms - rhs_ms) / max(inner, 1),
         "finite": finite, "pcie_inclusive_admm_it_per_s": pcie_value,
     }
+    if weak_value is not None:
+        out["weak_value"] = weak_value
+        out["weak"] = {"workload": "one blob1m_mix body per GPU (what --workload blobs_1m_per_gpu runs as its whole line)", "ms_per_step": weak_ms,
+                       "unit": "ADMM it/s summed over the %d bodies" % world, "expected_vs_one_gpu": float(world)}
+    elif world == 1 and default_workload:
+        out["weak_value"] = value            # N = 1: the same body, the same number
     if share:
         out["shared_gpu_functional_test"] = "ADMM_BENCH_SHARE_GPU=1: %d ranks time-share ONE device -- a check that the N-rank path runs, not a measurement" % world
     if world > 1 and not weak:
         # stated BEFORE any curve is measured: only local step + RHS shard, the solve is replicated, the all-reduce adds ~0.04 ms
-        loc, rhs, glo = out["split_ms_per_admm_iter"]["local"] * world, out["split_ms_per_admm_iter"]["rhs"] * world, out["split_ms_per_admm_iter"]["global"]
-        out["expected_speedup"] = {"model": "t_N = (local + rhs) / N + solve + 0.04 ms all-reduce; solve replicated", "vs_one_gpu": (loc + glo) / ((loc + rhs) / world + (glo - rhs / world) + 0.04)}
+        # inputs: this rank's SINGLE-GPU context of the same body when the weak leg ran (`one`), else the N-rank split scaled back
+        loc, rhs, glo = one if one is not None else (out["split_ms_per_admm_iter"]["local"] * world, out["split_ms_per_admm_iter"]["rhs"] * world,
+                                                     out["split_ms_per_admm_iter"]["global"] + out["split_ms_per_admm_iter"]["rhs"] * (world - 1))
+        out["expected_speedup"] = {"model": "t_N = (local + rhs) / N + solve + 0.04 ms all-reduce (4.4 MB over xGMI); the solve (one persistent on-chip launch, latency-bound) is replicated",
+                                   "single_gpu_ms_per_admm_iter": {"local": loc, "rhs": rhs, "solve": glo - rhs},
+                                   "vs_one_gpu": (loc + glo) / ((loc + rhs) / world + (glo - rhs) + 0.04)}
     if weak and world > 1:
         out["expected_speedup"] = {"model": "N independent bodies, no exchange inside a step: N x the single-GPU rate of one body", "vs_one_gpu": float(world)}
     if rank == 0:
@@ -417,7 +499,7 @@ def main():
             from admm_elastic_amd import meshes as _m
             tets_all = np.concatenate([t[1] + t[4] for t in sc.tets])
             out["config"]["vertex_valence"] = _m.valence_stats(nv, tets_all)   # edges per vertex (row of Ahat = valence + 1)
-        if not args.no_roofline and w["linsolver"] == 0 and world == 1:
+        if not args.no_roofline and contact_free and lean and world == 1:
             # The time-dominant kernel: the whole PCG solve is ONE persistent launch whose matrix and vectors stay in LDS /
             # registers, so it has no HBM roofline; an iteration is two dependent synchronisations -- the vector exchange
             # between neighbour blocks and the all-to-all of the block records behind one grid barrier.  Their latency floor
@@ -471,6 +553,11 @@ def main():
                                "algorithmic_bytes_per_launch": bytes_per_launch}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(w)
+            if nt >= 500000 and w["kinds"] != "cloth" and not args.n:
+                # the extrapolation-free figure: the same CPU code on the SAME mesh, GS as the global step (the fair 1 M baseline)
+                full = cpu_baseline_full_size(w, out["cpu_baseline"]["cores"])
+                out["cpu_baseline"]["full_size"] = full
+                out["cpu_baseline"]["gpu_over_cpu_at_full_size"] = value / full["admm_iters_per_s"]
             try:    # the port against the real reference pieces, measured in the build container (bench.py --calibrate-cpu-baseline)
                 cal = json.load(open(CALIBRATION_FILE))
                 out["cpu_baseline"]["calibration"] = dict(cal["summary"], file=os.path.relpath(CALIBRATION_FILE, ROOT), host=cal.get("host"),

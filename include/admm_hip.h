@@ -270,6 +270,13 @@ int admm_hip_get_colors(const admm_hip_ctx *ctx, int32_t *color, int32_t *n_colo
  * sum all-reduce of the [3*n_verts] partial right-hand side per ADMM iteration. */
 int admm_hip_comm_unique_id(char *id128);                                   /* ncclGetUniqueId */
 int admm_hip_comm_init(admm_hip_ctx *ctx, const char *id128, int rank, int world_size);
+/* The same exchange over the CALLER's transport instead of RCCL (MPI, gloo, a test harness that puts several ranks on one device
+ * -- which RCCL refuses): once per ADMM iteration the library copies the partial right-hand side to pinned host memory, calls
+ * fn(user, host_buf, 3 * n_verts) -- which must sum host_buf in place over all ranks and return 0 -- and copies the result back.
+ * Two PCIe copies and one stream synchronisation per ADMM iteration: a functional path, not the fast one.  A context with a
+ * communicator (admm_hip_comm_init) ignores it.  fn = NULL removes it. */
+typedef int (*admm_allreduce_fn)(void *user, double *host_buf, int64_t n);
+int admm_hip_set_rhs_allreduce(admm_hip_ctx *ctx, admm_allreduce_fn fn, void *user);
 void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end);
 
 /* A user-defined xu::Spline on the device (src/XuSpline.hpp:34-46 is an interface of six virtual functions; the reference calls them

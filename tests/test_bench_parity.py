@@ -1,0 +1,130 @@
+"""Parity at the BENCHMARKED settings and sizes (round-3 review, item 1): every workload bench.py quotes a number on has a twin
+here that runs it under a checker at the size, solver settings and frame count the driver times.
+
+  blob1m_mix            configs[2]  1 012 608 tets, pcg_tol 1e-8, recycled warm start, unverified short passes:
+                                    25 frames (the driver's timed region is frames 5-14, its statistics frames 15-24) against the
+                                    same path at 1e-12 + verification, rel_err < 1e-5 at EVERY frame; the 52 k-tet twin against the
+                                    oracle's exact (SuperLU) solves for 25 frames
+  cube100k_gs           configs[1]  105 456 tets, 30-sweep multi-colour GS: whole frames against the oracle, shared colouring
+  cloth200k_gs_floor    configs[4]  199 712 triangles, limits, pins, floor inside the sweeps: whole frames against the oracle until
+                                    the cloth lies on the floor
+  cube100k_uzawa_floor              105 456 tets on a floor, UzawaCG with 729 active rows, active set frozen per step on both sides
+
+Reference: src/Solver.cpp:80-101 (the ADMM loop), src/NodalMultiColorGS.hpp:60-146, src/UzawaCG.hpp:57-125.
+Tolerance: 1e-5 of the bounding-box diagonal per vertex (BASELINE.json north_star); tighter where the test says so."""
+import os
+
+import numpy as np
+import pytest
+
+import admm_elastic_amd as pkg
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench_scene(name, n=None):
+    import bench
+    return bench.build_scene(bench.WORKLOADS[name], n)
+
+
+def test_blob1m_drift_25_frames_bench_tolerance_vs_tight_solve():
+    """The driver's workload with the driver's settings against the same path converged to 1e-12 with every pass verified, frame by
+    frame through the driver's whole run (warm-up 4 + timed 10 + statistics 10 frames, one more for good measure)."""
+    n = int(os.environ.get("ADMM_TEST_BIG_BLOB_N", "118"))
+    sc, nt, nv = _bench_scene("blob1m_mix", n)
+    frames = int(os.environ.get("ADMM_TEST_DRIFT_FRAMES", "25"))
+    os.environ["ADMM_HIP_OC_VERIFY"] = "1"
+    try:
+        tight = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=1500)
+    finally:
+        os.environ.pop("ADMM_HIP_OC_VERIFY", None)
+    loose = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=600)        # bench.py's defaults
+    errs = []
+    for f in range(frames):
+        tight.step(); loose.step()
+        assert tight.runtime_data().unconverged_solves == 0 and loose.runtime_data().unconverged_solves == 0, f
+        errs.append(scenes.rel_err(loose.m_x, tight.m_x))
+    print("blob drift rel_err per frame:", " ".join("%.2e" % e for e in errs))
+    assert max(errs) < 1e-5, errs
+    assert np.abs(tight.m_x - sc.x.ravel()).max() > 1e-2      # the body actually moves
+    tight.close(); loose.close()
+
+
+def test_blob52k_drift_25_frames_bench_settings_vs_oracle():
+    """The same body at 52 464 tets, bench settings, against the ORACLE (exact minimiser + SuperLU direct solves) for 25 frames."""
+    sc, nt, nv = _bench_scene("blob1m_mix", 44)
+    assert nt == 52464
+    s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=600)
+    o = sc.make_oracle(mode=1, big=True)
+    errs = []
+    for f in range(25):
+        s.step(); o.step()
+        assert s.runtime_data().unconverged_solves == 0
+        errs.append(scenes.rel_err(s.m_x, o.x))
+    print("blob52k vs oracle rel_err per frame:", " ".join("%.2e" % e for e in errs))
+    assert max(errs) < 1e-5, errs
+    s.close()
+
+
+def test_cube100k_gs_full_size_vs_oracle():
+    """configs[1] at its benchmarked size: 105 456 NH tets, 20 ADMM iterations x 30 sweeps, multi-block colour kernels + hipGraph
+    replay + fused residual test, against the oracle's sweep-for-sweep GS on the shared colouring."""
+    sc, nt, nv = _bench_scene("cube100k_gs")
+    assert nt == 105456
+    s = sc.make_solver()
+    colors, nc = s.gs_colors()
+    o = sc.make_oracle(mode=1, gs_colors=colors, big=True)
+    for f in range(3):
+        s.step(); o.step()
+        err = scenes.rel_err(s.m_x, o.x)
+        assert err < 1e-6, (f, err)
+        assert s.runtime_data().inner_iters == o.inner_iters == 20 * 30
+    assert np.abs(s.m_x - sc.x.ravel()).max() > 1e-3
+    s.close()
+
+
+def test_cloth200k_gs_floor_full_size_vs_oracle():
+    """configs[4] at its benchmarked size: 199 712 strain-limited triangles, two pins, Floor handled inside the GS sweeps (three
+    colours: k_gs_colorN on a multi-block grid), until the cloth has come to lie on the floor."""
+    sc, nt, nv = _bench_scene("cloth200k_gs_floor")
+    assert nt == 199712
+    s = sc.make_solver()
+    colors, nc = s.gs_colors()
+    o = sc.make_oracle(mode=1, gs_colors=colors, big=True)
+    worst = 0.0
+    for f in range(8):
+        s.step(); o.step()
+        err = scenes.rel_err(s.m_x, o.x)
+        worst = max(worst, err)
+        assert err < 1e-6, (f, err)
+        assert s.runtime_data().inner_iters == o.inner_iters
+    y = s.m_x.reshape(-1, 3)[:, 1]
+    free = np.ones(len(y), bool); free[list(sc.pins)] = False
+    assert abs(y[free].min() - 0.3) < 1e-12        # rests exactly on the floor (plane projection inside the sweeps)
+    assert (y[free] < 0.3 + 1e-9).sum() > 1000     # and a good part of it does
+    print("cloth200k worst rel_err %.2e" % worst)
+    s.close()
+
+
+def test_cube100k_uzawa_floor_full_size_frozen_active_set(monkeypatch):
+    """The bench's contact workload at its size (105 456 NH tets dropped on a Floor, 729 active rows) with the chaos of the
+    free-running active set taken out as in test_step_uzawa_frozen_active_set_is_tight: Collider::detect in the first ADMM
+    iteration of a step on both sides.  Cached K^-1 columns, compact Schur iterations, bench tolerance."""
+    sc, nt, nv = _bench_scene("cube100k_uzawa_floor")
+    monkeypatch.setenv("ADMM_HIP_UZ_FREEZE", "1")
+    s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=600)
+    monkeypatch.delenv("ADMM_HIP_UZ_FREEZE")
+    o = sc.make_oracle(mode=1, big=True)
+    o.freeze_active = True
+    rows = 0
+    for f in range(3):
+        s.step(); o.step()
+        rows = max(rows, len(o._hits))
+        err = scenes.rel_err(s.m_x, o.x)
+        assert err < 1e-6, (f, err)
+    assert rows == 729, rows
+    st = s.uzawa_cache_stats()
+    assert st["schur_from_columns"] > 0 and st["schur_by_pcg"] == 0
+    assert s.m_x.reshape(-1, 3)[:, 1].min() > -0.02 - 1e-6
+    s.close()

@@ -1158,10 +1158,11 @@ def test_gs_two_colour_scheme_equals_three_kernel_scheme(floor):
         res = []
         for three in ("0", "1"):
             os.environ["ADMM_HIP_GS_THREE_KERNELS"] = three
+            os.environ["ADMM_HIP_GS_PERSIST"] = "0"         # (the launch-per-colour schemes: fall-back of gs_persist.hpp and the path of dynamic hits)
             try:
                 s = sc.make_solver(gs_tol=tol, gs_max_iters=mx)
             finally:
-                os.environ.pop("ADMM_HIP_GS_THREE_KERNELS", None)
+                os.environ.pop("ADMM_HIP_GS_THREE_KERNELS", None); os.environ.pop("ADMM_HIP_GS_PERSIST", None)
             assert s.gs_colors()[1] == 2
             x, it = s.global_solve(b, sc.x.ravel().copy())
             res.append((x, it)); s.close()
@@ -1193,10 +1194,11 @@ def test_gs_fused_residual_scheme_with_more_colours_equals_plain_scheme(what):
         for three in ("0", "1"):
             os.environ["ADMM_HIP_GS_THREE_KERNELS"] = three
             os.environ["ADMM_HIP_GS_FUSED_MAX"] = "64"      # (by default only three-colour meshes use the fused scheme: it pays there)
+            os.environ["ADMM_HIP_GS_PERSIST"] = "0"
             try:
                 s = sc.make_solver(gs_tol=tol, gs_max_iters=mx)
             finally:
-                os.environ.pop("ADMM_HIP_GS_THREE_KERNELS", None); os.environ.pop("ADMM_HIP_GS_FUSED_MAX", None)
+                os.environ.pop("ADMM_HIP_GS_THREE_KERNELS", None); os.environ.pop("ADMM_HIP_GS_FUSED_MAX", None); os.environ.pop("ADMM_HIP_GS_PERSIST", None)
             assert s.gs_colors()[1] >= 3
             x, it = s.global_solve(b, sc.x.ravel().copy())
             res.append((x, it)); s.close()

@@ -1,0 +1,83 @@
+"""The persistent multi-colour GS kernel (csrc/gs_persist.hpp: one launch per solve, neighbour hand-off by tagged granules) against
+the launch-per-colour kernels it replaces (k_gs_color*, ADMM_HIP_GS_PERSIST=0): the same sweeps, so bit-identical x and the same
+sweep counts -- for solves that run out of sweeps, that stop early (the replay path), with pins, with a floor inside the sweeps,
+on 2 / 3 / 9 colours, on one block and on many (ADMM_HIP_GS_ROWS makes small scenes span many blocks).
+Reference semantics: src/NodalMultiColorGS.hpp:60-146, 180-262."""
+import os
+
+import numpy as np
+import pytest
+
+import admm_elastic_amd as pkg
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(sc, persist, rows=None, **kw):
+    os.environ["ADMM_HIP_GS_PERSIST"] = "1" if persist else "0"
+    if rows:
+        os.environ["ADMM_HIP_GS_ROWS"] = str(rows)
+    try:
+        return sc.make_solver(**kw)
+    finally:
+        os.environ.pop("ADMM_HIP_GS_PERSIST", None); os.environ.pop("ADMM_HIP_GS_ROWS", None)
+
+
+def _scene(what):
+    if what == "cube":
+        return scenes.cube_scene(12, pkg.TET_NEOHOOKEAN, admm_iters=4, linsolver=1, size=0.5)
+    if what == "cube_floor":
+        sc = scenes.cube_scene(8, pkg.TET_NEOHOOKEAN, admm_iters=4, linsolver=1, size=0.5)
+        sc.obstacles.append((0, [0.02, 0.0, 0.0, 0.0]))
+        return sc
+    if what == "cloth_floor":
+        return scenes.cloth_scene(40, floor=0.46, admm_iters=4, linsolver=1)
+    if what == "blob":
+        return scenes.blob_scene(14, admm_iters=4, linsolver=1)
+    raise ValueError(what)
+
+
+@pytest.mark.parametrize("what", ["cube", "cube_floor", "cloth_floor", "blob"])
+@pytest.mark.parametrize("rows", [64, 4096])
+def test_persistent_gs_solve_equals_colour_kernels(what, rows):
+    sc = _scene(what)
+    o = sc.make_oracle()
+    rng = np.random.default_rng(23)
+    xt = sc.x + 0.01 * rng.standard_normal(sc.x.shape)
+    for v, p in sc.pins.items():
+        xt[v] = p
+    b = o.A @ xt.ravel()
+    for tol, mx in ((1e-2, 120), (1e-4, 150), (1e-10, 12), (0.0, 7)):
+        res = []
+        for persist in (True, False):
+            s = _solver(sc, persist, rows, gs_tol=tol, gs_max_iters=mx)
+            x, it = s.global_solve(b, sc.x.ravel().copy())
+            res.append((x, it, s.gs_colors()[1])); s.close()
+        (xp, itp, ncol), (xk, itk, _) = res
+        assert itp == itk, (what, rows, tol, itp, itk)
+        assert np.array_equal(xp, xk), (what, rows, tol, np.abs(xp - xk).max())
+        if tol == 0.0:
+            assert itp == mx
+    if what == "cube":
+        assert ncol == 2
+    if what == "cloth_floor":
+        assert ncol == 3
+
+
+@pytest.mark.parametrize("what", ["cube", "cloth_floor"])
+def test_persistent_gs_whole_steps_equal_colour_kernels(what):
+    """Whole frames (local step + RHS + GS) with the persistent kernel and with the colour kernels: bit-identical trajectories, same
+    inner iteration counts; moving pins in between (the pin data is read at every launch)."""
+    sc = _scene(what)
+    a = _solver(sc, True, 100)
+    bsol = _solver(sc, False)
+    keys = list(sc.pins.keys())
+    for f in range(4):
+        pts = [sc.pins[k] + np.array([0.0, 0.004 * (f + 1), 0.0]) for k in keys]
+        a.set_pins(keys, pts); bsol.set_pins(keys, pts)
+        a.step(); bsol.step()
+        assert a.runtime_data().inner_iters == bsol.runtime_data().inner_iters
+        assert np.array_equal(a.m_x, bsol.m_x), (f, np.abs(a.m_x - bsol.m_x).max())
+    assert np.abs(a.m_x - sc.x.ravel()).max() > 1e-3
+    a.close(); bsol.close()
