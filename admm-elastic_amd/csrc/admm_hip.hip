@@ -254,7 +254,7 @@ struct admm_hip_ctx {
     // persistent multi-colour GS (gs_persist.hpp): one launch per solve on the plan of oc_plan.cpp: build_gs_plan
     bool gsp_enabled = false; int gsp_G = 0, gsp_C = 0; size_t gsp_lds = 0; int64_t gsp_stat[6] = {0, 0, 0, 0, 0, 0};
     DevBuf<int> gsp_hdr, gsp_orig, gsp_out, gsp_hbox, gsp_horig; DevBuf<double> gsp_diag, gsp_vals; DevBuf<unsigned short> gsp_cols;
-    DevBuf<uint4> gsp_box, gsp_part, gsp_meet; DevBuf<unsigned> gsp_abort;
+    DevBuf<uint4> gsp_box, gsp_part, gsp_meet; DevBuf<unsigned> gsp_abort; DevBuf<unsigned long long> gsp_prof; int gsp_prof_block = 0;
     Obstacles obst{};
     // dynamic (self-)collision (dyn_collide.hpp): one entry per TetMeshCollision, payload arrays per vertex
     struct DynDev {
@@ -290,7 +290,7 @@ struct admm_hip_ctx {
         bk_x.release(); bk_v.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         gsp_hdr.release(); gsp_orig.release(); gsp_out.release(); gsp_hbox.release(); gsp_horig.release(); gsp_diag.release(); gsp_vals.release(); gsp_cols.release();
-        gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release();
+        gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release(); gsp_prof.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -1002,7 +1002,18 @@ void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
     a.seq = (unsigned)++c->solve_seq;
     a.box = (v4u *)c->gsp_box.p; a.part = (v4u *)c->gsp_part.p; a.meet = (v4u *)c->gsp_meet.p; a.abort_word = c->gsp_abort.p;
     a.done = c->counters.p + 1; a.sweeps = c->counters.p + 2; a.total = c->counters.p; a.sig = c->d_sig;
+    a.prof = c->gsp_prof.p; a.prof_block = c->gsp_prof_block;
     hipLaunchKernelGGL(k_gs_persist, dim3(c->gsp_G), dim3(kGspT), c->gsp_lds, st, a, c->obst);
+    if (c->gsp_prof.p && (c->solve_seq % 200) == 0) {     // diagnosis: one block's wall-clock split of the phases since the last print
+        unsigned long long h[8];
+        if (hipMemcpyAsync(h, c->gsp_prof.p, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && h[4]) {
+            const double k = 0.01 / (double)h[4];      // 100 MHz ticks -> us per phase
+            fprintf(stderr, "[gsp_prof] block %d, %llu phases: halo poll %.2f  block barrier %.2f  rows + publish %.2f  verdict etc. %.2f us per phase\n",
+                    c->gsp_prof_block, h[4], k * h[0], k * h[1], k * h[2], k * h[3]);
+            fprintf(stderr, "[gsp_prof]   of rows + publish (thread 0's row): row sum %.2f  relax %.2f  store + publish + residual %.2f us\n", k * h[5], k * h[6], k * h[7]);
+            (void)hipMemsetAsync(c->gsp_prof.p, 0, sizeof(h), st);
+        }
+    }
 }
 
 // Plan + buffers of the persistent GS kernel; leaves gsp_enabled = false when the scene does not fit (the colour kernels serve it).
@@ -1042,6 +1053,8 @@ hipError_t plan_gs_persist(admm_hip_ctx *c) {
     if ((e = c->gsp_meet.zero()) != hipSuccess) return e;
     if ((e = c->gsp_abort.alloc(16)) != hipSuccess) return e;
     if ((e = c->gsp_abort.zero()) != hipSuccess) return e;
+    { const char *pe = getenv("ADMM_HIP_GSP_PROF"), *pb = getenv("ADMM_HIP_GSP_PROF_BLOCK");
+      if (pe && pe[0] == '1') { if ((e = c->gsp_prof.alloc(8)) != hipSuccess) return e; if ((e = c->gsp_prof.zero()) != hipSuccess) return e; c->gsp_prof_block = pb ? atoi(pb) : 0; } }
     c->gsp_G = P.G; c->gsp_C = P.C; c->gsp_lds = (size_t)P.lds_bytes;
     c->gsp_stat[0] = P.G; c->gsp_stat[1] = P.max_rows; c->gsp_stat[2] = P.max_halo; c->gsp_stat[3] = P.max_nbr; c->gsp_stat[4] = P.ob_total; c->gsp_stat[5] = P.lds_bytes;
     if (getenv("ADMM_HIP_OC_DIAG"))

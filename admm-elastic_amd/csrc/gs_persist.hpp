@@ -49,6 +49,7 @@ struct GspArgs {
     unsigned *abort_word;                                     // raised by the first block that gives up
     int *done, *sweeps, *total;                               // counters[1], [2], [0] of the context (as the colour kernels)
     int *sig;                                                 // host-visible: sig[2] = 1 when the solve was aborted
+    unsigned long long *prof; int prof_block;                 // diagnosis (ADMM_HIP_GSP_PROF=1): wall-clock ticks per part of a phase
 };
 
 __device__ __forceinline__ v4u gsp_pack(double v, unsigned s) {
@@ -69,9 +70,9 @@ __device__ __forceinline__ void gsp_store(__amdgpu_buffer_rsrc_t rs, int byte_of
 __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x, t = (int)threadIdx.x;
-    // ---- LDS: scratch | x [L][3] | b [n_own][3] | a_ii [n_own][3] | values | columns | outbox node per row | halo source | pin flags
-    //      (host_setup.hpp: gsp_lds_bytes computes the same offsets)
-    LdsD *scr = (LdsD *)smem;                       // [0..15] reduction partials, [16..31] verdict sums
+    // ---- LDS: scratch | x [L][3] | x of the previous sweep [L][3] | b [n_own][3] | a_ii [n_own][3] | values | columns | outbox node per
+    //      row | halo source | pin flags   (host_setup.hpp: gsp_lds_bytes computes the same offsets)
+    LdsD *scr = (LdsD *)smem;                       // [0..3] wave sums of the residual partial, [8] |b|^2 of the block
     LdsI32 *ih = (LdsI32 *)(smem + 256);            // the block's header (64 ints)
     LdsI32 *ctl = (LdsI32 *)(smem + 512);           // [0] abort seen, [1] verdict
     if (t < kGspHdrK) ih[t] = a.hdr[b * kGspHdrK + t];
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
     const int n_own = ih[0], n_halo = ih[1], row_base = ih[2], halo_base = ih[3], ent_base = ih[4], ob_base = ih[5], ent_count = ih[7];
     const int L = n_own + n_halo, C = a.C;
     LdsD *xl = (LdsD *)(smem + 1024);
-    LdsD *bl = xl + 3 * L;
+    LdsD *xo = xl + 3 * L;
+    LdsD *bl = xo + 3 * L;
     LdsD *al = bl + 3 * n_own;
     LdsD *vl = al + 3 * n_own;
     LdsU16 *cl = (LdsU16 *)(vl + ent_count);
@@ -88,16 +90,26 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
     LdsI32 *hl = (LdsI32 *)((__attribute__((address_space(3))) char *)ol + (4 * n_own + 7) / 8 * 8);
     LdsU8 *pl = (LdsU8 *)((__attribute__((address_space(3))) char *)hl + (4 * n_halo + 7) / 8 * 8);
     const __amdgpu_buffer_rsrc_t rbox = soa_rsrc(a.box), rpart = soa_rsrc(a.part), rmeet = soa_rsrc(a.meet);
+    const int lane = t & 63, wv = t >> 6;
 
     // ---- fill: matrix, right-hand side, diagonal, lists (once), x (again before a replay) ----
     for (int i = t; i < ent_count; i += kGspT) { vl[i] = a.vals[(size_t)ent_base + i]; cl[i] = a.cols[(size_t)ent_base + i]; }
-    for (int i = t; i < n_own; i += kGspT) {
-        const int v = a.orig[row_base + i];
-        const double d = a.diag[row_base + i];
-        ol[i] = a.out_idx[row_base + i];
-        pl[i] = (a.pin_flag && a.pin_flag[v]) ? 1 : 0;
+    {
+        double bb = 0.0;
+        for (int i = t; i < n_own; i += kGspT) {
+            const int v = a.orig[row_base + i];
+            const double d = a.diag[row_base + i];
+            ol[i] = a.out_idx[row_base + i];
+            pl[i] = (a.pin_flag && a.pin_flag[v]) ? 1 : 0;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { bl[3 * i + q] = a.b[3 * (size_t)v + q]; al[3 * i + q] = d + a.m[3 * (size_t)v + q]; }
+            for (int q = 0; q < 3; ++q) {
+                const double bi = a.b[3 * (size_t)v + q];
+                bl[3 * i + q] = bi; al[3 * i + q] = d + a.m[3 * (size_t)v + q];
+                bb = fma(bi, bi, bb);
+            }
+        }
+        bb = wave_sum(bb);
+        if (lane == 0) scr[4 + wv] = bb;
     }
     for (int i = t; i < n_halo; i += kGspT) hl[i] = a.halo_box[halo_base + i];
     auto load_x = [&]() {
@@ -114,16 +126,25 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
     };
     load_x();
     __syncthreads();
+    if (t == 0) scr[8] = scr[4] + scr[5] + scr[6] + scr[7];     // |b|^2 of the block's rows (constant during the solve)
 
     auto give_up = [&]() {      // (one thread) tell everybody, and the host
         __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(a.sig + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     };
+    auto poll_failed = [&](unsigned &spins) -> bool {   // one more unsuccessful poll: give up?
+        if (++spins > kGspSpin || ((spins & 127u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (!ctl[0]) { ctl[0] = 1; give_up(); }
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        return false;
+    };
     // after a __syncthreads: did any thread of the block fail a poll?
     auto block_failed = [&]() -> bool { return ctl[0] != 0; };
 
-    // the halo entries of colour `cp`, published with stamp `want` in slot `par`
-    auto fetch_halo = [&](int cp, int par, unsigned want) {
+    // the halo entries of colour `cp`, published with stamp `want` in slot `par`; keep_old: park the values they replace in xo
+    auto fetch_halo = [&](int cp, int par, unsigned want, bool keep_old) {
         const int h0 = ih[21 + cp], h1 = ih[21 + cp + 1];
         for (int hh = h0 + t; hh < h1; hh += kGspT) {
             const int off = ((hl[hh] * 2 + par) * 3) * 16;
@@ -132,150 +153,227 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
             while (true) {
                 g0 = gsp_load(rbox, off); g1 = gsp_load(rbox, off + 16); g2 = gsp_load(rbox, off + 32);
                 if (gsp_ok(g0, want) && gsp_ok(g1, want) && gsp_ok(g2, want)) break;
-                if (++spins > kGspSpin || ((spins & 127u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                    if (!ctl[0]) { ctl[0] = 1; give_up(); }
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
+                if (poll_failed(spins)) break;
             }
-            xl[3 * (n_own + hh)] = gsp_val(g0); xl[3 * (n_own + hh) + 1] = gsp_val(g1); xl[3 * (n_own + hh) + 2] = gsp_val(g2);
+            const int j = 3 * (n_own + hh);
+            if (keep_old) { xo[j] = xl[j]; xo[j + 1] = xl[j + 1]; xo[j + 2] = xl[j + 2]; }
+            xl[j] = gsp_val(g0); xl[j + 1] = gsp_val(g1); xl[j + 2] = gsp_val(g2);
         }
     };
-    // sum_k Ahat(row, k) x_k of row i of colour c (entries in CSR order: the sums of k_gs_color)
-    auto row_sum = [&](int c, int i, double *acc) {
+    // cur = sum_k Ahat(row, k) x_k of row i of colour c (entries in CSR order: the sums of k_gs_color).  BOTH: also old = the same sum
+    // with the previous sweep's values (xo) of the neighbours whose colour is below the row's (bit 15 of the column, set by the plan)
+    auto row_sum = [&](int c, int i, double *cur, double *old, bool both) {
         const int n_c = ih[8 + c + 1] - ih[8 + c], W = ih[34 + c];
         const LdsD *vv = vl + ih[46 + c] + i;
         const LdsU16 *cc = cl + ih[46 + c] + i;
-        acc[0] = acc[1] = acc[2] = 0.0;
+        cur[0] = cur[1] = cur[2] = 0.0;
+        if (!both) {
+            int k = 0;
+            for (; k + 4 <= W; k += 4) {
+                int col[4]; double av[4], g[12];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { col[u] = 3 * (cc[(k + u) * n_c] & 0x7fff); av[u] = vv[(k + u) * n_c]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { g[3 * u] = xl[col[u]]; g[3 * u + 1] = xl[col[u] + 1]; g[3 * u + 2] = xl[col[u] + 2]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { cur[0] = fma(av[u], g[3 * u], cur[0]); cur[1] = fma(av[u], g[3 * u + 1], cur[1]); cur[2] = fma(av[u], g[3 * u + 2], cur[2]); }
+            }
+            for (; k < W; ++k) {
+                const int col = 3 * (cc[k * n_c] & 0x7fff);
+                const double av = vv[k * n_c];
+                cur[0] = fma(av, xl[col], cur[0]); cur[1] = fma(av, xl[col + 1], cur[1]); cur[2] = fma(av, xl[col + 2], cur[2]);
+            }
+            return;
+        }
+        old[0] = old[1] = old[2] = 0.0;
         for (int k = 0; k < W; ++k) {
-            const int col = cc[k * n_c];
+            const int raw = cc[k * n_c];
+            const int col = 3 * (raw & 0x7fff);
             const double av = vv[k * n_c];
-            acc[0] = fma(av, xl[3 * col], acc[0]); acc[1] = fma(av, xl[3 * col + 1], acc[1]); acc[2] = fma(av, xl[3 * col + 2], acc[2]);
+            const double g0 = xl[col], g1 = xl[col + 1], g2 = xl[col + 2];
+            const bool lo = (raw & 0x8000) != 0;
+            const double h0 = lo ? xo[col] : g0, h1 = lo ? xo[col + 1] : g1, h2 = lo ? xo[col + 2] : g2;
+            cur[0] = fma(av, g0, cur[0]); cur[1] = fma(av, g1, cur[1]); cur[2] = fma(av, g2, cur[2]);
+            old[0] = fma(av, h0, old[0]); old[1] = fma(av, h1, old[1]); old[2] = fma(av, h2, old[2]);
         }
     };
-    auto sweep_colour = [&](int c, int par, unsigned stamp) {
+    // One colour of one sweep.  role (residual test riding on the sweep, as in k_gs_color2 / k_gs_colorN): 0 none; 1 PRE -- the
+    // row's residual of the PREVIOUS sweep before it moves (first colour: nothing has moved yet; middle colours: the neighbours that
+    // have, by their parked values); 2 POST -- the residual of THIS sweep right after the update (last colour: every neighbour is
+    // final).  Returns the thread's sum of squared residuals.
+    unsigned long long fine[4] = {0ull, 0ull, 0ull, 0ull};
+    const bool fprof = a.prof != nullptr && b == a.prof_block && t == 0;
+    auto sweep_colour = [&](int c, int par, unsigned stamp, int role, bool keep_old) -> double {
+        unsigned long long f0 = fprof ? wall_clock64() : 0ull;
+        auto flap = [&](int k) { if (fprof) { const unsigned long long now = wall_clock64(); fine[k] += now - f0; f0 = now; } };
         const int r0 = ih[8 + c], n_c = ih[8 + c + 1] - r0;
+        const bool both = role == 1 && c > 0;
+        double rs = 0.0;
         for (int i = t; i < n_c; i += kGspT) {
-            double LUx[3];
-            row_sum(c, i, LUx);
+            double LUx[3], LUo[3];
+            flap(0);
+            row_sum(c, i, LUx, LUo, both);
+            flap(1);
             const int li = r0 + i;
+            const double bi[3] = {bl[3 * li], bl[3 * li + 1], bl[3 * li + 2]};
+            const double aii[3] = {al[3 * li], al[3 * li + 1], al[3 * li + 2]};
+            const double cx[3] = {xl[3 * li], xl[3 * li + 1], xl[3 * li + 2]};
             double nx[3];
+            if (role == 1) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const double r = bi[q] - fma(aii[q], cx[q], both ? LUo[q] : LUx[q]); rs = fma(r, r, rs); }
+            }
             if (pl[li]) { // :111-117
                 const int v = a.orig[row_base + li];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
-            } else {
-                const double bi[3] = {bl[3 * li], bl[3 * li + 1], bl[3 * li + 2]};
-                const double aii[3] = {al[3 * li], al[3 * li + 1], al[3 * li + 2]};
-                const double cx[3] = {xl[3 * li], xl[3 * li + 1], xl[3 * li + 2]};
-                gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
-            }
+            } else gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
+            flap(2);
+            if (keep_old) { xo[3 * li] = cx[0]; xo[3 * li + 1] = cx[1]; xo[3 * li + 2] = cx[2]; }
             xl[3 * li] = nx[0]; xl[3 * li + 1] = nx[1]; xl[3 * li + 2] = nx[2];
             const int o = ol[li];
             if (o >= 0) {
                 const int off = (((ob_base + o) * 2 + par) * 3) * 16;
                 gsp_store(rbox, off, gsp_pack(nx[0], stamp)); gsp_store(rbox, off + 16, gsp_pack(nx[1], stamp)); gsp_store(rbox, off + 32, gsp_pack(nx[2], stamp));
             }
+            if (role == 2) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const double r = bi[q] - fma(aii[q], nx[q], LUx[q]); rs = fma(r, r, rs); }
+            }
+            flap(3);
         }
+        return rs;
     };
-    // |b - A x|^2 and |b|^2 over the block's rows at the current (complete) state; published for sweep `k` with stamp `sp`
-    auto publish_partial = [&](int k, unsigned sp) {
-        double q2[2] = {0.0, 0.0};
-        for (int c = 0; c < C; ++c) {
+    // residuals of the rows of colours c0 .. c1-1 at the current (complete) state
+    auto direct_residual = [&](int c0, int c1) -> double {
+        double rs = 0.0;
+        for (int c = c0; c < c1; ++c) {
             const int r0 = ih[8 + c], n_c = ih[8 + c + 1] - r0;
             for (int i = t; i < n_c; i += kGspT) {
                 double acc[3];
-                row_sum(c, i, acc);
+                row_sum(c, i, acc, acc, false);
                 const int li = r0 + i;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const double bi = bl[3 * li + q];
-                    const double r = bi - fma(al[3 * li + q], xl[3 * li + q], acc[q]);
-                    q2[0] = fma(r, r, q2[0]); q2[1] = fma(bi, bi, q2[1]);
-                }
+                for (int q = 0; q < 3; ++q) { const double r = bl[3 * li + q] - fma(al[3 * li + q], xl[3 * li + q], acc[q]); rs = fma(r, r, rs); }
             }
         }
-        const int lane = t & 63, wv = t >> 6;
-        const double s0 = wave_sum(q2[0]), s1 = wave_sum(q2[1]);
-        if (lane == 0) { scr[wv] = s0; scr[4 + wv] = s1; }
-        __syncthreads();
+        return rs;
+    };
+    auto park = [&](double rs) { const double s = wave_sum(rs); if (lane == 0) scr[wv] = s; };     // ... a __syncthreads later:
+    auto publish_parked = [&](int k, unsigned sp) {       // thread 0: the block's partial of sweep k
         if (t == 0) {
-            const double r2 = scr[0] + scr[1] + scr[2] + scr[3], b2 = scr[4] + scr[5] + scr[6] + scr[7];
+            const double r2 = scr[0] + scr[1] + scr[2] + scr[3];
             const int off = ((b * 4 + (k & 3)) * 2) * 16;
-            gsp_store(rpart, off, gsp_pack(r2, sp)); gsp_store(rpart, off + 16, gsp_pack(b2, sp));
+            gsp_store(rpart, off, gsp_pack(r2, sp)); gsp_store(rpart, off + 16, gsp_pack(scr[8], sp));
         }
     };
-    // the residual test of sweep k from all blocks' partials (fixed order: every block gets the same verdict).  All threads call.
-    auto verdict = [&](int k, unsigned sp) -> bool {
-        double r2 = 0.0, b2 = 0.0;
-        if (t < 64) {            // wave 0: lane l sums blocks l, l + 64, ... in order; then the wave sum
-            for (int j = t; j < a.G; j += 64) {
-                const int off = ((j * 4 + (k & 3)) * 2) * 16;
-                v4u g0, g1;
-                unsigned spins = 0;
-                while (true) {
-                    g0 = gsp_load(rpart, off); g1 = gsp_load(rpart, off + 16);
-                    if (gsp_ok(g0, sp) && gsp_ok(g1, sp)) break;
-                    if (++spins > kGspSpin || ((spins & 127u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                        if (!ctl[0]) { ctl[0] = 1; give_up(); }
-                        break;
+    // The residual test of sweep k from all blocks' partials; every block adds the same numbers in the same order: identical
+    // verdicts.  Wave 0: lane l takes blocks l, l + 64, l + 128, l + 192.  `pre`: granules loaded earlier (their latency hidden behind
+    // the halo hand-off); whatever has not arrived yet is polled.  All threads call; one block barrier.
+    auto verdict = [&](int k, unsigned sp, v4u (*pre)[2], bool have_pre) -> bool {
+        if (t < 64) {
+            double r2 = 0.0, b2 = 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = t + 64 * u;
+                if (j < a.G) {
+                    const int off = ((j * 4 + (k & 3)) * 2) * 16;
+                    v4u g0, g1;
+                    if (have_pre) { g0 = pre[u][0]; g1 = pre[u][1]; }
+                    unsigned spins = 0;
+                    while (!have_pre || !(gsp_ok(g0, sp) && gsp_ok(g1, sp))) {
+                        g0 = gsp_load(rpart, off); g1 = gsp_load(rpart, off + 16);
+                        if (gsp_ok(g0, sp) && gsp_ok(g1, sp)) break;
+                        if (poll_failed(spins)) break;
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                    r2 += gsp_val(g0); b2 += gsp_val(g1);
                 }
-                r2 += gsp_val(g0); b2 += gsp_val(g1);
             }
             r2 = wave_sum(r2); b2 = wave_sum(b2);
             if (t == 0) ctl[1] = (r2 / b2 < a.tol2) ? 1 : 0;
         }
         __syncthreads();
-        const bool conv = ctl[1] != 0;
-        __syncthreads();
-        return conv;
+        return ctl[1] != 0;
     };
 
-    // n sweeps; with_tests: the residual test of every sweep, evaluated one sweep late.  Returns the first sweep that met the
-    // tolerance among 0 .. n-3 (-1: none -- the last two are settled by the caller), -2 after an abort.
-    auto run = [&](int n, bool with_tests, unsigned stamp0, unsigned part0) -> int {
+    // n sweeps.  tests: the residual test of every sweep (:136-140), riding on the sweeps and evaluated two sweeps late.  Returns the
+    // first sweep that met the tolerance (0 .. n-1), -1 if none did, -2 after an abort.
+    auto run = [&](int n, bool tests, unsigned stamp0) -> int {
+        const bool keep_old = tests && C >= 3;
+        const int c_pub = C >= 2 ? C - 2 : 0;        // the phase of sweep s + 1 after which the partial of sweep s is complete
+        double racc = 0.0;
+        int parked = -1;
+        const bool prof = a.prof != nullptr && b == a.prof_block && t == 0;
+        unsigned long long pt[4] = {0ull, 0ull, 0ull, 0ull}, tk = prof ? wall_clock64() : 0ull;
+        auto lap = [&](int k) { if (prof) { const unsigned long long now = wall_clock64(); pt[k] += now - tk; tk = now; } };
         for (int sweep = 0; sweep < n; ++sweep) {
             for (int c = 0; c < C; ++c) {
                 const int p = sweep * C + c;
-                if (p > 0) fetch_halo(c > 0 ? c - 1 : C - 1, (c > 0 ? sweep : sweep - 1) & 1, stamp0 + (unsigned)(p - 1));
-                __syncthreads();
-                if (block_failed()) return -2;
-                if (with_tests && c == 0 && sweep > 0) {
-                    publish_partial(sweep - 1, part0 + (unsigned)(sweep - 1));
-                    if (sweep >= 2) {
-                        const bool conv = verdict(sweep - 2, part0 + (unsigned)(sweep - 2));
-                        if (block_failed()) return -2;
-                        if (conv) return sweep - 2;
+                const bool due = tests && c == 0 && sweep >= 2;     // the verdict on sweep - 2
+                v4u pre[4][2];
+                if (due && t < 64) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = t + 64 * u;
+                        if (j < a.G) { const int off = ((j * 4 + ((sweep - 2) & 3)) * 2) * 16; pre[u][0] = gsp_load(rpart, off); pre[u][1] = gsp_load(rpart, off + 16); }
                     }
                 }
-                sweep_colour(c, sweep & 1, stamp0 + (unsigned)p);
+                lap(3);
+                if (p > 0) fetch_halo(c > 0 ? c - 1 : C - 1, (c > 0 ? sweep : sweep - 1) & 1, stamp0 + (unsigned)(p - 1), keep_old);
+                lap(0);
+                __syncthreads();
+                lap(1);
+                if (block_failed()) return -2;
+                if (parked >= 0) { publish_parked(parked, stamp0 + (unsigned)parked); parked = -1; }
+                if (due) {
+                    const bool conv = verdict(sweep - 2, stamp0 + (unsigned)(sweep - 2), pre, true);
+                    if (block_failed()) return -2;
+                    if (conv) return sweep - 2;
+                }
+                int role = 0;
+                if (tests) {
+                    if (C >= 2 && c == C - 1) role = 2;
+                    else if (sweep > 0) role = 1;
+                }
+                racc += sweep_colour(c, sweep & 1, stamp0 + (unsigned)p, role, keep_old);
+                if (tests && sweep > 0 && c == c_pub) { park(racc); parked = sweep - 1; racc = 0.0; }
+                lap(2);
             }
         }
+        if (prof) { a.prof[0] += pt[0]; a.prof[1] += pt[1]; a.prof[2] += pt[2]; a.prof[3] += pt[3]; a.prof[4] += (unsigned long long)(n * C);
+                    a.prof[5] += fine[1]; a.prof[6] += fine[2]; a.prof[7] += fine[3]; }
         // the values of the last colour of the last sweep: the block's state is complete again
-        if (n > 0 && a.G > 1) fetch_halo(C - 1, (n - 1) & 1, stamp0 + (unsigned)(n * C - 1));
+        if (n > 0 && a.G > 1) fetch_halo(C - 1, (n - 1) & 1, stamp0 + (unsigned)(n * C - 1), false);
         __syncthreads();
         if (block_failed()) return -2;
-        return -1;
+        if (!tests || n < 1) return -1;
+        if (parked >= 0) publish_parked(parked, stamp0 + (unsigned)parked);
+        __syncthreads();                                    // (thread 0 has read the parked sums)
+        // the last sweep: its last colour's rows were taken after their update, the others now
+        racc += direct_residual(0, C >= 2 ? C - 1 : 1);
+        park(racc);
+        __syncthreads();
+        publish_parked(n - 1, stamp0 + (unsigned)(n - 1));
+        if (n >= 2) {
+            const bool conv = verdict(n - 2, stamp0 + (unsigned)(n - 2), nullptr, false);
+            if (block_failed()) return -2;
+            if (conv) return n - 2;
+            __syncthreads();                                // (everybody has read the verdict word before it is written again)
+        }
+        const bool conv = verdict(n - 1, stamp0 + (unsigned)(n - 1), nullptr, false);
+        if (block_failed()) return -2;
+        return conv ? n - 1 : -1;
     };
 
-    const unsigned stamp0 = a.seq * 4096u + 1u;         // phases of the first run: stamp0 + p; of a replay: stamp0 + 2048 + p
+    const unsigned stamp0 = a.seq * 4096u + 1u;         // phases (and partials) of the first run: stamp0 + p; of a replay: stamp0 + 2048 + p
     const int n = a.max_sweeps;
     int failed_tests = n, conv_flag = 0;                // what the counters get: sweeps whose test failed, done
-    int first = run(n, a.check != 0, stamp0, stamp0);
+    const int first = run(n, a.check != 0, stamp0);
     if (first == -2) return;
-    if (a.check && first == -1 && n >= 1) {             // the last two sweeps' tests
-        publish_partial(n - 1, stamp0 + (unsigned)(n - 1));
-        if (n >= 2 && verdict(n - 2, stamp0 + (unsigned)(n - 2))) first = n - 2;
-        if (block_failed()) return;
-        if (first == -1 && verdict(n - 1, stamp0 + (unsigned)(n - 1))) { failed_tests = n - 1; conv_flag = 1; }    // the state is already the answer
-        if (block_failed()) return;
-    }
+    if (first >= 0) { failed_tests = first; conv_flag = 1; }
     if (first >= 0 && first < n - 1) {
         // sweep `first` met the tolerance: the reference stopped there.  Everybody meets (nobody may still be reading this run's
-        // granules, x in memory is still the input), then the solve is replayed for first + 1 sweeps without tests.
-        failed_tests = first; conv_flag = 1;
+        // granules; x in memory is still the input), then the solve is replayed for first + 1 sweeps without tests.
         const unsigned ms = stamp0 + 4000u;
         if (t == 0) gsp_store(rmeet, b * 16, gsp_pack(0.0, ms));
         if (t < 64) {
@@ -284,11 +382,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
                 while (true) {
                     const v4u g = gsp_load(rmeet, j * 16);
                     if (gsp_ok(g, ms)) break;
-                    if (++spins > kGspSpin || ((spins & 127u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                        if (!ctl[0]) { ctl[0] = 1; give_up(); }
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
+                    if (poll_failed(spins)) break;
                 }
             }
         }
@@ -296,8 +390,8 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
         if (block_failed()) return;
         load_x();
         __syncthreads();
-        if (run(first + 1, false, stamp0 + 2048u, 0u) == -2) return;
-    } else if (first == n - 1 && first >= 0) { failed_tests = n - 1; conv_flag = 1; }
+        if (run(first + 1, false, stamp0 + 2048u) == -2) return;
+    }
     // ---- write the block's rows back, counters ----
     for (int i = t; i < n_own; i += kGspT) {
         const int v = a.orig[row_base + i];

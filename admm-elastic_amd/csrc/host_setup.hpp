@@ -137,7 +137,9 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
 //   local column index : own row -> its position, halo entry h -> n_own + h (halo entries by colour as well)
 //   matrix entries     : per (block, colour) an ELL of that colour's rows, width W = longest row, entry (k, row i) at
 //                        ent_base + eoff[c] + k * n_c + i; the entries of a row keep their CSR order (ascending original column), so
-//                        the row sums are bit-identical to the colour kernels' (padding: value 0 on the row's own index)
+//                        the row sums are bit-identical to the colour kernels' (padding: value 0 on the row's own index); bit 15 of a
+//                        column: the neighbour's colour is below the row's (it has already moved when the row's residual of the
+//                        previous sweep is taken: the kernel then reads its parked value)
 constexpr int kGspMaxC = 12;       // colours a plan supports
 constexpr int kGspHdr = 64;        // ints per block header:
 //   0 n_own, 1 n_halo, 2 row_base (into orig / out_idx / diag), 3 halo_base (into halo_box / halo_orig), 4 ent_base (into vals / cols),
@@ -162,7 +164,7 @@ GsPlan build_gs_plan(const Csr &A, int n_colors, const int32_t *color, int max_b
 inline int32_t gsp_lds_bytes(int32_t n_own, int32_t n_halo, int32_t ent_count) {
     const int32_t L = n_own + n_halo;
     int32_t o = 1024;                         // scratch: reductions, control words
-    o += 24 * L;                              // x [L][3]
+    o += 48 * L;                              // x [L][3], x of the previous sweep [L][3]
     o += 48 * n_own;                          // b, a_ii [n_own][3]
     o += 8 * ent_count;                       // values
     o += (2 * ent_count + 7) / 8 * 8;         // 16-bit local columns

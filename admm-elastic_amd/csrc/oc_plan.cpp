@@ -682,7 +682,7 @@ GsPlan build_gs_plan(const Csr &A, int n_colors, const int32_t *color, int max_b
             return local[x] < local[y];
         });
         const int32_t n_own = h[0], n_halo = (int32_t)halo.size();
-        if (n_own + n_halo > 65535) return P;
+        if (n_own + n_halo > 32767) return P;       // (bit 15 of a column flags "the neighbour's colour is below the row's")
         h[1] = n_halo; h[3] = halo_base;
         std::vector<int32_t> hloc(n_halo);
         {
@@ -730,7 +730,7 @@ GsPlan build_gs_plan(const Csr &A, int n_colors, const int32_t *color, int max_b
                     if (A.col[q] == v) { P.diag[(size_t)h[2] + r0 + i] = A.val[q]; continue; }
                     if (A.val[q] == 0.0) continue;
                     P.vals[base + (size_t)k * n_c + i] = A.val[q];
-                    P.cols[base + (size_t)k * n_c + i] = (uint16_t)loc_of(A.col[q]);
+                    P.cols[base + (size_t)k * n_c + i] = (uint16_t)(loc_of(A.col[q]) | (color[A.col[q]] < color[v] ? 0x8000 : 0));
                     ++k;
                 }
                 for (; k < W; ++k) P.cols[base + (size_t)k * n_c + i] = (uint16_t)(r0 + i);      // padding: 0 x own value
