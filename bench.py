@@ -30,6 +30,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# Tolerance of the GPU PCG that replaces the reference's exact (prefactored LDLT) solves.  Chosen by the parity bar, not by speed:
+# the loosest value at which blob1m_mix stays within 1e-5 of the bounding box of the converged trajectory (same path at 1e-12,
+# every pass verified) at EVERY one of the driver's 25 frames, with margin (tests/test_bench_parity.py).  Round 3's 1e-8 met the bar
+# for two frames and drifted to 4.6e-4 by frame 21 (profiles/r04_drift_tolerance_study.txt: 1e-9 6.5e-6 at 25 frames but 1.7e-5 at
+# 50, 7e-10 8.6e-6 at 50, 5e-10 2.9e-6 at 50).
+PCG_TOL = 5e-10
+
 WORKLOADS = {
     "cube1m_mix": dict(n=55, kinds="mix", linsolver=0, admm_iters=20),
     "cube1m_nh": dict(n=55, kinds="nh", linsolver=0, admm_iters=20),
@@ -281,7 +288,7 @@ def main():
                     help="default: blob1m_mix -- on several GPUs the same body at fixed tet count (strong scaling, BASELINE configs[3]); "
                          "blobs_1m_per_gpu = one 1 M-tet body per GPU (weak scaling) as the whole line")
     ap.add_argument("--n", type=int, default=0, help="override cells per edge (testing only)")
-    ap.add_argument("--pcg-tol", type=float, default=1e-8)
+    ap.add_argument("--pcg-tol", type=float, default=PCG_TOL)
     ap.add_argument("--pcg-max-iters", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")

@@ -694,11 +694,11 @@ def test_step_parity_beams_config1():
 
 def test_step_parity_48k_tets_bench_settings():
     """The bench scene shape (NH/StVK slabs, pinned face, gravity) at 48 000 tets with the bench's solver
-    settings (pcg_tol 1e-8, recycled warm start) against the oracle's exact (SuperLU) solves."""
+    settings (bench.PCG_TOL, recycled warm start) against the oracle's exact (SuperLU) solves."""
     import bench
     sc, nt, nv = bench.build_scene(bench.WORKLOADS["cube1m_mix"], 20)
     assert nt == 48000
-    s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=600)
+    s = sc.make_solver(pcg_tol=bench.PCG_TOL, pcg_max_iters=600)
     o = sc.make_oracle(mode=1, big=True)
     for _ in range(2):
         s.step(); o.step()
@@ -755,7 +755,7 @@ def test_big_bench_tolerance_vs_tight_solve():
     n = int(os.environ.get("ADMM_TEST_BIG_N", "55"))
     sc, nt, nv = bench.build_scene(bench.WORKLOADS["cube1m_mix"], n)
     xs = []
-    for tol, mx in ((1e-12, 1500), (1e-8, 600)):
+    for tol, mx in ((1e-12, 1500), (bench.PCG_TOL, 600)):
         s = sc.make_solver(pcg_tol=tol, pcg_max_iters=mx)
         for _ in range(2):
             s.step()
@@ -1047,7 +1047,8 @@ def test_big_blob_bench_tolerance_vs_tight_solve(big_blob):
     same path converged to 1e-12 and verified after every pass: <= 1e-5 of the bounding box (the north-star bar) after two frames."""
     sc = big_blob
     xs = []
-    for tol, mx, env in ((1e-12, 1500, "1"), (1e-8, 600, "0")):
+    import bench
+    for tol, mx, env in ((1e-12, 1500, "1"), (bench.PCG_TOL, 600, "0")):
         os.environ["ADMM_HIP_OC_VERIFY"] = env
         try:
             s = sc.make_solver(pcg_tol=tol, pcg_max_iters=mx)
@@ -1089,7 +1090,7 @@ def test_big_blob_onchip_pcg_residual_and_uzawa_frame(big_blob):
     frames = []
     for ls in (0, 2):
         st = dict(sc.settings); sc.settings.update(linsolver=ls)
-        s = sc.make_solver(pcg_tol=1e-8, pcg_max_iters=600)
+        s = sc.make_solver(pcg_tol=bench.PCG_TOL, pcg_max_iters=600)
         sc.settings.update(st)
         s.step()
         assert s.runtime_data().unconverged_solves == 0 or ls == 2
