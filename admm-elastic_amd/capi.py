@@ -50,6 +50,7 @@ class Desc(C.Structure):
         ("tet_kappa", c_double_p),
         ("vert_xyz", c_double_p),
         ("n_spline_tables", C.c_int32), ("spline_tables", c_double_p), ("tet_spline", c_int_p),
+        ("n_obstacle_grids", C.c_int32), ("obstacle_grid_meta", c_double_p), ("obstacle_grid_data", c_double_p),
     ]
 
 
@@ -64,6 +65,7 @@ class Stats(C.Structure):
 
 SPLINE_TABLE_DOUBLES = 9228     # ADMM_SPLINE_TABLE_DOUBLES
 SPLINE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int, C.c_double)     # admm_spline_fn
+OBSTACLE_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))     # admm_obstacle_fn
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)     # admm_allreduce_fn
 
 # every symbol include/admm_hip.h declares: (name, restype, argtypes)
@@ -101,6 +103,8 @@ SYMBOLS = [
     ("admm_host_tet_rest_positions", C.c_int, [C.c_int32, C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_hip_tet_rest_mode", C.c_int, [C.c_void_p]),
     ("admm_hip_uzawa_cache_stats", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 5),
+    ("admm_hip_uzawa_unconverged_columns", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    ("admm_host_sample_obstacle", C.c_int, [OBSTACLE_FN, C.c_void_p, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p]),
     ("admm_host_tri_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     ("admm_host_greedy_coloring", C.c_int, [C.c_int32, c_int_p, c_int_p, c_int_p]),

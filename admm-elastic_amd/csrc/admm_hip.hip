@@ -237,9 +237,10 @@ struct admm_hip_ctx {
     size_t uzc_cap = 0; int uzc_n = 0, uzc_n_act = 0;
     DevBuf<double> uzc_cols; DevBuf<int> uzc_slot, uzc_act, uzc_miss, uzc_info; DevBuf<unsigned char> uzc_flag;
     DevBuf<double> uzc_G, uzc_part, uzc_gq, uz_y0; DevBuf<int> uzc_pos;   // Schur iterations on the active vertices (kernels.hpp: k_uzc_*)
+    int uzc_test_iters = 0;   // tests (ADMM_HIP_TEST_UZ_COL_ITERS=n): the column solves get n iterations, so they do not converge
     bool uzc_compact = true; int uzc_one_max = 1024, uzc_compact_max = 8192;   // (the limits are lowered by tests to reach the general paths on small scenes)
     std::vector<int> uzc_slot_h;
-    long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0, uzc_evictions = 0;
+    long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0, uzc_evictions = 0, uzc_unconverged = 0;
     bool uz_freeze = false, uz_detected = false;   // tests (ADMM_HIP_UZ_FREEZE=1): Collider::detect only in the first ADMM iteration of a step
     // GS: the whole solve (colours x sweeps + residual tests, ~500 tiny launches) is captured once into a
     // hipGraph and replayed -- the per-colour kernels are far below the host launch rate
@@ -255,7 +256,7 @@ struct admm_hip_ctx {
     bool gsp_enabled = false; int gsp_G = 0, gsp_C = 0; size_t gsp_lds = 0; int64_t gsp_stat[6] = {0, 0, 0, 0, 0, 0};
     DevBuf<int> gsp_hdr, gsp_orig, gsp_out, gsp_hbox, gsp_horig; DevBuf<double> gsp_diag, gsp_vals; DevBuf<unsigned short> gsp_cols;
     DevBuf<uint4> gsp_box, gsp_part, gsp_meet; DevBuf<unsigned> gsp_abort; DevBuf<unsigned long long> gsp_prof; int gsp_prof_block = 0;
-    Obstacles obst{};
+    Obstacles obst{}; DevBuf<double> obst_gmeta, obst_gdata;   // (sampled obstacles: ADMM_OBJ_GRID)
     // dynamic (self-)collision (dyn_collide.hpp): one entry per TetMeshCollision, payload arrays per vertex
     struct DynDev {
         DynMesh m{};
@@ -290,6 +291,7 @@ struct admm_hip_ctx {
         bk_x.release(); bk_v.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         gsp_hdr.release(); gsp_orig.release(); gsp_out.release(); gsp_hbox.release(); gsp_horig.release(); gsp_diag.release(); gsp_vals.release(); gsp_cols.release();
+        obst_gmeta.release(); obst_gdata.release();
         gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release(); gsp_prof.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
@@ -749,24 +751,44 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     const double keep_tol = c->pcg_tol;
     c->pcg_tol = std::min(1e-2 * keep_tol, 1e-10);
     int rc = 1;
+    // the solver's counters before the batch: [4] solves of this step that met their tolerance -- every column solve must add one --
+    // and [72..74] the totals admm_hip_solve_totals reports, which the column solves must not show up in (the caller's solves only)
+    int cnt0[8], tot0[3];
+    if (hipMemcpy(cnt0, c->counters.p, sizeof(cnt0), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(tot0, c->counters.p + 72, sizeof(tot0), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int launched = 0;
     for (int k = 0; k < n_missing && rc == 1; k += 3) {
         int v[3], sl[3];
         for (int j = 0; j < 3; ++j) { v[j] = k + j < n_missing ? miss[k + j] : -1; sl[j] = v[j] >= 0 ? slots[k + j] : -1; }
         if (hipMemsetAsync(c->uz_q1.p, 0, c->n3 * sizeof(double), st) != hipSuccess || hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) { rc = -1; break; }
         hipLaunchKernelGGL(k_uz_unit_rhs, dim3(1), dim3(1), 0, st, v[0], v[1], v[2], c->uz_q1.p);
-        if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, std::max(c->pcg_max_iters, 2000))) { rc = -1; break; }
+        if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, c->uzc_test_iters > 0 ? c->uzc_test_iters : std::max(c->pcg_max_iters, 2000))) { rc = -1; break; }
         hipLaunchKernelGGL(k_uz_store_cols, dim3(blocks_for(nv)), dim3(256), 0, st, nv, c->uz_q2.p, c->uzc_cols.p, sl[0], sl[1], sl[2]);
-        c->uzc_col_solves += 1;
+        c->uzc_col_solves += 1; ++launched;
     }
     c->pcg_tol = keep_tol;
     if (rc == 1 && hipStreamSynchronize(st) != hipSuccess) rc = -1;
     const bool aborted = c->h_sig && c->h_sig[2];     // a grid barrier of one of the solves timed out
+    // Did every column solve meet its tolerance?  A column that ran out of iterations would be a wrong Schur operator for every later
+    // solve: the batch is then not committed and this solve applies A^-1 by inner PCG solves (rc 0), counted in uzc_unconverged.
+    bool all_converged = true;
+    if (rc == 1 && !aborted) {
+        int cnt1[8];
+        if (hipMemcpy(cnt1, c->counters.p, sizeof(cnt1), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+        else {
+            all_converged = cnt1[4] - cnt0[4] == launched;
+            cnt1[0] = cnt0[0]; cnt1[3] = cnt0[3]; cnt1[4] = cnt0[4];      // the step's own statistics do not count the columns either
+            if (hipMemcpy(c->counters.p, cnt1, 5 * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(c->counters.p + 72, tot0, sizeof(tot0), hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+        }
+    }
     // (the evicted vertices' slots may have been overwritten whatever happened: they are given up in every case)
     for (int v : evicted) c->uzc_slot_h[v] = -1;
-    if (rc == 1 && !aborted) {
+    if (rc == 1 && !aborted && all_converged) {
         for (int k = 0; k < n_missing; ++k) c->uzc_slot_h[miss[k]] = slots[k];
         c->uzc_n += (int)fresh;
-    } else rc = -1;
+    } else if (rc == 1 && !aborted) { rc = 0; c->uzc_unconverged += launched; }
+    else rc = aborted ? -2 : -1;      // -2: the caller takes the recovery path of an aborted on-chip solve (kStepAborted)
     if (hipMemcpy(c->uzc_slot.p, c->uzc_slot_h.data(), sizeof(int) * (size_t)nv, hipMemcpyHostToDevice) != hipSuccess) return -1;
     c->uzc_evictions += (long long)evicted.size();
     return rc;
@@ -815,7 +837,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
         if (c->uzc_on) {
             c->uzc_n_act = info[0];
             c->uzc_usable = false;
-            if (nh > 0) { const int rc = uz_ensure_columns(c, info[1]); if (rc < 0) return -1; c->uzc_usable = rc == 1; }
+            if (nh > 0) { const int rc = uz_ensure_columns(c, info[1]); if (rc < 0) return rc; c->uzc_usable = rc == 1; }
         }
         if (c->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_coll0, c->ev_coll1) == hipSuccess) c->coll_ms_step += ms; }
     }
@@ -1240,6 +1262,18 @@ int validate(const admm_hip_desc *d) {
     if (d->n_obstacles < 0 || d->n_obstacles > kMaxObst) return fail(ADMM_HIP_ERR_ARG, "too many obstacles (max 8)");
     if (d->n_obstacles && d->linsolver == 0)
         return fail(ADMM_HIP_ERR_ARG, "No collisions with LDLT solver (Solver.cpp:249-254)");
+    for (int j = 0; j < d->n_obstacles; ++j) {
+        const int k = d->obstacle_kind[j];
+        const double *q = d->obstacle_params + 4 * (size_t)j;
+        if (k < ADMM_OBJ_FLOOR || k > ADMM_OBJ_GRID) return fail(ADMM_HIP_ERR_ARG, "unknown obstacle kind");
+        if (k == ADMM_OBJ_PLANE && !(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "plane obstacle with a zero normal");
+        if (k == ADMM_OBJ_GRID) {
+            const int g = (int)q[0];
+            if (g < 0 || g >= d->n_obstacle_grids || !d->obstacle_grid_meta || !d->obstacle_grid_data) return fail(ADMM_HIP_ERR_ARG, "sampled obstacle: its grid (admm_host_sample_obstacle) is missing");
+            const double *m = d->obstacle_grid_meta + 10 * (size_t)g;
+            if (!(m[3] > 0.0 && m[4] > 0.0 && m[5] > 0.0 && m[6] >= 2.0 && m[7] >= 2.0 && m[8] >= 2.0 && m[9] >= 0.0)) return fail(ADMM_HIP_ERR_ARG, "sampled obstacle: bad grid description");
+        }
+    }
     if (d->world_size > 1 && (d->rank < 0 || d->rank >= d->world_size)) return fail(ADMM_HIP_ERR_ARG, "rank out of range");
     for (int i = 0; i < 3 * d->n_verts; ++i)
         if (!(d->masses[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "non-positive mass");
@@ -1291,8 +1325,15 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     std::vector<int32_t> vrank(nv);
     const int32_t ncomp = admm_host::component_partition(nv, d->n_tets, d->tet_idx, d->n_tris, d->tri_idx, world, vrank.data());
     if (ncomp < world) {
-        if (force_co) return fail(ADMM_HIP_ERR_ARG, "ADMM_HIP_PARTITION=components: the scene has fewer connected components than ranks");
+        if (force_co) return fail(ADMM_HIP_ERR_ARG, "ADMM_HIP_PARTITION=components: the scene has fewer connected components (bodies with elements) than ranks");
         return create_impl(d, out);
+    }
+    if (!force_co) {     // one body that dominates the load (a large mesh + debris): whole bodies per rank would leave ranks idle -- element blocks then
+        std::vector<int64_t> load(world, 0);
+        for (int32_t t = 0; t < d->n_tets; ++t) load[vrank[d->tet_idx[4 * (size_t)t]]] += 1;
+        for (int32_t t = 0; t < d->n_tris; ++t) load[vrank[d->tri_idx[3 * (size_t)t]]] += 1;
+        const int64_t total = (int64_t)d->n_tets + d->n_tris, mx = *std::max_element(load.begin(), load.end());
+        if (mx * world > 2 * total) return create_impl(d, out);
     }
     // ---- the sub-scene of this rank, locally numbered ----
     std::vector<int32_t> l2g, g2l(nv, -1);
@@ -1539,9 +1580,24 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     c->constraint_w = (d->linsolver == 1) ? 3.0 * max_w : 1.0;
     if (d->constraint_w > 0.0) c->constraint_w = d->constraint_w;
     c->obst.n = d->n_obstacles;
+    c->obst.gmeta = nullptr; c->obst.gdata = nullptr;
     for (int j = 0; j < d->n_obstacles; ++j) {
         c->obst.kind[j] = d->obstacle_kind[j];
         for (int k = 0; k < 4; ++k) c->obst.par[j][k] = d->obstacle_params[4 * j + k];
+        if (d->obstacle_kind[j] == ADMM_OBJ_PLANE) {      // unit normal, offset scaled with it
+            const double il = 1.0 / std::sqrt(c->obst.par[j][0] * c->obst.par[j][0] + c->obst.par[j][1] * c->obst.par[j][1] + c->obst.par[j][2] * c->obst.par[j][2]);
+            for (int k = 0; k < 4; ++k) c->obst.par[j][k] *= il;
+        }
+    }
+    if (d->n_obstacle_grids > 0 && d->obstacle_grid_meta && d->obstacle_grid_data) {
+        size_t nodes = 0;
+        for (int g = 0; g < d->n_obstacle_grids; ++g) {
+            const double *m = d->obstacle_grid_meta + 10 * (size_t)g;
+            nodes = std::max(nodes, (size_t)m[9] + (size_t)m[6] * (size_t)m[7] * (size_t)m[8]);
+        }
+        HIP_TRY(c->obst_gmeta.upload(std::vector<double>(d->obstacle_grid_meta, d->obstacle_grid_meta + 10 * (size_t)d->n_obstacle_grids)));
+        HIP_TRY(c->obst_gdata.upload(std::vector<double>(d->obstacle_grid_data, d->obstacle_grid_data + 4 * nodes)));
+        c->obst.gmeta = c->obst_gmeta.p; c->obst.gdata = c->obst_gdata.p;
     }
 
     // ---- system matrix ----
@@ -1693,6 +1749,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 HIP_TRY(c->uzc_slot.upload(c->uzc_slot_h)); HIP_TRY(c->uzc_act.alloc(nv)); HIP_TRY(c->uzc_miss.alloc(nv));
                 HIP_TRY(c->uzc_info.alloc(2)); HIP_TRY(c->uzc_info.zero()); HIP_TRY(c->uzc_flag.alloc(nv));
                 HIP_TRY(c->uzc_pos.alloc(nv)); HIP_TRY(c->uz_y0.alloc(nv));
+                { const char *te = getenv("ADMM_HIP_TEST_UZ_COL_ITERS"); c->uzc_test_iters = te ? atoi(te) : 0; }
                 { const char *ce = getenv("ADMM_HIP_UZ_COMPACT"); c->uzc_compact = !(ce && ce[0] == '0'); }   // 0: full-height column pass in every Schur iteration (A/B)
                 { const char *e1 = getenv("ADMM_HIP_UZ_ONE_MAX"), *e2 = getenv("ADMM_HIP_UZ_COMPACT_MAX");      // test hooks
                   if (e1) c->uzc_one_max = std::max(0, std::min(1024, atoi(e1))); if (e2) c->uzc_compact_max = std::max(0, atoi(e2)); }
@@ -1727,12 +1784,17 @@ int admm_hip_set_state(admm_hip_ctx *c, const double *x, const double *v) {
 int admm_hip_get_state(admm_hip_ctx *c, double *x, double *v) {
     if (!c) return fail(ADMM_HIP_ERR_ARG, "get_state: NULL context");
     if (!c->cm.on) return get_state_impl(c, x, v);
-    std::vector<double> xl(x ? c->n3 : 0), vl(v ? c->n3 : 0);
-    if (int rc = get_state_impl(c, x ? xl.data() : nullptr, v ? vl.data() : nullptr)) return rc;
+    // With a communicator this call is a COLLECTIVE: every rank runs both merges (x, then v) whatever it asked for, so that ranks
+    // passing different NULL-ness cannot dead-lock each other.
+    const bool both = c->cm_comm != nullptr;
+    std::vector<double> xl((x || both) ? c->n3 : 0), vl((v || both) ? c->n3 : 0);
+    if (int rc = get_state_impl(c, (x || both) ? xl.data() : nullptr, (v || both) ? vl.data() : nullptr)) return rc;
     const size_t n3g = 3 * (size_t)c->cm.nv_global;
+    std::vector<double> sink;
     for (int pass = 0; pass < 2; ++pass) {
         double *dst = pass == 0 ? x : v;
         const std::vector<double> &src = pass == 0 ? xl : vl;
+        if (!dst && both) { sink.resize(n3g); dst = sink.data(); }
         if (!dst) continue;
         if (!c->cm_comm) {
             for (int i = 0; i < c->nv; ++i) for (int j = 0; j < 3; ++j) dst[3 * (size_t)c->cm.l2g[i] + j] = src[3 * (size_t)i + j];
@@ -2120,6 +2182,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         if (c->tol_last > 0.0 && s >= admm_iters - c->tol_last_n) c->pcg_tol = c->tol_last;
         const int grc = launch_global(c, c->b.p, c->curr.p);   // Solver.cpp:99
         c->pcg_tol = keep_tol;
+        if (grc == -2) return kStepAborted;       // a grid barrier timed out in a column solve of UzawaCG: same recovery as any aborted on-chip solve
         if (grc) return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     }
     c->timing = false;
@@ -2534,6 +2597,28 @@ int admm_hip_uzawa_cache_stats(admm_hip_ctx *c, int64_t *columns, int64_t *colum
     if (schur_from_columns) *schur_from_columns = c->uzc_applies;
     if (schur_by_pcg) *schur_by_pcg = c->uzc_pcg_solves;
     if (evicted) *evicted = c->uzc_evictions;
+    return ADMM_HIP_OK;
+}
+int admm_hip_uzawa_unconverged_columns(admm_hip_ctx *c, int64_t *n) {
+    if (!c || !n) return fail(ADMM_HIP_ERR_ARG, "uzawa_unconverged_columns: NULL argument");
+    *n = c->uzc_unconverged;
+    return ADMM_HIP_OK;
+}
+int admm_host_sample_obstacle(admm_obstacle_fn fn, void *user, const double *lo, const double *hi, const int32_t *dims, double *meta, double *data) {
+    if (!fn || !lo || !hi || !dims || !meta || !data) return fail(ADMM_HIP_ERR_ARG, "sample_obstacle: NULL argument");
+    for (int a = 0; a < 3; ++a) if (dims[a] < 2 || !(hi[a] > lo[a])) return fail(ADMM_HIP_ERR_ARG, "sample_obstacle: need hi > lo and at least two nodes per axis");
+    for (int a = 0; a < 3; ++a) { meta[a] = lo[a]; meta[3 + a] = (hi[a] - lo[a]) / (double)(dims[a] - 1); meta[6 + a] = (double)dims[a]; }
+    meta[9] = 0.0;
+    size_t node = 0;
+    for (int k = 0; k < dims[2]; ++k)
+        for (int j = 0; j < dims[1]; ++j)
+            for (int i = 0; i < dims[0]; ++i, ++node) {
+                const double x[3] = {lo[0] + meta[3] * i, lo[1] + meta[4] * j, lo[2] + meta[5] * k};
+                double out[7] = {0, 0, 0, 0, 0, 0, 0};
+                fn(user, x, out);
+                for (int q = 0; q < 7; ++q) if (!std::isfinite(out[q])) return fail(ADMM_HIP_ERR_ARG, "sample_obstacle: the object returned a non-finite value inside the box");
+                data[4 * node] = out[0]; data[4 * node + 1] = out[4]; data[4 * node + 2] = out[5]; data[4 * node + 3] = out[6];
+            }
     return ADMM_HIP_OK;
 }
 int admm_hip_tet_rest_mode(const admm_hip_ctx *c) { return c ? c->tet_rest_mode : -1; }

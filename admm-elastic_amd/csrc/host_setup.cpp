@@ -247,14 +247,16 @@ int32_t component_partition(int32_t nv, int32_t n_tets, const int32_t *tet_idx, 
     std::stable_sort(roots.begin(), roots.end(), [&](int32_t a, int32_t b) { return load_of_root[a] != load_of_root[b] ? load_of_root[a] > load_of_root[b] : a < b; });
     std::vector<int64_t> load(std::max(world, 1), 0);
     std::vector<int32_t> rank_of_root(nv, 0);
-    for (int32_t r : roots) {
+    int32_t bodies = 0;      // components that own at least one element: loose vertices (no tet, no triangle) are not bodies --
+    for (int32_t r : roots) {   // they go to the least loaded rank after the bodies (sorted last) and weigh nothing
         int best = 0;
         for (int k = 1; k < world; ++k) if (load[k] < load[best]) best = k;
         rank_of_root[r] = best;
-        load[best] += std::max<int64_t>(load_of_root[r], 1);      // (a loose vertex still counts as something)
+        load[best] += load_of_root[r];
+        bodies += load_of_root[r] > 0 ? 1 : 0;
     }
     for (int32_t v = 0; v < nv; ++v) vertex_rank[v] = rank_of_root[find(v)];
-    return (int32_t)roots.size();
+    return bodies;
 }
 
 // ---- tabulated user splines --------------------------------------------------------------------------------------------------

@@ -29,6 +29,8 @@ struct Obstacles {
     int n;
     int kind[kMaxObst];
     double par[kMaxObst][4];
+    const double *gmeta;      // sampled obstacles (kind 3): 10 doubles per grid -- origin xyz, spacing xyz, nodes nx ny nz, first node of its data
+    const double *gdata;      // ... and 4 doubles per node: signed distance, normal xyz (x fastest)
 };
 
 // scalars of one PCG solve, double-buffered by iteration parity
@@ -1080,22 +1082,66 @@ __global__ __launch_bounds__(256) void k_rc_record(int n3, const double *__restr
 
 // ---------------------------------------------------------------------------------------------------
 // GLOBAL STEP (ADMM_LS_NCMCGS): nodal multi-colour SOR, src/NodalMultiColorGS.hpp:60-146,180-262.
+// PassiveCollision::signed_distance of obstacle j at x (src/Collider.hpp:66-83): updates the payload (best, n, p) when its distance
+// is not above the current one, like every implementation in src/PassiveObject.hpp does.  Kinds: 0 Floor (:32-45), 1 Sphere (:48-64);
+// user-side PassiveCollision subclasses: 2 a plane n.x = d, 3 any object sampled on a grid at Solver::initialize
+// (admm_host_sample_obstacle: distance and normal per node, trilinear on the device, contact point = x - dx n; no hit outside the grid).
+__device__ __forceinline__ void obstacle_payload(const Obstacles &ob, int j, const double *x, double &best, double *n, double *p) {
+    const int kind = ob.kind[j];
+    if (kind == 0) {
+        const double dx = x[1] - ob.par[j][0];
+        if (!(dx > best)) { best = dx; p[0] = x[0]; p[1] = ob.par[j][0]; p[2] = x[2]; n[0] = 0.0; n[1] = 1.0; n[2] = 0.0; }
+    } else if (kind == 1) {
+        double d[3] = {x[0] - ob.par[j][0], x[1] - ob.par[j][1], x[2] - ob.par[j][2]};
+        const double l = sqrt(dot3(d, d)), dx = l - ob.par[j][3];
+        if (!(dx > best)) {
+            best = dx;
+            const double il = 1.0 / l;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { d[c] *= il; p[c] = ob.par[j][c] + d[c] * ob.par[j][3]; n[c] = d[c]; }
+        }
+    } else if (kind == 2) {
+        const double dx = fma(ob.par[j][2], x[2], fma(ob.par[j][1], x[1], ob.par[j][0] * x[0])) - ob.par[j][3];
+        if (!(dx > best)) {
+            best = dx;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { n[c] = ob.par[j][c]; p[c] = fma(-dx, ob.par[j][c], x[c]); }
+        }
+    } else {
+        const double *m = ob.gmeta + 10 * (int)ob.par[j][0];
+        double u[3]; int i0[3]; bool inside = true;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u[c] = (x[c] - m[c]) / m[3 + c];
+            inside = inside && u[c] >= 0.0 && u[c] <= m[6 + c] - 1.0;
+            i0[c] = min(max((int)floor(u[c]), 0), (int)m[6 + c] - 2);
+            u[c] -= (double)i0[c];
+        }
+        if (!inside) return;
+        const int nx = (int)m[6], ny = (int)m[7];
+        const double *g = ob.gdata + 4 * ((size_t)m[9] + (size_t)i0[0] + (size_t)nx * ((size_t)i0[1] + (size_t)ny * (size_t)i0[2]));
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int a = corner & 1, b = (corner >> 1) & 1, c2 = corner >> 2;
+            const double w = (a ? u[0] : 1.0 - u[0]) * (b ? u[1] : 1.0 - u[1]) * (c2 ? u[2] : 1.0 - u[2]);
+            const double *gc = g + 4 * ((size_t)a + (size_t)nx * ((size_t)b + (size_t)ny * (size_t)c2));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = fma(w, gc[k], q[k]);
+        }
+        const double dx = q[0];
+        if (!(dx > best)) {
+            best = dx;
+            const double il = 1.0 / sqrt(fma(q[3], q[3], fma(q[2], q[2], q[1] * q[1])));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { n[c] = q[1 + c] * il; p[c] = fma(-dx, n[c], x[c]); }
+        }
+    }
+}
 __device__ __forceinline__ bool passive_hit(const Obstacles &ob, const double *x, double *n, double *p) {
     double best = 1.7976931348623157e308; // Payload ctor (src/Collider.hpp:73)
     for (int j = 0; j < ob.n; ++j) {
-        if (ob.kind[j] == 0) { // Floor, src/PassiveObject.hpp:32-45
-            const double dx = x[1] - ob.par[j][0];
-            if (!(dx > best)) { best = dx; p[0] = x[0]; p[1] = ob.par[j][0]; p[2] = x[2]; n[0] = 0.0; n[1] = 1.0; n[2] = 0.0; }
-        } else {               // Sphere, src/PassiveObject.hpp:48-64
-            double d[3] = {x[0] - ob.par[j][0], x[1] - ob.par[j][1], x[2] - ob.par[j][2]};
-            const double l = sqrt(dot3(d, d)), dx = l - ob.par[j][3];
-            if (!(dx > best)) {
-                best = dx;
-                const double il = 1.0 / l;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { d[c] *= il; p[c] = ob.par[j][c] + d[c] * ob.par[j][3]; n[c] = d[c]; }
-            }
-        }
+        obstacle_payload(ob, j, x, best, n, p);
         if (best < 0.0) return true; // src/Collider.hpp:143-148: first object with dx < 0 wins
     }
     return false;
@@ -1526,21 +1572,7 @@ __global__ __launch_bounds__(256) void k_uz_detect(int nv, const double *__restr
     const double xv[3] = {x[3 * (size_t)v], x[3 * (size_t)v + 1], x[3 * (size_t)v + 2]};
     // Collider::detect: every object updates the payload when its distance is lower (no early exit)
     double best = 1.7976931348623157e308, n[3] = {0, 0, 0}, p[3] = {0, 0, 0};
-    for (int j = 0; j < ob.n; ++j) {
-        if (ob.kind[j] == 0) {
-            const double dx = xv[1] - ob.par[j][0];
-            if (!(dx > best)) { best = dx; p[0] = xv[0]; p[1] = ob.par[j][0]; p[2] = xv[2]; n[0] = 0.0; n[1] = 1.0; n[2] = 0.0; }
-        } else {
-            double d[3] = {xv[0] - ob.par[j][0], xv[1] - ob.par[j][1], xv[2] - ob.par[j][2]};
-            const double l = sqrt(dot3(d, d)), dx = l - ob.par[j][3];
-            if (!(dx > best)) {
-                best = dx;
-                const double il = 1.0 / l;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { d[c] *= il; p[c] = ob.par[j][c] + d[c] * ob.par[j][3]; n[c] = d[c]; }
-            }
-        }
-    }
+    for (int j = 0; j < ob.n; ++j) obstacle_payload(ob, j, xv, best, n, p);
     const bool hit = best < 0.0 && (mask == nullptr || mask[v]);
 #pragma unroll
     for (int c = 0; c < 3; ++c) cn[3 * (size_t)v + c] = hit ? ck * n[c] : 0.0;

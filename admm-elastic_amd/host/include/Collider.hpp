@@ -1,7 +1,7 @@
-// Collider.hpp -- collision interfaces (reference: src/Collider.hpp).  On the MI355X build passive objects
-// are evaluated inside the HIP kernels, so only the analytic obstacles (PassiveObject.hpp: Floor, Sphere)
-// and tet-mesh self-collision proxies (DynamicObject.hpp: TetMeshCollision) are accepted by Solver::initialize;
-// the interfaces are kept so scene code compiles unchanged.
+// Collider.hpp -- collision interfaces (reference: src/Collider.hpp).  On the MI355X build passive objects are evaluated inside
+// the HIP kernels: Floor, Sphere and Plane (PassiveObject.hpp) analytically, ANY OTHER PassiveCollision subclass from a grid that
+// Solver::initialize samples from the object's own signed_distance (Solver::obstacle_grid_*; include/admm_hip.h: ADMM_OBJ_GRID).
+// Dynamic colliders: tet-mesh self-collision proxies (DynamicObject.hpp: TetMeshCollision).
 #ifndef ADMM_COLLIDER_HPP
 #define ADMM_COLLIDER_HPP 1
 
@@ -38,7 +38,7 @@ public:
     };
     virtual ~PassiveCollision() {}
     virtual void signed_distance(const Vec3 &x, Payload &p) const = 0;
-    // GPU description: kind (ADMM_OBJ_*) + 4 parameters; false = no kernel for this obstacle type
+    // GPU description: kind (ADMM_OBJ_*) + 4 parameters; false = no analytic kernel: Solver::initialize samples the object on a grid
     virtual bool flatten(int &kind, double *params4) const { (void)kind; (void)params4; return false; }
 };
 

@@ -115,6 +115,18 @@ public:
     const std::vector<int> &colind() const { return col_; }
     const std::vector<double> &values() const { return val_; }
     void setCsr(int n, const std::vector<int> &rp, const std::vector<int> &ci, const std::vector<double> &va) { rows_ = cols_ = n; rowptr_ = rp; col_ = ci; val_ = va; }
+    SparseMat transpose() const {          // counting sort by column: rows of the result keep increasing column order
+        SparseMat t; t.rows_ = cols_; t.cols_ = rows_; t.rowptr_.assign(cols_ + 1, 0);
+        for (int c : col_) t.rowptr_[c + 1] += 1;
+        for (int i = 0; i < cols_; ++i) t.rowptr_[i + 1] += t.rowptr_[i];
+        t.col_.resize(col_.size()); t.val_.resize(val_.size());
+        std::vector<int> pos(t.rowptr_.begin(), t.rowptr_.end() - 1);
+        for (int i = 0; i < rows_; ++i)
+            for (int k = rowptr_[i]; k < rowptr_[i + 1]; ++k) { const int o = pos[col_[k]]++; t.col_[o] = i; t.val_[o] = val_[k]; }
+        return t;
+    }
+    void scaleColumns(const VecX &s, double f) { for (size_t k = 0; k < col_.size(); ++k) val_[k] *= f * s[col_[k]]; }   // this <- f * this * diag(s)
+    double coeff(int r, int c) const { for (int k = rowptr_[r]; k < rowptr_[r + 1]; ++k) if (col_[k] == c) return val_[k]; return 0.0; }
 private:
     int rows_, cols_;
     std::vector<int> rowptr_, col_;

@@ -32,5 +32,18 @@ public:
     bool flatten(int &kind, double *q) const { kind = 1; q[0] = center[0]; q[1] = center[1]; q[2] = center[2]; q[3] = rad; return true; }
 };
 
+// Not in the reference: a user-style PassiveCollision with a kernel of its own (ADMM_OBJ_PLANE) -- the half space n.x < d is solid.
+class Plane : public PassiveCollision {
+public:
+    Vec3 n; double d;
+    Plane(const Vec3 &normal, double offset) : n(normal * (1.0 / normal.norm())), d(offset / normal.norm()) {}
+    void signed_distance(const Vec3 &x, Payload &p) const {
+        const double dx = n.dot(x) - d;
+        if (dx > p.dx) return;
+        p.dx = dx; p.point = x - n * dx; p.normal = n;
+    }
+    bool flatten(int &kind, double *q) const { kind = 2; q[0] = n[0]; q[1] = n[1]; q[2] = n[2]; q[3] = d; return true; }
+};
+
 } // namespace admm
 #endif

@@ -76,6 +76,11 @@ public:
 
     // ---- additions of the GPU build ----
     int device;                                                   // HIP device ordinal used by initialize() (default 0)
+    // User-defined PassiveCollision subclasses are sampled at initialize() on obstacle_grid_nodes^3 nodes over the box
+    // [obstacle_grid_lo, obstacle_grid_hi]; an empty box (lo >= hi, the default) = the bounding box of m_x grown by half its diagonal.
+    int obstacle_grid_nodes; Vec3 obstacle_grid_lo, obstacle_grid_hi;
+    bool build_global_matrices;                                   // initialize() fills m_D / m_Dt / m_W_diag / solver_Dt_Wt_W (default true, like
+                                                                  // the reference; the GPU path itself never reads them -- switch off for very large scenes)
     std::shared_ptr<LinearSolver> linear_solver() { return m_linsolver; }
 
 protected:
@@ -84,7 +89,13 @@ protected:
     bool initialized;
     Settings m_settings;
     RuntimeData m_runtime;
-    SparseMat solver_termA;                                       // Ahat: A = diag(m) + Ahat (x) I3
+    // Global matrices of src/Solver.hpp:115-121, for subclasses that read them (the reference's own step() is their only other user;
+    // here the device holds its own copies in kernel layouts): reduction matrix D (rows x dof) and its transpose, the weights W,
+    // dt^2 D^T W^T W (dof x rows).
+    SparseMat m_D, m_Dt;
+    VecX m_W_diag;
+    SparseMat solver_Dt_Wt_W;
+    SparseMat solver_termA;                                       // Ahat (n_verts x n_verts): the reference's solver_termA = diag(m) + Ahat (x) I3
     std::shared_ptr<ConstraintSet> m_constraints;
     std::shared_ptr<LinearSolver> m_linsolver;
     std::unordered_map<int, std::shared_ptr<SpringPin> > m_pin_energies;

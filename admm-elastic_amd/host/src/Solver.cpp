@@ -287,7 +287,7 @@ int LinearSolver::solve(VecX &x, const VecX &b) {
 }
 
 // ---------------------------------------------------------------- Solver ----------------------------
-Solver::Solver() : device(0), m_ctx(nullptr), initialized(false), m_constraints(std::make_shared<ConstraintSet>()) {}
+Solver::Solver() : device(0), obstacle_grid_nodes(64), obstacle_grid_lo(0, 0, 0), obstacle_grid_hi(0, 0, 0), build_global_matrices(true), m_ctx(nullptr), initialized(false), m_constraints(std::make_shared<ConstraintSet>()) {}
 Solver::~Solver() { release(); }
 void Solver::release() { if (m_ctx) { admm_hip_destroy((admm_hip_ctx *)m_ctx); m_ctx = nullptr; } }
 
@@ -355,6 +355,18 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
                                      "(the MI355X hot path has no CPU fallback)");
         flat.add(ft);
     }
+    if (build_global_matrices) {      // src/Solver.cpp:204-226: D from the triplets, W, dt^2 D^T W^T W
+        const int n_row = (int)weights.size();
+        m_W_diag.resize(n_row);
+        for (int i = 0; i < n_row; ++i) m_W_diag[i] = weights[i];
+        m_D.resize(n_row, dof);
+        m_D.setFromTriplets(triplets.begin(), triplets.end());
+        m_Dt = m_D.transpose();
+        VecX w2(n_row);
+        for (int i = 0; i < n_row; ++i) w2[i] = weights[i] * weights[i];
+        solver_Dt_Wt_W = m_Dt;
+        solver_Dt_Wt_W.scaleColumns(w2, m_settings.timestep_s * m_settings.timestep_s);
+    }
     switch (m_settings.linsolver) {
         default: if (!std::dynamic_pointer_cast<LDLTSolver>(m_linsolver)) m_linsolver = std::make_shared<LDLTSolver>(); break;
         case 1: if (!std::dynamic_pointer_cast<NodalMultiColorGS>(m_linsolver)) m_linsolver = std::make_shared<NodalMultiColorGS>(m_constraints); break;
@@ -387,13 +399,37 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
     if (auto s0 = std::dynamic_pointer_cast<LDLTSolver>(m_linsolver)) { d.pcg_max_iters = s0->pcg_max_iters; d.pcg_tol = s0->pcg_tol; }
     if (auto s1 = std::dynamic_pointer_cast<NodalMultiColorGS>(m_linsolver)) { d.gs_max_iters = s1->max_iters; d.gs_tol = s1->m_tol; d.gs_omega = s1->m_omega; }
     if (auto s2 = std::dynamic_pointer_cast<UzawaCG>(m_linsolver)) { d.uzawa_max_iters = s2->max_iters; d.uzawa_tol = s2->m_tol; d.pcg_max_iters = s2->pcg_max_iters; d.pcg_tol = s2->pcg_tol; }
-    std::vector<int32_t> okind; std::vector<double> opar;
+    std::vector<int32_t> okind; std::vector<double> opar, gmeta, gdata;
     for (auto &obj : m_constraints->collider->passive_objs) {
         int k; double q[4];
-        if (!obj->flatten(k, q)) throw std::runtime_error("Solver::initialize: only Floor and Sphere obstacles have GPU kernels");
+        if (!obj->flatten(k, q)) {
+            // a user-defined PassiveCollision (src/Collider.hpp:66-83): sampled from its own signed_distance, interpolated on the device
+            Vec3 lo = obstacle_grid_lo, hi = obstacle_grid_hi;
+            if (!(hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2])) {
+                lo = hi = Vec3(m_x.segment<3>(0));
+                for (int v = 0; v < dof / 3; ++v) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], m_x[3 * v + a]); hi[a] = std::max(hi[a], m_x[3 * v + a]); }
+                const double grow = 0.5 * (hi - lo).norm() + 1e-9;
+                for (int a = 0; a < 3; ++a) { lo[a] -= grow; hi[a] += grow; }
+            }
+            const int32_t dims[3] = {obstacle_grid_nodes, obstacle_grid_nodes, obstacle_grid_nodes};
+            const size_t nodes = (size_t)dims[0] * dims[1] * dims[2], first = gdata.size() / 4;
+            double meta[10];
+            gdata.resize(gdata.size() + 4 * nodes);
+            PassiveCollision *raw = obj.get();
+            auto eval = [](void *user, const double *x, double *out) {
+                PassiveCollision::Payload p(0);
+                static_cast<PassiveCollision *>(user)->signed_distance(Vec3(x[0], x[1], x[2]), p);
+                out[0] = p.dx; for (int a = 0; a < 3; ++a) { out[1 + a] = p.point[a]; out[4 + a] = p.normal[a]; }
+            };
+            check(admm_host_sample_obstacle(eval, raw, lo.data(), hi.data(), dims, meta, gdata.data() + 4 * first), "Solver::initialize (sampling a user-defined obstacle)");
+            meta[9] = (double)first;
+            k = 3; q[0] = (double)(gmeta.size() / 10); q[1] = q[2] = q[3] = 0.0;
+            gmeta.insert(gmeta.end(), meta, meta + 10);
+        }
         okind.push_back(k); for (int i = 0; i < 4; ++i) opar.push_back(q[i]);
     }
     d.n_obstacles = (int32_t)okind.size(); d.obstacle_kind = okind.data(); d.obstacle_params = opar.data();
+    d.n_obstacle_grids = (int32_t)(gmeta.size() / 10); d.obstacle_grid_meta = gmeta.data(); d.obstacle_grid_data = gdata.data();
 
     admm_hip_ctx *ctx = nullptr;
     check(admm_hip_create(&d, &ctx), "Solver::initialize");
@@ -440,29 +476,37 @@ void Solver::save_matrix(const std::string &filename) { // src/Solver.cpp:264-26
             out << i << " " << solver_termA.colind()[k] << " " << solver_termA.values()[k] << "\n";
 }
 
-bool Solver::Settings::parse_args(int argc, char **argv) { // src/Solver.cpp:273-294
-    for (int i = 1; i < argc - 1; ++i) {
-        std::string arg(argv[i]);
-        std::stringstream val(argv[i + 1]);
-        if (arg == "-help" || arg == "--help" || arg == "-h") { help(); return true; }
-        else if (arg == "-dt") val >> timestep_s;
-        else if (arg == "-v") val >> verbose;
-        else if (arg == "-it") val >> admm_iters;
-        else if (arg == "-g") val >> gravity;
-        else if (arg == "-ls") val >> linsolver;
-        else if (arg == "-ck") val >> constraint_w;
-    }
-    if (argc > 0) {
-        std::string arg(argv[argc - 1]);
-        if (arg == "-help" || arg == "--help" || arg == "-h") { help(); return true; }
+// The command-line switches of the reference's samples (src/Solver.cpp:273-307), as one table: switch, the field it sets, help text.
+namespace {
+struct Switch { const char *flag; double Solver::Settings::*dfield; int Solver::Settings::*ifield; const char *text; };
+const Switch kSwitches[] = {
+    {"-dt", &Solver::Settings::timestep_s, nullptr, "time step (s)"},
+    {"-v", nullptr, &Solver::Settings::verbose, "verbosity (higher -> show more)"},
+    {"-it", nullptr, &Solver::Settings::admm_iters, "# admm iters"},
+    {"-g", &Solver::Settings::gravity, nullptr, "gravity (m/s^2)"},
+    {"-ls", nullptr, &Solver::Settings::linsolver, "linear solver (0=LDLT as GPU PCG, 1=NCMCGS, 2=UzawaCG) "},
+    {"-ck", &Solver::Settings::constraint_w, nullptr, "constraint weights (-1 = auto) "},
+};
+bool wants_help(const char *a) { const std::string s(a); return s == "-help" || s == "--help" || s == "-h"; }
+} // namespace
+
+bool Solver::Settings::parse_args(int argc, char **argv) {
+    for (int i = 1; i < argc; ++i) {
+        if (wants_help(argv[i])) { help(); return true; }
+        if (i + 1 >= argc) break;                     // a switch needs a value behind it
+        for (const Switch &sw : kSwitches) {
+            if (std::string(argv[i]) != sw.flag) continue;
+            std::stringstream val(argv[i + 1]);
+            if (sw.dfield) val >> this->*sw.dfield; else val >> this->*sw.ifield;
+        }
     }
     return false;
 }
 
 void Solver::Settings::help() {
-    printf("\n==========================================\nArgs:\n\t-dt: time step (s)\n\t-v: verbosity (higher -> show more)\n"
-           "\t-it: # admm iters\n\t-g: gravity (m/s^2)\n\t-ls: linear solver (0=LDLT as GPU PCG, 1=NCMCGS, 2=UzawaCG) \n"
-           "\t-ck: constraint weights (-1 = auto) \n==========================================\n");
+    printf("\n==========================================\nArgs:\n");
+    for (const Switch &sw : kSwitches) printf("\t%s: %s\n", sw.flag, sw.text);
+    printf("==========================================\n");
 }
 
 void Solver::RuntimeData::print(const Solver::Settings &settings) { // src/Solver.cpp:309-319

@@ -99,6 +99,45 @@ class Sphere:
         self.kind, self.params = 1, [float(center[0]), float(center[1]), float(center[2]), float(radius)]
 
 
+class Plane:
+    """A user-side PassiveCollision (src/Collider.hpp:66-83): the half space n.x < d is solid.  signed distance n.x - d (n normalised),
+    contact point x - dx n.  Floor(y) is Plane((0, 1, 0), y)."""
+
+    def __init__(self, normal, d):
+        n = f64(normal).ravel()
+        l = float(np.linalg.norm(n))
+        if not l > 0.0:
+            raise AdmmHipError(-1, "Plane: zero normal")
+        self.kind, self.params = 2, [float(n[0]), float(n[1]), float(n[2]), float(d)]
+
+
+class SampledObstacle:
+    """ANY user-defined PassiveCollision on the device: `obj.signed_distance(x) -> (dx, point[3], normal[3])` (the payload a fresh
+    Payload would hold after src/Collider.hpp:80-82) is sampled on a dims[0] x dims[1] x dims[2] grid over the box [lo, hi] at
+    Solver::initialize (admm_host_sample_obstacle); the kernels interpolate distance and normal trilinearly.  Outside the box the
+    object is never hit: make the box cover the region the scene can reach."""
+
+    def __init__(self, obj, lo, hi, dims=(64, 64, 64)):
+        self.kind, self.obj = 3, obj
+        self.lo, self.hi = f64(lo).ravel().copy(), f64(hi).ravel().copy()
+        self.dims = i32(dims).ravel().copy()
+        self.params = [0.0, 0.0, 0.0, 0.0]     # params[0] = index of its grid, set by make_desc
+
+    def sample(self):
+        n = int(self.dims[0]) * int(self.dims[1]) * int(self.dims[2])
+        meta = np.zeros(10); data = np.zeros(4 * n)
+        obj = self.obj
+
+        def cb(user, px, pout):
+            dx, point, normal = obj.signed_distance(np.array([px[0], px[1], px[2]]))
+            pout[0] = float(dx)
+            for a in range(3):
+                pout[1 + a] = float(point[a]); pout[4 + a] = float(normal[a])
+        fn = capi.OBSTACLE_FN(cb)
+        check(lib().admm_host_sample_obstacle(fn, None, dptr(self.lo), dptr(self.hi), iptr(self.dims), dptr(meta), dptr(data)))
+        return meta, data
+
+
 class TetMeshCollision:
     """admm::TetMeshCollision (src/DynamicObject.hpp:31-121): self-collision proxy of one tet mesh.  verts = REST
     vertices of the mesh, tets / faces index them (faces = surface triangles; meshes.surface_faces), v_offset = index
@@ -297,6 +336,15 @@ class Solver:
         d.pcg_max_iters, d.pcg_tol = s.pcg_max_iters, s.pcg_tol
         d.gs_max_iters, d.gs_tol, d.gs_omega = s.gs_max_iters, s.gs_tol, s.gs_omega
         d.uzawa_max_iters, d.uzawa_tol = s.uzawa_max_iters, s.uzawa_tol
+        metas, datas, nodes = [], [], 0
+        for o in self._obstacles:          # user-defined obstacles: sampled now, like Solver::initialize would first call them
+            if o.kind == 3:
+                meta, data = o.sample()
+                meta[9] = nodes; o.params = [float(len(metas)), 0.0, 0.0, 0.0]
+                metas.append(meta); datas.append(data); nodes += data.size // 4
+        if metas:
+            self._grid_meta = np.concatenate(metas); self._grid_data = np.concatenate(datas)
+            d.n_obstacle_grids = len(metas); d.obstacle_grid_meta = dptr(self._grid_meta); d.obstacle_grid_data = dptr(self._grid_data)
         self._obst_kind = i32([o.kind for o in self._obstacles])
         self._obst_par = f64([o.params for o in self._obstacles]).reshape(-1, 4) if self._obstacles else np.zeros((0, 4))
         d.n_obstacles = len(self._obstacles)
@@ -458,7 +506,11 @@ class Solver:
         self._need_ctx()
         a = [C.c_int64(0) for _ in range(5)]
         check(lib().admm_hip_uzawa_cache_stats(self._ctx, *[C.byref(x) for x in a]))
-        return dict(zip(("columns", "column_solves", "schur_from_columns", "schur_by_pcg", "evicted"), (x.value for x in a)))
+        d = dict(zip(("columns", "column_solves", "schur_from_columns", "schur_by_pcg", "evicted"), (x.value for x in a)))
+        u = C.c_int64(0)
+        check(lib().admm_hip_uzawa_unconverged_columns(self._ctx, C.byref(u)))
+        d["unconverged_columns"] = u.value
+        return d
 
     def tet_rest_mode(self):
         """admm_hip_tet_rest_mode: 0 = the local step streams Binv, 1 / 2 = it recomputes Binv from gathered rest positions."""

@@ -57,8 +57,14 @@ enum { ADMM_TET_LINEAR = 0, ADMM_TET_NEOHOOKEAN = 1, ADMM_TET_STVK = 2, ADMM_TET
  *    complement CG (src/UzawaCG.hpp) whose inner LDLT solves are the same GPU PCG. */
 enum { ADMM_LS_LDLT_AS_PCG = 0, ADMM_LS_NCMCGS = 1, ADMM_LS_UZAWACG = 2 };
 
-/* passive obstacles -- src/PassiveObject.hpp:32-45 (Floor: params[0]=y), :48-64 (Sphere: cx,cy,cz,r) */
-enum { ADMM_OBJ_FLOOR = 0, ADMM_OBJ_SPHERE = 1 };
+/* passive obstacles -- src/PassiveObject.hpp:32-45 (Floor: params[0]=y), :48-64 (Sphere: cx,cy,cz,r).
+ * User-defined PassiveCollision subclasses (src/Collider.hpp:66-83 is an interface of one virtual function) reach the kernels in two
+ * forms: ADMM_OBJ_PLANE, the half space n.x < d (params nx, ny, nz, d; n is normalised by the library; signed distance n.x - d, contact
+ * point x - dx n), and ADMM_OBJ_GRID, ANY object sampled at Solver::initialize (params[0] = index of its grid in
+ * desc.obstacle_grid_meta; admm_host_sample_obstacle fills the grid from the object's own signed_distance): the kernels interpolate
+ * distance and normal trilinearly and take the contact point as x - dx n (exact for a true signed distance function, O(h^2)
+ * otherwise); outside its grid an object is never hit. */
+enum { ADMM_OBJ_FLOOR = 0, ADMM_OBJ_SPHERE = 1, ADMM_OBJ_PLANE = 2, ADMM_OBJ_GRID = 3 };
 
 typedef struct admm_hip_ctx admm_hip_ctx;
 
@@ -141,6 +147,13 @@ typedef struct {
     int32_t n_spline_tables;
     const double *spline_tables;
     const int32_t *tet_spline;
+
+    /* Sampled obstacles (ADMM_OBJ_GRID): obstacle_grid_meta [10 * n_obstacle_grids] = origin xyz, spacing xyz, nodes nx ny nz
+     * (each >= 2), index of the grid's first node in obstacle_grid_data; obstacle_grid_data [4 per node, x fastest] = signed
+     * distance, normal xyz.  Both made by admm_host_sample_obstacle. */
+    int32_t n_obstacle_grids;
+    const double *obstacle_grid_meta;
+    const double *obstacle_grid_data;
 } admm_hip_desc;
 
 /* Maps 1:1 onto Solver::RuntimeData (src/Solver.hpp:54-61) plus GPU-side extras. */
@@ -254,7 +267,9 @@ int admm_hip_probe_sync(admm_hip_ctx *ctx, int32_t n, double *us_all_to_all, dou
 int admm_hip_time_local_launches(admm_hip_ctx *ctx, int32_t on);
 int admm_hip_local_launch_times(admm_hip_ctx *ctx, int64_t *n_pairs, double *sum_ms);
 
-/* Sizes: R = rows of D (9*n_tets + 6*n_tris + 6*n_pin_terms). */
+/* Sizes: R = rows of D (9*n_tets + 6*n_tris + 6*n_pin_terms).  A context of the component partition (whole bodies per rank) holds
+ * only its rank's bodies: it returns the rows of THOSE (the kernel-level entry points that use this layout refuse such a context);
+ * step statistics are per rank as well. */
 int admm_hip_num_rows(const admm_hip_ctx *ctx);
 
 /* The assembled scalar system matrix Ahat (A = M + Ahat (x) I3, src/Solver.cpp:225-226 with the
@@ -294,7 +309,9 @@ void admm_host_spline_table_eval(const double *table, int which, double x, doubl
  * world_size connected components (bodies that share no vertex), admm_hip_create gives every rank WHOLE bodies: its context
  * holds only them, renumbered locally, and steps them like a single-GPU scene -- no exchange inside a step, the global solve
  * is the rank's block of the block-diagonal system matrix.  The caller keeps the global numbering (set_state / get_state /
- * set_pins translate; admm_hip_get_state merges the ranks' parts over RCCL when admm_hip_comm_init was called).  Components go
+ * set_pins translate; admm_hip_get_state merges the ranks' parts over RCCL when admm_hip_comm_init was called -- it is then a
+ * COLLECTIVE call: every rank must make it, each runs both merges whatever pointers it passes).  Loose vertices (no element) are not
+ * bodies; a scene whose largest body holds more than twice a rank's fair share of the elements uses element blocks instead.  Components go
  * to ranks by decreasing element count, each to the least loaded rank so far.  Otherwise (a single body, or
  * ADMM_HIP_PARTITION=elements) the element-block partition above is used.  This host-only function returns the number of
  * components and, in vertex_rank [n_verts], the rank that would own every vertex. */
@@ -326,6 +343,18 @@ int admm_host_tet_rest_positions(int32_t n_verts, int32_t n_tets, const int32_t 
  * columns given up because the cache was full (it then drops the columns of every vertex that is not active in the current solve). */
 int admm_hip_uzawa_cache_stats(admm_hip_ctx *ctx, int64_t *columns, int64_t *column_solves, int64_t *schur_from_columns,
                                int64_t *schur_by_pcg, int64_t *evicted);
+/* Column solves that did NOT meet their tolerance within max(pcg_max_iters, 2000) iterations since create: their batch is not cached
+ * (an inexact column would be a wrong Schur operator for every later solve), the solve that asked for them applies A^-1 by inner PCG
+ * solves instead.  0 in every healthy run. */
+int admm_hip_uzawa_unconverged_columns(admm_hip_ctx *ctx, int64_t *n);
+/* A user-defined PassiveCollision on the device (src/Collider.hpp:66-83; the reference calls signed_distance per vertex inside
+ * Collider::detect_passive, :137-150).  fn(user, x, out7) evaluates the object at x on a FRESH payload: out7 = signed distance, contact
+ * point xyz, normal xyz.  Sampled at the nx x ny x nz nodes of the box [lo, hi] (each n >= 2) into meta10_out (node offset 0: the
+ * caller adds the offset of the grid inside its obstacle_grid_data) and data_out [4 * nx * ny * nz].  Returns ADMM_HIP_ERR_ARG for a bad
+ * box or a non-finite sample. */
+typedef void (*admm_obstacle_fn)(void *user, const double *x3, double *out7);
+int admm_host_sample_obstacle(admm_obstacle_fn fn, void *user, const double *lo3, const double *hi3, const int32_t *dims3, double *meta10_out,
+                              double *data_out);
 /* which of the above this context's local step uses: 0 streamed Binv, 1 / 2 rest positions; -1 NULL context */
 int admm_hip_tet_rest_mode(const admm_hip_ctx *ctx);
 /* TriEnergyTerm ctor (src/TriEnergyTerm.cpp:29-52): rest [4*n], area [n]. */

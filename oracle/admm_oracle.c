@@ -628,7 +628,7 @@ void orc_csr_matvec(int n, const int32_t *rp, const int32_t *ci, const double *v
  * src/NodalMultiColorGS.hpp:60-146,180-262 -- multi-colour nodal SOR on A = Ahat (x) I3.
  * Ahat in CSR (nv x nv).  colours: concatenated node lists, cptr[ncolors+1].
  * pin_flag[v] != 0 -> x_v = pin_xyz[v] (:111-117).  Passive objects: array of (kind, 4 params):
- * kind 0 = Floor(y0) (PassiveObject.hpp:32-45), kind 1 = Sphere(cx,cy,cz,r) (:48-64); first object
+ * kind 0 = Floor(y0) (PassiveObject.hpp:32-45), kind 1 = Sphere(cx,cy,cz,r) (:48-64), kind 2 = a user-side plane (unit n, d); first object
  * with dx<0 wins (Collider.hpp:137-150).  Returns the sweep count like the reference (iter at break).
  */
 static int passive_hit(int nobj, const int32_t *okind, const double *opar, const double *x, double *n, double *p) {
@@ -638,6 +638,9 @@ static int passive_hit(int nobj, const int32_t *okind, const double *opar, const
         if (okind[j] == 0) {
             double dx = x[1] - q[0];
             if (!(dx > best)) { best = dx; p[0] = x[0]; p[1] = q[0]; p[2] = x[2]; n[0] = 0; n[1] = 1; n[2] = 0; }
+        } else if (okind[j] == 2) { /* a user-side PassiveCollision (Collider.hpp:66-83): the half space n.x < d, q = unit n, d */
+            double dx = q[0] * x[0] + q[1] * x[1] + q[2] * x[2] - q[3];
+            if (!(dx > best)) { best = dx; for (int c = 0; c < 3; ++c) { n[c] = q[c]; p[c] = x[c] - dx * q[c]; } }
         } else {
             double dir[3] = {x[0] - q[0], x[1] - q[1], x[2] - q[2]};
             double l = norm3(dir), dx = l - q[3];

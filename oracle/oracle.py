@@ -392,6 +392,12 @@ class OracleSolver:
                 upd = ~(dx > best)
                 p = X.copy(); p[:, 1] = par[0]
                 n = np.zeros_like(X); n[:, 1] = 1.0
+            elif kind == 2:  # a user-side PassiveCollision: the half space n.x < d (unit n)
+                nn = np.asarray(par[:3], dtype=np.float64)
+                dx = X @ nn - par[3]
+                upd = ~(dx > best)
+                n = np.tile(nn, (len(X), 1))
+                p = X - dx[:, None] * nn
             else:           # Sphere, PassiveObject.hpp:55-62
                 d = X - np.asarray(par[:3])
                 l = np.linalg.norm(d, axis=1)

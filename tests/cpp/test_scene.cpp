@@ -3,6 +3,7 @@
 // (samples/utils/AddMeshes.hpp:97-177, samples/tvcg2017/boxes.cpp).  Prints the final positions; the
 // pytest wrapper compares them with the Python binding driving the same C ABI.
 //   usage: test_scene <linsolver 0|1|2> <frames>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -10,6 +11,26 @@
 #include "TetEnergyTerm.hpp"
 
 using namespace admm;
+
+// A subclass that reads the protected global matrices of src/Solver.hpp:115-121 the way user code of the reference may:
+// dt^2 D^T W^T W D must be the assembled system matrix (solver_termA = Ahat, one scalar block for the three axes).
+struct ProbeSolver : public Solver {
+    bool matrices_consistent() const {
+        const int dof = (int)m_x.size(), n_row = (int)m_W_diag.size();
+        if (m_D.rows() != n_row || m_D.cols() != dof || m_Dt.rows() != dof || solver_Dt_Wt_W.rows() != dof || solver_Dt_Wt_W.cols() != n_row) return false;
+        VecX v(dof);
+        for (int i = 0; i < dof; ++i) v[i] = std::sin(0.37 * i) + 0.1 * (i % 7);
+        const VecX lhs = solver_Dt_Wt_W * (m_D * v);
+        double worst = 0.0, scale = 0.0;
+        for (int i = 0; i < dof / 3; ++i)
+            for (int a = 0; a < 3; ++a) {
+                double r = 0.0;
+                for (int k = solver_termA.rowptr()[i]; k < solver_termA.rowptr()[i + 1]; ++k) r += solver_termA.values()[k] * v[3 * solver_termA.colind()[k] + a];
+                worst = std::max(worst, std::fabs(r - lhs[3 * i + a])); scale = std::max(scale, std::fabs(r));
+            }
+        return n_row > 0 && worst <= 1e-10 * scale;
+    }
+};
 
 int main(int argc, char **argv) {
     const int ls = argc > 1 ? atoi(argv[1]) : 0, frames = argc > 2 ? atoi(argv[2]) : 3;
@@ -36,7 +57,7 @@ int main(int argc, char **argv) {
     const double cell = 0.5 / n, vol = cell * cell * cell / 6.0;
     for (int t = 0; t < nt; ++t) for (int s = 0; s < 4; ++s) for (int a = 0; a < 3; ++a) m[3 * tets[4 * t + s] + a] += 1522.0 * vol / 4.0;
 
-    Solver solver;
+    ProbeSolver solver;
     solver.add_nodes(verts.data(), m.data(), nv);
     create_tets_from_mesh<double, NeoHookeanTet>(solver.energyterms, verts.data(), tets.data(), nt, Lame::soft_rubber(), 0);
     Solver::Settings st;
@@ -49,6 +70,7 @@ int main(int argc, char **argv) {
         solver.add_obstacle(std::make_shared<Floor>(0.0));
     }
     if (!solver.initialize(st)) return 2;
+    if (!solver.matrices_consistent()) { fprintf(stderr, "m_D / m_W_diag / solver_Dt_Wt_W do not reproduce solver_termA\n"); return 3; }
     for (int f = 0; f < frames; ++f) {
         if (ls == 0) {
             pts.clear();

@@ -86,26 +86,33 @@ def test_cube100k_gs_full_size_vs_oracle():
     s.close()
 
 
-def test_cloth200k_gs_floor_full_size_vs_oracle():
+@pytest.mark.parametrize("floor", [0.3, 0.47])
+def test_cloth200k_gs_floor_full_size_vs_oracle(floor):
     """configs[4] at its benchmarked size: 199 712 strain-limited triangles, two pins, Floor handled inside the GS sweeps (three
-    colours: k_gs_colorN on a multi-block grid), until the cloth has come to lie on the floor."""
+    colours, 256 blocks of the persistent kernel).  floor 0.3 = the bench scene: the cloth swings on its two pins and only comes down
+    on the floor in frame 29 (oracle), after the driver's timed frames; floor 0.47 = the same scene with the floor raised into the
+    cloth's first dip (frames 2-4: without it the lowest vertex passes 0.449, 0.398, 0.330): the plane projection inside the sweeps is
+    active there and no vertex ever ends a frame below the floor."""
+    import bench
     sc, nt, nv = _bench_scene("cloth200k_gs_floor")
     assert nt == 199712
+    sc.obstacles[:] = [(0, [floor, 0.0, 0.0, 0.0])]
     s = sc.make_solver()
     colors, nc = s.gs_colors()
     o = sc.make_oracle(mode=1, gs_colors=colors, big=True)
-    worst = 0.0
+    errs, on_floor = [], []
+    free = np.ones(nv, bool); free[list(sc.pins)] = False
     for f in range(8):
         s.step(); o.step()
-        err = scenes.rel_err(s.m_x, o.x)
-        worst = max(worst, err)
-        assert err < 1e-6, (f, err)
+        errs.append(scenes.rel_err(s.m_x, o.x))
         assert s.runtime_data().inner_iters == o.inner_iters
-    y = s.m_x.reshape(-1, 3)[:, 1]
-    free = np.ones(len(y), bool); free[list(sc.pins)] = False
-    assert abs(y[free].min() - 0.3) < 1e-12        # rests exactly on the floor (plane projection inside the sweeps)
-    assert (y[free] < 0.3 + 1e-9).sum() > 1000     # and a good part of it does
-    print("cloth200k worst rel_err %.2e" % worst)
+        y = s.m_x.reshape(-1, 3)[free, 1]
+        assert y.min() >= floor - 1e-12                  # never below the floor: the plane projection is exact
+        on_floor.append(float(y.min() - floor))
+    print("cloth200k floor %.2f rel_err per frame:" % floor, " ".join("%.1e" % e for e in errs), " lowest vertex above the floor:", " ".join("%.1e" % g for g in on_floor))
+    assert max(errs) < 1e-6, errs
+    if floor > 0.4:
+        assert min(on_floor) < 2e-2                      # it was stopped by the floor (and swings up again on its two pins)
     s.close()
 
 

@@ -213,6 +213,12 @@ def test_component_partition_assigns_whole_bodies():
     # largest body first to rank 0, the next to rank 1, ...
     n, vr = s.component_partition(2, sc.product_settings)
     assert vr[body == 1][0] == 0 and vr[body == 3][0] == 1
+    # loose vertices (no element) are not bodies: one body + 7 loose vertices is ONE component, whatever the world size
+    loose = scenes.cube_scene(3, pkg.TET_LINEAR, linsolver=0)
+    ls = loose.make_solver(init=False)
+    ls.add_nodes(np.arange(21.0).reshape(7, 3) + 5.0, np.ones(21))
+    n, vr = ls.component_partition(4, loose.product_settings)
+    assert n == 1 and len(vr) == len(loose.x) + 7 and len(set(vr[:len(loose.x)])) == 1
     one = scenes.mixed_cube_scene(4, linsolver=0).make_solver(init=False)
     n, vr = one.component_partition(4, scenes.mixed_cube_scene(4, linsolver=0).make_solver(init=False)._settings)
     assert n == 1 and (vr == 0).all()
@@ -349,23 +355,35 @@ def test_barrier_timeout_under_a_communicator_is_a_clean_comm_error(monkeypatch)
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_share_one_gpu_functional():
-    """`python bench.py --gpus 2` end to end on a one-GPU box (ADMM_BENCH_SHARE_GPU=1: both ranks on device 0, gloo): the weak-scaling
-    default workload (one body per rank), the component-aware partition, the barrier + max-over-ranks timing and the JSON line.
-    A functional check of the N-rank code path -- the two ranks time-share the device, the number means nothing."""
+@pytest.mark.parametrize("series", ["strong", "weak"])
+def test_bench_two_ranks_share_one_gpu_functional(series):
+    """`python bench.py --gpus 2` end to end on a one-GPU box (ADMM_BENCH_SHARE_GPU=1: both ranks on device 0, gloo, the partial
+    right-hand sides summed through admm_hip_set_rhs_allreduce because RCCL refuses two ranks on one device).  strong = the DEFAULT
+    line: BASELINE configs[3], ONE body at fixed tet count, element-block partition, one all-reduce per ADMM iteration, the weak
+    series riding along as `weak_value`; weak = `--workload blobs_1m_per_gpu`, one body per rank, component partition.  A functional
+    check of the N-rank code paths -- the two ranks time-share the device, the numbers mean nothing."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ADMM_BENCH_SHARE_GPU="1", ADMM_BENCH_N="30")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=900, env=env)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    if series == "weak":
+        cmd += ["--workload", "blobs_1m_per_gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["workload"].startswith("blobs_1m_per_gpu")
+    assert d["n_gpus"] == 2 and d["scaling"] == series
     assert d["unconverged_solves_in_timed_region"] == 0 and d["finite"] and d["value"] > 0
-    assert "whole bodies per rank x2" in d["config"]["parallelism"] and d["expected_speedup"]["vs_one_gpu"] == 2.0
+    if series == "strong":
+        assert d["config"]["workload"].startswith("blob1m_mix")
+        assert "element-block x2" in d["config"]["parallelism"]
+        assert d["weak_value"] > 0 and d["weak"]["expected_vs_one_gpu"] == 2.0
+        assert 0.5 < d["expected_speedup"]["vs_one_gpu"] < 2.0 and "single_gpu_ms_per_admm_iter" in d["expected_speedup"]
+    else:
+        assert d["config"]["workload"].startswith("blobs_1m_per_gpu")
+        assert "whole bodies per rank x2" in d["config"]["parallelism"] and d["expected_speedup"]["vs_one_gpu"] == 2.0
 
 
 def test_bench_gpus_flag_starts_that_many_ranks():
