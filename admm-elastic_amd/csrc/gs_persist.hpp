@@ -201,19 +201,13 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
     // row's residual of the PREVIOUS sweep before it moves (first colour: nothing has moved yet; middle colours: the neighbours that
     // have, by their parked values); 2 POST -- the residual of THIS sweep right after the update (last colour: every neighbour is
     // final).  Returns the thread's sum of squared residuals.
-    unsigned long long fine[4] = {0ull, 0ull, 0ull, 0ull};
-    const bool fprof = a.prof != nullptr && b == a.prof_block && t == 0;
     auto sweep_colour = [&](int c, int par, unsigned stamp, int role, bool keep_old) -> double {
-        unsigned long long f0 = fprof ? wall_clock64() : 0ull;
-        auto flap = [&](int k) { if (fprof) { const unsigned long long now = wall_clock64(); fine[k] += now - f0; f0 = now; } };
         const int r0 = ih[8 + c], n_c = ih[8 + c + 1] - r0;
         const bool both = role == 1 && c > 0;
         double rs = 0.0;
         for (int i = t; i < n_c; i += kGspT) {
             double LUx[3], LUo[3];
-            flap(0);
             row_sum(c, i, LUx, LUo, both);
-            flap(1);
             const int li = r0 + i;
             const double bi[3] = {bl[3 * li], bl[3 * li + 1], bl[3 * li + 2]};
             const double aii[3] = {al[3 * li], al[3 * li + 1], al[3 * li + 2]};
@@ -228,7 +222,6 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
             } else gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
-            flap(2);
             if (keep_old) { xo[3 * li] = cx[0]; xo[3 * li + 1] = cx[1]; xo[3 * li + 2] = cx[2]; }
             xl[3 * li] = nx[0]; xl[3 * li + 1] = nx[1]; xl[3 * li + 2] = nx[2];
             const int o = ol[li];
@@ -240,7 +233,6 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { const double r = bi[q] - fma(aii[q], nx[q], LUx[q]); rs = fma(r, r, rs); }
             }
-            flap(3);
         }
         return rs;
     };
@@ -340,8 +332,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
                 lap(2);
             }
         }
-        if (prof) { a.prof[0] += pt[0]; a.prof[1] += pt[1]; a.prof[2] += pt[2]; a.prof[3] += pt[3]; a.prof[4] += (unsigned long long)(n * C);
-                    a.prof[5] += fine[1]; a.prof[6] += fine[2]; a.prof[7] += fine[3]; }
+        if (prof) { a.prof[0] += pt[0]; a.prof[1] += pt[1]; a.prof[2] += pt[2]; a.prof[3] += pt[3]; a.prof[4] += (unsigned long long)(n * C); }
         // the values of the last colour of the last sweep: the block's state is complete again
         if (n > 0 && a.G > 1) fetch_halo(C - 1, (n - 1) & 1, stamp0 + (unsigned)(n * C - 1), false);
         __syncthreads();

@@ -1,11 +1,15 @@
-import sys
-sys.path.insert(0,'.'); sys.path.insert(0,'tests')
-import numpy as np, bench, scenes
-w = bench.WORKLOADS["cube1m_mix"]
-sc, nt, nv = bench.build_scene(w, int(sys.argv[1]) if len(sys.argv)>1 else 55)
-for tol in (1e-8, 1e-10):
-    s = sc.make_solver(pcg_tol=tol, pcg_max_iters=1500)
-    for f in range(4):
-        s.step()
-        print("tol", tol, "frame", f, "iters/solve", s.runtime_data().pcg_iters_per_solve)
-    s.close()
+"""PCG iterations of every solve of a frame (bench workload, bench tolerance): python experiments/iters_log.py [workload] [frames]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import bench
+wl = sys.argv[1] if len(sys.argv) > 1 else "blob1m_mix"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+sc, nt, nv = bench.build_scene(dict(bench.WORKLOADS[wl], linsolver=0) if bench.WORKLOADS[wl]["linsolver"] == 2 else bench.WORKLOADS[wl])   # (per-solve counts are reported for linsolver 0)
+s = sc.make_solver(pcg_tol=float(os.environ.get("TOL", bench.PCG_TOL)), pcg_max_iters=600)
+s.upload()
+for f in range(frames):
+    s.step_device(stats=True)
+    rd = s.runtime_data()
+    print("frame %2d: %s  sum %d  global %.3f ms" % (f, " ".join("%2d" % i for i in rd.pcg_iters_per_solve), sum(rd.pcg_iters_per_solve), rd.global_ms))
