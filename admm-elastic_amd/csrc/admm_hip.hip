@@ -256,7 +256,7 @@ struct admm_hip_ctx {
     bool gsp_enabled = false; int gsp_G = 0, gsp_C = 0; size_t gsp_lds = 0; int64_t gsp_stat[6] = {0, 0, 0, 0, 0, 0};
     DevBuf<int> gsp_hdr, gsp_orig, gsp_out, gsp_hbox, gsp_horig; DevBuf<double> gsp_diag, gsp_vals; DevBuf<unsigned short> gsp_cols;
     DevBuf<uint4> gsp_box, gsp_part, gsp_meet; DevBuf<unsigned> gsp_abort; DevBuf<unsigned long long> gsp_prof; int gsp_prof_block = 0;
-    Obstacles obst{}; DevBuf<double> obst_gmeta, obst_gdata;   // (sampled obstacles: ADMM_OBJ_GRID)
+    Obstacles obst{}; DevBuf<Obstacles> obst_dev; DevBuf<double> obst_gmeta, obst_gdata;   // (sampled obstacles: ADMM_OBJ_GRID)
     // dynamic (self-)collision (dyn_collide.hpp): one entry per TetMeshCollision, payload arrays per vertex
     struct DynDev {
         DynMesh m{};
@@ -291,7 +291,7 @@ struct admm_hip_ctx {
         bk_x.release(); bk_v.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         gsp_hdr.release(); gsp_orig.release(); gsp_out.release(); gsp_hbox.release(); gsp_horig.release(); gsp_diag.release(); gsp_vals.release(); gsp_cols.release();
-        obst_gmeta.release(); obst_gdata.release();
+        obst_gmeta.release(); obst_gdata.release(); obst_dev.release();
         gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release(); gsp_prof.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
@@ -1025,13 +1025,15 @@ void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
     a.box = (v4u *)c->gsp_box.p; a.part = (v4u *)c->gsp_part.p; a.meet = (v4u *)c->gsp_meet.p; a.abort_word = c->gsp_abort.p;
     a.done = c->counters.p + 1; a.sweeps = c->counters.p + 2; a.total = c->counters.p; a.sig = c->d_sig;
     a.prof = c->gsp_prof.p; a.prof_block = c->gsp_prof_block;
-    hipLaunchKernelGGL(k_gs_persist, dim3(c->gsp_G), dim3(kGspT), c->gsp_lds, st, a, c->obst);
+    a.ob = c->obst_dev.p;
+    hipLaunchKernelGGL(k_gs_persist, dim3(c->gsp_G), dim3(kGspT), c->gsp_lds, st, a);
     if (c->gsp_prof.p && (c->solve_seq % 200) == 0) {     // diagnosis: one block's wall-clock split of the phases since the last print
         unsigned long long h[8];
         if (hipMemcpyAsync(h, c->gsp_prof.p, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && h[4]) {
             const double k = 0.01 / (double)h[4];      // 100 MHz ticks -> us per phase
             fprintf(stderr, "[gsp_prof] block %d, %llu phases: halo poll %.2f  block barrier %.2f  rows + publish %.2f  verdict etc. %.2f us per phase\n",
                     c->gsp_prof_block, h[4], k * h[0], k * h[1], k * h[2], k * h[3]);
+            if (h[6]) fprintf(stderr, "[gsp_prof] shader clock during the solves: %.0f MHz\n", 100.0 * (double)h[5] / (double)h[6]);
             (void)hipMemsetAsync(c->gsp_prof.p, 0, sizeof(h), st);
         }
     }
@@ -1598,6 +1600,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->obst_gdata.upload(std::vector<double>(d->obstacle_grid_data, d->obstacle_grid_data + 4 * nodes)));
         c->obst.gmeta = c->obst_gmeta.p; c->obst.gdata = c->obst_gdata.p;
     }
+    HIP_TRY(c->obst_dev.upload(std::vector<Obstacles>(1, c->obst)));
 
     // ---- system matrix ----
     c->Ahat = admm_host::assemble_Ahat(nv, c->dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris, d->tri_idx,

@@ -49,6 +49,7 @@ struct GspArgs {
     unsigned *abort_word;                                     // raised by the first block that gives up
     int *done, *sweeps, *total;                               // counters[1], [2], [0] of the context (as the colour kernels)
     int *sig;                                                 // host-visible: sig[2] = 1 when the solve was aborted
+    const Obstacles *ob;                                      // passive obstacles (device copy: 80 SGPRs as a by-value argument)
     unsigned long long *prof; int prof_block;                 // diagnosis (ADMM_HIP_GSP_PROF=1): wall-clock ticks per part of a phase
 };
 
@@ -67,16 +68,16 @@ __device__ __forceinline__ void gsp_store(__amdgpu_buffer_rsrc_t rs, int byte_of
     __builtin_amdgcn_raw_buffer_store_b128(g, rs, byte_off, 0, 16 /* sc1: write-through */);
 }
 
-__global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
+__global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x, t = (int)threadIdx.x;
     // ---- LDS: scratch | x [L][3] | x of the previous sweep [L][3] | b [n_own][3] | a_ii [n_own][3] | values | columns | outbox node per
     //      row | halo source | pin flags   (host_setup.hpp: gsp_lds_bytes computes the same offsets)
     LdsD *scr = (LdsD *)smem;                       // [0..3] wave sums of the residual partial, [8] |b|^2 of the block
     LdsI32 *ih = (LdsI32 *)(smem + 256);            // the block's header (64 ints)
-    LdsI32 *ctl = (LdsI32 *)(smem + 512);           // [0] abort seen, [1] verdict
+    LdsI32 *ctl = (LdsI32 *)(smem + 512);           // [0] abort seen, [1] a sweep met the tolerance, [2] which one
     if (t < kGspHdrK) ih[t] = a.hdr[b * kGspHdrK + t];
-    if (t == 0) { ctl[0] = 0; ctl[1] = 0; }
+    if (t == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
     __syncthreads();
     const int n_own = ih[0], n_halo = ih[1], row_base = ih[2], halo_base = ih[3], ent_base = ih[4], ob_base = ih[5], ent_count = ih[7];
     const int L = n_own + n_halo, C = a.C;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
                 const int v = a.orig[row_base + li];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
-            } else gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
+            } else gs_relax(*a.ob, a.omega, bi, LUx, aii, cx, nx);
             if (keep_old) { xo[3 * li] = cx[0]; xo[3 * li + 1] = cx[1]; xo[3 * li + 2] = cx[2]; }
             xl[3 * li] = nx[0]; xl[3 * li + 1] = nx[1]; xl[3 * li + 2] = nx[2];
             const int o = ol[li];
@@ -288,6 +289,28 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
         return ctl[1] != 0;
     };
 
+    // ... the same by ONE wave from granules loaded earlier, without a barrier: the verdict is left in ctl[1] (met) / ctl[2] (sweep)
+    // for everybody to read after the next block barrier
+    auto verdict_wave = [&](int k, unsigned sp, v4u (*pre)[2]) {
+        double r2 = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = (t & 63) + 64 * u;
+            if (j < a.G) {
+                const int off = ((j * 4 + (k & 3)) * 2) * 16;
+                v4u g0 = pre[u][0], g1 = pre[u][1];
+                unsigned spins = 0;
+                while (!(gsp_ok(g0, sp) && gsp_ok(g1, sp))) {
+                    g0 = gsp_load(rpart, off); g1 = gsp_load(rpart, off + 16);
+                    if (gsp_ok(g0, sp) && gsp_ok(g1, sp)) break;
+                    if (poll_failed(spins)) break;
+                }
+                r2 += gsp_val(g0); b2 += gsp_val(g1);
+            }
+        }
+        r2 = wave_sum(r2); b2 = wave_sum(b2);
+        if ((t & 63) == 0 && r2 / b2 < a.tol2) { ctl[2] = k; ctl[1] = 1; }
+    };
     // n sweeps.  tests: the residual test of every sweep (:136-140), riding on the sweeps and evaluated two sweeps late.  Returns the
     // first sweep that met the tolerance (0 .. n-1), -1 if none did, -2 after an abort.
     auto run = [&](int n, bool tests, unsigned stamp0) -> int {
@@ -297,16 +320,20 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
         int parked = -1;
         const bool prof = a.prof != nullptr && b == a.prof_block && t == 0;
         unsigned long long pt[4] = {0ull, 0ull, 0ull, 0ull}, tk = prof ? wall_clock64() : 0ull;
+        const unsigned long long cyc0 = prof ? (unsigned long long)clock64() : 0ull, wc0 = tk;     // shader clock against the 100 MHz wall clock
         auto lap = [&](int k) { if (prof) { const unsigned long long now = wall_clock64(); pt[k] += now - tk; tk = now; } };
         for (int sweep = 0; sweep < n; ++sweep) {
             for (int c = 0; c < C; ++c) {
                 const int p = sweep * C + c;
-                const bool due = tests && c == 0 && sweep >= 2;     // the verdict on sweep - 2
+                // The verdict on sweep - 2 is formed by the LAST wave of the block (the one with the fewest rows) while the others
+                // sweep, and read by everybody one phase later: no barrier of its own, nothing on the sweeping waves' path.
+                const bool due = tests && c == 0 && sweep >= 2;
+                const bool judge = due && t >= kGspT - 64;
                 v4u pre[4][2];
-                if (due && t < 64) {
+                if (judge) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int j = t + 64 * u;
+                        const int j = (t & 63) + 64 * u;
                         if (j < a.G) { const int off = ((j * 4 + ((sweep - 2) & 3)) * 2) * 16; pre[u][0] = gsp_load(rpart, off); pre[u][1] = gsp_load(rpart, off + 16); }
                     }
                 }
@@ -316,12 +343,9 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
                 __syncthreads();
                 lap(1);
                 if (block_failed()) return -2;
+                if (tests && ctl[1] != 0) return ctl[2];         // a verdict of an earlier phase: that sweep met the tolerance
                 if (parked >= 0) { publish_parked(parked, stamp0 + (unsigned)parked); parked = -1; }
-                if (due) {
-                    const bool conv = verdict(sweep - 2, stamp0 + (unsigned)(sweep - 2), pre, true);
-                    if (block_failed()) return -2;
-                    if (conv) return sweep - 2;
-                }
+                if (judge) verdict_wave(sweep - 2, stamp0 + (unsigned)(sweep - 2), pre);
                 int role = 0;
                 if (tests) {
                     if (C >= 2 && c == C - 1) role = 2;
@@ -332,12 +356,14 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a, Obstacles ob) {
                 lap(2);
             }
         }
-        if (prof) { a.prof[0] += pt[0]; a.prof[1] += pt[1]; a.prof[2] += pt[2]; a.prof[3] += pt[3]; a.prof[4] += (unsigned long long)(n * C); }
+        if (prof) { a.prof[0] += pt[0]; a.prof[1] += pt[1]; a.prof[2] += pt[2]; a.prof[3] += pt[3]; a.prof[4] += (unsigned long long)(n * C);
+                    a.prof[5] += (unsigned long long)clock64() - cyc0; a.prof[6] += wall_clock64() - wc0; }
         // the values of the last colour of the last sweep: the block's state is complete again
         if (n > 0 && a.G > 1) fetch_halo(C - 1, (n - 1) & 1, stamp0 + (unsigned)(n * C - 1), false);
         __syncthreads();
         if (block_failed()) return -2;
         if (!tests || n < 1) return -1;
+        if (ctl[1] != 0) return ctl[2];
         if (parked >= 0) publish_parked(parked, stamp0 + (unsigned)parked);
         __syncthreads();                                    // (thread 0 has read the parked sums)
         // the last sweep: its last colour's rows were taken after their update, the others now
