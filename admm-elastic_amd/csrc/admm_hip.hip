@@ -228,6 +228,16 @@ struct admm_hip_ctx {
     static int rc_slot(int s) { return s < kRc ? s : kRc + (s - kRc) % kRcSlots; }
     double *rc_E(int s) { return rc_buf.p + ((size_t)rc_slot(s) * 2 + 0) * (size_t)n3i; }
     double *rc_R(int s) { return rc_buf.p + ((size_t)rc_slot(s) * 2 + 1) * (size_t)n3i; }
+    // FRAME HISTORY of the first kRcHist solves (round 4): their pairs are kept for three frames (slot by frame mod 3), so that solve s
+    // of frame f projects on the pairs of the same (and the next) solve index of frames f - 1 AND f - 2 as well.  At the bench
+    // tolerance the first five solves of a frame were 60 % of its PCG iterations (body: 31 56 25 43 25 of ~300); two frames of
+    // history bring solves 2-4 to 10-12 (frame total ~225, -25 %; 2 123 -> 2 404 ADMM it/s same-box).  For later solves the frame's own
+    // most recent pairs are worth more than any history (cube, history for all 20 solves: 556 -> 735 iterations per frame).
+    int kRcHist = 5;      // (ADMM_HIP_RC_HIST_N)
+    int rc_hist = 0, rc_prev2_valid = 0;
+    int rc_loc(int s, int frame) const { return (rc_hist && s < kRcHist) ? kRcAllSlots + ((frame % 3 + 3) % 3) * kRcHist + s : rc_slot(s); }
+    double *rc_Ef(int s, int frame) { return rc_buf.p + ((size_t)rc_loc(s, frame) * 2 + 0) * (size_t)n3i; }
+    double *rc_Rf(int s, int frame) { return rc_buf.p + ((size_t)rc_loc(s, frame) * 2 + 1) * (size_t)n3i; }
     // UzawaCG (per-vertex constraint rows)
     DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part, uz_dmax; DevBuf<long long> uz_dacc;   // uz_dacc / uz_dmax: dyn_collide.hpp, k_uz_ct_dyn
     DevBuf<UzScal> uz_scal;
@@ -657,6 +667,25 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     // basis: the (up to) kRc most recent pairs of THIS frame.  (Adding the previous frame's pair at the same
     // index was measured: it does not help the first solves of a frame.)
     const int rc_pairs = c->rc_pairs;
+    const int fr = c->rc_frame;
+    if (c->rc_hist) {
+        // own pairs and the history of the same solve index, interleaved by expected value: own(s-1), prev(s), prev2(s), own(s-2),
+        // prev(s+1), own(s-3), prev2(s+1), own(s-4)
+        auto add = [&](int q, int frame, bool valid) { if (valid && B.cnt < rc_pairs) { B.E[B.cnt] = c->rc_Ef(q, frame); B.R[B.cnt] = c->rc_Rf(q, frame); ++B.cnt; } };
+        const int H = c->kRcHist;
+        add(s - 1, fr, s - 1 >= 0);
+        add(s, fr - 1, s < H && s < c->rc_prev_valid);
+        add(s, fr - 2, s < H && s < c->rc_prev2_valid);
+        add(s - 2, fr, s - 2 >= 0);
+        add(s + 1, fr - 1, s + 1 < H && s + 1 < c->rc_prev_valid);
+        add(s - 3, fr, s - 3 >= 0);
+        add(s + 1, fr - 2, s + 1 < H && s + 1 < c->rc_prev2_valid);
+        add(s - 4, fr, s - 4 >= 0);
+        OcRc rc; rc.on = true; rc.B = B; rc.Eslot = c->rc_Ef(s, fr); rc.Rslot = c->rc_Rf(s, fr);
+        const int r = launch_pcg_onchip(c, b, x, c->pcg_max_iters, rc);
+        c->rc_iter = s + 1;
+        return r;
+    }
     for (int j = 1; j <= rc_pairs && s - j >= 0; ++j) { B.E[B.cnt] = c->rc_E(s - j); B.R[B.cnt] = c->rc_R(s - j); ++B.cnt; }
     // The first solves of a frame have few pairs of their own (the very first none: 85 of the 194 PCG iterations of a blob1m_mix
     // frame were its).  The free places of the basis go to the PREVIOUS frame's pairs of the same and the following solve indices
@@ -1648,7 +1677,9 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         c->NBR = std::max(1, std::min((nv + 255) / 256, 256));
         c->n3i = std::max(c->n3, 3 * c->oc_rows);
         if (c->rc_enabled) {
-            HIP_TRY(c->rc_buf.alloc((size_t)admm_hip_ctx::kRcAllSlots * 2 * c->n3i));
+            { const char *he = getenv("ADMM_HIP_RC_HIST"); c->rc_hist = (!(he && he[0] == '0') && c->oc_enabled && c->oc_plan) ? 1 : 0; }   // (=0: round 3's basis, A/B)
+            { const char *hn = getenv("ADMM_HIP_RC_HIST_N"); if (hn) c->kRcHist = std::max(1, std::min(64, atoi(hn))); }
+            HIP_TRY(c->rc_buf.alloc((size_t)(admm_hip_ctx::kRcAllSlots + (c->rc_hist ? 3 * c->kRcHist : 0)) * 2 * c->n3i));
             HIP_TRY(c->rc_r0.alloc(c->n3i)); HIP_TRY(c->rc_xs.alloc(c->n3i));
             HIP_TRY(c->rc_part.alloc((size_t)3 * kRcQ * c->NBR)); HIP_TRY(c->rc_coef.alloc(3 * kRc)); HIP_TRY(c->rc_coef.zero());
         }
@@ -2136,7 +2167,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     HIP_TRY(hipEventRecord(c->ev_step0, st));
     // counters[5] (closed chunks) must stay monotone across steps: only [0..4] are reset
     c->uz_iters_step = 0; c->uz_detected = false;
-    c->rc_prev_valid = c->rc_iter; c->rc_frame += 1; c->rc_iter = 0;   // this frame's pairs become "previous frame"
+    c->rc_prev2_valid = c->rc_prev_valid; c->rc_prev_valid = c->rc_iter; c->rc_frame += 1; c->rc_iter = 0;   // this frame's pairs become "previous frame"
     // How many pairs a projection uses is decided ONCE per context, from the scene's own behaviour: four pairs cost ~4 us per solve
     // more than three (8.8 MB of reads, 20 block sums) and pay when solves need many iterations (Kuhn cube: 17.4 -> 13.9 per solve),
     // not when they need few (unstructured body at 1e-8: 4.25 vs 4.35).  Decided from measurement, then fixed: deterministic.
@@ -2377,7 +2408,7 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     HIP_TRY(hipMemcpyAsync(c->b.p, b, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(c->curr.p, x_inout, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
     c->uz_iters_step = 0;
-    c->rc_prev_valid = 0; c->rc_frame += 1; c->rc_iter = 0;   // stand-alone solve: nothing to recycle
+    c->rc_prev_valid = 0; c->rc_prev2_valid = 0; c->rc_frame += 1; c->rc_iter = 0;   // stand-alone solve: nothing to recycle
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
     if (launch_global(c, c->b.p, c->curr.p)) return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     HIP_TRY(hipGetLastError());
