@@ -1,19 +1,19 @@
 #!/bin/bash
-# round-3 evidence, final code: PMC passes first (FETCH_SIZE and WRITE_SIZE separately, --kernel-trace only) -> the JSON bench.py
+# round-4 evidence, final code: PMC passes first (FETCH_SIZE and WRITE_SIZE separately, --kernel-trace only) -> the JSON bench.py
 # takes `roofline.traffic` from; then rocprofv3 kernel stats of the default bench (unstructured body), the cube and the UzawaCG
-# workload, the phase table of the persistent PCG kernel, bench JSON lines of every workload.  Writes under gpurun_out/r03p/.
+# workload, the phase table of the persistent PCG kernel, bench JSON lines of every workload.  Writes under gpurun_out/r04p/.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/r03p
+O=$GRAFT_REPO_ROOT/gpurun_out/r04p
 rm -rf $O; mkdir -p $O
 python -c "import torch" > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_${C} -o p -- python $GRAFT_REPO_ROOT/bench.py --workload blob1m_mix --steps 2 --warmup 3 --no-cpu-baseline --no-roofline > $O/pmc_bench_$C.json 2> $O/pmc_$C.err )
 done
 python experiments/pmc_to_json_r03.py $O $O/pmc_hbm_blob1m.json blob1m_mix
-cp $O/pmc_hbm_blob1m.json profiles/r03_e_pmc_hbm_blob1m.json      # (this box's copy of the repo: the bench lines below quote it)
+cp $O/pmc_hbm_blob1m.json profiles/r04_e_pmc_hbm_blob1m.json      # (this box's copy of the repo: the bench lines below quote it)
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-for wl in blob1m_mix cube1m_mix cube100k_uzawa_floor; do
+for wl in blob1m_mix cube100k_gs cloth200k_gs_floor cube100k_uzawa_floor; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 5 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof_$wl.json 2> $O/stats_$wl.err )
   cp $(find $O/stats_$wl -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$wl.csv
 done
@@ -23,4 +23,5 @@ for wl in blob1m_mix cube1m_mix cube1m_nh cube100k_gs cloth200k_gs_floor cube100
 done
 python bench.py 2>/dev/null | tail -1 > $O/bench_default_driver_flags.json
 for b in 0 100; do ADMM_HIP_OC_PROF_BLOCK=$b python experiments/oc_prof.py blob1m_mix 2>&1 | grep oc_prof | tail -6 > $O/ocprof_blob_block$b.txt; done
+for wl in cube100k_gs cloth200k_gs_floor; do ADMM_HIP_GSP_PROF=1 ADMM_HIP_GSP_PROF_BLOCK=20 python bench.py --workload $wl --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep gsp_prof | tail -2 > $O/gspprof_$wl.txt; done
 ls -la $O
