@@ -9,7 +9,7 @@
 //   * neighbour hand-off: a block announces its published slice with a (solve, phase) flag and a consumer starts gathering
 //     as soon as the <= 64 blocks its matrix rows reference have announced theirs -- no grid barrier in front of a gather.
 // Measured alternatives (two-level barrier, tagged granules instead of barrier + records, an auxiliary reduction wave):
-// profiles/HISTORY_rounds_1_2.md.
+// profiles/HISTORY_rounds_1_3.md.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels.hpp"

@@ -120,6 +120,51 @@ def test_rank_contexts_partition_the_local_step():
 
 
 @pytest.mark.gpu
+def test_world8_rank_contexts_of_the_1m_tet_body_reproduce_the_single_context():
+    """BASELINE configs[3] at its size on ONE GPU: the eight rank contexts of the element-block partition of the 1 012 608-tet body
+    (bench.py's default workload) against the single context, through the kernel-level entry points -- every ADMM iteration: the eight
+    local steps on their element blocks (disjoint z / u rows, partial right-hand sides: rank 0 carries M x_bar and the pin terms), the
+    sum of the partials (what the all-reduce does), the replicated solve on rank 0's context.  One frame of 3 ADMM iterations equals
+    the single context's frame to the solve tolerance."""
+    import bench
+    n = int(os.environ.get("ADMM_TEST_BIG_BLOB_N", "118"))
+    sc, nt, nv = bench.build_scene(bench.WORKLOADS["blob1m_mix"], n)
+    sc.settings.update(admm_iters=3, linsolver=0)
+    world, iters = 8, 3
+    single = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=2000)
+    single.step()
+    assert single.runtime_data().unconverged_solves == 0
+    ranks = [sc.make_solver(rank=r, world_size=world, pcg_tol=1e-11, pcg_max_iters=2000) for r in range(world)]
+    R = ranks[0].num_rows()
+    dt, g = sc.settings["timestep_s"], sc.settings["gravity"]
+    m = sc.masses3()
+    x0 = sc.x.ravel().copy(); v = np.zeros_like(x0); v[1::3] += dt * g
+    xbar = x0 + dt * v
+    Mxbar = m * xbar
+    curr = xbar.copy()
+    u = np.zeros(R)
+    for it in range(iters):
+        b = np.zeros_like(x0); u_new = u.copy(); rows_seen = np.zeros(R, bool)
+        for r in range(world):
+            z_r, u_r, b_r = ranks[r].local_step(curr, u, Mxbar)
+            own = u_r != u
+            if it == 0:
+                own = np.abs(z_r) > 0
+            assert not (rows_seen & own)[:9 * nt].any()      # the ranks' element rows are disjoint (every rank carries the pin rows)
+            rows_seen |= own
+            u_new = np.where(own, u_r, u_new)
+            b += b_r
+        u = u_new
+        curr, _ = ranks[0].global_solve(b, curr)
+    err = scenes.rel_err(curr, single.m_x)
+    assert err < 1e-8, err
+    assert np.abs(single.m_x - x0).max() > 1e-4
+    for s_ in ranks:
+        s_.close()
+    single.close()
+
+
+@pytest.mark.gpu
 def test_rccl_allreduce_path_on_one_gpu():
     """The RCCL leg of the multi-GPU step on a single GPU: a communicator of world size 1 (ADMM_HIP_FORCE_COMM=1)
     makes every ADMM iteration run the in-place ncclAllReduce of the right-hand side on the context's stream,
