@@ -1055,6 +1055,8 @@ void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
     a.done = c->counters.p + 1; a.sweeps = c->counters.p + 2; a.total = c->counters.p; a.sig = c->d_sig;
     a.prof = c->gsp_prof.p; a.prof_block = c->gsp_prof_block;
     a.ob = c->obst_dev.p;
+    if (c->test_abort_seq > 0 && (int)a.seq == c->test_abort_seq)   // test hook: this solve finds its hand-off given up
+        (void)hipMemsetAsync(c->gsp_abort.p, 1, sizeof(unsigned), st);
     hipLaunchKernelGGL(k_gs_persist, dim3(c->gsp_G), dim3(kGspT), c->gsp_lds, st, a);
     if (c->gsp_prof.p && (c->solve_seq % 200) == 0) {     // diagnosis: one block's wall-clock split of the phases since the last print
         unsigned long long h[8];
@@ -1113,6 +1115,7 @@ hipError_t plan_gs_persist(admm_hip_ctx *c) {
         fprintf(stderr, "[gs_plan] %d blocks x %d threads, <= %d rows and %d halo entries per block, <= %d neighbour blocks, %d outbox nodes, %d bytes of LDS\n",
                 P.G, kGspT, P.max_rows, P.max_halo, P.max_nbr, P.ob_total, P.lds_bytes);
     c->gsp_enabled = true;
+    { const char *ta = getenv("ADMM_HIP_TEST_ABORT_SOLVE"); c->test_abort_seq = ta ? atoi(ta) : 0; }
     return hipSuccess;
 }
 

@@ -77,8 +77,15 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     LdsI32 *ih = (LdsI32 *)(smem + 256);            // the block's header (64 ints)
     LdsI32 *ctl = (LdsI32 *)(smem + 512);           // [0] abort seen, [1] a sweep met the tolerance, [2] which one
     if (t < kGspHdrK) ih[t] = a.hdr[b * kGspHdrK + t];
-    if (t == 0) { ctl[0] = 0; ctl[1] = 0; ctl[2] = 0; }
+    if (t == 0) {
+        ctl[1] = 0; ctl[2] = 0;
+        // a solve of this context has been given up and the host has not recovered yet (steps are issued asynchronously): nothing may
+        // run on that state -- every later launch leaves at once, the host replays them after its next synchronisation
+        ctl[0] = __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+        if (ctl[0]) __hip_atomic_store(a.sig + 2, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();
+    if (ctl[0]) return;
     const int n_own = ih[0], n_halo = ih[1], row_base = ih[2], halo_base = ih[3], ent_base = ih[4], ob_base = ih[5], ent_count = ih[7];
     const int L = n_own + n_halo, C = a.C;
     LdsD *xl = (LdsD *)(smem + 1024);

@@ -81,3 +81,31 @@ def test_persistent_gs_whole_steps_equal_colour_kernels(what):
         assert np.array_equal(a.m_x, bsol.m_x), (f, np.abs(a.m_x - bsol.m_x).max())
     assert np.abs(a.m_x - sc.x.ravel()).max() > 1e-3
     a.close(); bsol.close()
+
+
+def test_persistent_gs_hand_off_timeout_falls_back_and_replays(monkeypatch):
+    """A neighbour hand-off of the persistent kernel that cannot complete (blocks not co-resident: another persistent kernel on the
+    GPU; here injected with ADMM_HIP_TEST_ABORT_SOLVE) must not fail the step or leave a half-swept state: the solve is given up, every
+    later launch leaves at once, and at the next synchronisation the context switches to the launch-per-colour kernels, restores the
+    last good state and replays the steps issued since -- asynchronous ones included.  The result is the colour kernels' trajectory."""
+    sc = _scene("cube")
+    ref = _solver(sc, False)
+    for _ in range(4):
+        ref.step()
+    monkeypatch.setenv("ADMM_HIP_TEST_ABORT_SOLVE", "11")      # 3rd frame, 3rd ADMM iteration (4 per frame)
+    s = _solver(sc, True, 100)
+    monkeypatch.delenv("ADMM_HIP_TEST_ABORT_SOLVE")
+    s.upload()
+    for _ in range(3):
+        s.step_device(stats=False)
+    s.step_device(stats=True)
+    s.download()
+    assert np.array_equal(s.m_x, ref.m_x), np.abs(s.m_x - ref.m_x).max()
+    assert s.runtime_data().inner_iters == ref.runtime_data().inner_iters
+    monkeypatch.setenv("ADMM_HIP_TEST_ABORT_SOLVE", "6")       # ... inside a step that asks for statistics
+    s2 = _solver(sc, True, 100)
+    monkeypatch.delenv("ADMM_HIP_TEST_ABORT_SOLVE")
+    for _ in range(4):
+        s2.step()
+    assert np.array_equal(s2.m_x, ref.m_x)
+    s.close(); s2.close(); ref.close()
