@@ -125,6 +125,8 @@ struct admm_hip_ctx {
     // multi-GPU (element-block partition, replicated global solve, RCCL all-reduce of the partial RHS)
     ncclComm_t comm = nullptr;
     admm_allreduce_fn ar_fn = nullptr; void *ar_user = nullptr; double *ar_host = nullptr;   // admm_hip_set_rhs_allreduce: the caller's own transport
+    // DISTRIBUTED global solve (ADMM_HIP_DIST_SOLVE=1 with world_size > 1): rank r owns the vertex rows [row_lo, row_hi) of the PCG
+    bool dist_solve = false; int row_lo = 0, row_hi = 0x7fffffff;
     int nt_total = 0, ntri_total = 0; // element counts of the whole scene (row layout of z/u)
     int tri_begin = 0;                // first triangle owned by this rank
 
@@ -393,21 +395,21 @@ void launch_gather(admm_hip_ctx *c) {
     hipLaunchKernelGGL(k_gather_rhs, dim3(grid), dim3(256), 0, c->stream, a);
 }
 
+// in-place sum all-reduce of n doubles on the context's stream: RCCL, or the caller's transport staged through pinned host memory
+int comm_allreduce(admm_hip_ctx *c, double *p, size_t n) {
+    if (c->comm) return g_rccl.AllReduce(p, p, n, ncclDouble, ncclSum, c->comm, c->stream) == ncclSuccess ? 0 : -3;
+    if (!c->ar_fn) return c->world > 1 ? -2 : 0;
+    if (n > (size_t)c->n3) return -3;
+    if (hipMemcpyAsync(c->ar_host, p, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -3;
+    if (c->ar_fn(c->ar_user, c->ar_host, (int64_t)n) != 0) return -3;
+    return hipMemcpyAsync(p, c->ar_host, n * sizeof(double), hipMemcpyHostToDevice, c->stream) == hipSuccess ? 0 : -3;
+}
+
 // b = M x_bar + dt^2 D^T W^2 (z - u): per-rank gather over the owned elements, then (multi-GPU) one
 // in-place RCCL sum all-reduce over xGMI; rank 0 contributed M x_bar and the pin terms.
 int launch_rhs(admm_hip_ctx *c) {
     launch_gather(c);
-    if (c->world > 1 || c->comm) {
-        if (c->comm) {
-            ncclResult_t r = g_rccl.AllReduce(c->b.p, c->b.p, (size_t)c->n3, ncclDouble, ncclSum, c->comm, c->stream);
-            if (r != ncclSuccess) return -3;
-        } else if (c->ar_fn) {     // the caller's transport, staged through pinned host memory (two copies + a stream synchronisation per ADMM iteration)
-            if (hipMemcpyAsync(c->ar_host, c->b.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) return -3;
-            if (c->ar_fn(c->ar_user, c->ar_host, (int64_t)c->n3) != 0) return -3;
-            if (hipMemcpyAsync(c->b.p, c->ar_host, c->n3 * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return -3;
-        } else return -2;
-    }
+    if (c->world > 1 || c->comm) return comm_allreduce(c, c->b.p, (size_t)c->n3);
     return 0;
 }
 
@@ -620,7 +622,44 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     return hipSuccess;
 }
 
+// DISTRIBUTED PCG of one body (SURVEY 8e option B; BASELINE configs[3]: "all-reduce per CG iteration"): the launch-per-iteration
+// solver with the rows split into contiguous vertex blocks.  A rank computes the matrix-vector product, the dot-product partials
+// and the vector updates of ITS rows only; per iteration two sum all-reduces assemble what the others need -- the partial sums
+// (6 x NB doubles: every rank then derives the same alpha / beta in the same order) and the preconditioned residual u, the input of
+// the next product (3 nv doubles; rows of other ranks are zero in every contribution).  x is assembled once, after the loop.  The
+// convergence decision is the device's as on one GPU; the host reads it after every iteration (one stream synchronisation) so that
+// all ranks leave the loop at the same iteration and issue the same collectives.  Compute shards 1 / N; the exchange does not:
+// this pays for bodies that do not fit one chip's LDS, not at 1 M tets.
+int launch_pcg_dist(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
+    hipStream_t st = c->stream;
+    const SellA A = sell_arg(c->A);
+    const int NB = c->NB, lo = c->row_lo, hi = c->row_hi;
+    const double tol2 = c->pcg_tol * c->pcg_tol;
+    const int seq = ++c->solve_seq;
+    hipLaunchKernelGGL(k_cg_resid, dim3(NB), dim3(256), 0, st, A, c->m.p, c->dinv.p, b, x, c->cg_u.p, c->part_b.p, NB, c->cg_scal.p, seq, lo, hi);
+    if (int r = comm_allreduce(c, c->cg_u.p, (size_t)c->n3)) return r;
+    if (int r = comm_allreduce(c, c->part_b.p, (size_t)3 * NB)) return r;
+    int launched = 0, converged = 0;
+    for (int it = 0; it < max_iters; ++it) {
+        const CgScal *prev = c->cg_scal.p + (it & 1);
+        CgScal *next = c->cg_scal.p + ((it + 1) & 1);
+        hipLaunchKernelGGL(k_cg_spmv, dim3(NB), dim3(256), 0, st, A, c->m.p, c->cg_u.p, c->dinv.p, c->cg_w.p, c->part.p, NB, prev, lo, hi);
+        if (int r = comm_allreduce(c, c->part.p, (size_t)6 * NB)) return r;
+        hipLaunchKernelGGL(k_cg_vec, dim3(c->NBV), dim3(256), 0, st, it, c->nv, NB, c->part.p, c->part_b.p, prev, next, tol2,
+                           c->counters.p, c->dinv.p, c->cg_p.p, c->cg_s.p, x, c->cg_u.p, c->cg_w.p, c->d_sig, 0, lo, hi);
+        launched = it + 1;
+        if (hipMemcpyAsync(&converged, &next->converged, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (converged) break;       // (u is still the assembled one of the previous iteration: the converged k_cg_vec wrote nothing)
+        if (int r = comm_allreduce(c, c->cg_u.p, (size_t)c->n3)) return r;
+    }
+    hipLaunchKernelGGL(k_keep_own_rows, dim3(blocks_for(c->nv)), dim3(256), 0, st, c->nv, lo, hi, x);
+    if (int r = comm_allreduce(c, x, (size_t)c->n3)) return r;
+    c->last_launched_iters = launched;
+    return 0;
+}
+
 int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters, const int *skip = nullptr) {
+    if (c->dist_solve) { const int r = launch_pcg_dist(c, b, x, max_iters); return r ? -1 : 0; }
     if (c->oc_enabled) { OcRc rc; rc.skip = skip; return launch_pcg_onchip(c, b, x, max_iters, rc); }
     hipStream_t st = c->stream;
     const SellA A = sell_arg(c->A);
@@ -1666,7 +1705,17 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
     HIP_TRY(c->counters.alloc(8 + 64 + 8)); HIP_TRY(c->counters.zero());   // [72..74]: totals since create (on-chip PCG)
     c->create_xyz = d->vert_xyz;
-    if (d->linsolver != 1) HIP_TRY(plan_pcg_onchip(c));
+    {   // distributed solve of ONE body (ADMM_HIP_DIST_SOLVE=1, element-block partition): contiguous vertex rows per rank, 64-aligned
+        const char *de = getenv("ADMM_HIP_DIST_SOLVE");
+        const char *fc = getenv("ADMM_HIP_FORCE_COMM");     // (tests: a world of ONE with a communicator runs the same collectives through RCCL)
+        if (de && de[0] == '1' && (c->world > 1 || (fc && fc[0] == '1')) && d->linsolver != 1) {
+            const int ns = (nv + 63) / 64;
+            c->row_lo = 64 * (int)((int64_t)ns * c->rank / c->world);
+            c->row_hi = c->rank + 1 == c->world ? nv : 64 * (int)((int64_t)ns * (c->rank + 1) / c->world);
+            c->dist_solve = true;
+        }
+    }
+    if (d->linsolver != 1 && !c->dist_solve) HIP_TRY(plan_pcg_onchip(c));
     c->create_xyz = nullptr;
     if (d->linsolver != 1) {
         const char *env = getenv("ADMM_HIP_NO_RECYCLE");

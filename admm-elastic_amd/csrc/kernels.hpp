@@ -736,7 +736,10 @@ __device__ __forceinline__ void sell_row(const SellA &A, int s, int lane, const 
 __global__ __launch_bounds__(256) void k_cg_resid(SellA A, const double *__restrict__ m, const double *__restrict__ dinv,
                                                   const double *__restrict__ b, const double *__restrict__ x,
                                                   double *__restrict__ u,
-                                                  double *__restrict__ part_b, int NB, CgScal *__restrict__ sc0, int seq) {
+                                                  double *__restrict__ part_b, int NB, CgScal *__restrict__ sc0, int seq,
+                                                  int row_lo = 0, int row_hi = 0x7fffffff) {
+    // [row_lo, row_hi): the rows this rank owns in the DISTRIBUTED solve (admm_hip.hip: launch_pcg_dist); rows of other ranks get
+    // u = 0 and add nothing to the sums -- a sum all-reduce then assembles the vector and the sums.  Single GPU: every row.
     __shared__ double lds[12];
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc0->converged = 0; sc0->iters = 0; sc0->seq = seq; }
     const int lane = threadIdx.x & 63;
@@ -744,16 +747,17 @@ __global__ __launch_bounds__(256) void k_cg_resid(SellA A, const double *__restr
     double q[3] = {0.0, 0.0, 0.0};
     if (s < A.n_slices) {
         const int row = s * 64 + lane;
-        double acc[3];
-        sell_row(A, s, lane, x, acc);
+        const bool own = row >= row_lo && row < row_hi;
+        double acc[3] = {0.0, 0.0, 0.0};
+        if (__any(own)) sell_row(A, s, lane, x, acc);          // (a slice of another rank's rows costs nothing)
         if (row < A.n_rows) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const size_t i = 3 * (size_t)row + j;
                 const double bi = b[i], di = dinv[i];
                 const double ri = bi - fma(m[i], x[i], acc[j]);
-                u[i] = di * ri;
-                q[j] = fma(bi * di, bi, q[j]);
+                u[i] = own ? di * ri : 0.0;
+                if (own) q[j] = fma(bi * di, bi, q[j]);
             }
         }
     }
@@ -764,7 +768,8 @@ __global__ __launch_bounds__(256) void k_cg_resid(SellA A, const double *__restr
 // w = A u ; partials gamma = r.u = sum u^2 / dinv, delta = w.u   (skipped when the solve has converged)
 __global__ __launch_bounds__(256) void k_cg_spmv(SellA A, const double *__restrict__ m, const double *__restrict__ u,
                                                  const double *__restrict__ dinv, double *__restrict__ w,
-                                                 double *__restrict__ part, int NB, const CgScal *__restrict__ sc) {
+                                                 double *__restrict__ part, int NB, const CgScal *__restrict__ sc,
+                                                 int row_lo = 0, int row_hi = 0x7fffffff) {
     __shared__ double lds[24];
     if (sc->converged) return;
     const int lane = threadIdx.x & 63;
@@ -772,17 +777,20 @@ __global__ __launch_bounds__(256) void k_cg_spmv(SellA A, const double *__restri
     double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (s < A.n_slices) {
         const int row = s * 64 + lane;
-        double acc[3];
-        sell_row(A, s, lane, u, acc);
-        if (row < A.n_rows) {
+        const bool own = row >= row_lo && row < row_hi;        // (distributed solve: see k_cg_resid)
+        if (__any(own)) {
+            double acc[3];
+            sell_row(A, s, lane, u, acc);
+            if (row < A.n_rows && own) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const size_t i = 3 * (size_t)row + j;
-                const double ui = u[i];
-                const double wi = fma(m[i], ui, acc[j]);
-                w[i] = wi;
-                q[j] = fma(ui * ui, fast_rcp(dinv[i]), q[j]);
-                q[3 + j] = fma(wi, ui, q[3 + j]);
+                for (int j = 0; j < 3; ++j) {
+                    const size_t i = 3 * (size_t)row + j;
+                    const double ui = u[i];
+                    const double wi = fma(m[i], ui, acc[j]);
+                    w[i] = wi;
+                    q[j] = fma(ui * ui, fast_rcp(dinv[i]), q[j]);
+                    q[3 + j] = fma(wi, ui, q[3 + j]);
+                }
             }
         }
     }
@@ -802,7 +810,7 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int nv, int NB, const do
                                                 const double *__restrict__ dinv, double *__restrict__ p,
                                                 double *__restrict__ s, double *__restrict__ x,
                                                 double *__restrict__ u, const double *__restrict__ w,
-                                                int *__restrict__ sig, int mark_here) {
+                                                int *__restrict__ sig, int mark_here, int row_lo = 0, int row_hi = 0x7fffffff) {
     __shared__ double lds[36];
     const CgScal pv = *prev;
     // progress mark for the host (pinned memory): the chunk this kernel closes has (almost) drained
@@ -877,6 +885,10 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int nv, int NB, const do
         atomicAdd(total_iters, 1);
     }
     if (!live) return;
+    if (v < row_lo || v >= row_hi) {      // distributed solve: another rank's row -- only its u is cleared, for the all-reduce that assembles u
+        u[i0] = 0.0; u[i0 + 1] = 0.0; u[i0 + 2] = 0.0;
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const double pi = fma(beta[a], rp[a], ru[a]);
@@ -885,6 +897,13 @@ __global__ __launch_bounds__(256) void k_cg_vec(int it, int nv, int NB, const do
         x[i0 + a] = fma(alpha[a], pi, rx[a]);
         u[i0 + a] = fma(-alpha[a] * rd[a], si, ru[a]);     // u = M^-1 (r - alpha s)
     }
+}
+
+// distributed solve: clear the rows of a node vector this rank does not own (a sum all-reduce then assembles the vector)
+__global__ __launch_bounds__(256) void k_keep_own_rows(int nv, int row_lo, int row_hi, double *__restrict__ x) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv || (v >= row_lo && v < row_hi)) return;
+    x[3 * (size_t)v] = 0.0; x[3 * (size_t)v + 1] = 0.0; x[3 * (size_t)v + 2] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------

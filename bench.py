@@ -463,7 +463,9 @@ def main():
                     if contact_free else "UzawaCG (Schur-complement CG, <= 20 iterations, stop decided on the device) over the on-chip PCG tol=%g" % args.pcg_tol) if w["linsolver"] == 2 else
                    "PCG (one persistent on-chip launch per solve: two-level preconditioned pipelined CG, matrix and vectors in LDS) tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters),
                    "parallelism": ("whole bodies per rank x%d (component-aware partition, no exchange inside a step)" % world if weak else
-                                   "element-block x%d (RCCL all-reduce of the right-hand side, replicated solve)" % world) if world > 1 else "single-gpu"},
+                                   "element-block x%d (RCCL all-reduce of the right-hand side, %s)" % (world,
+                                       "DISTRIBUTED solve: launch-path Jacobi PCG, rows split over the ranks, two all-reduces per PCG iteration (ADMM_HIP_DIST_SOLVE=1)"
+                                       if os.environ.get("ADMM_HIP_DIST_SOLVE") == "1" and not weak else "replicated solve")) if world > 1 else "single-gpu"},
         "ms_per_frame": ms_per_step,
         "split_ms_per_admm_iter": {"local": local_ms / (iters * args.steps), "rhs": rhs_ms / (iters * args.steps),
                                    "global": global_ms / (iters * args.steps)},

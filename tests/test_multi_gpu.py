@@ -67,7 +67,7 @@ def _worker(rank, world, port, n, frames, q):
 
 
 def test_sharded_step_matches_single_rank_gloo():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp          # (stdlib: the pytest process itself never imports torch -- its bundled ROCm libraries next to the system ones the library loads abort at exit)
     n, frames, world = 4, 3, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -188,13 +188,39 @@ def test_rccl_allreduce_path_on_one_gpu():
         s.step()
     assert np.array_equal(s.m_x, ref.m_x)
     assert s.runtime_data().unconverged_solves == 0
+    s.close(); ref.close()
 
 
-def _rccl_worker(rank, world, port, n, frames, q):
+@pytest.mark.gpu
+def test_distributed_solve_collectives_over_rccl_on_one_gpu(monkeypatch):
+    """The RCCL leg of the distributed solve on one GPU: a world of ONE with a communicator and ADMM_HIP_DIST_SOLVE=1 runs every
+    collective of launch_pcg_dist (partials, u, x) as an in-place ncclAllReduce on the context's stream; over one rank they are the
+    identity and the row range is everything, so the result is the launch-per-iteration solver's, and matches the on-chip one to
+    solver tolerance.  (Two ranks: test_distributed_solve_matches_single_context, gloo; two GPUs: test_two_ranks_two_gpus_*.)"""
+    import ctypes as C
+    sc = scenes.mixed_cube_scene(6, admm_iters=6, linsolver=0)
+    ref = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=1000)
+    monkeypatch.setenv("ADMM_HIP_FORCE_COMM", "1")
+    monkeypatch.setenv("ADMM_HIP_DIST_SOLVE", "1")
+    s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=1000)
+    buf = C.create_string_buffer(128)
+    capi.check(capi.lib().admm_hip_comm_unique_id(buf))
+    capi.check(capi.lib().admm_hip_comm_init(s._ctx, bytes(buf.raw), 0, 1))
+    for _ in range(3):
+        s.step(); ref.step()
+        assert s.runtime_data().unconverged_solves == 0
+    assert s.runtime_data().inner_iters > ref.runtime_data().inner_iters      # Jacobi PCG, not the on-chip two-level one: it is the other path
+    assert scenes.rel_err(s.m_x, ref.m_x) < 1e-9
+    s.close(); ref.close()
+
+
+def _rccl_worker(rank, world, port, n, frames, q, dist_solve=False):
     """One rank of a real multi-GPU run: own device, RCCL communicator, product contexts."""
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    if dist_solve:
+        os.environ["ADMM_HIP_DIST_SOLVE"] = "1"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)     # only carries the 128-byte RCCL id
     sc = scenes.mixed_cube_scene(n, admm_iters=6, linsolver=0)
@@ -209,18 +235,21 @@ def _rccl_worker(rank, world, port, n, frames, q):
 
 
 @pytest.mark.gpu
-def test_two_ranks_two_gpus_match_single_context():
+@pytest.mark.parametrize("dist_solve", [False, True])
+def test_two_ranks_two_gpus_match_single_context(dist_solve):
     """A real world-2 step (element-block partition, ncclAllReduce of the partial right-hand side over xGMI between the
     gather kernel and the persistent PCG kernel, replicated solve) on two devices reproduces the single-context
-    trajectory.  Needs two GPUs: skipped on the 1-GPU test boxes, run wherever the driver has a multi-GPU node."""
+    trajectory; dist_solve: the same with the PCG's rows split over the two devices (ADMM_HIP_DIST_SOLVE=1: RCCL all-reduces of the
+    partial sums and of u per PCG iteration).  Needs two GPUs: skipped on the 1-GPU test boxes, run wherever the driver has a
+    multi-GPU node."""
     if pkg.device_count() < 2:
         pytest.skip("needs 2 GPUs")
-    import torch.multiprocessing as mp
+    import multiprocessing as mp          # (stdlib: the pytest process itself never imports torch -- its bundled ROCm libraries next to the system ones the library loads abort at exit)
     n, frames, world = 6, 3, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, n, frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, n, frames, q, dist_solve)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -301,7 +330,7 @@ def _component_worker(rank, world, port, frames, q):
 
 
 def test_component_partition_matches_single_rank_gloo():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp          # (stdlib: the pytest process itself never imports torch -- its bundled ROCm libraries next to the system ones the library loads abort at exit)
     frames, world = 3, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -449,3 +478,79 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in (r.stdout + r.stderr)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# DISTRIBUTED global solve of ONE body (ADMM_HIP_DIST_SOLVE=1; SURVEY 8e option B, BASELINE configs[3]'s "all-reduce per CG
+# iteration"): vertex rows of the PCG split over the ranks, partial dot products + the preconditioned residual summed per iteration.
+def _dist_solve_worker(rank, world, port, kind, n, frames, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["ADMM_HIP_DIST_SOLVE"] = "1"
+    os.environ["ADMM_HIP_UZ_FREEZE"] = "1"        # (contact: active set fixed per step, as in test_step_uzawa_frozen_active_set_is_tight)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sc = _dist_scene(kind, n)
+    s = sc.make_solver(device=0, pcg_tol=1e-12, pcg_max_iters=2000, rank=rank, world_size=world)
+    calls = [0, 0]
+
+    def allreduce(buf):
+        calls[0] += 1; calls[1] += buf.size
+        dist.all_reduce(torch.from_numpy(buf))
+    s.set_rhs_allreduce(allreduce)
+    iters = 0
+    for _ in range(frames):
+        s.step()
+        rd = s.runtime_data()
+        assert rd.unconverged_solves == 0
+        iters += rd.inner_iters
+    q.put((rank, s.m_x.copy(), iters, calls[0], calls[1]))
+    s.close()
+    dist.destroy_process_group()
+
+
+def _dist_scene(kind, n):
+    if kind == "floor":      # a cube dropped on a Floor: UzawaCG with an active set, K^-1 columns solved by the distributed PCG
+        sc = scenes.mixed_cube_scene(n, admm_iters=8, linsolver=2)
+        sc.pins.clear()
+        sc.x = sc.x + np.array([0.0, 0.004, 0.0])
+        sc.obstacles.append((0, [0.0, 0.0, 0.0, 0.0]))
+        return sc
+    return scenes.mixed_cube_scene(n, admm_iters=8, linsolver=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,world", [("pcg", 2), ("pcg", 3), ("floor", 2)])
+def test_distributed_solve_matches_single_context(kind, world):
+    """Ranks of one body with the PCG's rows split between them (all on device 0, the exchange over gloo through
+    admm_hip_set_rhs_allreduce) against the single context at the same tolerance: same iterates up to summation order, every rank
+    holds the whole state after every step, and the collectives per solve are the ones DESIGN 6 prices
+    (1 per ADMM iteration for b + per solve 2 + 2 per PCG iteration [+1 less on the converged one] + 1 for x)."""
+    import multiprocessing as mp          # (stdlib: the pytest process itself never imports torch -- its bundled ROCm libraries next to the system ones the library loads abort at exit)
+    n, frames = 9, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dist_solve_worker, args=(r, world, port, kind, n, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc = _dist_scene(kind, n)
+    os.environ["ADMM_HIP_UZ_FREEZE"] = "1"
+    try:
+        single = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=2000)
+    finally:
+        os.environ.pop("ADMM_HIP_UZ_FREEZE")
+    it1 = 0
+    for _ in range(frames):
+        single.step(); it1 += single.runtime_data().inner_iters
+    assert np.abs(single.m_x - sc.x.ravel()).max() > 1e-4
+    for rank, x, iters, ncalls, nbytes in got:
+        assert scenes.rel_err(x, single.m_x) < (1e-9 if kind == "pcg" else 1e-7), (rank, scenes.rel_err(x, single.m_x))
+        assert np.array_equal(x, got[0][1])                       # every rank ends with the SAME bits (replicated scalars, summed vectors)
+        assert iters == got[0][2] and ncalls == got[0][3]
+    print("distributed solve (%s, world %d): PCG iterations %d vs single context %d, %d collectives" % (kind, world, got[0][2], it1, got[0][3]))
+    single.close()
