@@ -195,7 +195,7 @@ struct admm_hip_ctx {
     DevBuf<unsigned long long> oc_prof;   // diagnosis (ADMM_HIP_OC_PROF=1)
     bool oc_debug = false, oc_always_verify = false; int oc_prof_block = 0;
     // general-mesh plan of the on-chip PCG (oc_plan.cpp): internal row order, its SELL, slab shares, two-level data
-    double oc_sm_ab = 0.0, oc_sm_b = 0.0, oc_lam_bb = 0.0;   // block-local smoother of k_pcg2 (pcg_onchip2.hpp: smooth)
+    double oc_sm_ab = 0.0, oc_sm_b = 0.0, oc_lam_bb = 0.0, oc_sm_c0 = 0.0, oc_sm_k1 = 0.0, oc_sm_k2 = 0.0;   // block-local smoother of k_pcg2 (pcg_onchip2.hpp: smooth)
     bool oc_plan = false, oc_coarse = false; int oc_rows = 0, oc_bcols = 0, oc_nc = 0, oc_ncp = 0, oc_veclen = 0;
     SellDev oc_A; DevBuf<int> oc_orig, oc_ldsoff, oc_wls, oc_haloptr, oc_halosrc; DevBuf<unsigned short> oc_col16;
     DevBuf<double> oc_mdiag, oc_ainv, oc_cbuf; DevBuf<float> oc_cwt; bool oc_affine = false;
@@ -489,7 +489,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.cwt = c->oc_cwt.p;
     a.skip = rc.skip;
     a.trust_short = c->oc_always_verify ? 0 : 1;
-    a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b;
+    a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b; a.sm_c0 = c->oc_sm_c0; a.sm_k1 = c->oc_sm_k1; a.sm_k2 = c->oc_sm_k2;
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg2<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     c->last_launched_iters = 0;
@@ -576,6 +576,26 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
                         const double sg = th / de, r0 = 1.0 / sg, r1 = 1.0 / (2.0 * sg - r0);
                         const double al = (1.0 + r1 * r0) / th + 2.0 * r1 / de, be = 2.0 * r1 / (de * th);
                         c->oc_sm_ab = al - be; c->oc_sm_b = be;
+                        // ADMM_HIP_OC_CHEB=3: three Chebyshev steps = a degree-2 polynomial Z(B) = c0 + c1 B + c2 B^2 of B = D^-1 A_bb
+                        // (two block-local products per application).  The coefficients come from running the three-term
+                        // recurrence on polynomials: z = Z(B) y, D^-1 res = R(B) y with y = D^-1 r, R = 1 - B Z.  The kernel applies
+                        // it in Horner form, Z y = c0 y + B (c1 y + c2 B y):  v1 = (c1 + c2) y + c2 N y,  Z y = c0 y + v1 + N v1,
+                        // N = D^-1 offdiag(A_bb).  An odd-degree residual polynomial keeps Z positive above the interval too.
+                        c->oc_sm_c0 = c->oc_sm_k1 = c->oc_sm_k2 = 0.0;
+                        if (ch && ch[0] == '3') {
+                            double Z[3] = {0, 0, 0}, R[3] = {1, 0, 0}, P[3] = {1, 0, 0};
+                            double alpha = 1.0 / th, beta = 0.0;
+                            for (int k = 0; k < 3; ++k) {
+                                if (k > 0) {
+                                    beta = k > 1 ? 0.25 * (de * alpha) * (de * alpha) : 0.5 * (de * alpha) * (de * alpha);
+                                    alpha = 1.0 / (th - beta / alpha);
+                                    for (int i = 0; i < 3; ++i) P[i] = R[i] + beta * P[i];
+                                }
+                                for (int i = 0; i < 3; ++i) Z[i] += alpha * P[i];
+                                for (int i = 2; i > 0; --i) R[i] -= alpha * P[i - 1];
+                            }
+                            c->oc_sm_c0 = Z[0]; c->oc_sm_k1 = Z[1] + Z[2]; c->oc_sm_k2 = Z[2];
+                        }
                     }
                 }
                 if (getenv("ADMM_HIP_OC_DIAG"))

@@ -33,6 +33,8 @@ constexpr unsigned kGspSpin = 3000000u;
 typedef __attribute__((address_space(3))) unsigned short LdsU16;
 typedef __attribute__((address_space(3))) int LdsI32;
 typedef __attribute__((address_space(3))) unsigned char LdsU8;
+typedef __attribute__((address_space(3))) Obstacles LdsObst;
+static_assert(sizeof(Obstacles) % 4 == 0 && sizeof(Obstacles) <= 384, "the LDS copy of the obstacles sits at bytes 640..1023 of the scratch area");
 
 struct GspArgs {
     int G, C;
@@ -77,6 +79,10 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     LdsI32 *ih = (LdsI32 *)(smem + 256);            // the block's header (64 ints)
     LdsI32 *ctl = (LdsI32 *)(smem + 512);           // [0] abort seen, [1] a sweep met the tolerance, [2] which one
     if (t < kGspHdrK) ih[t] = a.hdr[b * kGspHdrK + t];
+    // the passive obstacles, once per launch: read through the argument pointer, the count, kind and parameters of every obstacle were
+    // three DEPENDENT global round trips inside every row update of every phase (the polling loads' memory clobbers forbid hoisting them)
+    LdsObst *obl = (LdsObst *)(smem + 640);
+    if (t < (int)(sizeof(Obstacles) / 4)) ((LdsI32 *)obl)[t] = ((const int *)a.ob)[t];
     if (t == 0) {
         ctl[1] = 0; ctl[2] = 0;
         // a solve of this context has been given up and the host has not recovered yet (steps are issued asynchronously): nothing may
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     // row's residual of the PREVIOUS sweep before it moves (first colour: nothing has moved yet; middle colours: the neighbours that
     // have, by their parked values); 2 POST -- the residual of THIS sweep right after the update (last colour: every neighbour is
     // final).  Returns the thread's sum of squared residuals.
-    auto sweep_colour = [&](int c, int par, unsigned stamp, int role, bool keep_old) -> double {
+    auto sweep_colour = [&](int c, int par, unsigned stamp, int role, bool keep_old, bool first_sweep) -> double {
         const int r0 = ih[8 + c], n_c = ih[8 + c + 1] - r0;
         const bool both = role == 1 && c > 0;
         double rs = 0.0;
@@ -226,10 +232,24 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                 for (int q = 0; q < 3; ++q) { const double r = bi[q] - fma(aii[q], cx[q], both ? LUo[q] : LUx[q]); rs = fma(r, r, rs); }
             }
             if (pl[li]) { // :111-117
-                const int v = a.orig[row_base + li];
+#ifdef ADMM_GSP_OB_GLOBAL
+                if (true) {
+#else
+                if (first_sweep) {
+#endif
+                    const int v = a.orig[row_base + li];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
-            } else gs_relax(*a.ob, a.omega, bi, LUx, aii, cx, nx);
+                    for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
+                } else {    // the row has held its pin's position since the first sweep of this run: no trip to memory
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) nx[q] = cx[q];
+                }
+            }
+#ifdef ADMM_GSP_OB_GLOBAL      // (same-box A/B only: the obstacles through the argument pointer, as before round 4's second session)
+            else gs_relax(*a.ob, a.omega, bi, LUx, aii, cx, nx);
+#else
+            else gs_relax(*obl, a.omega, bi, LUx, aii, cx, nx);
+#endif
             if (keep_old) { xo[3 * li] = cx[0]; xo[3 * li + 1] = cx[1]; xo[3 * li + 2] = cx[2]; }
             xl[3 * li] = nx[0]; xl[3 * li + 1] = nx[1]; xl[3 * li + 2] = nx[2];
             const int o = ol[li];
@@ -358,7 +378,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                     if (C >= 2 && c == C - 1) role = 2;
                     else if (sweep > 0) role = 1;
                 }
-                racc += sweep_colour(c, sweep & 1, stamp0 + (unsigned)p, role, keep_old);
+                racc += sweep_colour(c, sweep & 1, stamp0 + (unsigned)p, role, keep_old, sweep == 0);
                 if (tests && sweep > 0 && c == c_pub) { park(racc); parked = sweep - 1; racc = 0.0; }
                 lap(2);
             }

@@ -1105,7 +1105,8 @@ __global__ __launch_bounds__(256) void k_rc_record(int n3, const double *__restr
 // is not above the current one, like every implementation in src/PassiveObject.hpp does.  Kinds: 0 Floor (:32-45), 1 Sphere (:48-64);
 // user-side PassiveCollision subclasses: 2 a plane n.x = d, 3 any object sampled on a grid at Solver::initialize
 // (admm_host_sample_obstacle: distance and normal per node, trilinear on the device, contact point = x - dx n; no hit outside the grid).
-__device__ __forceinline__ void obstacle_payload(const Obstacles &ob, int j, const double *x, double &best, double *n, double *p) {
+template <class OB>   // Obstacles in any address space (k_gs_persist keeps its copy in LDS)
+__device__ __forceinline__ void obstacle_payload(const OB &ob, int j, const double *x, double &best, double *n, double *p) {
     const int kind = ob.kind[j];
     if (kind == 0) {
         const double dx = x[1] - ob.par[j][0];
@@ -1157,7 +1158,8 @@ __device__ __forceinline__ void obstacle_payload(const Obstacles &ob, int j, con
         }
     }
 }
-__device__ __forceinline__ bool passive_hit(const Obstacles &ob, const double *x, double *n, double *p) {
+template <class OB>
+__device__ __forceinline__ bool passive_hit(const OB &ob, const double *x, double *n, double *p) {
     double best = 1.7976931348623157e308; // Payload ctor (src/Collider.hpp:73)
     for (int j = 0; j < ob.n; ++j) {
         obstacle_payload(ob, j, x, best, n, p);
@@ -1171,7 +1173,8 @@ __device__ __forceinline__ bool passive_hit(const Obstacles &ob, const double *x
 // point, no over-relaxation).  One definition with every product-sum written as an explicit fma, shared by all sweep kernels
 // (k_gs_color, k_gs_color2, k_gs_colorN, k_gs_persist): their results are bit-identical by construction, not by the compiler's
 // contraction choices.
-__device__ __forceinline__ void gs_relax(const Obstacles &ob, double omega, const double *bi, const double *LUx, const double *aii,
+template <class OB>
+__device__ __forceinline__ void gs_relax(const OB &ob, double omega, const double *bi, const double *LUx, const double *aii,
                                          const double *cx, double *nx) {
     double jac[3];
 #pragma unroll

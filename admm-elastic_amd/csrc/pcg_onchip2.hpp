@@ -56,6 +56,8 @@ struct Oc2Args {
     const unsigned short *col16;     // its local column at ptr[s] + ((k / 4) 64 + lane) 4 + k % 4
     const int *lds_off, *wl_s;       // per slice: slab offset (columns) and columns held in LDS
     double sm_ab, sm_b;              // block-local smoother S v = D^-1 (sm_ab v - sm_b offdiag(A_bb) D^-1 v); sm_b = 0: S = D^-1
+    double sm_c0, sm_k1, sm_k2;      // sm_k2 != 0: three Chebyshev steps instead of two (two products): with y = D^-1 v, N = D^-1 offdiag(A_bb):
+                                     // v1 = sm_k1 y + sm_k2 N y,  S v = sm_c0 y + v1 + N v1
     int bcols;                       // slab columns per block
     const int *orig;                 // [n_rows] vertex | aggregate << 28 (-1 = dummy row)
     const int *halo_ptr, *halo_src;  // [G + 1]; internal rows of the halo entries (sorted per block)
@@ -303,6 +305,20 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         __syncthreads();
         double acc[3] = {0.0, 0.0, 0.0};
         row_times_local_vector(acc);
+        if (a.sm_k2 != 0.0) {     // (uniform) second product: the halo part of the local vector is still zero
+            __syncthreads();
+            const int tid = otid();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vec[OC2_VX(tid, j)] = rd[j] * fma(a.sm_k2, acc[j], a.sm_k1 * v[j]);
+            __syncthreads();
+            double acc2[3] = {0.0, 0.0, 0.0};
+            row_times_local_vector(acc2);
+            const int t2 = otid();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) out[j] = fma(rd[j], fma(a.sm_c0, v[j], acc2[j]), vec[OC2_VX(t2, j)]);
+            __syncthreads();
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) out[j] = rd[j] * fma(-a.sm_b, acc[j], a.sm_ab * v[j]);
         __syncthreads();   // the local vector is rewritten by the next publish
