@@ -176,40 +176,52 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     };
     // cur = sum_k Ahat(row, k) x_k of row i of colour c (entries in CSR order: the sums of k_gs_color).  BOTH: also old = the same sum
     // with the previous sweep's values (xo) of the neighbours whose colour is below the row's (bit 15 of the column, set by the plan)
+    // (W is a multiple of four -- the plan pads rows with 0 x own value -- and the entries are taken EIGHT, then four, at a time: all
+    // columns and values of a group in one LDS round trip, all gathers in a second one, then the fma chain in CSR order.  One wave per SIMD
+    // hides nothing: the round trips of a row are its time.)
     auto row_sum = [&](int c, int i, double *cur, double *old, bool both) {
         const int n_c = ih[8 + c + 1] - ih[8 + c], W = ih[34 + c];
         const LdsD *vv = vl + ih[46 + c] + i;
         const LdsU16 *cc = cl + ih[46 + c] + i;
         cur[0] = cur[1] = cur[2] = 0.0;
+        auto group = [&](int k, auto n_tag) {
+            constexpr int N = decltype(n_tag)::value;
+            int col[N]; double av[N], g[3 * N];
+#pragma unroll
+            for (int u = 0; u < N; ++u) { col[u] = 3 * (cc[(k + u) * n_c] & 0x7fff); av[u] = vv[(k + u) * n_c]; }
+#pragma unroll
+            for (int u = 0; u < N; ++u) { g[3 * u] = xl[col[u]]; g[3 * u + 1] = xl[col[u] + 1]; g[3 * u + 2] = xl[col[u] + 2]; }
+#pragma unroll
+            for (int u = 0; u < N; ++u) { cur[0] = fma(av[u], g[3 * u], cur[0]); cur[1] = fma(av[u], g[3 * u + 1], cur[1]); cur[2] = fma(av[u], g[3 * u + 2], cur[2]); }
+        };
+        auto group_both = [&](int k, auto n_tag) {
+            constexpr int N = decltype(n_tag)::value;
+            int raw[N]; double av[N], g[3 * N], h[3 * N];
+#pragma unroll
+            for (int u = 0; u < N; ++u) { raw[u] = cc[(k + u) * n_c]; av[u] = vv[(k + u) * n_c]; }
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const int col = 3 * (raw[u] & 0x7fff);
+                g[3 * u] = xl[col]; g[3 * u + 1] = xl[col + 1]; g[3 * u + 2] = xl[col + 2];
+                h[3 * u] = xo[col]; h[3 * u + 1] = xo[col + 1]; h[3 * u + 2] = xo[col + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < N; ++u) {
+                const bool lo = (raw[u] & 0x8000) != 0;
+                cur[0] = fma(av[u], g[3 * u], cur[0]); cur[1] = fma(av[u], g[3 * u + 1], cur[1]); cur[2] = fma(av[u], g[3 * u + 2], cur[2]);
+                old[0] = fma(av[u], lo ? h[3 * u] : g[3 * u], old[0]); old[1] = fma(av[u], lo ? h[3 * u + 1] : g[3 * u + 1], old[1]);
+                old[2] = fma(av[u], lo ? h[3 * u + 2] : g[3 * u + 2], old[2]);
+            }
+        };
+        int k = 0;
         if (!both) {
-            int k = 0;
-            for (; k + 4 <= W; k += 4) {
-                int col[4]; double av[4], g[12];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { col[u] = 3 * (cc[(k + u) * n_c] & 0x7fff); av[u] = vv[(k + u) * n_c]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { g[3 * u] = xl[col[u]]; g[3 * u + 1] = xl[col[u] + 1]; g[3 * u + 2] = xl[col[u] + 2]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { cur[0] = fma(av[u], g[3 * u], cur[0]); cur[1] = fma(av[u], g[3 * u + 1], cur[1]); cur[2] = fma(av[u], g[3 * u + 2], cur[2]); }
-            }
-            for (; k < W; ++k) {
-                const int col = 3 * (cc[k * n_c] & 0x7fff);
-                const double av = vv[k * n_c];
-                cur[0] = fma(av, xl[col], cur[0]); cur[1] = fma(av, xl[col + 1], cur[1]); cur[2] = fma(av, xl[col + 2], cur[2]);
-            }
+            for (; k + 8 <= W; k += 8) group(k, std::integral_constant<int, 8>());
+            if (k < W) group(k, std::integral_constant<int, 4>());
             return;
         }
         old[0] = old[1] = old[2] = 0.0;
-        for (int k = 0; k < W; ++k) {
-            const int raw = cc[k * n_c];
-            const int col = 3 * (raw & 0x7fff);
-            const double av = vv[k * n_c];
-            const double g0 = xl[col], g1 = xl[col + 1], g2 = xl[col + 2];
-            const bool lo = (raw & 0x8000) != 0;
-            const double h0 = lo ? xo[col] : g0, h1 = lo ? xo[col + 1] : g1, h2 = lo ? xo[col + 2] : g2;
-            cur[0] = fma(av, g0, cur[0]); cur[1] = fma(av, g1, cur[1]); cur[2] = fma(av, g2, cur[2]);
-            old[0] = fma(av, h0, old[0]); old[1] = fma(av, h1, old[1]); old[2] = fma(av, h2, old[2]);
-        }
+        for (; k + 8 <= W; k += 8) group_both(k, std::integral_constant<int, 8>());
+        if (k < W) group_both(k, std::integral_constant<int, 4>());
     };
     // One colour of one sweep.  role (residual test riding on the sweep, as in k_gs_color2 / k_gs_colorN): 0 none; 1 PRE -- the
     // row's residual of the PREVIOUS sweep before it moves (first colour: nothing has moved yet; middle colours: the neighbours that

@@ -719,6 +719,7 @@ GsPlan build_gs_plan(const Csr &A, int n_colors, const int32_t *color, int max_b
                 for (int32_t q = A.rowptr[v]; q < A.rowptr[v + 1]; ++q) len += (A.col[q] != v && A.val[q] != 0.0) ? 1 : 0;
                 W = std::max(W, len);
             }
+            W = (W + 3) & ~3;      // whole groups of four entries: the kernel's row loop has no remainder loop (padding = 0 x own value)
             h[34 + c] = W; h[46 + c] = eoff;
             const size_t base = P.vals.size();
             P.vals.resize(base + (size_t)W * n_c, 0.0);
