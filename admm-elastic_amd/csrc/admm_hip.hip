@@ -523,7 +523,11 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     while (spb < 16 && (ns + spb - 1) / spb > 32 * spb) ++spb;
     G = (ns + spb - 1) / spb;
     const int T = 64 * spb;
-    const size_t lds_max = std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
+    size_t lds_max = std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
+    {   // ADMM_HIP_OC_LDS_KB=n: plan for less LDS (experiments, tests of the slab's streamed tail: more of the matrix comes from L2)
+        const char *le = getenv("ADMM_HIP_OC_LDS_KB");
+        if (le && atoi(le) >= 32) lds_max = std::min<size_t>(lds_max, (size_t)atoi(le) * 1024);
+    }
     size_t lds = 0;
     // The plan: compact blocks by graph bisection, rows sorted by length, local vector + halo list + slab in LDS,
     // two-level preconditioner (ADMM_HIP_OC_COARSE=0: Jacobi on the same layout) -- oc_plan.cpp, pcg_onchip2.hpp.
