@@ -841,7 +841,9 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     std::vector<int> miss(n_missing);
     if (hipMemcpy(miss.data(), c->uzc_miss.p, sizeof(int) * (size_t)n_missing, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     const double keep_tol = c->pcg_tol;
-    c->pcg_tol = std::min(1e-2 * keep_tol, 1e-10);
+    // tolerance of a column: a fraction of the solver's own (ADMM_HIP_UZ_COL_TOL=f, default 0.01), never looser than 1e-10
+    static const double col_factor = [] { const char *e = getenv("ADMM_HIP_UZ_COL_TOL"); const double f = e ? atof(e) : 0.01; return f > 0.0 && f <= 1.0 ? f : 0.01; }();
+    c->pcg_tol = std::min(col_factor * keep_tol, 1e-10);
     int rc = 1;
     // the solver's counters before the batch: [4] solves of this step that met their tolerance -- every column solve must add one --
     // and [72..74] the totals admm_hip_solve_totals reports, which the column solves must not show up in (the caller's solves only)
