@@ -20,6 +20,7 @@
 #include "kernels.hpp"
 #include "pcg_onchip2.hpp"
 #include "gs_persist.hpp"
+#include "uz_persist.hpp"
 
 using namespace admm_k;
 
@@ -248,6 +249,8 @@ struct admm_hip_ctx {
     bool uzc_on = false, uzc_usable = false;
     size_t uzc_cap = 0; int uzc_n = 0, uzc_n_act = 0;
     DevBuf<double> uzc_cols; DevBuf<int> uzc_slot, uzc_act, uzc_miss, uzc_info; DevBuf<unsigned char> uzc_flag;
+    // the Schur CG on the active rows as one persistent launch (uz_persist.hpp)
+    DevBuf<uint4> uzp_dbox, uzp_sbox; DevBuf<unsigned> uzp_abort; bool uzp_enabled = true; unsigned uzp_seq = 0; long long uzp_launches = 0;
     DevBuf<double> uzc_G, uzc_part, uzc_gq, uz_y0; DevBuf<int> uzc_pos;   // Schur iterations on the active vertices (kernels.hpp: k_uzc_*)
     int uzc_test_iters = 0;   // tests (ADMM_HIP_TEST_UZ_COL_ITERS=n): the column solves get n iterations, so they do not converge
     bool uzc_compact = true; int uzc_one_max = 1024, uzc_compact_max = 8192;   // (the limits are lowered by tests to reach the general paths on small scenes)
@@ -975,12 +978,46 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
         if (compact && c->uzc_part.n < needP) { c->uzc_part.release(); if (c->uzc_part.alloc(2 * needP) != hipSuccess) return -1; }
         if (compact && c->uzc_gq.n < (size_t)3 * n_act) { c->uzc_gq.release(); if (c->uzc_gq.alloc((size_t)6 * n_act) != hipSuccess) return -1; }
     }
+    // Passive rows only, <= 1024 active vertices: the whole Schur CG is ONE persistent launch (uz_persist.hpp; ADMM_HIP_UZ_PERSIST=0:
+    // two launches per iteration, as before).  Decided before the extraction: the persistent kernel takes S_ij = G_ij (n_i . n_j).
+    bool persist = compact && !dyn && c->uzp_enabled && n_act <= std::min(kUzpMaxAct, c->uzc_one_max) && c->uz_max_iters > 0 && c->uz_max_iters < 31;
+    if (persist) {
+        const int R = uzp_rows_per_block(n_act), NB = (n_act + R - 1) / R;
+        if (!c->uzp_dbox.p) {
+            if (c->uzp_dbox.alloc(2 * kUzpMaxAct) != hipSuccess || c->uzp_sbox.alloc(2 * kUzpMaxBlocks * 8) != hipSuccess || c->uzp_abort.alloc(1) != hipSuccess ||
+                c->uzp_dbox.zero() != hipSuccess || c->uzp_sbox.zero() != hipSuccess || c->uzp_abort.zero() != hipSuccess ||
+                hipFuncSetAttribute((const void *)k_uz_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void)hipGetLastError(); persist = false; c->uzp_enabled = false; }
+        }
+        if (persist && (NB > kUzpMaxBlocks || uzp_lds_bytes(n_act, R) > (size_t)(160 * 1024 - 256))) persist = false;
+    }
     if (compact) {
         if (hipMemcpyAsync(c->uz_y0.p, c->uz_y.p, nv * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
-        hipLaunchKernelGGL(k_uzc_extract, dim3((n_act + 255) / 256, n_act), dim3(256), 0, st, nv, n_act, ldG, c->uzc_act.p, c->uzc_slot.p, c->uzc_cols.p, c->uzc_G.p);
+        hipLaunchKernelGGL(k_uzc_extract, dim3((n_act + 255) / 256, n_act), dim3(256), 0, st, nv, n_act, ldG, c->uzc_act.p, c->uzc_slot.p, c->uzc_cols.p, c->uzc_G.p,
+                           persist ? c->uz_cn.p : (const double *)nullptr);
     }
     const bool skip_honoured = use_cols || (c->oc_enabled && c->oc_plan);
     if (!skip_honoured) chunk = 1;
+    if (persist) {
+        const int R = uzp_rows_per_block(n_act), NB = (n_act + R - 1) / R;
+        const size_t lds = uzp_lds_bytes(n_act, R);
+        {
+            UzpArgs ua{};
+            ua.n_act = n_act; ua.ld = ldG; ua.R = R; ua.NB = NB; ua.max_iters = c->uz_max_iters;
+            ua.act = c->uzc_act.p; ua.G = c->uzc_G.p;
+            ua.d = c->uz_d.p; ua.r = c->uz_r.p; ua.y = c->uz_y.p; ua.q3 = c->uz_q3.p;
+            ua.tol2 = tol2; ua.sc = c->uz_scal.p;
+            ua.dbox = (v4u *)c->uzp_dbox.p; ua.sbox = (v4u *)c->uzp_sbox.p;
+            ua.stamp0 = (++c->uzp_seq) * 64u;
+            ua.abort_word = c->uzp_abort.p; ua.sig = c->d_sig;
+            hipLaunchKernelGGL(k_uz_persist, dim3(NB), dim3(kUzpT), lds, st, ua);
+            c->uzp_launches += 1;
+            if (hipMemcpyAsync(&h, c->uz_scal.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+            if (hipStreamSynchronize(st) != hipSuccess) return -1;
+            if (c->h_sig && c->h_sig[2]) return -2;      // a hand-off timed out: the recovery path of an aborted on-chip solve
+            c->uzc_applies += h.iters + (h.stop ? 1 : 0);     // products S d of this solve (the stopping iteration formed one too)
+            launched = c->uz_max_iters;
+        }
+    }
     while (launched < c->uz_max_iters) {
         const int n = std::min(chunk, c->uz_max_iters - launched);
         for (int it = 0; it < n; ++it) {
@@ -1861,7 +1898,8 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 HIP_TRY(c->uzc_info.alloc(2)); HIP_TRY(c->uzc_info.zero()); HIP_TRY(c->uzc_flag.alloc(nv));
                 HIP_TRY(c->uzc_pos.alloc(nv)); HIP_TRY(c->uz_y0.alloc(nv));
                 { const char *te = getenv("ADMM_HIP_TEST_UZ_COL_ITERS"); c->uzc_test_iters = te ? atoi(te) : 0; }
-                { const char *ce = getenv("ADMM_HIP_UZ_COMPACT"); c->uzc_compact = !(ce && ce[0] == '0'); }   // 0: full-height column pass in every Schur iteration (A/B)
+                { const char *ce = getenv("ADMM_HIP_UZ_COMPACT"); c->uzc_compact = !(ce && ce[0] == '0'); }
+                { const char *pe = getenv("ADMM_HIP_UZ_PERSIST"); c->uzp_enabled = !(pe && pe[0] == '0'); }   // 0: two launches per Schur iteration (A/B, tests)   // 0: full-height column pass in every Schur iteration (A/B)
                 { const char *e1 = getenv("ADMM_HIP_UZ_ONE_MAX"), *e2 = getenv("ADMM_HIP_UZ_COMPACT_MAX");      // test hooks
                   if (e1) c->uzc_one_max = std::max(0, std::min(1024, atoi(e1))); if (e2) c->uzc_compact_max = std::max(0, atoi(e2)); }
             }
@@ -1931,9 +1969,10 @@ static int set_state_impl(admm_hip_ctx *c, const double *x, const double *v) {
     else HIP_TRY(hipMemsetAsync(c->v.p, 0, c->n3 * sizeof(double), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->h_sig && c->h_sig[2]) {   // the steps before this call hit a barrier time-out; their result is overwritten anyway
-        c->h_sig[2] = 0; c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false; c->rc_iter = 0;
+        c->h_sig[2] = 0; c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false; c->uzp_enabled = false; c->rc_iter = 0;
         if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
         if (c->gsp_abort.p) HIP_TRY(c->gsp_abort.zero());
+        if (c->uzp_abort.p) HIP_TRY(c->uzp_abort.zero());
         HIP_TRY(hipMemcpy(c->x.p, x, c->n3 * sizeof(double), hipMemcpyHostToDevice));
         if (v) HIP_TRY(hipMemcpy(c->v.p, v, c->n3 * sizeof(double), hipMemcpyHostToDevice));
         else HIP_TRY(hipMemset(c->v.p, 0, c->n3 * sizeof(double)));
@@ -2368,8 +2407,9 @@ static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
     if (c->pending.empty() || !c->bk_x.p)
         return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)");
     if (!c->oc_gave_up) fprintf(stderr, "[admm_hip] on-chip PCG: a grid barrier timed out (blocks not co-resident?) -- falling back to the launch-per-iteration PCG and replaying %d step(s)\n", (int)c->pending.size());
-    c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false;
+    c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false; c->uzp_enabled = false;
     if (c->gsp_abort.p) HIP_TRY(c->gsp_abort.zero());
+    if (c->uzp_abort.p) HIP_TRY(c->uzp_abort.zero());
     c->rc_iter = 0;      // (the stored pairs are in the on-chip kernel's internal row order: the launch path must not project on them)
     if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
     HIP_TRY(hipMemcpyAsync(c->x.p, c->bk_x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));

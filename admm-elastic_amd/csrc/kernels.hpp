@@ -1830,10 +1830,15 @@ __global__ __launch_bounds__(256) void k_uz_cols_apply(int nv, int n_act, const 
 // sums the segments, q3 = C g, alpha, y += alpha d, r -= alpha q3, the stop test, beta, d = r - beta d: UzawaCG.hpp:96-118, the
 // arithmetic of k_uz_dots / alpha / step / beta / dir on the active rows).  x is not touched inside the loop:
 // x = x0 - A^-1 C^T (y - y0) is applied once after it through the full columns (k_uz_cols_apply).
+// cn != nullptr (the persistent Schur kernel, uz_persist.hpp, passive rows only): S_ij = G_ij (n_i . n_j) instead, n = the rows of C.
 __global__ __launch_bounds__(256) void k_uzc_extract(int nv, int n_act, int ld, const int *__restrict__ act, const int *__restrict__ slot,
-                                                     const double *__restrict__ cols, double *__restrict__ G) {
+                                                     const double *__restrict__ cols, double *__restrict__ G, const double *__restrict__ cn) {
     const int j = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_act) G[(size_t)j * ld + i] = cols[(size_t)slot[act[j]] * nv + act[i]];
+    if (i >= n_act) return;
+    const int vj = act[j], vi = act[i];
+    double g = cols[(size_t)slot[vj] * nv + vi];
+    if (cn) g *= fma(cn[3 * (size_t)vi], cn[3 * (size_t)vj], fma(cn[3 * (size_t)vi + 1], cn[3 * (size_t)vj + 1], cn[3 * (size_t)vi + 2] * cn[3 * (size_t)vj + 2]));
+    G[(size_t)j * ld + i] = g;
 }
 // part[s][i][:] = sum over the j of segment s of G[j][i] t_j; t_j = q1[act_j] (q1 = C^T d formed by the dense kernels: scenes with
 // dynamic rows) or cn[act_j] d[act_j] (passive rows only: q1 == nullptr).  Block = 64 i x 4 waves (wave w: j = w, w + 4, ...).
