@@ -244,7 +244,7 @@ struct admm_hip_ctx {
     // UzawaCG (per-vertex constraint rows)
     DevBuf<double> uz_cn, uz_cc, uz_y, uz_r, uz_d, uz_q3, uz_q1, uz_q2, uz_part, uz_dmax; DevBuf<long long> uz_dacc;   // uz_dacc / uz_dmax: dyn_collide.hpp, k_uz_ct_dyn
     DevBuf<UzScal> uz_scal;
-    int uz_prev_hits = -1, uz_last_hits = 0, NBU = 1, uz_iters_step = 0, uz_prev_iters = 0;
+    int uz_prev_hits = -1, uz_last_hits = 0, NBU = 1, uz_iters_step = 0, uz_prev_iters = 0; bool uz_hits_cleared = false;
     // cached columns of K^-1 for the Schur iterations (kernels.hpp: k_uz_cols_apply).  uzc_slot_h[v] = column slot of vertex v or -1.
     bool uzc_on = false, uzc_usable = false;
     size_t uzc_cap = 0; int uzc_n = 0, uzc_n_act = 0;
@@ -910,7 +910,9 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
         // Collider::detect at the current iterate + ConstraintSet::make_matrix (ck = sqrt(constraint_w))
         const double ck = std::sqrt(std::max(0.0, c->constraint_w));
         if (c->timing && hipEventRecord(c->ev_coll0, st) != hipSuccess) return -1;
-        if (hipMemsetAsync(c->counters.p + 6, 0, sizeof(int), st) != hipSuccess) return -1;
+        // (counters[6], the hit count: cleared by k_uz_act_compact after it has been read when the column cache is on -- see below)
+        if ((!c->uzc_on || !c->uz_hits_cleared) && hipMemsetAsync(c->counters.p + 6, 0, sizeof(int), st) != hipSuccess) return -1;
+        c->uz_hits_cleared = false;
         if (c->obst.n > 0)
             hipLaunchKernelGGL(k_uz_detect, dim3(gv), dim3(256), 0, st, nv, x, c->obst, ck, c->uz_cn.p, c->uz_cc.p, c->counters.p + 6,
                                c->n_surf > 0 ? c->surf_mask.p : nullptr);
@@ -922,15 +924,19 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
                                c->counters.p + 6);
         }
         if (c->timing && hipEventRecord(c->ev_coll1, st) != hipSuccess) return -1;
-        int info[2] = {0, 0};
-        if (c->uzc_on) {   // the vertices C^T touches (ascending), and those without a cached column
-            if (hipMemsetAsync(c->uzc_flag.p, 0, nv, st) != hipSuccess) return -1;
-            hipLaunchKernelGGL(k_uz_act_flags, dim3(gv), dim3(256), 0, st, nv, c->uz_cn.p, dface, c->uzc_flag.p);
-            hipLaunchKernelGGL(k_uz_act_compact, dim3(1), dim3(1024), 0, st, nv, c->uzc_flag.p, c->uzc_slot.p, c->uzc_act.p, c->uzc_miss.p, c->uzc_pos.p, c->uzc_info.p);
+        int info[3] = {0, 0, 0};
+        if (c->uzc_on) {   // the vertices C^T touches (ascending), and those without a cached column; the hit count rides along
+            if (dyn) {     // (a dynamic row also activates the three vertices of its face: flag pass)
+                if (hipMemsetAsync(c->uzc_flag.p, 0, nv, st) != hipSuccess) return -1;
+                hipLaunchKernelGGL(k_uz_act_flags, dim3(gv), dim3(256), 0, st, nv, c->uz_cn.p, dface, c->uzc_flag.p);
+            }
+            hipLaunchKernelGGL(k_uz_act_compact, dim3(1), dim3(1024), 0, st, nv, dyn ? c->uzc_flag.p : (const unsigned char *)nullptr, c->uzc_slot.p, c->uzc_act.p,
+                               c->uzc_miss.p, c->uzc_pos.p, c->uzc_info.p, c->uz_cn.p, c->counters.p + 6);
+            c->uz_hits_cleared = true;
             if (hipMemcpyAsync(info, c->uzc_info.p, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-        }
-        if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+        } else if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (c->uzc_on) nh = info[2];
         if (c->uzc_on) {
             c->uzc_n_act = info[0];
             c->uzc_usable = false;
@@ -950,8 +956,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     // (ADMM_HIP_UZ_RECYCLE=0: plain warm start, as in rounds 1-2)
     static const bool uz_rc = [] { const char *e = getenv("ADMM_HIP_UZ_RECYCLE"); return !(e && e[0] == '0'); }();
     if (uz_rc ? launch_pcg_recycled(c, c->uz_q1.p, x) : launch_pcg(c, c->uz_q1.p, x, c->pcg_max_iters)) return -1;
-    hipLaunchKernelGGL(k_uz_resid, dim3(gv), dim3(256), 0, st, nv, x, c->uz_cn.p, c->uz_cc.p, c->uz_r.p, c->uz_d.p, dface, dbary);
-    if (hipMemsetAsync(c->uz_scal.p, 0, sizeof(UzScal), st) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_uz_resid, dim3(gv), dim3(256), 0, st, nv, x, c->uz_cn.p, c->uz_cc.p, c->uz_r.p, c->uz_d.p, dface, dbary, c->uz_scal.p);
     const double tol2 = c->uz_tol * c->uz_tol;
     UzScal h{};
     // Schur-complement CG (src/UzawaCG.hpp:92-120).  The stop decision is taken on the device (k_uz_beta / k_uz_alpha set
@@ -1895,7 +1900,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
             if (c->uzc_on) {
                 c->uzc_slot_h.assign(nv, -1);
                 HIP_TRY(c->uzc_slot.upload(c->uzc_slot_h)); HIP_TRY(c->uzc_act.alloc(nv)); HIP_TRY(c->uzc_miss.alloc(nv));
-                HIP_TRY(c->uzc_info.alloc(2)); HIP_TRY(c->uzc_info.zero()); HIP_TRY(c->uzc_flag.alloc(nv));
+                HIP_TRY(c->uzc_info.alloc(4)); HIP_TRY(c->uzc_info.zero()); HIP_TRY(c->uzc_flag.alloc(nv));
                 HIP_TRY(c->uzc_pos.alloc(nv)); HIP_TRY(c->uz_y0.alloc(nv));
                 { const char *te = getenv("ADMM_HIP_TEST_UZ_COL_ITERS"); c->uzc_test_iters = te ? atoi(te) : 0; }
                 { const char *ce = getenv("ADMM_HIP_UZ_COMPACT"); c->uzc_compact = !(ce && ce[0] == '0'); }

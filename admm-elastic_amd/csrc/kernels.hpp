@@ -1618,7 +1618,8 @@ __global__ __launch_bounds__(256) void k_uz_ct(int nv, int mode, const double *_
 // r = C x - c ; d = r ; also clears y when the number of hits changed (UzawaCG.hpp:74)
 __global__ __launch_bounds__(256) void k_uz_resid(int nv, const double *__restrict__ x, const double *__restrict__ cn,
                                                   const double *__restrict__ cc, double *__restrict__ r, double *__restrict__ d,
-                                                  const int *__restrict__ dface, const double *__restrict__ dbary) {
+                                                  const int *__restrict__ dface, const double *__restrict__ dbary, UzScal *__restrict__ sc) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *sc = UzScal{};      // the scalars of the Schur CG this kernel opens (instead of a memset)
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= nv) return;
     const double rv = cn[3 * (size_t)v] * x[3 * (size_t)v] + cn[3 * (size_t)v + 1] * x[3 * (size_t)v + 1] +
@@ -1723,8 +1724,11 @@ __global__ __launch_bounds__(256) void k_uz_act_flags(int nv, const double *__re
 // One block: the flagged vertices in ascending order (the order of the sums in k_uz_cols_apply / k_uzc_matvec: deterministic),
 // those of them that have no column yet, and the inverse map pos[v] = place of v in the list (-1: not active).
 // info[0] = active vertices, info[1] = missing columns.  Four consecutive vertices per thread and pass.
+// flag == nullptr (passive rows only): a vertex is active iff its row of C is not zero -- read from cn directly (no flag pass, no memset).
+// nhits != nullptr: info[2] = *nhits, and the counter is cleared for the next detect (one read-back instead of two, no memset).
 __global__ __launch_bounds__(1024) void k_uz_act_compact(int nv, const unsigned char *__restrict__ flag, const int *__restrict__ slot,
-                                                         int *__restrict__ act, int *__restrict__ miss, int *__restrict__ pos, int *__restrict__ info) {
+                                                         int *__restrict__ act, int *__restrict__ miss, int *__restrict__ pos, int *__restrict__ info,
+                                                         const double *__restrict__ cn = nullptr, int *__restrict__ nhits = nullptr) {
     __shared__ int wsum[2][16], base[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < 2) base[tid] = 0;
@@ -1735,7 +1739,8 @@ __global__ __launch_bounds__(1024) void k_uz_act_compact(int nv, const unsigned 
         int na = 0, nm = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            a[k] = vb + k < nv && flag[vb + k] != 0;
+            if (flag) a[k] = vb + k < nv && flag[vb + k] != 0;
+            else a[k] = vb + k < nv && (cn[3 * (size_t)(vb + k)] != 0.0 || cn[3 * (size_t)(vb + k) + 1] != 0.0 || cn[3 * (size_t)(vb + k) + 2] != 0.0);
             m[k] = a[k] && slot[vb + k] < 0;
             na += a[k] ? 1 : 0; nm += m[k] ? 1 : 0;
         }
@@ -1760,7 +1765,7 @@ __global__ __launch_bounds__(1024) void k_uz_act_compact(int nv, const unsigned 
         if (tid == 0) { int ta = 0, tm = 0; for (int w = 0; w < 16; ++w) { ta += wsum[0][w]; tm += wsum[1][w]; } base[0] += ta; base[1] += tm; }
         __syncthreads();
     }
-    if (tid == 0) { info[0] = base[0]; info[1] = base[1]; }
+    if (tid == 0) { info[0] = base[0]; info[1] = base[1]; if (nhits) { info[2] = *nhits; *nhits = 0; } }
 }
 // unit right-hand sides of one column solve: axis j of the launch solves K g = e_(v_j)  (rhs zeroed by the caller; v_j < 0: none)
 __global__ void k_uz_unit_rhs(int v0, int v1, int v2, double *__restrict__ rhs) {
