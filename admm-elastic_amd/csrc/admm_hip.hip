@@ -985,6 +985,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     }
     // Passive rows only, <= 1024 active vertices: the whole Schur CG is ONE persistent launch (uz_persist.hpp; ADMM_HIP_UZ_PERSIST=0:
     // two launches per iteration, as before).  Decided before the extraction: the persistent kernel takes S_ij = G_ij (n_i . n_j).
+    bool persist_launched = false;
     bool persist = compact && !dyn && c->uzp_enabled && n_act <= std::min(kUzpMaxAct, c->uzc_one_max) && c->uz_max_iters > 0 && c->uz_max_iters < 31;
     if (persist) {
         const int R = uzp_rows_per_block(n_act), NB = (n_act + R - 1) / R;
@@ -1012,14 +1013,14 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
             ua.d = c->uz_d.p; ua.r = c->uz_r.p; ua.y = c->uz_y.p; ua.q3 = c->uz_q3.p;
             ua.tol2 = tol2; ua.sc = c->uz_scal.p;
             ua.dbox = (v4u *)c->uzp_dbox.p; ua.sbox = (v4u *)c->uzp_sbox.p;
-            ua.stamp0 = (++c->uzp_seq) * 64u;
+            ua.stamp0 = (++c->uzp_seq) * 128u;
             ua.abort_word = c->uzp_abort.p; ua.sig = c->d_sig;
+            ua.iters_step = c->counters.p + 7; ua.applies_total = c->counters.p + 76;
             hipLaunchKernelGGL(k_uz_persist, dim3(NB), dim3(kUzpT), lds, st, ua);
             c->uzp_launches += 1;
-            if (hipMemcpyAsync(&h, c->uz_scal.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-            if (hipStreamSynchronize(st) != hipSuccess) return -1;
-            if (c->h_sig && c->h_sig[2]) return -2;      // a hand-off timed out: the recovery path of an aborted on-chip solve
-            c->uzc_applies += h.iters + (h.stop ? 1 : 0);     // products S d of this solve (the stopping iteration formed one too)
+            // No synchronisation: the verdict stays on the device, the iteration count goes to counters[7] (read with the step's
+            // statistics), a hand-off time-out shows at the next synchronisation like any aborted on-chip solve.
+            persist_launched = true;
             launched = c->uz_max_iters;
         }
     }
@@ -1075,6 +1076,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
                            c->uz_q1.p, c->uz_q2.p, (const int *)nullptr);
         hipLaunchKernelGGL(k_uzc_xsub, dim3(blocks_for(c->n3)), dim3(256), 0, st, c->n3, x, c->uz_q2.p);
     }
+    if (persist_launched) { *iters = 0; return 0; }      // (counted on the device)
     c->uz_prev_iters = h.iters;
     *iters = h.iters;
     return 0;
@@ -2311,6 +2313,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         }
     }
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
+    if (c->linsolver == 2) HIP_TRY(hipMemsetAsync(c->counters.p + 7, 0, sizeof(int), st));   // Schur iterations of the persistent launches (uz_persist.hpp)
     if (c->wind_n > 0) {   // ExplicitForce::project of the wind, Solver.cpp:54 (before gravity and the prediction)
         hipLaunchKernelGGL(k_wind_tris, dim3(blocks_for(c->wind_n)), dim3(256), 0, st, c->wind_n, c->wind_tris.p, c->x.p, c->v.p,
                            c->wind_dir[0], c->wind_dir[1], c->wind_dir[2], c->dt, c->wind_force.p);
@@ -2381,7 +2384,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         stats->admm_iters = admm_iters;
         if (c->linsolver == 1) { stats->inner_iters = h[0]; stats->last_solve_converged = h[1] != 0; }   // (the done word carries the stamp of the launch that raised it)
         else if (c->linsolver == 2) {
-            stats->inner_iters = c->uz_iters_step; // the reference counts Schur-CG iterations (UzawaCG.hpp:124)
+            stats->inner_iters = c->uz_iters_step + h[7]; // the reference counts Schur-CG iterations (UzawaCG.hpp:124); h[7]: those of the persistent launches
             stats->n_constraints = c->uz_last_hits;
             stats->last_solve_converged = sc[c->last_launched_iters & 1].converged;
             stats->pcg_launched_iters = c->last_launched_iters;
@@ -2533,6 +2536,7 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     c->uz_iters_step = 0;
     c->rc_prev_valid = 0; c->rc_prev2_valid = 0; c->rc_frame += 1; c->rc_iter = 0;   // stand-alone solve: nothing to recycle
     HIP_TRY(hipMemsetAsync(c->counters.p, 0, 5 * sizeof(int), st));
+    if (c->linsolver == 2) HIP_TRY(hipMemsetAsync(c->counters.p + 7, 0, sizeof(int), st));   // Schur iterations of the persistent launches (uz_persist.hpp)
     if (launch_global(c, c->b.p, c->curr.p)) return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(x_inout, c->curr.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -2540,7 +2544,7 @@ int admm_hip_global_solve(admm_hip_ctx *c, const double *b, double *x_inout, int
     HIP_TRY(hipMemcpyAsync(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)"); }
-    if (iters) *iters = (c->linsolver == 1) ? h[2] : (c->linsolver == 2 ? c->uz_iters_step : h[0]);
+    if (iters) *iters = (c->linsolver == 1) ? h[2] : (c->linsolver == 2 ? c->uz_iters_step + h[7] : h[0]);
     return ADMM_HIP_OK;
 }
 
@@ -2755,7 +2759,13 @@ int admm_hip_uzawa_cache_stats(admm_hip_ctx *c, int64_t *columns, int64_t *colum
         if (c->uzc_on) { int64_t n = 0; for (int s : c->uzc_slot_h) n += s >= 0 ? 1 : 0; *columns = n; }
     }
     if (column_solves) *column_solves = c->uzc_col_solves;
-    if (schur_from_columns) *schur_from_columns = c->uzc_applies;
+    if (schur_from_columns) {
+        int dev = 0;      // the persistent Schur launches count on the device
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(&dev, c->counters.p + 76, sizeof(int), hipMemcpyDeviceToHost));
+        *schur_from_columns = c->uzc_applies + dev;
+    }
     if (schur_by_pcg) *schur_by_pcg = c->uzc_pcg_solves;
     if (evicted) *evicted = c->uzc_evictions;
     return ADMM_HIP_OK;

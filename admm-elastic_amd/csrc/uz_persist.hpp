@@ -11,9 +11,11 @@
 //   * every block adds the same partial sums in the same order: identical alpha / beta / verdicts everywhere, deterministic;
 //   * r.r and r.q3 of the UPDATED r (the stop test :112 and beta :115) come from the same round of sums as alpha:
 //         r' = r - alpha q3   =>   r'.q3 = r.q3 - alpha q3.q3,   r'.r' = r.r - 2 alpha r.q3 + alpha^2 q3.q3
-//     (one hand-off instead of two; a Schur iteration shrinks |r|^2 by ~10x, so the cancellation costs one digit of sixteen);
+//     (one hand-off instead of two; a typical Schur iteration shrinks |r|^2 by ~10x, so the cancellation costs one digit of sixteen;
+//     a step that shrinks it by more than 1e3 -- small active sets -- forms both from the updated r in a second round instead);
 //   * x is not touched: x = x0 - A^-1 C^T (y - y0) is applied once after the loop (launch_uzawa), as with the two-launch iterations;
-//   * every poll is bounded: a hand-off that cannot complete raises the abort word and sig[2], the host takes the recovery path.
+//   * every poll is bounded: a hand-off that cannot complete raises the abort word and sig[2], the host takes the recovery path;
+//   * the host does not wait for the launch: the stop verdict stays on the device, the iteration count goes to a device counter.
 // Passive rows only (a dynamic row couples four vertices: the two-launch path keeps those), n_act <= 1024.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -31,8 +33,9 @@ struct UzpArgs {
     double tol2; UzScal *sc;
     v4u *dbox;                             // [2][kUzpMaxAct] granules: d of an iteration, by parity
     v4u *sbox;                             // [2][kUzpMaxBlocks][8] granules: the blocks' five partial sums, by parity
-    unsigned stamp0;                       // solve number x 64: stamps of this launch are stamp0 + 2 k (+ 1)
+    unsigned stamp0;                       // solve number x 128: stamps of this launch are stamp0 + 4 k + {0: d, 1: sums, 2: exact r.r / r.q3}
     unsigned *abort_word; int *sig;
+    int *iters_step, *applies_total;       // device-side statistics (the host does not wait for the launch): Schur iterations of this step; products S d since create
 };
 
 inline int uzp_rows_per_block(int n_act) { return n_act <= 800 ? 16 : 8; }
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(kUzpT) void k_uz_persist(UzpArgs a) {
     for (int k = 0; k < a.max_iters; ++k) {
         const int par = k & 1;
         if (k > 0) {      // d of this iteration from every block
-            const unsigned want = a.stamp0 + 2u * (unsigned)k;
+            const unsigned want = a.stamp0 + 4u * (unsigned)k;
             for (int j = t; j < n; j += kUzpT) {
                 v4u g; unsigned spins = 0;
                 while (true) { g = gsp_load(rd, (par * kUzpMaxAct + j) * 16); if (gsp_ok(g, want) || poll_failed(spins)) break; }
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(kUzpT) void k_uz_persist(UzpArgs a) {
             red[0 * 16 + r_] = 0.0; red[1 * 16 + r_] = 0.0; red[2 * 16 + r_] = 0.0; red[3 * 16 + r_] = 0.0; red[4 * 16 + r_] = 0.0;
         }
         __syncthreads();
-        const unsigned sw = a.stamp0 + 2u * (unsigned)k + 1u;
+        const unsigned sw = a.stamp0 + 4u * (unsigned)k + 1u;
         if (t < 5) {
             double s = 0.0;
             for (int q = 0; q < R; ++q) s += red[t * 16 + q];
@@ -152,12 +155,40 @@ __global__ __launch_bounds__(kUzpT) void k_uz_persist(UzpArgs a) {
         alpha = dr / denom;                                                               // :104
         if (leader) { yi = fma(alpha, di, yi); ri = fma(-alpha, qi, ri); }                // :106-107 (x: after the loop)
         rr_new = fma(alpha * alpha, qq, fma(-2.0 * alpha, rq, rr));
-        if (rr_new < 0.0) rr_new = 0.0;
+        double rq_new = rq - alpha * qq;
+        if (!(rr_new > 1e-3 * rr)) {
+            // A step that takes |r|^2 down by more than three orders (small active sets converge superlinearly) leaves the expansions
+            // above with few correct digits -- or none, and a stop that is not one.  Then r.r and r.q3 are formed from the updated r
+            // itself, in a second round of sums (every block sees the same numbers and takes the same branch).
+            __syncthreads();      // (tot has been read by everybody)
+            if (l == 0) { red[0 * 16 + r_] = leader ? ri * ri : 0.0; red[1 * 16 + r_] = leader ? ri * qi : 0.0; }
+            __syncthreads();
+            const unsigned s2 = a.stamp0 + 4u * (unsigned)k + 2u;
+            if (t < 2) {
+                double sm = 0.0;
+                for (int q = 0; q < R; ++q) sm += red[t * 16 + q];
+                gsp_store(rs, ((par * kUzpMaxBlocks + b) * 8 + 5 + t) * 16, gsp_pack(sm, s2));
+            }
+            if (t < 128) {
+                const int q = t >> 6, lane = t & 63;
+                double v = 0.0;
+                for (int bb = lane; bb < a.NB; bb += 64) {
+                    v4u g; unsigned spins = 0;
+                    while (true) { g = gsp_load(rs, ((par * kUzpMaxBlocks + bb) * 8 + 5 + q) * 16); if (gsp_ok(g, s2) || poll_failed(spins)) break; }
+                    v += gsp_val(g);
+                }
+                v = wave_sum(v);
+                if (lane == 0) tot[q] = v;
+            }
+            __syncthreads();
+            if (ctl[0]) return;
+            rr_new = tot[0]; rq_new = tot[1];
+        }
         if (rr_new < a.tol2) { stop = 1; break; }                                         // :112
-        beta = (rq - alpha * qq) / denom;                                                 // :115
+        beta = rq_new / denom;                                                            // :115
         if (leader) {
             di = fma(-beta, di, ri);                                                      // :117
-            if (k + 1 < a.max_iters) gsp_store(rd, (((k + 1) & 1) * kUzpMaxAct + i) * 16, gsp_pack(di, a.stamp0 + 2u * (unsigned)(k + 1)));
+            if (k + 1 < a.max_iters) gsp_store(rd, (((k + 1) & 1) * kUzpMaxAct + i) * 16, gsp_pack(di, a.stamp0 + 4u * (unsigned)(k + 1)));
         }
         ++iters;
         __syncthreads();      // red / tot are rewritten by the next iteration
@@ -165,6 +196,7 @@ __global__ __launch_bounds__(kUzpT) void k_uz_persist(UzpArgs a) {
     if (leader) { a.y[vi] = yi; a.r[vi] = ri; a.d[vi] = di; a.q3[vi] = qi; }
     if (b == 0 && t == 0) {
         a.sc->denom = denom; a.sc->alpha = alpha; a.sc->beta = beta; a.sc->rr = rr_new; a.sc->stop = stop; a.sc->iters += iters;
+        *a.iters_step += iters; *a.applies_total += iters + stop;
     }
 }
 

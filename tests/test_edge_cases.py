@@ -177,10 +177,16 @@ class _UserSphere:
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ls", [1, 2])
-def test_plane_obstacle_equals_floor_and_oracle(ls):
+def test_plane_obstacle_equals_floor_and_oracle(ls, monkeypatch):
     """ADMM_OBJ_PLANE: the half space n.x < d.  With n = (0, 1, 0) it is the reference's Floor (src/PassiveObject.hpp:32-45) up to the
-    rounding of x - dx n; a tilted plane is checked against the oracle's restatement of the same object, whole steps."""
+    rounding of x - dx n; a tilted plane is checked against the oracle's restatement of the same object, whole steps.
+    UzawaCG (ls = 2): the active set is frozen per step (one Collider::detect per step, as in test_step_uzawa_frozen_active_set_is_tight).
+    Free-running, a vertex that rests ON the floor is detected or not by the last bit of its height, and the one-ulp difference between the
+    two contact points decides that differently from some frame on in EVERY solver variant (experiments/plane_floor_sensitivity.py: floor
+    heights -0.01 / -0.0123, cached columns or inner solves, persistent Schur kernel or two launches per iteration: 3e-5 at step 2-4)."""
     from admm_elastic_amd.solver import Plane
+    if ls == 2:
+        monkeypatch.setenv("ADMM_HIP_UZ_FREEZE", "1")
     sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=8, linsolver=ls, size=0.5)
     sc.pins.clear()
     res = []
