@@ -250,7 +250,7 @@ struct admm_hip_ctx {
     size_t uzc_cap = 0; int uzc_n = 0, uzc_n_act = 0;
     DevBuf<double> uzc_cols; DevBuf<int> uzc_slot, uzc_act, uzc_miss, uzc_info; DevBuf<unsigned char> uzc_flag;
     // the Schur CG on the active rows as one persistent launch (uz_persist.hpp)
-    DevBuf<uint4> uzp_dbox, uzp_sbox; DevBuf<unsigned> uzp_abort; bool uzp_enabled = true; unsigned uzp_seq = 0; long long uzp_launches = 0;
+    DevBuf<uint4> uzp_dbox, uzp_sbox; DevBuf<unsigned> uzp_abort; bool uzp_enabled = true; unsigned uzp_seq = 0; long long uzp_launches = 0; int uzp_rows = 0;   // uzp_rows: 8 | 16 forced (ADMM_HIP_UZ_PERSIST_ROWS, tests)
     DevBuf<double> uzc_G, uzc_part, uzc_gq, uz_y0; DevBuf<int> uzc_pos;   // Schur iterations on the active vertices (kernels.hpp: k_uzc_*)
     int uzc_test_iters = 0;   // tests (ADMM_HIP_TEST_UZ_COL_ITERS=n): the column solves get n iterations, so they do not converge
     bool uzc_compact = true; int uzc_one_max = 1024, uzc_compact_max = 8192;   // (the limits are lowered by tests to reach the general paths on small scenes)
@@ -988,7 +988,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     bool persist_launched = false;
     bool persist = compact && !dyn && c->uzp_enabled && n_act <= std::min(kUzpMaxAct, c->uzc_one_max) && c->uz_max_iters > 0 && c->uz_max_iters < 31;
     if (persist) {
-        const int R = uzp_rows_per_block(n_act), NB = (n_act + R - 1) / R;
+        const int R = c->uzp_rows > 0 ? c->uzp_rows : uzp_rows_per_block(n_act), NB = (n_act + R - 1) / R;
         if (!c->uzp_dbox.p) {
             if (c->uzp_dbox.alloc(2 * kUzpMaxAct) != hipSuccess || c->uzp_sbox.alloc(2 * kUzpMaxBlocks * 8) != hipSuccess || c->uzp_abort.alloc(1) != hipSuccess ||
                 c->uzp_dbox.zero() != hipSuccess || c->uzp_sbox.zero() != hipSuccess || c->uzp_abort.zero() != hipSuccess ||
@@ -1004,7 +1004,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     const bool skip_honoured = use_cols || (c->oc_enabled && c->oc_plan);
     if (!skip_honoured) chunk = 1;
     if (persist) {
-        const int R = uzp_rows_per_block(n_act), NB = (n_act + R - 1) / R;
+        const int R = c->uzp_rows > 0 ? c->uzp_rows : uzp_rows_per_block(n_act), NB = (n_act + R - 1) / R;
         const size_t lds = uzp_lds_bytes(n_act, R);
         {
             UzpArgs ua{};
@@ -1151,7 +1151,6 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
 // the whole solve as ONE persistent launch (gs_persist.hpp)
 void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
     hipStream_t st = c->stream;
-    (void)hipMemsetAsync(c->counters.p + 1, 0, 2 * sizeof(int), st);
     GspArgs a{};
     a.G = c->gsp_G; a.C = c->gsp_C;
     a.hdr = c->gsp_hdr.p; a.orig = c->gsp_orig.p; a.out_idx = c->gsp_out.p; a.halo_box = c->gsp_hbox.p; a.halo_orig = c->gsp_horig.p;
@@ -1906,7 +1905,8 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 HIP_TRY(c->uzc_pos.alloc(nv)); HIP_TRY(c->uz_y0.alloc(nv));
                 { const char *te = getenv("ADMM_HIP_TEST_UZ_COL_ITERS"); c->uzc_test_iters = te ? atoi(te) : 0; }
                 { const char *ce = getenv("ADMM_HIP_UZ_COMPACT"); c->uzc_compact = !(ce && ce[0] == '0'); }
-                { const char *pe = getenv("ADMM_HIP_UZ_PERSIST"); c->uzp_enabled = !(pe && pe[0] == '0'); }   // 0: two launches per Schur iteration (A/B, tests)   // 0: full-height column pass in every Schur iteration (A/B)
+                { const char *pe = getenv("ADMM_HIP_UZ_PERSIST"); c->uzp_enabled = !(pe && pe[0] == '0'); }
+                { const char *pr = getenv("ADMM_HIP_UZ_PERSIST_ROWS"); c->uzp_rows = (pr && (atoi(pr) == 8 || atoi(pr) == 16)) ? atoi(pr) : 0; }   // 0: two launches per Schur iteration (A/B, tests)   // 0: full-height column pass in every Schur iteration (A/B)
                 { const char *e1 = getenv("ADMM_HIP_UZ_ONE_MAX"), *e2 = getenv("ADMM_HIP_UZ_COMPACT_MAX");      // test hooks
                   if (e1) c->uzc_one_max = std::max(0, std::min(1024, atoi(e1))); if (e2) c->uzc_compact_max = std::max(0, atoi(e2)); }
             }

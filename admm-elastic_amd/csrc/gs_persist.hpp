@@ -455,8 +455,8 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
         for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = xl[3 * i + q];
     }
     if (b == 0 && t == 0) {
-        if (conv_flag) *a.done = 1;
-        atomicAdd(a.sweeps, failed_tests); atomicAdd(a.total, failed_tests);
+        *a.done = conv_flag; *a.sweeps = failed_tests;      // (stored, not accumulated: the launch needs no memset in front of it)
+        atomicAdd(a.total, failed_tests);
     }
 }
 
