@@ -248,7 +248,8 @@ struct admm_hip_ctx {
     // cached columns of K^-1 for the Schur iterations (kernels.hpp: k_uz_cols_apply).  uzc_slot_h[v] = column slot of vertex v or -1.
     bool uzc_on = false, uzc_usable = false;
     size_t uzc_cap = 0; int uzc_n = 0, uzc_n_act = 0;
-    DevBuf<double> uzc_cols; DevBuf<int> uzc_slot, uzc_act, uzc_miss, uzc_info; DevBuf<unsigned char> uzc_flag;
+    DevBuf<double> uzc_cols; DevBuf<int> uzc_slot, uzc_act, uzc_miss, uzc_info, uzc_counts; DevBuf<unsigned char> uzc_flag;
+    int uzc_one_block_max = 4;      // active list by ONE block up to this many passes of 4096 vertices (ADMM_HIP_UZ_LIST_BLOCKS: tests)
     // the Schur CG on the active rows as one persistent launch (uz_persist.hpp)
     DevBuf<uint4> uzp_dbox, uzp_sbox; DevBuf<unsigned> uzp_abort; bool uzp_enabled = true; unsigned uzp_seq = 0; long long uzp_launches = 0; int uzp_rows = 0;   // uzp_rows: 8 | 16 forced (ADMM_HIP_UZ_PERSIST_ROWS, tests)
     DevBuf<double> uzc_G, uzc_part, uzc_gq, uz_y0; DevBuf<int> uzc_pos;   // Schur iterations on the active vertices (kernels.hpp: k_uzc_*)
@@ -311,7 +312,7 @@ struct admm_hip_ctx {
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
-        uzc_cols.release(); uzc_slot.release(); uzc_act.release(); uzc_miss.release(); uzc_info.release(); uzc_flag.release();
+        uzc_cols.release(); uzc_slot.release(); uzc_act.release(); uzc_miss.release(); uzc_info.release(); uzc_counts.release(); uzc_flag.release();
         uzc_G.release(); uzc_part.release(); uzc_gq.release(); uz_y0.release(); uzc_pos.release();
         gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
         lk_ts.release(); lk_out.release();
@@ -930,8 +931,17 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
                 if (hipMemsetAsync(c->uzc_flag.p, 0, nv, st) != hipSuccess) return -1;
                 hipLaunchKernelGGL(k_uz_act_flags, dim3(gv), dim3(256), 0, st, nv, c->uz_cn.p, dface, c->uzc_flag.p);
             }
-            hipLaunchKernelGGL(k_uz_act_compact, dim3(1), dim3(1024), 0, st, nv, dyn ? c->uzc_flag.p : (const unsigned char *)nullptr, c->uzc_slot.p, c->uzc_act.p,
-                               c->uzc_miss.p, c->uzc_pos.p, c->uzc_info.p, c->uz_cn.p, c->counters.p + 6);
+            const unsigned char *fl = dyn ? c->uzc_flag.p : (const unsigned char *)nullptr;
+            const int nbc = (nv + 4095) / 4096;
+            if (nbc <= c->uzc_one_block_max)
+                hipLaunchKernelGGL(k_uz_act_compact, dim3(1), dim3(1024), 0, st, nv, fl, c->uzc_slot.p, c->uzc_act.p,
+                                   c->uzc_miss.p, c->uzc_pos.p, c->uzc_info.p, c->uz_cn.p, c->counters.p + 6);
+            else {      // many blocks: counts, then placement behind the blocks before (kernels.hpp)
+                if (c->uzc_counts.n < (size_t)2 * nbc) { c->uzc_counts.release(); if (c->uzc_counts.alloc((size_t)2 * nbc) != hipSuccess) return -1; }
+                hipLaunchKernelGGL(k_uz_act_count, dim3(nbc), dim3(1024), 0, st, nv, fl, c->uzc_slot.p, c->uz_cn.p, c->uzc_counts.p);
+                hipLaunchKernelGGL(k_uz_act_scatter, dim3(nbc), dim3(1024), 0, st, nv, fl, c->uzc_slot.p, c->uz_cn.p, c->uzc_counts.p, c->uzc_act.p,
+                                   c->uzc_miss.p, c->uzc_pos.p, c->uzc_info.p, c->counters.p + 6);
+            }
             c->uz_hits_cleared = true;
             if (hipMemcpyAsync(info, c->uzc_info.p, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         } else if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
@@ -1906,6 +1916,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 { const char *te = getenv("ADMM_HIP_TEST_UZ_COL_ITERS"); c->uzc_test_iters = te ? atoi(te) : 0; }
                 { const char *ce = getenv("ADMM_HIP_UZ_COMPACT"); c->uzc_compact = !(ce && ce[0] == '0'); }
                 { const char *pe = getenv("ADMM_HIP_UZ_PERSIST"); c->uzp_enabled = !(pe && pe[0] == '0'); }
+                { const char *lb = getenv("ADMM_HIP_UZ_LIST_BLOCKS"); if (lb) c->uzc_one_block_max = std::max(0, atoi(lb)); }
                 { const char *pr = getenv("ADMM_HIP_UZ_PERSIST_ROWS"); c->uzp_rows = (pr && (atoi(pr) == 8 || atoi(pr) == 16)) ? atoi(pr) : 0; }   // 0: two launches per Schur iteration (A/B, tests)   // 0: full-height column pass in every Schur iteration (A/B)
                 { const char *e1 = getenv("ADMM_HIP_UZ_ONE_MAX"), *e2 = getenv("ADMM_HIP_UZ_COMPACT_MAX");      // test hooks
                   if (e1) c->uzc_one_max = std::max(0, std::min(1024, atoi(e1))); if (e2) c->uzc_compact_max = std::max(0, atoi(e2)); }

@@ -1767,6 +1767,76 @@ __global__ __launch_bounds__(1024) void k_uz_act_compact(int nv, const unsigned 
     }
     if (tid == 0) { info[0] = base[0]; info[1] = base[1]; if (nhits) { info[2] = *nhits; *nhits = 0; } }
 }
+// The same list from many blocks (scenes with more than 16 384 vertices: one block would walk nv / 4096 passes): block b of
+// k_uz_act_count counts the active / missing vertices of its 4096, block b of k_uz_act_scatter adds the counts of the blocks before it
+// (fixed order) and places its own -- ascending order as above.  The last block writes info.
+__device__ __forceinline__ bool uz_vertex_active(const unsigned char *flag, const double *cn, int v) {
+    return flag ? flag[v] != 0 : (cn[3 * (size_t)v] != 0.0 || cn[3 * (size_t)v + 1] != 0.0 || cn[3 * (size_t)v + 2] != 0.0);
+}
+__global__ __launch_bounds__(1024) void k_uz_act_count(int nv, const unsigned char *__restrict__ flag, const int *__restrict__ slot,
+                                                       const double *__restrict__ cn, int *__restrict__ counts /* [2][gridDim.x] */) {
+    __shared__ int wsum[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vb = (int)blockIdx.x * 4096 + 4 * tid;
+    int na = 0, nm = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool a = vb + k < nv && uz_vertex_active(flag, cn, vb + k);
+        na += a ? 1 : 0; nm += (a && slot[vb + k] < 0) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { na += __shfl_xor(na, o, 64); nm += __shfl_xor(nm, o, 64); }
+    if (lane == 0) { wsum[0][wv] = na; wsum[1][wv] = nm; }
+    __syncthreads();
+    if (tid == 0) {
+        int ta = 0, tm = 0;
+        for (int w = 0; w < 16; ++w) { ta += wsum[0][w]; tm += wsum[1][w]; }
+        counts[blockIdx.x] = ta; counts[gridDim.x + blockIdx.x] = tm;
+    }
+}
+__global__ __launch_bounds__(1024) void k_uz_act_scatter(int nv, const unsigned char *__restrict__ flag, const int *__restrict__ slot,
+                                                         const double *__restrict__ cn, const int *__restrict__ counts, int *__restrict__ act,
+                                                         int *__restrict__ miss, int *__restrict__ pos, int *__restrict__ info, int *__restrict__ nhits) {
+    __shared__ int wsum[2][16], base[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, vb = (int)blockIdx.x * 4096 + 4 * tid, nb = (int)gridDim.x;
+    {   // counts of the blocks before this one
+        int ba = 0, bm = 0;
+        for (int b = tid; b < (int)blockIdx.x; b += 1024) { ba += counts[b]; bm += counts[nb + b]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ba += __shfl_xor(ba, o, 64); bm += __shfl_xor(bm, o, 64); }
+        if (lane == 0) { wsum[0][wv] = ba; wsum[1][wv] = bm; }
+        __syncthreads();
+        if (tid == 0) { int ta = 0, tm = 0; for (int w = 0; w < 16; ++w) { ta += wsum[0][w]; tm += wsum[1][w]; } base[0] = ta; base[1] = tm; }
+        __syncthreads();
+    }
+    bool a[4], m[4];
+    int na = 0, nm = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = vb + k < nv && uz_vertex_active(flag, cn, vb + k);
+        m[k] = a[k] && slot[vb + k] < 0;
+        na += a[k] ? 1 : 0; nm += m[k] ? 1 : 0;
+    }
+    int pa = na, pm = nm;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ta = __shfl_up(pa, o), tm = __shfl_up(pm, o);
+        if (lane >= o) { pa += ta; pm += tm; }
+    }
+    if (lane == 63) { wsum[0][wv] = pa; wsum[1][wv] = pm; }
+    __syncthreads();
+    int oa = base[0] + pa - na, om = base[1] + pm - nm;
+    for (int w = 0; w < wv; ++w) { oa += wsum[0][w]; om += wsum[1][w]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (vb + k < nv) pos[vb + k] = a[k] ? oa : -1;
+        if (a[k]) act[oa++] = vb + k;
+        if (m[k]) miss[om++] = vb + k;
+    }
+    if ((int)blockIdx.x == nb - 1 && tid == 1023) {      // (the last thread of the last block holds the totals)
+        info[0] = oa; info[1] = om;
+        if (nhits) { info[2] = *nhits; *nhits = 0; }
+    }
+}
 // unit right-hand sides of one column solve: axis j of the launch solves K g = e_(v_j)  (rhs zeroed by the caller; v_j < 0: none)
 __global__ void k_uz_unit_rhs(int v0, int v1, int v2, double *__restrict__ rhs) {
     if (v0 >= 0) rhs[3 * (size_t)v0] = 1.0;

@@ -572,9 +572,10 @@ def test_uzawa_cached_columns_equal_inner_solves(monkeypatch):
     x2, it2 = s2.global_solve(b, x)
     assert np.abs(x2 - xg).max() < 1e-10 and it2 == itg, (np.abs(x2 - xg).max(), it2, itg)
     # the default is the persistent Schur kernel (uz_persist.hpp: one launch per solve); ADMM_HIP_UZ_PERSIST=0: two launches per
-    # iteration; ..._ROWS=8: its layout for more than 800 active vertices (8 rows of S per block, 32 lanes per row); then the paths of larger active sets: several active vertices per thread of the row kernel; active block too large
+    # iteration; ..._ROWS=8: its layout for more than 800 active vertices (8 rows of S per block, 32 lanes per row); ..._LIST_BLOCKS=0: the active list by the
+    # many-block kernels of large scenes; then the paths of larger active sets: several active vertices per thread of the row kernel; active block too large
     # to extract
-    for knob, val in (("ADMM_HIP_UZ_PERSIST", "0"), ("ADMM_HIP_UZ_PERSIST_ROWS", "8"), ("ADMM_HIP_UZ_ONE_MAX", "8"), ("ADMM_HIP_UZ_COMPACT_MAX", "8")):
+    for knob, val in (("ADMM_HIP_UZ_PERSIST", "0"), ("ADMM_HIP_UZ_PERSIST_ROWS", "8"), ("ADMM_HIP_UZ_LIST_BLOCKS", "0"), ("ADMM_HIP_UZ_ONE_MAX", "8"), ("ADMM_HIP_UZ_COMPACT_MAX", "8")):
         monkeypatch.setenv(knob, val)
         s3 = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
         monkeypatch.delenv(knob)
