@@ -251,6 +251,7 @@ struct admm_hip_ctx {
     DevBuf<double> uzc_cols; DevBuf<int> uzc_slot, uzc_act, uzc_miss, uzc_info, uzc_counts; DevBuf<unsigned char> uzc_flag;
     int uzc_one_block_max = 4;      // active list by ONE block up to this many passes of 4096 vertices (ADMM_HIP_UZ_LIST_BLOCKS: tests)
     // the Schur CG on the active rows as one persistent launch (uz_persist.hpp)
+    DevBuf<int> uzp_rowlist; int uzp_rowinfo[2] = {0, 0}; DevBuf<double> uzp_S;   // coupled (dynamic) rows: the row vertices and their Schur matrix
     DevBuf<uint4> uzp_dbox, uzp_sbox; DevBuf<unsigned> uzp_abort; bool uzp_enabled = true; unsigned uzp_seq = 0; long long uzp_launches = 0; int uzp_rows = 0;   // uzp_rows: 8 | 16 forced (ADMM_HIP_UZ_PERSIST_ROWS, tests)
     DevBuf<double> uzc_G, uzc_part, uzc_gq, uz_y0; DevBuf<int> uzc_pos;   // Schur iterations on the active vertices (kernels.hpp: k_uzc_*)
     int uzc_test_iters = 0;   // tests (ADMM_HIP_TEST_UZ_COL_ITERS=n): the column solves get n iterations, so they do not converge
@@ -313,7 +314,7 @@ struct admm_hip_ctx {
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
         uzc_cols.release(); uzc_slot.release(); uzc_act.release(); uzc_miss.release(); uzc_info.release(); uzc_counts.release(); uzc_flag.release();
-        uzc_G.release(); uzc_part.release(); uzc_gq.release(); uz_y0.release(); uzc_pos.release();
+        uzc_G.release(); uzc_part.release(); uzc_gq.release(); uz_y0.release(); uzc_pos.release(); uzp_rowlist.release(); uzp_S.release();
         gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
         lk_ts.release(); lk_out.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
@@ -933,17 +934,27 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
             }
             const unsigned char *fl = dyn ? c->uzc_flag.p : (const unsigned char *)nullptr;
             const int nbc = (nv + 4095) / 4096;
-            if (nbc <= c->uzc_one_block_max)
-                hipLaunchKernelGGL(k_uz_act_compact, dim3(1), dim3(1024), 0, st, nv, fl, c->uzc_slot.p, c->uzc_act.p,
-                                   c->uzc_miss.p, c->uzc_pos.p, c->uzc_info.p, c->uz_cn.p, c->counters.p + 6);
-            else {      // many blocks: counts, then placement behind the blocks before (kernels.hpp)
-                if (c->uzc_counts.n < (size_t)2 * nbc) { c->uzc_counts.release(); if (c->uzc_counts.alloc((size_t)2 * nbc) != hipSuccess) return -1; }
-                hipLaunchKernelGGL(k_uz_act_count, dim3(nbc), dim3(1024), 0, st, nv, fl, c->uzc_slot.p, c->uz_cn.p, c->uzc_counts.p);
-                hipLaunchKernelGGL(k_uz_act_scatter, dim3(nbc), dim3(1024), 0, st, nv, fl, c->uzc_slot.p, c->uz_cn.p, c->uzc_counts.p, c->uzc_act.p,
-                                   c->uzc_miss.p, c->uzc_pos.p, c->uzc_info.p, c->counters.p + 6);
-            }
+            if (nbc > c->uzc_one_block_max && c->uzc_counts.n < (size_t)2 * nbc) { c->uzc_counts.release(); if (c->uzc_counts.alloc((size_t)2 * nbc) != hipSuccess) return -1; }
+            // ascending list of the flagged vertices (flag == nullptr: of the vertices whose row of C is not zero)
+            auto list = [&](const unsigned char *flag, int *out, int *miss_out, int *pos_out, int *info_out, int *hits) {
+                if (nbc <= c->uzc_one_block_max)
+                    hipLaunchKernelGGL(k_uz_act_compact, dim3(1), dim3(1024), 0, st, nv, flag, c->uzc_slot.p, out, miss_out, pos_out, info_out, c->uz_cn.p, hits);
+                else {      // many blocks: counts, then placement behind the blocks before (kernels.hpp)
+                    hipLaunchKernelGGL(k_uz_act_count, dim3(nbc), dim3(1024), 0, st, nv, flag, c->uzc_slot.p, c->uz_cn.p, c->uzc_counts.p);
+                    hipLaunchKernelGGL(k_uz_act_scatter, dim3(nbc), dim3(1024), 0, st, nv, flag, c->uzc_slot.p, c->uz_cn.p, c->uzc_counts.p, out, miss_out, pos_out, info_out, hits);
+                }
+            };
+            list(fl, c->uzc_act.p, c->uzc_miss.p, c->uzc_pos.p, c->uzc_info.p, c->counters.p + 6);
             c->uz_hits_cleared = true;
             if (hipMemcpyAsync(info, c->uzc_info.p, sizeof(info), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+            if (dyn && c->uzp_enabled) {     // the ROWS (vertices that carry a row), for the persistent Schur kernel on coupled rows (k_uzc_schur)
+                if (!c->uzp_rowlist.p && (c->uzp_rowlist.alloc((size_t)3 * nv + 8) != hipSuccess)) { (void)hipGetLastError(); c->uzp_enabled = false; }
+                else {
+                    int *rl = c->uzp_rowlist.p;      // [nv] rows | [nv] scratch (missing) | [nv] scratch (places) | [8] info
+                    list(nullptr, rl, rl + nv, rl + 2 * (size_t)nv, rl + 3 * (size_t)nv, nullptr);
+                    if (hipMemcpyAsync(c->uzp_rowinfo, rl + 3 * (size_t)nv, 2 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+                }
+            }
         } else if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         if (c->uzc_on) nh = info[2];
@@ -996,30 +1007,38 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     // Passive rows only, <= 1024 active vertices: the whole Schur CG is ONE persistent launch (uz_persist.hpp; ADMM_HIP_UZ_PERSIST=0:
     // two launches per iteration, as before).  Decided before the extraction: the persistent kernel takes S_ij = G_ij (n_i . n_j).
     bool persist_launched = false;
-    bool persist = compact && !dyn && c->uzp_enabled && n_act <= std::min(kUzpMaxAct, c->uzc_one_max) && c->uz_max_iters > 0 && c->uz_max_iters < 31;
+    // n_rows: the rows of the Schur CG -- the active vertices themselves with passive rows only; with dynamic rows (a row couples its hit
+    // vertex and the three vertices of a face) the vertices that carry a row, listed next to the active ones in the detect phase
+    const int n_rows = dyn ? c->uzp_rowinfo[0] : n_act, ldS = (n_rows + 63) & ~63;
+    bool persist = compact && c->uzp_enabled && n_rows > 0 && n_rows <= std::min(kUzpMaxAct, c->uzc_one_max) && c->uz_max_iters > 0 && c->uz_max_iters < 31 &&
+                   (!dyn || c->uzp_rowlist.p);
     if (persist) {
-        const int R = c->uzp_rows > 0 ? c->uzp_rows : uzp_rows_per_block(n_act), NB = (n_act + R - 1) / R;
+        const int R = c->uzp_rows > 0 ? c->uzp_rows : uzp_rows_per_block(n_rows), NB = (n_rows + R - 1) / R;
         if (!c->uzp_dbox.p) {
             if (c->uzp_dbox.alloc(2 * kUzpMaxAct) != hipSuccess || c->uzp_sbox.alloc(2 * kUzpMaxBlocks * 8) != hipSuccess || c->uzp_abort.alloc(1) != hipSuccess ||
                 c->uzp_dbox.zero() != hipSuccess || c->uzp_sbox.zero() != hipSuccess || c->uzp_abort.zero() != hipSuccess ||
                 hipFuncSetAttribute((const void *)k_uz_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void)hipGetLastError(); persist = false; c->uzp_enabled = false; }
         }
-        if (persist && (NB > kUzpMaxBlocks || uzp_lds_bytes(n_act, R) > (size_t)(160 * 1024 - 256))) persist = false;
+        if (persist && (NB > kUzpMaxBlocks || uzp_lds_bytes(n_rows, R) > (size_t)(160 * 1024 - 256))) persist = false;
+        if (persist && dyn && c->uzp_S.n < (size_t)n_rows * ldS) { c->uzp_S.release(); if (c->uzp_S.alloc((size_t)n_rows * ldS * 2) != hipSuccess) { (void)hipGetLastError(); persist = false; } }
     }
     if (compact) {
         if (hipMemcpyAsync(c->uz_y0.p, c->uz_y.p, nv * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
         hipLaunchKernelGGL(k_uzc_extract, dim3((n_act + 255) / 256, n_act), dim3(256), 0, st, nv, n_act, ldG, c->uzc_act.p, c->uzc_slot.p, c->uzc_cols.p, c->uzc_G.p,
-                           persist ? c->uz_cn.p : (const double *)nullptr);
+                           (persist && !dyn) ? c->uz_cn.p : (const double *)nullptr);
+        if (persist && dyn)
+            hipLaunchKernelGGL(k_uzc_schur, dim3((n_rows + 255) / 256, n_rows), dim3(256), 0, st, n_rows, ldS, ldG, c->uzp_rowlist.p, c->uzc_pos.p, dface, dbary,
+                               c->uz_cn.p, c->uzc_G.p, c->uzp_S.p);
     }
     const bool skip_honoured = use_cols || (c->oc_enabled && c->oc_plan);
     if (!skip_honoured) chunk = 1;
     if (persist) {
-        const int R = c->uzp_rows > 0 ? c->uzp_rows : uzp_rows_per_block(n_act), NB = (n_act + R - 1) / R;
-        const size_t lds = uzp_lds_bytes(n_act, R);
+        const int R = c->uzp_rows > 0 ? c->uzp_rows : uzp_rows_per_block(n_rows), NB = (n_rows + R - 1) / R;
+        const size_t lds = uzp_lds_bytes(n_rows, R);
         {
             UzpArgs ua{};
-            ua.n_act = n_act; ua.ld = ldG; ua.R = R; ua.NB = NB; ua.max_iters = c->uz_max_iters;
-            ua.act = c->uzc_act.p; ua.G = c->uzc_G.p;
+            ua.n_act = n_rows; ua.ld = dyn ? ldS : ldG; ua.R = R; ua.NB = NB; ua.max_iters = c->uz_max_iters;
+            ua.act = dyn ? c->uzp_rowlist.p : c->uzc_act.p; ua.G = dyn ? c->uzp_S.p : c->uzc_G.p;
             ua.d = c->uz_d.p; ua.r = c->uz_r.p; ua.y = c->uz_y.p; ua.q3 = c->uz_q3.p;
             ua.tol2 = tol2; ua.sc = c->uz_scal.p;
             ua.dbox = (v4u *)c->uzp_dbox.p; ua.sbox = (v4u *)c->uzp_sbox.p;

@@ -1915,6 +1915,26 @@ __global__ __launch_bounds__(256) void k_uzc_extract(int nv, int n_act, int ld, 
     if (cn) g *= fma(cn[3 * (size_t)vi], cn[3 * (size_t)vj], fma(cn[3 * (size_t)vi + 1], cn[3 * (size_t)vj + 1], cn[3 * (size_t)vi + 2] * cn[3 * (size_t)vj + 2]));
     G[(size_t)j * ld + i] = g;
 }
+// The Schur matrix of the ROWS when rows couple several vertices (dynamic rows: the hit vertex with weight 1 and the three vertices of
+// the face with weights -bary, ConstraintSet.hpp:92-110), from the active x active block G of K^-1:
+//     S[k][i] = (n_i . n_k) sum_p sum_q w_ip w_kq G[a_kq][a_ip],    a = place of a vertex in the active list (pos), n = the row of C at
+// the hit vertex.  rows = the vertices that carry a row, ascending.  Input of the persistent Schur kernel (uz_persist.hpp).
+__global__ __launch_bounds__(256) void k_uzc_schur(int n_rows, int ldS, int ldG, const int *__restrict__ rows, const int *__restrict__ pos,
+                                                   const int *__restrict__ dface, const double *__restrict__ dbary, const double *__restrict__ cn,
+                                                   const double *__restrict__ G, double *__restrict__ S) {
+    const int k = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows) return;
+    const int vi = rows[i], vk = rows[k];
+    int ai[4], ak[4], ni = 1, nk = 1; double wi[4], wk[4];
+    ai[0] = pos[vi]; wi[0] = 1.0; ak[0] = pos[vk]; wk[0] = 1.0;
+    if (dface != nullptr && dface[3 * (size_t)vi] >= 0) { for (int j = 0; j < 3; ++j) { ai[1 + j] = pos[dface[3 * (size_t)vi + j]]; wi[1 + j] = -dbary[3 * (size_t)vi + j]; } ni = 4; }
+    if (dface != nullptr && dface[3 * (size_t)vk] >= 0) { for (int j = 0; j < 3; ++j) { ak[1 + j] = pos[dface[3 * (size_t)vk + j]]; wk[1 + j] = -dbary[3 * (size_t)vk + j]; } nk = 4; }
+    double sm = 0.0;
+    for (int q = 0; q < nk; ++q)
+        for (int p = 0; p < ni; ++p) sm = fma(wi[p] * wk[q], G[(size_t)ak[q] * ldG + ai[p]], sm);
+    const double nn = fma(cn[3 * (size_t)vi], cn[3 * (size_t)vk], fma(cn[3 * (size_t)vi + 1], cn[3 * (size_t)vk + 1], cn[3 * (size_t)vi + 2] * cn[3 * (size_t)vk + 2]));
+    S[(size_t)k * ldS + i] = nn * sm;
+}
 // part[s][i][:] = sum over the j of segment s of G[j][i] t_j; t_j = q1[act_j] (q1 = C^T d formed by the dense kernels: scenes with
 // dynamic rows) or cn[act_j] d[act_j] (passive rows only: q1 == nullptr).  Block = 64 i x 4 waves (wave w: j = w, w + 4, ...).
 __global__ __launch_bounds__(256) void k_uzc_matvec(int n_act, int ld, int seg_len, const int *__restrict__ act, const double *__restrict__ G,

@@ -16,7 +16,8 @@
 //   * x is not touched: x = x0 - A^-1 C^T (y - y0) is applied once after the loop (launch_uzawa), as with the two-launch iterations;
 //   * every poll is bounded: a hand-off that cannot complete raises the abort word and sig[2], the host takes the recovery path;
 //   * the host does not wait for the launch: the stop verdict stays on the device, the iteration count goes to a device counter.
-// Passive rows only (a dynamic row couples four vertices: the two-launch path keeps those), n_act <= 1024.
+// Rows that couple several vertices (dynamic rows: hit vertex + the three vertices of a face) run the same kernel: the host lists the
+// ROW vertices and k_uzc_schur (kernels.hpp) forms S on them from the active x active block of K^-1.  At most 1024 rows.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gs_persist.hpp"
