@@ -210,6 +210,7 @@ struct admm_hip_ctx {
     // WindForce on the device (admm_hip_set_wind): triangles, their vertex incidence, per-triangle forces
     int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
     int test_abort_seq = 0;   // tests only (ADMM_HIP_TEST_ABORT_SOLVE=k): the k-th on-chip solve of the context finds its barrier aborted
+    int test_abort_uzp = 0;   // tests only (ADMM_HIP_TEST_ABORT_SCHUR=k): the k-th persistent Schur launch finds its hand-off given up
     int n3i = 0;   // length of the solver-internal scratch vectors (recycled pairs): max(n3, 3 * oc_rows)
     int solve_seq = 0;
     int marks_expected = 0;       // chunks closed so far (host count)
@@ -957,6 +958,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
             }
         } else if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (c->h_sig && c->h_sig[2]) return -2;      // an earlier persistent launch (Schur CG, on-chip PCG) was given up: recovery path
         if (c->uzc_on) nh = info[2];
         if (c->uzc_on) {
             c->uzc_n_act = info[0];
@@ -1045,6 +1047,8 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
             ua.stamp0 = (++c->uzp_seq) * 128u;
             ua.abort_word = c->uzp_abort.p; ua.sig = c->d_sig;
             ua.iters_step = c->counters.p + 7; ua.applies_total = c->counters.p + 76;
+            if (c->test_abort_uzp > 0 && (int)c->uzp_seq == c->test_abort_uzp)      // test hook: this launch finds its hand-off given up
+                (void)hipMemsetAsync(c->uzp_abort.p, 1, sizeof(unsigned), st);
             hipLaunchKernelGGL(k_uz_persist, dim3(NB), dim3(kUzpT), lds, st, ua);
             c->uzp_launches += 1;
             // No synchronisation: the verdict stays on the device, the iteration count goes to counters[7] (read with the step's
@@ -1936,6 +1940,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 { const char *ce = getenv("ADMM_HIP_UZ_COMPACT"); c->uzc_compact = !(ce && ce[0] == '0'); }
                 { const char *pe = getenv("ADMM_HIP_UZ_PERSIST"); c->uzp_enabled = !(pe && pe[0] == '0'); }
                 { const char *lb = getenv("ADMM_HIP_UZ_LIST_BLOCKS"); if (lb) c->uzc_one_block_max = std::max(0, atoi(lb)); }
+                { const char *ta = getenv("ADMM_HIP_TEST_ABORT_SCHUR"); c->test_abort_uzp = ta ? atoi(ta) : 0; }
                 { const char *pr = getenv("ADMM_HIP_UZ_PERSIST_ROWS"); c->uzp_rows = (pr && (atoi(pr) == 8 || atoi(pr) == 16)) ? atoi(pr) : 0; }   // 0: two launches per Schur iteration (A/B, tests)   // 0: full-height column pass in every Schur iteration (A/B)
                 { const char *e1 = getenv("ADMM_HIP_UZ_ONE_MAX"), *e2 = getenv("ADMM_HIP_UZ_COMPACT_MAX");      // test hooks
                   if (e1) c->uzc_one_max = std::max(0, std::min(1024, atoi(e1))); if (e2) c->uzc_compact_max = std::max(0, atoi(e2)); }

@@ -675,6 +675,38 @@ def test_step_uzawa_frozen_active_set_is_tight(what, monkeypatch):
     assert scenes.rel_err(s.m_x, o.x) < 1e-7, scenes.rel_err(s.m_x, o.x)
 
 
+def test_persistent_schur_hand_off_timeout_recovers(monkeypatch):
+    """A hand-off of the persistent Schur kernel (uz_persist.hpp) that cannot complete -- injected with ADMM_HIP_TEST_ABORT_SCHUR -- must
+    not fail the step or leave a half-updated state: the launch is given up, later ones leave at once, and at the next synchronisation
+    the context restores the last good state, switches the persistent kernels off and replays the steps issued since.  The result agrees
+    with the oracle like an undisturbed run (active set frozen per step on both sides, as in the test above)."""
+    sc = scenes.cube_scene(3, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=8, linsolver=2, size=0.5)
+    for k in list(sc.pins):
+        del sc.pins[k]
+    sc.obstacles.append((0, [-0.0217, 0.0, 0.0, 0.0]))
+    o = sc.make_oracle(mode=1)
+    o.freeze_active = True
+    for _ in range(8):
+        o.step()
+    monkeypatch.setenv("ADMM_HIP_UZ_FREEZE", "1")
+    for k, asynchronous in ((5, True), (9, False)):
+        monkeypatch.setenv("ADMM_HIP_TEST_ABORT_SCHUR", str(k))
+        s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=600)
+        monkeypatch.delenv("ADMM_HIP_TEST_ABORT_SCHUR")
+        if asynchronous:
+            s.upload()
+            for _ in range(7):
+                s.step_device(stats=False)
+            s.step_device(stats=True)
+            s.download()
+        else:
+            for _ in range(8):
+                s.step()
+        assert s.uzawa_cache_stats()["schur_from_columns"] > 0
+        assert scenes.rel_err(s.m_x, o.x) < 1e-7, (k, scenes.rel_err(s.m_x, o.x))
+        s.close()
+
+
 def test_step_parity_beams_config1():
     """BASELINE configs[0] / samples/sca2016/beams.cpp: three 12x3x3-cell beams (1 944 tets), linear / NH /
     StVK, soft rubber, scaled to 1 m height and spread along y (beams.cpp:43-90), pins = all vertices within
