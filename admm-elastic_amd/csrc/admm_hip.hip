@@ -1012,7 +1012,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     // n_rows: the rows of the Schur CG -- the active vertices themselves with passive rows only; with dynamic rows (a row couples its hit
     // vertex and the three vertices of a face) the vertices that carry a row, listed next to the active ones in the detect phase
     const int n_rows = dyn ? c->uzp_rowinfo[0] : n_act, ldS = (n_rows + 63) & ~63;
-    bool persist = compact && c->uzp_enabled && n_rows > 0 && n_rows <= std::min(kUzpMaxAct, c->uzc_one_max) && c->uz_max_iters > 0 && c->uz_max_iters < 31 &&
+    bool persist = compact && c->uzp_enabled && n_rows > 0 && n_rows <= std::min(kUzpMaxAct, c->uzc_one_max) && c->uz_max_iters > 0 && c->uz_max_iters < 250 &&
                    (!dyn || c->uzp_rowlist.p);
     if (persist) {
         const int R = c->uzp_rows > 0 ? c->uzp_rows : uzp_rows_per_block(n_rows), NB = (n_rows + R - 1) / R;
@@ -1044,7 +1044,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
             ua.d = c->uz_d.p; ua.r = c->uz_r.p; ua.y = c->uz_y.p; ua.q3 = c->uz_q3.p;
             ua.tol2 = tol2; ua.sc = c->uz_scal.p;
             ua.dbox = (v4u *)c->uzp_dbox.p; ua.sbox = (v4u *)c->uzp_sbox.p;
-            ua.stamp0 = (++c->uzp_seq) * 128u;
+            ua.stamp0 = (++c->uzp_seq) * 1024u;      // (four stamps per iteration, < 250 iterations)
             ua.abort_word = c->uzp_abort.p; ua.sig = c->d_sig;
             ua.iters_step = c->counters.p + 7; ua.applies_total = c->counters.p + 76;
             if (c->test_abort_uzp > 0 && (int)c->uzp_seq == c->test_abort_uzp)      // test hook: this launch finds its hand-off given up

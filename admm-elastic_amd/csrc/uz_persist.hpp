@@ -34,7 +34,7 @@ struct UzpArgs {
     double tol2; UzScal *sc;
     v4u *dbox;                             // [2][kUzpMaxAct] granules: d of an iteration, by parity
     v4u *sbox;                             // [2][kUzpMaxBlocks][8] granules: the blocks' five partial sums, by parity
-    unsigned stamp0;                       // solve number x 128: stamps of this launch are stamp0 + 4 k + {0: d, 1: sums, 2: exact r.r / r.q3}
+    unsigned stamp0;                       // launch number x 1024: stamps of this launch are stamp0 + 4 k + {0: d, 1: sums, 2: exact r.r / r.q3}
     unsigned *abort_word; int *sig;
     int *iters_step, *applies_total;       // device-side statistics (the host does not wait for the launch): Schur iterations of this step; products S d since create
 };

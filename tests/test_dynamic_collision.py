@@ -174,11 +174,18 @@ def test_detect_three_meshes_first_object_keeps_the_payload():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["persistent", "two_launches", "list_by_many_blocks"])
 @pytest.mark.parametrize("floor", [None, 0.02])
-def test_global_solve_uzawa_dynamic_rows(floor):
+def test_global_solve_uzawa_dynamic_rows(floor, variant, monkeypatch):
     """UzawaCG::solve with dynamic rows (and passive ones next to them) at the SOLVE level.  34 rows need ~31 Schur-CG
     iterations; the reference's cap is 20 (UzawaCG.hpp:44), where both sides stop unconverged (|Cx-c| ~ 7e-5) and CG's
-    sensitivity shows (1.6e-6) -- so the tight comparison runs with the cap lifted, the default cap loosely."""
+    sensitivity shows (1.6e-6) -- so the tight comparison runs with the cap lifted, the default cap loosely.
+    Variants: the persistent Schur kernel on the coupled rows (default: uz_persist.hpp + k_uzc_schur), two launches per Schur
+    iteration (ADMM_HIP_UZ_PERSIST=0), the active / row lists by the many-block kernels of large scenes (ADMM_HIP_UZ_LIST_BLOCKS=0)."""
+    if variant == "two_launches":
+        monkeypatch.setenv("ADMM_HIP_UZ_PERSIST", "0")
+    if variant == "list_by_many_blocks":
+        monkeypatch.setenv("ADMM_HIP_UZ_LIST_BLOCKS", "0")
     for cap, tol in ((100, 1e-8), (20, 1e-5)):
         sc = scenes.two_blocks_scene(3, floor=floor)
         s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=600, uzawa_max_iters=cap)
