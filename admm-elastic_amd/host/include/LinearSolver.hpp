@@ -1,5 +1,5 @@
-// LinearSolver.hpp -- global-step solvers (reference: src/LinearSolver.hpp, src/UzawaCG.hpp,
-// src/NodalMultiColorGS.hpp).  The objects carry the reference's public tuning members; the arithmetic
+// LinearSolver.hpp -- the interface of the global-step solvers and the prefactored solve (reference: src/LinearSolver.hpp;
+// UzawaCG and NodalMultiColorGS: UzawaCG.hpp, NodalMultiColorGS.hpp).  The objects carry the reference's public tuning members; the arithmetic
 // runs in the HIP kernels of the Solver's context, which the Solver attaches after initialize().
 #ifndef ADMM_LINEARSOLVER_HPP
 #define ADMM_LINEARSOLVER_HPP 1
@@ -34,26 +34,10 @@ public:
     int kind() const { return 0; }
 };
 
-// src/UzawaCG.hpp:33-55
-class UzawaCG : public LinearSolver {
-public:
-    int max_iters; double m_tol;
-    int pcg_max_iters; double pcg_tol;
-    std::shared_ptr<ConstraintSet> constraints;
-    UzawaCG(std::shared_ptr<ConstraintSet> c) : max_iters(20), m_tol(1e-10), pcg_max_iters(500), pcg_tol(1e-10), constraints(c) {}
-    UzawaCG() : UzawaCG(std::make_shared<ConstraintSet>()) {}
-    int kind() const { return 2; }
-};
-
-// src/NodalMultiColorGS.hpp:33-59
-class NodalMultiColorGS : public LinearSolver {
-public:
-    int max_iters; double m_tol, m_omega;
-    std::shared_ptr<ConstraintSet> constraints;
-    NodalMultiColorGS(std::shared_ptr<ConstraintSet> c) : max_iters(30), m_tol(1e-10), m_omega(1.9), constraints(c) {}
-    NodalMultiColorGS() : NodalMultiColorGS(std::make_shared<ConstraintSet>()) {}
-    int kind() const { return 1; }
-};
-
 } // namespace admm
+
+// (the reference's users include LinearSolver.hpp and get the solvers it needs; the classes themselves live in their own headers,
+// as in src/)
+#include "UzawaCG.hpp"
+#include "NodalMultiColorGS.hpp"
 #endif
