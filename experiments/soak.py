@@ -37,4 +37,6 @@ good &= run("cloth60 uzawa floor", sc, 60, pcg_tol=1e-10, pcg_max_iters=2000)
 for wl, frames in (("cube100k_gs", 80), ("cloth200k_gs_floor", 120)):     # the persistent multi-colour GS kernel (one launch per solve)
     sc, nt, nv = bench.build_scene(bench.WORKLOADS[wl], None)
     good &= run(wl + " (k_gs_persist)", sc, frames, pcg_tol=bench.PCG_TOL, pcg_max_iters=600)
+sc, nt, nv = bench.build_scene(bench.WORKLOADS["cube100k_uzawa_floor"], None)      # UzawaCG with the persistent Schur kernel at the bench size
+good &= run("cube100k_uzawa_floor (k_uz_persist)", sc, 60, pcg_tol=bench.PCG_TOL, pcg_max_iters=600)
 print("SOAK", "OK" if good else "FAILED")
