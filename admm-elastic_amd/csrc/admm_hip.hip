@@ -2,6 +2,7 @@
 // ADMM elastic hot path.  gfx950 only.  Reference call stack being replaced: Solver::initialize
 // (src/Solver.cpp:167-261) -> admm_hip_create, Solver::step (src/Solver.cpp:35-110) -> admm_hip_step.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <algorithm>
@@ -111,6 +112,7 @@ struct admm_hip_ctx {
     DevBuf<unsigned long long> lk_ts, lk_out; int lk_tsn = 0, lk_launch = 0, lk_cap = 0; double lk_tick_ms = 0.0;
     std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration (+1) when stats are requested
     bool lt_on = false; std::vector<hipEvent_t> lt_ev; size_t lt_used = 0;   // admm_hip_time_local_launches: event pairs of the lean steps
+    int lt_mode = 1; hipEvent_t lt_k0 = nullptr, lt_k1 = nullptr;   // mode 2: the pair is attached to the dominant local-step kernel's dispatch (hipExtLaunchKernelGGL)
 
     int nv = 0, n3 = 0;
     double dt = 1.0 / 24.0;
@@ -365,20 +367,32 @@ void launch_local_impl(admm_hip_ctx *c) {
             hipLaunchKernelGGL((k_local_tets<3, WRITE_Z, REST>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, b3, b4, a);
         if (b3 > b0) stamp();
         a.chunk0 = b1 > b0 ? 0 : b2 > b1 ? c->chunk_base[1] : c->chunk_base[2];   // (fused: chunks 0 .. of the models it covers)
+        // (measurement, admm_hip_time_local_launches(2): the event pair rides on this kernel's own dispatch -- its begin and end
+        // time stamps, what rocprofv3 reports as the kernel's duration -- instead of bracketing the launches)
+        hipEvent_t k0 = c->lt_k0, k1 = c->lt_k1;
         if (kinds >= 2) { // mixed scene: one launch over all models
             const int n0 = blocks_for(b1 - b0), n1 = blocks_for(b2 - b1), n2 = blocks_for(b3 - b2);
-            hipLaunchKernelGGL((k_local_tets_fused<WRITE_Z, REST>), dim3(n0 + n1 + n2), dim3(256), 0, st, b0, b1, b2, b3, n0, n0 + n1, a);
+            if (k0) hipExtLaunchKernelGGL((k_local_tets_fused<WRITE_Z, REST>), dim3(n0 + n1 + n2), dim3(256), 0, st, k0, k1, 0, b0, b1, b2, b3, n0, n0 + n1, a);
+            else hipLaunchKernelGGL((k_local_tets_fused<WRITE_Z, REST>), dim3(n0 + n1 + n2), dim3(256), 0, st, b0, b1, b2, b3, n0, n0 + n1, a);
         } else if (b1 > b0) {
-            hipLaunchKernelGGL((k_local_tets<0, WRITE_Z, REST>), dim3(blocks_for(b1 - b0)), dim3(256), 0, st, b0, b1, a);
+            if (k0) hipExtLaunchKernelGGL((k_local_tets<0, WRITE_Z, REST>), dim3(blocks_for(b1 - b0)), dim3(256), 0, st, k0, k1, 0, b0, b1, a);
+            else hipLaunchKernelGGL((k_local_tets<0, WRITE_Z, REST>), dim3(blocks_for(b1 - b0)), dim3(256), 0, st, b0, b1, a);
         } else if (b2 > b1) {
-            hipLaunchKernelGGL((k_local_tets<1, WRITE_Z, REST>), dim3(blocks_for(b2 - b1)), dim3(256), 0, st, b1, b2, a);
+            if (k0) hipExtLaunchKernelGGL((k_local_tets<1, WRITE_Z, REST>), dim3(blocks_for(b2 - b1)), dim3(256), 0, st, k0, k1, 0, b1, b2, a);
+            else hipLaunchKernelGGL((k_local_tets<1, WRITE_Z, REST>), dim3(blocks_for(b2 - b1)), dim3(256), 0, st, b1, b2, a);
         } else if (b3 > b2) {
-            hipLaunchKernelGGL((k_local_tets<2, WRITE_Z, REST>), dim3(blocks_for(b3 - b2)), dim3(256), 0, st, b2, b3, a);
+            if (k0) hipExtLaunchKernelGGL((k_local_tets<2, WRITE_Z, REST>), dim3(blocks_for(b3 - b2)), dim3(256), 0, st, k0, k1, 0, b2, b3, a);
+            else hipLaunchKernelGGL((k_local_tets<2, WRITE_Z, REST>), dim3(blocks_for(b3 - b2)), dim3(256), 0, st, b2, b3, a);
         }
     }
-    if (c->ntri > 0)
-        hipLaunchKernelGGL((k_local_tris<WRITE_Z>), dim3(blocks_for(c->ntri)), dim3(256), 0, st, c->ntri, c->ldr, c->r_idx.p,
-                           c->r_rest.p, c->r_u.p, c->r_z.p, c->r_sc.p, c->r_lmin.p, c->r_lmax.p, c->curr.p, c->r_cf.p);
+    if (c->ntri > 0) {
+        if (c->nt == 0 && c->lt_k0)      // (a scene of triangles only: their kernel is the dominant one)
+            hipExtLaunchKernelGGL((k_local_tris<WRITE_Z>), dim3(blocks_for(c->ntri)), dim3(256), 0, st, c->lt_k0, c->lt_k1, 0, c->ntri, c->ldr, c->r_idx.p,
+                                  c->r_rest.p, c->r_u.p, c->r_z.p, c->r_sc.p, c->r_lmin.p, c->r_lmax.p, c->curr.p, c->r_cf.p);
+        else
+            hipLaunchKernelGGL((k_local_tris<WRITE_Z>), dim3(blocks_for(c->ntri)), dim3(256), 0, st, c->ntri, c->ldr, c->r_idx.p,
+                               c->r_rest.p, c->r_u.p, c->r_z.p, c->r_sc.p, c->r_lmin.p, c->r_lmax.p, c->curr.p, c->r_cf.p);
+    }
 }
 template <bool WRITE_Z>
 void launch_local(admm_hip_ctx *c) {      // Binv recomputed from the rest positions / streamed: decided once, in admm_hip_create
@@ -2366,10 +2380,15 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         const bool lt = !timed && c->lt_on;
         if (lt) {
             while (c->lt_ev.size() < c->lt_used + 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->lt_ev.push_back(e); }
-            HIP_TRY(hipEventRecord(c->lt_ev[c->lt_used], st));
+            if (c->lt_mode == 2) { c->lt_k0 = c->lt_ev[c->lt_used]; c->lt_k1 = c->lt_ev[c->lt_used + 1]; }
+            else HIP_TRY(hipEventRecord(c->lt_ev[c->lt_used], st));
         }
         launch_local<false>(c);                 // Solver.cpp:84-87
-        if (lt) { HIP_TRY(hipEventRecord(c->lt_ev[c->lt_used + 1], st)); c->lt_used += 2; }
+        if (lt) {
+            if (c->lt_mode == 2) { c->lt_k0 = nullptr; c->lt_k1 = nullptr; }
+            else HIP_TRY(hipEventRecord(c->lt_ev[c->lt_used + 1], st));
+            c->lt_used += 2;
+        }
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 1], st));
         // passive collisions are resolved inside the GS sweeps (linsolver 1, Solver.cpp:76)
         if (int rr = launch_rhs(c))             // Solver.cpp:98
@@ -2636,6 +2655,7 @@ int admm_hip_probe_sync(admm_hip_ctx *c, int32_t n, double *us_all_to_all, doubl
 int admm_hip_time_local_launches(admm_hip_ctx *c, int32_t on) {
     if (!c) return fail(ADMM_HIP_ERR_ARG, "time_local_launches: NULL context");
     c->lt_on = on != 0;
+    c->lt_mode = on == 2 ? 2 : 1;
     return ADMM_HIP_OK;
 }
 

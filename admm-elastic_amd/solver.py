@@ -490,9 +490,10 @@ class Solver:
         return a.value, b.value, dict(zip(keys, list(st)))
 
     def time_local_launches(self, on=True):
-        """admm_hip_time_local_launches: event pairs around the local-step launches of the steps issued without statistics."""
+        """admm_hip_time_local_launches: event pairs around the local-step launches of the steps issued without statistics
+        (on = 2: attached to the dominant local-step kernel's own dispatch)."""
         self._need_ctx()
-        check(lib().admm_hip_time_local_launches(self._ctx, 1 if on else 0))
+        check(lib().admm_hip_time_local_launches(self._ctx, int(on) if on in (0, 1, 2) else (1 if on else 0)))
 
     def local_launch_times(self):
         """admm_hip_local_launch_times: (pairs recorded since the last call, sum of their intervals in ms)."""

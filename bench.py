@@ -372,7 +372,7 @@ def main():
     lean = tot0[0] >= 0
     lt_pairs, lt_ms = 0, 0.0       # the local-step launches of the TIMED region: event pairs, read after it
     if lean:
-        s.time_local_launches(True)
+        s.time_local_launches(2)   # a hipEvent pair attached to the dispatch of every local-step kernel of the timed region
         s.local_launch_times()     # (clears what the warm-up recorded)
     uz0 = s.uzawa_cache_stats() if w["linsolver"] == 2 else None
     t0 = time.perf_counter()
@@ -541,22 +541,25 @@ def main():
             launches = max(lt_pairs, 1)
             # (with N ranks, rank 0 times its own element block: nt / N elements per launch)
             bytes_per_launch = ((188.0 if w["kinds"] == "cloth" else 304.0) + 24.0 * nv / nt) * nt / world
-            # Duration of one launch, measured live in the timed region on the context's own stream, three ways that bracket
-            # each other: (1) `avg_launch_us` = interval between two hipEventRecords around the launch (kernel + the two
-            # dispatch gaps: the CONSERVATIVE figure, used for `achieved` / `frac`); (2) rocprofv3 --kernel-trace of the same
-            # command (profiles/): 4-5 us shorter; (3) `kernel_us_device_clock` (only with ADMM_HIP_KERNEL_CLOCK=1: the stamps
-            # cost the launch ~2 %): every wave stamps the device wall clock at entry and exit -- max exit - min entry is
-            # another 2-3 us shorter than rocprofv3 (it misses the dispatch ramp-up, the drain of the last stores and the
-            # end-of-kernel cache release).
+            # Duration of one launch, measured live on the context's own stream, four ways that bracket each other:
+            # (1) `avg_launch_us`, used for `achieved` / `frac`: HIP events ATTACHED TO THE KERNEL'S DISPATCH in the timed region
+            # (hipExtLaunchKernelGGL start / stop events: the kernel's own begin and end time stamps -- what "the kernel's launch
+            # duration" means and what rocprofv3 reports; rounds 1-3 and the first session of round 4 used (2) here);
+            # (2) `avg_launch_us_statistics_frames`: the interval between two hipEventRecords AROUND the launch in the statistics
+            # frames (kernel + the two dispatch gaps: 1.5-3 us longer); (3) rocprofv3 --kernel-trace of the same command
+            # (profiles/): within ~1 us of (1); (4) `kernel_us_device_clock` (only with ADMM_HIP_KERNEL_CLOCK=1: the stamps cost the
+            # launch ~2 %): every wave stamps the device wall clock at entry and exit -- max exit - min entry is 2-3 us shorter than
+            # rocprofv3 (it misses the dispatch ramp-up, the drain of the last stores and the end-of-kernel cache release).
             avg_s = 1e-3 * lt_ms / launches
             achieved = bytes_per_launch / avg_s / 1e9
             out["roofline"] = {"role": "the HBM-bound kernel the north-star names (local step): %.0f %% of a statistics frame, second by time behind `roofline_global`"
                                        % (100.0 * local_ms / max(local_ms + global_ms, 1e-30)),
-                               "measured_in": ("the TIMED region: %d hipEvent pairs, one around every local-step launch" % lt_pairs) if lean else "the timed region (statistics frames)",
+                               "measured_in": ("the TIMED region: %d hipEvent pairs, one attached to the dispatch of every local-step kernel" % lt_pairs) if lean else "the timed region (statistics frames)",
                                "kernel": "k_local_tris" if w["kinds"] == "cloth" else "k_local_tets (all constitutive models of one ADMM iteration)", "bound": "hbm",
                                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": pmc_traffic(args.workload), "avg_launch_us": 1e6 * avg_s,
-                               "timing": "hipEventRecord pair around the launch, context stream",
+                               "timing": ("hipExtLaunchKernelGGL start / stop events of the kernel's dispatch, context stream (the pair of hipEventRecords around the launch: `avg_launch_us_statistics_frames`)"
+                                          if lean else "hipEventRecord pair around the launch, context stream"),
                                "kernel_us_device_clock": (1e3 * lk_ms / (iters * args.steps)) if lk_ms > 0 else None,
                                "avg_launch_us_statistics_frames": 1e3 * local_ms / (iters * args.steps) if lean else None,
                                "algorithmic_bytes_per_launch": bytes_per_launch}

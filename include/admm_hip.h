@@ -263,7 +263,9 @@ int admm_hip_probe_sync(admm_hip_ctx *ctx, int32_t n, double *us_all_to_all, dou
  * src/Solver.cpp:83-88).  on = 1: every later admm_hip_step WITHOUT statistics records a hipEvent pair around the launches of
  * its local step (all constitutive models of one ADMM iteration) on the context's stream -- nothing else changes, no
  * synchronisation is added.  admm_hip_local_launch_times synchronises the stream and returns the number of pairs recorded since
- * the last call and the sum of their intervals in milliseconds (kernel + the two dispatch gaps of the pair). */
+ * the last call and the sum of their intervals in milliseconds (kernel + the two dispatch gaps of the pair).
+ * on = 2: the pair is attached to the dispatch of the dominant local-step kernel instead (hipExtLaunchKernelGGL start / stop events:
+ * the kernel's own begin and end time stamps, the duration a profiler reports for it). */
 int admm_hip_time_local_launches(admm_hip_ctx *ctx, int32_t on);
 int admm_hip_local_launch_times(admm_hip_ctx *ctx, int64_t *n_pairs, double *sum_ms);
 
