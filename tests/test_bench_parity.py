@@ -116,11 +116,14 @@ def test_cloth200k_gs_floor_full_size_vs_oracle(floor):
     s.close()
 
 
-def test_cube100k_uzawa_floor_full_size_frozen_active_set(monkeypatch):
+@pytest.mark.parametrize("n, n_rows", [(26, 729), (30, 961)])
+def test_cube100k_uzawa_floor_full_size_frozen_active_set(n, n_rows, monkeypatch):
     """The bench's contact workload at its size (105 456 NH tets dropped on a Floor, 729 active rows) with the chaos of the
     free-running active set taken out as in test_step_uzawa_frozen_active_set_is_tight: Collider::detect in the first ADMM
-    iteration of a step on both sides.  Cached K^-1 columns, compact Schur iterations, bench tolerance."""
-    sc, nt, nv = _bench_scene("cube100k_uzawa_floor")
+    iteration of a step on both sides.  Cached K^-1 columns, the Schur CG of a solve as one persistent launch, bench tolerance.
+    n = 30 (162 000 tets, 961 rows): the persistent kernel's layout for more than 800 rows (8 rows of the Schur matrix per block,
+    121 blocks) at a real size."""
+    sc, nt, nv = _bench_scene("cube100k_uzawa_floor", n)
     monkeypatch.setenv("ADMM_HIP_UZ_FREEZE", "1")
     import bench
     s = sc.make_solver(pcg_tol=bench.PCG_TOL, pcg_max_iters=600)
@@ -133,7 +136,7 @@ def test_cube100k_uzawa_floor_full_size_frozen_active_set(monkeypatch):
         rows = max(rows, len(o._hits))
         err = scenes.rel_err(s.m_x, o.x)
         assert err < 1e-6, (f, err)
-    assert rows == 729, rows
+    assert rows == n_rows, rows
     st = s.uzawa_cache_stats()
     assert st["schur_from_columns"] > 0 and st["schur_by_pcg"] == 0
     assert s.m_x.reshape(-1, 3)[:, 1].min() > -0.02 - 1e-6
