@@ -313,6 +313,9 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:      # (before the heavy imports: a rank that dies early must not hide that the others were started)
+        print("bench.py: rank %s of %s started (local rank %s)" % (os.environ.get("RANK", "0"), os.environ["WORLD_SIZE"], os.environ.get("LOCAL_RANK", "0")),
+              file=sys.stderr, flush=True)
     import torch
     import admm_elastic_amd as pkg
     rank = int(os.environ.get("RANK", "0"))
