@@ -1,5 +1,6 @@
 """Would block CG over the three axes (same matrix, three right-hand sides) need fewer iterations than three independent CGs?"""
-import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo/experiments')
+import os, sys
+_R = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, 'tests'))
 import numpy as np, scipy.sparse as sp, time
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 44

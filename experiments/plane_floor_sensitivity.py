@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 import numpy as np, scenes
 import admm_elastic_amd as pkg
 from admm_elastic_amd.solver import Plane
