@@ -86,6 +86,9 @@ SYMBOLS = [
     ("admm_hip_global_solve", C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int_p]),
     ("admm_hip_num_rows", C.c_int, [C.c_void_p]),
     ("admm_hip_solve_totals", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("admm_hip_set_solver_params", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double]),
+    ("admm_hip_get_solver_params", C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_double_p, c_double_p]),
+    ("admm_hip_persistent_launches", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 3),
     ("admm_hip_probe_sync", C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
     ("admm_hip_time_local_launches", C.c_int, [C.c_void_p, C.c_int32]),
     ("admm_hip_local_launch_times", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), c_double_p]),

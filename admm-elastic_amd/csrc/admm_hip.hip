@@ -112,6 +112,7 @@ struct admm_hip_ctx {
     DevBuf<unsigned long long> lk_ts, lk_out; int lk_tsn = 0, lk_launch = 0, lk_cap = 0; double lk_tick_ms = 0.0;
     std::vector<hipEvent_t> ev_phase; // 3 per ADMM iteration (+1) when stats are requested
     bool lt_on = false; std::vector<hipEvent_t> lt_ev; size_t lt_used = 0;   // admm_hip_time_local_launches: event pairs of the lean steps
+    bool lt_taken = false;   // mode 2: a kernel of this ADMM iteration took the pair (a scene without elements leaves it unrecorded: the pair is then not counted)
     int lt_mode = 1; hipEvent_t lt_k0 = nullptr, lt_k1 = nullptr;   // mode 2: the pair is attached to the dominant local-step kernel's dispatch (hipExtLaunchKernelGGL)
 
     int nv = 0, n3 = 0;
@@ -211,8 +212,10 @@ struct admm_hip_ctx {
     DevBuf<double> bk_x, bk_v; std::vector<std::pair<int, double> > pending; bool oc_gave_up = false;
     // WindForce on the device (admm_hip_set_wind): triangles, their vertex incidence, per-triangle forces
     int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
+    long long oc_launches = 0, gsp_launches = 0;   // persistent launches since create (admm_hip_persistent_launches)
     int test_abort_seq = 0;   // tests only (ADMM_HIP_TEST_ABORT_SOLVE=k): the k-th on-chip solve of the context finds its barrier aborted
     int test_abort_uzp = 0;   // tests only (ADMM_HIP_TEST_ABORT_SCHUR=k): the k-th persistent Schur launch finds its hand-off given up
+    int n_cus = 256;   // multiProcessorCount of the device (persistent kernels need all their blocks resident at once)
     int n3i = 0;   // length of the solver-internal scratch vectors (recycled pairs): max(n3, 3 * oc_rows)
     int solve_seq = 0;
     int marks_expected = 0;       // chunks closed so far (host count)
@@ -358,18 +361,24 @@ void launch_local_impl(admm_hip_ctx *c) {
         };
         const int b4 = c->kind_begin[4], b5 = c->kind_begin[5];
         const int kinds = (b1 > b0) + (b2 > b1) + (b3 > b2);
-        if (b5 > b4) {    // SplineTet splines with a compression term: their own launch
+        // (measurement, admm_hip_time_local_launches(2): the event pair rides on ONE kernel's own dispatch -- the dominant one: the
+        // launch over the linear / NH / StVK groups when the scene has any, else the co-rotated splines', else the dense-Hessian group's)
+        const int dom = b3 > b0 ? 0 : b4 > b3 ? 3 : 4;
+        if (b5 > b4) {    // SplineTet splines with a compression term, tabulated splines, stable Neo-Hookean: their own launch
             stamp(); a.chunk0 = c->chunk_base[4];
-            hipLaunchKernelGGL((k_local_tets<4, WRITE_Z, REST>), dim3(blocks_for(b5 - b4)), dim3(256), 0, st, b4, b5, a);
+            if (dom == 4 && c->lt_k0) { hipExtLaunchKernelGGL((k_local_tets<4, WRITE_Z, REST>), dim3(blocks_for(b5 - b4)), dim3(256), 0, st, c->lt_k0, c->lt_k1, 0, b4, b5, a); c->lt_taken = true; }
+            else hipLaunchKernelGGL((k_local_tets<4, WRITE_Z, REST>), dim3(blocks_for(b5 - b4)), dim3(256), 0, st, b4, b5, a);
         }
-        if (b4 > b3) { stamp(); a.chunk0 = c->chunk_base[3]; }
-        if (b4 > b3)      // co-rotated spline tets: their own launch (no BASELINE config mixes them in)
-            hipLaunchKernelGGL((k_local_tets<3, WRITE_Z, REST>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, b3, b4, a);
+        if (b4 > b3) {    // co-rotated spline tets: their own launch (no BASELINE config mixes them in)
+            stamp(); a.chunk0 = c->chunk_base[3];
+            if (dom == 3 && c->lt_k0) { hipExtLaunchKernelGGL((k_local_tets<3, WRITE_Z, REST>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, c->lt_k0, c->lt_k1, 0, b3, b4, a); c->lt_taken = true; }
+            else hipLaunchKernelGGL((k_local_tets<3, WRITE_Z, REST>), dim3(blocks_for(b4 - b3)), dim3(256), 0, st, b3, b4, a);
+        }
         if (b3 > b0) stamp();
         a.chunk0 = b1 > b0 ? 0 : b2 > b1 ? c->chunk_base[1] : c->chunk_base[2];   // (fused: chunks 0 .. of the models it covers)
-        // (measurement, admm_hip_time_local_launches(2): the event pair rides on this kernel's own dispatch -- its begin and end
-        // time stamps, what rocprofv3 reports as the kernel's duration -- instead of bracketing the launches)
+        // (its begin and end time stamps: what rocprofv3 reports as the kernel's duration -- instead of bracketing the launches)
         hipEvent_t k0 = c->lt_k0, k1 = c->lt_k1;
+        if (k0 && b3 > b0) c->lt_taken = true;
         if (kinds >= 2) { // mixed scene: one launch over all models
             const int n0 = blocks_for(b1 - b0), n1 = blocks_for(b2 - b1), n2 = blocks_for(b3 - b2);
             if (k0) hipExtLaunchKernelGGL((k_local_tets_fused<WRITE_Z, REST>), dim3(n0 + n1 + n2), dim3(256), 0, st, k0, k1, 0, b0, b1, b2, b3, n0, n0 + n1, a);
@@ -386,7 +395,7 @@ void launch_local_impl(admm_hip_ctx *c) {
         }
     }
     if (c->ntri > 0) {
-        if (c->nt == 0 && c->lt_k0)      // (a scene of triangles only: their kernel is the dominant one)
+        if (c->nt == 0 && c->lt_k0 && (c->lt_taken = true))      // (a scene of triangles only: their kernel is the dominant one)
             hipExtLaunchKernelGGL((k_local_tris<WRITE_Z>), dim3(blocks_for(c->ntri)), dim3(256), 0, st, c->lt_k0, c->lt_k1, 0, c->ntri, c->ldr, c->r_idx.p,
                                   c->r_rest.p, c->r_u.p, c->r_z.p, c->r_sc.p, c->r_lmin.p, c->r_lmax.p, c->curr.p, c->r_cf.p);
         else
@@ -510,6 +519,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.skip = rc.skip;
     a.trust_short = c->oc_always_verify ? 0 : 1;
     a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b; a.sm_c0 = c->oc_sm_c0; a.sm_k1 = c->oc_sm_k1; a.sm_k2 = c->oc_sm_k2;
+    c->oc_launches += 1;
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg2<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     c->last_launched_iters = 0;
@@ -751,7 +761,7 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     // index was measured: it does not help the first solves of a frame.)
     const int rc_pairs = c->rc_pairs;
     const int fr = c->rc_frame;
-    if (c->rc_hist) {
+    if (c->rc_hist && c->oc_enabled && c->oc_plan) {   // (the history slots hold pairs in the on-chip kernel's internal row order: only it may project on them)
         // own pairs and the history of the same solve index, interleaved by expected value: own(s-1), prev(s), prev2(s), own(s-2),
         // prev(s+1), own(s-3), prev2(s+1), own(s-4)
         auto add = [&](int q, int frame, bool valid) { if (valid && B.cnt < rc_pairs) { B.E[B.cnt] = c->rc_Ef(q, frame); B.R[B.cnt] = c->rc_Rf(q, frame); ++B.cnt; } };
@@ -1035,7 +1045,8 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
                 c->uzp_dbox.zero() != hipSuccess || c->uzp_sbox.zero() != hipSuccess || c->uzp_abort.zero() != hipSuccess ||
                 hipFuncSetAttribute((const void *)k_uz_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void)hipGetLastError(); persist = false; c->uzp_enabled = false; }
         }
-        if (persist && (NB > kUzpMaxBlocks || uzp_lds_bytes(n_rows, R) > (size_t)(160 * 1024 - 256))) persist = false;
+        // (its blocks hand granules to each other: all of them must be resident at once -- one block per CU at this LDS size)
+        if (persist && (NB > kUzpMaxBlocks || NB > c->n_cus || uzp_lds_bytes(n_rows, R) > (size_t)(160 * 1024 - 256))) persist = false;
         if (persist && dyn && c->uzp_S.n < (size_t)n_rows * ldS) { c->uzp_S.release(); if (c->uzp_S.alloc((size_t)n_rows * ldS * 2) != hipSuccess) { (void)hipGetLastError(); persist = false; } }
     }
     if (compact) {
@@ -1213,6 +1224,7 @@ void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
     if (c->test_abort_seq > 0 && (int)a.seq == c->test_abort_seq)   // test hook: this solve finds its hand-off given up
         (void)hipMemsetAsync(c->gsp_abort.p, 1, sizeof(unsigned), st);
     hipLaunchKernelGGL(k_gs_persist, dim3(c->gsp_G), dim3(kGspT), c->gsp_lds, st, a);
+    c->gsp_launches += 1;
     if (c->gsp_prof.p && (c->solve_seq % 200) == 0) {     // diagnosis: one block's wall-clock split of the phases since the last print
         unsigned long long h[8];
         if (hipMemcpyAsync(h, c->gsp_prof.p, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && h[4]) {
@@ -1275,7 +1287,8 @@ hipError_t plan_gs_persist(admm_hip_ctx *c) {
 }
 
 void launch_gs(admm_hip_ctx *c, const double *b, double *x) {
-    if (c->gsp_enabled) { launch_gs_persist(c, b, x); return; }
+    // (the persistent kernel stamps its phases: sweeps x colours of one solve must stay inside the stamp space -- admm_hip_set_solver_params may raise max_iters)
+    if (c->gsp_enabled && (int64_t)c->gs_max_iters * c->gsp_C < 2000) { launch_gs_persist(c, b, x); return; }
     if (c->gs_exec && (c->gs_graph_b != b || c->gs_graph_x != x)) { (void)hipGraphExecDestroy(c->gs_exec); c->gs_exec = nullptr; }
     if (!c->gs_exec) {
         hipGraph_t g = nullptr;
@@ -1584,6 +1597,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     admm_hip_ctx *c = new admm_hip_ctx();
     std::unique_ptr<admm_hip_ctx> guard(c);
     c->device = d->device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d->device) == hipSuccess && cus > 0) c->n_cus = cus; }
     c->nv = d->n_verts; c->n3 = 3 * d->n_verts;
     c->dt = d->dt > 0.0 ? d->dt : 1.0 / 24.0;
     c->linsolver = d->linsolver;
@@ -2026,6 +2040,7 @@ static int set_state_impl(admm_hip_ctx *c, const double *x, const double *v) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->h_sig && c->h_sig[2]) {   // the steps before this call hit a barrier time-out; their result is overwritten anyway
         c->h_sig[2] = 0; c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false; c->uzp_enabled = false; c->rc_iter = 0;
+        c->rc_hist = 0; c->rc_prev_valid = 0; c->rc_prev2_valid = 0;   // (pairs half-written by the aborted solve, and in the on-chip row order)
         if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
         if (c->gsp_abort.p) HIP_TRY(c->gsp_abort.zero());
         if (c->uzp_abort.p) HIP_TRY(c->uzp_abort.zero());
@@ -2380,14 +2395,14 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         const bool lt = !timed && c->lt_on;
         if (lt) {
             while (c->lt_ev.size() < c->lt_used + 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); c->lt_ev.push_back(e); }
-            if (c->lt_mode == 2) { c->lt_k0 = c->lt_ev[c->lt_used]; c->lt_k1 = c->lt_ev[c->lt_used + 1]; }
+            if (c->lt_mode == 2) { c->lt_k0 = c->lt_ev[c->lt_used]; c->lt_k1 = c->lt_ev[c->lt_used + 1]; c->lt_taken = false; }
             else HIP_TRY(hipEventRecord(c->lt_ev[c->lt_used], st));
         }
         launch_local<false>(c);                 // Solver.cpp:84-87
         if (lt) {
             if (c->lt_mode == 2) { c->lt_k0 = nullptr; c->lt_k1 = nullptr; }
             else HIP_TRY(hipEventRecord(c->lt_ev[c->lt_used + 1], st));
-            c->lt_used += 2;
+            if (c->lt_mode != 2 || c->lt_taken) c->lt_used += 2;      // (mode 2: a pair no kernel took was never recorded)
         }
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 1], st));
         // passive collisions are resolved inside the GS sweeps (linsolver 1, Solver.cpp:76)
@@ -2470,6 +2485,7 @@ static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
         return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)");
     if (!c->oc_gave_up) fprintf(stderr, "[admm_hip] on-chip PCG: a grid barrier timed out (blocks not co-resident?) -- falling back to the launch-per-iteration PCG and replaying %d step(s)\n", (int)c->pending.size());
     c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false; c->uzp_enabled = false;
+    c->rc_hist = 0; c->rc_prev_valid = 0; c->rc_prev2_valid = 0;   // the history slots may hold pairs half-written by the aborted solve, in the on-chip kernel's row order
     if (c->gsp_abort.p) HIP_TRY(c->gsp_abort.zero());
     if (c->uzp_abort.p) HIP_TRY(c->uzp_abort.zero());
     c->rc_iter = 0;      // (the stored pairs are in the on-chip kernel's internal row order: the launch path must not project on them)
@@ -2497,7 +2513,7 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
     if (!c->state_set) return fail(ADMM_HIP_ERR_STATE, "step: call admm_hip_set_state first");
     if (admm_iters < 0) return fail(ADMM_HIP_ERR_ARG, "step: admm_iters < 0");
     HIP_TRY(hipSetDevice(c->device));
-    if (((c->oc_enabled && c->linsolver != 1) || (c->gsp_enabled && c->linsolver == 1)) && c->world == 1 && !c->comm && !c->ar_fn) {
+    if (((c->oc_enabled && c->linsolver != 1) || (c->gsp_enabled && c->linsolver == 1) || (c->uzp_enabled && c->linsolver == 2 && c->uzc_on)) && c->world == 1 && !c->comm && !c->ar_fn) {
         if (c->pending.empty()) {   // the state every later replay starts from
             if (!c->bk_x.p) { HIP_TRY(c->bk_x.alloc(c->n3)); HIP_TRY(c->bk_v.alloc(c->n3)); }
             HIP_TRY(hipMemcpyAsync(c->bk_x.p, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
@@ -2613,6 +2629,59 @@ int admm_hip_solve_totals(admm_hip_ctx *c, int64_t *solves, int64_t *converged, 
     if (solves) *solves = counted ? h[0] : -1;
     if (converged) *converged = counted ? h[1] : -1;
     if (inner_iters) *inner_iters = counted ? h[2] : -1;
+    return ADMM_HIP_OK;
+}
+
+// LinearSolver tuning members changed after Solver::initialize (the reference reads them on every solve: src/NodalMultiColorGS.hpp:40-46,100,
+// src/UzawaCG.hpp:44-45,92).  Takes effect from the next solve; nothing is re-planned.
+int admm_hip_set_solver_params(admm_hip_ctx *c, int32_t kind, int32_t max_iters, double tol, double omega) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "set_solver_params: NULL context");
+    if (kind == ADMM_LS_NCMCGS) {
+        if (c->linsolver != 1) return fail(ADMM_HIP_ERR_ARG, "set_solver_params: this context does not run the multi-colour GS");
+        const int it0 = c->gs_max_iters; const double tol0 = c->gs_tol, om0 = c->gs_omega;
+        if (max_iters > 0) c->gs_max_iters = max_iters;
+        if (tol >= 0.0) c->gs_tol = tol;
+        if (omega > 0.0) c->gs_omega = omega;
+        if ((it0 != c->gs_max_iters || tol0 != c->gs_tol || om0 != c->gs_omega) && c->gs_exec) {   // the captured colour-kernel sequence holds the old values
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            (void)hipGraphExecDestroy(c->gs_exec); c->gs_exec = nullptr;
+        }
+        return ADMM_HIP_OK;
+    }
+    if (kind == ADMM_LS_UZAWACG) {
+        if (c->linsolver != 2) return fail(ADMM_HIP_ERR_ARG, "set_solver_params: this context does not run UzawaCG");
+        if (max_iters > 0) c->uz_max_iters = max_iters;
+        if (tol > 0.0) c->uz_tol = tol;
+        return ADMM_HIP_OK;
+    }
+    if (kind == ADMM_LS_LDLT_AS_PCG) {      // the PCG that stands for the prefactored solve (linsolver 0, and inside UzawaCG)
+        if (c->linsolver == 1) return fail(ADMM_HIP_ERR_ARG, "set_solver_params: this context runs no PCG");
+        if (max_iters > 0) c->pcg_max_iters = max_iters;
+        if (tol > 0.0) c->pcg_tol = tol;
+        return ADMM_HIP_OK;
+    }
+    return fail(ADMM_HIP_ERR_ARG, "set_solver_params: kind must be ADMM_LS_LDLT_AS_PCG, ADMM_LS_NCMCGS or ADMM_LS_UZAWACG");
+}
+
+int admm_hip_get_solver_params(const admm_hip_ctx *c, int32_t kind, int32_t *max_iters, double *tol, double *omega) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "get_solver_params: NULL context");
+    int it; double t, o = 0.0;
+    if (kind == ADMM_LS_NCMCGS) { it = c->gs_max_iters; t = c->gs_tol; o = c->gs_omega; }
+    else if (kind == ADMM_LS_UZAWACG) { it = c->uz_max_iters; t = c->uz_tol; }
+    else if (kind == ADMM_LS_LDLT_AS_PCG) { it = c->pcg_max_iters; t = c->pcg_tol; }
+    else return fail(ADMM_HIP_ERR_ARG, "get_solver_params: unknown kind");
+    if (max_iters) *max_iters = it;
+    if (tol) *tol = t;
+    if (omega) *omega = o;
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_persistent_launches(const admm_hip_ctx *c, int64_t *pcg, int64_t *gs, int64_t *schur) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "persistent_launches: NULL context");
+    if (pcg) *pcg = c->oc_launches;
+    if (gs) *gs = c->gsp_launches;
+    if (schur) *schur = c->uzp_launches;
     return ADMM_HIP_OK;
 }
 

@@ -77,14 +77,16 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     //      row | halo source | pin flags   (host_setup.hpp: gsp_lds_bytes computes the same offsets)
     LdsD *scr = (LdsD *)smem;                       // [0..3] wave sums of the residual partial, [8] |b|^2 of the block
     LdsI32 *ih = (LdsI32 *)(smem + 256);            // the block's header (64 ints)
-    LdsI32 *ctl = (LdsI32 *)(smem + 512);           // [0] abort seen, [1] a sweep met the tolerance, [2] which one
+    LdsI32 *ctl = (LdsI32 *)(smem + 512);           // [0] abort seen, [1] a sweep met the tolerance, [2] which one (verdict(): written and read across a barrier);
+                                                    // [4 + 2 q], [5 + 2 q]: the same from verdict_wave of a phase of parity q -- written in phase p, read in phase
+                                                    // p + 1 behind that phase's barrier, so a wave that is late after a barrier never sees a verdict of its own phase
     if (t < kGspHdrK) ih[t] = a.hdr[b * kGspHdrK + t];
     // the passive obstacles, once per launch: read through the argument pointer, the count, kind and parameters of every obstacle were
     // three DEPENDENT global round trips inside every row update of every phase (the polling loads' memory clobbers forbid hoisting them)
     LdsObst *obl = (LdsObst *)(smem + 640);
     if (t < (int)(sizeof(Obstacles) / 4)) ((LdsI32 *)obl)[t] = ((const int *)a.ob)[t];
     if (t == 0) {
-        ctl[1] = 0; ctl[2] = 0;
+        ctl[1] = 0; ctl[2] = 0; ctl[4] = 0; ctl[5] = 0; ctl[6] = 0; ctl[7] = 0;
         // a solve of this context has been given up and the host has not recovered yet (steps are issued asynchronously): nothing may
         // run on that state -- every later launch leaves at once, the host replays them after its next synchronisation
         ctl[0] = __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
@@ -328,9 +330,10 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
         return ctl[1] != 0;
     };
 
-    // ... the same by ONE wave from granules loaded earlier, without a barrier: the verdict is left in ctl[1] (met) / ctl[2] (sweep)
-    // for everybody to read after the next block barrier
-    auto verdict_wave = [&](int k, unsigned sp, v4u (*pre)[2]) {
+    // ... the same by ONE wave from granules loaded earlier, without a barrier: the verdict is left in the slot of the phase's parity
+    // (ctl[4 + 2 q] met, ctl[5 + 2 q] sweep) for everybody to read after the NEXT phase's block barrier.  (One slot read in the phase it
+    // is written in was a race: a wave held up behind the barrier could see the verdict one phase before its siblings and leave alone.)
+    auto verdict_wave = [&](int k, unsigned sp, v4u (*pre)[2], int q) {
         double r2 = 0.0, b2 = 0.0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
             }
         }
         r2 = wave_sum(r2); b2 = wave_sum(b2);
-        if ((t & 63) == 0 && r2 / b2 < a.tol2) { ctl[2] = k; ctl[1] = 1; }
+        if ((t & 63) == 0 && r2 / b2 < a.tol2) { ctl[5 + 2 * q] = k; ctl[4 + 2 * q] = 1; }
     };
     // n sweeps.  tests: the residual test of every sweep (:136-140), riding on the sweeps and evaluated two sweeps late.  Returns the
     // first sweep that met the tolerance (0 .. n-1), -1 if none did, -2 after an abort.
@@ -382,9 +385,9 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                 __syncthreads();
                 lap(1);
                 if (block_failed()) return -2;
-                if (tests && ctl[1] != 0) return ctl[2];         // a verdict of an earlier phase: that sweep met the tolerance
+                if (tests && ctl[4 + 2 * ((p + 1) & 1)] != 0) return ctl[5 + 2 * ((p + 1) & 1)];   // the verdict of the PREVIOUS phase: that sweep met the tolerance
                 if (parked >= 0) { publish_parked(parked, stamp0 + (unsigned)parked); parked = -1; }
-                if (judge) verdict_wave(sweep - 2, stamp0 + (unsigned)(sweep - 2), pre);
+                if (judge) verdict_wave(sweep - 2, stamp0 + (unsigned)(sweep - 2), pre, p & 1);
                 int role = 0;
                 if (tests) {
                     if (C >= 2 && c == C - 1) role = 2;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
         __syncthreads();
         if (block_failed()) return -2;
         if (!tests || n < 1) return -1;
-        if (ctl[1] != 0) return ctl[2];
+        { const int q = ((n - 1) * C) & 1; if (ctl[4 + 2 * q] != 0) return ctl[5 + 2 * q]; }   // the last judged phase, (n - 1) C: read here (C = 1) or seen one phase later already
         if (parked >= 0) publish_parked(parked, stamp0 + (unsigned)parked);
         __syncthreads();                                    // (thread 0 has read the parked sums)
         // the last sweep: its last colour's rows were taken after their update, the others now

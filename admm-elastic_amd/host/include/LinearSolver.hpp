@@ -20,6 +20,7 @@ public:
     virtual int kind() const = 0; // ADMM_LS_*
     const SparseMat &matrix() const { return A; }
     void attach(void *ctx) { ctx_ = ctx; }
+    void push_params();      // the object's public tuning members -> the context (called before every solve / step)
 protected:
     LinearSolver() : ctx_(nullptr) {}
     SparseMat A;

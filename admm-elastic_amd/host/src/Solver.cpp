@@ -279,8 +279,24 @@ bool SpringPin::flatten(FlatTerm &o) const {
 }
 
 // ---------------------------------------------------------------- LinearSolver ----------------------
+// The reference reads a solver object's public tuning members on EVERY solve (src/NodalMultiColorGS.hpp:40-46,100; src/UzawaCG.hpp:44-45,92),
+// so callers may cast Solver::m_linsolver and change them after initialize(): whatever the members hold now goes to the context
+// before the next solve (the library does nothing when the values are the ones in effect).
+void LinearSolver::push_params() {
+    if (!ctx_) return;
+    admm_hip_ctx *c = (admm_hip_ctx *)ctx_;
+    if (auto *s1 = dynamic_cast<NodalMultiColorGS *>(this))
+        check(admm_hip_set_solver_params(c, ADMM_LS_NCMCGS, s1->max_iters, s1->m_tol, s1->m_omega), "NodalMultiColorGS (tuning members)");
+    else if (auto *s2 = dynamic_cast<UzawaCG *>(this)) {
+        check(admm_hip_set_solver_params(c, ADMM_LS_UZAWACG, s2->max_iters, s2->m_tol, 0.0), "UzawaCG (tuning members)");
+        check(admm_hip_set_solver_params(c, ADMM_LS_LDLT_AS_PCG, s2->pcg_max_iters, s2->pcg_tol, 0.0), "UzawaCG (tuning members)");
+    } else if (auto *s0 = dynamic_cast<LDLTSolver *>(this))
+        check(admm_hip_set_solver_params(c, ADMM_LS_LDLT_AS_PCG, s0->pcg_max_iters, s0->pcg_tol, 0.0), "LDLTSolver (tuning members)");
+}
+
 int LinearSolver::solve(VecX &x, const VecX &b) {
     if (!ctx_) throw std::runtime_error("LinearSolver::solve: not attached to an initialized Solver");
+    push_params();
     int32_t it = 0;
     check(admm_hip_global_solve((admm_hip_ctx *)ctx_, b.data(), x.data(), &it), "LinearSolver::solve");
     return it;
@@ -458,6 +474,7 @@ void Solver::step() { // src/Solver.cpp:35-110
     const double dt = m_settings.timestep_s;
     for (auto &f : ext_forces) f->project(dt, m_x, m_v, m_masses); // :54 (host, pre-loop)
     admm_hip_ctx *ctx = (admm_hip_ctx *)m_ctx;
+    m_linsolver->push_params();      // (tuning members changed since the last step, src/NodalMultiColorGS.hpp:40-46, src/UzawaCG.hpp:44-45)
     check(admm_hip_set_state(ctx, m_x.data(), m_v.data()), "Solver::step");
     admm_hip_stats st;
     check(admm_hip_step(ctx, m_settings.admm_iters, m_settings.gravity, &st), "Solver::step");

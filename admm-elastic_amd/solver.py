@@ -108,7 +108,8 @@ class Plane:
         l = float(np.linalg.norm(n))
         if not l > 0.0:
             raise AdmmHipError(-1, "Plane: zero normal")
-        self.kind, self.params = 2, [float(n[0]), float(n[1]), float(n[2]), float(d)]
+        # unit normal, offset scaled with it -- as the C++ mirror's Plane and the library do: oracle and device see the same plane
+        self.kind, self.params = 2, [float(n[0] / l), float(n[1] / l), float(n[2] / l), float(d) / l]
 
 
 class SampledObstacle:
@@ -128,13 +129,25 @@ class SampledObstacle:
         meta = np.zeros(10); data = np.zeros(4 * n)
         obj = self.obj
 
+        failed = []
+
         def cb(user, px, pout):
-            dx, point, normal = obj.signed_distance(np.array([px[0], px[1], px[2]]))
-            pout[0] = float(dx)
-            for a in range(3):
-                pout[1 + a] = float(point[a]); pout[4 + a] = float(normal[a])
+            # a Python exception must not unwind through the C frames, and a sample that was never written must not read as
+            # "distance 0, normal 0": NaN makes admm_host_sample_obstacle return ADMM_HIP_ERR_ARG, the exception is re-raised below
+            try:
+                dx, point, normal = obj.signed_distance(np.array([px[0], px[1], px[2]]))
+                vals = [float(dx)] + [float(point[a]) for a in range(3)] + [float(normal[a]) for a in range(3)]
+            except Exception as e:
+                if not failed:
+                    failed.append(e)
+                vals = [float("nan")] * 7
+            for a in range(7):
+                pout[a] = vals[a]
         fn = capi.OBSTACLE_FN(cb)
-        check(lib().admm_host_sample_obstacle(fn, None, dptr(self.lo), dptr(self.hi), iptr(self.dims), dptr(meta), dptr(data)))
+        rc = lib().admm_host_sample_obstacle(fn, None, dptr(self.lo), dptr(self.hi), iptr(self.dims), dptr(meta), dptr(data))
+        if failed:
+            raise failed[0]
+        check(rc)
         return meta, data
 
 
@@ -480,6 +493,27 @@ class Solver:
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         check(lib().admm_hip_solve_totals(self._ctx, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def set_solver_params(self, kind, max_iters=0, tol=-1.0, omega=0.0):
+        """admm_hip_set_solver_params: the LinearSolver objects' public tuning members after initialize (the reference reads them on
+        every solve: src/NodalMultiColorGS.hpp:40-46,100, src/UzawaCG.hpp:44-45,92).  kind = LS_NCMCGS (max_iters, tol, omega),
+        LS_UZAWACG (max_iters, tol) or LS_LDLT (the PCG standing for the prefactored solve); values <= 0 (tol < 0) keep the current one."""
+        self._need_ctx()
+        check(lib().admm_hip_set_solver_params(self._ctx, int(kind), int(max_iters), float(tol), float(omega)))
+
+    def solver_params(self, kind):
+        """admm_hip_get_solver_params: (max_iters, tol, omega) in effect for that solver."""
+        self._need_ctx()
+        it = C.c_int32(0); t = C.c_double(0.0); o = C.c_double(0.0)
+        check(lib().admm_hip_get_solver_params(self._ctx, int(kind), C.byref(it), C.byref(t), C.byref(o)))
+        return it.value, t.value, o.value
+
+    def persistent_launches(self):
+        """admm_hip_persistent_launches: dict(pcg, gs, schur) -- launches of the persistent solver kernels since initialize."""
+        self._need_ctx()
+        a = [C.c_int64(0) for _ in range(3)]
+        check(lib().admm_hip_persistent_launches(self._ctx, *[C.byref(x) for x in a]))
+        return dict(zip(("pcg", "gs", "schur"), (x.value for x in a)))
 
     def probe_sync(self, n=200):
         """admm_hip_probe_sync: (us per all-to-all, us per vector exchange, plan statistics dict) of the on-chip PCG."""

@@ -251,6 +251,21 @@ int admm_hip_global_solve(admm_hip_ctx *ctx, const double *b, double *x_inout, i
  * does not use the general-mesh on-chip PCG. */
 int admm_hip_solve_totals(admm_hip_ctx *ctx, int64_t *solves, int64_t *converged, int64_t *inner_iters);   /* returns ADMM_HIP_OK; the three values are -1 when this context's solver keeps no totals */
 
+/* The LinearSolver objects' public tuning members, changed AFTER Solver::initialize.  The reference reads them on every solve --
+ * NodalMultiColorGS::max_iters / m_tol / m_omega (src/NodalMultiColorGS.hpp:40-46, used at :100 and :136-140), UzawaCG::max_iters /
+ * m_tol (src/UzawaCG.hpp:44-45, used at :92 and :109) -- so a caller may cast Solver::m_linsolver and change them between steps.
+ * kind = ADMM_LS_NCMCGS (max_iters, tol, omega), ADMM_LS_UZAWACG (max_iters, tol) or ADMM_LS_LDLT_AS_PCG (max_iters, tol of the GPU
+ * PCG that stands for the prefactored solve, with linsolver 0 or 2); ADMM_HIP_ERR_ARG when the context does not run that solver.
+ * max_iters <= 0, tol < 0 (GS: tol = 0 switches the residual test off, like the reference; the others: tol <= 0) and omega <= 0 keep
+ * the current value.  In effect from the next solve.  admm_hip_get_solver_params reads the values in effect (pointers may be NULL). */
+int admm_hip_set_solver_params(admm_hip_ctx *ctx, int32_t kind, int32_t max_iters, double tol, double omega);
+int admm_hip_get_solver_params(const admm_hip_ctx *ctx, int32_t kind, int32_t *max_iters, double *tol, double *omega);
+
+/* Launches of the three persistent solver kernels since admm_hip_create (no reference counterpart): the on-chip PCG (one per solve of
+ * linsolver 0 / 2 and per batch of K^-1 columns), the multi-colour GS, the Schur CG of UzawaCG.  After a barrier / hand-off time-out
+ * the context falls back to the launch-per-iteration kernels for good: the counts then stop growing (tests). */
+int admm_hip_persistent_launches(const admm_hip_ctx *ctx, int64_t *pcg, int64_t *gs, int64_t *schur);
+
 /* Diagnostics of the on-chip PCG (linsolver 0 / 2; no reference counterpart): the latency floor of the two
  * synchronisations one CG iteration consists of, measured on this context's grid with the kernel's own primitives and
  * payloads but no arithmetic, as microseconds per repetition over n repetitions: the all-to-all (block record -> grid barrier

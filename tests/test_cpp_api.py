@@ -42,6 +42,16 @@ def test_cpp_lineartet_known_answers():
 def test_cpp_scene_builds():
     _build_exe("test_scene")
     _build_exe("test_splines")
+    _build_exe("test_solver_params")
+
+
+@pytest.mark.gpu
+def test_cpp_solver_tuning_members_after_initialize():
+    """NodalMultiColorGS::max_iters / UzawaCG::max_iters changed through Solver::linear_solver() after initialize() are read on the
+    next step, like the reference does on every solve (src/NodalMultiColorGS.hpp:40-46,100; src/UzawaCG.hpp:44-45,92)."""
+    exe = _build_exe("test_solver_params")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SUCCESS" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu

@@ -134,6 +134,19 @@ def test_barrier_timeout_falls_back_and_replays(monkeypatch):
     assert np.isfinite(s.m_x).all()
     assert scenes.rel_err(s.m_x, ref.m_x) < 1e-8, scenes.rel_err(s.m_x, ref.m_x)
     assert s.runtime_data().unconverged_solves == 0
+    # after the abort the context must not go back to the persistent kernel -- neither in the replay nor later (the
+    # frame-history branch of the recycled start used to launch it unconditionally)
+    n_oc = s.persistent_launches()["pcg"]
+    assert 0 < n_oc <= 15
+    for _ in range(2):
+        s.step_device(stats=True); ref.step()
+    s.download()
+    assert s.persistent_launches()["pcg"] == n_oc
+    assert scenes.rel_err(s.m_x, ref.m_x) < 1e-8
+    assert s.runtime_data().unconverged_solves == 0
+    ref = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=2000)
+    for _ in range(4):
+        ref.step()
     # the same with the time-out inside a step that asks for statistics
     monkeypatch.setenv("ADMM_HIP_TEST_ABORT_SOLVE", "8")
     s2 = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=2000)
@@ -239,3 +252,76 @@ def test_sampled_user_obstacle_matches_the_analytic_object():
         assert len(o.detect_passive(o.x)) > 0 or np.linalg.norm(o.x.reshape(-1, 3) - c, axis=1).min() < r + 1e-6     # it does touch
         sol.close()
     assert errs[0] < 2e-3 and errs[1] < 0.4 * errs[0], errs
+
+
+def test_plane_normal_is_normalised_and_failing_obstacle_callbacks_raise():
+    """the Python Plane stores the unit normal and the offset scaled with it (as the C++ mirror's Plane and the library
+    do), so the oracle's kind-2 plane sees the same half space; a user obstacle whose signed_distance raises (or returns something
+    malformed) must fail the sampling loudly instead of leaving distance 0 / normal 0 in the grid."""
+    from admm_elastic_amd.solver import Plane, SampledObstacle
+    p = Plane((0.0, 2.0, 0.0), 1.0)
+    assert p.params == [0.0, 1.0, 0.0, 0.5]
+
+    class Bad:
+        def __init__(self):
+            self.calls = 0
+
+        def signed_distance(self, x):
+            self.calls += 1
+            if self.calls == 5:
+                raise ValueError("user obstacle failed at a node")
+            return x[1], (x[0], 0.0, x[2]), (0.0, 1.0, 0.0)
+    with pytest.raises(ValueError, match="failed at a node"):
+        SampledObstacle(Bad(), (-1, -1, -1), (1, 1, 1), dims=(4, 4, 4)).sample()
+
+    class Malformed:
+        def signed_distance(self, x):
+            return 0.0, (0.0, 0.0)          # two components instead of three
+    with pytest.raises((IndexError, TypeError, ValueError)):
+        SampledObstacle(Malformed(), (-1, -1, -1), (1, 1, 1), dims=(4, 4, 4)).sample()
+
+
+@pytest.mark.gpu
+def test_solver_params_after_initialize():
+    """admm_hip_set_solver_params (round 4 review, boundary item): the reference reads NodalMultiColorGS::max_iters / m_tol / m_omega and
+    UzawaCG::max_iters / m_tol on every solve (src/NodalMultiColorGS.hpp:40-46,100; src/UzawaCG.hpp:44-45,92)."""
+    import scenes
+    sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, admm_iters=6, linsolver=1)
+    s = sc.make_solver()
+    assert s.solver_params(pkg.LS_NCMCGS) == (30, 1e-10, 1.9)
+    s.step()
+    assert s.runtime_data().inner_iters == 6 * 30
+    s.set_solver_params(pkg.LS_NCMCGS, max_iters=15)
+    s.step()
+    assert s.runtime_data().inner_iters == 6 * 15
+    assert s.solver_params(pkg.LS_NCMCGS) == (15, 1e-10, 1.9)
+    # omega and the tolerance against the oracle run with the same members
+    colors, nc = s.gs_colors()
+    o = sc.make_oracle(mode=1, gs_colors=colors, gs_max_iters=12, gs_omega=1.5, gs_tol=1e-3)
+    s2 = sc.make_solver()
+    s2.set_solver_params(pkg.LS_NCMCGS, max_iters=12, tol=1e-3, omega=1.5)
+    for _ in range(2):
+        s2.step(); o.step()
+        assert s2.runtime_data().inner_iters == o.inner_iters        # (the loose tolerance stops sweeps early on both sides)
+    assert scenes.rel_err(s2.m_x, o.x) < 1e-8
+    # the colour-kernel path (captured hipGraph) picks the new values up as well
+    import os
+    os.environ["ADMM_HIP_GS_PERSIST"] = "0"
+    try:
+        s3 = sc.make_solver()
+    finally:
+        os.environ.pop("ADMM_HIP_GS_PERSIST")
+    s3.step()
+    assert s3.runtime_data().inner_iters == 6 * 30
+    s3.set_solver_params(pkg.LS_NCMCGS, max_iters=15)
+    s3.step()
+    assert s3.runtime_data().inner_iters == 6 * 15
+    with pytest.raises(pkg.AdmmHipError):
+        s3.set_solver_params(pkg.LS_UZAWACG, max_iters=5)            # this context does not run UzawaCG
+    # PCG standing for the prefactored solve: a tolerance change is honoured by the next solve
+    sc0 = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, admm_iters=6, linsolver=0)
+    a = sc0.make_solver(pcg_tol=1e-4, pcg_max_iters=500); b = sc0.make_solver(pcg_tol=1e-12, pcg_max_iters=500)
+    a.set_solver_params(pkg.LS_LDLT, tol=1e-12)
+    for _ in range(2):
+        a.step(); b.step()
+    assert scenes.rel_err(a.m_x, b.m_x) < 1e-10
