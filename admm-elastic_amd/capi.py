@@ -51,6 +51,8 @@ class Desc(C.Structure):
         ("vert_xyz", c_double_p),
         ("n_spline_tables", C.c_int32), ("spline_tables", c_double_p), ("tet_spline", c_int_p),
         ("n_obstacle_grids", C.c_int32), ("obstacle_grid_meta", c_double_p), ("obstacle_grid_data", c_double_p),
+        ("pin_normal", c_double_p),
+        ("n_bends", C.c_int32), ("bend_idx", c_int_p), ("bend_coef", c_double_p), ("bend_weight", c_double_p), ("bend_stiffness", c_double_p),
     ]
 
 
@@ -77,6 +79,7 @@ SYMBOLS = [
     ("admm_hip_set_state", C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     ("admm_hip_get_state", C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     ("admm_hip_set_pins", C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_double_p]),
+    ("admm_hip_set_pin_normals", C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_double_p]),
     ("admm_hip_set_surface_inds", C.c_int, [C.c_void_p, C.c_int32, c_int_p]),
     ("admm_hip_set_wind", C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_double_p]),
     ("admm_hip_add_dynamic_tetmesh", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p, C.c_int32, c_int_p, C.c_int32, c_int_p]),
@@ -88,6 +91,7 @@ SYMBOLS = [
     ("admm_hip_solve_totals", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("admm_hip_set_solver_params", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double]),
     ("admm_hip_get_solver_params", C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_double_p, c_double_p]),
+    ("admm_hip_contact_totals", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("admm_hip_persistent_launches", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 3),
     ("admm_hip_probe_sync", C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
     ("admm_hip_time_local_launches", C.c_int, [C.c_void_p, C.c_int32]),
@@ -96,6 +100,7 @@ SYMBOLS = [
     ("admm_hip_get_colors", C.c_int, [C.c_void_p, c_int_p, c_int_p]),
     ("admm_hip_comm_unique_id", C.c_int, [C.c_char_p]),
     ("admm_hip_comm_init", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    ("admm_hip_comm_info", C.c_int, [C.c_void_p, c_int_p, c_int_p, C.c_char_p]),
     ("admm_hip_set_rhs_allreduce", C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
     ("admm_host_assemble_matrix", C.c_int, [C.POINTER(Desc), c_int_p, c_int_p, c_double_p, c_int_p]),
     ("admm_host_partition", None, [C.c_int32, C.c_int, C.c_int, c_int_p, c_int_p]),
@@ -108,6 +113,7 @@ SYMBOLS = [
     ("admm_hip_uzawa_cache_stats", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 5),
     ("admm_hip_uzawa_unconverged_columns", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("admm_host_sample_obstacle", C.c_int, [OBSTACLE_FN, C.c_void_p, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p]),
+    ("admm_host_bend_hinges", C.c_int32, [C.c_int32, C.c_int32, c_int_p, c_double_p, C.c_int32, c_int_p, c_double_p, c_double_p]),
     ("admm_host_tri_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("admm_host_lame", None, [C.c_double, C.c_double, c_double_p, c_double_p, c_double_p]),
     ("admm_host_greedy_coloring", C.c_int, [C.c_int32, c_int_p, c_int_p, c_int_p]),
@@ -187,6 +193,18 @@ def tri_rest(verts, tris):
     rest = np.empty((n, 4)); area = np.empty(n)
     check(lib().admm_host_tri_rest(n, iptr(tris), dptr(verts), dptr(rest), dptr(area)))
     return rest, area
+
+
+def bend_hinges(verts, tris):
+    """admm_host_bend_hinges: (hinge idx [n,4], cotangent stencil coef [n,4], rest area [n]) of the interior edges of a triangle mesh."""
+    verts = f64(verts, (-1, 3)); tris = i32(tris, (-1, 3))
+    n = lib().admm_host_bend_hinges(verts.shape[0], tris.shape[0], iptr(tris), dptr(verts), 0, None, None, None)
+    if n < 0:
+        raise AdmmHipError(-1, "bend_hinges: triangle index out of range")
+    idx = np.zeros((n, 4), np.int32); coef = np.zeros((n, 4)); area = np.zeros(n)
+    if n:
+        lib().admm_host_bend_hinges(verts.shape[0], tris.shape[0], iptr(tris), dptr(verts), n, iptr(idx), dptr(coef), dptr(area))
+    return idx, coef, area
 
 
 def lame(youngs, poisson):

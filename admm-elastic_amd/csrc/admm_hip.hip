@@ -83,6 +83,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;          // (optional: admm_hip_comm_info)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     bool load() {
         if (h) return true;
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -95,6 +97,8 @@ struct RcclApi {
         CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
         AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
         GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        CommCount = (decltype(CommCount))dlsym(h, "ncclCommCount");
+        CommUserRank = (decltype(CommUserRank))dlsym(h, "ncclCommUserRank");
         return GetUniqueId && CommInitRank && CommDestroy && AllReduce && GetErrorString;
     }
 };
@@ -121,6 +125,7 @@ struct admm_hip_ctx {
     double constraint_w = 1.0;
     int pcg_max_iters = 500; double pcg_tol = 1e-10;
     double tol_last = 0.0; int tol_last_n = 0;      // experiments: see step_impl
+    std::vector<double> tol_sched;                  // pcg_tol multipliers of the first solves of a step (admm_hip_set_pcg_tol_schedule)
     int gs_max_iters = 30; double gs_tol = 1e-10, gs_omega = 1.9;
     int uz_max_iters = 20; double uz_tol = 1e-10;
     bool state_set = false;
@@ -162,12 +167,18 @@ struct admm_hip_ctx {
     DevBuf<int4> r_idx;
     DevBuf<double> r_rest, r_u, r_z, r_sc, r_cf, r_lmin, r_lmax;
     SellDev r_inc;
+    // bending hinges (desc.bend_*): SoA like the triangles, corner forces [12][ld], vertex incidence
+    int nbend = 0, ldb = 0, nbend_total = 0, bend_begin = 0;
+    std::vector<int> bend_perm;
+    DevBuf<int4> h_idx; DevBuf<double> h_coef, h_u, h_z, h_sc, h_gam, h_cf; SellDev h_inc;
     // pins
     int npin_terms = 0;      // SpringPin energy terms (linsolver 0/2)
     std::vector<int> pin_vert_h; // creation-time pin vertices (terms), in term order
     DevBuf<int> vert_pin, pin_active;
     DevBuf<double> pin_xyz, pin_u, pin_z;
     double pin_weight = 0.0;
+    // slide pins (desc.pin_normal): unit normals per pin term (linsolver 0 / 2) or per vertex (linsolver 1); zero = ordinary pin
+    DevBuf<double> pin_nrm, gs_pin_nrm; std::vector<double> pin_nrm_h; bool has_slide = false;
     // in-sweep pins (linsolver 1)
     DevBuf<int> gs_pin_flag;
     DevBuf<double> gs_pin_xyz;
@@ -212,6 +223,7 @@ struct admm_hip_ctx {
     DevBuf<double> bk_x, bk_v; std::vector<std::pair<int, double> > pending; bool oc_gave_up = false;
     // WindForce on the device (admm_hip_set_wind): triangles, their vertex incidence, per-triangle forces
     int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
+    DevBuf<unsigned long long> gs_proj; long long uz_rows_total = 0;   // admm_hip_contact_totals: rows projected inside the GS sweeps (device), rows of C over all UzawaCG solves (host)
     long long oc_launches = 0, gsp_launches = 0;   // persistent launches since create (admm_hip_persistent_launches)
     int test_abort_seq = 0;   // tests only (ADMM_HIP_TEST_ABORT_SOLVE=k): the k-th on-chip solve of the context finds its barrier aborted
     int test_abort_uzp = 0;   // tests only (ADMM_HIP_TEST_ABORT_SCHUR=k): the k-th persistent Schur launch finds its hand-off given up
@@ -304,6 +316,7 @@ struct admm_hip_ctx {
         t_mat.release(); mats.release(); spl_tab.release(); t_inc.release(); g_order.release();
         r_idx.release(); r_rest.release(); r_u.release(); r_z.release(); r_sc.release(); r_cf.release();
         r_lmin.release(); r_lmax.release(); r_inc.release();
+        h_idx.release(); h_coef.release(); h_u.release(); h_z.release(); h_sc.release(); h_gam.release(); h_cf.release(); h_inc.release(); pin_nrm.release(); gs_pin_nrm.release();
         vert_pin.release(); pin_active.release(); pin_xyz.release(); pin_u.release(); pin_z.release();
         gs_pin_flag.release(); gs_pin_xyz.release();
         A.release(); csr_rowptr.release(); csr_col.release(); csr_val.release();
@@ -315,7 +328,7 @@ struct admm_hip_ctx {
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         gsp_hdr.release(); gsp_orig.release(); gsp_out.release(); gsp_hbox.release(); gsp_horig.release(); gsp_diag.release(); gsp_vals.release(); gsp_cols.release();
         obst_gmeta.release(); obst_gdata.release(); obst_dev.release();
-        gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release(); gsp_prof.release();
+        gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release(); gsp_prof.release(); gs_proj.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -402,6 +415,9 @@ void launch_local_impl(admm_hip_ctx *c) {
             hipLaunchKernelGGL((k_local_tris<WRITE_Z>), dim3(blocks_for(c->ntri)), dim3(256), 0, st, c->ntri, c->ldr, c->r_idx.p,
                                c->r_rest.p, c->r_u.p, c->r_z.p, c->r_sc.p, c->r_lmin.p, c->r_lmax.p, c->curr.p, c->r_cf.p);
     }
+    if (c->nbend > 0)
+        hipLaunchKernelGGL((k_local_bends<WRITE_Z>), dim3(blocks_for(c->nbend)), dim3(256), 0, st, c->nbend, c->ldb, c->h_idx.p, c->h_coef.p, c->h_u.p, c->h_z.p,
+                           c->h_sc.p, c->h_gam.p, c->curr.p, c->h_cf.p);
 }
 template <bool WRITE_Z>
 void launch_local(admm_hip_ctx *c) {      // Binv recomputed from the rest positions / streamed: decided once, in admm_hip_create
@@ -414,7 +430,9 @@ void launch_gather(admm_hip_ctx *c) {
     a.nv = c->nv; a.n_slices = (c->nv + 63) / 64;
     if (c->nt > 0) { a.t_ptr = c->t_inc.ptr.p; a.t_w = c->t_inc.w.p; a.t_inc = c->t_inc.idx.p; a.t_rec = c->t_rec.p; }
     if (c->ntri > 0) { a.r_ptr = c->r_inc.ptr.p; a.r_w = c->r_inc.w.p; a.r_inc = c->r_inc.idx.p; a.r_cf = c->r_cf.p; a.r_ld = c->ldr; }
+    if (c->nbend > 0) { a.h_ptr = c->h_inc.ptr.p; a.h_w = c->h_inc.w.p; a.h_inc = c->h_inc.idx.p; a.h_cf = c->h_cf.p; a.h_ld = c->ldb; }
     if (c->npin_terms > 0) {
+        a.pin_nrm = c->has_slide ? c->pin_nrm.p : nullptr;
         a.vert_pin = c->vert_pin.p; a.pin_xyz = c->pin_xyz.p; a.pin_active = c->pin_active.p;
         a.pin_u = c->pin_u.p; a.pin_z = c->pin_z.p; a.pin_sc = c->dt * c->dt * c->pin_weight * c->pin_weight;
     }
@@ -991,7 +1009,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
         }
         if (c->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_coll0, c->ev_coll1) == hipSuccess) c->coll_ms_step += ms; }
     }
-    c->uz_last_hits = nh;
+    c->uz_last_hits = nh; c->uz_rows_total += nh;
     if (nh != c->uz_prev_hits) { // multipliers are kept only while the number of rows is unchanged (UzawaCG.hpp:74)
         if (hipMemsetAsync(c->uz_y.p, 0, nv * sizeof(double), st) != hipSuccess) return -1;
         c->uz_prev_hits = nh;
@@ -1145,9 +1163,10 @@ void enqueue_gs(admm_hip_ctx *c, const double *b, double *x) {
     (void)hipMemsetAsync(c->counters.p + 1, 0, 2 * sizeof(int), st);
     GsArgs a{};
     a.S = sell_arg(c->gs_sell); a.slot_node = c->gs_slot_node.p; a.diag = c->gs_diag.p; a.m = c->m.p; a.b = b; a.x = x;
-    a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p;
+    a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p; a.pin_nrm = c->gs_pin_nrm.p;
     a.omega = c->gs_omega; a.done = c->counters.p + 1;
     a.part = c->part.p; a.NBp = c->NB; a.tol2 = c->gs_tol * c->gs_tol; a.sweeps = c->counters.p + 2; a.total = c->counters.p;
+    a.proj = c->gs_proj.p;
     const SellA A = sell_arg(c->A);
     const int check = c->gs_tol > 0.0 ? 1 : 0;
     if (check && c->n_colors == 2 && c->gs_xb.p && c->gs_max_iters > 0) {
@@ -1214,13 +1233,13 @@ void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
     a.hdr = c->gsp_hdr.p; a.orig = c->gsp_orig.p; a.out_idx = c->gsp_out.p; a.halo_box = c->gsp_hbox.p; a.halo_orig = c->gsp_horig.p;
     a.diag = c->gsp_diag.p; a.vals = c->gsp_vals.p; a.cols = c->gsp_cols.p;
     a.m = c->m.p; a.b = b; a.x = x;
-    a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p;
+    a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p; a.pin_nrm = c->gs_pin_nrm.p;
     a.omega = c->gs_omega; a.tol2 = c->gs_tol * c->gs_tol; a.max_sweeps = c->gs_max_iters; a.check = c->gs_tol > 0.0 ? 1 : 0;
     a.seq = (unsigned)++c->solve_seq;
     a.box = (v4u *)c->gsp_box.p; a.part = (v4u *)c->gsp_part.p; a.meet = (v4u *)c->gsp_meet.p; a.abort_word = c->gsp_abort.p;
     a.done = c->counters.p + 1; a.sweeps = c->counters.p + 2; a.total = c->counters.p; a.sig = c->d_sig;
     a.prof = c->gsp_prof.p; a.prof_block = c->gsp_prof_block;
-    a.ob = c->obst_dev.p;
+    a.ob = c->obst_dev.p; a.proj = c->gs_proj.p;
     if (c->test_abort_seq > 0 && (int)a.seq == c->test_abort_seq)   // test hook: this solve finds its hand-off given up
         (void)hipMemsetAsync(c->gsp_abort.p, 1, sizeof(unsigned), st);
     hipLaunchKernelGGL(k_gs_persist, dim3(c->gsp_G), dim3(kGspT), c->gsp_lds, st, a);
@@ -1416,7 +1435,7 @@ int launch_gs_dynamic(admm_hip_ctx *c, const double *b, double *x) {
     const int NBp = c->NB + 1;
     GsArgs a{};
     a.S = sell_arg(c->gs_sell); a.slot_node = c->gs_slot_node.p; a.diag = c->gs_diag.p; a.m = c->m.p; a.b = b; a.x = x;
-    a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p;
+    a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p; a.pin_nrm = c->gs_pin_nrm.p;
     a.omega = c->gs_omega; a.done = c->counters.p + 1;
     a.part = c->gsd_part.p; a.NBp = NBp; a.tol2 = c->gs_tol * c->gs_tol; a.sweeps = c->counters.p + 2; a.total = c->counters.p;
     a.skip = c->gsd_skip.p;
@@ -1459,6 +1478,18 @@ int validate(const admm_hip_desc *d) {
     if (d->n_tris && (!d->tri_idx || !d->tri_rest || !d->tri_weight || !d->tri_limit_min || !d->tri_limit_max))
         return fail(ADMM_HIP_ERR_ARG, "tri arrays missing");
     if (d->n_pins && (!d->pin_vert || !d->pin_xyz)) return fail(ADMM_HIP_ERR_ARG, "pin arrays missing");
+    if (d->n_bends < 0) return fail(ADMM_HIP_ERR_ARG, "negative count");
+    if (d->n_bends && (!d->bend_idx || !d->bend_coef || !d->bend_weight || !d->bend_stiffness)) return fail(ADMM_HIP_ERR_ARG, "bend arrays missing");
+    if ((int64_t)96 * ((int64_t)d->n_bends + 1) >= ((int64_t)1 << 31)) return fail(ADMM_HIP_ERR_ARG, "scene too large for one context (limit: 22.3 M bending hinges per rank)");
+    for (int64_t i = 0; i < (int64_t)4 * d->n_bends; ++i)
+        if (d->bend_idx[i] < 0 || d->bend_idx[i] >= d->n_verts) return fail(ADMM_HIP_ERR_ARG, "bend index out of range");
+    for (int i = 0; i < d->n_bends; ++i) {
+        if (!(d->bend_weight[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "Some weight leq 0 (EnergyTerm.hpp:124-126)");
+        if (!(d->bend_stiffness[i] >= 0.0)) return fail(ADMM_HIP_ERR_ARG, "negative bending stiffness");
+    }
+    if (d->pin_normal)
+        for (int64_t i = 0; i < (int64_t)3 * d->n_pins; ++i)
+            if (!std::isfinite(d->pin_normal[i])) return fail(ADMM_HIP_ERR_ARG, "non-finite pin normal");
     if (d->linsolver < 0 || d->linsolver > 2) return fail(ADMM_HIP_ERR_ARG, "linsolver must be 0, 1 or 2");
     if (d->n_obstacles < 0 || d->n_obstacles > kMaxObst) return fail(ADMM_HIP_ERR_ARG, "too many obstacles (max 8)");
     if (d->n_obstacles && d->linsolver == 0)
@@ -1484,7 +1515,7 @@ int validate(const admm_hip_desc *d) {
         if (d->tri_idx[i] < 0 || d->tri_idx[i] >= d->n_verts) return fail(ADMM_HIP_ERR_ARG, "tri index out of range");
     for (int i = 0; i < d->n_tets; ++i) {
         if (!(d->tet_weight[i] > 0.0)) return fail(ADMM_HIP_ERR_ARG, "Some weight leq 0 (EnergyTerm.hpp:124-126)");
-        if (d->tet_kind[i] < 0 || d->tet_kind[i] > ADMM_TET_SPLINE_TABLE) return fail(ADMM_HIP_ERR_ARG, "unknown tet kind");
+        if (d->tet_kind[i] < 0 || d->tet_kind[i] > ADMM_TET_STABLE_NH) return fail(ADMM_HIP_ERR_ARG, "unknown tet kind");
         if (d->tet_kind[i] == ADMM_TET_SPLINE_TABLE &&
             (!d->spline_tables || !d->tet_spline || d->tet_spline[i] < 0 || d->tet_spline[i] >= d->n_spline_tables))
             return fail(ADMM_HIP_ERR_ARG, "SplineTet with a user-defined spline: its table (admm_host_tabulate_spline) is missing");
@@ -1524,7 +1555,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     if (d->world_size <= 1 || force_el) return create_impl(d, out);
     const int world = d->world_size, rank = d->rank, nv = d->n_verts;
     std::vector<int32_t> vrank(nv);
-    const int32_t ncomp = admm_host::component_partition(nv, d->n_tets, d->tet_idx, d->n_tris, d->tri_idx, world, vrank.data());
+    const int32_t ncomp = admm_host::component_partition(nv, d->n_tets, d->tet_idx, d->n_tris, d->tri_idx, world, vrank.data(), d->n_bends, d->bend_idx);
     if (ncomp < world) {
         if (force_co) return fail(ADMM_HIP_ERR_ARG, "ADMM_HIP_PARTITION=components: the scene has fewer connected components (bodies with elements) than ranks");
         return create_impl(d, out);
@@ -1544,7 +1575,13 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     for (int32_t i = 0; i < nl; ++i) for (int j = 0; j < 3; ++j) masses[3 * (size_t)i + j] = d->masses[3 * (size_t)l2g[i] + j];
     if (d->vert_xyz) { xyz.resize(3 * (size_t)nl); for (int32_t i = 0; i < nl; ++i) for (int j = 0; j < 3; ++j) xyz[3 * (size_t)i + j] = d->vert_xyz[3 * (size_t)l2g[i] + j]; }
     std::vector<int32_t> t_idx, t_kind, r_idx, p_vert, p_act, colors, t_spl;
-    std::vector<double> t_Binv, t_w, t_mu, t_la, t_k, t_kap, r_rest, r_w, r_lmin, r_lmax, p_xyz;
+    std::vector<double> t_Binv, t_w, t_mu, t_la, t_k, t_kap, r_rest, r_w, r_lmin, r_lmax, p_xyz, p_nrm, h_coef, h_w, h_k;
+    std::vector<int32_t> h_idx;
+    for (int32_t t = 0; t < d->n_bends; ++t) {
+        if (vrank[d->bend_idx[4 * (size_t)t]] != rank) continue;
+        for (int k = 0; k < 4; ++k) { h_idx.push_back(g2l[d->bend_idx[4 * (size_t)t + k]]); h_coef.push_back(d->bend_coef[4 * (size_t)t + k]); }
+        h_w.push_back(d->bend_weight[t]); h_k.push_back(d->bend_stiffness[t]);
+    }
     for (int32_t t = 0; t < d->n_tets; ++t) {
         if (vrank[d->tet_idx[4 * (size_t)t]] != rank) continue;
         for (int k = 0; k < 4; ++k) t_idx.push_back(g2l[d->tet_idx[4 * (size_t)t + k]]);
@@ -1564,6 +1601,7 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
         p_vert.push_back(g2l[d->pin_vert[p]]);
         for (int j = 0; j < 3; ++j) p_xyz.push_back(d->pin_xyz[3 * (size_t)p + j]);
         if (d->pin_active) p_act.push_back(d->pin_active[p]);
+        if (d->pin_normal) for (int j = 0; j < 3; ++j) p_nrm.push_back(d->pin_normal[3 * (size_t)p + j]);
     }
     if (d->gs_colors) { colors.resize(nl); for (int32_t i = 0; i < nl; ++i) colors[i] = d->gs_colors[l2g[i]]; }
     admm_hip_desc sub = *d;
@@ -1575,6 +1613,8 @@ int admm_hip_create(const admm_hip_desc *d, admm_hip_ctx **out) {
     sub.tri_limit_min = r_lmin.data(); sub.tri_limit_max = r_lmax.data();
     sub.n_pins = (int32_t)p_vert.size(); sub.pin_vert = p_vert.data(); sub.pin_xyz = p_xyz.data(); sub.pin_active = d->pin_active ? p_act.data() : nullptr;
     sub.gs_colors = d->gs_colors ? colors.data() : nullptr;
+    sub.pin_normal = d->pin_normal ? p_nrm.data() : nullptr;
+    sub.n_bends = (int32_t)h_w.size(); sub.bend_idx = h_idx.data(); sub.bend_coef = h_coef.data(); sub.bend_weight = h_w.data(); sub.bend_stiffness = h_k.data();
     sub.rank = 0; sub.world_size = 0;
     if (int rc = create_impl(&sub, out)) return rc;
     admm_hip_ctx *c = *out;
@@ -1604,6 +1644,9 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     c->pcg_max_iters = d->pcg_max_iters > 0 ? d->pcg_max_iters : 500;
     c->pcg_tol = d->pcg_tol > 0 ? d->pcg_tol : 1e-10;
     { const char *e1 = getenv("ADMM_HIP_TOL_LAST"), *e2 = getenv("ADMM_HIP_TOL_LAST_N"); c->tol_last = e1 ? atof(e1) : 0.0; c->tol_last_n = e2 ? atoi(e2) : 0; }
+    if (const char *ts = getenv("ADMM_HIP_TOL_SCHED")) {   // experiments: "20,20,5" = the first three solves of a step at 20x, 20x, 5x pcg_tol
+        for (const char *q = ts; *q; ) { char *end = nullptr; const double v = strtod(q, &end); if (end == q) break; c->tol_sched.push_back(v > 0.0 ? v : 1.0); q = *end == ',' ? end + 1 : end; }
+    }
     c->gs_max_iters = d->gs_max_iters > 0 ? d->gs_max_iters : 30;
     c->gs_tol = d->gs_tol >= 0 ? d->gs_tol : 1e-10;
     c->gs_omega = d->gs_omega > 0 ? d->gs_omega : 1.9;
@@ -1622,12 +1665,13 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     // ---- element-block partition (multi-GPU): contiguous blocks of the caller's element order ----
     c->world = d->world_size > 1 ? d->world_size : 1;
     c->rank = d->world_size > 1 ? d->rank : 0;
-    int32_t tb = 0, te = d->n_tets, rb = 0, re = d->n_tris;
+    int32_t tb = 0, te = d->n_tets, rb = 0, re = d->n_tris, hb = 0, he = d->n_bends;
     if (c->world > 1) {
         admm_host::partition(d->n_tets, c->world, c->rank, &tb, &te);
         admm_host::partition(d->n_tris, c->world, c->rank, &rb, &re);
+        admm_host::partition(d->n_bends, c->world, c->rank, &hb, &he);
     }
-    c->nt_total = d->n_tets; c->ntri_total = d->n_tris; c->tri_begin = rb;
+    c->nt_total = d->n_tets; c->ntri_total = d->n_tris; c->tri_begin = rb; c->nbend_total = d->n_bends; c->bend_begin = hb;
     // rows of the vertex -> (element, corner) incidence lists (k_gather_rhs): by list length inside 512-vertex windows
     std::vector<int32_t> g_order;
     {
@@ -1640,10 +1684,10 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     c->nt = te - tb; c->ldt = c->nt + 1;
     if (c->nt > 0) {
         const int nt = c->nt, ld = c->ldt;
-        auto kap = [&](int t) { return (d->tet_kappa && d->tet_kind[t] >= ADMM_TET_SPLINE_NH) ? d->tet_kappa[t] : 0.0; };
+        auto kap = [&](int t) { return (d->tet_kappa && d->tet_kind[t] >= ADMM_TET_SPLINE_NH && d->tet_kind[t] <= ADMM_TET_SPLINE_COROTATED) ? d->tet_kappa[t] : 0.0; };
         auto grp_t = [&](int t) {   // xu::NeoHookean / xu::StVK splines with kappa = 0 ARE the NH / StVK models
             const int k = d->tet_kind[t];
-            if (kap(t) != 0.0 || k == ADMM_TET_SPLINE_TABLE) return 4;
+            if (kap(t) != 0.0 || k == ADMM_TET_SPLINE_TABLE || k == ADMM_TET_STABLE_NH) return 4;
             return k == ADMM_TET_LINEAR ? 0 : (k == ADMM_TET_STVK || k == ADMM_TET_SPLINE_STVK) ? 2 : k == ADMM_TET_SPLINE_COROTATED ? 3 : 1;
         };
         c->tet_perm.resize(nt);
@@ -1674,10 +1718,10 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
             idx[n] = make_int4(d->tet_idx[4 * o], d->tet_idx[4 * o + 1], d->tet_idx[4 * o + 2], d->tet_idx[4 * o + 3]);
             for (int k = 0; k < 9; ++k) Binv[(size_t)k * ld + n] = d->tet_Binv[9 * (size_t)o + k];
             sc[n] = dt2 * d->tet_weight[o] * d->tet_weight[o];
-            const bool tabulated = d->tet_kind[o] == ADMM_TET_SPLINE_TABLE;
-            const int stype = tabulated ? 3 : d->tet_kind[o] == ADMM_TET_SPLINE_STVK ? 1 : d->tet_kind[o] == ADMM_TET_SPLINE_COROTATED ? 2 : 0;
+            const bool tabulated = d->tet_kind[o] == ADMM_TET_SPLINE_TABLE, snh = d->tet_kind[o] == ADMM_TET_STABLE_NH;
+            const int stype = tabulated ? 3 : snh ? 4 : d->tet_kind[o] == ADMM_TET_SPLINE_STVK ? 1 : d->tet_kind[o] == ADMM_TET_SPLINE_COROTATED ? 2 : 0;
             const int table = tabulated ? d->tet_spline[o] : 0;
-            auto key = std::make_tuple(d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), (kap(o) != 0.0 || tabulated) ? stype : 0, table);
+            auto key = std::make_tuple(d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), (kap(o) != 0.0 || tabulated || snh) ? stype : 0, table);
             auto it = mat_map.find(key);
             if (it == mat_map.end()) { it = mat_map.emplace(key, (int)mats.size()).first; mats.push_back(Mat{d->tet_mu[o], d->tet_lambda[o], d->tet_k[o], kap(o), stype, table}); }
             mat[n] = it->second;
@@ -1742,10 +1786,45 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->r_cf.alloc((size_t)12 * ld)); HIP_TRY(c->r_cf.zero());
         HIP_TRY(c->r_inc.upload(admm_host::incidence_sell(nv, n, 3, tri_sorted.data(), n * 4, g_order.data())));
     }
+    // ---- bending hinges ----
+    c->nbend = he - hb; c->ldb = c->nbend + 1;
+    if (c->nbend > 0) {
+        const int n = c->nbend, ld = c->ldb;
+        c->bend_perm.resize(n);
+        std::iota(c->bend_perm.begin(), c->bend_perm.end(), hb);
+        auto hmin = [&](int t) { const int32_t *q = d->bend_idx + 4 * (size_t)t; return std::min(std::min(q[0], q[1]), std::min(q[2], q[3])); };
+        std::stable_sort(c->bend_perm.begin(), c->bend_perm.end(), [&](int a, int b) { return hmin(a) < hmin(b); });   // same locality rule as the other elements
+        std::vector<int4> idx(n);
+        std::vector<int32_t> sorted(4 * (size_t)n);
+        std::vector<double> coef((size_t)4 * ld, 0.0), sc(ld, 0.0), gam(ld, 0.0);
+        for (int t = 0; t < n; ++t) {
+            const int o = c->bend_perm[t];
+            const int32_t *q = d->bend_idx + 4 * (size_t)o;
+            idx[t] = make_int4(q[0], q[1], q[2], q[3]);
+            for (int k = 0; k < 4; ++k) { sorted[4 * (size_t)t + k] = q[k]; coef[(size_t)k * ld + t] = d->bend_coef[4 * (size_t)o + k]; }
+            const double w2 = d->bend_weight[o] * d->bend_weight[o];
+            sc[t] = dt2 * w2; gam[t] = w2 / (d->bend_stiffness[o] + w2);
+        }
+        HIP_TRY(c->h_idx.upload(idx)); HIP_TRY(c->h_coef.upload(coef)); HIP_TRY(c->h_sc.upload(sc)); HIP_TRY(c->h_gam.upload(gam));
+        HIP_TRY(c->h_u.alloc((size_t)3 * ld)); HIP_TRY(c->h_u.zero());
+        HIP_TRY(c->h_z.alloc((size_t)3 * ld)); HIP_TRY(c->h_z.zero());
+        HIP_TRY(c->h_cf.alloc((size_t)12 * ld)); HIP_TRY(c->h_cf.zero());
+        HIP_TRY(c->h_inc.upload(admm_host::incidence_sell(nv, n, 4, sorted.data(), n * 4, g_order.data())));
+    }
     // ---- pins ----
     double max_w = 0.0;
     for (int t = 0; t < d->n_tets; ++t) max_w = std::max(max_w, d->tet_weight[t]);
     for (int t = 0; t < d->n_tris; ++t) max_w = std::max(max_w, d->tri_weight[t]);
+    for (int t = 0; t < d->n_bends; ++t) max_w = std::max(max_w, d->bend_weight[t]);
+    // unit normals of the slide pins (zero = ordinary pin)
+    std::vector<double> nrm_pin(3 * (size_t)d->n_pins, 0.0);
+    bool any_slide = false;
+    if (d->pin_normal)
+        for (int p = 0; p < d->n_pins; ++p) {
+            const double *q = d->pin_normal + 3 * (size_t)p;
+            const double l = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+            if (l > 0.0) { for (int j = 0; j < 3; ++j) nrm_pin[3 * (size_t)p + j] = q[j] / l; any_slide = true; }
+        }
     {
         double mu, la, k;
         admm_host::lame(10000000.0, 0.499, &mu, &la, &k); // Lame::rubber(), SpringEnergyTerm.hpp:50-51
@@ -1766,17 +1845,22 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->vert_pin.upload(vp)); HIP_TRY(c->pin_active.upload(act)); HIP_TRY(c->pin_xyz.upload(xyz));
         HIP_TRY(c->pin_u.alloc(3 * (size_t)d->n_pins)); HIP_TRY(c->pin_u.zero());
         HIP_TRY(c->pin_z.alloc(3 * (size_t)d->n_pins)); HIP_TRY(c->pin_z.zero());
+        c->pin_nrm_h = nrm_pin; c->has_slide = any_slide;
+        HIP_TRY(c->pin_nrm.upload(nrm_pin));
     }
     if (d->linsolver == 1) {
         std::vector<int> flag(nv, 0);
         std::vector<double> xyz((size_t)3 * nv, 0.0);
+        c->pin_nrm_h.assign((size_t)3 * nv, 0.0);      // (per VERTEX with this solver: the pin set is replaced freely)
         for (int p = 0; p < d->n_pins; ++p) {
             if (d->pin_active && !d->pin_active[p]) continue;
-            flag[d->pin_vert[p]] = 1;
-            for (int j = 0; j < 3; ++j) xyz[3 * (size_t)d->pin_vert[p] + j] = d->pin_xyz[3 * (size_t)p + j];
+            const bool slide = nrm_pin[3 * (size_t)p] != 0.0 || nrm_pin[3 * (size_t)p + 1] != 0.0 || nrm_pin[3 * (size_t)p + 2] != 0.0;
+            flag[d->pin_vert[p]] = slide ? 2 : 1;
+            for (int j = 0; j < 3; ++j) { xyz[3 * (size_t)d->pin_vert[p] + j] = d->pin_xyz[3 * (size_t)p + j]; c->pin_nrm_h[3 * (size_t)d->pin_vert[p] + j] = nrm_pin[3 * (size_t)p + j]; }
             c->gs_has_pins = true;
         }
-        HIP_TRY(c->gs_pin_flag.upload(flag)); HIP_TRY(c->gs_pin_xyz.upload(xyz));
+        c->has_slide = any_slide;
+        HIP_TRY(c->gs_pin_flag.upload(flag)); HIP_TRY(c->gs_pin_xyz.upload(xyz)); HIP_TRY(c->gs_pin_nrm.upload(c->pin_nrm_h));
     }
     // constraint weight: Solver.cpp:235 (GS: 3 max W), :239 (Uzawa: 1), :245 (override)
     c->constraint_w = (d->linsolver == 1) ? 3.0 * max_w : 1.0;
@@ -1806,6 +1890,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     // ---- system matrix ----
     c->Ahat = admm_host::assemble_Ahat(nv, c->dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris, d->tri_idx,
                                        d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, c->pin_weight);
+    if (d->n_bends > 0) c->Ahat = admm_host::add_stencil_terms(c->Ahat, c->dt, d->n_bends, d->bend_idx, d->bend_coef, d->bend_weight);
     {
         const admm_host::Sell S = admm_host::csr_to_sell(c->Ahat);
         for (int w : S.slice_width) c->A_wmax = std::max(c->A_wmax, w);
@@ -1939,6 +2024,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
             }
         }
     }
+    if (d->linsolver == 1) { HIP_TRY(c->gs_proj.alloc(1)); HIP_TRY(c->gs_proj.zero()); }
     if (d->linsolver == 1) HIP_TRY(plan_gs_persist(c));
     if (d->linsolver == 2) {
         { const char *fz = getenv("ADMM_HIP_UZ_FREEZE"); c->uz_freeze = fz && fz[0] == '1'; }
@@ -1982,7 +2068,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
 
 void admm_hip_destroy(admm_hip_ctx *ctx) { delete ctx; }
 
-int admm_hip_num_rows(const admm_hip_ctx *c) { return c ? 9 * c->nt_total + 6 * c->ntri_total + 6 * c->npin_terms : 0; }
+int admm_hip_num_rows(const admm_hip_ctx *c) { return c ? 9 * c->nt_total + 6 * c->ntri_total + 3 * c->nbend_total + 6 * c->npin_terms : 0; }
 
 static int set_state_impl(admm_hip_ctx *c, const double *x, const double *v);
 static int get_state_impl(admm_hip_ctx *c, double *x, double *v);
@@ -2093,7 +2179,8 @@ static int set_pins_impl(admm_hip_ctx *c, int32_t n, const int32_t *vert, const 
         std::vector<double> p((size_t)c->n3, 0.0);
         for (int i = 0; i < n; ++i) {
             if (vert[i] < 0 || vert[i] >= c->nv) return fail(ADMM_HIP_ERR_ARG, "set_pins: index out of range");
-            flag[vert[i]] = 1;
+            const double *q = c->pin_nrm_h.data() + 3 * (size_t)vert[i];      // (a vertex keeps the slide normal it was given)
+            flag[vert[i]] = (c->has_slide && (q[0] != 0.0 || q[1] != 0.0 || q[2] != 0.0)) ? 2 : 1;
             for (int j = 0; j < 3; ++j) p[3 * (size_t)vert[i] + j] = xyz[3 * (size_t)i + j];
         }
         c->gs_has_pins = n > 0;
@@ -2123,6 +2210,44 @@ static int set_pins_impl(admm_hip_ctx *c, int32_t n, const int32_t *vert, const 
 }
 
 // Solver::ext_forces.push_back(std::make_shared<WindForce>(tris)) + WindForce::direction (src/ExplicitForce.hpp:39-46)
+int admm_hip_set_pin_normals(admm_hip_ctx *c, int32_t n, const int32_t *vert, const double *normals) {
+    if (!c || n < 0 || (n > 0 && (!vert || !normals))) return fail(ADMM_HIP_ERR_ARG, "set_pin_normals: bad input");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = settle(c)) return rc;
+    std::map<int, int> term_of;
+    if (c->linsolver != 1) for (int i = 0; i < c->npin_terms; ++i) term_of[c->pin_vert_h[i]] = i;
+    std::vector<int> flag;
+    if (c->linsolver == 1) { flag.resize(c->nv); HIP_TRY(hipMemcpy(flag.data(), c->gs_pin_flag.p, flag.size() * sizeof(int), hipMemcpyDeviceToHost)); }
+    for (int i = 0; i < n; ++i) {
+        int32_t v = vert[i];
+        if (c->cm.on) { if (v < 0 || v >= c->cm.nv_global) return fail(ADMM_HIP_ERR_ARG, "set_pin_normals: index out of range"); v = c->cm.g2l[v]; if (v < 0) continue; }
+        if (v < 0 || v >= c->nv) return fail(ADMM_HIP_ERR_ARG, "set_pin_normals: index out of range");
+        const double *q = normals + 3 * (size_t)i;
+        const double l = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        if (!std::isfinite(l)) return fail(ADMM_HIP_ERR_ARG, "set_pin_normals: non-finite normal");
+        size_t slot;
+        if (c->linsolver == 1) {
+            if (!flag[v]) return fail(ADMM_HIP_ERR_ARG, "Solver::set_pins Error: Constraint for " + std::to_string(vert[i]) + " not found.");
+            slot = (size_t)v; flag[v] = l > 0.0 ? 2 : 1;
+        } else {
+            auto it = term_of.find(v);
+            if (it == term_of.end()) return fail(ADMM_HIP_ERR_ARG, "Solver::set_pins Error: Constraint for " + std::to_string(vert[i]) + " not found.");
+            slot = (size_t)it->second;
+        }
+        for (int j = 0; j < 3; ++j) c->pin_nrm_h[3 * slot + j] = l > 0.0 ? q[j] / l : 0.0;
+    }
+    c->has_slide = false;
+    for (double x : c->pin_nrm_h) if (x != 0.0) { c->has_slide = true; break; }
+    if (c->linsolver == 1) {
+        if (c->gs_exec) { (void)hipGraphExecDestroy(c->gs_exec); c->gs_exec = nullptr; }
+        HIP_TRY(hipMemcpy(c->gs_pin_flag.p, flag.data(), flag.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->gs_pin_nrm.p, c->pin_nrm_h.data(), c->pin_nrm_h.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else if (c->npin_terms)
+        HIP_TRY(hipMemcpy(c->pin_nrm.p, c->pin_nrm_h.data(), c->pin_nrm_h.size() * sizeof(double), hipMemcpyHostToDevice));
+    return ADMM_HIP_OK;
+}
+
 static int set_wind_impl(admm_hip_ctx *c, int32_t n_tris, const int32_t *tris, const double *direction);
 int admm_hip_set_wind(admm_hip_ctx *c, int32_t n_tris, const int32_t *tris, const double *direction) {
     if (!c || n_tris < 0 || (n_tris > 0 && (!tris || !direction))) return fail(ADMM_HIP_ERR_ARG, "set_wind: bad input");
@@ -2200,6 +2325,7 @@ static int set_surface_inds_impl(admm_hip_ctx *c, int32_t n, const int32_t *inds
 // Solver::add_dynamic_collider(TetMeshCollision(mesh, v_offset)) -- src/Solver.cpp:163-165, src/DynamicObject.hpp:45-64
 int admm_hip_add_dynamic_tetmesh(admm_hip_ctx *c, int32_t vert_offset, int32_t n_verts, const double *rest_verts,
                                  int32_t n_tets, const int32_t *tets, int32_t n_faces, const int32_t *faces) {
+    if (c && c->linsolver == 1 && c->has_slide) return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: slide pins inside the sweeps of the dynamic-hit GS path are not supported (use linsolver 2)");
     if (c && c->cm.on) return fail(ADMM_HIP_ERR_STATE, "add_dynamic_tetmesh: dynamic colliders couple the bodies -- create the rank contexts with ADMM_HIP_PARTITION=elements");
     if (!c || !rest_verts || !tets || n_verts <= 0 || n_tets <= 0 || vert_offset < 0 || vert_offset + n_verts > c->nv)
         return fail(ADMM_HIP_ERR_ARG, "add_dynamic_tetmesh: bad input");
@@ -2389,6 +2515,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     // curr_u = 0 (Solver.cpp:71); curr_z = D x is a dead store in the reference (:70)
     if (c->nt) HIP_TRY(hipMemsetAsync(c->t_u.p, 0, c->t_u.n * sizeof(double), st));
     if (c->ntri) HIP_TRY(hipMemsetAsync(c->r_u.p, 0, c->r_u.n * sizeof(double), st));
+    if (c->nbend) HIP_TRY(hipMemsetAsync(c->h_u.p, 0, c->h_u.n * sizeof(double), st));
     if (c->npin_terms) HIP_TRY(hipMemsetAsync(c->pin_u.p, 0, c->pin_u.n * sizeof(double), st));
     for (int s = 0; s < admm_iters; ++s) {
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s], st));
@@ -2412,6 +2539,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         // experiments (ADMM_HIP_TOL_LAST=tol, ADMM_HIP_TOL_LAST_N=k): the last k solves of a step at another tolerance
         const double keep_tol = c->pcg_tol;
         if (c->tol_last > 0.0 && s >= admm_iters - c->tol_last_n) c->pcg_tol = c->tol_last;
+        if ((size_t)s < c->tol_sched.size()) c->pcg_tol = keep_tol * c->tol_sched[s];
         const int grc = launch_global(c, c->b.p, c->curr.p);   // Solver.cpp:99
         c->pcg_tol = keep_tol;
         if (grc == -2) return kStepAborted;       // a grid barrier timed out in a column solve of UzawaCG: same recovery as any aborted on-chip solve
@@ -2534,24 +2662,30 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
 }
 
 // z/u between the reference row layout (AoS, caller's term order) and the device SoA (sorted tets)
-static void rows_to_dev(const admm_hip_ctx *c, const double *rows, std::vector<double> &tu, std::vector<double> &ru, std::vector<double> &pu) {
-    tu.assign((size_t)9 * c->ldt, 0.0); ru.assign((size_t)6 * c->ldr, 0.0); pu.assign(3 * (size_t)c->npin_terms, 0.0);
+static void rows_to_dev(const admm_hip_ctx *c, const double *rows, std::vector<double> &tu, std::vector<double> &ru, std::vector<double> &pu, std::vector<double> &hu) {
+    tu.assign((size_t)9 * c->ldt, 0.0); ru.assign((size_t)6 * c->ldr, 0.0); pu.assign(3 * (size_t)c->npin_terms, 0.0); hu.assign((size_t)3 * c->ldb, 0.0);
     for (int n = 0; n < c->nt; ++n)
         for (int k = 0; k < 9; ++k) tu[(size_t)k * c->ldt + n] = rows[9 * (size_t)c->tet_perm[n] + k];
     const double *r = rows + 9 * (size_t)c->nt_total;
     for (int t = 0; t < c->ntri; ++t)
         for (int k = 0; k < 6; ++k) ru[(size_t)k * c->ldr + t] = r[6 * (size_t)c->tri_perm[t] + k];
     r += 6 * (size_t)c->ntri_total;
+    for (int t = 0; t < c->nbend; ++t)
+        for (int k = 0; k < 3; ++k) hu[(size_t)k * c->ldb + t] = r[3 * (size_t)c->bend_perm[t] + k];
+    r += 3 * (size_t)c->nbend_total;
     for (int p = 0; p < c->npin_terms; ++p)
         for (int k = 0; k < 3; ++k) pu[3 * (size_t)p + k] = r[6 * (size_t)p + k];
 }
-static void dev_to_rows(const admm_hip_ctx *c, const std::vector<double> &tu, const std::vector<double> &ru, const std::vector<double> &pu, double *rows) {
+static void dev_to_rows(const admm_hip_ctx *c, const std::vector<double> &tu, const std::vector<double> &ru, const std::vector<double> &pu, const std::vector<double> &hu, double *rows) {
     for (int n = 0; n < c->nt; ++n)
         for (int k = 0; k < 9; ++k) rows[9 * (size_t)c->tet_perm[n] + k] = tu[(size_t)k * c->ldt + n];
     double *r = rows + 9 * (size_t)c->nt_total;
     for (int t = 0; t < c->ntri; ++t)
         for (int k = 0; k < 6; ++k) r[6 * (size_t)c->tri_perm[t] + k] = ru[(size_t)k * c->ldr + t];
     r += 6 * (size_t)c->ntri_total;
+    for (int t = 0; t < c->nbend; ++t)
+        for (int k = 0; k < 3; ++k) r[3 * (size_t)c->bend_perm[t] + k] = hu[(size_t)k * c->ldb + t];
+    r += 3 * (size_t)c->nbend_total;
     for (int p = 0; p < c->npin_terms; ++p) {
         for (int k = 0; k < 3; ++k) r[6 * (size_t)p + k] = pu[3 * (size_t)p + k];
         for (int k = 3; k < 6; ++k) r[6 * (size_t)p + k] = 0.0; // rows 3..5 of a SpringPin are never populated
@@ -2563,12 +2697,13 @@ int admm_hip_local_step(admm_hip_ctx *c, const double *x, double *u_inout, doubl
     if (c->cm.on) return fail(ADMM_HIP_ERR_STATE, "local_step: kernel-level entry points work on the rows of the whole scene; this context holds only its rank's bodies (ADMM_HIP_PARTITION=elements)");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    std::vector<double> tu, ru, pu;
-    rows_to_dev(c, u_inout, tu, ru, pu);
+    std::vector<double> tu, ru, pu, hu;
+    rows_to_dev(c, u_inout, tu, ru, pu, hu);
     HIP_TRY(hipMemcpyAsync(c->curr.p, x, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
     if (c->nt) HIP_TRY(hipMemcpyAsync(c->t_u.p, tu.data(), tu.size() * sizeof(double), hipMemcpyHostToDevice, st));
     if (c->ntri) HIP_TRY(hipMemcpyAsync(c->r_u.p, ru.data(), ru.size() * sizeof(double), hipMemcpyHostToDevice, st));
     if (c->npin_terms) HIP_TRY(hipMemcpyAsync(c->pin_u.p, pu.data(), pu.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    if (c->nbend) HIP_TRY(hipMemcpyAsync(c->h_u.p, hu.data(), hu.size() * sizeof(double), hipMemcpyHostToDevice, st));
     if (Mxbar) HIP_TRY(hipMemcpyAsync(c->Mxbar.p, Mxbar, c->n3 * sizeof(double), hipMemcpyHostToDevice, st));
     else HIP_TRY(hipMemsetAsync(c->Mxbar.p, 0, c->n3 * sizeof(double), st));
     launch_local<true>(c);
@@ -2576,7 +2711,11 @@ int admm_hip_local_step(admm_hip_ctx *c, const double *x, double *u_inout, doubl
     if (c->world > 1 && !c->comm && !c->ar_fn) launch_gather(c);
     else if (launch_rhs(c)) return fail(ADMM_HIP_ERR_COMM, "local_step: ncclAllReduce failed");
     HIP_TRY(hipGetLastError());
-    std::vector<double> tz((size_t)9 * c->ldt), rz((size_t)6 * c->ldr), pz(3 * (size_t)c->npin_terms);
+    std::vector<double> tz((size_t)9 * c->ldt), rz((size_t)6 * c->ldr), pz(3 * (size_t)c->npin_terms), hz((size_t)3 * c->ldb);
+    if (c->nbend) {
+        HIP_TRY(hipMemcpyAsync(hu.data(), c->h_u.p, hu.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hz.data(), c->h_z.p, hz.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     if (c->nt) {
         HIP_TRY(hipMemcpyAsync(tu.data(), c->t_u.p, tu.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(tz.data(), c->t_z.p, tz.size() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -2591,8 +2730,8 @@ int admm_hip_local_step(admm_hip_ctx *c, const double *x, double *u_inout, doubl
     }
     if (b_out) HIP_TRY(hipMemcpyAsync(b_out, c->b.p, c->n3 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    dev_to_rows(c, tu, ru, pu, u_inout);
-    dev_to_rows(c, tz, rz, pz, z_out);
+    dev_to_rows(c, tu, ru, pu, hu, u_inout);
+    dev_to_rows(c, tz, rz, pz, hz, z_out);
     return ADMM_HIP_OK;
 }
 
@@ -2674,6 +2813,21 @@ int admm_hip_get_solver_params(const admm_hip_ctx *c, int32_t kind, int32_t *max
     if (max_iters) *max_iters = it;
     if (tol) *tol = t;
     if (omega) *omega = o;
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_contact_totals(admm_hip_ctx *c, int64_t *rows) {
+    if (!c || !rows) return fail(ADMM_HIP_ERR_ARG, "contact_totals: NULL argument");
+    *rows = 0;
+    if (c->linsolver == 2) { *rows = c->uz_rows_total; return ADMM_HIP_OK; }
+    if (c->linsolver == 1 && c->gs_proj.p) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (int rc = settle(c)) return rc;
+        unsigned long long h = 0;
+        HIP_TRY(hipMemcpy(&h, c->gs_proj.p, sizeof(h), hipMemcpyDeviceToHost));
+        *rows = (int64_t)h;
+    }
     return ADMM_HIP_OK;
 }
 
@@ -2800,6 +2954,33 @@ int admm_hip_comm_init(admm_hip_ctx *c, const char *id128, int rank, int world_s
     return ADMM_HIP_OK;
 }
 
+int admm_hip_comm_info(const admm_hip_ctx *c, int32_t *n_ranks, int32_t *rank, char *device_id64) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "comm_info: NULL context");
+    ncclComm_t cm = c->comm ? c->comm : c->cm_comm;
+    int n = 0, r = -1;
+    if (cm && g_rccl.CommCount && g_rccl.CommUserRank) {      // asked of RCCL itself, not echoed from the arguments of comm_init
+        if (g_rccl.CommCount(cm, &n) != ncclSuccess || g_rccl.CommUserRank(cm, &r) != ncclSuccess) return fail(ADMM_HIP_ERR_COMM, "comm_info: ncclCommCount / ncclCommUserRank failed");
+    }
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
+    if (device_id64) {
+        device_id64[0] = 0;
+        hipUUID u;
+        char bus[32] = {0};
+        (void)hipDeviceGetPCIBusId(bus, (int)sizeof(bus), c->device);
+        std::string sid = "pci ";
+        sid += bus;
+        if (hipDeviceGetUuid(&u, c->device) == hipSuccess) {
+            char hex[40]; int k = 0;
+            for (int i = 0; i < 16 && k < 38; ++i) k += snprintf(hex + k, sizeof(hex) - k, "%02x", (unsigned)(unsigned char)u.bytes[i]);
+            sid += " uuid "; sid += hex;
+        }
+        (void)hipGetLastError();
+        std::strncpy(device_id64, sid.c_str(), 63); device_id64[63] = 0;
+    }
+    return ADMM_HIP_OK;
+}
+
 int admm_hip_set_rhs_allreduce(admm_hip_ctx *c, admm_allreduce_fn fn, void *user) {
     if (!c) return fail(ADMM_HIP_ERR_ARG, "set_rhs_allreduce: NULL context");
     if (c->cm.on) return fail(ADMM_HIP_ERR_STATE, "set_rhs_allreduce: the component partition exchanges nothing inside a step");
@@ -2821,6 +3002,7 @@ int admm_host_assemble_matrix(const admm_hip_desc *d, int32_t *rowptr, int32_t *
     const bool pins_as_terms = (d->linsolver == 0 || d->linsolver == 2);
     admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
                                                 d->tri_idx, d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, pw);
+    if (d->n_bends > 0) A = admm_host::add_stencil_terms(A, dt, d->n_bends, d->bend_idx, d->bend_coef, d->bend_weight);
     if (nnz) *nnz = (int32_t)A.col.size();
     if (rowptr) std::copy(A.rowptr.begin(), A.rowptr.end(), rowptr);
     if (col) std::copy(A.col.begin(), A.col.end(), col);
@@ -2862,7 +3044,7 @@ void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *beg
 }
 int32_t admm_host_component_partition(const admm_hip_desc *d, int world_size, int32_t *vertex_rank) {
     if (!d || !vertex_rank || d->n_verts < 1) return -1;
-    return admm_host::component_partition(d->n_verts, d->n_tets, d->tet_idx, d->n_tris, d->tri_idx, std::max(world_size, 1), vertex_rank);
+    return admm_host::component_partition(d->n_verts, d->n_tets, d->tet_idx, d->n_tris, d->tri_idx, std::max(world_size, 1), vertex_rank, d->n_bends, d->bend_idx);
 }
 int admm_host_tabulate_spline(admm_spline_fn fn, void *user, double s_min, double s_max, double *table_out) {
     const int r = admm_host::tabulate_spline(fn, user, s_min, s_max, table_out);
@@ -2921,6 +3103,10 @@ int admm_host_tet_rest(int32_t n, const int32_t *idx, const double *verts, doubl
     int r = admm_host::tet_rest(n, idx, verts, Binv, vol);
     if (r) return fail(ADMM_HIP_ERR_GEOMETRY, "TetEnergyTerm Error: Inverted initial tet " + std::to_string(-r - 1));
     return ADMM_HIP_OK;
+}
+int32_t admm_host_bend_hinges(int32_t n_verts, int32_t n_tris, const int32_t *tris, const double *verts, int32_t cap, int32_t *hinge_idx, double *coef, double *area) {
+    if (n_verts < 0 || n_tris < 0 || (n_tris > 0 && (!tris || !verts))) return -1;
+    return admm_host::bend_hinges(n_verts, n_tris, tris, verts, cap, hinge_idx, coef, area);
 }
 int admm_host_tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area) {
     int r = admm_host::tri_rest(n, idx, verts, rest, area);

@@ -800,6 +800,55 @@ __device__ __forceinline__ void prox_stretches_kappa(int type, double mu, double
     newton_stretch_dense(m, S, 200);
 }
 
+// ---- STABLE NEO-HOOKEAN (the reference's README lists it as a TODO, README.md:23-28; no reference code: "parity unpinned") -------------
+// Smith, de Goes, Kim, "Stable Neo-Hookean Flesh Simulation", ACM TOG 37(2), 2018, Eq. 14 with the re-parametrisation of their section
+// 3.4 so that the model meets linear elasticity at the rest state with the TET's Lame constants:
+//     Psi(F) = mu_s / 2 (I_C - 3) + la_s / 2 (J - alpha)^2 - mu_s / 2 log(I_C + 1),
+//     mu_s = 4/3 mu,  la_s = lambda + 5/6 mu,  alpha = 1 + mu_s / la_s - mu_s / (4 la_s) = 1 + 3 mu_s / (4 la_s),
+// I_C = |F|_F^2 = sum s_i^2, J = det F = s0 s1 s2: rotation invariant, so the prox of HyperElasticTet::prox (src/TetEnergyTerm.cpp:114-136)
+// is a minimisation over the signed stretches like for the other models -- finite and smooth for inverted and degenerate elements (no
+// log J barrier), which is the point of the model.  Gradient and Hessian in the stretches (dJ_i = prod_{j != i} s_j, q = 1 / (I_C + 1)):
+//     g_i  = mu_s s_i (1 - q) + la_s (J - alpha) dJ_i + k (s_i - x0_i)
+//     H_ii = mu_s (1 - q) + 2 mu_s q^2 s_i^2 + la_s dJ_i^2 + k
+//     H_ij = 2 mu_s q^2 s_i s_j + la_s (dJ_i dJ_j + (J - alpha) s_k)
+// minimised by the dense-Hessian safeguarded Newton above (no bound on the stretches: type 0, always feasible).
+struct StableNHModel {
+    int type;                 // 0: no projected steps (newton_stretch_dense)
+    double mu, la, k, alpha, x0[3];      // mu, la = mu_s, la_s (already divided by k when the caller scales the problem)
+    __device__ __forceinline__ double lower() const { return -1.7976931348623157e308; }
+    __device__ __forceinline__ bool feasible(const double *) const { return true; }
+    __device__ __forceinline__ double eval(const double *s, double *g, double *H) const {
+        const double IC = fma(s[0], s[0], fma(s[1], s[1], s[2] * s[2])), J = s[0] * s[1] * s[2], q = 1.0 / (IC + 1.0);
+        const double dJ[3] = {s[1] * s[2], s[2] * s[0], s[0] * s[1]};
+        const double Ja = J - alpha, a1 = mu * (1.0 - q), a2 = 2.0 * mu * q * q;
+        double f = 0.5 * mu * (IC - 3.0) + 0.5 * la * Ja * Ja - 0.5 * mu * log(IC + 1.0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double dx = s[i] - x0[i];
+            f = fma(0.5 * k * dx, dx, f);
+            g[i] = fma(a1, s[i], fma(la * Ja, dJ[i], k * dx));
+        }
+        H[0] = a1 + a2 * s[0] * s[0] + la * dJ[0] * dJ[0] + k;
+        H[3] = a1 + a2 * s[1] * s[1] + la * dJ[1] * dJ[1] + k;
+        H[5] = a1 + a2 * s[2] * s[2] + la * dJ[2] * dJ[2] + k;
+        H[1] = a2 * s[0] * s[1] + la * (dJ[0] * dJ[1] + Ja * s[2]);
+        H[2] = a2 * s[0] * s[2] + la * (dJ[0] * dJ[2] + Ja * s[1]);
+        H[4] = a2 * s[1] * s[2] + la * (dJ[1] * dJ[2] + Ja * s[0]);
+        return f;
+    }
+};
+// HyperElasticTet::prox on the stretches (src/TetEnergyTerm.cpp:124-135) for the stable Neo-Hookean model; mu, la = the tet's Lame constants
+__device__ __forceinline__ void prox_stretches_stable_nh(double mu, double la, double k, double *S) {
+    StableNHModel m;
+    const double ik = fast_rcp(k), mus = (4.0 / 3.0) * mu, las = la + (5.0 / 6.0) * mu;
+    m.type = 0; m.mu = mus * ik; m.la = las * ik; m.k = 1.0; m.alpha = 1.0 + 0.75 * mus / las;
+    m.x0[0] = S[0]; m.x0[1] = S[1]; m.x0[2] = S[2];       // :124 set_x0 (before the fix-ups)
+    const double eps = 1e-6;
+    if (fabs(S[0]) < eps && fabs(S[1]) < eps && fabs(S[2]) < eps) { S[0] = eps; S[1] = eps; S[2] = eps; } // :128-131
+    S[0] = fabs(S[0]); S[1] = fabs(S[1]); S[2] = fabs(S[2]);   // :133 (the start only: the minimiser itself may cross zero)
+    newton_stretch_dense(m, S, 200);
+}
+
 template <int KIND>
 __device__ __forceinline__ void prox_stretches(double mu, double la, double k, double *S) {
     if (KIND == 0) {

@@ -41,7 +41,8 @@ struct GspArgs {
     const int *hdr, *orig, *out_idx, *halo_box, *halo_orig;   // host_setup.hpp: GsPlan
     const double *diag, *vals; const unsigned short *cols;
     const double *m, *b; double *x;
-    const int *pin_flag; const double *pin_xyz;               // per node (pin_flag nullptr: no pins)
+    const int *pin_flag; const double *pin_xyz;               // per node (pin_flag nullptr: no pins); flag 2 = slide pin, normal in pin_nrm
+    const double *pin_nrm;
     double omega, tol2;
     int max_sweeps, check;
     unsigned seq;                                             // solve number of the context (stamps)
@@ -53,6 +54,7 @@ struct GspArgs {
     int *sig;                                                 // host-visible: sig[2] = 1 when the solve was aborted
     const Obstacles *ob;                                      // passive obstacles (device copy: 80 SGPRs as a by-value argument)
     unsigned long long *prof; int prof_block;                 // diagnosis (ADMM_HIP_GSP_PROF=1): wall-clock ticks per part of a phase
+    unsigned long long *proj;                                 // rows projected onto a passive obstacle since create (admm_hip_contact_totals)
 };
 
 __device__ __forceinline__ v4u gsp_pack(double v, unsigned s) {
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     LdsObst *obl = (LdsObst *)(smem + 640);
     if (t < (int)(sizeof(Obstacles) / 4)) ((LdsI32 *)obl)[t] = ((const int *)a.ob)[t];
     if (t == 0) {
-        ctl[1] = 0; ctl[2] = 0; ctl[4] = 0; ctl[5] = 0; ctl[6] = 0; ctl[7] = 0;
+        ctl[1] = 0; ctl[2] = 0; ctl[4] = 0; ctl[5] = 0; ctl[6] = 0; ctl[7] = 0; ctl[10] = 0;
         // a solve of this context has been given up and the host has not recovered yet (steps are issued asynchronously): nothing may
         // run on that state -- every later launch leaves at once, the host replays them after its next synchronisation
         ctl[0] = __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
             const int v = a.orig[row_base + i];
             const double d = a.diag[row_base + i];
             ol[i] = a.out_idx[row_base + i];
-            pl[i] = (a.pin_flag && a.pin_flag[v]) ? 1 : 0;
+            pl[i] = a.pin_flag ? (unsigned char)a.pin_flag[v] : 0;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const double bi = a.b[3 * (size_t)v + q];
@@ -245,7 +247,10 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { const double r = bi[q] - fma(aii[q], cx[q], both ? LUo[q] : LUx[q]); rs = fma(r, r, rs); }
             }
-            if (pl[li]) { // :111-117
+            if (pl[li] == 2) {      // slide pin (normal-only constraint): the unrelaxed value projected onto the pin's plane, every sweep
+                const int v = a.orig[row_base + li];
+                gs_pin_value(2, a.pin_xyz + 3 * (size_t)v, a.pin_nrm + 3 * (size_t)v, bi, LUx, aii, nx);
+            } else if (pl[li]) { // :111-117
 #ifdef ADMM_GSP_OB_GLOBAL
                 if (true) {
 #else
@@ -260,9 +265,9 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                 }
             }
 #ifdef ADMM_GSP_OB_GLOBAL      // (same-box A/B only: the obstacles through the argument pointer, as before round 4's second session)
-            else gs_relax(*a.ob, a.omega, bi, LUx, aii, cx, nx);
+            else if (gs_relax(*a.ob, a.omega, bi, LUx, aii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-            else gs_relax(*obl, a.omega, bi, LUx, aii, cx, nx);
+            else if (gs_relax(*obl, a.omega, bi, LUx, aii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS add: rows projected, counted below)
 #endif
             if (keep_old) { xo[3 * li] = cx[0]; xo[3 * li + 1] = cx[1]; xo[3 * li + 2] = cx[2]; }
             xl[3 * li] = nx[0]; xl[3 * li + 1] = nx[1]; xl[3 * li + 2] = nx[2];
@@ -448,6 +453,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
         __syncthreads();
         if (block_failed()) return;
         load_x();
+        if (t == 0) ctl[10] = 0;     // (the projections of the abandoned run do not count)
         __syncthreads();
         if (run(first + 1, false, stamp0 + 2048u) == -2) return;
     }
@@ -457,6 +463,8 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = xl[3 * i + q];
     }
+    __syncthreads();
+    if (t == 0 && a.proj && ctl[10] > 0) atomicAdd(a.proj, (unsigned long long)ctl[10]);
     if (b == 0 && t == 0) {
         *a.done = conv_flag; *a.sweeps = failed_tests;      // (stored, not accumulated: the launch needs no memset in front of it)
         atomicAdd(a.total, failed_tests);

@@ -232,13 +232,15 @@ Sell record_incidence(int32_t n_verts, int32_t n_rec, const int32_t *rec_vertex,
     return S;
 }
 
-int32_t component_partition(int32_t nv, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int world, int32_t *vertex_rank) {
+int32_t component_partition(int32_t nv, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int world, int32_t *vertex_rank,
+                            int32_t n_bends, const int32_t *bend_idx) {
     std::vector<int32_t> parent(nv);
     std::iota(parent.begin(), parent.end(), 0);
     auto find = [&](int32_t a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
     auto unite = [&](int32_t a, int32_t b) { a = find(a); b = find(b); if (a != b) parent[std::max(a, b)] = std::min(a, b); };   // root = lowest vertex
     for (int32_t t = 0; t < n_tets; ++t) for (int k = 1; k < 4; ++k) unite(tet_idx[4 * (size_t)t], tet_idx[4 * (size_t)t + k]);
     for (int32_t t = 0; t < n_tris; ++t) for (int k = 1; k < 3; ++k) unite(tri_idx[3 * (size_t)t], tri_idx[3 * (size_t)t + k]);
+    for (int32_t t = 0; t < n_bends; ++t) for (int k = 1; k < 4; ++k) unite(bend_idx[4 * (size_t)t], bend_idx[4 * (size_t)t + k]);   // (a hinge couples its four vertices)
     std::vector<int64_t> load_of_root(nv, 0);
     for (int32_t t = 0; t < n_tets; ++t) load_of_root[find(tet_idx[4 * (size_t)t])] += 1;
     for (int32_t t = 0; t < n_tris; ++t) load_of_root[find(tri_idx[3 * (size_t)t])] += 1;
@@ -257,6 +259,81 @@ int32_t component_partition(int32_t nv, int32_t n_tets, const int32_t *tet_idx, 
     }
     for (int32_t v = 0; v < nv; ++v) vertex_rank[v] = rank_of_root[find(v)];
     return bodies;
+}
+
+// ---- 4-vertex stencil terms (bending hinges) ------------------------------------------------------------------------------------
+Csr add_stencil_terms(const Csr &A, double dt, int32_t n, const int32_t *idx4, const double *coef4, const double *w) {
+    if (n <= 0) return A;
+    const double dt2 = dt * dt;
+    const int32_t nv = A.n;
+    std::vector<int64_t> cnt(nv + 1, 0);
+    for (int32_t h = 0; h < n; ++h) for (int a = 0; a < 4; ++a) cnt[idx4[4 * (size_t)h + a] + 1] += 4;
+    for (int32_t i = 0; i < nv; ++i) cnt[i + 1] += cnt[i];
+    std::vector<Entry> ent(cnt[nv]);
+    std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+    for (int32_t h = 0; h < n; ++h) {
+        const int32_t *id = idx4 + 4 * (size_t)h; const double *c = coef4 + 4 * (size_t)h;
+        const double w2 = w[h] * w[h] * dt2;
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) ent[pos[id[a]]++] = {id[b], w2 * c[a] * c[b]};
+    }
+    Csr B; B.n = nv; B.rowptr.assign(nv + 1, 0);
+    B.col.reserve(A.col.size() + ent.size() / 4); B.val.reserve(A.col.size() + ent.size() / 4);
+    for (int32_t i = 0; i < nv; ++i) {
+        Entry *b = ent.data() + cnt[i], *e = ent.data() + cnt[i + 1];
+        std::stable_sort(b, e, [](const Entry &x, const Entry &y) { return x.col < y.col; });
+        int32_t k = A.rowptr[i]; const int32_t ke = A.rowptr[i + 1];
+        Entry *q = b;
+        while (k < ke || q < e) {       // merge of two sorted lists; equal columns add (the stencil's entries after A's: fixed order)
+            const int32_t ca = k < ke ? A.col[k] : 0x7fffffff, cb = q < e ? q->col : 0x7fffffff, cmin = std::min(ca, cb);
+            double sum = 0.0;
+            if (ca == cmin) sum = A.val[k++];
+            for (; q < e && q->col == cmin; ++q) sum += q->val;
+            B.col.push_back(cmin); B.val.push_back(sum);
+        }
+        B.rowptr[i + 1] = (int32_t)B.col.size();
+    }
+    return B;
+}
+
+int32_t bend_hinges(int32_t n_verts, int32_t n_tris, const int32_t *tris, const double *verts, int32_t cap, int32_t *hinge_idx, double *coef, double *area) {
+    struct EdgeUse { int32_t a, b, tri, opp; };
+    std::vector<EdgeUse> use; use.reserve(3 * (size_t)std::max(n_tris, 0));
+    for (int32_t t = 0; t < n_tris; ++t)
+        for (int e = 0; e < 3; ++e) {
+            const int32_t p = tris[3 * (size_t)t + e], q = tris[3 * (size_t)t + (e + 1) % 3], o = tris[3 * (size_t)t + (e + 2) % 3];
+            if (p < 0 || q < 0 || o < 0 || p >= n_verts || q >= n_verts || o >= n_verts) return -1;
+            use.push_back({std::min(p, q), std::max(p, q), t, o});
+        }
+    std::stable_sort(use.begin(), use.end(), [](const EdgeUse &x, const EdgeUse &y) { return x.a != y.a ? x.a < y.a : x.b != y.b ? x.b < y.b : x.tri < y.tri; });
+    auto cot_at = [&](int32_t p, int32_t q, int32_t r) {      // cotangent of the angle at p between (q - p) and (r - p)
+        double u[3], v[3], cr[3];
+        for (int j = 0; j < 3; ++j) { u[j] = verts[3 * (size_t)q + j] - verts[3 * (size_t)p + j]; v[j] = verts[3 * (size_t)r + j] - verts[3 * (size_t)p + j]; }
+        cr[0] = u[1] * v[2] - u[2] * v[1]; cr[1] = u[2] * v[0] - u[0] * v[2]; cr[2] = u[0] * v[1] - u[1] * v[0];
+        return (u[0] * v[0] + u[1] * v[1] + u[2] * v[2]) / std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+    };
+    auto tri_area = [&](int32_t p, int32_t q, int32_t r) {
+        double u[3], v[3], cr[3];
+        for (int j = 0; j < 3; ++j) { u[j] = verts[3 * (size_t)q + j] - verts[3 * (size_t)p + j]; v[j] = verts[3 * (size_t)r + j] - verts[3 * (size_t)p + j]; }
+        cr[0] = u[1] * v[2] - u[2] * v[1]; cr[1] = u[2] * v[0] - u[0] * v[2]; cr[2] = u[0] * v[1] - u[1] * v[0];
+        return 0.5 * std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+    };
+    int32_t n = 0;
+    for (size_t i = 0; i < use.size();) {
+        size_t j = i;
+        while (j < use.size() && use[j].a == use[i].a && use[j].b == use[i].b) ++j;
+        if (j - i == 2 && use[i].opp != use[i + 1].opp) {      // an interior, manifold edge
+            const int32_t v0 = use[i].a, v1 = use[i].b, v2 = use[i].opp, v3 = use[i + 1].opp;
+            if (n < cap && hinge_idx && coef && area) {
+                const double c01 = cot_at(v0, v1, v2), c02 = cot_at(v0, v1, v3), c03 = cot_at(v1, v0, v2), c04 = cot_at(v1, v0, v3);
+                hinge_idx[4 * (size_t)n] = v0; hinge_idx[4 * (size_t)n + 1] = v1; hinge_idx[4 * (size_t)n + 2] = v2; hinge_idx[4 * (size_t)n + 3] = v3;
+                coef[4 * (size_t)n] = c03 + c04; coef[4 * (size_t)n + 1] = c01 + c02; coef[4 * (size_t)n + 2] = -(c01 + c03); coef[4 * (size_t)n + 3] = -(c02 + c04);
+                area[n] = tri_area(v0, v1, v2) + tri_area(v0, v1, v3);
+            }
+            ++n;
+        }
+        i = j;
+    }
+    return n;
 }
 
 // ---- tabulated user splines --------------------------------------------------------------------------------------------------

@@ -35,6 +35,11 @@ Csr assemble_Ahat(int32_t n_verts, double dt,
                   int32_t n_tris, const int32_t *tri_idx, const double *tri_rest, const double *tri_w,
                   int32_t n_pins, const int32_t *pin_vert, double pin_w);
 
+// A + dt^2 sum_h w_h^2 c_h c_h^T for 4-vertex stencil terms (bending hinges: D-block = (c0..c3) (x) I3), merged into the sorted CSR
+Csr add_stencil_terms(const Csr &A, double dt, int32_t n, const int32_t *idx4, const double *coef4, const double *w);
+// interior edges of a triangle mesh and their cotangent stencils (include/admm_hip.h: admm_host_bend_hinges)
+int32_t bend_hinges(int32_t n_verts, int32_t n_tris, const int32_t *tris, const double *verts, int32_t cap, int32_t *hinge_idx, double *coef, double *area);
+
 Sell csr_to_sell(const Csr &A);
 
 // vertex -> list of (element, corner) codes, code = elem * stride + corner; padding = pad_code
@@ -182,7 +187,7 @@ void block_order(int32_t n_verts, int32_t n_elems, int32_t corners, const int32_
 // decreasing element count (ties: lowest vertex first), each to the least loaded rank so far (ties: lowest rank).  Returns the
 // number of components; vertex_rank[v] = owning rank.  The multi-GPU partition that needs NO exchange inside a step.
 int32_t component_partition(int32_t n_verts, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int world,
-                            int32_t *vertex_rank);
+                            int32_t *vertex_rank, int32_t n_bends = 0, const int32_t *bend_idx = nullptr);
 
 // tabulated user splines (device_math.hpp: spline_table_eval; layout: 3 functions x {t0, dt, 1/dt, n, n x (F, dF/dt, d2F/dt2)})
 constexpr int kSplineNodesH = 1024, kSplineFnDoublesH = 4 + 3 * kSplineNodesH, kSplineTableDoublesH = 3 * kSplineFnDoublesH;

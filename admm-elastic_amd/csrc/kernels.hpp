@@ -22,7 +22,7 @@ namespace admm_k {
 
 using namespace admm_dev;
 
-struct Mat { double mu, la, k, kappa; int type, table; };   // KIND 4: type 0..2 = xu:: spline with a compression term kappa; type 3 = tabulated (user-defined) spline `table`
+struct Mat { double mu, la, k, kappa; int type, table; };   // KIND 4: type 0..2 = xu:: spline with a compression term kappa; type 3 = tabulated (user-defined) spline `table`; type 4 = stable Neo-Hookean
 
 constexpr int kMaxObst = 8;
 struct Obstacles {
@@ -390,6 +390,7 @@ __device__ __forceinline__ void tet_compute_store(const TetArgs &a, int t, bool 
     } else if (KIND == 4) {   // xu:: spline with kappa != 0 (dense-Hessian Newton; rare, not tuned)
         const Mat mt = mats[in.mid];
         if (mt.type == 3) prox_stretches_table(a.spl + (size_t)mt.table * kSplineTableDoubles, mt.k, S1);
+        else if (mt.type == 4) prox_stretches_stable_nh(mt.mu, mt.la, mt.k, S1);      // ADMM_TET_STABLE_NH
         else prox_stretches_kappa(mt.type, mt.mu, mt.la, mt.k, mt.kappa, S1);
     } else {
         // NH, StVK and the co-rotated spline fit 4 waves/SIMD (128 VGPRs) with V out of the way during the stretch
@@ -580,6 +581,43 @@ __global__ __launch_bounds__(256) void k_local_tris(int n, int ld, const int4 *_
     }
 }
 
+// LOCAL STEP, bending hinges (README.md:23-28 TODO of the reference, no reference code; include/admm_hip.h: desc.bend_*).  One EnergyTerm
+// per hinge in the mould of EnergyTerm::update (src/EnergyTerm.hpp:130-140): D_i x = sum_k c_k x_{v_k} (3 rows), quadratic energy
+// E(z) = kappa / 2 |z|^2  =>  prox(q) = gam q with gam = w^2 / (kappa + w^2), u += D_i x - z; the four corner forces
+// dt^2 w^2 c_k (z - u) go to cf [12][ld] and are summed per vertex by k_gather_rhs.  lane = hinge, SoA like the triangles.
+template <bool WRITE_Z>
+__global__ __launch_bounds__(256) void k_local_bends(int n, int ld, const int4 *__restrict__ idx, const double *__restrict__ coef,
+                                                     double *__restrict__ u, double *__restrict__ z, const double *__restrict__ sc,
+                                                     const double *__restrict__ gam, const double *__restrict__ x, double *__restrict__ cf) {
+    const int t = xcd_block() * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int4 id = idx[t];
+    const int vid[4] = {id.x, id.y, id.z, id.w};
+    double c[4], Dx[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c[k] = coef[(size_t)k * ld + t];
+        const double *p = x + 3 * (size_t)vid[k];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Dx[j] = fma(c[k], p[j], Dx[j]);
+    }
+    const double s = sc[t], g = gam[t];
+    double G[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double uo = u[(size_t)j * ld + t];
+        const double zi = g * (Dx[j] + uo);
+        const double un = uo + (Dx[j] - zi);
+        u[(size_t)j * ld + t] = un;
+        if (WRITE_Z) z[(size_t)j * ld + t] = zi;
+        G[j] = s * (zi - un);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cf[(size_t)(3 * k + j) * ld + t] = c[k] * G[j];
+}
+
 // ---------------------------------------------------------------------------------------------------
 // RHS: b = [M x_bar] + dt^2 D^T W^2 (z - u)  (src/Solver.cpp:98), gathered per vertex from the corner
 // forces, plus the SpringPin terms (src/SpringEnergyTerm.hpp:54-61), whose local step is done here.
@@ -587,8 +625,10 @@ struct GatherArgs {
     int nv, n_slices;
     const int *t_ptr, *t_w, *t_inc; const double *t_rec;           // tets: lists of records [.][4] (t_inc == nullptr -> none)
     const int *r_ptr, *r_w, *r_inc; const double *r_cf; int r_ld;  // tris
+    const int *h_ptr, *h_w, *h_inc; const double *h_cf; int h_ld;  // bending hinges (h_inc == nullptr -> none)
     const int *vert_pin;       // [nv] pin term index or -1 (nullptr -> no pin terms)
     const double *pin_xyz; const int *pin_active; double *pin_u, *pin_z; double pin_sc; // dt^2 w_pin^2
+    const double *pin_nrm;     // [3 per pin term] or nullptr: a non-zero (unit) normal makes the term a SLIDE pin -- prox = projection onto the plane n.(z - p) = 0
     const double *x;           // curr_x (for the pin terms)
     const double *Mxbar;       // added when add_mxbar
     double *b;
@@ -664,16 +704,29 @@ __global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
         double acc[3] = {0.0, 0.0, 0.0};
         if (a.t_inc) gather_records(a.t_inc + a.t_ptr[s] + lane, a.t_w[s], a.t_rec, acc);
         if (a.r_inc) gather_corners<false>(a.r_inc + a.r_ptr[s] + lane, a.r_w[s], a.r_cf, a.r_ld, acc);
+        if (a.h_inc) gather_corners<false>(a.h_inc + a.h_ptr[s] + lane, a.h_w[s], a.h_cf, a.h_ld, acc);
         if (v < a.nv) {
             if (a.vert_pin) {
                 const int pi = a.vert_pin[v];
                 if (pi >= 0) {
                     const bool act = a.pin_active[pi] != 0;
+                    // SLIDE pin (README.md:23-28 TODO of the reference; a SpringPin, src/SpringEnergyTerm.hpp:31-73, whose prox projects onto
+                    // the plane through the pin's point instead of onto the point): z = q - n (n . (q - p)), q = D x + u
+                    double sl = 0.0, nrm[3] = {0.0, 0.0, 0.0};
+                    if (a.pin_nrm && act) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) nrm[j] = a.pin_nrm[3 * (size_t)pi + j];
+                        if (nrm[0] != 0.0 || nrm[1] != 0.0 || nrm[2] != 0.0) {
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) sl = fma(nrm[j], a.x[3 * (size_t)v + j] + a.pin_u[3 * (size_t)pi + j] - a.pin_xyz[3 * (size_t)pi + j], sl);
+                        }
+                    }
+                    const bool slide = nrm[0] != 0.0 || nrm[1] != 0.0 || nrm[2] != 0.0;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const double Dix = a.x[3 * (size_t)v + j];
                         const double uo = a.pin_u[3 * (size_t)pi + j];
-                        const double zi = act ? a.pin_xyz[3 * (size_t)pi + j] : (Dix + uo);
+                        const double zi = !act ? (Dix + uo) : slide ? fma(-sl, nrm[j], Dix + uo) : a.pin_xyz[3 * (size_t)pi + j];
                         const double un = uo + (Dix - zi);
                         a.pin_u[3 * (size_t)pi + j] = un;
                         a.pin_z[3 * (size_t)pi + j] = zi;
@@ -1173,8 +1226,9 @@ __device__ __forceinline__ bool passive_hit(const OB &ob, const double *x, doubl
 // point, no over-relaxation).  One definition with every product-sum written as an explicit fma, shared by all sweep kernels
 // (k_gs_color, k_gs_color2, k_gs_colorN, k_gs_persist): their results are bit-identical by construction, not by the compiler's
 // contraction choices.
+// Returns whether the row was projected onto an obstacle (counted: admm_hip_contact_totals).
 template <class OB>
-__device__ __forceinline__ void gs_relax(const OB &ob, double omega, const double *bi, const double *LUx, const double *aii,
+__device__ __forceinline__ bool gs_relax(const OB &ob, double omega, const double *bi, const double *LUx, const double *aii,
                                          const double *cx, double *nx) {
     double jac[3];
 #pragma unroll
@@ -1198,7 +1252,21 @@ __device__ __forceinline__ void gs_relax(const OB &ob, double omega, const doubl
         const double t0 = fma(uu[2], dx[2], fma(uu[1], dx[1], uu[0] * dx[0])), t1 = fma(vv[2], dx[2], fma(vv[1], dx[1], vv[0] * dx[0]));
 #pragma unroll
         for (int q = 0; q < 3; ++q) nx[q] = fma(uu[q], t0, fma(vv[q], t1, p[q]));
+        return true;
     }
+    return false;
+}
+
+// A pinned node of a sweep (:111-117): its pin's position.  flag 2 = a SLIDE pin (normal-only constraint n . (x - p) = 0, README.md:23-28
+// TODO of the reference): the plane-constrained Jacobi value of :218-262 on the pin's own plane -- the unrelaxed value
+// D^-1 (b - LUx) projected onto it, G G^T (jac - p) + p = jac - n (n . (jac - p)).
+__device__ __forceinline__ void gs_pin_value(int flag, const double *pin, const double *nrm, const double *bi, const double *LUx, const double *aii, double *nx) {
+    if (flag != 2) { nx[0] = pin[0]; nx[1] = pin[1]; nx[2] = pin[2]; return; }
+    double jac[3], d = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { jac[q] = (bi[q] - LUx[q]) / aii[q]; d = fma(nrm[q], jac[q] - pin[q], d); }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) nx[q] = fma(-d, nrm[q], jac[q]);
 }
 
 struct GsArgs {
@@ -1207,7 +1275,8 @@ struct GsArgs {
     const double *diag;         // Ahat(v,v) per lane
     const double *m;            // [3 nv]
     const double *b; double *x;
-    const int *pin_flag; const double *pin_xyz; // per node (nullptr -> no pins)
+    const int *pin_flag; const double *pin_xyz; // per node (nullptr -> no pins); flag 2 = slide pin (its unit normal in pin_nrm)
+    const double *pin_nrm;
     double omega;
     int *done;                  // set once the residual test passed
     // residual test of the PREVIOUS sweep, decided here by every block of the first colour kernel of a sweep
@@ -1215,6 +1284,7 @@ struct GsArgs {
     const double *part; int NBp; double tol2; int *sweeps; int *total;
     const unsigned char *skip;  // nodes whose rows are not rows of A in this solve (touched by dynamic hits: they are
                                 // swept by k_gs_touched); nullptr when there are none
+    unsigned long long *proj;   // rows projected onto a passive obstacle since create (admm_hip_contact_totals); may be nullptr
 };
 
 // one colour of one sweep: wave = one 64-node slice of that colour, lane = node.  The off-diagonal row sum is
@@ -1243,7 +1313,8 @@ __global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nsli
     sell_row(a.S, s, lane, a.x, LUx);
     if (v < 0 || done_flag) return;
     if (a.skip && a.skip[v]) return;
-    if (a.pin_flag && a.pin_flag[v]) { // :111-117
+    const int pflag = a.pin_flag ? a.pin_flag[v] : 0;
+    if (pflag == 1) { // :111-117
 #pragma unroll
         for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = a.pin_xyz[3 * (size_t)v + q];
         return;
@@ -1252,7 +1323,13 @@ __global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nsli
     double aii[3], cx[3], bi[3], nx[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) { aii[q] = ad + a.m[3 * (size_t)v + q]; cx[q] = a.x[3 * (size_t)v + q]; bi[q] = a.b[3 * (size_t)v + q]; }
-    gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
+    if (pflag == 2) {     // slide pin
+        gs_pin_value(2, a.pin_xyz + 3 * (size_t)v, a.pin_nrm + 3 * (size_t)v, bi, LUx, aii, nx);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
+        return;
+    }
+    if (gs_relax(ob, a.omega, bi, LUx, aii, cx, nx) && a.proj) atomicAdd(a.proj, 1ull);
 #pragma unroll
     for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
 }
@@ -1316,7 +1393,8 @@ __global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int n
         sell_row(a.S, s, lane, a.x, LUx);
         if (v >= 0) {
             const double ad = a.diag[(size_t)64 * s + lane];
-            const bool pinned = a.pin_flag && a.pin_flag[v];
+            const int pflag = a.pin_flag ? a.pin_flag[v] : 0;
+            const bool pinned = pflag != 0;
             double aii[3], cx[3], bi[3], nx[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -1334,10 +1412,9 @@ __global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int n
                 }
             }
             if (UPDATE && !done_flag) {
-                if (pinned) { // :111-117
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
-                } else gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
+                if (pinned) { // :111-117 (flag 2: slide pin)
+                    gs_pin_value(pflag, a.pin_xyz + 3 * (size_t)v, pflag == 2 ? a.pin_nrm + 3 * (size_t)v : a.pin_xyz, bi, LUx, aii, nx);
+                } else if (gs_relax(ob, a.omega, bi, LUx, aii, cx, nx) && a.proj) atomicAdd(a.proj, 1ull);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
             }
@@ -1464,7 +1541,8 @@ __global__ __launch_bounds__(256) void k_gs_colorN(GsNArgs aN, int slice0, int n
         }
         if (v >= 0) {
             const double ad = a.diag[(size_t)64 * s + lane];
-            const bool pinned = a.pin_flag && a.pin_flag[v];
+            const int pflag = a.pin_flag ? a.pin_flag[v] : 0;
+            const bool pinned = pflag != 0;
             double aii[3], cx[3], bi[3], nx[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
@@ -1485,10 +1563,9 @@ __global__ __launch_bounds__(256) void k_gs_colorN(GsNArgs aN, int slice0, int n
                 for (int q = 0; q < 3; ++q) aN.xb[3 * (size_t)v + q] = cx[q];
             }
             if (UPDATE && !done_flag) {
-                if (pinned) { // :111-117
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) nx[q] = a.pin_xyz[3 * (size_t)v + q];
-                } else gs_relax(ob, a.omega, bi, LUx, aii, cx, nx);
+                if (pinned) { // :111-117 (flag 2: slide pin)
+                    gs_pin_value(pflag, a.pin_xyz + 3 * (size_t)v, pflag == 2 ? a.pin_nrm + 3 * (size_t)v : a.pin_xyz, bi, LUx, aii, nx);
+                } else if (gs_relax(ob, a.omega, bi, LUx, aii, cx, nx) && a.proj) atomicAdd(a.proj, 1ull);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
             }

@@ -13,6 +13,7 @@ public:
     double constraint_w;
     std::shared_ptr<Collider> collider;
     std::unordered_map<int, Vec3> pins; // index -> location
+    std::unordered_map<int, std::pair<Vec3, Vec3> > slides; // index -> (point, unit normal): slide constraints (README.md:23-28 TODO; not in the reference)
     ConstraintSet() : constraint_w(1.0), collider(std::make_shared<Collider>()) {}
 };
 

@@ -29,7 +29,7 @@ public:
 
 // What Solver::initialize needs from one term, in the layout of admm_hip_desc.
 struct FlatTerm {
-    enum Type { TET = 0, TRI = 1, PIN = 2 };
+    enum Type { TET = 0, TRI = 1, PIN = 2, BEND = 3 };   // BEND: idx = the hinge's four vertices, mat[0..3] = its stencil, k = its stiffness
     int type;
     int idx[4];
     double mat[9];      // tet: edges_inv (col-major 3x3); tri: rest_pose (col-major 2x2)
@@ -40,6 +40,7 @@ struct FlatTerm {
     const void *user_spline = nullptr;   // SplineTet with a user-defined xu::Spline (kind ADMM_TET_SPLINE_TABLE): the object to tabulate
     double pin[3];
     int active;
+    double nrm[3];      // PIN: non-zero = a slide pin (SlidePin): the vertex may move in the plane through `pin` with this normal
 };
 
 class EnergyTerm {

@@ -9,6 +9,7 @@
 #include "ConstraintSet.hpp"
 #include "EnergyTerm.hpp"
 #include "SpringEnergyTerm.hpp"
+#include "BendEnergyTerm.hpp"
 #include "ExplicitForce.hpp"
 #include "LinearSolver.hpp"
 #include "PassiveObject.hpp"
@@ -58,6 +59,10 @@ public:
     virtual bool initialize(const Settings &settings_ = Settings());
     virtual void step();
     virtual void set_pins(const std::vector<int> &inds, const std::vector<Vec3> &points = std::vector<Vec3>());
+    // Slide constraints (README.md:23-28 TODO of the reference; the counterpart of set_pins for normal-only constraints): node inds[i] may move
+    // in the plane through points[i] with normal normals[i].  Replaces the current set; after initialize() only nodes that had a slide
+    // constraint at initialize() may be given again (like pins with linsolver 0 / 2, src/Solver.cpp:147-151).
+    virtual void set_slide_pins(const std::vector<int> &inds, const std::vector<Vec3> &points, const std::vector<Vec3> &normals);
     virtual void add_obstacle(std::shared_ptr<PassiveCollision> obj);
     virtual void add_dynamic_collider(std::shared_ptr<DynamicCollision> obj);
     virtual void save_matrix(const std::string &filename);
@@ -99,6 +104,8 @@ protected:
     std::shared_ptr<ConstraintSet> m_constraints;
     std::shared_ptr<LinearSolver> m_linsolver;
     std::unordered_map<int, std::shared_ptr<SpringPin> > m_pin_energies;
+    std::unordered_map<int, std::shared_ptr<SlidePin> > m_slide_energies;
+    void push_pins();                                            // pins + slide constraints -> the context
 };
 
 } // namespace admm

@@ -31,5 +31,22 @@ protected:
     double weight;
 };
 
+// SLIDE constraint (the reference's README lists "slide constraints" as a TODO, README.md:23-28; no reference code).  A SpringPin whose prox
+// projects D_i x + u_i onto the PLANE through `pin` with normal `normal` instead of onto the point (src/SpringEnergyTerm.hpp:61): the
+// vertex slides freely in the plane.  Same D-block, weight and dim-6 row layout as SpringPin.
+class SlidePin : public SpringPin {
+public:
+    SlidePin(int idx_, const Vec3 &point_, const Vec3 &normal_) : SpringPin(idx_, point_), normal(normal_) {
+        const double l = normal.norm();
+        if (!(l > 0.0)) throw std::runtime_error("**SlidePin Error: zero normal");
+        normal = normal * (1.0 / l);
+    }
+    void set_normal(const Vec3 &n) { const double l = n.norm(); if (!(l > 0.0)) throw std::runtime_error("**SlidePin Error: zero normal"); normal = n * (1.0 / l); }
+    const Vec3 &plane_normal() const { return normal; }
+    bool flatten(FlatTerm &out) const;
+protected:
+    Vec3 normal;
+};
+
 } // namespace admm
 #endif

@@ -44,6 +44,17 @@ protected:
     double energy(const VecX &F);
 };
 
+// STABLE NEO-HOOKEAN (the reference's README lists it as a TODO, README.md:23-28; it would be one more HyperElasticTet beside
+// NeoHookeanTet, src/TetEnergyTerm.hpp:116-136).  Smith, de Goes, Kim 2018: Psi = mu_s/2 (I_C - 3) + la_s/2 (J - alpha)^2 - mu_s/2 log(I_C + 1),
+// mu_s = 4/3 mu, la_s = lambda + 5/6 mu, alpha = 1 + 3 mu_s / (4 la_s); finite and smooth for inverted elements (ADMM_TET_STABLE_NH).
+class StableNeoHookeanTet : public TetEnergyTerm {
+public:
+    StableNeoHookeanTet(const Vec4i &tet, const std::vector<Vec3> &verts, const Lame &lame) : TetEnergyTerm(tet, verts, lame) {}
+    int kind() const { return 7; }
+protected:
+    double energy(const VecX &F);
+};
+
 // src/TetEnergyTerm.hpp:176-206.  Defaults to xu::NeoHookean(mu, lambda, 0) like the reference (:191-195); the second
 // constructor takes any xu::Spline (XuSpline.hpp): the reference's three with or without compression term run closed-form
 // kernels, a user-defined one is tabulated by Solver::initialize and runs the table kernel (ADMM_TET_SPLINE_TABLE).

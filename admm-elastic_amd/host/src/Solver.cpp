@@ -25,7 +25,8 @@ struct Flat {
     std::vector<int32_t> tet_idx, tet_kind, tri_idx, pin_vert, pin_active, tet_spline;
     std::vector<const void *> splines;      // distinct user-defined splines, in order of first use
     std::vector<double> spline_tables;
-    std::vector<double> tet_Binv, tet_w, tet_mu, tet_la, tet_k, tet_kappa, tri_rest, tri_w, tri_lmin, tri_lmax, pin_xyz;
+    std::vector<double> tet_Binv, tet_w, tet_mu, tet_la, tet_k, tet_kappa, tri_rest, tri_w, tri_lmin, tri_lmax, pin_xyz, pin_nrm, bend_coef, bend_w, bend_k;
+    std::vector<int32_t> bend_idx; bool any_slide = false;
     double pin_weight = 0.0;
     void add(const FlatTerm &t) {
         if (t.type == FlatTerm::TET) {
@@ -43,9 +44,12 @@ struct Flat {
             for (int i = 0; i < 3; ++i) tri_idx.push_back(t.idx[i]);
             for (int i = 0; i < 4; ++i) tri_rest.push_back(t.mat[i]);
             tri_w.push_back(t.weight); tri_lmin.push_back(t.limit_min); tri_lmax.push_back(t.limit_max);
+        } else if (t.type == FlatTerm::BEND) {
+            for (int i = 0; i < 4; ++i) { bend_idx.push_back(t.idx[i]); bend_coef.push_back(t.mat[i]); }
+            bend_w.push_back(t.weight); bend_k.push_back(t.k);
         } else {
             pin_vert.push_back(t.idx[0]);
-            for (int i = 0; i < 3; ++i) pin_xyz.push_back(t.pin[i]);
+            for (int i = 0; i < 3; ++i) { pin_xyz.push_back(t.pin[i]); pin_nrm.push_back(t.nrm[i]); any_slide = any_slide || t.nrm[i] != 0.0; }
             pin_active.push_back(t.active); pin_weight = t.weight;
         }
     }
@@ -72,6 +76,9 @@ struct Flat {
         d.tri_limit_min = tri_lmin.data(); d.tri_limit_max = tri_lmax.data();
         d.n_pins = (int32_t)pin_vert.size();
         d.pin_vert = pin_vert.data(); d.pin_xyz = pin_xyz.data(); d.pin_active = pin_active.data(); d.pin_weight = pin_weight;
+        d.pin_normal = any_slide ? pin_nrm.data() : nullptr;
+        d.n_bends = (int32_t)bend_w.size();
+        d.bend_idx = bend_idx.data(); d.bend_coef = bend_coef.data(); d.bend_weight = bend_w.data(); d.bend_stiffness = bend_k.data();
     }
 };
 
@@ -274,8 +281,55 @@ double TriEnergyTerm::gradient(const VecX &, VecX &) { throw std::runtime_error(
 
 bool SpringPin::flatten(FlatTerm &o) const {
     o.type = FlatTerm::PIN; o.idx[0] = idx; o.weight = weight; o.active = active ? 1 : 0;
-    for (int i = 0; i < 3; ++i) o.pin[i] = pin[i];
+    for (int i = 0; i < 3; ++i) { o.pin[i] = pin[i]; o.nrm[i] = 0.0; }
     return true;
+}
+bool SlidePin::flatten(FlatTerm &o) const {
+    if (!SpringPin::flatten(o)) return false;
+    for (int i = 0; i < 3; ++i) o.nrm[i] = normal[i];
+    return true;
+}
+
+// ---------------------------------------------------------------- bending / stable Neo-Hookean (README TODOs of the reference) ------
+BendEnergyTerm::BendEnergyTerm(const Vec4i &hinge_, const std::vector<Vec3> &verts, double k_bend) : hinge(hinge_) {
+    if (verts.size() != 4) throw std::runtime_error("**BendEnergyTerm Error: a hinge has four vertices");
+    double vv[12];
+    for (int c = 0; c < 4; ++c) for (int j = 0; j < 3; ++j) vv[3 * c + j] = verts[c][j];
+    const int32_t tris[6] = {0, 1, 2, 1, 0, 3};      // the two triangles of the hinge: shared edge (0, 1), opposite vertices 2 and 3
+    int32_t idx[4];
+    if (admm_host_bend_hinges(4, 2, tris, vv, 1, idx, coef, &area) != 1 || !(area > 0.0))
+        throw std::runtime_error("**BendEnergyTerm Error: degenerate hinge");
+    stiffness = k_bend * 3.0 / area; weight = std::sqrt(stiffness);
+}
+BendEnergyTerm::BendEnergyTerm(const Vec4i &hinge_, const double *coef4, double rest_area, double k_bend) : hinge(hinge_), area(rest_area) {
+    for (int k = 0; k < 4; ++k) coef[k] = coef4[k];
+    if (!(area > 0.0)) throw std::runtime_error("**BendEnergyTerm Error: degenerate hinge");
+    stiffness = k_bend * 3.0 / area; weight = std::sqrt(stiffness);
+}
+bool BendEnergyTerm::flatten(FlatTerm &o) const {
+    o.type = FlatTerm::BEND;
+    for (int i = 0; i < 4; ++i) { o.idx[i] = hinge[i]; o.mat[i] = coef[i]; }
+    o.weight = weight; o.k = stiffness;
+    return true;
+}
+int create_bends_from_mesh_d(std::vector<std::shared_ptr<EnergyTerm> > &energyterms, const double *verts, int n_verts, const int *inds, int n_tris,
+                             double k_bend, int vertex_offset) {
+    std::vector<int32_t> tris(inds, inds + 3 * (size_t)n_tris);
+    const int32_t n = admm_host_bend_hinges(n_verts, n_tris, tris.data(), verts, 0, nullptr, nullptr, nullptr);
+    if (n < 0) throw std::runtime_error("create_bends_from_mesh: triangle index out of range");
+    std::vector<int32_t> idx(4 * (size_t)n); std::vector<double> coef(4 * (size_t)n), area(n);
+    if (n) admm_host_bend_hinges(n_verts, n_tris, tris.data(), verts, n, idx.data(), coef.data(), area.data());
+    for (int32_t h = 0; h < n; ++h)
+        energyterms.emplace_back(std::make_shared<BendEnergyTerm>(Vec4i(idx[4 * h] + vertex_offset, idx[4 * h + 1] + vertex_offset, idx[4 * h + 2] + vertex_offset, idx[4 * h + 3] + vertex_offset),
+                                                                  &coef[4 * (size_t)h], area[h], k_bend));
+    return n;
+}
+double StableNeoHookeanTet::energy(const VecX &F) {      // Smith et al. 2018, Eq. 14 with the Lame re-parametrisation, times the volume
+    double U[9], S[3], V[9];
+    host_signed_svd3(F.data(), U, S, V);
+    const double mus = (4.0 / 3.0) * lame.mu, las = lame.lambda + (5.0 / 6.0) * lame.mu, al = 1.0 + 0.75 * mus / las;
+    const double IC = S[0] * S[0] + S[1] * S[1] + S[2] * S[2], J = S[0] * S[1] * S[2];
+    return (0.5 * mus * (IC - 3.0) + 0.5 * las * (J - al) * (J - al) - 0.5 * mus * std::log(IC + 1.0)) * volume;
 }
 
 // ---------------------------------------------------------------- LinearSolver ----------------------
@@ -330,8 +384,46 @@ void Solver::set_pins(const std::vector<int> &inds, const std::vector<Vec3> &poi
             it->second->set_pin(m_constraints->pins[inds[i]]);
         }
     }
+    push_pins();
+}
+
+void Solver::push_pins() {      // the context's pin list = ordinary pins + slide constraints (a pin it is not given again is deactivated)
+    std::vector<int32_t> v; std::vector<double> p;
     for (auto &kv : m_constraints->pins) { v.push_back(kv.first); for (int j = 0; j < 3; ++j) p.push_back(kv.second[j]); }
+    for (auto &kv : m_constraints->slides) {
+        if (m_constraints->pins.count(kv.first)) continue;
+        v.push_back(kv.first); for (int j = 0; j < 3; ++j) p.push_back(kv.second.first[j]);
+    }
     check(admm_hip_set_pins((admm_hip_ctx *)m_ctx, (int32_t)v.size(), v.data(), p.data()), "Solver::set_pins");
+}
+
+void Solver::set_slide_pins(const std::vector<int> &inds, const std::vector<Vec3> &points, const std::vector<Vec3> &normals) {
+    if (points.size() != inds.size() || normals.size() != inds.size()) throw std::runtime_error("**Solver::set_slide_pins Error: Bad input.");
+    std::unordered_map<int, std::pair<Vec3, Vec3> > fresh;
+    for (size_t i = 0; i < inds.size(); ++i) {
+        const double l = normals[i].norm();
+        if (!(l > 0.0)) throw std::runtime_error("**Solver::set_slide_pins Error: zero normal");
+        fresh[inds[i]] = std::make_pair(points[i], normals[i] * (1.0 / l));
+    }
+    if (initialized && (m_settings.linsolver == 0 || m_settings.linsolver == 2))
+        for (auto &kv : fresh)
+            if (!m_slide_energies.count(kv.first)) {
+                std::stringstream err;
+                err << "**Solver::set_pins Error: Constraint for " << kv.first << " not found.\n";
+                throw std::runtime_error(err.str());
+            }
+    m_constraints->slides = fresh;
+    if (!initialized) return;
+    for (auto &se : m_slide_energies) se.second->set_active(false);
+    for (auto &kv : fresh) {
+        auto it = m_slide_energies.find(kv.first);
+        if (it == m_slide_energies.end()) continue;
+        it->second->set_active(true); it->second->set_pin(kv.second.first); it->second->set_normal(kv.second.second);
+    }
+    push_pins();
+    std::vector<int32_t> v; std::vector<double> n;
+    for (auto &kv : fresh) { v.push_back(kv.first); for (int j = 0; j < 3; ++j) n.push_back(kv.second.second[j]); }
+    check(admm_hip_set_pin_normals((admm_hip_ctx *)m_ctx, (int32_t)v.size(), v.data(), n.data()), "Solver::set_slide_pins");
 }
 
 void Solver::add_obstacle(std::shared_ptr<PassiveCollision> obj) { m_constraints->collider->add_passive_obj(obj); }
@@ -358,6 +450,12 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
         for (auto &pin : m_constraints->pins) {
             m_pin_energies[pin.first] = std::make_shared<SpringPin>(pin.first, pin.second);
             energyterms.emplace_back(m_pin_energies[pin.first]);
+        }
+    if (m_settings.linsolver == 0 || m_settings.linsolver == 2)      // slide constraints: SlidePin terms behind the pins
+        for (auto &sl : m_constraints->slides) {
+            if (m_constraints->pins.count(sl.first)) continue;           // (a pinned node cannot slide as well)
+            m_slide_energies[sl.first] = std::make_shared<SlidePin>(sl.first, sl.second.first, sl.second.second);
+            energyterms.emplace_back(m_slide_energies[sl.first]);
         }
     // the reference sizes D here (and assigns every term its first row); we keep that side effect
     std::vector<Triplet> triplets; std::vector<double> weights;
@@ -405,10 +503,15 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
     flat.tabulate();              // user-defined xu::Spline objects -> device tables
     flat.fill(d);
     // pins that are not energy terms (linsolver 1) go through the in-sweep pin list
-    std::vector<int32_t> gs_v; std::vector<double> gs_p;
+    std::vector<int32_t> gs_v; std::vector<double> gs_p, gs_n;
     if (m_settings.linsolver == 1) {
-        for (auto &kv : m_constraints->pins) { gs_v.push_back(kv.first); for (int j = 0; j < 3; ++j) gs_p.push_back(kv.second[j]); }
+        for (auto &kv : m_constraints->pins) { gs_v.push_back(kv.first); for (int j = 0; j < 3; ++j) { gs_p.push_back(kv.second[j]); gs_n.push_back(0.0); } }
+        for (auto &kv : m_constraints->slides) {
+            if (m_constraints->pins.count(kv.first)) continue;
+            gs_v.push_back(kv.first); for (int j = 0; j < 3; ++j) { gs_p.push_back(kv.second.first[j]); gs_n.push_back(kv.second.second[j]); }
+        }
         d.n_pins = (int32_t)gs_v.size(); d.pin_vert = gs_v.data(); d.pin_xyz = gs_p.data(); d.pin_active = nullptr;
+        d.pin_normal = m_constraints->slides.empty() ? nullptr : gs_n.data();
     }
     d.linsolver = m_settings.linsolver; d.constraint_w = m_settings.constraint_w;
     d.gs_tol = -1.0;

@@ -11,7 +11,7 @@ import numpy as np
 from . import capi
 from .capi import AdmmHipError, Desc, Stats, check, dptr, f64, i32, iptr, lib
 
-TET_LINEAR, TET_NEOHOOKEAN, TET_STVK, TET_SPLINE_NH, TET_SPLINE_STVK, TET_SPLINE_COROTATED, TET_SPLINE_TABLE = 0, 1, 2, 3, 4, 5, 6
+TET_LINEAR, TET_NEOHOOKEAN, TET_STVK, TET_SPLINE_NH, TET_SPLINE_STVK, TET_SPLINE_COROTATED, TET_SPLINE_TABLE, TET_STABLE_NH = 0, 1, 2, 3, 4, 5, 6, 7
 LS_LDLT, LS_NCMCGS, LS_UZAWACG = 0, 1, 2
 
 
@@ -176,6 +176,8 @@ class Solver:
         self._user_splines = []   # user-defined xu::Spline objects (TET_SPLINE_TABLE), in order of first use
         self._tris = []   # (idx[n,3], rest[n,4], weight[n], lmin[n], lmax[n])
         self._pins = {}   # vertex -> xyz   (ConstraintSet::pins)
+        self._slides = {}  # vertex -> (point, unit normal): slide constraints (README TODO of the reference; include/admm_hip.h: desc.pin_normal)
+        self._bends = []   # (idx[n,4], coef[n,4], weight[n], stiffness[n]): bending hinges (desc.bend_*)
         self._obstacles = []
         self._dynamic = []      # TetMeshCollision objects (Collider::dynamic_objs)
         self.surface_inds = []  # Solver::surface_inds (src/Solver.hpp:70): empty = every vertex is tested
@@ -247,6 +249,48 @@ class Solver:
         self._tris.append((inds + vertex_offset, rest, w, np.full(n, lame.limit_min), np.full(n, lame.limit_max)))
         return n
 
+    def add_bends(self, verts, tris, k_bend, vertex_offset=0):
+        """Bending terms for a triangle mesh (README.md:23-28 TODO of the reference; no reference code): one hinge term per interior edge,
+        created like create_tris_from_mesh creates the stretch terms (src/TriEnergyTerm.hpp:31-46).  Discrete quadratic bending energy
+        (Bergou et al. 2006): E = k_bend * 3 / (A0 + A1) / 2 * |sum_k c_k x_k|^2 with the cotangent stencil c of the REST shape
+        (admm_host_bend_hinges); weight = sqrt(stiffness), so that the prox is q / 2 (the idiom of src/TriEnergyTerm.cpp:77-83).
+        Returns the number of hinges."""
+        idx, coef, area = capi.bend_hinges(verts, tris)
+        stiff = float(k_bend) * 3.0 / area
+        self._bends.append((idx + vertex_offset, coef, np.sqrt(stiff), stiff))
+        return idx.shape[0]
+
+    def set_slide_pins(self, inds, points, normals):
+        """Slide constraints (README.md:23-28 TODO of the reference; the counterpart of Solver::set_pins, src/Solver.cpp:113-157, for
+        normal-only constraints): vertex inds[i] may move freely in the plane through points[i] with normal normals[i].  Replaces the
+        current set of slide constraints; ordinary pins are set_pins' business.  After initialize only constraints created before it may
+        be moved / re-oriented (like pins with linsolver 0 / 2, src/Solver.cpp:147-151)."""
+        new = {}
+        for i, idx in enumerate(inds):
+            n = f64(normals[i]).ravel().copy()
+            l = float(np.linalg.norm(n))
+            if not l > 0.0:
+                raise AdmmHipError(-1, "set_slide_pins: zero normal")
+            new[int(idx)] = (f64(points[i]).ravel().copy(), n / l)
+        self._slides = new
+        if self.initialized:
+            self._push_pins()
+            v = i32(list(self._slides.keys()))
+            nn = f64(np.array([q[1] for q in self._slides.values()]).reshape(-1, 3)) if len(v) else np.zeros((0, 3))
+            check(lib().admm_hip_set_pin_normals(self._ctx, len(v), iptr(v), dptr(nn)))
+
+    def _all_pins(self):
+        """ordinary pins, then slide pins: (vertex list, points [n,3], normals [n,3] -- zero for ordinary pins)"""
+        v = list(self._pins.keys()) + [k for k in self._slides if k not in self._pins]
+        pts = [self._pins[k] for k in self._pins] + [self._slides[k][0] for k in self._slides if k not in self._pins]
+        nrm = [np.zeros(3) for _ in self._pins] + [self._slides[k][1] for k in self._slides if k not in self._pins]
+        return v, (f64(np.array(pts)).reshape(-1, 3) if v else np.zeros((0, 3))), (f64(np.array(nrm)).reshape(-1, 3) if v else np.zeros((0, 3)))
+
+    def _push_pins(self):
+        v, p, _ = self._all_pins()
+        vi = i32(v)
+        check(lib().admm_hip_set_pins(self._ctx, len(vi), iptr(vi), dptr(p)))
+
     def set_pins(self, inds, points=None):
         """Solver::set_pins (src/Solver.cpp:113-157)."""
         inds = [int(i) for i in inds]
@@ -260,9 +304,7 @@ class Solver:
         for i, idx in enumerate(inds):
             self._pins[idx] = self.m_x[3 * idx:3 * idx + 3].copy() if pin_in_place else f64(points[i]).copy()
         if self.initialized:
-            v = i32(list(self._pins.keys()))
-            p = f64(np.array(list(self._pins.values())).reshape(-1, 3)) if n else np.zeros((0, 3))
-            check(lib().admm_hip_set_pins(self._ctx, len(v), iptr(v), dptr(p)))
+            self._push_pins()
 
     def add_obstacle(self, obj):
         """Solver::add_obstacle (src/Solver.cpp:159-161)."""
@@ -300,15 +342,17 @@ class Solver:
         """Flat arrays of every energy term, in the order tets, tris (pins are appended by the library)."""
         def cat(lst, k, shape, dt):
             return np.concatenate([t[k] for t in lst]).astype(dt) if lst else np.zeros(shape, dt)
-        T, R = self._tets, self._tris
+        T, R, H = self._tets, self._tris, self._bends
+        pv, pp, pn = self._all_pins()
         out = dict(
+            bend_idx=cat(H, 0, (0, 4), np.int32), bend_coef=cat(H, 1, (0, 4), np.float64), bend_weight=cat(H, 2, (0,), np.float64),
+            bend_stiffness=cat(H, 3, (0,), np.float64), pin_normal=pn,
             tet_idx=cat(T, 0, (0, 4), np.int32), tet_Binv=cat(T, 1, (0, 9), np.float64), tet_weight=cat(T, 2, (0,), np.float64),
             tet_kind=cat(T, 3, (0,), np.int32), tet_mu=cat(T, 4, (0,), np.float64), tet_lambda=cat(T, 5, (0,), np.float64),
             tet_k=cat(T, 6, (0,), np.float64), tet_kappa=cat(T, 7, (0,), np.float64), tet_spline=cat(T, 8, (0,), np.int32),
             tri_idx=cat(R, 0, (0, 3), np.int32), tri_rest=cat(R, 1, (0, 4), np.float64), tri_weight=cat(R, 2, (0,), np.float64),
             tri_limit_min=cat(R, 3, (0,), np.float64), tri_limit_max=cat(R, 4, (0,), np.float64),
-            pin_vert=i32(list(self._pins.keys())),
-            pin_xyz=f64(np.array(list(self._pins.values())).reshape(-1, 3)) if self._pins else np.zeros((0, 3)),
+            pin_vert=i32(pv), pin_xyz=pp,
         )
         return out
 
@@ -345,6 +389,11 @@ class Solver:
         d.tri_limit_min, d.tri_limit_max = dptr(f["tri_limit_min"]), dptr(f["tri_limit_max"])
         d.n_pins = f["pin_vert"].shape[0]
         d.pin_vert, d.pin_xyz, d.pin_active, d.pin_weight = iptr(f["pin_vert"]), dptr(f["pin_xyz"]), None, 0.0
+        d.pin_normal = dptr(f["pin_normal"]) if self._slides else None
+        d.n_bends = f["bend_idx"].shape[0]
+        if d.n_bends:
+            d.bend_idx, d.bend_coef = iptr(f["bend_idx"]), dptr(f["bend_coef"])
+            d.bend_weight, d.bend_stiffness = dptr(f["bend_weight"]), dptr(f["bend_stiffness"])
         d.linsolver, d.constraint_w = s.linsolver, s.constraint_w
         d.pcg_max_iters, d.pcg_tol = s.pcg_max_iters, s.pcg_tol
         d.gs_max_iters, d.gs_tol, d.gs_omega = s.gs_max_iters, s.gs_tol, s.gs_omega
@@ -461,6 +510,13 @@ class Solver:
         dist.broadcast_object_list(obj, src=0)
         check(lib().admm_hip_comm_init(self._ctx, obj[0], s.rank, s.world_size))
 
+    def comm_info(self):
+        """admm_hip_comm_info: dict(n_ranks, rank, device) -- what RCCL says about the context's communicator, and the context's device."""
+        self._need_ctx()
+        n = C.c_int32(0); r = C.c_int32(-1); buf = C.create_string_buffer(64)
+        check(lib().admm_hip_comm_info(self._ctx, C.byref(n), C.byref(r), buf))
+        return dict(n_ranks=n.value, rank=r.value, device=buf.value.decode("ascii", "replace"))
+
     def set_rhs_allreduce(self, fn):
         """admm_hip_set_rhs_allreduce: the multi-GPU exchange over the caller's own transport instead of RCCL.  fn(buf) must sum
         the numpy array `buf` (a view of the library's pinned host buffer, [3 n_verts]) IN PLACE over all ranks; None removes it."""
@@ -507,6 +563,13 @@ class Solver:
         it = C.c_int32(0); t = C.c_double(0.0); o = C.c_double(0.0)
         check(lib().admm_hip_get_solver_params(self._ctx, int(kind), C.byref(it), C.byref(t), C.byref(o)))
         return it.value, t.value, o.value
+
+    def contact_totals(self):
+        """admm_hip_contact_totals: rows of C over all UzawaCG solves / rows projected onto an obstacle over all GS sweeps, since initialize."""
+        self._need_ctx()
+        n = C.c_int64(0)
+        check(lib().admm_hip_contact_totals(self._ctx, C.byref(n)))
+        return n.value
 
     def persistent_launches(self):
         """admm_hip_persistent_launches: dict(pcg, gs, schur) -- launches of the persistent solver kernels since initialize."""

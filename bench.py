@@ -378,6 +378,9 @@ def main():
         s.time_local_launches(2)   # a hipEvent pair attached to the dispatch of every local-step kernel of the timed region
         s.local_launch_times()     # (clears what the warm-up recorded)
     uz0 = s.uzawa_cache_stats() if w["linsolver"] == 2 else None
+    has_contact = bool(sc.obstacles or sc.dynamic) and w["linsolver"] != 0
+    ct0 = s.contact_totals() if has_contact else 0       # rows of C (UzawaCG) / rows projected inside the sweeps (GS) so far
+    frame_ms = []                                        # HIP-event time of every statistics frame (median: SURVEY 8d)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         s.step_device(stats=not lean)
@@ -386,9 +389,11 @@ def main():
             local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms; inner += rd.inner_iters
             lk_ms += rd.local_kernel_ms
             unconv += rd.unconverged_solves
+            frame_ms.append(rd.step_ms)
     sync()
     elapsed = time.perf_counter() - t0
     stats_elapsed = elapsed
+    ct1 = s.contact_totals() if has_contact else 0
     uz1 = s.uzawa_cache_stats() if w["linsolver"] == 2 else None
     if lean:
         lt_pairs, lt_ms = s.local_launch_times()
@@ -402,6 +407,7 @@ def main():
             rd = s.runtime_data()
             local_ms += rd.local_ms; rhs_ms += rd.rhs_ms; global_ms += rd.global_ms
             lk_ms += rd.local_kernel_ms
+            frame_ms.append(rd.step_ms)
         sync()
         stats_elapsed = time.perf_counter() - t1s
         tot2 = s.solve_totals()
@@ -442,6 +448,31 @@ def main():
             one[0] += r1.local_ms / (3 * iters); one[1] += r1.rhs_ms / (3 * iters); one[2] += r1.global_ms / (3 * iters)
         sw.close()
 
+    # BASELINE configs[4] names "floor-collision ConstraintSet, dynamic constraints": the cloth of the bench scene swings on its two pins
+    # and reaches the floor only around frame 29, AFTER the default timed frames -- so the same run goes on until rows are being projected
+    # inside the sweeps (admm_hip_contact_totals moves) and times `steps` more frames there.  Both regimes are quoted.
+    contact_leg = None
+    if has_contact and w["linsolver"] == 1 and world == 1 and os.environ.get("ADMM_BENCH_CONTACT_LEG", "1") != "0":
+        waited, c_prev = 0, s.contact_totals()
+        in_contact = ct1 > ct0
+        while not in_contact and waited < 120:
+            s.step_device(stats=False); waited += 1
+            c_now = s.contact_totals(); in_contact = c_now > c_prev; c_prev = c_now
+        if in_contact:
+            for _ in range(2):
+                s.step_device(stats=False)
+            sync()
+            c_a = s.contact_totals(); fm = []
+            tc = time.perf_counter()
+            for _ in range(args.steps):
+                s.step_device(stats=True); fm.append(s.runtime_data().step_ms)
+            sync()
+            tc = time.perf_counter() - tc
+            c_b = s.contact_totals()
+            contact_leg = {"what": "the same run continued until the cloth lies on the floor (%d more frames), then %d frames timed with per-step statistics" % (waited + 2, args.steps),
+                           "value": iters * args.steps / tc, "unit": "ADMM it/s", "ms_per_step": 1e3 * tc / max(args.steps, 1),
+                           "median_ms_per_frame": float(np.median(fm)), "rows_projected_in_timed_region": c_b - c_a,
+                           "rows_projected_per_sweep": (c_b - c_a) / max(1, args.steps * iters * 30)}
     rd = s.runtime_data()
     s.download()
     finite = bool(np.isfinite(s.m_x).all())
@@ -477,6 +508,13 @@ def main():
                          "`roofline`); split / iteration counts from as many STATISTICS FRAMES right after, which take %.3f x the time of the timed ones "
                          "(`stats_frames_ms_per_step`)" % (stats_elapsed / elapsed)) if lean else "frames with per-step statistics",
         "stats_frames_ms_per_step": 1e3 * stats_elapsed / max(args.steps, 1),
+        # "time >= 20 frames, report median": HIP-event time of each statistics frame (`value` stays the contract's K frames / wall clock)
+        "median_ms_per_frame_statistics_frames": float(np.median(frame_ms)) if frame_ms else None,
+        "median_admm_it_per_s_statistics_frames": (1e3 * iters / float(np.median(frame_ms))) if frame_ms else None,
+        # contact work inside the timed region (admm_hip_contact_totals): rows of C summed over the UzawaCG solves / rows projected onto an
+        # obstacle summed over the GS sweeps.  0 = the timed frames were contact-free (see `contact_regime`)
+        "rows_projected_in_timed_region": (ct1 - ct0) if has_contact else None,
+        "contact_regime": contact_leg,
         # UzawaCG: how the Schur iterations of the timed region applied A^-1 (cached columns of K^-1 / inner PCG solves), and the
         # PCG launches the region spent on new columns (vertices that touched an obstacle for the first time)
         "uzawa": None if uz0 is None else {"cached_columns": uz1["columns"],
@@ -494,6 +532,13 @@ def main():
                        "unit": "ADMM it/s summed over the %d bodies" % world, "expected_vs_one_gpu": float(world)}
     elif world == 1 and default_workload:
         out["weak_value"] = value            # N = 1: the same body, the same number
+    if world > 1:
+        # so that a scaling run can be CHECKED: the rank count RCCL itself reports for the context's communicator, and every rank's device
+        info = s.comm_info()
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
+        out["rccl"] = {"communicator_ranks": info["n_ranks"], "devices": [i["device"] for i in infos],
+                       "distinct_devices": len({i["device"] for i in infos}), "ranks_reporting": [i["rank"] for i in infos]}
     if share:
         out["shared_gpu_functional_test"] = "ADMM_BENCH_SHARE_GPU=1: %d ranks time-share ONE device -- a check that the N-rank path runs, not a measurement" % world
     if world > 1 and not weak:
@@ -565,14 +610,23 @@ def main():
                                           if lean else "hipEventRecord pair around the launch, context stream"),
                                "kernel_us_device_clock": (1e3 * lk_ms / (iters * args.steps)) if lk_ms > 0 else None,
                                "avg_launch_us_statistics_frames": 1e3 * local_ms / (iters * args.steps) if lean else None,
+                               # both definitions every round (round-4 review): `frac` = events attached to the kernel's dispatch (round 4's
+                               # final definition), `frac_events_around_launch` = the pair of hipEventRecords around it (rounds 1-3)
+                               "frac_events_around_launch": (bytes_per_launch / (1e-3 * local_ms / (iters * args.steps)) / 1e9 / 8000.0) if (lean and local_ms > 0) else None,
                                "algorithmic_bytes_per_launch": bytes_per_launch}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(w)
+            sample = cpu_baseline(w)
+            out["cpu_baseline"] = sample
             if nt >= 500000 and w["kinds"] != "cloth" and not args.n:
-                # the extrapolation-free figure: the same CPU code on the SAME mesh, GS as the global step (the fair 1 M baseline)
-                full = cpu_baseline_full_size(w, out["cpu_baseline"]["cores"])
-                out["cpu_baseline"]["full_size"] = full
-                out["cpu_baseline"]["gpu_over_cpu_at_full_size"] = value / full["admm_iters_per_s"]
+                # the extrapolation-free figure, and the PRIMARY one: the same CPU code on the SAME mesh, GS as the global step (the fair
+                # 1 M baseline: the reference's LDLT needs a 31-minute factorisation at this size); the reduced-size
+                # SuperLU sample of rounds 1-3 rides along as `sample_reduced_size`
+                full = cpu_baseline_full_size(w, sample["cores"])
+                out["cpu_baseline"] = {"value": full["admm_iters_per_s"], "unit": "ADMM it/s", "cores": full["cores"], "kind": "port",
+                                       "sample": "the benchmarked mesh itself (%d elements): %d whole ADMM iterations in %.1f s on %d OpenMP threads; %s" %
+                                                 (full["elements"], full["admm_iterations_timed"], full["seconds"], full["cores"], full["what"]),
+                                       "full_size": full, "gpu_over_cpu_at_full_size": value / full["admm_iters_per_s"],
+                                       "sample_reduced_size": sample}
             try:    # the port against the real reference pieces, measured in the build container (bench.py --calibrate-cpu-baseline)
                 cal = json.load(open(CALIBRATION_FILE))
                 out["cpu_baseline"]["calibration"] = dict(cal["summary"], file=os.path.relpath(CALIBRATION_FILE, ROOT), host=cal.get("host"),

@@ -12,8 +12,8 @@
  *   - node vectors (x, v, b, masses) are [3*n_verts], interleaved xyz, exactly like Solver::m_x
  *     (src/Solver.hpp:66-68)
  *   - 3x3 / 2x2 matrices are column-major (Eigen default)
- *   - energy-term order inside a context is: tets (given order), then tris, then pins; the ADMM
- *     vectors z,u use the reference's row layout (9 rows per tet, 6 per tri, 6 per pin:
+ *   - energy-term order inside a context is: tets (given order), then tris, then bending hinges, then pins; the ADMM
+ *     vectors z,u use the reference's row layout (9 rows per tet, 6 per tri, 3 per hinge, 6 per pin:
  *     src/TetEnergyTerm.hpp:68, src/TriEnergyTerm.hpp:66, src/SpringEnergyTerm.hpp:42)
  *   - every function returns 0 on success or a negative admm_hip_status; the message of the last
  *     failure on the calling thread is available from admm_hip_last_error()
@@ -46,8 +46,12 @@ typedef enum {
  * (src/TetEnergyTerm.hpp:192-204).  User-defined splines have no kernel. */
 enum { ADMM_TET_LINEAR = 0, ADMM_TET_NEOHOOKEAN = 1, ADMM_TET_STVK = 2, ADMM_TET_SPLINE_NH = 3, ADMM_TET_SPLINE_STVK = 4,
        ADMM_TET_SPLINE_COROTATED = 5,
-       ADMM_TET_SPLINE_TABLE = 6 };   /* SplineTet with a USER-DEFINED xu::Spline (src/TetEnergyTerm.hpp:197-204, src/XuSpline.hpp:34-46):
+       ADMM_TET_SPLINE_TABLE = 6,     /* SplineTet with a USER-DEFINED xu::Spline (src/TetEnergyTerm.hpp:197-204, src/XuSpline.hpp:34-46):
                                        * the spline's six functions sampled by admm_host_tabulate_spline, desc.tet_spline = its table */
+       ADMM_TET_STABLE_NH = 7 };      /* stable Neo-Hookean (README.md:23-28 lists it as a TODO the reference never shipped; it would sit beside
+                                       * NeoHookeanTet, src/TetEnergyTerm.hpp:116-136, as one more HyperElasticTet): Smith, de Goes, Kim 2018,
+                                       * Psi = mu_s/2 (I_C - 3) + la_s/2 (J - alpha)^2 - mu_s/2 log(I_C + 1) with mu_s = 4/3 mu, la_s = lambda + 5/6 mu,
+                                       * alpha = 1 + 3 mu_s / (4 la_s) from the tet's tet_mu / tet_lambda; finite for inverted elements */
 #define ADMM_SPLINE_TABLE_DOUBLES 9228   /* doubles of one table: 3 functions x (4 header + 3 x 1024 node values) */
 
 /* global solvers -- Solver::Settings::linsolver, src/Solver.hpp:46 ("0=LDLT, 1=NCMCGS, 2=UzawaCG").
@@ -154,6 +158,28 @@ typedef struct {
     int32_t n_obstacle_grids;
     const double *obstacle_grid_meta;
     const double *obstacle_grid_data;
+
+    /* SLIDE constraints (README.md:23-28 lists them as a TODO the reference never shipped; no reference code).  [3*n_pins] or NULL:
+     * a pin with a non-zero normal n (normalised by the library) constrains only n . (x - pin_xyz) = 0 -- the vertex slides in the
+     * plane through the pin's point.  linsolver 0 / 2: a SpringPin term (src/SpringEnergyTerm.hpp:31-73: same D-block I3, same
+     * weight) whose prox projects q = D x + u onto that plane instead of onto the point (:61); linsolver 1: inside the sweeps
+     * (src/NodalMultiColorGS.hpp:111-117) the node takes the plane-constrained Jacobi value of :218-262 on its own plane.  A zero
+     * normal = an ordinary pin.  admm_hip_set_pins moves the points and keeps the normals; admm_hip_set_pin_normals changes them. */
+    const double *pin_normal;
+
+    /* BENDING terms for cloth (README.md:23-28 TODO "bending force"; no reference code).  One EnergyTerm per hinge -- an interior edge
+     * (v0, v1) and the two vertices v2, v3 opposite to it -- beside TriEnergyTerm (src/TriEnergyTerm.cpp:54-101): dim 3, D-block =
+     * (c0, c1, c2, c3) (x) I3, i.e. D_i x = sum_k c_k x_{v_k} (the discrete mean-curvature normal of the hinge, Bergou et al. 2006, "A
+     * Quadratic Bending Model for Inextensible Surfaces"), energy E(z) = bend_stiffness / 2 |z|^2, weight bend_weight, so that
+     * prox(q) = q w^2 / (stiffness + w^2).  bend_idx [4*n_bends], bend_coef [4*n_bends], bend_weight [n_bends] (> 0), bend_stiffness
+     * [n_bends] (>= 0).  admm_host_bend_hinges builds idx / coef / rest areas from a triangle mesh; the mirrors then use
+     * stiffness = k_bend * 3 / area and weight = sqrt(stiffness) (prox = q / 2, the idiom of src/TriEnergyTerm.cpp:77-83).
+     * Rows of z / u: after the triangles, before the pins, 3 per hinge. */
+    int32_t n_bends;
+    const int32_t *bend_idx;
+    const double *bend_coef;
+    const double *bend_weight;
+    const double *bend_stiffness;
 } admm_hip_desc;
 
 /* Maps 1:1 onto Solver::RuntimeData (src/Solver.hpp:54-61) plus GPU-side extras. */
@@ -195,6 +221,11 @@ int admm_hip_get_state(admm_hip_ctx *ctx, double *x, double *v);
  * linsolver 0/2: idx must be among the pins given at create (else ADMM_HIP_ERR_ARG, like the throw
  * at Solver.cpp:147-151); all other pins become inactive.  linsolver 1: the set is replaced freely. */
 int admm_hip_set_pins(admm_hip_ctx *ctx, int32_t n, const int32_t *vert, const double *xyz);
+
+/* Slide pins after initialize (see desc.pin_normal): normals [3*n] of the pins at `vert` (a zero normal makes it an ordinary pin again).
+ * linsolver 0 / 2: vert must be among the pins given at create; linsolver 1: among the current pins.  Points and activation are
+ * admm_hip_set_pins' business. */
+int admm_hip_set_pin_normals(admm_hip_ctx *ctx, int32_t n, const int32_t *vert, const double *normals);
 
 /* Solver::ext_forces with a WindForce (src/ExplicitForce.hpp:39-46, src/ExplicitForce.cpp:47-104), applied on the DEVICE at the
  * start of every admm_hip_step, where Solver::step calls ExplicitForce::project (src/Solver.cpp:54): tris [3*n_tris] = the node
@@ -261,6 +292,12 @@ int admm_hip_solve_totals(admm_hip_ctx *ctx, int64_t *solves, int64_t *converged
 int admm_hip_set_solver_params(admm_hip_ctx *ctx, int32_t kind, int32_t max_iters, double tol, double omega);
 int admm_hip_get_solver_params(const admm_hip_ctx *ctx, int32_t kind, int32_t *max_iters, double *tol, double *omega);
 
+/* Contact work since admm_hip_create (measurement: that a timed region really exercised the collision path).  linsolver 2: rows of C
+ * (ConstraintSet::make_matrix, src/ConstraintSet.hpp:59-116) summed over all UzawaCG solves; linsolver 1: node updates replaced by the
+ * plane-constrained update of src/NodalMultiColorGS.hpp:218-262 (a row projected onto a passive obstacle), summed over all sweeps
+ * (passive obstacles; dynamic hits of the GS path are penalty rows and not counted); linsolver 0: 0.  Synchronises the stream (GS). */
+int admm_hip_contact_totals(admm_hip_ctx *ctx, int64_t *rows);
+
 /* Launches of the three persistent solver kernels since admm_hip_create (no reference counterpart): the on-chip PCG (one per solve of
  * linsolver 0 / 2 and per batch of K^-1 columns), the multi-colour GS, the Schur CG of UzawaCG.  After a barrier / hand-off time-out
  * the context falls back to the launch-per-iteration kernels for good: the counts then stop growing (tests). */
@@ -302,6 +339,10 @@ int admm_hip_get_colors(const admm_hip_ctx *ctx, int32_t *color, int32_t *n_colo
  * sum all-reduce of the [3*n_verts] partial right-hand side per ADMM iteration. */
 int admm_hip_comm_unique_id(char *id128);                                   /* ncclGetUniqueId */
 int admm_hip_comm_init(admm_hip_ctx *ctx, const char *id128, int rank, int world_size);
+/* What the context's RCCL communicator says about itself (ncclCommCount / ncclCommUserRank: 0 / -1 without a communicator) and which
+ * device the context sits on (device_id64: at least 64 chars, "pci <bus id> uuid <hex>") -- printed by bench.py in its N > 1 line so
+ * that a scaling run can be checked for N distinct devices in ONE communicator.  Pointers may be NULL. */
+int admm_hip_comm_info(const admm_hip_ctx *ctx, int32_t *n_ranks, int32_t *rank, char *device_id64);
 /* The same exchange over the CALLER's transport instead of RCCL (MPI, gloo, a test harness that puts several ranks on one device
  * -- which RCCL refuses): once per ADMM iteration the library copies the partial right-hand side to pinned host memory, calls
  * fn(user, host_buf, 3 * n_verts) -- which must sum host_buf in place over all ranks and return 0 -- and copies the result back.
@@ -376,6 +417,13 @@ int admm_host_sample_obstacle(admm_obstacle_fn fn, void *user, const double *lo3
 int admm_hip_tet_rest_mode(const admm_hip_ctx *ctx);
 /* TriEnergyTerm ctor (src/TriEnergyTerm.cpp:29-52): rest [4*n], area [n]. */
 int admm_host_tri_rest(int32_t n, const int32_t *idx, const double *verts, double *rest, double *area);
+/* Bending hinges of a triangle mesh (desc.bend_*; no reference counterpart): every interior edge shared by exactly two triangles gives
+ * one hinge (v0 < v1 the edge, v2 / v3 the opposite vertices of the first / second triangle in index order), hinges sorted by (v0, v1).
+ * coef = (c03 + c04, c01 + c02, -(c01 + c03), -(c02 + c04)) with the cotangents of the REST angles at v0 (c01 in the first triangle, c02 in
+ * the second) and at v1 (c03, c04): sum_k coef_k x_k = 0 for any flat configuration; area = rest area of the two triangles.
+ * Returns the number of hinges (may exceed cap: then only cap are written; NULL arrays to count). */
+int32_t admm_host_bend_hinges(int32_t n_verts, int32_t n_tris, const int32_t *tris, const double *verts, int32_t cap,
+                              int32_t *hinge_idx, double *coef, double *area);
 /* Lame (src/EnergyTerm.hpp:34-59) */
 void admm_host_lame(double youngs, double poisson, double *mu, double *lambda, double *bulk);
 /* Greedy nodal colouring on a CSR pattern (role of the absent mcl::graphcolor::color_matrix,

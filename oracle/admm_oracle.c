@@ -211,7 +211,21 @@ static double xu_dg(int kind, double la, double x) {
 }
 static double xu_dh(int kind, double mu, double la, double kappa, double x) { return (kind == 3 ? xu_nh_dh(mu, la, x) : 0.0) + xu_d_compress(kappa, x); }
 
+/* STABLE NEO-HOOKEAN, kind 7 -- no reference code ("parity unpinned"): the reference's README lists it as a TODO (README.md:23-28); it
+ * would be one more HyperElasticTet beside NeoHookeanTet (src/TetEnergyTerm.hpp:116-136).  Restated from the paper: Smith, de Goes, Kim,
+ * "Stable Neo-Hookean Flesh Simulation", ACM TOG 37(2), 2018, Eq. 14 with the Lame re-parametrisation of section 3.4:
+ *   Psi = mu_s/2 (I_C - 3) + la_s/2 (J - alpha)^2 - mu_s/2 log(I_C + 1),  mu_s = 4/3 mu, la_s = lambda + 5/6 mu, alpha = 1 + 3 mu_s / (4 la_s),
+ * I_C = sum x_i^2, J = x0 x1 x2 in the principal stretches.  Defined for negative stretches: value() has no FLT_MAX barrier. */
+static void snh_constants(const prox_problem *p, double *mus, double *las, double *alpha) {
+    *mus = (4.0 / 3.0) * p->mu; *las = p->lambda + (5.0 / 6.0) * p->mu; *alpha = 1.0 + 0.75 * (*mus) / (*las);
+}
+
 static double energy_density(const prox_problem *p, const double *x) {
+    if (p->kind == 7) {
+        double mus, las, al; snh_constants(p, &mus, &las, &al);
+        const double IC = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], J = x[0] * x[1] * x[2];
+        return 0.5 * mus * (IC - 3.0) + 0.5 * las * (J - al) * (J - al) - 0.5 * mus * log(IC + 1.0);
+    }
     if (p->kind == 1) { /* TetEnergyTerm.cpp:173-182 */
         double J = x[0] * x[1] * x[2];
         double I1 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
@@ -231,7 +245,7 @@ static double energy_density(const prox_problem *p, const double *x) {
 
 /* ::value  -- TetEnergyTerm.cpp:184-192, :210-218, :249-257 */
 static double prox_value(const prox_problem *p, const double *x) {
-    if (x[0] < 0.0 || x[1] < 0.0 || x[2] < 0.0) return ORC_FLT_MAX;
+    if (p->kind != 7 && (x[0] < 0.0 || x[1] < 0.0 || x[2] < 0.0)) return ORC_FLT_MAX;
     double q = 0.0;
     for (int i = 0; i < 3; ++i) q += (x[i] - p->x0[i]) * (x[i] - p->x0[i]);
     return energy_density(p, x) + 0.5 * p->k * q;
@@ -240,7 +254,12 @@ static double prox_value(const prox_problem *p, const double *x) {
 /* ::gradient -- TetEnergyTerm.cpp:195-204, :228-237, :259-265.  Returns value.  The reference throws
  * for NH when J <= 0; callers here never evaluate the gradient at an infeasible point. */
 static double prox_gradient(const prox_problem *p, const double *x, double *g) {
-    if (p->kind == 1) {
+    if (p->kind == 7) {
+        double mus, las, al; snh_constants(p, &mus, &las, &al);
+        const double IC = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], J = x[0] * x[1] * x[2], q = 1.0 / (IC + 1.0);
+        const double dJ[3] = {x[1] * x[2], x[2] * x[0], x[0] * x[1]};
+        for (int i = 0; i < 3; ++i) g[i] = mus * x[i] * (1.0 - q) + las * (J - al) * dJ[i] + p->k * (x[i] - p->x0[i]);
+    } else if (p->kind == 1) {
         double J = x[0] * x[1] * x[2], lJ = log(J);
         for (int i = 0; i < 3; ++i) {
             double xi = 1.0 / x[i];
@@ -264,6 +283,16 @@ static double prox_gradient(const prox_problem *p, const double *x, double *g) {
 /* Hessian of value() -- derived, used only for the "tight" Newton polish */
 static void prox_hessian(const prox_problem *p, const double *x, double *H) {
     memset(H, 0, 9 * sizeof(double));
+    if (p->kind == 7) {
+        double mus, las, al; snh_constants(p, &mus, &las, &al);
+        const double IC = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], J = x[0] * x[1] * x[2], q = 1.0 / (IC + 1.0);
+        const double dJ[3] = {x[1] * x[2], x[2] * x[0], x[0] * x[1]};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                M3(H, i, j) = 2.0 * mus * q * q * x[i] * x[j] + las * (dJ[i] * dJ[j] + (i == j ? 0.0 : (J - al) * x[3 - i - j]));
+        for (int i = 0; i < 3; ++i) M3(H, i, i) += mus * (1.0 - q) + p->k;
+        return;
+    }
     if (p->kind == 1 || p->kind == 3) {
         double lJ = log(x[0] * x[1] * x[2]);
         double xi[3] = {1.0 / x[0], 1.0 / x[1], 1.0 / x[2]};
@@ -292,7 +321,7 @@ static void prox_hessian(const prox_problem *p, const double *x, double *H) {
 }
 
 static int feasible(const prox_problem *p, const double *x) {
-    (void)p;
+    if (p->kind == 7) return 1;                    /* stable Neo-Hookean: defined everywhere */
     return x[0] > 0.0 && x[1] > 0.0 && x[2] > 0.0;
 }
 
@@ -654,6 +683,23 @@ static int passive_hit(int nobj, const int32_t *okind, const double *opar, const
     return 0;
 }
 
+/* SLIDE pins inside the sweeps (README.md:23-28 TODO of the reference, no reference code: "parity unpinned"): pin_flag[v] == 2 -> the node
+ * takes the plane-constrained Jacobi value of :218-262 on the plane through pin_xyz[v] with the unit normal g_pin_nrm[v] (set by
+ * orc_gs_set_pin_normals before the solve): x_v = jac - n (n . (jac - p)), jac = D^-1 (b - LUx).  */
+static const double *g_pin_nrm = 0;
+void orc_gs_set_pin_normals(const double *nrm) { g_pin_nrm = nrm; }
+static void slide_update(int v, const int32_t *rp, const int32_t *ci, const double *val, const double *b, const double *pin_xyz, double *x) {
+    double LUx[3] = {0, 0, 0}, aii = 0.0, jac[3], d = 0.0;
+    for (int k = rp[v]; k < rp[v + 1]; ++k) {
+        if (fabs(val[k]) <= 0.0) continue;
+        int col = ci[k];
+        if (col == v) { aii = val[k]; continue; }
+        for (int s = 0; s < 3; ++s) LUx[s] += val[k] * x[3 * col + s];
+    }
+    for (int s = 0; s < 3; ++s) { jac[s] = (b[3 * v + s] - LUx[s]) / aii; d += g_pin_nrm[3 * v + s] * (jac[s] - pin_xyz[3 * v + s]); }
+    for (int s = 0; s < 3; ++s) x[3 * v + s] = jac[s] - d * g_pin_nrm[3 * v + s];
+}
+
 int orc_gs_solve(int nv, const int32_t *rp, const int32_t *ci, const double *val,
                  const double *b, double *x,
                  int ncolors, const int32_t *cptr, const int32_t *cnodes,
@@ -669,6 +715,7 @@ int orc_gs_solve(int nv, const int32_t *rp, const int32_t *ci, const double *val
 #pragma omp parallel for schedule(static) if (end - beg > 31)
             for (int ii = beg; ii < end; ++ii) {
                 int v = cnodes[ii];
+                if (pin_flag && pin_flag[v] == 2 && g_pin_nrm) { slide_update(v, rp, ci, val, b, pin_xyz, x); continue; }
                 if (pin_flag && pin_flag[v]) { for (int s = 0; s < 3; ++s) x[3 * v + s] = pin_xyz[3 * v + s]; continue; }
                 double LUx[3] = {0, 0, 0}, aii = 0.0;
                 for (int k = rp[v]; k < rp[v + 1]; ++k) {
@@ -838,6 +885,7 @@ int orc_gs_solve_full(int nv, const int32_t *rp, const int32_t *ci, const double
 #pragma omp parallel for schedule(static) if (end - beg > 31)
             for (int ii = beg; ii < end; ++ii) {
                 int v = cnodes[ii];
+                if (pin_flag && pin_flag[v] == 2 && g_pin_nrm) { slide_update(v, rp, ci, val, b, pin_xyz, x); continue; }
                 if (pin_flag && pin_flag[v]) { for (int s = 0; s < 3; ++s) x[3 * v + s] = pin_xyz[3 * v + s]; continue; }
                 double LUx[3] = {0, 0, 0}, aii[3] = {0, 0, 0}, nx[3], jac[3];
                 for (int s = 0; s < 3; ++s) {

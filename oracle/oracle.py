@@ -85,6 +85,7 @@ def lib():
         L.orc_gs_solve_full.argtypes = [C.c_int, ip, ip, dp, dp, dp, C.c_int, ip, ip, ip, dp, C.c_int, ip, dp,
                                         C.c_double, C.c_int, C.c_double]
         L.orc_gs_solve_full.restype = C.c_int
+        L.orc_gs_set_pin_normals.argtypes = [dp]
         L.orc_detect_dynamic.argtypes = [C.c_int, ip, dp, C.c_int, dp, C.c_int, ip, C.c_int, ip, ip, ip, dp, dp, dp]
         _lib = L
     return _lib
@@ -202,6 +203,36 @@ def tri_rest(verts, tris):
     return rest, area
 
 
+def bend_hinges(verts, tris):
+    """Hinges of a triangle mesh for the bending term (no reference code; README.md:23-28 TODO): every interior edge (v0 < v1) shared by
+    exactly two triangles, v2 / v3 the opposite vertices of the first / second triangle in index order, hinges sorted by (v0, v1); the
+    stencil of Bergou et al. 2006 ("A Quadratic Bending Model for Inextensible Surfaces", the vector K of their Eq. 4):
+    (c03 + c04, c01 + c02, -(c01 + c03), -(c02 + c04)) with the cotangents of the rest angles at v0 (c01: first triangle, c02: second) and at
+    v1 (c03, c04); area = rest area of the two triangles.  Returns (idx [n,4], coef [n,4], area [n])."""
+    X = np.asarray(verts, dtype=np.float64).reshape(-1, 3); T = np.asarray(tris, dtype=np.int64).reshape(-1, 3)
+    edges = {}
+    for t in range(len(T)):
+        for e in range(3):
+            p, q, o = int(T[t, e]), int(T[t, (e + 1) % 3]), int(T[t, (e + 2) % 3])
+            edges.setdefault((min(p, q), max(p, q)), []).append((t, o))
+
+    def cot(p, q, r):
+        u, v = X[q] - X[p], X[r] - X[p]
+        return u.dot(v) / np.linalg.norm(np.cross(u, v))
+
+    def area(p, q, r):
+        return 0.5 * np.linalg.norm(np.cross(X[q] - X[p], X[r] - X[p]))
+    idx, coef, ar = [], [], []
+    for (a, b) in sorted(edges):
+        use = sorted(edges[(a, b)])
+        if len(use) != 2 or use[0][1] == use[1][1]:
+            continue
+        v2, v3 = use[0][1], use[1][1]
+        c01, c02, c03, c04 = cot(a, b, v2), cot(a, b, v3), cot(b, a, v2), cot(b, a, v3)
+        idx.append([a, b, v2, v3]); coef.append([c03 + c04, c01 + c02, -(c01 + c03), -(c02 + c04)]); ar.append(area(a, b, v2) + area(a, b, v3))
+    return (np.array(idx, dtype=np.int32).reshape(-1, 4), np.array(coef, dtype=np.float64).reshape(-1, 4), np.array(ar, dtype=np.float64))
+
+
 PIN_WEIGHT = np.sqrt(lame(10000000.0, 0.499)[2] * 2.0)  # src/SpringEnergyTerm.hpp:47-52
 
 
@@ -239,18 +270,98 @@ def recolor_touched(base_colors, Ah, dhits):
     return colors
 
 
+class BigExactSolve:
+    """A x = b TO ROUND-OFF for A = K (x) I3 at sizes where a sparse direct factorisation is out of reach for a test: at the 1 M-tet body
+    of bench.py (K: 183 844^2, 2.6 M non-zeros) scipy's SuperLU needs 12 minutes and 345 M non-zeros of fill with MMD(A^T+A), 20 minutes /
+    714 M with COLAMD (measured in the build container, round 5).  Stands for the reference's prefactored LDLT (src/LinearSolver.hpp:79-90)
+    like the SuperLU solve does at small sizes: preconditioned CG in numpy / scipy on the three axes at once, iterated until the TRUE
+    relative residual |b - K x| / |b| of every axis is <= rtol (default 1e-13), re-formed from scratch before it is trusted.
+    Nothing of the product is used: the preconditioner is geometric (coordinate boxes carrying {1, x, y, z}, dense coarse inverse,
+    three Chebyshev-Jacobi steps) and cannot change the solution, only the iteration count."""
+
+    def __init__(self, K, xyz, rtol=1e-13, max_iters=4000):
+        self.K = K.tocsr(); self.rtol, self.max_iters = rtol, max_iters
+        nv = K.shape[0]
+        self.dinv = 1.0 / K.diagonal()
+        X = np.asarray(xyz, dtype=np.float64).reshape(-1, 3)
+        lo, hi = X.min(axis=0), X.max(axis=0)
+        g = max(2, int(round((nv / 500.0) ** (1.0 / 3.0))))
+        ijk = np.minimum((np.floor((X - lo) / np.maximum(hi - lo, 1e-300) * g)).astype(np.int64), g - 1)
+        _, box = np.unique((ijk[:, 0] * g + ijk[:, 1]) * g + ijk[:, 2], return_inverse=True)
+        order = np.argsort(box, kind="stable"); cnt = np.bincount(box); start = np.concatenate([[0], np.cumsum(cnt)])
+        rows, cols, vals = [], [], []; nc = 0
+        for b in range(len(cnt)):
+            idx = order[start[b]:start[b + 1]]
+            Y = X[idx] - X[idx].mean(axis=0)
+            sc = max(np.abs(Y).max(), 1e-300)
+            F = np.column_stack([np.ones(len(idx)), Y / sc]) if len(idx) >= 16 else np.ones((len(idx), 1))
+            for j in range(F.shape[1]):
+                rows.append(idx); cols.append(np.full(len(idx), nc)); vals.append(F[:, j]); nc += 1
+        self.P = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nv, nc))
+        Kc = (self.P.T @ self.K @ self.P).toarray()
+        self.Kci = np.linalg.inv(Kc + 1e-12 * np.trace(Kc) / nc * np.eye(nc))
+        v = np.random.default_rng(1).standard_normal(nv)
+        lam = 2.0
+        for _ in range(30):
+            w = self.dinv * (self.K @ v); lam = np.linalg.norm(w) / np.linalg.norm(v); v = w / np.linalg.norm(w)
+        hi_l = 1.1 * lam; lo_l = hi_l / 30.0
+        self.th, self.de = 0.5 * (hi_l + lo_l), 0.5 * (hi_l - lo_l)
+        self.iterations = 0; self.solves = 0; self.worst_residual = 0.0
+
+    def _prec(self, R):
+        th, de, di = self.th, self.de, self.dinv[:, None]
+        y = di * R; al = 1.0 / th; z = al * y; res = R - al * (self.K @ y); p = y
+        for k in (1, 2):
+            be = (0.5 if k == 1 else 0.25) * (de * al) ** 2
+            al = 1.0 / (th - be / al); p = di * res + be * p
+            z = z + al * p
+            if k == 1:
+                res = res - al * (self.K @ p)
+        return z + self.P @ (self.Kci @ (self.P.T @ R))
+
+    def solve(self, b, x0=None):
+        B = np.ascontiguousarray(b, dtype=np.float64).reshape(-1, 3)
+        X = np.zeros_like(B) if x0 is None else np.array(x0, dtype=np.float64).reshape(-1, 3).copy()
+        bn = np.maximum(np.linalg.norm(B, axis=0), 1e-300 * max(1.0, np.abs(B).max()))
+        it = 0
+        while True:
+            R = B - self.K @ X                                   # true residual: start of a pass
+            rel = np.linalg.norm(R, axis=0) / bn
+            if rel.max() <= self.rtol or it >= self.max_iters:
+                break
+            U = self._prec(R); Pd = U.copy(); g = np.einsum("ij,ij->j", R, U)
+            for _ in range(300):                                  # one pass; the recursive residual is re-formed above
+                W = self.K @ Pd
+                a = g / np.maximum(np.einsum("ij,ij->j", Pd, W), 1e-300)
+                X += a * Pd; R -= a * W; it += 1
+                if (np.linalg.norm(R, axis=0) / bn).max() <= 0.5 * self.rtol or it >= self.max_iters:
+                    break
+                U = self._prec(R); g2 = np.einsum("ij,ij->j", R, U)
+                Pd = U + (g2 / np.maximum(g, 1e-300)) * Pd; g = g2
+        self.iterations += it; self.solves += 1; self.worst_residual = max(self.worst_residual, float(rel.max()))
+        if rel.max() > 10.0 * self.rtol:
+            raise RuntimeError("BigExactSolve: relative residual %.2e after %d iterations" % (rel.max(), it))
+        return X.reshape(-1)
+
+
 class OracleSolver:
     """Restatement of admm::Solver for tets / tris / pins / Floor / Sphere."""
 
     def __init__(self, x, masses, dt=1.0 / 24.0, gravity=-9.8, admm_iters=10, linsolver=0, constraint_w=-1.0,
                  tets=None, tris=None, pins=None, obstacles=(), mode=1, gs_colors=None,
                  gs_max_iters=30, gs_tol=1e-10, gs_omega=1.9, uzawa_max_iters=20, uzawa_tol=1e-10, big=False,
-                 dynamic=(), surface_inds=None):
+                 dynamic=(), surface_inds=None, exact="lu", bends=None, slides=None):
         """tets = dict(idx[n,4], verts(rest), kind[n], mu[n], la[n][, k[n]]); tris = dict(idx[n,3], verts, mu, la,
         limit_min, limit_max); pins = {vertex: xyz}; obstacles = [(kind, [4 params])];
         dynamic = [dict(offset, rest[n,3], tets[nt,4] local, faces[nf,3] local)] (TetMeshCollision, in
         add_dynamic_collider order); surface_inds = Solver::surface_inds (None / empty = every vertex);
-        masses [3*nv]; mode 0 = reference stop rule, 1 = tight minimiser."""
+        masses [3*nv]; mode 0 = reference stop rule, 1 = tight minimiser.
+        NOT IN THE REFERENCE (its README lists them as TODOs, README.md:23-28; "parity unpinned: no reference code"), restated from the
+        papers / the definitions in include/admm_hip.h: tets of kind 7 = stable Neo-Hookean (Smith et al. 2018; admm_oracle.c);
+        bends = dict(idx[n,4], coef[n,4], weight[n], stiffness[n]): bending hinges, D_i x = sum_k c_k x_k (3 rows), E(z) = stiffness/2
+        |z|^2 (Bergou et al. 2006), rows after the triangles; slides = {vertex: (point, unit normal)}: slide pins -- SpringPin terms
+        (linsolver 0 / 2) whose prox projects onto the plane, or the plane-constrained update inside the GS sweeps (linsolver 1); their
+        terms follow the ordinary pins."""
         self.x = np.ascontiguousarray(x, dtype=np.float64).ravel().copy()
         self.dof = self.x.size
         self.nv = self.dof // 3
@@ -320,13 +431,30 @@ class OracleSolver:
                     trip_r.append(row + 6 * np.arange(self.ntri) + 3 + i); trip_c.append(3 * idx[:, j] + i); trip_v.append(Dm[:, j, 1])
             weights.append(np.repeat(self.r_w, 6))
             row += 6 * self.ntri
-        # pins become SpringPin terms for LDLT / Uzawa (Solver.cpp:190-196)
+        self.nbend = 0
+        if bends is not None and len(bends["idx"]):
+            self.h_idx = np.ascontiguousarray(bends["idx"], dtype=np.int64).reshape(-1, 4)
+            self.h_coef = np.ascontiguousarray(bends["coef"], dtype=np.float64).reshape(-1, 4)
+            self.h_w = np.ascontiguousarray(bends["weight"], dtype=np.float64)
+            self.h_k = np.ascontiguousarray(bends["stiffness"], dtype=np.float64)
+            self.nbend = self.h_idx.shape[0]
+            for k in range(4):
+                for j in range(3):
+                    trip_r.append(row + 3 * np.arange(self.nbend) + j); trip_c.append(3 * self.h_idx[:, k] + j); trip_v.append(self.h_coef[:, k])
+            weights.append(np.repeat(self.h_w, 3))
+            self.h_row = row
+            row += 3 * self.nbend
+        # pins become SpringPin terms for LDLT / Uzawa (Solver.cpp:190-196); slide pins (not in the reference) follow them
         self.npin = 0
-        if linsolver in (0, 2) and self.pins:
-            self.p_vert = np.array(list(self.pins.keys()), dtype=np.int32)
-            self.p_xyz = np.ascontiguousarray(np.array(list(self.pins.values()), dtype=np.float64).reshape(-1, 3))
+        self.slides = {int(k): (np.asarray(v[0], dtype=np.float64), np.asarray(v[1], dtype=np.float64) / np.linalg.norm(v[1])) for k, v in (slides or {}).items()}
+        self.nslide = 0
+        if linsolver in (0, 2) and (self.pins or self.slides):
+            allv = list(self.pins.keys()) + list(self.slides.keys())
+            self.p_vert = np.array(allv, dtype=np.int32)
+            self.p_xyz = np.ascontiguousarray(np.array(list(self.pins.values()) + [v[0] for v in self.slides.values()], dtype=np.float64).reshape(-1, 3))
+            self.p_nrm = np.ascontiguousarray(np.array([np.zeros(3)] * len(self.pins) + [v[1] for v in self.slides.values()], dtype=np.float64).reshape(-1, 3))
             self.p_active = np.ones(len(self.p_vert), dtype=np.int32)
-            self.npin = len(self.p_vert)
+            self.npin = len(self.p_vert); self.nslide = len(self.slides)
             for j in range(3):
                 trip_r.append(row + 6 * np.arange(self.npin) + j); trip_c.append(3 * self.p_vert + j); trip_v.append(np.ones(self.npin))
             weights.append(np.full(6 * self.npin, PIN_WEIGHT))
@@ -346,8 +474,14 @@ class OracleSolver:
         self.constraint_w = 3.0 * wmax if linsolver == 1 else 1.0
         if constraint_w > 0:
             self.constraint_w = constraint_w
-        self._lu = None
-        if linsolver in (0, 2):
+        self._lu = None; self._big = None
+        if linsolver in (0, 2) and exact == "pcg":
+            # (exact = "pcg": the prefactored solve at sizes SuperLU cannot factor in test time -- BigExactSolve, to round-off)
+            K = self.A[0::3, :][:, 0::3].tocsr()
+            if not (np.array_equal(self.m[0::3], self.m[1::3]) and np.array_equal(self.m[0::3], self.m[2::3])):
+                raise RuntimeError("exact='pcg' needs per-vertex masses (A = K (x) I3)")
+            self._big = BigExactSolve(K, self.x)
+        elif linsolver in (0, 2):
             self._lu = spla.splu(self.A.tocsc())
         if linsolver == 1:
             Ah = self.A[0::3, :][:, 0::3].tocsr()
@@ -374,9 +508,28 @@ class OracleSolver:
             L.orc_local_tris(self.ntri, _i(self.r_idx), _p(self.r_rest), _p(self.r_lmin), _p(self.r_lmax), _p(curr_x), _p(zz), _p(uu))
             z[o:o + 6 * self.ntri] = zz; u[o:o + 6 * self.ntri] = uu
             o += 6 * self.ntri
+        if self.nbend:      # EnergyTerm::update (EnergyTerm.hpp:130-140) of a bending hinge: prox of E(z) = stiffness / 2 |z|^2
+            X = curr_x.reshape(-1, 3)
+            Dx = np.einsum("hk,hkj->hj", self.h_coef, X[self.h_idx])
+            uu = u[o:o + 3 * self.nbend].reshape(-1, 3)
+            q = Dx + uu
+            w2 = self.h_w * self.h_w
+            zz = q * (w2 / (self.h_k + w2))[:, None]
+            u[o:o + 3 * self.nbend] = (uu + Dx - zz).ravel(); z[o:o + 3 * self.nbend] = zz.ravel()
+            o += 3 * self.nbend
         if self.npin:
             zz = np.ascontiguousarray(z[o:o + 6 * self.npin]); uu = np.ascontiguousarray(u[o:o + 6 * self.npin])
+            uu_in = uu.copy()
             L.orc_local_pins(self.npin, _i(self.p_vert), _p(self.p_xyz), _i(self.p_active), _p(curr_x), _p(zz), _p(uu))
+            if self.nslide:     # slide pins: z = q - n (n . (q - p)), q = x_v + u (rows 0-2 of the term; 3-5 stay zero like a SpringPin's)
+                X = curr_x.reshape(-1, 3)
+                for i in range(self.npin - self.nslide, self.npin):
+                    if not self.p_active[i]:
+                        continue
+                    xv = X[self.p_vert[i]]; uo = uu_in[6 * i:6 * i + 3]; n = self.p_nrm[i]
+                    q = xv + uo
+                    zi = q - n * n.dot(q - self.p_xyz[i])
+                    zz[6 * i:6 * i + 3] = zi; uu[6 * i:6 * i + 3] = uo + xv - zi
             z[o:o + 6 * self.npin] = zz; u[o:o + 6 * self.npin] = uu
 
     # -- Collider::detect with passive objects (Collider.hpp:152-212); hits in vertex order
@@ -457,7 +610,9 @@ class OracleSolver:
         return Cm, c
 
     # -- global solvers
-    def solve_ldlt(self, b):
+    def solve_ldlt(self, b, x0=None):
+        if self._big is not None:
+            return self._big.solve(b, x0)         # (warm start: fewer iterations, the same solution to round-off)
         return self._lu.solve(b)
 
     def solve_uzawa(self, x, b, hits):
@@ -466,7 +621,7 @@ class OracleSolver:
         if self.y.shape[0] != Cm.shape[0]:
             self.y = np.zeros(Cm.shape[0])
         if Cm.nnz == 0:
-            return self._lu.solve(b), 1
+            return self.solve_ldlt(b, x), 1
         Ct = Cm.T.tocsr()
         x = self._lu.solve(b - Ct @ self.y)
         r = Cm @ x - c
@@ -502,6 +657,11 @@ class OracleSolver:
         pin_flag = np.zeros(self.nv, dtype=np.int32); pin_xyz = np.zeros((self.nv, 3))
         for k, p in self.pins.items():
             pin_flag[k] = 1; pin_xyz[k] = p
+        if self.slides:
+            self._gs_nrm = np.zeros((self.nv, 3))
+            for k, (p, n) in self.slides.items():
+                pin_flag[k] = 2; pin_xyz[k] = p; self._gs_nrm[k] = n
+            L.orc_gs_set_pin_normals(_p(self._gs_nrm))
         okind = np.array([o[0] for o in self.obstacles], dtype=np.int32)
         opar = np.ascontiguousarray(np.array([o[1] for o in self.obstacles], dtype=np.float64).reshape(-1, 4))
         x = np.ascontiguousarray(x).copy()
@@ -518,14 +678,14 @@ class OracleSolver:
             b2 = np.ascontiguousarray(b + Cm.T @ c)
             it = L.orc_gs_solve_full(self.nv, _i(np.ascontiguousarray(M.indptr, dtype=np.int32)),
                                      _i(np.ascontiguousarray(M.indices, dtype=np.int32)), _p(np.ascontiguousarray(M.data)), _p(b2), _p(x),
-                                     nc2, _i(cptr2), _i(order2), _i(pin_flag) if self.pins else None, _p(pin_xyz), len(self.obstacles),
+                                     nc2, _i(cptr2), _i(order2), _i(pin_flag) if (self.pins or self.slides) else None, _p(pin_xyz), len(self.obstacles),
                                      _i(okind) if len(okind) else None, _p(opar) if len(okind) else None,
                                      self.gs_omega, self.gs_max_iters, self.gs_tol)
             return x, it
         rp = np.ascontiguousarray(self.Ah.indptr, dtype=np.int32); ci = np.ascontiguousarray(self.Ah.indices, dtype=np.int32)
         va = np.ascontiguousarray(self.Ah.data)
         it = L.orc_gs_solve(self.nv, _i(rp), _i(ci), _p(va), _p(b), _p(x), nc, _i(cptr), _i(order),
-                            _i(pin_flag) if self.pins else None, _p(pin_xyz), len(self.obstacles),
+                            _i(pin_flag) if (self.pins or self.slides) else None, _p(pin_xyz), len(self.obstacles),
                             _i(okind) if len(okind) else None, _p(opar) if len(okind) else None,
                             self.gs_omega, self.gs_max_iters, self.gs_tol)
         return x, it
@@ -538,7 +698,7 @@ class OracleSolver:
             return self.solve_gs(x, b)
         if self.linsolver == 2:
             return self.solve_uzawa(x, b, self._hits)
-        return self.solve_ldlt(b), 1
+        return self.solve_ldlt(b, x), 1
 
     def step(self, trace=None):
         """Solver::step (Solver.cpp:35-110). trace: optional list receiving (z,u,b,x) per ADMM iteration."""

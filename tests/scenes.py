@@ -14,6 +14,8 @@ class Scene:
         self.tets = []   # (verts_rest, idx, lame, kind)
         self.tris = []   # (verts_rest, idx, lame)
         self.pins = {}
+        self.slides = {}     # vertex -> (point, normal): slide constraints
+        self.bends = []      # (verts_rest, tris, k_bend, offset): bending terms of a triangle mesh
         self.obstacles = []  # (kind, params)
         self.dynamic = []    # dict(offset, rest, tets, faces): TetMeshCollision per mesh
         self.surface_inds = []
@@ -50,8 +52,12 @@ class Scene:
             s.add_tets(verts, tets, lame, kind, vertex_offset=off)
         for verts, tris, lame, off in self.tris:
             s.add_tris(verts, tris, lame, vertex_offset=off)
+        for verts, tris, k_bend, off in self.bends:
+            s.add_bends(verts, tris, k_bend, vertex_offset=off)
         if self.pins:
             s.set_pins(list(self.pins.keys()), [self.pins[k] for k in self.pins])
+        if self.slides:
+            s.set_slide_pins(list(self.slides.keys()), [self.slides[k][0] for k in self.slides], [self.slides[k][1] for k in self.slides])
         for kind, par in self.obstacles:
             s.add_obstacle(Floor(par[0]) if kind == 0 else Sphere(par[:3], par[3]))
         for d in self.dynamic:
@@ -83,6 +89,14 @@ class Scene:
             lmin = np.concatenate([np.full(len(t[1]), t[2].limit_min) for t in self.tris])
             lmax = np.concatenate([np.full(len(t[1]), t[2].limit_max) for t in self.tris])
             tris = dict(idx=idx, verts=self.x, mu=mu, la=la, limit_min=lmin, limit_max=lmax)
+        bends = None
+        if self.bends:      # hinges by the oracle's own (numpy) restatement of the stencil
+            hs = [orc.bend_hinges(verts, tris) + (k_bend, off) for verts, tris, k_bend, off in self.bends]
+            stiff = np.concatenate([k_bend * 3.0 / h[2] for h in hs for k_bend in [h[3]]])
+            bends = dict(idx=np.concatenate([h[0] + h[4] for h in hs]), coef=np.concatenate([h[1] for h in hs]), weight=np.sqrt(stiff), stiffness=stiff)
+            kw = dict(kw, bends=bends)
+        if self.slides:
+            kw = dict(kw, slides=self.slides)
         st = self.settings
         return orc.OracleSolver(self.x, self.masses3(), dt=st["timestep_s"], gravity=st["gravity"],
                                 admm_iters=st["admm_iters"], linsolver=st["linsolver"], constraint_w=st["constraint_w"],

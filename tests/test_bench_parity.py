@@ -28,12 +28,44 @@ def _bench_scene(name, n=None):
     return bench.build_scene(bench.WORKLOADS[name], n)
 
 
-def test_blob1m_drift_25_frames_bench_tolerance_vs_tight_solve():
-    """The driver's workload with the driver's settings against the same path converged to 1e-12 with every pass verified, frame by
-    frame through the driver's whole run (warm-up 4 + timed 10 + statistics 10 frames, one more for good measure)."""
+def test_blob1m_two_frames_vs_oracle_exact_solves():
+    """Round-4 review, item 1(a): the parity chain closed AT THE HEADLINE SIZE.  Two whole frames (40 ADMM iterations) of the 1 012 608-tet
+    body: HIP at 1e-12 with every pass verified against the ORACLE -- its OpenMP local step (exact minimiser) and exact global solves.
+    The exact solve at this size is oracle.BigExactSolve (CPU conjugate gradients in numpy / scipy to a TRUE relative residual of 1e-13
+    per axis, re-formed from scratch; SuperLU needs a 12-minute factorisation and 345 M non-zeros of fill here -- measured -- and agrees
+    with it to 3e-10 of the bounding box on the 52 k-tet twin).  Together with test_blob1m_drift_* (bench settings vs this 1e-12 path
+    at every frame) the chain bench settings -> oracle holds at 1 M tets.  Bound: 1e-7 of the bounding box (measured ~1e-9)."""
     n = int(os.environ.get("ADMM_TEST_BIG_BLOB_N", "118"))
     sc, nt, nv = _bench_scene("blob1m_mix", n)
-    frames = int(os.environ.get("ADMM_TEST_DRIFT_FRAMES", "25"))
+    if n == 118:
+        assert nt == 1012608
+    os.environ["ADMM_HIP_OC_VERIFY"] = "1"
+    try:
+        s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=1500)
+    finally:
+        os.environ.pop("ADMM_HIP_OC_VERIFY", None)
+    o = sc.make_oracle(mode=1, big=True, exact="pcg")
+    errs = []
+    for f in range(2):
+        s.step(); o.step()
+        assert s.runtime_data().unconverged_solves == 0
+        errs.append(scenes.rel_err(s.m_x, o.x))
+    print("blob1m vs oracle (exact solves) rel_err per frame:", " ".join("%.2e" % e for e in errs),
+          " oracle CG: %d iterations in %d solves, worst true relative residual %.1e" % (o._big.iterations, o._big.solves, o._big.worst_residual))
+    assert o._big.worst_residual <= 1e-13
+    assert max(errs) < 1e-7, errs
+    assert np.abs(s.m_x - sc.x.ravel()).max() > 1e-4
+    s.close()
+
+
+def test_blob1m_drift_200_frames_bench_tolerance_vs_tight_solve():
+    """The driver's workload with the driver's settings against the same path converged to 1e-12 with every pass verified, frame by
+    frame -- through the driver's whole run (warm-up + timed + statistics frames) and far beyond it: 200 frames (round-4 review, item
+    1(b): "nobody knows the error at frame 300"; ADMM_TEST_DRIFT_FRAMES overrides).  The per-frame record goes to
+    gpurun_out/drift_blob1m_frames.txt (committed under profiles/ per round)."""
+    n = int(os.environ.get("ADMM_TEST_BIG_BLOB_N", "118"))
+    sc, nt, nv = _bench_scene("blob1m_mix", n)
+    frames = int(os.environ.get("ADMM_TEST_DRIFT_FRAMES", "200"))
     os.environ["ADMM_HIP_OC_VERIFY"] = "1"
     try:
         tight = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=1500)
@@ -46,7 +78,17 @@ def test_blob1m_drift_25_frames_bench_tolerance_vs_tight_solve():
         tight.step(); loose.step()
         assert tight.runtime_data().unconverged_solves == 0 and loose.runtime_data().unconverged_solves == 0, f
         errs.append(scenes.rel_err(loose.m_x, tight.m_x))
-    print("blob drift rel_err per frame:", " ".join("%.2e" % e for e in errs))
+    print("blob drift rel_err, %d frames at pcg_tol %g: max %.2e at frame %d; every 10th:" % (frames, bench.PCG_TOL, max(errs), int(np.argmax(errs))),
+          " ".join("%.2e" % e for e in errs[9::10]))
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "drift_blob1m_frames.txt"), "w") as fh:
+            fh.write("# blob1m_mix (%d tets), bench settings (pcg_tol %g, schedule %s) vs the same path at 1e-12 verified: rel_err per frame\n" %
+                     (nt, bench.PCG_TOL, os.environ.get("ADMM_HIP_TOL_SCHED", "-")))
+            fh.write("\n".join("%d %.3e" % (i, e) for i, e in enumerate(errs)) + "\n")
+    except OSError:
+        pass
     assert max(errs) < 1e-5, errs
     assert np.abs(tight.m_x - sc.x.ravel()).max() > 1e-3      # the body actually moves (it sways by ~0.3 % of its size)
     tight.close(); loose.close()
@@ -141,3 +183,33 @@ def test_cube100k_uzawa_floor_full_size_frozen_active_set(n, n_rows, monkeypatch
     assert st["schur_from_columns"] > 0 and st["schur_by_pcg"] == 0
     assert s.m_x.reshape(-1, 3)[:, 1].min() > -0.02 - 1e-6
     s.close()
+
+
+def test_contact_counters_cloth_and_cube():
+    """admm_hip_contact_totals (round-4 review, item 1(c): bench.py states `rows_projected_in_timed_region`): rows projected onto the
+    floor inside the GS sweeps -- counted by the persistent kernel (LDS counter, one atomic per block and solve) exactly like by the
+    colour kernels -- and rows of C over the UzawaCG solves."""
+    sc = scenes.cloth_scene(40, limits=(0.95, 1.05), floor=0.47, admm_iters=10, linsolver=1)
+    counts = []
+    for persist in ("1", "0"):
+        os.environ["ADMM_HIP_GS_PERSIST"] = persist
+        try:
+            s = sc.make_solver()
+        finally:
+            os.environ.pop("ADMM_HIP_GS_PERSIST")
+        assert s.contact_totals() == 0
+        per_frame = []
+        for f in range(6):
+            s.step(); per_frame.append(s.contact_totals())
+        assert per_frame[-1] > 0                       # the cloth dips into the raised floor within the first frames
+        counts.append(per_frame)
+        s.close()
+    assert counts[0] == counts[1], counts              # bit-identical sweeps: identical projection counts
+    scu = scenes.cube_scene(6, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=8, linsolver=2)
+    scu.pins.clear(); scu.obstacles.append((0, [-0.02, 0.0, 0.0, 0.0]))
+    su = scu.make_solver(pcg_tol=1e-10)
+    tot = 0
+    for f in range(8):
+        su.step()
+    assert su.contact_totals() >= 49                   # the bottom face (7 x 7 vertices) rests on the floor
+    su.close()

@@ -33,7 +33,7 @@ def test_mesh_layer_cpu(tmp_path):
 
 
 def test_samples_build_and_print_help():
-    for name in ("beams", "trianglestrain", "boxes", "bunnyexpand", "signorini", "torus"):
+    for name in ("beams", "trianglestrain", "boxes", "bunnyexpand", "signorini", "torus", "curtain"):
         exe = _sample(name)
         r = subprocess.run([exe, "-help"], capture_output=True, text=True, timeout=60)
         assert r.returncode == 0 and "-it" in (r.stdout + r.stderr)
@@ -184,3 +184,25 @@ def test_torus_sample_uzawa_floor_and_self_collision(tmp_path):
     assert np.isfinite(X).all()
     assert X[:, 1].min() > -1.0 - 2e-2 and X[:, 1].min() < -0.9        # resting on the floor
     assert X[:, 1].max() < 0.5                                          # fell from y ~ 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ls", [0, 1, 2])
+def test_curtain_sample_bending_slide_stable_nh(tmp_path, ls):
+    """samples/curtain.cpp: the three terms of the reference's README TODO list (README.md:23-28) through the C++ class API -- a cloth with
+    BendEnergyTerm hinges whose top edge hangs on a rail by slide constraints (free along the rail plane, never leaving its height), and a
+    StableNeoHookeanTet block that starts folded through its glued bottom face (every tet inverted) and unfolds."""
+    exe = _sample("curtain")
+    out = str(tmp_path / "curtain")
+    r = subprocess.run([exe, "-ls", str(ls), "-v", "0", "-it", "20", "--frames", "30", "--cells", "10", "--out", out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("curtain:")][-1]
+    assert " 280 hinges, 9 slide constraints" in line, line          # 3 m^2 - 2 m interior edges at m = 10; 11 top vertices minus the 2 pinned ends
+    off = float(line.split("off the rail plane by ")[1].split(",")[0]); slid = float(line.split("moved ")[1].split(" ")[0])
+    assert off < (1e-10 if ls == 1 else 5e-3) and slid > 1e-3, line
+    X = np.loadtxt(out + ".xyz")
+    assert np.isfinite(X).all()
+    sheet, block = X[:121], X[121:]
+    assert sheet[:, 1].min() < 0.3                                    # the free part of the curtain fell
+    ymin = block[:, 1].min()
+    assert block[:, 1].max() > ymin + 0.5                            # the block unfolded: its top is above its glued bottom face again
