@@ -20,6 +20,7 @@
 #include "host_setup.hpp"
 #include "kernels.hpp"
 #include "pcg_onchip2.hpp"
+#include "pcg_big.hpp"
 #include "gs_persist.hpp"
 #include "uz_persist.hpp"
 
@@ -224,6 +225,14 @@ struct admm_hip_ctx {
     // WindForce on the device (admm_hip_set_wind): triangles, their vertex incidence, per-triangle forces
     int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
     DevBuf<unsigned long long> gs_proj; long long uz_rows_total = 0;   // admm_hip_contact_totals: rows projected inside the GS sweeps (device), rows of C over all UzawaCG solves (host)
+    // launch-path two-level PCG (pcg_big.hpp): systems beyond the chip's LDS, and the fall-back of the on-chip kernel
+    bool big_enabled = false, big_tried = false; std::vector<double> xyz_h;
+    int big_G = 0, big_ra = 0, big_rows = 0, big_nc = 0, big_ncp = 0, big_NBt = 0;
+    SellDev big_A; DevBuf<int> big_orig; DevBuf<float> big_ainv;
+    DevBuf<double> big_mass, big_dinv, big_cwt, big_xi, big_r, big_u, big_w, big_p, big_s, big_part, big_cvec, big_rho;
+    long long big_solves = 0;
+    // end projection of every PCG solve on soft modes (admm_hip_set_soft_modes; kernels.hpp: k_defl_*)
+    int defl_k = 0; DevBuf<double> defl_Z, defl_Ginv, defl_part, defl_y;
     long long oc_launches = 0, gsp_launches = 0;   // persistent launches since create (admm_hip_persistent_launches)
     int test_abort_seq = 0;   // tests only (ADMM_HIP_TEST_ABORT_SOLVE=k): the k-th on-chip solve of the context finds its barrier aborted
     int test_abort_uzp = 0;   // tests only (ADMM_HIP_TEST_ABORT_SCHUR=k): the k-th persistent Schur launch finds its hand-off given up
@@ -329,6 +338,9 @@ struct admm_hip_ctx {
         gsp_hdr.release(); gsp_orig.release(); gsp_out.release(); gsp_hbox.release(); gsp_horig.release(); gsp_diag.release(); gsp_vals.release(); gsp_cols.release();
         obst_gmeta.release(); obst_gdata.release(); obst_dev.release();
         gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release(); gsp_prof.release(); gs_proj.release();
+        defl_Z.release(); defl_Ginv.release(); defl_part.release(); defl_y.release();
+        big_A.release(); big_orig.release(); big_ainv.release(); big_mass.release(); big_dinv.release(); big_cwt.release(); big_xi.release(); big_r.release();
+        big_u.release(); big_w.release(); big_p.release(); big_s.release(); big_part.release(); big_cvec.release(); big_rho.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -730,9 +742,80 @@ int launch_pcg_dist(admm_hip_ctx *c, const double *b, double *x, int max_iters) 
     return 0;
 }
 
+// Plan of the launch-path two-level PCG, made the first time a solve needs it (a body beyond the chip, or after the on-chip kernel was given up)
+bool ensure_big_plan(admm_hip_ctx *c) {
+    if (c->big_tried) return c->big_enabled;
+    c->big_tried = true;
+    { const char *e = getenv("ADMM_HIP_BIG"); if (e && e[0] == '0') return false; }      // A/B: the Jacobi PCG of rounds 1-4
+    std::vector<double> mass(c->n3);
+    if (hipMemcpy(mass.data(), c->m.p, mass.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    const char *ma = getenv("ADMM_HIP_BIG_AGGREGATES");
+    const admm_host::BigPlan P = admm_host::build_big_plan(c->Ahat, mass.data(), c->xyz_h.size() == (size_t)c->n3 ? c->xyz_h.data() : nullptr, ma ? std::max(1, atoi(ma)) : 1024);
+    if (!P.ok) return false;
+    auto ok = [](hipError_t e) { return e == hipSuccess; };
+    const size_t n3r = 3 * (size_t)P.n_rows;
+    if (!ok(c->big_A.upload(P.A)) || !ok(c->big_orig.upload(std::vector<int>(P.orig.begin(), P.orig.end()))) || !ok(c->big_ainv.upload(P.ainv)) ||
+        !ok(c->big_mass.upload(P.mass)) || !ok(c->big_dinv.upload(P.dinv)) || !ok(c->big_cwt.upload(P.cwt)) ||
+        !ok(c->big_xi.alloc(n3r)) || !ok(c->big_r.alloc(n3r)) || !ok(c->big_u.alloc(n3r)) || !ok(c->big_w.alloc(n3r)) || !ok(c->big_p.alloc(n3r)) || !ok(c->big_s.alloc(n3r)) ||
+        !ok(c->big_u.zero()) || !ok(c->big_w.zero()) || !ok(c->big_r.zero()) ||
+        !ok(c->big_part.alloc((size_t)6 * (P.n_rows / 256))) || !ok(c->big_cvec.alloc((size_t)3 * P.ncp)) || !ok(c->big_cvec.zero()) || !ok(c->big_rho.alloc((size_t)3 * P.G))) {
+        (void)hipGetLastError();
+        return false;
+    }
+    c->big_G = P.G; c->big_ra = P.ra; c->big_rows = P.n_rows; c->big_nc = P.nc; c->big_ncp = P.ncp; c->big_NBt = P.n_rows / 256;
+    c->big_enabled = true;
+    if (getenv("ADMM_HIP_OC_DIAG")) fprintf(stderr, "[big_plan] %d aggregates of %d rows, %d coarse unknowns (dense inverse %.1f MB), SELL %d slices\n", P.G, P.ra, P.nc, 4e-6 * (double)P.nc * P.ncp, P.A.n_slices);
+    return true;
+}
+
+// The launch-path two-level PCG (pcg_big.hpp): three launches per iteration, chunks of iterations one ahead of the GPU, the device
+// signals convergence through pinned host memory (as launch_pcg below).
+int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
+    hipStream_t st = c->stream;
+    BigArgs a{};
+    a.A = sell_arg(c->big_A); a.mass = c->big_mass.p; a.dinv = c->big_dinv.p; a.cwt = c->big_cwt.p; a.ainv = c->big_ainv.p; a.orig = c->big_orig.p;
+    a.n_rows = c->big_rows; a.NBt = c->big_NBt; a.G = c->big_G; a.ra = c->big_ra; a.nc = c->big_nc; a.ncp = c->big_ncp;
+    a.b_api = b; a.x_api = x; a.u_api = c->cg_u.p; a.dinv_api = c->dinv.p;
+    a.xi = c->big_xi.p; a.r = c->big_r.p; a.u = c->big_u.p; a.w = c->big_w.p; a.p = c->big_p.p; a.s = c->big_s.p;
+    a.part = c->big_part.p; a.cvec = c->big_cvec.p; a.rho = c->big_rho.p;
+    a.scal = c->cg_scal.p; a.counters = c->counters.p; a.sig = c->d_sig;
+    a.tol2 = c->pcg_tol * c->pcg_tol; a.seq = ++c->solve_seq;
+    a.row_lo = 0; a.row_hi = 0x7fffffff;
+    const int nbr = c->big_rows / 256;
+    hipLaunchKernelGGL(k_big_gather, dim3(nbr), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_big_resid, dim3(c->big_NBt), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1, 0);
+    hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(256), 0, st, a, -1);
+    volatile int *sig = c->h_sig;
+    int launched = 0, chunks = 0;
+    const int chunk = 16;
+    while (launched < max_iters) {
+        const int n = std::min(chunk, max_iters - launched);
+        for (int it = launched; it < launched + n; ++it) {
+            hipLaunchKernelGGL(k_big_spmv, dim3(c->big_NBt), dim3(256), 0, st, a, it);
+            hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, it, (it == launched + n - 1) ? 1 : 0);
+            hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(256), 0, st, a, it);
+        }
+        launched += n;
+        ++chunks;
+        ++c->marks_expected;
+        if (chunks >= 2 && launched < max_iters) {
+            const int need = c->marks_expected - 1;
+            long spins = 0;
+            while (sig[1] < need) { if (++spins > 2000000000L) return -1; }
+            if (sig[0] == a.seq) break;
+        }
+    }
+    hipLaunchKernelGGL(k_big_scatter, dim3(nbr), dim3(256), 0, st, a, launched & 1);
+    c->last_launched_iters = launched;
+    c->big_solves += 1;
+    return 0;
+}
+
 int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters, const int *skip = nullptr) {
     if (c->dist_solve) { const int r = launch_pcg_dist(c, b, x, max_iters); return r ? -1 : 0; }
     if (c->oc_enabled) { OcRc rc; rc.skip = skip; return launch_pcg_onchip(c, b, x, max_iters, rc); }
+    if (ensure_big_plan(c)) return launch_pcg_big(c, b, x, max_iters);
     hipStream_t st = c->stream;
     const SellA A = sell_arg(c->A);
     const int NB = c->NB;
@@ -769,8 +852,23 @@ int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters, const
     return 0;
 }
 
-// The ADMM global solve with the recycled (Galerkin) warm start around the PCG.
+// End projection of a finished solve on the soft modes (kernels.hpp: k_defl_*)
+void launch_deflation(admm_hip_ctx *c, const double *b, double *x) {
+    hipStream_t st = c->stream;
+    const int NB = c->NB, k = c->defl_k;
+    hipLaunchKernelGGL(k_defl_dots, dim3(NB), dim3(256), 0, st, sell_arg(c->A), c->m.p, b, x, k, c->defl_Z.p, c->nv, c->defl_part.p, NB);
+    hipLaunchKernelGGL(k_defl_solve, dim3(1), dim3(256), 0, st, k, c->defl_part.p, NB, c->defl_Ginv.p, c->defl_y.p);
+    hipLaunchKernelGGL(k_defl_apply, dim3(blocks_for(c->nv)), dim3(256), 0, st, c->nv, k, c->defl_Z.p, c->defl_y.p, x);
+}
+
+int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x);
+// The ADMM global solve with the recycled (Galerkin) warm start around the PCG (+ the end projection on the soft modes, when set).
 int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
+    const int rc = launch_pcg_recycled_impl(c, b, x);
+    if (rc == 0 && c->defl_k > 0) launch_deflation(c, b, x);
+    return rc;
+}
+int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x) {
     const int s = c->rc_iter;
     if (!c->rc_enabled) return launch_pcg(c, b, x, c->pcg_max_iters);
     hipStream_t st = c->stream;
@@ -1920,6 +2018,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
     HIP_TRY(c->counters.alloc(8 + 64 + 8)); HIP_TRY(c->counters.zero());   // [72..74]: totals since create (on-chip PCG)
     c->create_xyz = d->vert_xyz;
+    if (d->vert_xyz && d->linsolver != 1) c->xyz_h.assign(d->vert_xyz, d->vert_xyz + c->n3);      // (the launch-path two-level PCG plans lazily)
     {   // distributed solve of ONE body (ADMM_HIP_DIST_SOLVE=1, element-block partition): contiguous vertex rows per rank, 64-aligned
         const char *de = getenv("ADMM_HIP_DIST_SOLVE");
         const char *fc = getenv("ADMM_HIP_FORCE_COMM");     // (tests: a world of ONE with a communicator runs the same collectives through RCCL)
@@ -2764,7 +2863,7 @@ int admm_hip_solve_totals(admm_hip_ctx *c, int64_t *solves, int64_t *converged, 
     if (int rc = settle(c)) return rc;
     int h[3] = {0, 0, 0};
     HIP_TRY(hipMemcpy(h, c->counters.p + 72, sizeof(h), hipMemcpyDeviceToHost));
-    const bool counted = c->oc_enabled && c->oc_plan;     // only the general-mesh on-chip PCG keeps these totals
+    const bool counted = (c->oc_enabled && c->oc_plan) || c->big_enabled || (c->linsolver != 1 && !c->oc_enabled && !c->dist_solve && ensure_big_plan(c));     // the on-chip PCG and the launch-path two-level PCG keep these totals
     if (solves) *solves = counted ? h[0] : -1;
     if (converged) *converged = counted ? h[1] : -1;
     if (inner_iters) *inner_iters = counted ? h[2] : -1;
@@ -2813,6 +2912,59 @@ int admm_hip_get_solver_params(const admm_hip_ctx *c, int32_t kind, int32_t *max
     if (max_iters) *max_iters = it;
     if (tol) *tol = t;
     if (omega) *omega = o;
+    return ADMM_HIP_OK;
+}
+
+int admm_hip_set_soft_modes(admm_hip_ctx *c, int32_t k, const double *Z) {
+    if (!c || k < 0 || k > kDeflMax || (k > 0 && !Z)) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: bad input (at most 64 modes)");
+    if (c->linsolver == 1) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: this context runs no PCG");
+    if (c->cm.on || c->world > 1) return fail(ADMM_HIP_ERR_STATE, "set_soft_modes: single-GPU contexts only");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = settle(c)) return rc;
+    c->defl_k = 0;
+    if (k == 0) return ADMM_HIP_OK;
+    const int nv = c->nv;
+    std::vector<double> mass(c->n3);
+    HIP_TRY(hipMemcpy(mass.data(), c->m.p, mass.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int v = 0; v < nv; ++v)
+        if (mass[3 * (size_t)v] != mass[3 * (size_t)v + 1] || mass[3 * (size_t)v] != mass[3 * (size_t)v + 2]) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: needs per-vertex masses (A = K (x) I3)");
+    // exact pairs: K Z on the host, G = Z^T K Z, its inverse by Cholesky
+    std::vector<double> KZ((size_t)k * nv), G((size_t)k * k, 0.0);
+    for (int q = 0; q < k; ++q)
+        for (int v = 0; v < nv; ++v) {
+            double acc = mass[3 * (size_t)v] * Z[(size_t)q * nv + v];
+            for (int e = c->Ahat.rowptr[v]; e < c->Ahat.rowptr[v + 1]; ++e) acc += c->Ahat.val[e] * Z[(size_t)q * nv + c->Ahat.col[e]];
+            if (!std::isfinite(acc)) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: non-finite mode");
+            KZ[(size_t)q * nv + v] = acc;
+        }
+    for (int q = 0; q < k; ++q)
+        for (int p = 0; p <= q; ++p) {
+            double acc = 0.0;
+            for (int v = 0; v < nv; ++v) acc += Z[(size_t)q * nv + v] * KZ[(size_t)p * nv + v];
+            G[(size_t)q * k + p] = acc; G[(size_t)p * k + q] = acc;
+        }
+    {   // inverse of the SPD k x k matrix (Gauss-Jordan on the symmetric matrix, pivots checked)
+        std::vector<double> a(G), inv((size_t)k * k, 0.0);
+        for (int i = 0; i < k; ++i) inv[(size_t)i * k + i] = 1.0;
+        for (int i = 0; i < k; ++i) {
+            const double piv = a[(size_t)i * k + i];
+            if (!(piv > 1e-14 * G[(size_t)i * k + i]) || !(piv > 0.0)) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: the modes are linearly dependent");
+            for (int j = 0; j < k; ++j) { a[(size_t)i * k + j] /= piv; inv[(size_t)i * k + j] /= piv; }
+            for (int r = 0; r < k; ++r) {
+                if (r == i) continue;
+                const double f = a[(size_t)r * k + i];
+                if (f == 0.0) continue;
+                for (int j = 0; j < k; ++j) { a[(size_t)r * k + j] -= f * a[(size_t)i * k + j]; inv[(size_t)r * k + j] -= f * inv[(size_t)i * k + j]; }
+            }
+        }
+        G = inv;
+    }
+    c->defl_Z.release(); c->defl_Ginv.release(); c->defl_part.release(); c->defl_y.release();
+    HIP_TRY(c->defl_Z.upload(std::vector<double>(Z, Z + (size_t)k * nv)));
+    HIP_TRY(c->defl_Ginv.upload(G));
+    HIP_TRY(c->defl_part.alloc((size_t)3 * k * c->NB)); HIP_TRY(c->defl_y.alloc((size_t)3 * k));
+    c->defl_k = k;
     return ADMM_HIP_OK;
 }
 

@@ -134,6 +134,23 @@ struct OcPlan {
 // xyz (optional, [3 n]): smooth vertex coordinates for the affine coarse space
 OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_bytes, bool want_coarse, const double *xyz = nullptr);
 
+// Plan of the LAUNCH-PATH two-level PCG (oc_plan.cpp: build_big_plan; kernels: pcg_big.hpp) -- the global solve of bodies that do not fit
+// the chip's LDS (more than 262 144 vertices) and the fall-back of the on-chip kernel: the same preconditioner M^-1 = D^-1 + P (P^T A P)^-1 P^T
+// with the affine coarse space, in kernels that stream the matrix.  Internal row order: compact aggregates of `ra` rows (a multiple of 256,
+// dummy rows orig = -1), each carrying {1, x, y, z} energy-orthonormalised; A in that order as SELL-64 with global (internal) columns.
+struct BigPlan {
+    bool ok = false;
+    int G = 0, ra = 0;                  // aggregates, rows per aggregate
+    int32_t n_rows = 0;                 // G * ra
+    std::vector<int32_t> orig, pos;     // internal row -> vertex (-1 = dummy), vertex -> internal row
+    Sell A;                             // Ahat (with its diagonal) in internal order
+    std::vector<double> mass, dinv;     // [3 n_rows]
+    std::vector<double> cwt;            // [4 n_rows] row r of P
+    int nc = 0, ncp = 0;
+    std::vector<float> ainv;            // [nc][ncp] (P^T A P)^-1, single precision (applied to FP64 vectors, accumulated in FP64)
+};
+BigPlan build_big_plan(const Csr &A, const double *mass3, const double *xyz, int max_aggregates);
+
 // Plan of the PERSISTENT multi-colour Gauss-Seidel kernel (oc_plan.cpp: build_gs_plan; kernels: gs_persist.hpp).  The vertices are
 // split into G compact blocks (one per CU, the recursive bisection of the on-chip PCG); a block keeps its rows' matrix entries,
 // its part of x and the values of the rows of other blocks it references (its halo) in LDS for the whole solve, and a colour phase

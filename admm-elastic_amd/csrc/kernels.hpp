@@ -1140,6 +1140,67 @@ __global__ __launch_bounds__(256) void k_rc_apply(int n3, RcBasis B, const doubl
     x[i] = acc;
 }
 
+// ---- END PROJECTION ON SOFT MODES (round 5; admm_hip_set_soft_modes) ---------------------------------------------------------------
+// A residual-norm stop leaves the error of a PCG solve in the soft modes of the body (error = residual / eigenvalue), every solve of a
+// frame lags the same way and the lag accumulates in the velocity: the drift that set the bench tolerance (profiles/r04_drift_*).  With k
+// smooth global vectors Z (the lowest eigenvectors of K = M + Ahat, one scalar field for the three axes) the FINAL iterate of a solve is
+// corrected by the exact Galerkin step  x += Z (Z^T K Z)^-1 Z^T (b - A x)  (exact pairs (Z, K Z): exact whatever the accuracy of Z), which
+// removes the error in span(Z) A-orthogonally.  CPU prototype (experiments/end_deflation_proto.py, 52 k-tet twin, 25 frames): 32 modes cut
+// the position error 10-40x at every tolerance; a projection at the START of a solve does not (round 4).
+// k_defl_dots: r = b - A x and the partial sums of Z^T r per block; k_defl_solve: one block reduces them and applies (Z^T K Z)^-1;
+// k_defl_apply: x += Z y.
+constexpr int kDeflMax = 64;
+__global__ __launch_bounds__(256) void k_defl_dots(SellA A, const double *__restrict__ m, const double *__restrict__ b, const double *__restrict__ x,
+                                                   int k, const double *__restrict__ Z, int nv, double *__restrict__ part, int NB) {
+    __shared__ double lds[12];
+    const int lane = threadIdx.x & 63;
+    const int s = wave_slice();
+    double r[3] = {0.0, 0.0, 0.0};
+    int row = -1;
+    if (s < A.n_slices) {
+        row = s * 64 + lane;
+        double acc[3];
+        sell_row(A, s, lane, x, acc);
+        if (row < A.n_rows) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const size_t i = 3 * (size_t)row + j; r[j] = b[i] - fma(m[i], x[i], acc[j]); }
+        } else row = -1;
+    }
+    for (int q = 0; q < k; ++q) {
+        const double z = row >= 0 ? Z[(size_t)q * nv + row] : 0.0;
+        double t[3] = {z * r[0], z * r[1], z * r[2]};
+        block_sum<3>(t, lds);
+        if (threadIdx.x == 0) { part[(size_t)(3 * q) * NB + blockIdx.x] = t[0]; part[(size_t)(3 * q + 1) * NB + blockIdx.x] = t[1]; part[(size_t)(3 * q + 2) * NB + blockIdx.x] = t[2]; }
+    }
+}
+__global__ __launch_bounds__(256) void k_defl_solve(int k, const double *__restrict__ part, int NB, const double *__restrict__ Ginv, double *__restrict__ y) {
+    __shared__ double lds[12];
+    __shared__ double d[3 * kDeflMax];
+    for (int q = 0; q < 3 * k; ++q) {
+        double t[1] = {0.0};
+        for (int i = threadIdx.x; i < NB; i += 256) t[0] += part[(size_t)q * NB + i];
+        block_sum<1>(t, lds);
+        if (threadIdx.x == 0) d[q] = t[0];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 3 * k; o += 256) {      // y[q][axis] = sum_p Ginv[q][p] d[p][axis]
+        const int q = o / 3, ax = o % 3;
+        double acc = 0.0;
+        for (int pp = 0; pp < k; ++pp) acc = fma(Ginv[q * k + pp], d[3 * pp + ax], acc);
+        y[o] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_defl_apply(int nv, int k, const double *__restrict__ Z, const double *__restrict__ y, double *__restrict__ x) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv) return;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int q = 0; q < k; ++q) {
+        const double z = Z[(size_t)q * nv + v];
+        acc[0] = fma(z, y[3 * q], acc[0]); acc[1] = fma(z, y[3 * q + 1], acc[1]); acc[2] = fma(z, y[3 * q + 2], acc[2]);
+    }
+    x[3 * (size_t)v] += acc[0]; x[3 * (size_t)v + 1] += acc[1]; x[3 * (size_t)v + 2] += acc[2];
+}
+
 // after the solve: store the pair (e = x - xs, A e) in a ring slot.  A e = r0 - r_final exactly, and the PCG
 // carries r_final = u / dinv, so the pair is exact (up to round-off) even though the solve stopped at pcg_tol.
 __global__ __launch_bounds__(256) void k_rc_record(int n3, const double *__restrict__ x, const double *__restrict__ xs,

@@ -614,6 +614,169 @@ OcPlan build_oc_plan(const Csr &A, const double *mass3, int G, int spb, int lds_
 }
 
 
+// ---- plan of the launch-path two-level PCG (pcg_big.hpp) -------------------------------------------------------------------------
+BigPlan build_big_plan(const Csr &A, const double *mass3, const double *xyz, int max_aggregates) {
+    BigPlan P;
+    const int32_t nv = A.n;
+    for (int32_t v = 0; v < nv; ++v)
+        if (!(mass3[3 * (size_t)v] == mass3[3 * (size_t)v + 1] && mass3[3 * (size_t)v] == mass3[3 * (size_t)v + 2])) return P;   // one coarse operator for the three axes
+    // aggregates of ~768 rows (the block size the on-chip solver's coarse space was tuned on), more only to keep the dense coarse inverse
+    // at <= 4 max_aggregates unknowns
+    int ra = 768;
+    while ((nv + ra - 1) / ra > max_aggregates) ra += 256;
+    const int G = std::max(1, (nv + ra - 1) / ra);
+    P.G = G; P.ra = ra; P.n_rows = G * ra;
+    const Graph g = coupling_graph(A);
+    std::vector<int32_t> part_of(nv, 0), mark(nv, 0);
+    std::vector<char> seen(nv, 0);
+    int32_t next_id = 1;
+    {
+        std::vector<int32_t> sizes(G), members(nv);
+        for (int b = 0; b < G; ++b) sizes[b] = (int32_t)(((int64_t)nv * (b + 1)) / G - ((int64_t)nv * b) / G);
+        std::iota(members.begin(), members.end(), 0);
+        bisect(g, members, sizes.data(), G, 0, mark, next_id, seen, part_of);
+    }
+    std::vector<std::vector<int32_t> > blocks(G);
+    for (int32_t v = 0; v < nv; ++v) blocks[part_of[v]].push_back(v);
+    P.orig.assign(P.n_rows, -1); P.pos.assign(nv, -1);
+    for (int b = 0; b < G; ++b) {      // rows of an aggregate breadth-first: neighbouring lanes gather neighbouring entries
+        std::vector<int32_t> &mem = blocks[b];
+        if ((int)mem.size() > ra) return P;
+        if (mem.empty()) continue;
+        const int32_t idb = next_id++;
+        for (int32_t v : mem) mark[v] = idb;
+        std::vector<int32_t> bfs;
+        bfs_order(g, mem, mark, idb, mem[0], seen, bfs);
+        int32_t slot = b * ra;
+        for (int32_t v : bfs) { P.orig[slot] = v; P.pos[v] = slot; ++slot; }
+    }
+    // ---- A in the internal order (rows of dummy slots: empty) ----
+    {
+        Csr B; B.n = P.n_rows; B.rowptr.assign(P.n_rows + 1, 0);
+        std::vector<std::pair<int32_t, double> > row;
+        for (int32_t r = 0; r < P.n_rows; ++r) {
+            const int32_t v = P.orig[r];
+            if (v >= 0) {
+                row.clear();
+                for (int32_t k = A.rowptr[v]; k < A.rowptr[v + 1]; ++k) if (A.val[k] != 0.0 || A.col[k] == v) row.emplace_back(P.pos[A.col[k]], A.val[k]);
+                std::sort(row.begin(), row.end());
+                for (auto &e : row) { B.col.push_back(e.first); B.val.push_back(e.second); }
+            }
+            B.rowptr[r + 1] = (int32_t)B.col.size();
+        }
+        P.A = csr_to_sell(B);
+    }
+    P.mass.assign(3 * (size_t)P.n_rows, 1.0); P.dinv.assign(3 * (size_t)P.n_rows, 0.0);
+    for (int32_t r = 0; r < P.n_rows; ++r) {
+        const int32_t v = P.orig[r];
+        if (v < 0) continue;
+        double aii = 0.0;
+        for (int32_t k = A.rowptr[v]; k < A.rowptr[v + 1]; ++k) if (A.col[k] == v) aii += A.val[k];
+        for (int j = 0; j < 3; ++j) { P.mass[3 * (size_t)r + j] = mass3[3 * (size_t)v + j]; P.dinv[3 * (size_t)r + j] = 1.0 / (mass3[3 * (size_t)v + j] + aii); }
+    }
+    // ---- coarse space: {1, x, y, z} per aggregate (constants only without coordinates), energy-orthonormalised per aggregate (as in
+    //      build_oc_plan: the diagonal blocks of P^T A P become identities, the dense inverse stays well conditioned in single precision) ----
+    P.nc = 4 * G; P.ncp = (P.nc + 63) / 64 * 64;
+    P.cwt.assign(4 * (size_t)P.n_rows, 0.0);
+    for (int b = 0; b < G; ++b) {
+        const std::vector<int32_t> &mem = blocks[b];
+        if (mem.empty()) continue;
+        double c[3] = {0.0, 0.0, 0.0}, h[3] = {0.0, 0.0, 0.0}, hmax = 0.0;
+        if (xyz) {
+            for (int32_t v : mem) for (int k = 0; k < 3; ++k) c[k] += xyz[3 * (size_t)v + k];
+            for (int k = 0; k < 3; ++k) c[k] /= (double)mem.size();
+            for (int32_t v : mem) for (int k = 0; k < 3; ++k) h[k] = std::max(h[k], std::fabs(xyz[3 * (size_t)v + k] - c[k]));
+            for (int k = 0; k < 3; ++k) hmax = std::max(hmax, h[k]);
+        }
+        for (int32_t v : mem) {
+            double *wt = &P.cwt[4 * (size_t)P.pos[v]];
+            wt[0] = 1.0;
+            for (int k = 0; k < 3; ++k) wt[1 + k] = (xyz && mem.size() >= 4 && h[k] > 1e-6 * hmax && hmax > 0.0) ? (xyz[3 * (size_t)v + k] - c[k]) / h[k] : 0.0;
+        }
+    }
+    {
+        std::vector<double> Gb((size_t)G * 16, 0.0);
+        for (int32_t v = 0; v < nv; ++v) {
+            const double *wv = &P.cwt[4 * (size_t)P.pos[v]];
+            const int b = part_of[v];
+            bool diag_seen = false;
+            for (int32_t q = A.rowptr[v]; q < A.rowptr[v + 1]; ++q) {
+                const int32_t u = A.col[q];
+                if (part_of[u] != b) continue;
+                if (u == v) diag_seen = true;
+                const double a = A.val[q] + (u == v ? mass3[3 * (size_t)v] : 0.0);
+                const double *wu = &P.cwt[4 * (size_t)P.pos[u]];
+                for (int k = 0; k < 4; ++k) for (int l = 0; l < 4; ++l) Gb[(size_t)b * 16 + 4 * k + l] += wv[k] * a * wu[l];
+            }
+            if (!diag_seen) for (int k = 0; k < 4; ++k) for (int l = 0; l < 4; ++l) Gb[(size_t)b * 16 + 4 * k + l] += wv[k] * mass3[3 * (size_t)v] * wv[l];
+        }
+        for (int b = 0; b < G; ++b) {
+            double *gm = &Gb[(size_t)b * 16], L[16] = {0.0};
+            bool keep[4];
+            double dmax = 0.0;
+            for (int k = 0; k < 4; ++k) dmax = std::max(dmax, gm[5 * k]);
+            for (int j = 0; j < 4; ++j) {
+                double d = gm[5 * j];
+                for (int k = 0; k < j; ++k) if (keep[k]) d -= L[4 * j + k] * L[4 * j + k];
+                keep[j] = d > 1e-12 * dmax && dmax > 0.0;
+                if (!keep[j]) continue;
+                L[5 * j] = std::sqrt(d);
+                for (int i = j + 1; i < 4; ++i) {
+                    double sm = gm[4 * i + j];
+                    for (int k = 0; k < j; ++k) if (keep[k]) sm -= L[4 * i + k] * L[4 * j + k];
+                    L[4 * i + j] = sm / L[5 * j];
+                }
+            }
+            for (int32_t v : blocks[b]) {
+                double *wt = &P.cwt[4 * (size_t)P.pos[v]], y[4];
+                for (int j = 0; j < 4; ++j) {
+                    if (!keep[j]) { y[j] = 0.0; continue; }
+                    double sm = wt[j];
+                    for (int k = 0; k < j; ++k) if (keep[k]) sm -= L[4 * j + k] * y[k];
+                    y[j] = sm / L[5 * j];
+                }
+                for (int j = 0; j < 4; ++j) wt[j] = y[j];
+            }
+        }
+    }
+    {
+        const int nc = P.nc;
+        std::vector<double> Ac((size_t)nc * nc, 0.0);
+        std::vector<char> has_diag(nv, 0);
+        for (int32_t v = 0; v < nv; ++v) {
+            const double *wv = &P.cwt[4 * (size_t)P.pos[v]];
+            const int bv = part_of[v] * 4;
+            for (int32_t q = A.rowptr[v]; q < A.rowptr[v + 1]; ++q) {
+                const int32_t u = A.col[q];
+                if (u == v) has_diag[v] = 1;
+                const double a = A.val[q] + (u == v ? mass3[3 * (size_t)v] : 0.0);
+                if (a == 0.0) continue;
+                const double *wu = &P.cwt[4 * (size_t)P.pos[u]];
+                const int bu = part_of[u] * 4;
+                for (int k = 0; k < 4; ++k) {
+                    if (wv[k] == 0.0) continue;
+                    double *row = &Ac[(size_t)(bv + k) * nc + bu];
+                    for (int l = 0; l < 4; ++l) row[l] += wv[k] * a * wu[l];
+                }
+            }
+        }
+        for (int32_t v = 0; v < nv; ++v)
+            if (!has_diag[v]) {
+                const double *wv = &P.cwt[4 * (size_t)P.pos[v]];
+                const int bv = part_of[v] * 4;
+                for (int k = 0; k < 4; ++k) for (int l = 0; l < 4; ++l) Ac[(size_t)(bv + k) * nc + bv + l] += wv[k] * mass3[3 * (size_t)v] * wv[l];
+            }
+        for (int c = 0; c < nc; ++c) if (Ac[(size_t)c * nc + c] == 0.0) Ac[(size_t)c * nc + c] = 1.0;
+        for (int i = 0; i < nc; ++i)
+            for (int j = 0; j < i; ++j) { const double sm = 0.5 * (Ac[(size_t)i * nc + j] + Ac[(size_t)j * nc + i]); Ac[(size_t)i * nc + j] = sm; Ac[(size_t)j * nc + i] = sm; }
+        if (!spd_inverse(nc, Ac)) return P;
+        P.ainv.assign((size_t)nc * P.ncp, 0.0f);
+        for (int i = 0; i < nc; ++i) for (int j = 0; j < nc; ++j) P.ainv[(size_t)i * P.ncp + j] = (float)Ac[(size_t)i * nc + j];
+    }
+    P.ok = true;
+    return P;
+}
+
 // ---- plan of the persistent multi-colour GS kernel (host_setup.hpp: GsPlan) -------------------------------------------------------
 GsPlan build_gs_plan(const Csr &A, int n_colors, const int32_t *color, int max_blocks, int rows_target, int lds_limit) {
     GsPlan P;

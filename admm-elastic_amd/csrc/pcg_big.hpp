@@ -1,0 +1,277 @@
+// pcg_big.hpp -- the LAUNCH-PATH two-level PCG: the global solve (src/LinearSolver.hpp:87-90, the prefactored LDLT the north-star replaces
+// by a GPU sparse solve) of systems that do not fit the chip's LDS -- more than 262 144 vertices, where k_pcg2 (pcg_onchip2.hpp) cannot hold
+// matrix and vectors on chip -- and the fall-back of k_pcg2 after a barrier time-out.  Rounds 1-4 served those systems with Jacobi-PCG
+// (k_cg_*: 7x the iterations); this is the SAME preconditioner as the on-chip solver's,
+//     M^-1 = D^-1 + P (P^T A P)^-1 P^T,   P = {1, x, y, z} per compact aggregate of ~768 vertices, energy-orthonormalised (oc_plan.cpp: build_big_plan),
+// in kernels that stream the matrix (SELL-64, internal row order = aggregate by aggregate) -- bound by HBM / L2 bandwidth, three launches
+// per iteration:
+//     k_big_spmv   w = A u, partial sums of gamma = r.u and delta = u.w per thread block                      (12 B per non-zero + 72 B per row)
+//     k_big_vec    alpha, beta from the partials (every block re-reduces them: fixed order, no atomics); p = u + beta p, s = w + beta s,
+//                  x += alpha p, r -= alpha s; c = P^T r and rho = r.D^-1 r of the block's aggregate         (10 vector passes: 240 B per row)
+//     k_big_coarse y = (P^T A P)^-1 c (the aggregate's four rows of the dense single-precision inverse, accumulated in FP64); stop test on
+//                  rho (the Jacobi-scaled residual norm, the documented meaning of pcg_tol); u = D^-1 r + P y   (4 nc floats + 24 nc B per block)
+// Conjugate gradients in the Chronopoulos-Gear form (one reduction point per iteration), the three axes as three systems sharing Ahat
+// (own alpha / beta per axis), like k_cg_*.  Vectors live in the internal order; b is gathered and x scattered through `orig` once per
+// solve.  Deterministic: every sum has a fixed order.
+#pragma once
+#include "kernels.hpp"
+
+namespace admm_k {
+
+struct BigArgs {
+    SellA A;                                      // Ahat, internal order, global (internal) columns
+    const double *mass, *dinv, *cwt; const float *ainv;
+    const int *orig;
+    int n_rows, NBt, G, ra, nc, ncp;
+    const double *b_api; double *x_api, *u_api;   // API order: right-hand side, solution (in/out), M_jacobi^-1 r_final for the recycled pairs
+    const double *dinv_api;
+    double *xi, *r, *u, *w, *p, *s;               // internal order [3 n_rows]
+    double *part;                                 // [6][NBt]: gamma / delta partials of k_big_spmv; [3][NBt] of the entry residual's b.D^-1 b
+    double *cvec;                                 // [3][ncp]: c = P^T r
+    double *rho;                                  // [3][G]: r.D^-1 r per aggregate
+    CgScal *scal;                                 // two slots, alternating by iteration parity
+    int *counters; int *sig;
+    double tol2; int seq;
+    int row_lo, row_hi;                           // distributed solve: the internal rows this rank owns (aggregate-aligned)
+};
+
+constexpr int kBigVecT = 1024;
+template <int NQ>
+__device__ __forceinline__ void block_sum_big(double *q, double *lds /* [16 NQ] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const double s = wave_sum(q[i]);
+        if (lane == 0) lds[wv * NQ + i] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { double s = 0.0; for (int k = 0; k < nw; ++k) s += lds[k * NQ + i]; q[i] = s; }
+    __syncthreads();
+}
+
+// x, b into the internal order; p = s = 0
+__global__ __launch_bounds__(256) void k_big_gather(BigArgs a) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.n_rows) return;
+    const int v = a.orig[row];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const size_t i = 3 * (size_t)row + j;
+        a.xi[i] = v >= 0 ? a.x_api[3 * (size_t)v + j] : 0.0;
+        a.p[i] = 0.0; a.s[i] = 0.0;
+    }
+}
+
+// r = b - A x (b gathered through orig), partial sums of b.D^-1 b
+__global__ __launch_bounds__(256) void k_big_resid(BigArgs a) {
+    __shared__ double lds[12];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal[0].converged = 0; a.scal[0].iters = 0; a.scal[0].seq = a.seq; a.scal[0].pad_ = 0; }
+    const int lane = threadIdx.x & 63;
+    const int s = wave_slice();
+    double q[3] = {0.0, 0.0, 0.0};
+    if (s < a.A.n_slices) {
+        const int row = s * 64 + lane;
+        const bool own = row >= a.row_lo && row < a.row_hi;
+        double acc[3] = {0.0, 0.0, 0.0};
+        if (__any(own)) sell_row(a.A, s, lane, a.xi, acc);
+        const int v = row < a.n_rows ? a.orig[row] : -1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const size_t i = 3 * (size_t)row + j;
+            if (row < a.n_rows) {
+                const double bi = (v >= 0 && own) ? a.b_api[3 * (size_t)v + j] : 0.0;
+                a.r[i] = (v >= 0 && own) ? bi - fma(a.mass[i], a.xi[i], acc[j]) : 0.0;
+                q[j] = fma(bi * a.dinv[i], bi, q[j]);
+            }
+        }
+    }
+    block_sum<3>(q, lds);
+    if (threadIdx.x == 0) { a.part[blockIdx.x] = q[0]; a.part[a.NBt + blockIdx.x] = q[1]; a.part[2 * a.NBt + blockIdx.x] = q[2]; }
+}
+
+// w = A u ; partials gamma = r.u, delta = u.w
+__global__ __launch_bounds__(256) void k_big_spmv(BigArgs a, int it) {
+    __shared__ double lds[24];
+    if (a.scal[it & 1].converged) return;
+    const int lane = threadIdx.x & 63;
+    const int s = wave_slice();
+    double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (s < a.A.n_slices) {
+        const int row = s * 64 + lane;
+        const bool own = row >= a.row_lo && row < a.row_hi;
+        if (__any(own)) {
+            double acc[3];
+            sell_row(a.A, s, lane, a.u, acc);
+            if (row < a.n_rows && own) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const size_t i = 3 * (size_t)row + j;
+                    const double ui = a.u[i], wi = fma(a.mass[i], ui, acc[j]);
+                    a.w[i] = wi;
+                    q[j] = fma(a.r[i], ui, q[j]);
+                    q[3 + j] = fma(wi, ui, q[3 + j]);
+                }
+            }
+        }
+    }
+    block_sum<6>(q, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.part[i * a.NBt + blockIdx.x] = q[i];
+    }
+}
+
+// it < 0: the entry pass (no update: c = P^T r, rho, and gamma_b = b.D^-1 b from the entry residual's partials).
+// it >= 0: alpha / beta, the vector updates, then c and rho.  One block = one aggregate.
+__global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mark_here) {
+    __shared__ double lds[16 * 15];
+    const bool entry = it < 0;
+    const CgScal pv = a.scal[entry ? 0 : (it & 1)];
+    CgScal *next = a.scal + (entry ? 0 : ((it + 1) & 1));
+    if (mark_here && blockIdx.x == 0 && threadIdx.x == 0) {      // progress mark for the host: the chunk this kernel closes has (almost) drained
+        const int m = atomicAdd(a.counters + 5, 1) + 1;
+        __hip_atomic_store(a.sig + 1, m, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (!entry && pv.converged) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *next = pv;
+        return;
+    }
+    const int g = (int)blockIdx.x;
+    double alpha[3] = {0.0, 0.0, 0.0}, beta[3] = {0.0, 0.0, 0.0};
+    {   // every block reduces the same partials in the same order: identical scalars everywhere
+        double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        const int nq = entry ? 3 : 6;
+        for (int i = threadIdx.x; i < a.NBt; i += kBigVecT)
+            for (int kk = 0; kk < nq; ++kk) q[kk] += a.part[kk * a.NBt + i];
+        block_sum_big<6>(q, lds);
+        if (entry) {
+            if (g == 0 && threadIdx.x == 0) {
+                CgScal o = pv;
+                for (int j = 0; j < 3; ++j) { o.gamma_b[j] = q[j]; o.gamma[j] = 0.0; o.alpha[j] = 0.0; }
+                o.converged = 0; o.iters = 0; o.seq = a.seq;
+                *next = o;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double gm = q[j], d = q[3 + j];
+                if (it == 0) { beta[j] = 0.0; alpha[j] = (d > 0.0) ? gm / d : 0.0; }
+                else {
+                    beta[j] = (pv.gamma[j] > 0.0) ? gm / pv.gamma[j] : 0.0;
+                    const double den = (pv.alpha[j] != 0.0) ? d - beta[j] * gm / pv.alpha[j] : d;
+                    alpha[j] = (den > 0.0) ? gm / den : 0.0;
+                }
+            }
+            if (g == 0 && threadIdx.x == 0) {
+                CgScal o = pv;
+                for (int j = 0; j < 3; ++j) { o.gamma[j] = q[j]; o.alpha[j] = alpha[j]; }
+                o.converged = 0; o.iters = pv.iters + 1;
+                *next = o;
+                atomicAdd(a.counters, 1);
+            }
+        }
+    }
+    double q[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) q[i] = 0.0;
+    const int r0 = g * a.ra;
+    if (r0 >= a.row_lo && r0 < a.row_hi) {
+        for (int row = r0 + (int)threadIdx.x; row < r0 + a.ra; row += kBigVecT) {
+            const size_t i0 = 3 * (size_t)row;
+            double rr[3];
+            if (entry) { rr[0] = a.r[i0]; rr[1] = a.r[i0 + 1]; rr[2] = a.r[i0 + 2]; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double pi = fma(beta[j], a.p[i0 + j], a.u[i0 + j]);
+                    const double si = fma(beta[j], a.s[i0 + j], a.w[i0 + j]);
+                    a.p[i0 + j] = pi; a.s[i0 + j] = si;
+                    a.xi[i0 + j] = fma(alpha[j], pi, a.xi[i0 + j]);
+                    rr[j] = fma(-alpha[j], si, a.r[i0 + j]);
+                    a.r[i0 + j] = rr[j];
+                }
+            }
+            const double c0 = a.cwt[4 * (size_t)row], c1 = a.cwt[4 * (size_t)row + 1], c2 = a.cwt[4 * (size_t)row + 2], c3 = a.cwt[4 * (size_t)row + 3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                q[j] = fma(c0, rr[j], q[j]); q[3 + j] = fma(c1, rr[j], q[3 + j]); q[6 + j] = fma(c2, rr[j], q[6 + j]); q[9 + j] = fma(c3, rr[j], q[9 + j]);
+                q[12 + j] = fma(rr[j] * a.dinv[i0 + j], rr[j], q[12 + j]);
+            }
+        }
+    }
+    block_sum_big<15>(q, lds);
+    if (threadIdx.x < 12) a.cvec[(threadIdx.x % 3) * a.ncp + 4 * g + threadIdx.x / 3] = q[threadIdx.x];      // c[axis][4 g + k] = q[3 k + axis]
+    else if (threadIdx.x < 15) a.rho[(threadIdx.x - 12) * a.G + g] = q[threadIdx.x];
+}
+
+// y_g = rows 4 g .. 4 g + 3 of (P^T A P)^-1 times c; the stop test; u = D^-1 r + P y on the aggregate's rows
+__global__ __launch_bounds__(256) void k_big_coarse(BigArgs a, int it) {
+    __shared__ double lds[60];
+    CgScal *cur = a.scal + ((it + 1) & 1);        // the slot k_big_vec (it) wrote (entry pass: it = -1 -> slot 0)
+    if (cur->converged) return;
+    const int g = (int)blockIdx.x;
+    double q[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) q[i] = 0.0;
+    for (int j = threadIdx.x; j < a.nc; j += 256) {
+        const double c0 = a.cvec[j], c1 = a.cvec[a.ncp + j], c2 = a.cvec[2 * a.ncp + j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double m = (double)a.ainv[(size_t)(4 * g + k) * a.ncp + j];
+            q[3 * k] = fma(m, c0, q[3 * k]); q[3 * k + 1] = fma(m, c1, q[3 * k + 1]); q[3 * k + 2] = fma(m, c2, q[3 * k + 2]);
+        }
+    }
+    for (int j = threadIdx.x; j < a.G; j += 256) { q[12] += a.rho[j]; q[13] += a.rho[a.G + j]; q[14] += a.rho[2 * a.G + j]; }
+    block_sum<15>(q, lds);
+    const CgScal sc = *cur;
+    bool conv = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) conv = conv && (q[12 + j] <= a.tol2 * sc.gamma_b[j] + 1e-300);
+    __syncthreads();      // (everybody has read *cur before block 0 changes it)
+    if (conv) {
+        if (g == 0 && threadIdx.x == 0) {
+            cur->converged = 1;
+            atomicAdd(a.counters + 4, 1);
+            atomicMax(a.counters + 3, sc.iters);
+            a.counters[8 + (sc.seq & 63)] = sc.iters;
+            atomicAdd(a.counters + 73, 1);      // converged solves since create (admm_hip_solve_totals; solves and iterations: k_big_scatter)
+            __hip_atomic_store(a.sig, sc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    const int r0 = g * a.ra;
+    if (r0 < a.row_lo || r0 >= a.row_hi) return;
+    for (int row = r0 + (int)threadIdx.x; row < r0 + a.ra; row += 256) {
+        const size_t i0 = 3 * (size_t)row;
+        const double c0 = a.cwt[4 * (size_t)row], c1 = a.cwt[4 * (size_t)row + 1], c2 = a.cwt[4 * (size_t)row + 2], c3 = a.cwt[4 * (size_t)row + 3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            a.u[i0 + j] = fma(a.dinv[i0 + j], a.r[i0 + j], fma(c0, q[j], fma(c1, q[3 + j], fma(c2, q[6 + j], c3 * q[9 + j]))));
+    }
+}
+
+// x back to the API order; u_api = D^-1 r_final (what k_rc_record expects of the Jacobi path: r = u / dinv)
+__global__ __launch_bounds__(256) void k_big_scatter(BigArgs a, int final_slot) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // totals since create; a solve that ran out of iterations is logged here (a converged one: k_big_coarse)
+        const CgScal sc = a.scal[final_slot];
+        atomicAdd(a.counters + 72, 1); atomicAdd(a.counters + 74, sc.iters);
+        if (!sc.converged) { atomicMax(a.counters + 3, sc.iters); a.counters[8 + (sc.seq & 63)] = sc.iters; }
+    }
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.n_rows) return;
+    const int v = a.orig[row];
+    if (v < 0) return;
+    if (row < a.row_lo || row >= a.row_hi) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { a.x_api[3 * (size_t)v + j] = 0.0; if (a.u_api) a.u_api[3 * (size_t)v + j] = 0.0; }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        a.x_api[3 * (size_t)v + j] = a.xi[3 * (size_t)row + j];
+        if (a.u_api) a.u_api[3 * (size_t)v + j] = a.dinv_api[3 * (size_t)v + j] * a.r[3 * (size_t)row + j];
+    }
+}
+
+} // namespace admm_k

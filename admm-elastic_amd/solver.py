@@ -564,6 +564,37 @@ class Solver:
         check(lib().admm_hip_get_solver_params(self._ctx, int(kind), C.byref(it), C.byref(t), C.byref(o)))
         return it.value, t.value, o.value
 
+    def set_soft_modes(self, Z):
+        """admm_hip_set_soft_modes: Z [k, n_verts] (or None): every PCG solve ends with the exact Galerkin projection of its residual on them."""
+        self._need_ctx()
+        if Z is None or len(Z) == 0:
+            check(lib().admm_hip_set_soft_modes(self._ctx, 0, None)); return
+        Zc = f64(Z).reshape(len(Z), -1)
+        check(lib().admm_hip_set_soft_modes(self._ctx, Zc.shape[0], dptr(Zc)))
+
+    def soft_modes(self, k, iters=8, seed=0):
+        """The k lowest eigenvectors of K = diag(m) + Ahat by inverse subspace iteration on the context's own solver (three right-hand sides
+        per global solve) with Rayleigh-Ritz steps on the host; returns (eigenvalues, Z [k, n_verts])."""
+        import scipy.sparse as sp
+        self._need_ctx()
+        rp, ci, va = self.system_matrix()
+        nv = self.m_x.size // 3
+        K = (sp.csr_matrix((va, ci, rp), shape=(nv, nv)) + sp.diags(f64(self.m_masses)[0::3])).tocsr()
+        k3 = 3 * ((k + 2) // 3)
+        X = np.random.default_rng(seed).standard_normal((nv, k3))
+        ew = np.zeros(k3)
+        for it in range(iters):
+            X, _ = np.linalg.qr(X)
+            Y = np.empty_like(X)
+            for c0 in range(0, k3, 3):
+                y, _ = self.global_solve(np.ascontiguousarray(X[:, c0:c0 + 3]).ravel(), np.zeros(3 * nv))
+                Y[:, c0:c0 + 3] = y.reshape(-1, 3)
+            Q, _ = np.linalg.qr(Y)
+            H = Q.T @ (K @ Q)
+            ew, V = np.linalg.eigh(0.5 * (H + H.T))
+            X = Q @ V
+        return ew[:k], np.ascontiguousarray(X[:, :k].T)
+
     def contact_totals(self):
         """admm_hip_contact_totals: rows of C over all UzawaCG solves / rows projected onto an obstacle over all GS sweeps, since initialize."""
         self._need_ctx()

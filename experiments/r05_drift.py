@@ -20,6 +20,9 @@ sc, nt, nv = bench.build_scene(bench.WORKLOADS[wl], n if wl.startswith("blob") e
 print("%s n=%d: %d tets %d verts, %d frames" % (wl, n, nt, nv, frames), flush=True)
 
 
+MODES = None
+
+
 def run(tol, mx, verify, env=None, ref=None):
     for k, v in (env or {}).items():
         os.environ[k] = v
@@ -32,6 +35,12 @@ def run(tol, mx, verify, env=None, ref=None):
             os.environ.pop(k, None)
     xs, errs = [], []
     t_frames = 0.0
+    k_soft = int((env or {}).get("SOFT", "0"))       # pseudo-switch of this script: end projection of every solve on the k lowest modes
+    if k_soft:
+        global MODES
+        if MODES is None or MODES[1].shape[0] < k_soft:
+            t0 = time.time(); MODES = s.soft_modes(max(k_soft, int(os.environ.get("ADMM_DRIFT_MODES_MAX", "64")))); print("soft modes: lowest eigenvalues %s ... %.3g (%.0f s)" % (" ".join("%.3g" % e for e in MODES[0][:6]), MODES[0][-1], time.time() - t0), flush=True)
+        s.set_soft_modes(MODES[1][:k_soft])
     s.upload()
     for f in range(frames):
         s.step_device(stats=True)

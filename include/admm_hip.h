@@ -292,6 +292,13 @@ int admm_hip_solve_totals(admm_hip_ctx *ctx, int64_t *solves, int64_t *converged
 int admm_hip_set_solver_params(admm_hip_ctx *ctx, int32_t kind, int32_t max_iters, double tol, double omega);
 int admm_hip_get_solver_params(const admm_hip_ctx *ctx, int32_t kind, int32_t *max_iters, double *tol, double *omega);
 
+/* End projection of every PCG solve on SOFT MODES (linsolver 0 / 2; no reference counterpart -- the reference solves exactly).  Z [k][n_verts]:
+ * k <= 64 smooth scalar fields, normally the lowest eigenvectors of K = diag(m) + Ahat (one field serves the three axes).  After every solve
+ * of the ADMM loop the iterate is corrected by the exact Galerkin step x += Z (Z^T K Z)^-1 Z^T (b - A x), which removes the error a
+ * residual-norm stop leaves in span(Z) -- the soft modes in which the error of an inexact solve is largest and accumulates from frame to
+ * frame.  The result of a converged solve changes only within the solver's tolerance.  k = 0 removes the modes. */
+int admm_hip_set_soft_modes(admm_hip_ctx *ctx, int32_t k, const double *Z);
+
 /* Contact work since admm_hip_create (measurement: that a timed region really exercised the collision path).  linsolver 2: rows of C
  * (ConstraintSet::make_matrix, src/ConstraintSet.hpp:59-116) summed over all UzawaCG solves; linsolver 1: node updates replaced by the
  * plane-constrained update of src/NodalMultiColorGS.hpp:218-262 (a row projected onto a passive obstacle), summed over all sweeps

@@ -33,7 +33,9 @@ int main() {
         Solver solver;
         solver.add_nodes(verts.data(), m.data(), nv);
         create_tets_from_mesh<double, NeoHookeanTet>(solver.energyterms, verts.data(), tets.data(), nt, Lame::soft_rubber(), 0);
-        solver.add_obstacle(std::make_shared<Floor>(0.0));
+        std::vector<int> pins;      // a cantilever (x = 0 face pinned): the sweeps never meet 1e-10, every solve runs max_iters of them
+        for (int j = 0; j <= n; ++j) for (int k = 0; k <= n; ++k) pins.push_back(vid(0, j, k));
+        solver.set_pins(pins);
         Solver::Settings st; st.verbose = 0; st.admm_iters = 8; st.linsolver = 1;
         if (!solver.initialize(st)) return 2;
         solver.step();

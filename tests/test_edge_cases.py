@@ -137,7 +137,7 @@ def test_barrier_timeout_falls_back_and_replays(monkeypatch):
     # after the abort the context must not go back to the persistent kernel -- neither in the replay nor later (the
     # frame-history branch of the recycled start used to launch it unconditionally)
     n_oc = s.persistent_launches()["pcg"]
-    assert 0 < n_oc <= 15
+    assert n_oc == 24          # (the four frames were all issued on the on-chip kernel before the abort was seen; launches behind the abort leave at once)
     for _ in range(2):
         s.step_device(stats=True); ref.step()
     s.download()
