@@ -92,6 +92,8 @@ SYMBOLS = [
     ("admm_hip_set_solver_params", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double]),
     ("admm_hip_get_solver_params", C.c_int, [C.c_void_p, C.c_int32, c_int_p, c_double_p, c_double_p]),
     ("admm_hip_set_soft_modes", C.c_int, [C.c_void_p, C.c_int32, c_double_p]),
+    ("admm_hip_compute_soft_modes", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("admm_hip_get_soft_modes", C.c_int, [C.c_void_p, c_int_p, c_double_p]),
     ("admm_hip_contact_totals", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("admm_hip_persistent_launches", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 3),
     ("admm_hip_probe_sync", C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, C.POINTER(C.c_int64)]),

@@ -233,7 +233,8 @@ struct admm_hip_ctx {
     long long big_solves = 0;
     int big_row_lo = 0, big_row_hi = 0x7fffffff, big_nif = 0; DevBuf<int> big_if_rows; DevBuf<double> big_ifbuf;      // distributed solve: owned internal rows, interface rows
     // end projection of every PCG solve on soft modes (admm_hip_set_soft_modes; kernels.hpp: k_defl_*)
-    int defl_k = 0, defl_every = 1; bool defl_now = true; DevBuf<double> defl_Z, defl_Ginv, defl_part, defl_y;      // defl_every: experiments (ADMM_HIP_DEFL_EVERY=n: only every n-th solve of a step)
+    int defl_k = 0, defl_every = 1; bool defl_now = true, defl_fused = false; DevBuf<double> defl_Z, defl_Ginv, defl_part, defl_y, defl_Zint, defl_rec;
+    std::vector<int32_t> oc_orig_h;      // internal row -> vertex of the on-chip plan (host copy: the soft modes are stored in that order for k_pcg2)      // defl_every: experiments (ADMM_HIP_DEFL_EVERY=n: only every n-th solve of a step)
     long long oc_launches = 0, gsp_launches = 0;   // persistent launches since create (admm_hip_persistent_launches)
     int test_abort_seq = 0;   // tests only (ADMM_HIP_TEST_ABORT_SOLVE=k): the k-th on-chip solve of the context finds its barrier aborted
     int test_abort_uzp = 0;   // tests only (ADMM_HIP_TEST_ABORT_SCHUR=k): the k-th persistent Schur launch finds its hand-off given up
@@ -339,7 +340,7 @@ struct admm_hip_ctx {
         gsp_hdr.release(); gsp_orig.release(); gsp_out.release(); gsp_hbox.release(); gsp_horig.release(); gsp_diag.release(); gsp_vals.release(); gsp_cols.release();
         obst_gmeta.release(); obst_gdata.release(); obst_dev.release();
         gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release(); gsp_prof.release(); gs_proj.release();
-        defl_Z.release(); defl_Ginv.release(); defl_part.release(); defl_y.release();
+        defl_Z.release(); defl_Ginv.release(); defl_part.release(); defl_y.release(); defl_Zint.release(); defl_rec.release();
         big_A.release(); big_orig.release(); big_ainv.release(); big_mass.release(); big_dinv.release(); big_cwt.release(); big_xi.release(); big_r.release();
         big_u.release(); big_w.release(); big_p.release(); big_s.release(); big_part.release(); big_cvec.release(); big_rho.release(); big_if_rows.release(); big_ifbuf.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
@@ -549,6 +550,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.cwt = c->oc_cwt.p;
     a.skip = rc.skip;
     a.trust_short = c->oc_always_verify ? 0 : 1;
+    if (rc.on && c->defl_fused && c->defl_k > 0 && c->defl_now) { a.defl_k = c->defl_k; a.defl_Z = c->defl_Zint.p; a.defl_Ginv = c->defl_Ginv.p; a.defl_rec = c->defl_rec.p; }      // (the ADMM loop's solves only: not the K^-1 columns of UzawaCG)
     a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b; a.sm_c0 = c->oc_sm_c0; a.sm_k1 = c->oc_sm_k1; a.sm_k2 = c->oc_sm_k2;
     c->oc_launches += 1;
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
@@ -608,6 +610,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
                 if ((e = c->oc_A.val.upload(plan.A.val)) != hipSuccess) return e;
                 c->oc_A.n_rows = plan.A.n_rows; c->oc_A.n_slices = plan.A.n_slices;
                 if ((e = c->oc_col16.upload(plan.col16)) != hipSuccess) return e;
+                c->oc_orig_h.assign(plan.orig.begin(), plan.orig.end());
                 std::vector<int> oa(plan.orig);
                 for (size_t r = 0; r < oa.size(); ++r) if (oa[r] >= 0) oa[r] |= (int)plan.row_agg[r] << 28;
                 if ((e = c->oc_orig.upload(oa)) != hipSuccess) return e;
@@ -865,7 +868,7 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
     hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(256), 0, st, a, -1);
     volatile int *sig = c->h_sig;
     int launched = 0, chunks = 0;
-    const int chunk = 16;
+    const int chunk = 8;      // (iterations launched behind a converged one are no-ops, but 3 launches each)
     while (launched < max_iters) {
         const int n = std::min(chunk, max_iters - launched);
         for (int it = launched; it < launched + n; ++it) {
@@ -945,7 +948,7 @@ int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x);
 // The ADMM global solve with the recycled (Galerkin) warm start around the PCG (+ the end projection on the soft modes, when set).
 int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     const int rc = launch_pcg_recycled_impl(c, b, x);
-    if (rc == 0 && c->defl_k > 0 && c->defl_now) launch_deflation(c, b, x);
+    if (rc == 0 && c->defl_k > 0 && c->defl_now && !(c->defl_fused && c->oc_enabled)) launch_deflation(c, b, x);      // (fused into k_pcg2's epilogue when the on-chip kernel runs)
     return rc;
 }
 int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x) {
@@ -2795,6 +2798,7 @@ static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
     if (!c->oc_gave_up) fprintf(stderr, "[admm_hip] on-chip PCG: a grid barrier timed out (blocks not co-resident?) -- falling back to the launch-per-iteration PCG and replaying %d step(s)\n", (int)c->pending.size());
     c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false; c->uzp_enabled = false;
     c->rc_hist = 0; c->rc_prev_valid = 0; c->rc_prev2_valid = 0;   // the history slots may hold pairs half-written by the aborted solve, in the on-chip kernel's row order
+    c->defl_fused = false;      // (the end projection on the soft modes goes on as separate launches)
     if (c->gsp_abort.p) HIP_TRY(c->gsp_abort.zero());
     if (c->uzp_abort.p) HIP_TRY(c->uzp_abort.zero());
     c->rc_iter = 0;      // (the stored pairs are in the on-chip kernel's internal row order: the launch path must not project on them)
@@ -3046,8 +3050,132 @@ int admm_hip_set_soft_modes(admm_hip_ctx *c, int32_t k, const double *Z) {
     HIP_TRY(c->defl_Z.upload(std::vector<double>(Z, Z + (size_t)k * nv)));
     HIP_TRY(c->defl_Ginv.upload(G));
     HIP_TRY(c->defl_part.alloc((size_t)3 * k * c->NB)); HIP_TRY(c->defl_y.alloc((size_t)3 * k));
+    c->defl_fused = false;
+    { const char *fe = getenv("ADMM_HIP_DEFL_FUSED");      // (=0: the separate k_defl_* launches, the A/B and the checker of the fused epilogue)
+      if (!(fe && fe[0] == '0') && c->oc_enabled && c->oc_plan && k <= kOc2DeflMax && !c->oc_orig_h.empty()) {
+        std::vector<double> Zi((size_t)k * c->oc_rows, 0.0);
+        for (int q = 0; q < k; ++q)
+            for (int r = 0; r < c->oc_rows; ++r) { const int v = c->oc_orig_h[r]; if (v >= 0) Zi[(size_t)q * c->oc_rows + r] = Z[(size_t)q * nv + v]; }
+        c->defl_Zint.release(); c->defl_rec.release();
+        HIP_TRY(c->defl_Zint.upload(Zi));
+        HIP_TRY(c->defl_rec.alloc((size_t)2 * 3 * kOc2DeflMax * c->oc_G)); HIP_TRY(c->defl_rec.zero());
+        c->defl_fused = true;
+      } }
     c->defl_k = k;
     { const char *e = getenv("ADMM_HIP_DEFL_EVERY"); c->defl_every = e ? std::max(1, atoi(e)) : 1; }
+    return ADMM_HIP_OK;
+}
+
+// The k lowest eigenvectors of K = diag(m) + Ahat by inverse subspace iteration on the context's own PCG (three right-hand sides per solve),
+// Rayleigh-Ritz steps on the host; then admm_hip_set_soft_modes.  Deterministic (fixed start vectors).
+int admm_hip_compute_soft_modes(admm_hip_ctx *c, int32_t k, int32_t iters) {
+    if (!c || k < 0 || k > kDeflMax) return fail(ADMM_HIP_ERR_ARG, "compute_soft_modes: bad input (at most 64 modes)");
+    if (k == 0) return admm_hip_set_soft_modes(c, 0, nullptr);
+    if (c->linsolver == 1) return fail(ADMM_HIP_ERR_ARG, "compute_soft_modes: this context runs no PCG");
+    if (c->cm.on || c->world > 1) return fail(ADMM_HIP_ERR_STATE, "compute_soft_modes: single-GPU contexts only");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = settle(c)) return rc;
+    if (int rc = admm_hip_set_soft_modes(c, 0, nullptr)) return rc;
+    const int nv = c->nv, k3 = std::min(nv, 3 * ((k + 2) / 3 + 1));      // (a few guard vectors: the wanted ones converge faster)
+    if (k > nv) return fail(ADMM_HIP_ERR_ARG, "compute_soft_modes: more modes than vertices");
+    if (iters <= 0) iters = 8;
+    std::vector<double> mass(c->n3);
+    HIP_TRY(hipMemcpy(mass.data(), c->m.p, mass.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::vector<double> X((size_t)k3 * nv), Y((size_t)k3 * nv), KQ((size_t)k3 * nv), H((size_t)k3 * k3), V((size_t)k3 * k3), col3((size_t)c->n3);
+    {   // deterministic start: a linear congruential sequence
+        unsigned long long st = 0x9E3779B97F4A7C15ull;
+        for (double &x : X) { st = st * 6364136223846793005ull + 1442695040888963407ull; x = (double)((st >> 11) & 0xFFFFFFFFFFFFFull) / 4503599627370496.0 - 0.5; }
+    }
+    auto mgs = [&](std::vector<double> &A) -> bool {      // modified Gram-Schmidt on the k3 rows of length nv
+        for (int i = 0; i < k3; ++i) {
+            double *ai = &A[(size_t)i * nv];
+            for (int j = 0; j < i; ++j) {
+                const double *aj = &A[(size_t)j * nv];
+                double d = 0.0;
+                for (int v = 0; v < nv; ++v) d += ai[v] * aj[v];
+                for (int v = 0; v < nv; ++v) ai[v] -= d * aj[v];
+            }
+            double n2 = 0.0;
+            for (int v = 0; v < nv; ++v) n2 += ai[v] * ai[v];
+            if (!(n2 > 0.0) || !std::isfinite(n2)) return false;
+            const double il = 1.0 / std::sqrt(n2);
+            for (int v = 0; v < nv; ++v) ai[v] *= il;
+        }
+        return true;
+    };
+    DevBuf<double> db, dx;
+    HIP_TRY(db.alloc(c->n3)); HIP_TRY(dx.alloc(c->n3));
+    int rcode = ADMM_HIP_OK;
+    for (int it = 0; it < iters && rcode == ADMM_HIP_OK; ++it) {
+        if (!mgs(X)) { rcode = fail(ADMM_HIP_ERR_DEVICE, "compute_soft_modes: the subspace collapsed"); break; }
+        for (int c0 = 0; c0 < k3 && rcode == ADMM_HIP_OK; c0 += 3) {      // Y = K^-1 X, three columns = the three axes of one solve
+            for (int v = 0; v < nv; ++v) for (int j = 0; j < 3; ++j) col3[3 * (size_t)v + j] = c0 + j < k3 ? X[(size_t)(c0 + j) * nv + v] : 0.0;
+            if (hipMemcpyAsync(db.p, col3.data(), col3.size() * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                hipMemsetAsync(dx.p, 0, col3.size() * sizeof(double), c->stream) != hipSuccess) { rcode = fail(ADMM_HIP_ERR_DEVICE, "compute_soft_modes: copy failed"); break; }
+            if (launch_pcg(c, db.p, dx.p, std::max(c->pcg_max_iters, 2000))) { rcode = fail(ADMM_HIP_ERR_DEVICE, "compute_soft_modes: the solve failed"); break; }
+            if (hipMemcpyAsync(col3.data(), dx.p, col3.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { rcode = fail(ADMM_HIP_ERR_DEVICE, "compute_soft_modes: copy failed"); break; }
+            if (c->h_sig && c->h_sig[2]) { rcode = recover_from_abort(c, nullptr); if (rcode == ADMM_HIP_OK) { c0 -= 3; } continue; }
+            for (int v = 0; v < nv; ++v) for (int j = 0; j < 3; ++j) if (c0 + j < k3) Y[(size_t)(c0 + j) * nv + v] = col3[3 * (size_t)v + j];
+        }
+        if (rcode != ADMM_HIP_OK) break;
+        if (!mgs(Y)) { rcode = fail(ADMM_HIP_ERR_DEVICE, "compute_soft_modes: the subspace collapsed"); break; }
+        for (int q = 0; q < k3; ++q)      // K Q on the host
+            for (int v = 0; v < nv; ++v) {
+                double acc = mass[3 * (size_t)v] * Y[(size_t)q * nv + v];
+                for (int e = c->Ahat.rowptr[v]; e < c->Ahat.rowptr[v + 1]; ++e) acc += c->Ahat.val[e] * Y[(size_t)q * nv + c->Ahat.col[e]];
+                KQ[(size_t)q * nv + v] = acc;
+            }
+        for (int p = 0; p < k3; ++p)
+            for (int q = 0; q <= p; ++q) {
+                double acc = 0.0;
+                for (int v = 0; v < nv; ++v) acc += Y[(size_t)p * nv + v] * KQ[(size_t)q * nv + v];
+                H[(size_t)p * k3 + q] = acc; H[(size_t)q * k3 + p] = acc;
+            }
+        // eigenvectors of the small symmetric matrix: cyclic Jacobi
+        for (int i = 0; i < k3; ++i) for (int j = 0; j < k3; ++j) V[(size_t)i * k3 + j] = i == j ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 60; ++sweep) {
+            double off = 0.0, dg = 0.0;
+            for (int i = 0; i < k3; ++i) for (int j = 0; j < k3; ++j) (i == j ? dg : off) += H[(size_t)i * k3 + j] * H[(size_t)i * k3 + j];
+            if (off <= 1e-28 * dg) break;
+            for (int p = 0; p < k3; ++p)
+                for (int q = p + 1; q < k3; ++q) {
+                    const double apq = H[(size_t)p * k3 + q];
+                    if (apq == 0.0) continue;
+                    const double th = (H[(size_t)q * k3 + q] - H[(size_t)p * k3 + p]) / (2.0 * apq);
+                    const double t = (th >= 0.0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0)), cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                    for (int r = 0; r < k3; ++r) { const double a = H[(size_t)r * k3 + p], b2 = H[(size_t)r * k3 + q]; H[(size_t)r * k3 + p] = cs * a - sn * b2; H[(size_t)r * k3 + q] = sn * a + cs * b2; }
+                    for (int r = 0; r < k3; ++r) { const double a = H[(size_t)p * k3 + r], b2 = H[(size_t)q * k3 + r]; H[(size_t)p * k3 + r] = cs * a - sn * b2; H[(size_t)q * k3 + r] = sn * a + cs * b2; }
+                    for (int r = 0; r < k3; ++r) { const double a = V[(size_t)r * k3 + p], b2 = V[(size_t)r * k3 + q]; V[(size_t)r * k3 + p] = cs * a - sn * b2; V[(size_t)r * k3 + q] = sn * a + cs * b2; }
+                }
+        }
+        std::vector<int> ord(k3);
+        std::iota(ord.begin(), ord.end(), 0);
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b2) { return H[(size_t)a * k3 + a] < H[(size_t)b2 * k3 + b2]; });
+        for (int q = 0; q < k3; ++q) {      // X = Q V, columns by ascending Ritz value
+            double *xq = &X[(size_t)q * nv];
+            std::fill(xq, xq + nv, 0.0);
+            for (int p = 0; p < k3; ++p) {
+                const double w = V[(size_t)p * k3 + ord[q]];
+                const double *yp = &Y[(size_t)p * nv];
+                for (int v = 0; v < nv; ++v) xq[v] += w * yp[v];
+            }
+        }
+    }
+    db.release(); dx.release();
+    if (rcode != ADMM_HIP_OK) return rcode;
+    c->rc_iter = 0; c->rc_prev_valid = 0; c->rc_prev2_valid = 0;      // (the recycled basis of the ADMM loop starts clean)
+    return admm_hip_set_soft_modes(c, k, X.data());
+}
+
+int admm_hip_get_soft_modes(admm_hip_ctx *c, int32_t *k, double *Z) {
+    if (!c || !k) return fail(ADMM_HIP_ERR_ARG, "get_soft_modes: NULL argument");
+    *k = c->defl_k;
+    if (Z && c->defl_k > 0) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(Z, c->defl_Z.p, (size_t)c->defl_k * c->nv * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return ADMM_HIP_OK;
 }
 

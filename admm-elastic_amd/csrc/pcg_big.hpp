@@ -35,20 +35,7 @@ struct BigArgs {
     int row_lo, row_hi;                           // distributed solve: the internal rows this rank owns (aggregate-aligned)
 };
 
-constexpr int kBigVecT = 1024;
-template <int NQ>
-__device__ __forceinline__ void block_sum_big(double *q, double *lds /* [16 NQ] */) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        const double s = wave_sum(q[i]);
-        if (lane == 0) lds[wv * NQ + i] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NQ; ++i) { double s = 0.0; for (int k = 0; k < nw; ++k) s += lds[k * NQ + i]; q[i] = s; }
-    __syncthreads();
-}
+constexpr int kBigVecT = 256;      // (1024 threads with one row each spent their time in the 16-wave reductions: 70 us at 2 M tets; rocprofv3, round 5)
 
 // x, b into the internal order; p = s = 0
 __global__ __launch_bounds__(256) void k_big_gather(BigArgs a) {
@@ -125,7 +112,7 @@ __global__ __launch_bounds__(256) void k_big_spmv(BigArgs a, int it) {
 // it < 0: the entry pass (no update: c = P^T r, rho, and gamma_b = b.D^-1 b from the entry residual's partials).
 // it >= 0: alpha / beta, the vector updates, then c and rho.  One block = one aggregate.
 __global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mark_here) {
-    __shared__ double lds[16 * 15];
+    __shared__ double lds[4 * 15];
     const bool entry = it < 0;
     const CgScal pv = a.scal[entry ? 0 : (it & 1)];
     CgScal *next = a.scal + (entry ? 0 : ((it + 1) & 1));
@@ -144,7 +131,7 @@ __global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mar
         const int nq = entry ? 3 : 6;
         for (int i = threadIdx.x; i < a.NBt; i += kBigVecT)
             for (int kk = 0; kk < nq; ++kk) q[kk] += a.part[kk * a.NBt + i];
-        block_sum_big<6>(q, lds);
+        block_sum<6>(q, lds);
         if (entry) {
             if (g == 0 && threadIdx.x == 0) {
                 CgScal o = pv;
@@ -200,7 +187,7 @@ __global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mar
             }
         }
     }
-    block_sum_big<15>(q, lds);
+    block_sum<15>(q, lds);
     if (threadIdx.x < 12) a.cvec[(threadIdx.x % 3) * a.ncp + 4 * g + threadIdx.x / 3] = q[threadIdx.x];      // c[axis][4 g + k] = q[3 k + axis]
     else if (threadIdx.x < 15) a.rho[(threadIdx.x - 12) * a.G + g] = q[threadIdx.x];
 }

@@ -80,7 +80,11 @@ struct Oc2Args {
     int trust_short;     // 1: a short first pass needs no verification of its residual (see kOc2TrustIters)
     const int *skip;     // optional: *skip != 0 (set by an earlier kernel of the stream, e.g. UzawaCG's stop flag) makes the
                          // launch a no-op -- lets the host enqueue outer iterations ahead without synchronising
+    // END PROJECTION ON SOFT MODES (admm_hip_set_soft_modes; kernels.hpp: k_defl_* is the same step as separate launches): after a converged
+    // solve x += Z (Z^T K Z)^-1 Z^T r on defl_k <= kOc2DeflMax smooth global vectors Z (internal row order, [defl_k][n_rows]).
+    int defl_k; const double *defl_Z, *defl_Ginv; double *defl_rec;      // defl_rec: [2][3 kOc2DeflMax][G] block sums, by solve parity
 };
+constexpr int kOc2DeflMax = 32;
 
 #ifndef ADMM_OC2_ATTR
 #define ADMM_OC2_ATTR
@@ -942,17 +946,68 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     } while (false);
     if (prof) a.prof[63 * 8 + 3] = wall_clock64();
 #undef OC2_STAMP
+    if (live && a.rc_on) {   // this solve's pair: e = x - x_entry, A e = r_entry - r_final (exact: u carries the true residual; taken BEFORE the
+#pragma unroll           // end projection below, which moves x without updating r)
+        for (int j = 0; j < 3; ++j) {
+            const size_t i = 3 * (size_t)row + j;
+            a.rc_Eslot[i] = rx[j] - a.rc_xs[i];
+            a.rc_Rslot[i] = a.rc_r0[i] - ru[j] * fast_rcp(rd[j]);
+        }
+    }
+    if (a.defl_k > 0 && conv && !aborted) {
+        // ---- end projection on the soft modes: x += Z G^-1 Z^T r (one more all-to-all) ----
+        // r of the block's rows -> the (idle) local vector; wave w takes the modes w, w + nw, ...: lanes over the block's rows, ONE wave sum
+        // per mode and axis (every thread summing every mode's product costs 6 x 96 lane exchanges per wave: measured on k_big_vec)
+        const int K = a.defl_k, dpar = a.seq & 1;
+        {
+            const int t = otid();
+#pragma unroll
+            for (int j = 0; j < 3; ++j) vec[OC2_VX(t, j)] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
+        }
+        __syncthreads();
+        __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void *)a.defl_rec, 0, 2 * 3 * kOc2DeflMax * a.G * 8, 0x00020000);
+        const size_t zrow0 = (size_t)blockIdx.x * (size_t)T;
+        for (int q = wv; q < K; q += nw) {
+            double acc[3] = {0.0, 0.0, 0.0};
+            const double *zq = a.defl_Z + (size_t)q * a.n_rows + zrow0;
+            for (int i = 0; i < a.spb; ++i) {
+                const int rl = lane + 64 * i;
+                const double z = zq[rl];
+                acc[0] = fma(z, vec[OC2_VX(rl, 0)], acc[0]); acc[1] = fma(z, vec[OC2_VX(rl, 1)], acc[1]); acc[2] = fma(z, vec[OC2_VX(rl, 2)], acc[2]);
+            }
+            acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]); acc[2] = wave_sum(acc[2]);
+            if (lane < 3) oc_store_sc1(rs_d, ((dpar * 3 * kOc2DeflMax + 3 * q + lane) * a.G + (int)blockIdx.x) * 8, lane == 0 ? acc[0] : lane == 1 ? acc[1] : acc[2]);
+        }
+        ++be;
+        if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) aborted = true;
+        else {
+            for (int k = wv; k < 3 * K; k += nw) {       // the blocks' sums, every block in the same order
+                double sm = 0.0;
+                for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_d, ((dpar * 3 * kOc2DeflMax + k) * a.G + g) * 8);
+                sm = wave_sum(sm);
+                if (lane == 0) red[k] = sm;
+            }
+            __syncthreads();
+            for (int o = tid; o < 3 * K; o += T) {       // y = G^-1 d
+                const int q = o / 3, ax = o - 3 * q;
+                double acc = 0.0;
+                for (int pp = 0; pp < K; ++pp) acc = fma(a.defl_Ginv[q * K + pp], red[3 * pp + ax], acc);
+                red[3 * kOc2DeflMax + o] = acc;
+            }
+            __syncthreads();
+            if (live) {
+                const double *zr = a.defl_Z + row;
+                for (int q = 0; q < K; ++q) {
+                    const double z = zr[(size_t)q * a.n_rows];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) rx[j] = fma(z, red[3 * kOc2DeflMax + 3 * q + j], rx[j]);
+                }
+            }
+        }
+    }
     if (live) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { a.x[3 * (size_t)vi + j] = rx[j]; a.u_out[3 * (size_t)vi + j] = ru[j]; }
-        if (a.rc_on) {   // this solve's pair: e = x - x_entry, A e = r_entry - r_final (exact: u carries the true residual)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const size_t i = 3 * (size_t)row + j;
-                a.rc_Eslot[i] = rx[j] - a.rc_xs[i];
-                a.rc_Rslot[i] = a.rc_r0[i] - ru[j] * fast_rcp(rd[j]);
-            }
-        }
     }
     if (blockIdx.x == 0 && tid == 0) {
         CgScal o;

@@ -59,6 +59,7 @@ class Settings:
         self.gs_omega = 0.0
         self.uzawa_max_iters = 0
         self.uzawa_tol = 0.0
+        self.soft_modes = 0          # GPU build: end projection of every PCG solve on the k lowest modes of the system matrix (admm_hip_compute_soft_modes)
         self.device = 0
         self.rank = 0
         self.world_size = 1
@@ -462,6 +463,8 @@ class Solver:
         for o in self._dynamic:   # Solver.cpp:249-254 (LDLT: "No collisions with LDLT solver") is checked by the library
             check(lib().admm_hip_add_dynamic_tetmesh(ctx, o.vert_offset, o.rest.shape[0], dptr(o.rest), o.tets.shape[0],
                                                      iptr(o.tets), o.faces.shape[0], iptr(o.faces)))
+        if s.soft_modes > 0 and s.linsolver != 1 and s.world_size <= 1:
+            check(lib().admm_hip_compute_soft_modes(ctx, int(s.soft_modes), 0))
         self.initialized = True
         return True
 
@@ -571,6 +574,21 @@ class Solver:
             check(lib().admm_hip_set_soft_modes(self._ctx, 0, None)); return
         Zc = f64(Z).reshape(len(Z), -1)
         check(lib().admm_hip_set_soft_modes(self._ctx, Zc.shape[0], dptr(Zc)))
+
+    def compute_soft_modes(self, k, iters=0):
+        """admm_hip_compute_soft_modes: the library computes the k lowest modes itself and installs them."""
+        self._need_ctx()
+        check(lib().admm_hip_compute_soft_modes(self._ctx, int(k), int(iters)))
+
+    def get_soft_modes(self):
+        """admm_hip_get_soft_modes: Z [k, n_verts] in effect (k = 0: none)."""
+        self._need_ctx()
+        k = C.c_int32(0)
+        check(lib().admm_hip_get_soft_modes(self._ctx, C.byref(k), None))
+        Z = np.zeros((k.value, self.m_x.size // 3))
+        if k.value:
+            check(lib().admm_hip_get_soft_modes(self._ctx, C.byref(k), dptr(Z)))
+        return Z
 
     def soft_modes(self, k, iters=8, seed=0):
         """The k lowest eigenvectors of K = diag(m) + Ahat by inverse subspace iteration on the context's own solver (three right-hand sides

@@ -36,6 +36,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # for two frames and drifted to 4.6e-4 by frame 21 (profiles/r04_drift_tolerance_study.txt: 1e-9 6.5e-6 at 25 frames but 1.7e-5 at
 # 50, 7e-10 8.6e-6 at 50, 5e-10 2.9e-6 at 50).
 PCG_TOL = 5e-10
+# Round 5: the 200-frame drift record (tests/test_bench_parity.py, profiles/r05_drift_*) put 5e-10 alone at 1.06e-5 -- over the bar -- and 2e-10 at
+# 3.1e-6.  What the error consists of is the part of every solve's residual that lives in the body's soft modes; the bench now ends every
+# solve with the exact projection of its residual on the 32 lowest modes of the system matrix (admm_hip_compute_soft_modes: part of the
+# persistent launch): 2.7e-6 over 200 frames at 5e-10, with FEWER iterations per solve (the corrected iterate is a better start).
+SOFT_MODES = 32
 
 WORKLOADS = {
     "cube1m_mix": dict(n=55, kinds="mix", linsolver=0, admm_iters=20),
@@ -290,6 +295,7 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override cells per edge (testing only)")
     ap.add_argument("--pcg-tol", type=float, default=PCG_TOL)
     ap.add_argument("--pcg-max-iters", type=int, default=600)
+    ap.add_argument("--soft-modes", type=int, default=SOFT_MODES, help="end projection of every PCG solve on this many lowest modes (0: off); single-GPU PCG workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--calibrate-cpu-baseline", action="store_true", help="build container only: time the oracle port against the compiled reference pieces -> profiles/")
@@ -344,7 +350,8 @@ def main():
     sc, nt, nv = build_scene(w, args.n or None, copies=world)
     iters = w["admm_iters"]
     weak = w["kinds"] == "blobs"
-    s = sc.make_solver(device=local_rank, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters, rank=rank, world_size=world)
+    soft = args.soft_modes if (world == 1 and w["linsolver"] != 1) else 0
+    s = sc.make_solver(device=local_rank, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters, rank=rank, world_size=world, soft_modes=soft)
     if world > 1 and not share:
         s.comm_init(dist)
     elif world > 1 and not weak:
@@ -491,6 +498,7 @@ def main():
         # the DEFAULT lines of --gpus 1, 2, 4, 8 are BASELINE's series: ONE 1 M-tet body at fixed tet count (configs[3]); the weak
         # series (one such body per GPU) is `weak_value` of the same lines
         "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "soft_modes": soft,
         "config": {"workload": args.workload + (" (n=%d override)" % args.n if args.n else ""), "elements": nt, "verts": nv,
                    "admm_iters_per_step": iters, "global_solver": "multicolor-GS(30 sweeps)" if w["linsolver"] == 1 else
                    ("UzawaCG, no active constraints: every solve is the prefactored solve (src/UzawaCG.hpp:78-81) = one persistent on-chip two-level pipelined PCG launch, tol=%g max=%d" % (args.pcg_tol, args.pcg_max_iters)

@@ -41,6 +41,9 @@ def run(tol, mx, verify, env=None, ref=None):
         if MODES is None or MODES[1].shape[0] < k_soft:
             t0 = time.time(); MODES = s.soft_modes(max(k_soft, int(os.environ.get("ADMM_DRIFT_MODES_MAX", "64")))); print("soft modes: lowest eigenvalues %s ... %.3g (%.0f s)" % (" ".join("%.3g" % e for e in MODES[0][:6]), MODES[0][-1], time.time() - t0), flush=True)
         s.set_soft_modes(MODES[1][:k_soft])
+    if "SOFTLIB" in (env or {}):      # the product path: the library computes the modes, the projection runs inside k_pcg2
+        t0 = time.time(); s.compute_soft_modes(int(env["SOFTLIB"])); print("  (library modes: %.1f s)" % (time.time() - t0), flush=True)
+    tot0 = s.solve_totals()
     s.upload()
     for f in range(frames):
         s.step_device(stats=True)
@@ -52,7 +55,7 @@ def run(tol, mx, verify, env=None, ref=None):
             xs.append(s.m_x.astype(np.float64).copy())
         else:
             errs.append(scenes.rel_err(s.m_x, ref[f]))
-    tot = s.solve_totals()
+    tot = tuple(a - b for a, b in zip(s.solve_totals(), tot0))      # (without the solves that computed the modes)
     s.close()
     return xs, errs, tot, 1e3 * sc.settings["admm_iters"] * (frames - 5) / t_frames
 

@@ -298,6 +298,12 @@ int admm_hip_get_solver_params(const admm_hip_ctx *ctx, int32_t kind, int32_t *m
  * residual-norm stop leaves in span(Z) -- the soft modes in which the error of an inexact solve is largest and accumulates from frame to
  * frame.  The result of a converged solve changes only within the solver's tolerance.  k = 0 removes the modes. */
 int admm_hip_set_soft_modes(admm_hip_ctx *ctx, int32_t k, const double *Z);
+/* ... with the modes computed by the library: the k lowest eigenvectors of K by `iters` (<= 0: 8) steps of inverse subspace iteration on
+ * the context's own PCG (a few seconds at 1 M tets, once per scene -- A never changes after Solver::initialize, src/Solver.cpp:225-226).
+ * With the on-chip PCG and k <= 32 the projection is part of the solve's one persistent launch (one more all-to-all). */
+int admm_hip_compute_soft_modes(admm_hip_ctx *ctx, int32_t k, int32_t iters);
+/* the modes in effect: *k, and Z [k][n_verts] when Z is not NULL */
+int admm_hip_get_soft_modes(admm_hip_ctx *ctx, int32_t *k, double *Z);
 
 /* Contact work since admm_hip_create (measurement: that a timed region really exercised the collision path).  linsolver 2: rows of C
  * (ConstraintSet::make_matrix, src/ConstraintSet.hpp:59-116) summed over all UzawaCG solves; linsolver 1: node updates replaced by the

@@ -72,7 +72,7 @@ def test_blob1m_drift_200_frames_bench_tolerance_vs_tight_solve():
     finally:
         os.environ.pop("ADMM_HIP_OC_VERIFY", None)
     import bench
-    loose = sc.make_solver(pcg_tol=bench.PCG_TOL, pcg_max_iters=600)        # bench.py's defaults
+    loose = sc.make_solver(pcg_tol=bench.PCG_TOL, pcg_max_iters=600, soft_modes=bench.SOFT_MODES)        # bench.py's defaults
     errs = []
     for f in range(frames):
         tight.step(); loose.step()
@@ -84,8 +84,8 @@ def test_blob1m_drift_200_frames_bench_tolerance_vs_tight_solve():
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "drift_blob1m_frames.txt"), "w") as fh:
-            fh.write("# blob1m_mix (%d tets), bench settings (pcg_tol %g, schedule %s) vs the same path at 1e-12 verified: rel_err per frame\n" %
-                     (nt, bench.PCG_TOL, os.environ.get("ADMM_HIP_TOL_SCHED", "-")))
+            fh.write("# blob1m_mix (%d tets), bench settings (pcg_tol %g, %s) vs the same path at 1e-12 verified: rel_err per frame\n" %
+                     (nt, bench.PCG_TOL, "soft modes %d" % bench.SOFT_MODES))
             fh.write("\n".join("%d %.3e" % (i, e) for i, e in enumerate(errs)) + "\n")
     except OSError:
         pass
@@ -99,7 +99,7 @@ def test_blob52k_drift_25_frames_bench_settings_vs_oracle():
     sc, nt, nv = _bench_scene("blob1m_mix", 44)
     assert nt == 52464
     import bench
-    s = sc.make_solver(pcg_tol=bench.PCG_TOL, pcg_max_iters=600)
+    s = sc.make_solver(pcg_tol=bench.PCG_TOL, pcg_max_iters=600, soft_modes=bench.SOFT_MODES)
     o = sc.make_oracle(mode=1, big=True)
     errs = []
     for f in range(25):
