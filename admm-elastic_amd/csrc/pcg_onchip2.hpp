@@ -957,50 +957,81 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     if (a.defl_k > 0 && conv && !aborted) {
         // ---- end projection on the soft modes: x += Z G^-1 Z^T r (one more all-to-all) ----
         // r of the block's rows -> the (idle) local vector; wave w takes the modes w, w + nw, ...: lanes over the block's rows, ONE wave sum
-        // per mode and axis (every thread summing every mode's product costs 6 x 96 lane exchanges per wave: measured on k_big_vec)
+        // per mode and axis (every thread summing every mode's product would cost 6 x 96 lane exchanges per wave: measured on k_big_vec).
+        // Every phase issues ALL its global loads before the first use: as chains of dependent loads the same code cost 60 us (measured).
         const int K = a.defl_k, dpar = a.seq & 1;
+        constexpr int SPBMAX = MAXT / 64;
         {
             const int t = otid();
 #pragma unroll
             for (int j = 0; j < 3; ++j) vec[OC2_VX(t, j)] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
         }
+        // (G^-1 into LDS behind the dots: the slab's first K K doubles are not needed any more)
+        LdsD *ginv_l = lv_all;
+        for (int o = tid; o < K * K; o += T) ginv_l[o] = a.defl_Ginv[o];
         __syncthreads();
         __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void *)a.defl_rec, 0, 2 * 3 * kOc2DeflMax * a.G * 8, 0x00020000);
         const size_t zrow0 = (size_t)blockIdx.x * (size_t)T;
         for (int q = wv; q < K; q += nw) {
+            const double *zq = a.defl_Z + (size_t)q * a.n_rows + zrow0 + lane;
+            double z[SPBMAX];
+#pragma unroll
+            for (int i = 0; i < SPBMAX; ++i) z[i] = i < a.spb ? zq[64 * i] : 0.0;
             double acc[3] = {0.0, 0.0, 0.0};
-            const double *zq = a.defl_Z + (size_t)q * a.n_rows + zrow0;
-            for (int i = 0; i < a.spb; ++i) {
-                const int rl = lane + 64 * i;
-                const double z = zq[rl];
-                acc[0] = fma(z, vec[OC2_VX(rl, 0)], acc[0]); acc[1] = fma(z, vec[OC2_VX(rl, 1)], acc[1]); acc[2] = fma(z, vec[OC2_VX(rl, 2)], acc[2]);
-            }
+#pragma unroll
+            for (int i = 0; i < SPBMAX; ++i)
+                if (i < a.spb) {
+                    const int rl = lane + 64 * i;
+                    acc[0] = fma(z[i], vec[OC2_VX(rl, 0)], acc[0]); acc[1] = fma(z[i], vec[OC2_VX(rl, 1)], acc[1]); acc[2] = fma(z[i], vec[OC2_VX(rl, 2)], acc[2]);
+                }
             acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]); acc[2] = wave_sum(acc[2]);
             if (lane < 3) oc_store_sc1(rs_d, ((dpar * 3 * kOc2DeflMax + 3 * q + lane) * a.G + (int)blockIdx.x) * 8, lane == 0 ? acc[0] : lane == 1 ? acc[1] : acc[2]);
         }
+        // this row's entries of Z for the update below: in flight across the grid barrier
+        double zmine[kOc2DeflMax];
+#pragma unroll
+        for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K) ? a.defl_Z[(size_t)q * a.n_rows + row] : 0.0;
         ++be;
         if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) aborted = true;
         else {
-            for (int k = wv; k < 3 * K; k += nw) {       // the blocks' sums, every block in the same order
+            // the blocks' sums, every block in the same order: wave w the quantities w, w + nw, ... (<= 8 of 96 with 12 waves), four blocks per lane
+            constexpr int QW = (3 * kOc2DeflMax + 11) / 12 + 1;
+            double part[QW][4];
+#pragma unroll
+            for (int u = 0; u < QW; ++u) {
+                const int k = wv + u * nw;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int g = lane + 64 * i; part[u][i] = (k < 3 * K && g < a.G) ? oc_load_sc1_f64(rs_d, ((dpar * 3 * kOc2DeflMax + k) * a.G + g) * 8) : 0.0; }
+            }
+#pragma unroll
+            for (int u = 0; u < QW; ++u) {
+                const int k = wv + u * nw;
+                if (k < 3 * K) {
+                    double sm = (part[u][0] + part[u][1]) + (part[u][2] + part[u][3]);
+                    for (int g = lane + 256; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_d, ((dpar * 3 * kOc2DeflMax + k) * a.G + g) * 8);
+                    sm = wave_sum(sm);
+                    if (lane == 0) red[k] = sm;
+                }
+            }
+            for (int k = wv + QW * nw; k < 3 * K; k += nw) {      // (fewer than 12 waves: the rest, plainly)
                 double sm = 0.0;
                 for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_d, ((dpar * 3 * kOc2DeflMax + k) * a.G + g) * 8);
                 sm = wave_sum(sm);
                 if (lane == 0) red[k] = sm;
             }
             __syncthreads();
-            for (int o = tid; o < 3 * K; o += T) {       // y = G^-1 d
+            for (int o = tid; o < 3 * K; o += T) {       // y = G^-1 d, from LDS
                 const int q = o / 3, ax = o - 3 * q;
                 double acc = 0.0;
-                for (int pp = 0; pp < K; ++pp) acc = fma(a.defl_Ginv[q * K + pp], red[3 * pp + ax], acc);
+                for (int pp = 0; pp < K; ++pp) acc = fma(ginv_l[q * K + pp], red[3 * pp + ax], acc);
                 red[3 * kOc2DeflMax + o] = acc;
             }
             __syncthreads();
-            if (live) {
-                const double *zr = a.defl_Z + row;
-                for (int q = 0; q < K; ++q) {
-                    const double z = zr[(size_t)q * a.n_rows];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) rx[j] = fma(z, red[3 * kOc2DeflMax + 3 * q + j], rx[j]);
+            for (int q = 0; q < kOc2DeflMax; ++q) {
+                if (q < K) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) rx[j] = fma(zmine[q], red[3 * kOc2DeflMax + 3 * q + j], rx[j]);
                 }
             }
         }

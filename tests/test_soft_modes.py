@@ -55,6 +55,13 @@ def test_end_projection_makes_the_residual_orthogonal_to_the_modes(fused, monkey
     r = b - K @ x.reshape(-1, 3); rp_ = b - K @ xp.reshape(-1, 3)
     proj = np.abs(Z @ r).max(); proj_plain = np.abs(Z @ rp_).max()
     assert proj < 1e-6 * max(proj_plain, 1e-300) or proj < 1e-9 * np.abs(b).max(), (proj, proj_plain)
+    if fused == "1":      # the two forms of the step on ONE solve at a tight tolerance: equal to round-off level
+        a = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=3000, soft_modes=16)
+        monkeypatch.setenv("ADMM_HIP_DEFL_FUSED", "0")
+        b2 = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=3000, soft_modes=16)
+        monkeypatch.delenv("ADMM_HIP_DEFL_FUSED")
+        xa, _ = a.global_solve(b.ravel(), np.zeros(b.size)); xb, _ = b2.global_solve(b.ravel(), np.zeros(b.size))
+        assert np.abs(xa - xb).max() < 1e-8 * np.abs(xs).max()
     err = np.abs(x.reshape(-1, 3) - xs).max(); err_plain = np.abs(xp.reshape(-1, 3) - xs).max()
     assert err < err_plain                                            # and the iterate is closer to the solution
     assert (s.persistent_launches()["pcg"] > 0)
@@ -71,7 +78,9 @@ def test_fused_and_separate_projection_agree_over_frames_and_help_the_drift(monk
     for f in range(12):
         for q in (tight, fused, sep, plain):
             q.step()
-    assert scenes.rel_err(fused.m_x, sep.m_x) < 1e-9                   # the same step, in the kernel's epilogue or as three launches
+    # (the same step, in the kernel's epilogue -- on the recursive residual -- or as three launches on the true one: equal to the solver's
+    # tolerance per solve, which twelve frames of a swaying body amplify)
+    assert scenes.rel_err(fused.m_x, sep.m_x) < 2e-6
     e_f, e_p = scenes.rel_err(fused.m_x, tight.m_x), scenes.rel_err(plain.m_x, tight.m_x)
     print("12 frames at pcg_tol 1e-7: rel_err %.2e with the end projection, %.2e without" % (e_f, e_p))
     assert e_f < 0.5 * e_p
