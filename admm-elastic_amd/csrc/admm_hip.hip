@@ -828,7 +828,7 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
         if (int r = comm_allreduce(c, c->big_part.p, (size_t)3 * c->big_NBt)) return r;
         hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1, 0);
         if (int r = comm_allreduce(c, c->big_cvec.p, ncr)) return r;
-        hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(256), 0, st, a, -1);
+        hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1);
         if (int r = xchg_u()) return r;
         volatile int *sig = c->h_sig;
         int launched = 0, chunks = 0;
@@ -840,7 +840,7 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
                 if (int r = comm_allreduce(c, c->big_part.p, (size_t)6 * c->big_NBt)) return r;
                 hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, it, (it == launched + n - 1) ? 1 : 0);
                 if (int r = comm_allreduce(c, c->big_cvec.p, ncr)) return r;
-                hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(256), 0, st, a, it);
+                hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(kBigVecT), 0, st, a, it);
                 if (int r = xchg_u()) return r;
             }
             const int end_prev = launched;        // iterations [0, launched) belong to the chunks before this one
@@ -865,7 +865,7 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
     hipLaunchKernelGGL(k_big_gather, dim3(nbr), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_big_resid, dim3(c->big_NBt), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1, 0);
-    hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(256), 0, st, a, -1);
+    hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1);
     volatile int *sig = c->h_sig;
     int launched = 0, chunks = 0;
     const int chunk = 8;      // (iterations launched behind a converged one are no-ops, but 3 launches each)
@@ -874,7 +874,7 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
         for (int it = launched; it < launched + n; ++it) {
             hipLaunchKernelGGL(k_big_spmv, dim3(c->big_NBt), dim3(256), 0, st, a, it);
             hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, it, (it == launched + n - 1) ? 1 : 0);
-            hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(256), 0, st, a, it);
+            hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(kBigVecT), 0, st, a, it);
         }
         launched += n;
         ++chunks;

@@ -647,8 +647,13 @@ BigPlan build_big_plan(const Csr &A, const double *mass3, const double *xyz, int
         for (int32_t v : mem) mark[v] = idb;
         std::vector<int32_t> bfs;
         bfs_order(g, mem, mark, idb, mem[0], seen, bfs);
+        // longest rows first (the 64 rows of a SELL slice then have similar lengths: less padding to stream), rows of equal length breadth-first
+        std::vector<int32_t> rank_of(bfs.size());
+        std::vector<std::pair<int32_t, int32_t> > key(bfs.size());
+        for (size_t i = 0; i < bfs.size(); ++i) key[i] = std::make_pair(-(g.ptr[bfs[i] + 1] - g.ptr[bfs[i]]), (int32_t)i);
+        std::sort(key.begin(), key.end());
         int32_t slot = b * ra;
-        for (int32_t v : bfs) { P.orig[slot] = v; P.pos[v] = slot; ++slot; }
+        for (const auto &kv : key) { const int32_t v = bfs[kv.second]; P.orig[slot] = v; P.pos[v] = slot; ++slot; }
     }
     // ---- A in the internal order (rows of dummy slots: empty) ----
     {

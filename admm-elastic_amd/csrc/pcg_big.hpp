@@ -35,7 +35,24 @@ struct BigArgs {
     int row_lo, row_hi;                           // distributed solve: the internal rows this rank owns (aggregate-aligned)
 };
 
-constexpr int kBigVecT = 256;      // (1024 threads with one row each spent their time in the 16-wave reductions: 70 us at 2 M tets; rocprofv3, round 5)
+constexpr int kBigVecT = 768;      // one row per thread (rocprofv3, 2 M tets: 1024 threads whose EVERY thread formed every final sum 70 us; 256 threads with
+                                   // three rows each 43 us -- seven waves per CU hide nothing; now the final sums are formed by 15 threads)
+// block-wide sum of NQ quantities over any number of waves (<= 16): wave sums to LDS, the first NQ threads add them up, everybody reads
+template <int NQ>
+__device__ __forceinline__ void block_sum_wide(double *q, double *lds /* [16 NQ + NQ] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const double s = wave_sum(q[i]);
+        if (lane == 0) lds[wv * NQ + i] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NQ) { double s = 0.0; for (int k = 0; k < nw; ++k) s += lds[k * NQ + threadIdx.x]; lds[16 * NQ + threadIdx.x] = s; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) q[i] = lds[16 * NQ + i];
+    __syncthreads();
+}
 
 // x, b into the internal order; p = s = 0
 __global__ __launch_bounds__(256) void k_big_gather(BigArgs a) {
@@ -112,7 +129,7 @@ __global__ __launch_bounds__(256) void k_big_spmv(BigArgs a, int it) {
 // it < 0: the entry pass (no update: c = P^T r, rho, and gamma_b = b.D^-1 b from the entry residual's partials).
 // it >= 0: alpha / beta, the vector updates, then c and rho.  One block = one aggregate.
 __global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mark_here) {
-    __shared__ double lds[4 * 15];
+    __shared__ double lds[17 * 15];
     const bool entry = it < 0;
     const CgScal pv = a.scal[entry ? 0 : (it & 1)];
     CgScal *next = a.scal + (entry ? 0 : ((it + 1) & 1));
@@ -131,7 +148,7 @@ __global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mar
         const int nq = entry ? 3 : 6;
         for (int i = threadIdx.x; i < a.NBt; i += kBigVecT)
             for (int kk = 0; kk < nq; ++kk) q[kk] += a.part[kk * a.NBt + i];
-        block_sum<6>(q, lds);
+        block_sum_wide<6>(q, lds);
         if (entry) {
             if (g == 0 && threadIdx.x == 0) {
                 CgScal o = pv;
@@ -187,21 +204,21 @@ __global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mar
             }
         }
     }
-    block_sum<15>(q, lds);
+    block_sum_wide<15>(q, lds);
     if (threadIdx.x < 12) a.cvec[(threadIdx.x % 3) * a.ncp + 4 * g + threadIdx.x / 3] = q[threadIdx.x];      // c[axis][4 g + k] = q[3 k + axis]
     else if (threadIdx.x < 15) a.rho[(threadIdx.x - 12) * a.G + g] = q[threadIdx.x];
 }
 
 // y_g = rows 4 g .. 4 g + 3 of (P^T A P)^-1 times c; the stop test; u = D^-1 r + P y on the aggregate's rows
-__global__ __launch_bounds__(256) void k_big_coarse(BigArgs a, int it) {
-    __shared__ double lds[60];
+__global__ __launch_bounds__(kBigVecT) void k_big_coarse(BigArgs a, int it) {
+    __shared__ double lds[17 * 15];
     CgScal *cur = a.scal + ((it + 1) & 1);        // the slot k_big_vec (it) wrote (entry pass: it = -1 -> slot 0)
     if (cur->converged) return;
     const int g = (int)blockIdx.x;
     double q[15];
 #pragma unroll
     for (int i = 0; i < 15; ++i) q[i] = 0.0;
-    for (int j = threadIdx.x; j < a.nc; j += 256) {
+    for (int j = threadIdx.x; j < a.nc; j += kBigVecT) {
         const double c0 = a.cvec[j], c1 = a.cvec[a.ncp + j], c2 = a.cvec[2 * a.ncp + j];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -209,8 +226,8 @@ __global__ __launch_bounds__(256) void k_big_coarse(BigArgs a, int it) {
             q[3 * k] = fma(m, c0, q[3 * k]); q[3 * k + 1] = fma(m, c1, q[3 * k + 1]); q[3 * k + 2] = fma(m, c2, q[3 * k + 2]);
         }
     }
-    for (int j = threadIdx.x; j < a.G; j += 256) { q[12] += a.rho[j]; q[13] += a.rho[a.G + j]; q[14] += a.rho[2 * a.G + j]; }
-    block_sum<15>(q, lds);
+    for (int j = threadIdx.x; j < a.G; j += kBigVecT) { q[12] += a.rho[j]; q[13] += a.rho[a.G + j]; q[14] += a.rho[2 * a.G + j]; }
+    block_sum_wide<15>(q, lds);
     const CgScal sc = *cur;
     bool conv = true;
 #pragma unroll
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(256) void k_big_coarse(BigArgs a, int it) {
     }
     const int r0 = g * a.ra;
     if (r0 < a.row_lo || r0 >= a.row_hi) return;
-    for (int row = r0 + (int)threadIdx.x; row < r0 + a.ra; row += 256) {
+    for (int row = r0 + (int)threadIdx.x; row < r0 + a.ra; row += kBigVecT) {
         const size_t i0 = 3 * (size_t)row;
         const double c0 = a.cwt[4 * (size_t)row], c1 = a.cwt[4 * (size_t)row + 1], c2 = a.cwt[4 * (size_t)row + 2], c3 = a.cwt[4 * (size_t)row + 3];
 #pragma unroll
