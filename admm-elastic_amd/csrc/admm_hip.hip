@@ -233,7 +233,7 @@ struct admm_hip_ctx {
     long long big_solves = 0;
     int big_row_lo = 0, big_row_hi = 0x7fffffff, big_nif = 0; DevBuf<int> big_if_rows; DevBuf<double> big_ifbuf;      // distributed solve: owned internal rows, interface rows
     // end projection of every PCG solve on soft modes (admm_hip_set_soft_modes; kernels.hpp: k_defl_*)
-    int defl_k = 0, defl_every = 1; bool defl_now = true, defl_fused = false; DevBuf<double> defl_Z, defl_Ginv, defl_part, defl_y, defl_Zint, defl_rec;
+    int defl_k = 0, defl_every = 1; bool defl_now = true, defl_fused = false; DevBuf<double> defl_Z, defl_Ginv, defl_part, defl_y, defl_rec; DevBuf<float> defl_Zint;
     std::vector<int32_t> oc_orig_h;      // internal row -> vertex of the on-chip plan (host copy: the soft modes are stored in that order for k_pcg2)      // defl_every: experiments (ADMM_HIP_DEFL_EVERY=n: only every n-th solve of a step)
     long long oc_launches = 0, gsp_launches = 0;   // persistent launches since create (admm_hip_persistent_launches)
     int test_abort_seq = 0;   // tests only (ADMM_HIP_TEST_ABORT_SOLVE=k): the k-th on-chip solve of the context finds its barrier aborted
@@ -3015,7 +3015,13 @@ int admm_hip_set_soft_modes(admm_hip_ctx *c, int32_t k, const double *Z) {
     HIP_TRY(hipMemcpy(mass.data(), c->m.p, mass.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int v = 0; v < nv; ++v)
         if (mass[3 * (size_t)v] != mass[3 * (size_t)v + 1] || mass[3 * (size_t)v] != mass[3 * (size_t)v + 2]) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: needs per-vertex masses (A = K (x) I3)");
-    // exact pairs: K Z on the host, G = Z^T K Z, its inverse by Cholesky
+    // The fused epilogue of k_pcg2 keeps the modes in SINGLE precision (half the bytes of the step's two passes over them).  The step stays an
+    // exact Galerkin step because everything below -- K Z, G = Z^T K Z, the copy the separate kernels use -- is formed from the ROUNDED vectors.
+    std::vector<double> Zr;
+    const char *fe0 = getenv("ADMM_HIP_DEFL_FUSED");
+    const bool want_fused = !(fe0 && fe0[0] == '0') && c->oc_enabled && c->oc_plan && k <= kOc2DeflMax && !c->oc_orig_h.empty();
+    if (want_fused) { Zr.assign(Z, Z + (size_t)k * nv); for (double &z : Zr) z = (double)(float)z; Z = Zr.data(); }
+    // exact pairs: K Z on the host, G = Z^T K Z, its inverse
     std::vector<double> KZ((size_t)k * nv), G((size_t)k * k, 0.0);
     for (int q = 0; q < k; ++q)
         for (int v = 0; v < nv; ++v) {
@@ -3052,10 +3058,11 @@ int admm_hip_set_soft_modes(admm_hip_ctx *c, int32_t k, const double *Z) {
     HIP_TRY(c->defl_part.alloc((size_t)3 * k * c->NB)); HIP_TRY(c->defl_y.alloc((size_t)3 * k));
     c->defl_fused = false;
     { const char *fe = getenv("ADMM_HIP_DEFL_FUSED");      // (=0: the separate k_defl_* launches, the A/B and the checker of the fused epilogue)
-      if (!(fe && fe[0] == '0') && c->oc_enabled && c->oc_plan && k <= kOc2DeflMax && !c->oc_orig_h.empty()) {
-        std::vector<double> Zi((size_t)k * c->oc_rows, 0.0);
+      if (want_fused) {
+        (void)fe;
+        std::vector<float> Zi((size_t)k * c->oc_rows, 0.0f);
         for (int q = 0; q < k; ++q)
-            for (int r = 0; r < c->oc_rows; ++r) { const int v = c->oc_orig_h[r]; if (v >= 0) Zi[(size_t)q * c->oc_rows + r] = Z[(size_t)q * nv + v]; }
+            for (int r = 0; r < c->oc_rows; ++r) { const int v = c->oc_orig_h[r]; if (v >= 0) Zi[(size_t)q * c->oc_rows + r] = (float)Z[(size_t)q * nv + v]; }
         c->defl_Zint.release(); c->defl_rec.release();
         HIP_TRY(c->defl_Zint.upload(Zi));
         HIP_TRY(c->defl_rec.alloc((size_t)2 * 3 * kOc2DeflMax * c->oc_G)); HIP_TRY(c->defl_rec.zero());

@@ -35,8 +35,9 @@ struct BigArgs {
     int row_lo, row_hi;                           // distributed solve: the internal rows this rank owns (aggregate-aligned)
 };
 
-constexpr int kBigVecT = 768;      // one row per thread (rocprofv3, 2 M tets: 1024 threads whose EVERY thread formed every final sum 70 us; 256 threads with
-                                   // three rows each 43 us -- seven waves per CU hide nothing; now the final sums are formed by 15 threads)
+constexpr int kBigVecT = 256;      // rocprofv3 at 2 M tets (profiles/r05_*_blob2m_launch_path_*.csv): 1024 threads whose EVERY thread formed every final sum
+                                   // 70 us; 256 threads with three rows each 43 us; 768 threads, one row each, 54 us (k_big_coarse 21 -> 34 us) -- the kernel
+                                   // streams 344 B per row from HBM (ten vectors of 8.5 MB), more waves per block only add barrier time
 // block-wide sum of NQ quantities over any number of waves (<= 16): wave sums to LDS, the first NQ threads add them up, everybody reads
 template <int NQ>
 __device__ __forceinline__ void block_sum_wide(double *q, double *lds /* [16 NQ + NQ] */) {

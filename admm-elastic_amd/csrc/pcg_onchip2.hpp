@@ -82,7 +82,8 @@ struct Oc2Args {
                          // launch a no-op -- lets the host enqueue outer iterations ahead without synchronising
     // END PROJECTION ON SOFT MODES (admm_hip_set_soft_modes; kernels.hpp: k_defl_* is the same step as separate launches): after a converged
     // solve x += Z (Z^T K Z)^-1 Z^T r on defl_k <= kOc2DeflMax smooth global vectors Z (internal row order, [defl_k][n_rows]).
-    int defl_k; const double *defl_Z, *defl_Ginv; double *defl_rec;      // defl_rec: [2][3 kOc2DeflMax][G] block sums, by solve parity
+    int defl_k; const float *defl_Z; const double *defl_Ginv; double *defl_rec;      // defl_Z: SINGLE precision (the step stays an exact Galerkin step: G is formed
+                                                                                     // from the rounded vectors); defl_rec: [2][3 kOc2DeflMax][G] block sums, by solve parity
 };
 constexpr int kOc2DeflMax = 32;
 
@@ -973,24 +974,25 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void *)a.defl_rec, 0, 2 * 3 * kOc2DeflMax * a.G * 8, 0x00020000);
         const size_t zrow0 = (size_t)blockIdx.x * (size_t)T;
         for (int q = wv; q < K; q += nw) {
-            const double *zq = a.defl_Z + (size_t)q * a.n_rows + zrow0 + lane;
-            double z[SPBMAX];
+            const float *zq = a.defl_Z + (size_t)q * a.n_rows + zrow0 + lane;
+            float z[SPBMAX];
 #pragma unroll
-            for (int i = 0; i < SPBMAX; ++i) z[i] = i < a.spb ? zq[64 * i] : 0.0;
+            for (int i = 0; i < SPBMAX; ++i) z[i] = i < a.spb ? zq[64 * i] : 0.0f;
             double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < SPBMAX; ++i)
                 if (i < a.spb) {
                     const int rl = lane + 64 * i;
-                    acc[0] = fma(z[i], vec[OC2_VX(rl, 0)], acc[0]); acc[1] = fma(z[i], vec[OC2_VX(rl, 1)], acc[1]); acc[2] = fma(z[i], vec[OC2_VX(rl, 2)], acc[2]);
+                    const double zd = (double)z[i];
+                    acc[0] = fma(zd, vec[OC2_VX(rl, 0)], acc[0]); acc[1] = fma(zd, vec[OC2_VX(rl, 1)], acc[1]); acc[2] = fma(zd, vec[OC2_VX(rl, 2)], acc[2]);
                 }
             acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]); acc[2] = wave_sum(acc[2]);
             if (lane < 3) oc_store_sc1(rs_d, ((dpar * 3 * kOc2DeflMax + 3 * q + lane) * a.G + (int)blockIdx.x) * 8, lane == 0 ? acc[0] : lane == 1 ? acc[1] : acc[2]);
         }
         // this row's entries of Z for the update below: in flight across the grid barrier
-        double zmine[kOc2DeflMax];
+        float zmine[kOc2DeflMax];
 #pragma unroll
-        for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K) ? a.defl_Z[(size_t)q * a.n_rows + row] : 0.0;
+        for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K) ? a.defl_Z[(size_t)q * a.n_rows + row] : 0.0f;
         ++be;
         if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) aborted = true;
         else {
@@ -1031,7 +1033,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
             for (int q = 0; q < kOc2DeflMax; ++q) {
                 if (q < K) {
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) rx[j] = fma(zmine[q], red[3 * kOc2DeflMax + 3 * q + j], rx[j]);
+                    for (int j = 0; j < 3; ++j) rx[j] = fma((double)zmine[q], red[3 * kOc2DeflMax + 3 * q + j], rx[j]);
                 }
             }
         }

@@ -27,7 +27,7 @@ def test_library_modes_are_the_lowest_eigenvectors():
     K = _K(s, sc)
     assert Z.shape == (12, len(sc.x))
     G = Z @ Z.T
-    assert np.abs(G - np.eye(12)).max() < 1e-8                       # orthonormal
+    assert np.abs(G - np.eye(12)).max() < 1e-6                       # orthonormal (to the single precision the fused projection stores them in)
     ritz = np.array([z @ (K @ z) for z in Z])
     assert (np.diff(ritz) > -1e-9 * ritz[-1]).all()                  # ascending
     ew = np.linalg.eigvalsh(K.toarray())[:12]
