@@ -494,6 +494,9 @@ int oc_diagnostics(admm_hip_ctx *c, int seq) {
     if (c->oc_plan) {   // k_pcg2: eight stamps per pipelined iteration
         fprintf(stderr, "[oc_prof] seq %d: LDS fill %.2f  start phase %.2f  loop + end game %.2f  epilogue %.2f us\n", seq, us(63 * 8 + 1, 63 * 8), us(63 * 8 + 2, 63 * 8 + 1),
                 us(63 * 8 + 3, 63 * 8 + 2), us(63 * 8 + 4, 63 * 8 + 3));
+        if (h[63 * 8 + 7] > h[63 * 8 + 3])
+            fprintf(stderr, "[oc_prof] end projection on the soft modes: pair stores + dots %.2f  grid barrier %.2f  reduce %.2f  G^-1 d + update + stores %.2f us\n",
+                    us(63 * 8 + 5, 63 * 8 + 3), us(63 * 8 + 6, 63 * 8 + 5), us(63 * 8 + 7, 63 * 8 + 6), us(63 * 8 + 4, 63 * 8 + 7));
         if (h[62 * 8 + 6] > h[62 * 8])
             fprintf(stderr, "[oc_prof] start: entry residual %.2f  recycled sums %.2f  barrier %.2f  reduce + Cholesky %.2f  coarse(r) %.2f  u exchange + rows %.2f  record %.2f  barrier + reduce + coarse(w) %.2f us\n",
                     us(62 * 8, 63 * 8 + 1), us(62 * 8 + 1, 62 * 8), us(62 * 8 + 2, 62 * 8 + 1), us(62 * 8 + 3, 62 * 8 + 2), us(62 * 8 + 4, 62 * 8 + 3),

@@ -993,9 +993,11 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         float zmine[kOc2DeflMax];
 #pragma unroll
         for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K) ? a.defl_Z[(size_t)q * a.n_rows + row] : 0.0f;
+        if (prof) a.prof[63 * 8 + 5] = wall_clock64();
         ++be;
         if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) aborted = true;
         else {
+            if (prof) a.prof[63 * 8 + 6] = wall_clock64();
             // the blocks' sums, every block in the same order: wave w the quantities w, w + nw, ... (<= 8 of 96 with 12 waves), four blocks per lane
             constexpr int QW = (3 * kOc2DeflMax + 11) / 12 + 1;
             double part[QW][4];
@@ -1022,6 +1024,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                 if (lane == 0) red[k] = sm;
             }
             __syncthreads();
+            if (prof) a.prof[63 * 8 + 7] = wall_clock64();
             for (int o = tid; o < 3 * K; o += T) {       // y = G^-1 d, from LDS
                 const int q = o / 3, ax = o - 3 * q;
                 double acc = 0.0;
