@@ -947,12 +947,16 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     } while (false);
     if (prof) a.prof[63 * 8 + 3] = wall_clock64();
 #undef OC2_STAMP
-    if (live && a.rc_on) {   // this solve's pair: e = x - x_entry, A e = r_entry - r_final (exact: u carries the true residual; taken BEFORE the
-#pragma unroll           // end projection below, which moves x without updating r)
+    // this solve's pair: e = x - x_entry, A e = r_entry - r_final (exact: u carries the true residual).  Formed BEFORE the end projection below,
+    // which moves x without updating r; STORED behind it: on this hardware a wave's loads return in order with its stores, so six stores per row
+    // in front of the projection's loads cost it 10 us (measured: ADMM_HIP_OC_PROF)
+    double pe[3] = {0.0, 0.0, 0.0}, pr[3] = {0.0, 0.0, 0.0};
+    if (live && a.rc_on) {
+#pragma unroll
         for (int j = 0; j < 3; ++j) {
             const size_t i = 3 * (size_t)row + j;
-            a.rc_Eslot[i] = rx[j] - a.rc_xs[i];
-            a.rc_Rslot[i] = a.rc_r0[i] - ru[j] * fast_rcp(rd[j]);
+            pe[j] = rx[j] - a.rc_xs[i];
+            pr[j] = a.rc_r0[i] - ru[j] * fast_rcp(rd[j]);
         }
     }
     if (a.defl_k > 0 && conv && !aborted) {
@@ -1044,6 +1048,10 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     if (live) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { a.x[3 * (size_t)vi + j] = rx[j]; a.u_out[3 * (size_t)vi + j] = ru[j]; }
+        if (a.rc_on) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const size_t i = 3 * (size_t)row + j; a.rc_Eslot[i] = pe[j]; a.rc_Rslot[i] = pr[j]; }
+        }
     }
     if (blockIdx.x == 0 && tid == 0) {
         CgScal o;
