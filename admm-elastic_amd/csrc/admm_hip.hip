@@ -553,7 +553,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.cwt = c->oc_cwt.p;
     a.skip = rc.skip;
     a.trust_short = c->oc_always_verify ? 0 : 1;
-    if (rc.on && c->defl_fused && c->defl_k > 0 && c->defl_now) { a.defl_k = c->defl_k; a.defl_Z = c->defl_Zint.p; a.defl_Ginv = c->defl_Ginv.p; a.defl_rec = c->defl_rec.p; }      // (the ADMM loop's solves only: not the K^-1 columns of UzawaCG)
+    if (rc.on && c->defl_fused && c->defl_k > 0 && c->defl_now) { static const int dbg = getenv("ADMM_HIP_DEFL_DBG") ? atoi(getenv("ADMM_HIP_DEFL_DBG")) : 0; a.defl_dbg = dbg; a.defl_k = c->defl_k; a.defl_Z = c->defl_Zint.p; a.defl_Ginv = c->defl_Ginv.p; a.defl_rec = c->defl_rec.p; }      // (the ADMM loop's solves only: not the K^-1 columns of UzawaCG)
     a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b; a.sm_c0 = c->oc_sm_c0; a.sm_k1 = c->oc_sm_k1; a.sm_k2 = c->oc_sm_k2;
     c->oc_launches += 1;
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);

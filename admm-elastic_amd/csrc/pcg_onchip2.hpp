@@ -82,6 +82,7 @@ struct Oc2Args {
                          // launch a no-op -- lets the host enqueue outer iterations ahead without synchronising
     // END PROJECTION ON SOFT MODES (admm_hip_set_soft_modes; kernels.hpp: k_defl_* is the same step as separate launches): after a converged
     // solve x += Z (Z^T K Z)^-1 Z^T r on defl_k <= kOc2DeflMax smooth global vectors Z (internal row order, [defl_k][n_rows]).
+    int defl_dbg;      // (experiments: bit 0 no mode loads in the dots, bit 1 no own-row loads, bit 2 no G^-1 staging)
     int defl_k; const float *defl_Z; const double *defl_Ginv; double *defl_rec;      // defl_Z: SINGLE precision (the step stays an exact Galerkin step: G is formed
                                                                                      // from the rounded vectors); defl_rec: [2][3 kOc2DeflMax][G] block sums, by solve parity
 };
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         }
         // (G^-1 into LDS behind the dots: the slab's first K K doubles are not needed any more)
         LdsD *ginv_l = lv_all;
-        for (int o = tid; o < K * K; o += T) ginv_l[o] = a.defl_Ginv[o];
+        if (!(a.defl_dbg & 4)) for (int o = tid; o < K * K; o += T) ginv_l[o] = a.defl_Ginv[o];
         __syncthreads();
         __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void *)a.defl_rec, 0, 2 * 3 * kOc2DeflMax * a.G * 8, 0x00020000);
         const size_t zrow0 = (size_t)blockIdx.x * (size_t)T;
@@ -981,7 +982,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
             const float *zq = a.defl_Z + (size_t)q * a.n_rows + zrow0 + lane;
             float z[SPBMAX];
 #pragma unroll
-            for (int i = 0; i < SPBMAX; ++i) z[i] = i < a.spb ? zq[64 * i] : 0.0f;
+            for (int i = 0; i < SPBMAX; ++i) z[i] = (i < a.spb && !(a.defl_dbg & 1)) ? zq[64 * i] : 0.0f;
             double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < SPBMAX; ++i)
@@ -996,7 +997,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         // this row's entries of Z for the update below: in flight across the grid barrier
         float zmine[kOc2DeflMax];
 #pragma unroll
-        for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K) ? a.defl_Z[(size_t)q * a.n_rows + row] : 0.0f;
+        for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K && !(a.defl_dbg & 2)) ? a.defl_Z[(size_t)q * a.n_rows + row] : 0.0f;
         if (prof) a.prof[63 * 8 + 5] = wall_clock64();
         ++be;
         if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) aborted = true;
