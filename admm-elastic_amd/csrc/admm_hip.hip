@@ -3063,10 +3063,9 @@ int admm_hip_set_soft_modes(admm_hip_ctx *c, int32_t k, const double *Z) {
     { const char *fe = getenv("ADMM_HIP_DEFL_FUSED");      // (=0: the separate k_defl_* launches, the A/B and the checker of the fused epilogue)
       if (want_fused) {
         (void)fe;
-        std::vector<float> Zi((size_t)k * c->oc_rows, 0.0f);      // [block][mode][row of the block] (pcg_onchip2.hpp)
-        const int T = c->oc_T;
+        std::vector<float> Zi((size_t)k * c->oc_rows, 0.0f);      // [mode][internal row] (pcg_onchip2.hpp)
         for (int q = 0; q < k; ++q)
-            for (int r = 0; r < c->oc_rows; ++r) { const int v = c->oc_orig_h[r]; if (v >= 0) Zi[((size_t)(r / T) * k + q) * T + (r % T)] = (float)Z[(size_t)q * nv + v]; }
+            for (int r = 0; r < c->oc_rows; ++r) { const int v = c->oc_orig_h[r]; if (v >= 0) Zi[(size_t)q * c->oc_rows + r] = (float)Z[(size_t)q * nv + v]; }
         c->defl_Zint.release(); c->defl_rec.release();
         HIP_TRY(c->defl_Zint.upload(Zi));
         HIP_TRY(c->defl_rec.alloc((size_t)2 * 3 * kOc2DeflMax * c->oc_G)); HIP_TRY(c->defl_rec.zero());

@@ -977,11 +977,12 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         if (!(a.defl_dbg & 4)) for (int o = tid; o < K * K; o += T) ginv_l[o] = a.defl_Ginv[o];
         __syncthreads();
         __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void *)a.defl_rec, 0, 2 * 3 * kOc2DeflMax * a.G * 8, 0x00020000);
-        // modes: [block][mode][row of the block], single precision -- a block's slice is ONE contiguous run (K T floats: 74 KB at 24 modes), read
-        // once from HBM by the dots and again, out of the XCD's L2, by the update (mode-major over all rows: 17 us for the two passes, measured)
-        const float *zblk = a.defl_Z + (size_t)blockIdx.x * (size_t)K * (size_t)T;
+        // modes: [mode][internal row], single precision.  (Measured, ADMM_HIP_OC_PROF + ADMM_HIP_DEFL_DBG: of the step's ~33 us at 24 modes the two
+        // passes over the modes are 17 -- 2 x 19 MB of first-touch HBM reads --, the grid barrier 3-8, the reduction of the 72 sums 4.7; a
+        // [block][mode][row] layout, one contiguous 74-KB slice per block, was SLOWER: 44 us.)
+        const size_t zrow0 = (size_t)blockIdx.x * (size_t)T;
         for (int q = wv; q < K; q += nw) {
-            const float *zq = zblk + (size_t)q * T + lane;
+            const float *zq = a.defl_Z + (size_t)q * a.n_rows + zrow0 + lane;
             float z[SPBMAX];
 #pragma unroll
             for (int i = 0; i < SPBMAX; ++i) z[i] = (i < a.spb && !(a.defl_dbg & 1)) ? zq[64 * i] : 0.0f;
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         // this row's entries of Z for the update below: in flight across the grid barrier
         float zmine[kOc2DeflMax];
 #pragma unroll
-        for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K && !(a.defl_dbg & 2)) ? zblk[(size_t)q * T + tid] : 0.0f;
+        for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K && !(a.defl_dbg & 2)) ? a.defl_Z[(size_t)q * a.n_rows + row] : 0.0f;
         if (prof) a.prof[63 * 8 + 5] = wall_clock64();
         ++be;
         if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) aborted = true;
