@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.." || exit 1
 O=${1:-gpurun_out/r05_size}; mkdir -p $O
 for n in 74 93 118 130 148 187; do
-  timeout 1500 python bench.py --workload blob1m_mix --n $n --steps 10 --warmup 4 --no-cpu-baseline > $O/size_$n.json 2> $O/size_$n.err
+  timeout 1500 python bench.py --workload blob1m_mix --n $n --steps 10 --warmup 5 --no-cpu-baseline > $O/size_$n.json 2> $O/size_$n.err
   python - $O/size_$n.json <<'PY'
 import json, sys
 try:
