@@ -28,7 +28,7 @@ def run(tol, mx, verify, env=None, ref=None):
         os.environ[k] = v
     os.environ["ADMM_HIP_OC_VERIFY"] = "1" if verify else "0"
     try:
-        s = sc.make_solver(pcg_tol=tol, pcg_max_iters=mx)
+        s = sc.make_solver(pcg_tol=tol, pcg_max_iters=mx, soft_modes=int((env or {}).get("SOFTSET", "0")))      # SOFTSET=k: Settings.soft_modes (the product path, environment switches in effect)
     finally:
         os.environ.pop("ADMM_HIP_OC_VERIFY", None)
         for k in (env or {}):
