@@ -226,7 +226,7 @@ struct admm_hip_ctx {
     int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
     DevBuf<unsigned long long> gs_proj; long long uz_rows_total = 0;   // admm_hip_contact_totals: rows projected inside the GS sweeps (device), rows of C over all UzawaCG solves (host)
     // launch-path two-level PCG (pcg_big.hpp): systems beyond the chip's LDS, and the fall-back of the on-chip kernel
-    bool big_enabled = false, big_tried = false, big_allowed = true; std::vector<double> xyz_h;
+    bool big_enabled = false, big_tried = false, big_allowed = true; int defl_dbg = 0; std::vector<double> xyz_h;
     int big_G = 0, big_ra = 0, big_rows = 0, big_nc = 0, big_ncp = 0, big_NBt = 0;
     SellDev big_A; DevBuf<int> big_orig; DevBuf<float> big_ainv;
     DevBuf<double> big_mass, big_dinv, big_cwt, big_xi, big_r, big_u, big_w, big_p, big_s, big_part, big_cvec, big_rho;
@@ -553,7 +553,7 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.cwt = c->oc_cwt.p;
     a.skip = rc.skip;
     a.trust_short = c->oc_always_verify ? 0 : 1;
-    if (rc.on && c->defl_fused && c->defl_k > 0 && c->defl_now) { static const int dbg = getenv("ADMM_HIP_DEFL_DBG") ? atoi(getenv("ADMM_HIP_DEFL_DBG")) : 0; a.defl_dbg = dbg; a.defl_k = c->defl_k; a.defl_Z = c->defl_Zint.p; a.defl_Ginv = c->defl_Ginv.p; a.defl_rec = c->defl_rec.p; }      // (the ADMM loop's solves only: not the K^-1 columns of UzawaCG)
+    if (rc.on && c->defl_fused && c->defl_k > 0 && c->defl_now) { a.defl_dbg = c->defl_dbg; a.defl_k = c->defl_k; a.defl_Z = c->defl_Zint.p; a.defl_Ginv = c->defl_Ginv.p; a.defl_rec = c->defl_rec.p; }      // (the ADMM loop's solves only: not the K^-1 columns of UzawaCG)
     a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b; a.sm_c0 = c->oc_sm_c0; a.sm_k1 = c->oc_sm_k1; a.sm_k2 = c->oc_sm_k2;
     c->oc_launches += 1;
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
@@ -2105,6 +2105,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->counters.alloc(8 + 64 + 8)); HIP_TRY(c->counters.zero());   // [72..74]: totals since create (on-chip PCG)
     c->create_xyz = d->vert_xyz;
     { const char *e = getenv("ADMM_HIP_BIG"); c->big_allowed = !(e && e[0] == '0'); }
+    { const char *e = getenv("ADMM_HIP_DEFL_DBG"); if (e) c->defl_dbg = atoi(e); }      // (experiments; bit 3 = the recycled pair carries the soft step: 9.28 -> 8.93 iterations per solve, +1 % ADMM it/s, 200-frame drift 3.9e-6 -> 6.1e-6: off)
     if (d->vert_xyz && d->linsolver != 1) c->xyz_h.assign(d->vert_xyz, d->vert_xyz + c->n3);      // (the launch-path two-level PCG plans lazily)
     {   // distributed solve of ONE body (ADMM_HIP_DIST_SOLVE=1, element-block partition): contiguous vertex rows per rank, 64-aligned
         const char *de = getenv("ADMM_HIP_DIST_SOLVE");

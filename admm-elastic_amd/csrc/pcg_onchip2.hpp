@@ -1045,6 +1045,10 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                 if (q < K) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) rx[j] = fma((double)zmine[q], red[3 * kOc2DeflMax + 3 * q + j], rx[j]);
+                    if (a.defl_dbg & 8) {      // the pair carries the soft step too: e += Z y, A e += K Z y ~ Z (G y) = Z d (Z: Ritz vectors of K)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) { pe[j] = fma((double)zmine[q], red[3 * kOc2DeflMax + 3 * q + j], pe[j]); pr[j] = fma((double)zmine[q], red[3 * q + j], pr[j]); }
+                    }
                 }
             }
         }
