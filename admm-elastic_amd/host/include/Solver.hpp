@@ -20,13 +20,15 @@ namespace solver_detail {
 
 // Solver::Settings (src/Solver.hpp:39-50): command-line switches in the comments
 struct SolverSettings {
-    SolverSettings() : timestep_s(1.0 / 24.0), verbose(1), admm_iters(10), gravity(-9.8), linsolver(0), constraint_w(-1) {}
+    SolverSettings() : timestep_s(1.0 / 24.0), verbose(1), admm_iters(10), gravity(-9.8), linsolver(0), constraint_w(-1), soft_modes(0) {}
     double timestep_s;   // -dt
     int verbose;         // -v
     int admm_iters;      // -it
     double gravity;      // -g
     int linsolver;       // -ls  0 = LDLT (here: GPU PCG), 1 = NCMCGS, 2 = UzawaCG
     double constraint_w; // -ck  (-1 = automatic)
+    int soft_modes;      // -sm  (GPU build, appended: the reference's fields keep their order) every PCG solve ends with an exact Galerkin step on
+                         //      the k softest modes of the system matrix (admm_hip_compute_soft_modes at initialize); 0 = off
     void help();
     bool parse_args(int argc, char **argv);   // true when help() was printed
 };
@@ -87,6 +89,7 @@ public:
     bool build_global_matrices;                                   // initialize() fills m_D / m_Dt / m_W_diag / solver_Dt_Wt_W (default true, like
                                                                   // the reference; the GPU path itself never reads them -- switch off for very large scenes)
     std::shared_ptr<LinearSolver> linear_solver() { return m_linsolver; }
+    void *context() { return m_ctx; }                             // the admm_hip_ctx behind this solver (include/admm_hip.h), for the C ABI's extras
 
 protected:
     void release();

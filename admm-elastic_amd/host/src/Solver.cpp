@@ -559,6 +559,8 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
         check(admm_hip_add_dynamic_tetmesh(ctx, f.vert_offset, (int32_t)(f.rest.size() / 3), f.rest.data(), (int32_t)(f.tets.size() / 4),
                                            f.tets.data(), (int32_t)(f.faces.size() / 3), f.faces.data()), "Solver::initialize");
     m_linsolver->attach(ctx);
+    if (m_settings.soft_modes > 0 && m_settings.linsolver != 1)      // (not in any step: inverse subspace iteration with the context's own solver)
+        check(admm_hip_compute_soft_modes(ctx, (int32_t)m_settings.soft_modes, 0), "Solver::initialize (soft modes)");
     // keep the assembled matrix host-side (save_matrix, LinearSolver::matrix)
     int32_t nnz = 0;
     check(admm_hip_get_matrix(ctx, nullptr, nullptr, nullptr, &nnz), "Solver::initialize");
@@ -606,6 +608,7 @@ const Switch kSwitches[] = {
     {"-g", &Solver::Settings::gravity, nullptr, "gravity (m/s^2)"},
     {"-ls", nullptr, &Solver::Settings::linsolver, "linear solver (0=LDLT as GPU PCG, 1=NCMCGS, 2=UzawaCG) "},
     {"-ck", &Solver::Settings::constraint_w, nullptr, "constraint weights (-1 = auto) "},
+    {"-sm", nullptr, &Solver::Settings::soft_modes, "soft modes of the PCG's end projection (GPU build; 0 = off) "},
 };
 bool wants_help(const char *a) { const std::string s(a); return s == "-help" || s == "--help" || s == "-h"; }
 } // namespace

@@ -2,10 +2,13 @@
 // (src/NodalMultiColorGS.hpp:40-46 used at :100; src/UzawaCG.hpp:44-45 used at :92), so user code may cast the solver and change
 // them between steps.  Multi-colour GS at tolerance 1e-10 never converges in 30 sweeps, so the inner iteration
 // count of a step is exactly admm_iters x max_iters: halving max_iters must halve it.
+#include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <memory>
 #include <vector>
 #include "Solver.hpp"
+#include "../../include/admm_hip.h"
 #include "TetEnergyTerm.hpp"
 
 using namespace admm;
@@ -68,6 +71,27 @@ int main() {
         const int capped = solver.runtime_data().inner_iters;
         printf("UzawaCG: inner_iters %d with max_iters 20, %d with max_iters 2\n", full, capped);
         if (!(full > 8 * 2 && capped <= 8 * 2 && capped > 0)) { fprintf(stderr, "FAILURE: UzawaCG max_iters changed after initialize was not honoured\n"); ++failures; }
+    }
+    {   // ---- Settings::soft_modes (GPU build): the end projection changes a converged trajectory by no more than the tolerance ----
+        VecX xs[2];
+        for (int pass = 0; pass < 2; ++pass) {
+            Solver solver;
+            solver.add_nodes(verts.data(), m.data(), nv);
+            create_tets_from_mesh<double, NeoHookeanTet>(solver.energyterms, verts.data(), tets.data(), nt, Lame::soft_rubber(), 0);
+            std::vector<int> pins;
+            for (int j = 0; j <= n; ++j) for (int k = 0; k <= n; ++k) pins.push_back(vid(0, j, k));
+            solver.set_pins(pins);
+            Solver::Settings st; st.verbose = 0; st.admm_iters = 8; st.linsolver = 0; st.soft_modes = pass ? 6 : 0;
+            if (!solver.initialize(st)) return 2;
+            int32_t k = -1;
+            if (admm_hip_get_soft_modes((admm_hip_ctx *)solver.context(), &k, nullptr) != ADMM_HIP_OK || k != st.soft_modes) { fprintf(stderr, "FAILURE: %d soft modes installed, %d asked for\n", (int)k, st.soft_modes); ++failures; }
+            for (int f = 0; f < 3; ++f) solver.step();
+            xs[pass] = solver.m_x;
+        }
+        double dmax = 0.0, moved = 0.0;
+        for (int i = 0; i < 3 * nv; ++i) { dmax = std::max(dmax, std::fabs(xs[0][i] - xs[1][i])); moved = std::max(moved, std::fabs(xs[0][i] - verts[i])); }
+        printf("soft modes: trajectories differ by %.2e (moved %.2e)\n", dmax, moved);
+        if (!(dmax < 1e-8 && moved > 1e-3)) { fprintf(stderr, "FAILURE: Settings::soft_modes changed the converged trajectory\n"); ++failures; }
     }
     if (failures) return 1;
     printf("SUCCESS\n");
