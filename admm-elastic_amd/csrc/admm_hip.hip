@@ -229,7 +229,7 @@ struct admm_hip_ctx {
     bool big_enabled = false, big_tried = false, big_allowed = true; int defl_dbg = 0; std::vector<double> xyz_h;
     int big_G = 0, big_ra = 0, big_rows = 0, big_nc = 0, big_ncp = 0, big_NBt = 0;
     SellDev big_A; DevBuf<int> big_orig; DevBuf<float> big_ainv;
-    DevBuf<double> big_mass, big_dinv, big_cwt, big_xi, big_r, big_u, big_w, big_p, big_s, big_part, big_cvec, big_rho;
+    DevBuf<double> big_mass, big_dinv, big_cwt, big_xi, big_r, big_u, big_w, big_p, big_s, big_part, big_cvec, big_rho, big_dots; DevBuf<int> big_tick;
     long long big_solves = 0;
     int big_row_lo = 0, big_row_hi = 0x7fffffff, big_nif = 0; DevBuf<int> big_if_rows; DevBuf<double> big_ifbuf;      // distributed solve: owned internal rows, interface rows
     // end projection of every PCG solve on soft modes (admm_hip_set_soft_modes; kernels.hpp: k_defl_*)
@@ -342,7 +342,7 @@ struct admm_hip_ctx {
         gsp_box.release(); gsp_part.release(); gsp_meet.release(); gsp_abort.release(); gsp_prof.release(); gs_proj.release();
         defl_Z.release(); defl_Ginv.release(); defl_part.release(); defl_y.release(); defl_Zint.release(); defl_rec.release();
         big_A.release(); big_orig.release(); big_ainv.release(); big_mass.release(); big_dinv.release(); big_cwt.release(); big_xi.release(); big_r.release();
-        big_u.release(); big_w.release(); big_p.release(); big_s.release(); big_part.release(); big_cvec.release(); big_rho.release(); big_if_rows.release(); big_ifbuf.release();
+        big_u.release(); big_w.release(); big_p.release(); big_s.release(); big_part.release(); big_dots.release(); big_tick.release(); big_cvec.release(); big_rho.release(); big_if_rows.release(); big_ifbuf.release();
         rc_buf.release(); rc_r0.release(); rc_xs.release(); rc_part.release(); rc_coef.release();
         uz_cn.release(); uz_cc.release(); uz_y.release(); uz_r.release(); uz_d.release(); uz_q3.release(); uz_q1.release(); uz_dmax.release(); uz_dacc.release();
         uz_q2.release(); uz_part.release(); uz_scal.release();
@@ -765,7 +765,7 @@ bool ensure_big_plan(admm_hip_ctx *c) {
         !ok(c->big_mass.upload(P.mass)) || !ok(c->big_dinv.upload(P.dinv)) || !ok(c->big_cwt.upload(P.cwt)) ||
         !ok(c->big_xi.alloc(n3r)) || !ok(c->big_r.alloc(n3r)) || !ok(c->big_u.alloc(n3r)) || !ok(c->big_w.alloc(n3r)) || !ok(c->big_p.alloc(n3r)) || !ok(c->big_s.alloc(n3r)) ||
         !ok(c->big_u.zero()) || !ok(c->big_w.zero()) || !ok(c->big_r.zero()) ||
-        !ok(c->big_part.alloc((size_t)6 * (P.n_rows / 256))) || !ok(c->big_cvec.alloc((size_t)3 * P.ncp + (size_t)3 * P.G)) || !ok(c->big_cvec.zero())) {      // (c and rho side by side: one all-reduce in the distributed solve)
+        !ok(c->big_part.alloc((size_t)6 * (P.n_rows / 256))) || !ok(c->big_dots.alloc(8)) || !ok(c->big_dots.zero()) || !ok(c->big_tick.alloc(2)) || !ok(c->big_tick.zero()) || !ok(c->big_cvec.alloc((size_t)3 * P.ncp + (size_t)3 * P.G)) || !ok(c->big_cvec.zero())) {      // (c and rho side by side: one all-reduce in the distributed solve)
         (void)hipGetLastError();
         return false;
     }
@@ -807,14 +807,14 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
     a.n_rows = c->big_rows; a.NBt = c->big_NBt; a.G = c->big_G; a.ra = c->big_ra; a.nc = c->big_nc; a.ncp = c->big_ncp;
     a.b_api = b; a.x_api = x; a.u_api = c->cg_u.p; a.dinv_api = c->dinv.p;
     a.xi = c->big_xi.p; a.r = c->big_r.p; a.u = c->big_u.p; a.w = c->big_w.p; a.p = c->big_p.p; a.s = c->big_s.p;
-    a.part = c->big_part.p; a.cvec = c->big_cvec.p; a.rho = c->big_cvec.p + (size_t)3 * c->big_ncp;
+    a.part = c->big_part.p; a.dots = c->big_dots.p; a.tick = c->big_tick.p; a.cvec = c->big_cvec.p; a.rho = c->big_cvec.p + (size_t)3 * c->big_ncp;
     a.scal = c->cg_scal.p; a.counters = c->counters.p; a.sig = c->d_sig;
     a.tol2 = c->pcg_tol * c->pcg_tol; a.seq = ++c->solve_seq;
     a.row_lo = c->big_row_lo; a.row_hi = c->big_row_hi;
     const int nbr = c->big_rows / 256;
     if (c->dist_solve) {
-        // DISTRIBUTED: the same kernels on the rank's own aggregates; per iteration three small sum all-reduces -- the dot-product partials
-        // (6 NBt doubles), c = P^T r with rho (3 ncp + 3 G), the interface rows of u (3 n_if) -- instead of the whole vector (round 4).  Every
+        // DISTRIBUTED: the same kernels on the rank's own aggregates; per iteration three small sum all-reduces -- the six dot products
+        // (summed per rank by its last block), c = P^T r with rho (3 ncp + 3 G), the interface rows of u (3 n_if) -- instead of the whole vector (round 4).  Every
         // rank derives the same scalars from the same numbers, reaches the same verdict at the same iteration, and stops at the same chunk
         // boundary (the device reports the iteration it converged at), so the ranks issue the same collectives.
         const size_t ncr = (size_t)3 * c->big_ncp + (size_t)3 * c->big_G;
@@ -828,7 +828,7 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
         };
         hipLaunchKernelGGL(k_big_gather, dim3(nbr), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_big_resid, dim3(c->big_NBt), dim3(256), 0, st, a);
-        if (int r = comm_allreduce(c, c->big_part.p, (size_t)3 * c->big_NBt)) return r;
+        if (int r = comm_allreduce(c, c->big_dots.p, 3)) return r;
         hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1, 0);
         if (int r = comm_allreduce(c, c->big_cvec.p, ncr)) return r;
         hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1);
@@ -840,7 +840,7 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
             const int n = std::min(chunk, max_iters - launched);
             for (int it = launched; it < launched + n; ++it) {
                 hipLaunchKernelGGL(k_big_spmv, dim3(c->big_NBt), dim3(256), 0, st, a, it);
-                if (int r = comm_allreduce(c, c->big_part.p, (size_t)6 * c->big_NBt)) return r;
+                if (int r = comm_allreduce(c, c->big_dots.p, 6)) return r;
                 hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, it, (it == launched + n - 1) ? 1 : 0);
                 if (int r = comm_allreduce(c, c->big_cvec.p, ncr)) return r;
                 hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(kBigVecT), 0, st, a, it);
@@ -943,7 +943,7 @@ void launch_deflation(admm_hip_ctx *c, const double *b, double *x) {
     hipStream_t st = c->stream;
     const int NB = c->NB, k = c->defl_k;
     hipLaunchKernelGGL(k_defl_dots, dim3(NB), dim3(256), 0, st, sell_arg(c->A), c->m.p, b, x, k, c->defl_Z.p, c->nv, c->defl_part.p, NB);
-    hipLaunchKernelGGL(k_defl_solve, dim3(1), dim3(256), 0, st, k, c->defl_part.p, NB, c->defl_Ginv.p, c->defl_y.p);
+    hipLaunchKernelGGL(k_defl_solve, dim3(1), dim3(1024), 0, st, k, c->defl_part.p, NB, c->defl_Ginv.p, c->defl_y.p);
     hipLaunchKernelGGL(k_defl_apply, dim3(blocks_for(c->nv)), dim3(256), 0, st, c->nv, k, c->defl_Z.p, c->defl_y.p, x);
 }
 

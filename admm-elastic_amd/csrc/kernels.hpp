@@ -1152,8 +1152,8 @@ __global__ __launch_bounds__(256) void k_rc_apply(int n3, RcBasis B, const doubl
 constexpr int kDeflMax = 64;
 __global__ __launch_bounds__(256) void k_defl_dots(SellA A, const double *__restrict__ m, const double *__restrict__ b, const double *__restrict__ x,
                                                    int k, const double *__restrict__ Z, int nv, double *__restrict__ part, int NB) {
-    __shared__ double lds[12];
-    const int lane = threadIdx.x & 63;
+    __shared__ double lds[4][3 * kDeflMax];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int s = wave_slice();
     double r[3] = {0.0, 0.0, 0.0};
     int row = -1;
@@ -1166,24 +1166,35 @@ __global__ __launch_bounds__(256) void k_defl_dots(SellA A, const double *__rest
             for (int j = 0; j < 3; ++j) { const size_t i = 3 * (size_t)row + j; r[j] = b[i] - fma(m[i], x[i], acc[j]); }
         } else row = -1;
     }
-    for (int q = 0; q < k; ++q) {
-        const double z = row >= 0 ? Z[(size_t)q * nv + row] : 0.0;
-        double t[3] = {z * r[0], z * r[1], z * r[2]};
-        block_sum<3>(t, lds);
-        if (threadIdx.x == 0) { part[(size_t)(3 * q) * NB + blockIdx.x] = t[0]; part[(size_t)(3 * q + 1) * NB + blockIdx.x] = t[1]; part[(size_t)(3 * q + 2) * NB + blockIdx.x] = t[2]; }
-    }
-}
-__global__ __launch_bounds__(256) void k_defl_solve(int k, const double *__restrict__ part, int NB, const double *__restrict__ Ginv, double *__restrict__ y) {
-    __shared__ double lds[12];
-    __shared__ double d[3 * kDeflMax];
-    for (int q = 0; q < 3 * k; ++q) {
-        double t[1] = {0.0};
-        for (int i = threadIdx.x; i < NB; i += 256) t[0] += part[(size_t)q * NB + i];
-        block_sum<1>(t, lds);
-        if (threadIdx.x == 0) d[q] = t[0];
+    // eight modes' loads in flight, ONE wave sum per mode and axis, the four waves' sums added once at the end (a block-wide sum per mode
+    // -- 24 block barriers -- cost 101 us at 2 M tets: rocprofv3, profiles/r05_a_kernel_stats_blob2m_launch_path.csv)
+    for (int q0 = 0; q0 < k; q0 += 8) {
+        double z[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = (row >= 0 && q0 + i < k) ? Z[(size_t)(q0 + i) * nv + row] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (q0 + i < k) {
+                const double t0 = wave_sum(z[i] * r[0]), t1 = wave_sum(z[i] * r[1]), t2 = wave_sum(z[i] * r[2]);
+                if (lane == 0) { lds[wv][3 * (q0 + i)] = t0; lds[wv][3 * (q0 + i) + 1] = t1; lds[wv][3 * (q0 + i) + 2] = t2; }
+            }
+        }
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < 3 * k; o += 256) {      // y[q][axis] = sum_p Ginv[q][p] d[p][axis]
+    for (int o = threadIdx.x; o < 3 * k; o += 256) part[(size_t)o * NB + blockIdx.x] = (lds[0][o] + lds[1][o]) + (lds[2][o] + lds[3][o]);
+}
+// one block of 1024 threads: wave w adds up the quantities w, w + 16, ... over the blocks (lanes stride the blocks: fixed order), then y = G^-1 d
+__global__ __launch_bounds__(1024) void k_defl_solve(int k, const double *__restrict__ part, int NB, const double *__restrict__ Ginv, double *__restrict__ y) {
+    __shared__ double d[3 * kDeflMax];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
+    for (int q = wv; q < 3 * k; q += nw) {
+        double t = 0.0;
+        for (int i = lane; i < NB; i += 64) t += part[(size_t)q * NB + i];
+        t = wave_sum(t);
+        if (lane == 0) d[q] = t;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 3 * k; o += (int)blockDim.x) {      // y[q][axis] = sum_p Ginv[q][p] d[p][axis]
         const int q = o / 3, ax = o % 3;
         double acc = 0.0;
         for (int pp = 0; pp < k; ++pp) acc = fma(Ginv[q * k + pp], d[3 * pp + ax], acc);

@@ -27,6 +27,7 @@ struct BigArgs {
     const double *dinv_api;
     double *xi, *r, *u, *w, *p, *s;               // internal order [3 n_rows]
     double *part;                                 // [6][NBt]: gamma / delta partials of k_big_spmv; [3][NBt] of the entry residual's b.D^-1 b
+    double *dots; int *tick;                      // [6]: their sums, formed by the LAST block of the kernel that wrote the partials (ticket counter)
     double *cvec;                                 // [3][ncp]: c = P^T r
     double *rho;                                  // [3][G]: r.D^-1 r per aggregate
     CgScal *scal;                                 // two slots, alternating by iteration parity
@@ -53,6 +54,36 @@ __device__ __forceinline__ void block_sum_wide(double *q, double *lds /* [16 NQ 
 #pragma unroll
     for (int i = 0; i < NQ; ++i) q[i] = lds[16 * NQ + i];
     __syncthreads();
+}
+
+
+// The partial sums of a kernel's blocks, added up by whichever block finishes LAST (ticket counter), in the fixed order of the block
+// index: one reduction per launch instead of one per consumer block (every block of k_big_vec re-reduced 6 NBt doubles -- 133 KB at
+// 4 M tets).  Partials and ticket travel at agent scope (the XCDs' L2s are not coherent for plain accesses inside a kernel).
+template <int NQ>
+__device__ __forceinline__ void big_last_block_sums(const BigArgs &a, const double *q, double *lds /* [4 NQ] */) {
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) __hip_atomic_store(a.part + (size_t)i * a.NBt + blockIdx.x, q[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int t = __hip_atomic_fetch_add(a.tick, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    double t[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) t[i] = 0.0;
+    for (int b = threadIdx.x; b < a.NBt; b += 256) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) t[i] += __hip_atomic_load(a.part + (size_t)i * a.NBt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    block_sum<NQ>(t, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) a.dots[i] = t[i];
+        __hip_atomic_store(a.tick, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // x, b into the internal order; p = s = 0
@@ -92,7 +123,7 @@ __global__ __launch_bounds__(256) void k_big_resid(BigArgs a) {
         }
     }
     block_sum<3>(q, lds);
-    if (threadIdx.x == 0) { a.part[blockIdx.x] = q[0]; a.part[a.NBt + blockIdx.x] = q[1]; a.part[2 * a.NBt + blockIdx.x] = q[2]; }
+    big_last_block_sums<3>(a, q, lds);
 }
 
 // w = A u ; partials gamma = r.u, delta = u.w
@@ -121,10 +152,7 @@ __global__ __launch_bounds__(256) void k_big_spmv(BigArgs a, int it) {
         }
     }
     block_sum<6>(q, lds);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) a.part[i * a.NBt + blockIdx.x] = q[i];
-    }
+    big_last_block_sums<6>(a, q, lds);
 }
 
 // it < 0: the entry pass (no update: c = P^T r, rho, and gamma_b = b.D^-1 b from the entry residual's partials).
@@ -144,12 +172,10 @@ __global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mar
     }
     const int g = (int)blockIdx.x;
     double alpha[3] = {0.0, 0.0, 0.0}, beta[3] = {0.0, 0.0, 0.0};
-    {   // every block reduces the same partials in the same order: identical scalars everywhere
-        double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        const int nq = entry ? 3 : 6;
-        for (int i = threadIdx.x; i < a.NBt; i += kBigVecT)
-            for (int kk = 0; kk < nq; ++kk) q[kk] += a.part[kk * a.NBt + i];
-        block_sum_wide<6>(q, lds);
+    {   // the sums of the partials (k_big_resid / k_big_spmv's last block; distributed: all-reduced over the ranks): identical scalars everywhere
+        double q[6];
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) q[kk] = a.dots[kk];
         if (entry) {
             if (g == 0 && threadIdx.x == 0) {
                 CgScal o = pv;
@@ -182,26 +208,47 @@ __global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mar
     for (int i = 0; i < 15; ++i) q[i] = 0.0;
     const int r0 = g * a.ra;
     if (r0 >= a.row_lo && r0 < a.row_hi) {
-        for (int row = r0 + (int)threadIdx.x; row < r0 + a.ra; row += kBigVecT) {
-            const size_t i0 = 3 * (size_t)row;
-            double rr[3];
-            if (entry) { rr[0] = a.r[i0]; rr[1] = a.r[i0 + 1]; rr[2] = a.r[i0 + 2]; }
-            else {
+        // three rows per thread, ALL their loads issued before the first store (the compiler cannot move a load of u above a store to p:
+        // as a plain loop the rows went one after the other, ~2 waves per SIMD hiding nothing)
+        constexpr int RPT = 3;
+        for (int base = r0 + (int)threadIdx.x; base < r0 + a.ra; base += RPT * kBigVecT) {
+            double P[RPT][3], U[RPT][3], S[RPT][3], W[RPT][3], X[RPT][3], R[RPT][3], DI[RPT][3], CW[RPT][4];
+            bool ok[RPT];
+#pragma unroll
+            for (int t = 0; t < RPT; ++t) {
+                const int row = base + t * kBigVecT;
+                ok[t] = row < r0 + a.ra;
+                const size_t i0 = 3 * (size_t)(ok[t] ? row : r0);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const double pi = fma(beta[j], a.p[i0 + j], a.u[i0 + j]);
-                    const double si = fma(beta[j], a.s[i0 + j], a.w[i0 + j]);
-                    a.p[i0 + j] = pi; a.s[i0 + j] = si;
-                    a.xi[i0 + j] = fma(alpha[j], pi, a.xi[i0 + j]);
-                    rr[j] = fma(-alpha[j], si, a.r[i0 + j]);
-                    a.r[i0 + j] = rr[j];
+                    R[t][j] = a.r[i0 + j]; DI[t][j] = a.dinv[i0 + j];
+                    if (!entry) { P[t][j] = a.p[i0 + j]; U[t][j] = a.u[i0 + j]; S[t][j] = a.s[i0 + j]; W[t][j] = a.w[i0 + j]; X[t][j] = a.xi[i0 + j]; }
                 }
-            }
-            const double c0 = a.cwt[4 * (size_t)row], c1 = a.cwt[4 * (size_t)row + 1], c2 = a.cwt[4 * (size_t)row + 2], c3 = a.cwt[4 * (size_t)row + 3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                q[j] = fma(c0, rr[j], q[j]); q[3 + j] = fma(c1, rr[j], q[3 + j]); q[6 + j] = fma(c2, rr[j], q[6 + j]); q[9 + j] = fma(c3, rr[j], q[9 + j]);
-                q[12 + j] = fma(rr[j] * a.dinv[i0 + j], rr[j], q[12 + j]);
+                for (int k = 0; k < 4; ++k) CW[t][k] = a.cwt[4 * (size_t)(ok[t] ? row : r0) + k];
+            }
+#pragma unroll
+            for (int t = 0; t < RPT; ++t) {
+                if (!ok[t]) continue;
+                const size_t i0 = 3 * (size_t)(base + t * kBigVecT);
+                double rr[3];
+                if (entry) { rr[0] = R[t][0]; rr[1] = R[t][1]; rr[2] = R[t][2]; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double pi = fma(beta[j], P[t][j], U[t][j]);
+                        const double si = fma(beta[j], S[t][j], W[t][j]);
+                        a.p[i0 + j] = pi; a.s[i0 + j] = si;
+                        a.xi[i0 + j] = fma(alpha[j], pi, X[t][j]);
+                        rr[j] = fma(-alpha[j], si, R[t][j]);
+                        a.r[i0 + j] = rr[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    q[j] = fma(CW[t][0], rr[j], q[j]); q[3 + j] = fma(CW[t][1], rr[j], q[3 + j]); q[6 + j] = fma(CW[t][2], rr[j], q[6 + j]); q[9 + j] = fma(CW[t][3], rr[j], q[9 + j]);
+                    q[12 + j] = fma(rr[j] * DI[t][j], rr[j], q[12 + j]);
+                }
             }
         }
     }
@@ -219,12 +266,23 @@ __global__ __launch_bounds__(kBigVecT) void k_big_coarse(BigArgs a, int it) {
     double q[15];
 #pragma unroll
     for (int i = 0; i < 15; ++i) q[i] = 0.0;
-    for (int j = threadIdx.x; j < a.nc; j += kBigVecT) {
-        const double c0 = a.cvec[j], c1 = a.cvec[a.ncp + j], c2 = a.cvec[2 * a.ncp + j];
+    // four columns per thread and trip, all 28 loads in flight before the first product (the rows of the inverse come from HBM exactly once)
+    for (int j0 = threadIdx.x; j0 < a.nc; j0 += 4 * kBigVecT) {
+        double cc[4][3]; float mm[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double m = (double)a.ainv[(size_t)(4 * g + k) * a.ncp + j];
-            q[3 * k] = fma(m, c0, q[3 * k]); q[3 * k + 1] = fma(m, c1, q[3 * k + 1]); q[3 * k + 2] = fma(m, c2, q[3 * k + 2]);
+        for (int t = 0; t < 4; ++t) {
+            const int j = j0 + t * kBigVecT, jj = j < a.nc ? j : 0;
+            cc[t][0] = a.cvec[jj]; cc[t][1] = a.cvec[a.ncp + jj]; cc[t][2] = a.cvec[2 * a.ncp + jj];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mm[t][k] = j < a.nc ? a.ainv[(size_t)(4 * g + k) * a.ncp + jj] : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double m = (double)mm[t][k];
+                q[3 * k] = fma(m, cc[t][0], q[3 * k]); q[3 * k + 1] = fma(m, cc[t][1], q[3 * k + 1]); q[3 * k + 2] = fma(m, cc[t][2], q[3 * k + 2]);
+            }
         }
     }
     for (int j = threadIdx.x; j < a.G; j += kBigVecT) { q[12] += a.rho[j]; q[13] += a.rho[a.G + j]; q[14] += a.rho[2 * a.G + j]; }
@@ -248,12 +306,25 @@ __global__ __launch_bounds__(kBigVecT) void k_big_coarse(BigArgs a, int it) {
     }
     const int r0 = g * a.ra;
     if (r0 < a.row_lo || r0 >= a.row_hi) return;
-    for (int row = r0 + (int)threadIdx.x; row < r0 + a.ra; row += kBigVecT) {
-        const size_t i0 = 3 * (size_t)row;
-        const double c0 = a.cwt[4 * (size_t)row], c1 = a.cwt[4 * (size_t)row + 1], c2 = a.cwt[4 * (size_t)row + 2], c3 = a.cwt[4 * (size_t)row + 3];
+    constexpr int RPT = 3;
+    for (int base = r0 + (int)threadIdx.x; base < r0 + a.ra; base += RPT * kBigVecT) {      // (loads of all three rows first: see k_big_vec)
+        double R[RPT][3], DI[RPT][3], CW[RPT][4];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            a.u[i0 + j] = fma(a.dinv[i0 + j], a.r[i0 + j], fma(c0, q[j], fma(c1, q[3 + j], fma(c2, q[6 + j], c3 * q[9 + j]))));
+        for (int t = 0; t < RPT; ++t) {
+            const int row = base + t * kBigVecT, rw = row < r0 + a.ra ? row : r0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { R[t][j] = a.r[3 * (size_t)rw + j]; DI[t][j] = a.dinv[3 * (size_t)rw + j]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) CW[t][k] = a.cwt[4 * (size_t)rw + k];
+        }
+#pragma unroll
+        for (int t = 0; t < RPT; ++t) {
+            const int row = base + t * kBigVecT;
+            if (row >= r0 + a.ra) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                a.u[3 * (size_t)row + j] = fma(DI[t][j], R[t][j], fma(CW[t][0], q[j], fma(CW[t][1], q[3 + j], fma(CW[t][2], q[6 + j], CW[t][3] * q[9 + j]))));
+        }
     }
 }
 
