@@ -66,7 +66,10 @@ __device__ __forceinline__ void big_last_block_sums(const BigArgs &a, const doub
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int i = 0; i < NQ; ++i) __hip_atomic_store(a.part + (size_t)i * a.NBt + blockIdx.x, q[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int t = __hip_atomic_fetch_add(a.tick, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // (no release / acquire: at agent scope they write back and invalidate the whole L2 -- k_big_spmv 27 -> 77 us, measured.  The partials
+        // are write-through stores, drained before the ticket is taken; the last block reads them with loads that bypass its L2.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(a.tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last = (t == (int)gridDim.x - 1) ? 1 : 0;
     }
     __syncthreads();
@@ -74,9 +77,19 @@ __device__ __forceinline__ void big_last_block_sums(const BigArgs &a, const doub
     double t[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) t[i] = 0.0;
-    for (int b = threadIdx.x; b < a.NBt; b += 256) {
+    for (int b0 = threadIdx.x; b0 < a.NBt; b0 += 2 * 256) {      // 2 NQ loads in flight (more: registers the streaming part of k_big_spmv would pay for)
+        double v[2][NQ];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) t[i] += __hip_atomic_load(a.part + (size_t)i * a.NBt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int u = 0; u < 2; ++u) {
+            const int b = b0 + 256 * u;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) v[u][i] = b < a.NBt ? __hip_atomic_load(a.part + (size_t)i * a.NBt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) t[i] += v[u][i];
+        }
     }
     block_sum<NQ>(t, lds);
     if (threadIdx.x == 0) {
@@ -155,6 +168,8 @@ __global__ __launch_bounds__(256) void k_big_spmv(BigArgs a, int it) {
     big_last_block_sums<6>(a, q, lds);
 }
 
+// (Measured and dropped: the rows' loads at the very top of k_big_vec / k_big_coarse, ahead of the scalars -- 222 / 165 VGPRs, one block per CU
+// fewer resident: 44 -> 51 and 36 -> 57 us at 4 M tets, unchanged at 2 M.)
 // it < 0: the entry pass (no update: c = P^T r, rho, and gamma_b = b.D^-1 b from the entry residual's partials).
 // it >= 0: alpha / beta, the vector updates, then c and rho.  One block = one aggregate.
 __global__ __launch_bounds__(kBigVecT) void k_big_vec(BigArgs a, int it, int mark_here) {

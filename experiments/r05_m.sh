@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r05m; rm -rf $O; mkdir -p $O
-python -m pytest tests/test_big_pcg.py tests/test_soft_modes.py "tests/test_multi_gpu.py::test_distributed_solve_matches_single_context" tests/test_multi_gpu.py::test_distributed_solve_collectives_over_rccl_on_one_gpu -x -q 2>&1 | tail -5 > $O/tests.txt
+python -m pytest tests/test_big_pcg.py tests/test_soft_modes.py "tests/test_multi_gpu.py::test_distributed_solve_matches_single_context" tests/test_multi_gpu.py::test_distributed_solve_collectives_over_rccl_on_one_gpu -x -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -5 > $O/tests.txt
 for n in 148 187; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$n -o p -- python $GRAFT_REPO_ROOT/bench.py --workload blob1m_mix --n $n --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $O/bench_under_rocprof_n$n.json 2> $O/stats_$n.err )
   cp $(find $O/stats_$n -name "*kernel_stats.csv" | head -1) $O/kernel_stats_n$n.csv
