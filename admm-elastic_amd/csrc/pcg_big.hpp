@@ -140,6 +140,10 @@ __global__ __launch_bounds__(256) void k_big_resid(BigArgs a) {
 }
 
 // w = A u ; partials gamma = r.u, delta = u.w
+// (Measured and dropped: one block per aggregate with the aggregate's own entries of u staged in LDS -- four of five gathers become LDS reads --
+// 768 / 1024 threads: 32.9 -> 39.0 us at 2 M tets, 76 -> 81 us at 4 M.  The product is not bound by its gathers: every SpMV-shaped kernel of
+// the library takes ~80 us at 4 M tets whatever its row order -- ~2.8 TB/s of matrix + vectors once the working set leaves the 256-MB MALL,
+// against 5.9 TB/s at 1 M tets where it fits.)
 __global__ __launch_bounds__(256) void k_big_spmv(BigArgs a, int it) {
     __shared__ double lds[24];
     if (a.scal[it & 1].converged) return;
