@@ -951,56 +951,89 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     // this solve's pair: e = x - x_entry, A e = r_entry - r_final (exact: u carries the true residual).  Formed BEFORE the end projection below,
     // which moves x without updating r; STORED behind it: on this hardware a wave's loads return in order with its stores, so six stores per row
     // in front of the projection's loads cost it 10 us (measured: ADMM_HIP_OC_PROF)
+    // ALL global loads of the epilogue are issued here, before the first use of any (a wave's loads return in order): the pair's inputs, the
+    // wave's modes for the dots (up to three of them), the row's own entries of every mode, G^-1.  As four dependent stages -- pair, G^-1 -> LDS,
+    // first mode, second mode -- the same loads cost four round trips to HBM (ADMM_HIP_OC_PROF: 18.8 us for "pair stores + dots").
+    constexpr int SPBMAX = MAXT / 64;
+    constexpr int MPW = (kOc2DeflMax + (MAXT / 64) - 1) / (MAXT / 64) + 1;      // modes per wave: 32 modes over 12 (16) waves, +1 when fewer waves run
+    const bool proj = a.defl_k > 0 && conv && !aborted;
+    const int K = a.defl_k;
+    double xs_in[3] = {0.0, 0.0, 0.0}, r0_in[3] = {0.0, 0.0, 0.0};
+    if (live && a.rc_on) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const size_t i = 3 * (size_t)row + j; xs_in[j] = a.rc_xs[i]; r0_in[j] = a.rc_r0[i]; }
+    }
+    float zw[MPW][SPBMAX], zmine[kOc2DeflMax];
+    double gv[2] = {0.0, 0.0};
+    if (proj) {
+        const size_t zrow0 = (size_t)blockIdx.x * (size_t)T;
+#pragma unroll
+        for (int u = 0; u < MPW; ++u) {
+            const int q = wv + u * nw;
+            const float *zq = a.defl_Z + (size_t)(q < K ? q : 0) * a.n_rows + zrow0 + lane;
+#pragma unroll
+            for (int i = 0; i < SPBMAX; ++i) zw[u][i] = (q < K && i < a.spb && !(a.defl_dbg & 1)) ? zq[64 * i] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K && !(a.defl_dbg & 2)) ? a.defl_Z[(size_t)q * a.n_rows + row] : 0.0f;
+        if (!(a.defl_dbg & 4)) { if (tid < K * K) gv[0] = a.defl_Ginv[tid]; if (tid + T < K * K) gv[1] = a.defl_Ginv[tid + T]; }
+    }
     double pe[3] = {0.0, 0.0, 0.0}, pr[3] = {0.0, 0.0, 0.0};
     if (live && a.rc_on) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const size_t i = 3 * (size_t)row + j;
-            pe[j] = rx[j] - a.rc_xs[i];
-            pr[j] = a.rc_r0[i] - ru[j] * fast_rcp(rd[j]);
+            pe[j] = rx[j] - xs_in[j];
+            pr[j] = r0_in[j] - ru[j] * fast_rcp(rd[j]);
         }
     }
-    if (a.defl_k > 0 && conv && !aborted) {
+    if (proj) {
         // ---- end projection on the soft modes: x += Z G^-1 Z^T r (one more all-to-all) ----
         // r of the block's rows -> the (idle) local vector; wave w takes the modes w, w + nw, ...: lanes over the block's rows, ONE wave sum
         // per mode and axis (every thread summing every mode's product would cost 6 x 96 lane exchanges per wave: measured on k_big_vec).
-        // Every phase issues ALL its global loads before the first use: as chains of dependent loads the same code cost 60 us (measured).
-        const int K = a.defl_k, dpar = a.seq & 1;
-        constexpr int SPBMAX = MAXT / 64;
+        const int dpar = a.seq & 1;
         {
             const int t = otid();
 #pragma unroll
             for (int j = 0; j < 3; ++j) vec[OC2_VX(t, j)] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
         }
-        // (G^-1 into LDS behind the dots: the slab's first K K doubles are not needed any more)
+        // (G^-1 into LDS: the slab's first K K doubles are not needed any more)
         LdsD *ginv_l = lv_all;
-        if (!(a.defl_dbg & 4)) for (int o = tid; o < K * K; o += T) ginv_l[o] = a.defl_Ginv[o];
+        if (!(a.defl_dbg & 4)) {
+            if (tid < K * K) ginv_l[tid] = gv[0];
+            if (tid + T < K * K) ginv_l[tid + T] = gv[1];
+            for (int o = tid + 2 * T; o < K * K; o += T) ginv_l[o] = a.defl_Ginv[o];      // (small blocks, many modes)
+        }
         __syncthreads();
         __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void *)a.defl_rec, 0, 2 * 3 * kOc2DeflMax * a.G * 8, 0x00020000);
-        // modes: [mode][internal row], single precision.  (Measured, ADMM_HIP_OC_PROF + ADMM_HIP_DEFL_DBG: of the step's ~33 us at 24 modes the two
-        // passes over the modes are 17 -- 2 x 19 MB of first-touch HBM reads --, the grid barrier 3-8, the reduction of the 72 sums 4.7; a
-        // [block][mode][row] layout, one contiguous 74-KB slice per block, was SLOWER: 44 us.)
-        const size_t zrow0 = (size_t)blockIdx.x * (size_t)T;
-        for (int q = wv; q < K; q += nw) {
-            const float *zq = a.defl_Z + (size_t)q * a.n_rows + zrow0 + lane;
-            float z[SPBMAX];
+        // modes: [mode][internal row], single precision.  (A [block][mode][row] layout, one contiguous 74-KB slice per block, was SLOWER: 44 us.)
 #pragma unroll
-            for (int i = 0; i < SPBMAX; ++i) z[i] = (i < a.spb && !(a.defl_dbg & 1)) ? zq[64 * i] : 0.0f;
+        for (int u = 0; u < MPW; ++u) {
+            const int q = wv + u * nw;
+            if (q < K) {
+                double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < SPBMAX; ++i)
+                    if (i < a.spb) {
+                        const int rl = lane + 64 * i;
+                        const double zd = (double)zw[u][i];
+                        acc[0] = fma(zd, vec[OC2_VX(rl, 0)], acc[0]); acc[1] = fma(zd, vec[OC2_VX(rl, 1)], acc[1]); acc[2] = fma(zd, vec[OC2_VX(rl, 2)], acc[2]);
+                    }
+                acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]); acc[2] = wave_sum(acc[2]);
+                if (lane < 3) oc_store_sc1(rs_d, ((dpar * 3 * kOc2DeflMax + 3 * q + lane) * a.G + (int)blockIdx.x) * 8, lane == 0 ? acc[0] : lane == 1 ? acc[1] : acc[2]);
+            }
+        }
+        for (int q = wv + MPW * nw; q < K; q += nw) {      // (blocks of fewer waves than the instance allows: the remaining modes, plainly)
+            const float *zq = a.defl_Z + (size_t)q * a.n_rows + (size_t)blockIdx.x * (size_t)T + lane;
             double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int i = 0; i < SPBMAX; ++i)
-                if (i < a.spb) {
-                    const int rl = lane + 64 * i;
-                    const double zd = (double)z[i];
-                    acc[0] = fma(zd, vec[OC2_VX(rl, 0)], acc[0]); acc[1] = fma(zd, vec[OC2_VX(rl, 1)], acc[1]); acc[2] = fma(zd, vec[OC2_VX(rl, 2)], acc[2]);
-                }
+            for (int i = 0; i < a.spb; ++i) {
+                const int rl = lane + 64 * i;
+                const double zd = (a.defl_dbg & 1) ? 0.0 : (double)zq[64 * i];
+                acc[0] = fma(zd, vec[OC2_VX(rl, 0)], acc[0]); acc[1] = fma(zd, vec[OC2_VX(rl, 1)], acc[1]); acc[2] = fma(zd, vec[OC2_VX(rl, 2)], acc[2]);
+            }
             acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]); acc[2] = wave_sum(acc[2]);
             if (lane < 3) oc_store_sc1(rs_d, ((dpar * 3 * kOc2DeflMax + 3 * q + lane) * a.G + (int)blockIdx.x) * 8, lane == 0 ? acc[0] : lane == 1 ? acc[1] : acc[2]);
         }
-        // this row's entries of Z for the update below: in flight across the grid barrier
-        float zmine[kOc2DeflMax];
-#pragma unroll
-        for (int q = 0; q < kOc2DeflMax; ++q) zmine[q] = (live && q < K && !(a.defl_dbg & 2)) ? a.defl_Z[(size_t)q * a.n_rows + row] : 0.0f;
+        // (this row's entries of Z for the update below stay in registers across the grid barrier)
         if (prof) a.prof[63 * 8 + 5] = wall_clock64();
         ++be;
         if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) aborted = true;
