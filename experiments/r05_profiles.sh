@@ -16,6 +16,7 @@ rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 for wl in blob1m_mix cube100k_gs cloth200k_gs_floor cube100k_uzawa_floor; do
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 5 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof_$wl.json 2> $O/stats_$wl.err )
   cp $(find $O/stats_$wl -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$wl.csv
+  if [ $wl = blob1m_mix ]; then python experiments/pcg2_from_trace.py $O/stats_$wl $O/kernel_trace_split_blob1m_mix.txt; fi
 done
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_blob2m -o p -- python $GRAFT_REPO_ROOT/bench.py --workload blob1m_mix --n 148 --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > $O/bench_under_rocprof_blob2m.json 2> $O/stats_blob2m.err )
 cp $(find $O/stats_blob2m -name "*kernel_stats.csv" | head -1) $O/kernel_stats_blob2m_launch_path.csv
