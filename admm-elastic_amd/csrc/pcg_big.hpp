@@ -286,7 +286,9 @@ __global__ __launch_bounds__(kBigVecT) void k_big_coarse(BigArgs a, int it) {
 #pragma unroll
     for (int i = 0; i < 15; ++i) q[i] = 0.0;
     // four columns per thread and trip, all 28 loads in flight before the first product (the rows of the inverse come from HBM exactly once)
-    for (int j0 = threadIdx.x; j0 < a.nc; j0 += 4 * kBigVecT) {
+    const int r0c = g * a.ra;
+    const bool mine_c = r0c >= a.row_lo && r0c < a.row_hi;      // (distributed solve: the dense rows of the rank's own aggregates only)
+    for (int j0 = threadIdx.x; j0 < (mine_c ? a.nc : 0); j0 += 4 * kBigVecT) {
         double cc[4][3]; float mm[4][4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
