@@ -3008,7 +3008,7 @@ int admm_hip_get_solver_params(const admm_hip_ctx *c, int32_t kind, int32_t *max
 int admm_hip_set_soft_modes(admm_hip_ctx *c, int32_t k, const double *Z) {
     if (!c || k < 0 || k > kDeflMax || (k > 0 && !Z)) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: bad input (at most 64 modes)");
     if (c->linsolver == 1) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: this context runs no PCG");
-    if (c->cm.on || c->world > 1) return fail(ADMM_HIP_ERR_STATE, "set_soft_modes: single-GPU contexts only");
+    if (c->dist_solve) return fail(ADMM_HIP_ERR_STATE, "set_soft_modes: not with the distributed solve (ADMM_HIP_DIST_SOLVE=1)");      // (see admm_hip_compute_soft_modes)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (int rc = settle(c)) return rc;
@@ -3083,7 +3083,10 @@ int admm_hip_compute_soft_modes(admm_hip_ctx *c, int32_t k, int32_t iters) {
     if (!c || k < 0 || k > kDeflMax) return fail(ADMM_HIP_ERR_ARG, "compute_soft_modes: bad input (at most 64 modes)");
     if (k == 0) return admm_hip_set_soft_modes(c, 0, nullptr);
     if (c->linsolver == 1) return fail(ADMM_HIP_ERR_ARG, "compute_soft_modes: this context runs no PCG");
-    if (c->cm.on || c->world > 1) return fail(ADMM_HIP_ERR_STATE, "compute_soft_modes: single-GPU contexts only");
+    // multi-rank contexts: the element-block partition replicates the solve (every rank computes the same modes from the same matrix with the
+    // same deterministic code, no collective inside a solve), the component partition solves the rank's own bodies; the DISTRIBUTED solve is
+    // the one configuration whose modes would have to be assembled across ranks
+    if (c->dist_solve) return fail(ADMM_HIP_ERR_STATE, "compute_soft_modes: not with the distributed solve (ADMM_HIP_DIST_SOLVE=1)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (int rc = settle(c)) return rc;

@@ -5,6 +5,7 @@ method), sitting on the C ABI in include/admm_hip.h.  All per-iteration work run
 of libadmm_hip.so; this file only flattens the scene description, like Solver::initialize does.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -463,7 +464,7 @@ class Solver:
         for o in self._dynamic:   # Solver.cpp:249-254 (LDLT: "No collisions with LDLT solver") is checked by the library
             check(lib().admm_hip_add_dynamic_tetmesh(ctx, o.vert_offset, o.rest.shape[0], dptr(o.rest), o.tets.shape[0],
                                                      iptr(o.tets), o.faces.shape[0], iptr(o.faces)))
-        if s.soft_modes > 0 and s.linsolver != 1 and s.world_size <= 1:
+        if s.soft_modes > 0 and s.linsolver != 1 and not (s.world_size > 1 and os.environ.get("ADMM_HIP_DIST_SOLVE") == "1"):
             check(lib().admm_hip_compute_soft_modes(ctx, int(s.soft_modes), 0))
         self.initialized = True
         return True

@@ -297,7 +297,7 @@ def main():
     ap.add_argument("--n", type=int, default=0, help="override cells per edge (testing only)")
     ap.add_argument("--pcg-tol", type=float, default=PCG_TOL)
     ap.add_argument("--pcg-max-iters", type=int, default=600)
-    ap.add_argument("--soft-modes", type=int, default=SOFT_MODES, help="end projection of every PCG solve on this many lowest modes (0: off); single-GPU PCG workloads")
+    ap.add_argument("--soft-modes", type=int, default=SOFT_MODES, help="end projection of every PCG solve on this many lowest modes (0: off); PCG workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--calibrate-cpu-baseline", action="store_true", help="build container only: time the oracle port against the compiled reference pieces -> profiles/")
@@ -352,7 +352,7 @@ def main():
     sc, nt, nv = build_scene(w, args.n or None, copies=world)
     iters = w["admm_iters"]
     weak = w["kinds"] == "blobs"
-    soft = args.soft_modes if (world == 1 and w["linsolver"] != 1) else 0
+    soft = args.soft_modes if (w["linsolver"] != 1 and not (world > 1 and os.environ.get("ADMM_HIP_DIST_SOLVE") == "1")) else 0      # (every rank computes the modes of the system it solves)
     s = sc.make_solver(device=local_rank, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters, rank=rank, world_size=world, soft_modes=soft)
     if world > 1 and not share:
         s.comm_init(dist)

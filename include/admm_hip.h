@@ -300,7 +300,9 @@ int admm_hip_get_solver_params(const admm_hip_ctx *ctx, int32_t kind, int32_t *m
 int admm_hip_set_soft_modes(admm_hip_ctx *ctx, int32_t k, const double *Z);
 /* ... with the modes computed by the library: the k lowest eigenvectors of K by `iters` (<= 0: 8) steps of inverse subspace iteration on
  * the context's own PCG (a few seconds at 1 M tets, once per scene -- A never changes after Solver::initialize, src/Solver.cpp:225-226).
- * With the on-chip PCG and k <= 32 the projection is part of the solve's one persistent launch (one more all-to-all). */
+ * With the on-chip PCG and k <= 32 the projection is part of the solve's one persistent launch (one more all-to-all).  Multi-rank contexts:
+ * every rank computes the modes of the system it solves (element blocks: the replicated system; components: its own bodies); refused with the
+ * distributed solve (ADMM_HIP_DIST_SOLVE=1). */
 int admm_hip_compute_soft_modes(admm_hip_ctx *ctx, int32_t k, int32_t iters);
 /* the modes in effect: *k, and Z [k][n_verts] when Z is not NULL */
 int admm_hip_get_soft_modes(admm_hip_ctx *ctx, int32_t *k, double *Z);

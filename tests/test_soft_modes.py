@@ -99,3 +99,20 @@ def test_soft_modes_argument_checks():
     s0.compute_soft_modes(4); assert s0.get_soft_modes().shape[0] == 4
     s0.set_soft_modes(None); assert s0.get_soft_modes().shape[0] == 0
     s0.step(); assert np.isfinite(s0.m_x).all()
+
+
+def test_rank_contexts_compute_the_same_modes_as_the_single_context():
+    """Multi-rank contexts (element-block partition: the solve is replicated): every rank computes the modes of the system it solves with
+    the same deterministic code -- identical on all ranks, equal to the single context's.  (bench.py --gpus N runs its PCG workloads with
+    the same settings as --gpus 1: tolerance AND soft modes.)"""
+    sc = scenes.blob_scene(16, admm_iters=6, linsolver=0)
+    single = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=2000, soft_modes=6)
+    Z1 = single.get_soft_modes()
+    assert Z1.shape[0] == 6
+    single.close()
+    for r in range(2):
+        s = sc.make_solver(pcg_tol=1e-11, pcg_max_iters=2000, soft_modes=6, rank=r, world_size=2)
+        Z = s.get_soft_modes()
+        assert Z.shape == Z1.shape
+        assert np.array_equal(Z, Z1), np.abs(Z - Z1).max()
+        s.close()
