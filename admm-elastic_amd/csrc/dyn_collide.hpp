@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64) void k_gs_touched(GsArgs a, GsDyn d, int t0, in
     gsd_rows(d, t, v, a.m, a.x, LUx, aii);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        jac[q] = (a.b[3 * (size_t)v + q] - LUx[q]) / aii[q];
+        jac[q] = (a.b[3 * (size_t)v + q] - LUx[q]) * (1.0 / aii[q]);      // (the same two roundings as gs_relax: kernels.hpp)
         nx[q] = (1.0 - a.omega) * a.x[3 * (size_t)v + q] + a.omega * jac[q];
     }
     double n[3], p[3];

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x, t = (int)threadIdx.x;
     // ---- LDS: scratch | x [L][3] | x of the previous sweep [L][3] | b [n_own][3] | a_ii [n_own][3] | values | columns | outbox node per
-    //      row | halo source | pin flags   (host_setup.hpp: gsp_lds_bytes computes the same offsets)
+    //      row | halo source | pin flags | 1 / a_ii [n_own][3]   (host_setup.hpp: gsp_lds_bytes computes the same offsets)
     LdsD *scr = (LdsD *)smem;                       // [0..3] wave sums of the residual partial, [8] |b|^2 of the block
     LdsI32 *ih = (LdsI32 *)(smem + 256);            // the block's header (64 ints)
     LdsI32 *ctl = (LdsI32 *)(smem + 512);           // [0] abort seen, [1] a sweep met the tolerance, [2] which one (verdict(): written and read across a barrier);
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     LdsI32 *ol = (LdsI32 *)((__attribute__((address_space(3))) char *)cl + (2 * ent_count + 7) / 8 * 8);
     LdsI32 *hl = (LdsI32 *)((__attribute__((address_space(3))) char *)ol + (4 * n_own + 7) / 8 * 8);
     LdsU8 *pl = (LdsU8 *)((__attribute__((address_space(3))) char *)hl + (4 * n_halo + 7) / 8 * 8);
+    LdsD *il = (LdsD *)((__attribute__((address_space(3))) char *)pl + (n_own + 7) / 8 * 8);      // 1 / a_ii [n_own][3]
     const __amdgpu_buffer_rsrc_t rbox = soa_rsrc(a.box), rpart = soa_rsrc(a.part), rmeet = soa_rsrc(a.meet);
     const int lane = t & 63, wv = t >> 6;
 
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const double bi = a.b[3 * (size_t)v + q];
-                bl[3 * i + q] = bi; al[3 * i + q] = d + a.m[3 * (size_t)v + q];
+                const double aq = d + a.m[3 * (size_t)v + q];
+                bl[3 * i + q] = bi; al[3 * i + q] = aq; il[3 * i + q] = 1.0 / aq;
                 bb = fma(bi, bi, bb);
             }
         }
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
             const int li = r0 + i;
             const double bi[3] = {bl[3 * li], bl[3 * li + 1], bl[3 * li + 2]};
             const double aii[3] = {al[3 * li], al[3 * li + 1], al[3 * li + 2]};
+            const double iaii[3] = {il[3 * li], il[3 * li + 1], il[3 * li + 2]};
             const double cx[3] = {xl[3 * li], xl[3 * li + 1], xl[3 * li + 2]};
             double nx[3];
             if (role == 1) {
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
             }
             if (pl[li] == 2) {      // slide pin (normal-only constraint): the unrelaxed value projected onto the pin's plane, every sweep
                 const int v = a.orig[row_base + li];
-                gs_pin_value(2, a.pin_xyz + 3 * (size_t)v, a.pin_nrm + 3 * (size_t)v, bi, LUx, aii, nx);
+                gs_pin_value(2, a.pin_xyz + 3 * (size_t)v, a.pin_nrm + 3 * (size_t)v, bi, LUx, iaii, nx);
             } else if (pl[li]) { // :111-117
 #ifdef ADMM_GSP_OB_GLOBAL
                 if (true) {
@@ -265,9 +268,9 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                 }
             }
 #ifdef ADMM_GSP_OB_GLOBAL      // (same-box A/B only: the obstacles through the argument pointer, as before round 4's second session)
-            else if (gs_relax(*a.ob, a.omega, bi, LUx, aii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else if (gs_relax(*a.ob, a.omega, bi, LUx, iaii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-            else if (gs_relax(*obl, a.omega, bi, LUx, aii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS add: rows projected, counted below)
+            else if (gs_relax(*obl, a.omega, bi, LUx, iaii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS add: rows projected, counted below)
 #endif
             if (keep_old) { xo[3 * li] = cx[0]; xo[3 * li + 1] = cx[1]; xo[3 * li + 2] = cx[2]; }
             xl[3 * li] = nx[0]; xl[3 * li + 1] = nx[1]; xl[3 * li + 2] = nx[2];

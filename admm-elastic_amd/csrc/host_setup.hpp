@@ -193,6 +193,7 @@ inline int32_t gsp_lds_bytes(int32_t n_own, int32_t n_halo, int32_t ent_count) {
     o += (4 * n_own + 7) / 8 * 8;             // outbox node of every own row
     o += (4 * n_halo + 7) / 8 * 8;            // source of every halo entry
     o += (n_own + 7) / 8 * 8;                 // pin flags
+    o += 24 * n_own;                          // 1 / a_ii [n_own][3]
     return o;
 }
 

@@ -1300,12 +1300,14 @@ __device__ __forceinline__ bool passive_hit(const OB &ob, const double *x, doubl
 // contraction choices.
 // Returns whether the row was projected onto an obstacle (counted: admm_hip_contact_totals).
 template <class OB>
-__device__ __forceinline__ bool gs_relax(const OB &ob, double omega, const double *bi, const double *LUx, const double *aii,
+__device__ __forceinline__ bool gs_relax(const OB &ob, double omega, const double *bi, const double *LUx, const double *inv_aii,
                                          const double *cx, double *nx) {
+    // inv_aii = 1 / a_ii, formed ONCE per row (IEEE division) by every caller -- the persistent kernel keeps it in LDS next to a_ii: three
+    // division sequences less on the dependent chain of a row update.  (The reference divides, :210; one rounding of difference per update.)
     double jac[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        jac[q] = (bi[q] - LUx[q]) / aii[q];
+        jac[q] = (bi[q] - LUx[q]) * inv_aii[q];
         nx[q] = fma(omega, jac[q], (1.0 - omega) * cx[q]); // :210
     }
     double n[3], p[3];
@@ -1332,11 +1334,11 @@ __device__ __forceinline__ bool gs_relax(const OB &ob, double omega, const doubl
 // A pinned node of a sweep (:111-117): its pin's position.  flag 2 = a SLIDE pin (normal-only constraint n . (x - p) = 0, README.md:23-28
 // TODO of the reference): the plane-constrained Jacobi value of :218-262 on the pin's own plane -- the unrelaxed value
 // D^-1 (b - LUx) projected onto it, G G^T (jac - p) + p = jac - n (n . (jac - p)).
-__device__ __forceinline__ void gs_pin_value(int flag, const double *pin, const double *nrm, const double *bi, const double *LUx, const double *aii, double *nx) {
+__device__ __forceinline__ void gs_pin_value(int flag, const double *pin, const double *nrm, const double *bi, const double *LUx, const double *inv_aii, double *nx) {
     if (flag != 2) { nx[0] = pin[0]; nx[1] = pin[1]; nx[2] = pin[2]; return; }
     double jac[3], d = 0.0;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { jac[q] = (bi[q] - LUx[q]) / aii[q]; d = fma(nrm[q], jac[q] - pin[q], d); }
+    for (int q = 0; q < 3; ++q) { jac[q] = (bi[q] - LUx[q]) * inv_aii[q]; d = fma(nrm[q], jac[q] - pin[q], d); }
 #pragma unroll
     for (int q = 0; q < 3; ++q) nx[q] = fma(-d, nrm[q], jac[q]);
 }
@@ -1395,13 +1397,14 @@ __global__ __launch_bounds__(256) void k_gs_color(GsArgs a, int slice0, int nsli
     double aii[3], cx[3], bi[3], nx[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) { aii[q] = ad + a.m[3 * (size_t)v + q]; cx[q] = a.x[3 * (size_t)v + q]; bi[q] = a.b[3 * (size_t)v + q]; }
+    const double iaii[3] = {1.0 / aii[0], 1.0 / aii[1], 1.0 / aii[2]};
     if (pflag == 2) {     // slide pin
-        gs_pin_value(2, a.pin_xyz + 3 * (size_t)v, a.pin_nrm + 3 * (size_t)v, bi, LUx, aii, nx);
+        gs_pin_value(2, a.pin_xyz + 3 * (size_t)v, a.pin_nrm + 3 * (size_t)v, bi, LUx, iaii, nx);
 #pragma unroll
         for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
         return;
     }
-    if (gs_relax(ob, a.omega, bi, LUx, aii, cx, nx) && a.proj) atomicAdd(a.proj, 1ull);
+    if (gs_relax(ob, a.omega, bi, LUx, iaii, cx, nx) && a.proj) atomicAdd(a.proj, 1ull);
 #pragma unroll
     for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
 }
@@ -1484,9 +1487,10 @@ __global__ __launch_bounds__(256) void k_gs_color2(Gs2Args a2, int slice0, int n
                 }
             }
             if (UPDATE && !done_flag) {
+                const double iaii[3] = {1.0 / aii[0], 1.0 / aii[1], 1.0 / aii[2]};
                 if (pinned) { // :111-117 (flag 2: slide pin)
-                    gs_pin_value(pflag, a.pin_xyz + 3 * (size_t)v, pflag == 2 ? a.pin_nrm + 3 * (size_t)v : a.pin_xyz, bi, LUx, aii, nx);
-                } else if (gs_relax(ob, a.omega, bi, LUx, aii, cx, nx) && a.proj) atomicAdd(a.proj, 1ull);
+                    gs_pin_value(pflag, a.pin_xyz + 3 * (size_t)v, pflag == 2 ? a.pin_nrm + 3 * (size_t)v : a.pin_xyz, bi, LUx, iaii, nx);
+                } else if (gs_relax(ob, a.omega, bi, LUx, iaii, cx, nx) && a.proj) atomicAdd(a.proj, 1ull);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
             }
@@ -1635,9 +1639,10 @@ __global__ __launch_bounds__(256) void k_gs_colorN(GsNArgs aN, int slice0, int n
                 for (int q = 0; q < 3; ++q) aN.xb[3 * (size_t)v + q] = cx[q];
             }
             if (UPDATE && !done_flag) {
+                const double iaii[3] = {1.0 / aii[0], 1.0 / aii[1], 1.0 / aii[2]};
                 if (pinned) { // :111-117 (flag 2: slide pin)
-                    gs_pin_value(pflag, a.pin_xyz + 3 * (size_t)v, pflag == 2 ? a.pin_nrm + 3 * (size_t)v : a.pin_xyz, bi, LUx, aii, nx);
-                } else if (gs_relax(ob, a.omega, bi, LUx, aii, cx, nx) && a.proj) atomicAdd(a.proj, 1ull);
+                    gs_pin_value(pflag, a.pin_xyz + 3 * (size_t)v, pflag == 2 ? a.pin_nrm + 3 * (size_t)v : a.pin_xyz, bi, LUx, iaii, nx);
+                } else if (gs_relax(ob, a.omega, bi, LUx, iaii, cx, nx) && a.proj) atomicAdd(a.proj, 1ull);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) a.x[3 * (size_t)v + q] = nx[q];
             }
