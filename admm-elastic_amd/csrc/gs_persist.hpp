@@ -72,6 +72,13 @@ __device__ __forceinline__ void gsp_store(__amdgpu_buffer_rsrc_t rs, int byte_of
     __builtin_amdgcn_raw_buffer_store_b128(g, rs, byte_off, 0, 16 /* sc1: write-through */);
 }
 
+#ifndef ADMM_GSP_STAGGER
+#define ADMM_GSP_STAGGER -1
+#endif
+constexpr int kGspStagger = ADMM_GSP_STAGGER;      // >= 0: a second poll that many s_sleep periods behind the first -- measured and OFF: 2 / 5 / 9 / 14
+                                                   // periods give 4 190 / 4 249 / 4 281 / 4 270 against 4 330-4 390 ADMM it/s (cube), 2 857 ... 2 927 against 3 107 (cloth):
+                                                   // the second poll's loads queue in front of everything the wave issues next (loads return in order)
+
 __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x, t = (int)threadIdx.x;
@@ -171,8 +178,14 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
             v4u g0, g1, g2;
             unsigned spins = 0;
             while (true) {
+                // (kGspStagger >= 0, an experiment: TWO polls under way, the second a fraction of a round trip behind the first)
                 g0 = gsp_load(rbox, off); g1 = gsp_load(rbox, off + 16); g2 = gsp_load(rbox, off + 32);
-                if (gsp_ok(g0, want) && gsp_ok(g1, want) && gsp_ok(g2, want)) break;
+                if constexpr (kGspStagger >= 0) {
+                    __builtin_amdgcn_s_sleep(kGspStagger);
+                    const v4u h0 = gsp_load(rbox, off), h1 = gsp_load(rbox, off + 16), h2 = gsp_load(rbox, off + 32);
+                    if (gsp_ok(g0, want) && gsp_ok(g1, want) && gsp_ok(g2, want)) break;
+                    if (gsp_ok(h0, want) && gsp_ok(h1, want) && gsp_ok(h2, want)) { g0 = h0; g1 = h1; g2 = h2; break; }
+                } else if (gsp_ok(g0, want) && gsp_ok(g1, want) && gsp_ok(g2, want)) break;
                 if (poll_failed(spins)) break;
             }
             const int j = 3 * (n_own + hh);
