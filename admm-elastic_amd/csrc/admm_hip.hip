@@ -3418,6 +3418,25 @@ int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int
     }
     return ADMM_HIP_OK;
 }
+int admm_host_big_plan(const admm_hip_desc *d, int32_t max_aggregates, int32_t *stats, int32_t *row_vertex, double *row_weights, float *coarse_inv) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!stats) return fail(ADMM_HIP_ERR_ARG, "big_plan: stats is NULL");
+    const double dt = d->dt > 0.0 ? d->dt : 1.0 / 24.0;
+    double mu, la, k;
+    admm_host::lame(10000000.0, 0.499, &mu, &la, &k);
+    const double pw = d->pin_weight > 0 ? d->pin_weight : std::sqrt(k * 2.0);
+    const bool pins_as_terms = (d->linsolver == 0 || d->linsolver == 2);
+    const admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
+                                                      d->tri_idx, d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, pw);
+    const admm_host::BigPlan P = admm_host::build_big_plan(A, d->masses, d->vert_xyz, max_aggregates > 0 ? max_aggregates : 1024);
+    if (!P.ok) return fail(ADMM_HIP_ERR_ARG, "big_plan: no plan (masses differ between the axes of a vertex)");
+    stats[0] = P.G; stats[1] = P.ra; stats[2] = P.n_rows; stats[3] = P.nc; stats[4] = P.ncp; stats[5] = P.A.n_slices;
+    if (row_vertex) std::copy(P.orig.begin(), P.orig.end(), row_vertex);
+    if (row_weights) std::copy(P.cwt.begin(), P.cwt.end(), row_weights);
+    if (coarse_inv) for (int i = 0; i < P.nc; ++i) std::copy(P.ainv.begin() + (size_t)i * P.ncp, P.ainv.begin() + (size_t)i * P.ncp + P.nc, coarse_inv + (size_t)i * P.nc);
+    return ADMM_HIP_OK;
+}
 void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end) {
     admm_host::partition(n_items, world_size, rank, begin, end);
 }

@@ -444,6 +444,17 @@ class Solver:
         stats.update(lambda_bb=st[8] * 1e-9, bank_load_by_index=st[9] * 1e-6, bank_load_placed=st[10] * 1e-6)
         return dict(row_vertex=rv, row_aggregate=ra, coarse_inv=ci, stats=stats, row_weights=wt)
 
+    def host_big_plan(self, max_aggregates=0, settings=None):
+        """The plan of the launch-path two-level PCG of this scene (admm_host_big_plan, no GPU): dict(G, ra, rows, nc, ncp, slices, row_vertex,
+        row_weights [rows, 4], coarse_inv [nc, nc])."""
+        d = self.make_desc(settings if settings is not None else self._settings)
+        st = np.zeros(6, np.int32)
+        check(lib().admm_host_big_plan(C.byref(d), int(max_aggregates), iptr(st), None, None, None))
+        rows, nc = int(st[2]), int(st[3])
+        rv = np.zeros(rows, np.int32); wt = np.zeros((rows, 4)); ci = np.zeros((nc, nc), np.float32)
+        check(lib().admm_host_big_plan(C.byref(d), int(max_aggregates), iptr(st), iptr(rv), dptr(wt), ci.ctypes.data_as(C.POINTER(C.c_float))))
+        return dict(G=int(st[0]), ra=int(st[1]), rows=rows, nc=nc, ncp=int(st[4]), slices=int(st[5]), row_vertex=rv, row_weights=wt, coarse_inv=ci)
+
     def initialize(self, settings=None):
         s = settings if settings is not None else Settings()
         self._settings = s

@@ -472,6 +472,13 @@ void admm_host_locality_order(int32_t n_verts, int32_t n_elems, int32_t corners,
 int admm_host_oc_plan(const admm_hip_desc *desc, int32_t n_blocks, int32_t slices_per_block, int32_t lds_bytes,
                       int32_t *row_vertex, int32_t *row_aggregate, double *coarse_inv, int64_t *stats, float *row_weights);
 
+/* The plan of the LAUNCH-PATH two-level PCG (csrc/pcg_big.hpp; csrc/oc_plan.cpp: build_big_plan) for this scene, no GPU -- bodies beyond the
+ * chip's LDS and the fall-back of the on-chip solver; replaces the same prefactored solve, src/LinearSolver.hpp:87-90.  The vertices are
+ * dealt to G compact aggregates of `ra` rows each (at most max_aggregates, <= 0: 1024); stats [6]: G, ra, rows (G ra), coarse unknowns nc
+ * = 4 G, their padded count, SELL slices.  row_vertex [rows] (-1 = unused slot), row_weights [4 rows] (row r of P, energy-orthonormal per
+ * aggregate), coarse_inv [nc nc] = (P^T A P)^-1 in single precision; any of the three may be NULL (call once for the sizes). */
+int admm_host_big_plan(const admm_hip_desc *desc, int32_t max_aggregates, int32_t *stats, int32_t *row_vertex, double *row_weights, float *coarse_inv);
+
 /* Mesh preprocessing, second ordering (no counterpart in the reference): hierarchical BLOCK order.  The vertices are split
  * into compact leaves of about `leaf` vertices by recursive graph bisection (the method the on-chip PCG uses for its blocks),
  * leaves numbered in recursion-tree order, vertices breadth-first inside a leaf.  Reverse Cuthill-McKee minimises the

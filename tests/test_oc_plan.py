@@ -140,3 +140,51 @@ def test_plan_rejects_too_few_slots():
     s = sc.make_solver(init=False)
     with pytest.raises(pkg.AdmmHipError):
         s.host_oc_plan(2, 2, settings=sc.product_settings)      # 256 slots for 343 vertices
+
+
+def test_launch_path_two_level_plan():
+    """admm_host_big_plan (csrc/oc_plan.cpp: build_big_plan, the plan of csrc/pcg_big.hpp), no GPU: every vertex in exactly one aggregate slot,
+    aggregates of equal size, the coarse functions energy-orthonormal per aggregate (diagonal blocks of P^T A P = I), the stored single-precision
+    inverse the inverse of P^T A P, and M^-1 = D^-1 + P (P^T A P)^-1 P^T a preconditioner that clusters the spectrum (CG on the host: several
+    times fewer iterations than Jacobi)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    sc = scenes.blob_scene(48, admm_iters=4, linsolver=0)
+    s = sc.make_solver(init=False)
+    nv = len(sc.x)
+    rp, ci, va = s.host_matrix(sc.product_settings)
+    A = (sp.csr_matrix((va, ci, rp), shape=(nv, nv)) + sp.diags(sc.m)).tocsr()
+    P = s.host_big_plan(max_aggregates=0, settings=sc.product_settings)
+    G, ra, rows, nc = P["G"], P["ra"], P["rows"], P["nc"]
+    assert G >= 8 and rows == G * ra and ra % 256 == 0 and nc == 4 * G
+    rv = P["row_vertex"]
+    live = np.nonzero(rv >= 0)[0]
+    assert len(live) == nv and np.array_equal(np.sort(rv[live]), np.arange(nv))
+    agg = live // ra
+    assert np.bincount(agg, minlength=G).max() <= ra
+    # prolongation in vertex order: column 4 g + k = function k of aggregate g
+    Pm = sp.lil_matrix((nv, nc))
+    for r in live:
+        for k in range(4):
+            Pm[rv[r], 4 * (r // ra) + k] = P["row_weights"][r, k]
+    Pm = Pm.tocsr()
+    Ac = (Pm.T @ A @ Pm).toarray()
+    for g in range(G):
+        blk = Ac[4 * g:4 * g + 4, 4 * g:4 * g + 4]
+        keep = np.abs(np.diag(blk)) > 0.5          # (a function dropped by the pivoted Cholesky has a zero column)
+        assert np.abs(blk[np.ix_(keep, keep)] - np.eye(keep.sum())).max() < 1e-9
+    keep = np.abs(np.diag(Ac)) > 0.5
+    inv = P["coarse_inv"].astype(float)
+    assert np.abs(inv[np.ix_(keep, keep)] @ Ac[np.ix_(keep, keep)] - np.eye(keep.sum())).max() < 2e-3      # single precision, cond ~1e2
+    dinv = 1.0 / A.diagonal()
+    M2 = spl.LinearOperator((nv, nv), matvec=lambda r: dinv * r + Pm @ (inv @ (Pm.T @ r)))
+    MJ = spl.LinearOperator((nv, nv), matvec=lambda r: dinv * r)
+    b = np.random.default_rng(2).standard_normal(nv)
+    its = {}
+    for name, M in (("jacobi", MJ), ("two_level", M2)):
+        n = [0]
+        x, info = spl.cg(A, b, rtol=1e-8, maxiter=5000, M=M, callback=lambda xk: n.__setitem__(0, n[0] + 1))
+        assert info == 0
+        its[name] = n[0]
+    print("host CG iterations", its, "aggregates", G)
+    assert its["two_level"] * 2 < its["jacobi"], its
