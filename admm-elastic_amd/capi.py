@@ -123,6 +123,7 @@ SYMBOLS = [
     ("admm_host_locality_order", None, [C.c_int32, C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, c_double_p]),
     ("admm_host_block_order", None, [C.c_int32, C.c_int32, C.c_int32, c_int_p, C.c_int32, c_int_p]),
     ("admm_host_chunk_reduce", C.c_int, [C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
+    ("admm_host_gs_plan_sweeps", C.c_int, [C.POINTER(Desc), C.c_int32, c_int_p, C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_int32, C.c_double, c_int_p]),
     ("admm_host_big_plan", C.c_int, [C.POINTER(Desc), C.c_int32, c_int_p, c_int_p, c_double_p, C.POINTER(C.c_float)]),
     ("admm_host_oc_plan", C.c_int, [C.POINTER(Desc), C.c_int32, C.c_int32, C.c_int32, c_int_p, c_int_p, c_double_p, C.POINTER(C.c_int64), C.POINTER(C.c_float)]),
 ]

@@ -3437,6 +3437,73 @@ int admm_host_big_plan(const admm_hip_desc *d, int32_t max_aggregates, int32_t *
     if (coarse_inv) for (int i = 0; i < P.nc; ++i) std::copy(P.ainv.begin() + (size_t)i * P.ncp, P.ainv.begin() + (size_t)i * P.ncp + P.nc, coarse_inv + (size_t)i * P.nc);
     return ADMM_HIP_OK;
 }
+int admm_host_gs_plan_sweeps(const admm_hip_desc *d, int32_t n_colors, const int32_t *color, int32_t max_blocks, int32_t rows_target,
+                             const double *b, double *x, int32_t sweeps, double omega, int32_t *stats) {
+    int rc = validate(d);
+    if (rc) return rc;
+    if (!color || !b || !x || sweeps < 0) return fail(ADMM_HIP_ERR_ARG, "gs_plan_sweeps: NULL argument");
+    const double dt = d->dt > 0.0 ? d->dt : 1.0 / 24.0;
+    const admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
+                                                      d->tri_idx, d->tri_rest, d->tri_weight, 0, d->pin_vert, 0.0);
+    const admm_host::GsPlan P = admm_host::build_gs_plan(A, n_colors, color, max_blocks > 0 ? max_blocks : 256, rows_target > 0 ? rows_target : 384, 160 * 1024);
+    if (!P.ok) return fail(ADMM_HIP_ERR_ARG, "gs_plan_sweeps: no plan (too many colours, or a block does not fit the LDS)");
+    const int G = P.G, C = P.C, H = admm_host::kGspHdr;
+    if (stats) { stats[0] = G; stats[1] = C; stats[2] = P.lds_bytes; stats[3] = P.max_halo; stats[4] = P.max_nbr; stats[5] = P.max_rows; }
+    // the kernel's data flow on the host: per block a local vector (own rows, then halo entries), per phase fetch the halo entries of the
+    // colour swept in the previous phase from the outbox, sweep the rows of this phase's colour out of the ELL with LOCAL columns, publish
+    // the boundary rows.  All blocks finish a phase before the next one starts (the kernel's hand-offs enforce exactly that order).
+    std::vector<double> box((size_t)3 * std::max(P.ob_total, 1), 0.0);
+    std::vector<std::vector<double> > xl(G);
+    for (int g = 0; g < G; ++g) {
+        const int32_t *h = &P.hdr[(size_t)g * H];
+        xl[g].assign((size_t)3 * (h[0] + h[1]), 0.0);
+        for (int i = 0; i < h[0]; ++i) for (int q = 0; q < 3; ++q) xl[g][3 * i + q] = x[3 * (size_t)P.orig[h[2] + i] + q];
+        for (int i = 0; i < h[1]; ++i) for (int q = 0; q < 3; ++q) xl[g][3 * (h[0] + i) + q] = x[3 * (size_t)P.halo_orig[h[3] + i] + q];
+    }
+    auto fetch = [&](int cp) {
+        for (int g = 0; g < G; ++g) {
+            const int32_t *h = &P.hdr[(size_t)g * H];
+            for (int hh = h[21 + cp]; hh < h[21 + cp + 1]; ++hh)
+                for (int q = 0; q < 3; ++q) xl[g][3 * (h[0] + hh) + q] = box[3 * (size_t)P.halo_box[h[3] + hh] + q];
+        }
+    };
+    for (int sw = 0; sw < sweeps; ++sw)
+        for (int c = 0; c < C; ++c) {
+            if (sw > 0 || c > 0) fetch(c > 0 ? c - 1 : C - 1);
+            for (int g = 0; g < G; ++g) {
+                const int32_t *h = &P.hdr[(size_t)g * H];
+                const int r0 = h[8 + c], n_c = h[8 + c + 1] - r0, W = h[34 + c];
+                const size_t e0 = (size_t)h[4] + h[46 + c];
+                std::vector<double> nx((size_t)3 * std::max(n_c, 1));
+                for (int i = 0; i < n_c; ++i) {
+                    double acc[3] = {0.0, 0.0, 0.0};
+                    for (int k = 0; k < W; ++k) {
+                        const int col = P.cols[e0 + (size_t)k * n_c + i] & 0x7fff;
+                        const double a = P.vals[e0 + (size_t)k * n_c + i];
+                        for (int q = 0; q < 3; ++q) acc[q] = std::fma(a, xl[g][3 * col + q], acc[q]);
+                    }
+                    const int li = r0 + i, v = P.orig[h[2] + li];
+                    for (int q = 0; q < 3; ++q) {
+                        const double aii = P.diag[h[2] + li] + d->masses[3 * (size_t)v + q];
+                        const double jac = (b[3 * (size_t)v + q] - acc[q]) * (1.0 / aii);
+                        nx[3 * i + q] = std::fma(omega, jac, (1.0 - omega) * xl[g][3 * li + q]);
+                    }
+                }
+                for (int i = 0; i < n_c; ++i) {
+                    const int li = r0 + i, o = P.out_idx[h[2] + li];
+                    for (int q = 0; q < 3; ++q) {
+                        xl[g][3 * li + q] = nx[3 * i + q];
+                        if (o >= 0) box[3 * (size_t)(h[5] + o) + q] = nx[3 * i + q];
+                    }
+                }
+            }
+        }
+    for (int g = 0; g < G; ++g) {
+        const int32_t *h = &P.hdr[(size_t)g * H];
+        for (int i = 0; i < h[0]; ++i) for (int q = 0; q < 3; ++q) x[3 * (size_t)P.orig[h[2] + i] + q] = xl[g][3 * i + q];
+    }
+    return ADMM_HIP_OK;
+}
 void admm_host_partition(int32_t n_items, int world_size, int rank, int32_t *begin, int32_t *end) {
     admm_host::partition(n_items, world_size, rank, begin, end);
 }

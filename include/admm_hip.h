@@ -479,6 +479,15 @@ int admm_host_oc_plan(const admm_hip_desc *desc, int32_t n_blocks, int32_t slice
  * aggregate), coarse_inv [nc nc] = (P^T A P)^-1 in single precision; any of the three may be NULL (call once for the sizes). */
 int admm_host_big_plan(const admm_hip_desc *desc, int32_t max_aggregates, int32_t *stats, int32_t *row_vertex, double *row_weights, float *coarse_inv);
 
+/* The plan of the PERSISTENT multi-colour Gauss-Seidel kernel (csrc/gs_persist.hpp; csrc/oc_plan.cpp: build_gs_plan) run ON THE HOST, no
+ * GPU (tests): `sweeps` plain SOR sweeps (src/NodalMultiColorGS.hpp:180-216, no pins, no obstacles) over the plan's own data -- blocks, the ELL of
+ * every (block, colour) with local columns, halo lists, outbox nodes -- in the kernel's order of phases, x [3 n_verts] in and out.  A plan that
+ * drops or misroutes an entry, a halo value or a boundary row gives another x than the sweeps on the assembled matrix.  color [n_verts] as
+ * from admm_host_greedy_coloring; max_blocks / rows_target <= 0: 256 / 384; stats [6] (may be NULL): blocks, colours, LDS bytes of the fullest
+ * block, largest halo list, most neighbour blocks, most rows of a block. */
+int admm_host_gs_plan_sweeps(const admm_hip_desc *desc, int32_t n_colors, const int32_t *color, int32_t max_blocks, int32_t rows_target,
+                             const double *b, double *x, int32_t sweeps, double omega, int32_t *stats);
+
 /* Mesh preprocessing, second ordering (no counterpart in the reference): hierarchical BLOCK order.  The vertices are split
  * into compact leaves of about `leaf` vertices by recursive graph bisection (the method the on-chip PCG uses for its blocks),
  * leaves numbered in recursion-tree order, vertices breadth-first inside a leaf.  Reverse Cuthill-McKee minimises the

@@ -2,6 +2,7 @@
 src/LinearSolver.hpp:87-90): internal row order, aggregates and the dense coarse inverse, checked on the CPU by running
 the two-level preconditioned CG it describes in numpy / scipy."""
 import numpy as np
+import pytest
 import scipy.sparse as sp
 
 import scenes
@@ -188,3 +189,43 @@ def test_launch_path_two_level_plan():
         its[name] = n[0]
     print("host CG iterations", its, "aggregates", G)
     assert its["two_level"] * 2 < its["jacobi"], its
+
+
+@pytest.mark.parametrize("kind", ["cube", "blob", "cloth"])
+def test_persistent_gs_plan_swept_on_the_host(kind):
+    """admm_host_gs_plan_sweeps: the plan of the persistent multi-colour GS kernel (csrc/oc_plan.cpp: build_gs_plan) run on the host in the
+    kernel's order of phases -- blocks, per-colour ELLs with local columns, halo lists, outbox nodes -- against plain multi-colour SOR sweeps
+    on the assembled matrix (src/NodalMultiColorGS.hpp:180-216).  A dropped entry, a misrouted halo value or boundary row shows at once."""
+    import scipy.sparse as sp
+    import admm_elastic_amd as pkg
+    from admm_elastic_amd import capi
+    import ctypes as C
+    if kind == "cube": sc = scenes.cube_scene(9, pkg.TET_NEOHOOKEAN, linsolver=1)
+    elif kind == "blob": sc = scenes.blob_scene(22, admm_iters=4, linsolver=1)
+    else: sc = scenes.cloth_scene(30, linsolver=1)
+    s = sc.make_solver(init=False)
+    nv = len(sc.x)
+    rp, ci, va = s.host_matrix(sc.product_settings)
+    A = sp.csr_matrix((va, ci, rp), shape=(nv, nv)); A.eliminate_zeros(); A.sort_indices()
+    color, nc = capi.greedy_coloring(A.indptr.astype(np.int32), A.indices.astype(np.int32))
+    assert nc <= 12
+    rng = np.random.default_rng(7)
+    b = rng.standard_normal((nv, 3)); x0 = rng.standard_normal((nv, 3))
+    masses = np.repeat(np.asarray(sc.m, float).reshape(nv, -1)[:, :1], 3, axis=1) if np.asarray(sc.m).size == nv else np.asarray(sc.m, float).reshape(nv, 3)
+    omega, sweeps = 1.9, 3
+    # reference: colour by colour, every row of a colour from the current x
+    x = x0.copy()
+    offd = A - sp.diags(A.diagonal())
+    aii = A.diagonal()[:, None] + masses
+    for _ in range(sweeps):
+        for c in range(nc):
+            rows = np.nonzero(color == c)[0]
+            lux = offd[rows] @ x
+            x[rows] = omega * (b[rows] - lux) / aii[rows] + (1.0 - omega) * x[rows]
+    d = s.make_desc(sc.product_settings)
+    xs = np.ascontiguousarray(x0.ravel().copy()); bb = np.ascontiguousarray(b.ravel())
+    st = np.zeros(6, np.int32)
+    capi.check(capi.lib().admm_host_gs_plan_sweeps(C.byref(d), int(nc), capi.iptr(color.astype(np.int32)), 8, 64, capi.dptr(bb), capi.dptr(xs), sweeps, omega, capi.iptr(st)))
+    assert st[0] > 1 and st[1] == nc and st[3] > 0          # several blocks, a halo
+    err = np.abs(xs.reshape(nv, 3) - x).max() / np.abs(x).max()
+    assert err < 1e-12, err
