@@ -226,7 +226,7 @@ struct admm_hip_ctx {
     int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
     DevBuf<unsigned long long> gs_proj; long long uz_rows_total = 0;   // admm_hip_contact_totals: rows projected inside the GS sweeps (device), rows of C over all UzawaCG solves (host)
     // launch-path two-level PCG (pcg_big.hpp): systems beyond the chip's LDS, and the fall-back of the on-chip kernel
-    bool big_enabled = false, big_tried = false, big_allowed = true; int defl_dbg = 0; std::vector<double> xyz_h;
+    bool big_enabled = false, big_tried = false, big_allowed = true; int defl_dbg = 0, defl_start = 2; std::vector<double> xyz_h;
     int big_G = 0, big_ra = 0, big_rows = 0, big_nc = 0, big_ncp = 0, big_NBt = 0;
     SellDev big_A; DevBuf<int> big_orig; DevBuf<float> big_ainv;
     DevBuf<double> big_mass, big_dinv, big_cwt, big_xi, big_r, big_u, big_w, big_p, big_s, big_part, big_cvec, big_rho, big_dots; DevBuf<int> big_tick;
@@ -950,6 +950,13 @@ void launch_deflation(admm_hip_ctx *c, const double *b, double *x) {
 int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x);
 // The ADMM global solve with the recycled (Galerkin) warm start around the PCG (+ the end projection on the soft modes, when set).
 int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
+    // The Galerkin step on the soft modes ALSO IN FRONT of the solves of a frame whose bit is set in defl_start (ADMM_HIP_DEFL_START=mask at
+    // create; default 2 = the SECOND solve of a frame).  That solve is ADMM's transient -- the first dual update of the frame moves the
+    // right-hand side along the soft modes, by an amount the corrections of earlier frames do not predict -- and it alone took 65-69 of a
+    // frame's ~190 PCG iterations on the bench body whatever the recycled basis held; with the step in front 18-22 (experiments/iters_log.py),
+    // 8.2 -> 5.4 iterations per solve over 200 frames, drift 3.9e-6 -> 3.2e-6 (profiles/r05_drift_start_projection.txt).  In front of the first
+    // solve (mask 3) or the third (mask 6) it costs more than it saves.  Three small launches (k_defl_*), ~0.1 ms per frame.
+    if (c->defl_start && c->defl_k > 0 && c->defl_now && c->rc_iter < 31 && ((c->defl_start >> c->rc_iter) & 1)) launch_deflation(c, b, x);
     const int rc = launch_pcg_recycled_impl(c, b, x);
     if (rc == 0 && c->defl_k > 0 && c->defl_now && !(c->defl_fused && c->oc_enabled)) launch_deflation(c, b, x);      // (fused into k_pcg2's epilogue when the on-chip kernel runs)
     return rc;
@@ -2105,6 +2112,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->counters.alloc(8 + 64 + 8)); HIP_TRY(c->counters.zero());   // [72..74]: totals since create (on-chip PCG)
     c->create_xyz = d->vert_xyz;
     { const char *e = getenv("ADMM_HIP_BIG"); c->big_allowed = !(e && e[0] == '0'); }
+    { const char *e = getenv("ADMM_HIP_DEFL_START"); if (e) c->defl_start = atoi(e); }
     { const char *e = getenv("ADMM_HIP_DEFL_DBG"); if (e) c->defl_dbg = atoi(e); }      // (experiments; bit 3 = the recycled pair carries the soft step: 9.28 -> 8.93 iterations per solve, +1 % ADMM it/s, 200-frame drift 3.9e-6 -> 6.1e-6: off)
     if (d->vert_xyz && d->linsolver != 1) c->xyz_h.assign(d->vert_xyz, d->vert_xyz + c->n3);      // (the launch-path two-level PCG plans lazily)
     {   // distributed solve of ONE body (ADMM_HIP_DIST_SOLVE=1, element-block partition): contiguous vertex rows per rank, 64-aligned
