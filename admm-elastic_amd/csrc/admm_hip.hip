@@ -226,7 +226,7 @@ struct admm_hip_ctx {
     int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
     DevBuf<unsigned long long> gs_proj; long long uz_rows_total = 0;   // admm_hip_contact_totals: rows projected inside the GS sweeps (device), rows of C over all UzawaCG solves (host)
     // launch-path two-level PCG (pcg_big.hpp): systems beyond the chip's LDS, and the fall-back of the on-chip kernel
-    bool big_enabled = false, big_tried = false, big_allowed = true; int defl_dbg = 0, defl_start = 2; std::vector<double> xyz_h;
+    bool big_enabled = false, big_tried = false, big_allowed = true; int defl_dbg = 0, defl_start = 2; bool defl_start_hold = false; std::vector<double> xyz_h;
     int big_G = 0, big_ra = 0, big_rows = 0, big_nc = 0, big_ncp = 0, big_NBt = 0;
     SellDev big_A; DevBuf<int> big_orig; DevBuf<float> big_ainv;
     DevBuf<double> big_mass, big_dinv, big_cwt, big_xi, big_r, big_u, big_w, big_p, big_s, big_part, big_cvec, big_rho, big_dots; DevBuf<int> big_tick;
@@ -956,7 +956,7 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     // frame's ~190 PCG iterations on the bench body whatever the recycled basis held; with the step in front 18-22 (experiments/iters_log.py),
     // 8.2 -> 5.4 iterations per solve over 200 frames, drift 3.9e-6 -> 3.2e-6 (profiles/r05_drift_start_projection.txt).  In front of the first
     // solve (mask 3) or the third (mask 6) it costs more than it saves.  Three small launches (k_defl_*), ~0.1 ms per frame.
-    if (c->defl_start && c->defl_k > 0 && c->defl_now && c->rc_iter < 31 && ((c->defl_start >> c->rc_iter) & 1)) launch_deflation(c, b, x);
+    if (c->defl_start && !c->defl_start_hold && c->defl_k > 0 && c->defl_now && c->rc_iter < 31 && ((c->defl_start >> c->rc_iter) & 1)) launch_deflation(c, b, x);
     const int rc = launch_pcg_recycled_impl(c, b, x);
     if (rc == 0 && c->defl_k > 0 && c->defl_now && !(c->defl_fused && c->oc_enabled)) launch_deflation(c, b, x);      // (fused into k_pcg2's epilogue when the on-chip kernel runs)
     return rc;
@@ -1211,7 +1211,11 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     // x = A^-1 q1, warm-started from the current x and -- like the contact-free solves -- projected on the recycled pairs first
     // (ADMM_HIP_UZ_RECYCLE=0: plain warm start, as in rounds 1-2)
     static const bool uz_rc = [] { const char *e = getenv("ADMM_HIP_UZ_RECYCLE"); return !(e && e[0] == '0'); }();
-    if (uz_rc ? launch_pcg_recycled(c, c->uz_q1.p, x) : launch_pcg(c, c->uz_q1.p, x, c->pcg_max_iters)) return -1;
+    c->defl_start_hold = true;      // (with constraint rows the first solve's right-hand side b - C^T y is the multipliers' kick, not the soft-mode
+                                    // transient of the free solve: the step in front buys nothing there -- cube100k_uzawa_floor 1 357 against 1 396)
+    const int rc_first = uz_rc ? launch_pcg_recycled(c, c->uz_q1.p, x) : launch_pcg(c, c->uz_q1.p, x, c->pcg_max_iters);
+    c->defl_start_hold = false;
+    if (rc_first) return -1;
     hipLaunchKernelGGL(k_uz_resid, dim3(gv), dim3(256), 0, st, nv, x, c->uz_cn.p, c->uz_cc.p, c->uz_r.p, c->uz_d.p, dface, dbary, c->uz_scal.p);
     const double tol2 = c->uz_tol * c->uz_tol;
     UzScal h{};

