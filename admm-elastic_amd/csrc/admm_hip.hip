@@ -854,8 +854,12 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
                 const int need = c->marks_expected - 1;
                 long spins = 0;
                 while (sig[1] < need) { if (++spins > 2000000000L) return -1; }
-                // converged inside the chunks that have DRAINED (iteration count <= their last): a fact every rank reads the same way
-                if (sig[0] == a.seq && sig[3] <= end_prev) break;
+                // Converged inside the chunks that have DRAINED: a fact every rank must read the same way.  The mark the host has just seen is
+                // written by k_big_vec of the previous chunk's LAST iteration (end_prev - 1, 0-based); the verdict of that iteration is written
+                // by the k_big_coarse BEHIND it and may or may not be visible yet -- one rank leaving on it while another launches one more
+                // chunk of collectives is a deadlock (seen once in 40 runs of the suite: a 30-minute gloo time-out).  Verdicts of the iterations
+                // before it (count <= end_prev - 1) precede the mark in stream order: visible to every rank that has seen the mark.
+                if (sig[0] == a.seq && sig[3] <= end_prev - 1) break;
             }
         }
         hipLaunchKernelGGL(k_big_scatter, dim3(nbr), dim3(256), 0, st, a, launched & 1);
