@@ -296,7 +296,9 @@ int admm_hip_get_solver_params(const admm_hip_ctx *ctx, int32_t kind, int32_t *m
  * k <= 64 smooth scalar fields, normally the lowest eigenvectors of K = diag(m) + Ahat (one field serves the three axes).  After every solve
  * of the ADMM loop the iterate is corrected by the exact Galerkin step x += Z (Z^T K Z)^-1 Z^T (b - A x), which removes the error a
  * residual-norm stop leaves in span(Z) -- the soft modes in which the error of an inexact solve is largest and accumulates from frame to
- * frame.  The result of a converged solve changes only within the solver's tolerance.  k = 0 removes the modes. */
+ * frame.  The same step is also taken IN FRONT of the second solve of every frame (ADMM's transient: what the recycled warm start leaves of its
+ * entry error lies in these modes; ADMM_HIP_DEFL_START=mask at create chooses other solves, 0 none).  The result of a converged solve changes
+ * only within the solver's tolerance.  k = 0 removes the modes. */
 int admm_hip_set_soft_modes(admm_hip_ctx *ctx, int32_t k, const double *Z);
 /* ... with the modes computed by the library: the k lowest eigenvectors of K by `iters` (<= 0: 8) steps of inverse subspace iteration on
  * the context's own PCG (a few seconds at 1 M tets, once per scene -- A never changes after Solver::initialize, src/Solver.cpp:225-226).
