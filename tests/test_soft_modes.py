@@ -118,3 +118,25 @@ def test_rank_contexts_compute_the_same_modes_as_the_single_context():
         assert Z.shape == Z1.shape
         assert np.array_equal(Z, Z1), np.abs(Z - Z1).max()
         s.close()
+
+
+def test_start_step_in_front_of_the_second_solve_changes_iterations_not_results(monkeypatch):
+    """ADMM_HIP_DEFL_START (default mask 2): the soft-mode Galerkin step in front of the second solve of a frame is one more exact projection --
+    the converged trajectory moves within the tolerance, the PCG iterations of a frame do not go up (on the bench body: 65 -> 20 for that solve,
+    profiles/r05_drift_start_projection.txt)."""
+    sc = scenes.blob_scene(20, admm_iters=10, linsolver=0)
+    monkeypatch.setenv("ADMM_HIP_DEFL_START", "0")
+    off = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=3000, soft_modes=8)
+    monkeypatch.delenv("ADMM_HIP_DEFL_START")
+    on = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=3000, soft_modes=8)
+    it_on = it_off = 0
+    for f in range(8):
+        on.step(); off.step()
+        if f >= 3:
+            it_on += on.runtime_data().inner_iters; it_off += off.runtime_data().inner_iters
+    d = scenes.rel_err(on.m_x, off.m_x)
+    print("start step: %d vs %d PCG iterations over 5 frames, trajectories differ by %.2e" % (it_on, it_off, d))
+    assert d < 1e-8      # (measured 9e-11; two runs at 1e-10 of this body differ by 5e-6 after eight frames -- each is that far from the 1e-12 trajectory)
+    assert it_on <= 1.02 * it_off
+    assert on.runtime_data().unconverged_solves == 0
+    on.close(); off.close()
