@@ -136,7 +136,7 @@ def test_start_step_in_front_of_the_second_solve_changes_iterations_not_results(
             it_on += on.runtime_data().inner_iters; it_off += off.runtime_data().inner_iters
     d = scenes.rel_err(on.m_x, off.m_x)
     print("start step: %d vs %d PCG iterations over 5 frames, trajectories differ by %.2e" % (it_on, it_off, d))
-    assert d < 1e-8      # (measured 9e-11; two runs at 1e-10 of this body differ by 5e-6 after eight frames -- each is that far from the 1e-12 trajectory)
+    assert d < 1e-8      # (measured 9e-11)
     assert it_on <= 1.02 * it_off
     assert on.runtime_data().unconverged_solves == 0
     on.close(); off.close()
