@@ -552,7 +552,8 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     if (c->oc_coarse) { a.ainv = c->oc_ainv.p; a.cbuf = c->oc_cbuf.p; a.nc = c->oc_nc; a.ncp = c->oc_ncp; }
     a.cwt = c->oc_cwt.p;
     a.skip = rc.skip;
-    a.trust_short = c->oc_always_verify ? 0 : 1;
+    // (every 16th solve and a context's first 40 verify whatever the rule says: the sample that can revoke the trust, pcg_onchip2.hpp)
+    a.trust_short = (c->oc_always_verify || c->oc_launches < 40 || (c->oc_launches & 15) == 0) ? 0 : 1;
     if (rc.on && c->defl_fused && c->defl_k > 0 && c->defl_now) { a.defl_dbg = c->defl_dbg; a.defl_k = c->defl_k; a.defl_Z = c->defl_Zint.p; a.defl_Ginv = c->defl_Ginv.p; a.defl_rec = c->defl_rec.p; }      // (the ADMM loop's solves only: not the K^-1 columns of UzawaCG)
     a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b; a.sm_c0 = c->oc_sm_c0; a.sm_k1 = c->oc_sm_k1; a.sm_k2 = c->oc_sm_k2;
     c->oc_launches += 1;

@@ -1048,6 +1048,26 @@ def test_short_pass_needs_no_verification(monkeypatch):
             assert np.abs(x0 - xe).max() <= 1e-5 * np.abs(xe).max()       # (a residual of 1e-8 is an error of up to cond x 1e-8)
 
 
+def test_trust_rule_is_checked_on_a_sample_and_revoked_when_a_check_fails(monkeypatch):
+    """The short-pass trust rule is an estimate: every 16th solve (and a context's first 40) verifies whatever it says, and a failed check
+    revokes the trust for the context (pcg_onchip2.hpp, counters[76]).  A 1 k-vertex swaying body at pcg_tol 1e-10 is the case it was built
+    for: believed unverified, its solves stop early (5e-6 from the 1e-13 trajectory after eight frames); with the check it lands where the
+    always-verifying run lands (8e-9).  experiments/r05_small_body_accuracy.py."""
+    sc = scenes.blob_scene(20, admm_iters=10, linsolver=0)
+    def run(tol, verify):
+        if verify: monkeypatch.setenv("ADMM_HIP_OC_VERIFY", "1")
+        s = sc.make_solver(pcg_tol=tol, pcg_max_iters=3000)
+        if verify: monkeypatch.delenv("ADMM_HIP_OC_VERIFY")
+        for _ in range(8): s.step()
+        assert s.runtime_data().unconverged_solves == 0
+        x = s.m_x.copy(); s.close()
+        return x
+    ref = run(1e-13, True)
+    e_default, e_verified = scenes.rel_err(run(1e-10, False), ref), scenes.rel_err(run(1e-10, True), ref)
+    print("pcg_tol 1e-10, eight frames: %.2e from the 1e-13 trajectory by default, %.2e with every pass verified" % (e_default, e_verified))
+    assert e_default < 2e-7 and e_default < 20 * max(e_verified, 1e-9)
+
+
 # ---- configs[2] AS BENCHMARKED: the unstructured 1 M-tet body of bench.py (blob1m_mix, n = 118) at full size ----------------
 @pytest.fixture(scope="module")
 def big_blob():
