@@ -15,6 +15,7 @@
 #include <string>
 #include <tuple>
 #include <vector>
+#include <chrono>
 
 #include "../../include/admm_hip.h"
 #include "host_setup.hpp"
@@ -286,6 +287,23 @@ struct admm_hip_ctx {
     int uzc_test_iters = 0;   // tests (ADMM_HIP_TEST_UZ_COL_ITERS=n): the column solves get n iterations, so they do not converge
     bool uzc_compact = true; int uzc_one_max = 1024, uzc_compact_max = 8192;   // (the limits are lowered by tests to reach the general paths on small scenes)
     std::vector<int> uzc_slot_h;
+    // Column solves on side streams (uz_ensure_columns): on a small body k_pcg2 occupies a fraction of the chip (77 blocks at 20 k
+    // vertices) and its iteration is bound by the grid barrier's latency, so several independent solves run side by side.  A lane owns
+    // every buffer the kernel WRITES (published vector, partial sums, barrier words, hand-off flags, coarse sums, counters, b, x, u).
+    struct OcLane {
+        hipStream_t st = nullptr; hipEvent_t done = nullptr; int seq = 0;
+        DevBuf<char> slab;      // one allocation per lane (hipMalloc costs ~0.3 ms: a lane is set up inside a frame)
+        double *ubuf = nullptr, *part = nullptr, *cbuf = nullptr, *b = nullptr, *x = nullptr, *u = nullptr;
+        unsigned *bar = nullptr; unsigned long long *flags = nullptr; CgScal *scal = nullptr; int *counters = nullptr;
+        void release() {
+            slab.release();
+            if (done) (void)hipEventDestroy(done);
+            if (st) (void)hipStreamDestroy(st);
+            done = nullptr; st = nullptr;
+        }
+    };
+    std::vector<OcLane> uz_lanes; hipEvent_t uz_fork = nullptr; int uz_lanes_cfg = -1;   // uz_lanes_cfg: ADMM_HIP_UZ_LANES (1 = the main stream only; default: what fits, <= 8)
+    long long uzc_lane_batches = 0;
     long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0, uzc_evictions = 0, uzc_unconverged = 0;
     bool uz_freeze = false, uz_detected = false;   // tests (ADMM_HIP_UZ_FREEZE=1): Collider::detect only in the first ADMM iteration of a step
     // GS: the whole solve (colours x sweeps + residual tests, ~500 tiny launches) is captured once into a
@@ -351,6 +369,9 @@ struct admm_hip_ctx {
         gsd_hits.release(); gsd_skip.release(); gsd_part.release(); gsd_int.release(); gsd_dbl.release(); gsd_hnode.release();
         lk_ts.release(); lk_out.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
+        for (OcLane &ln : uz_lanes) ln.release();
+        uz_lanes.clear();
+        if (uz_fork) (void)hipEventDestroy(uz_fork);
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
         for (hipEvent_t e : lt_ev) (void)hipEventDestroy(e);
         if (gs_exec) (void)hipGraphExecDestroy(gs_exec);
@@ -531,8 +552,8 @@ int oc_diagnostics(admm_hip_ctx *c, int seq) {
 struct OcRc { bool on = false; RcBasis B{}; double *Eslot = nullptr, *Rslot = nullptr; const int *skip = nullptr; };
 
 // General-mesh plan: k_pcg2 (pcg_onchip2.hpp)
-int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, const OcRc &rc) {
-    hipStream_t st = c->stream;
+int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, const OcRc &rc, admm_hip_ctx::OcLane *ln = nullptr) {
+    hipStream_t st = ln ? ln->st : c->stream;
     Oc2Args a{};
     a.n_rows = c->oc_rows; a.n_slices = c->oc_A.n_slices;
     a.ptr = c->oc_A.ptr.p; a.w = c->oc_A.w.p; a.val = c->oc_A.val.p; a.col16 = c->oc_col16.p;
@@ -543,8 +564,8 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.nbr = c->oc_nbr.p; a.flags = c->oc_flags.p;
     a.counters = c->counters.p; a.scal = c->cg_scal.p; a.sig = c->d_sig;
     a.prof = c->oc_prof.p; a.prof_block = c->oc_prof_block;
-    a.spb = c->oc_spb; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ++c->solve_seq;
-    if (c->test_abort_seq > 0 && a.seq == c->test_abort_seq)   // test hook: raise the abort word of this solve's barrier set
+    a.spb = c->oc_spb; a.G = c->oc_G; a.max_iters = max_iters; a.seq = ln ? ++ln->seq : ++c->solve_seq;
+    if (!ln && c->test_abort_seq > 0 && a.seq == c->test_abort_seq)   // test hook: raise the abort word of this solve's barrier set
         if (hipMemsetAsync(c->oc_bar.p + 32 * 16 * (a.seq & 1) + 16 * 17, 1, sizeof(unsigned), st) != hipSuccess) return -1;
     a.tol2 = c->pcg_tol * c->pcg_tol;
     a.rc_on = rc.on ? 1 : 0; a.rc = rc.B; a.rc_xs = c->rc_xs.p; a.rc_r0 = c->rc_r0.p; a.rc_Eslot = rc.Eslot; a.rc_Rslot = rc.Rslot;
@@ -557,8 +578,15 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     if (rc.on && c->defl_fused && c->defl_k > 0 && c->defl_now) { a.defl_dbg = c->defl_dbg; a.defl_k = c->defl_k; a.defl_Z = c->defl_Zint.p; a.defl_Ginv = c->defl_Ginv.p; a.defl_rec = c->defl_rec.p; }      // (the ADMM loop's solves only: not the K^-1 columns of UzawaCG)
     a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b; a.sm_c0 = c->oc_sm_c0; a.sm_k1 = c->oc_sm_k1; a.sm_k2 = c->oc_sm_k2;
     c->oc_launches += 1;
+    if (ln) {      // a side-stream solve (UzawaCG's columns): the lane's own copies of everything the kernel writes, no diagnosis
+        a.u_out = ln->u; a.ubuf = ln->ubuf; a.part = ln->part; a.bar = ln->bar; a.flags = c->oc_flags.p ? ln->flags : nullptr;
+        a.counters = ln->counters; a.scal = ln->scal; a.prof = nullptr;
+        if (c->oc_coarse) a.cbuf = ln->cbuf;
+        a.trust_short = 0;
+    }
     if (c->oc_T <= 768) hipLaunchKernelGGL((k_pcg2<768>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
     else hipLaunchKernelGGL((k_pcg2<1024>), dim3(c->oc_G), dim3(c->oc_T), c->oc_lds, st, a);
+    if (ln) return 0;
     c->last_launched_iters = 0;
     if (c->oc_debug || c->oc_prof.p) return oc_diagnostics(c, a.seq);
     return 0;
@@ -1051,6 +1079,101 @@ int enqueue_dyn_detect(admm_hip_ctx *c, const double *x) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// How many column solves may run side by side: as many instances of k_pcg2 as the chip holds at once (every block of a persistent
+// kernel must be resident: the occupancy query decides, never the switch), at most 8.  1 = the main stream only.  The lanes cycle
+// through the stream priorities: the runtime multiplexes streams of ONE priority on four hardware queues, where two lanes on the same
+// queue serialise (measured, 243 launches on the 20 k-vertex cube: 231 ms on the main stream; equal priorities 116 / 84-152 / 116 / 91 ms
+// on 2 / 3 / 4 / 8 lanes depending on which lanes collide; cycled priorities 117 / 89 / 70 / 49 / 38 ms on 2 / 3 / 4 / 6 / 8 lanes --
+// profiles/r05_uzawa_column_lanes.txt).
+int uz_lane_count(admm_hip_ctx *c, int launches) {
+    if (!c->oc_enabled || c->dist_solve || c->oc_debug || c->oc_prof.p || launches < 2) return 1;
+    if (c->uz_lanes_cfg == 1) return 1;
+    int per_cu = 0;
+    const hipError_t e = c->oc_T <= 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<768>, c->oc_T, c->oc_lds)
+                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<1024>, c->oc_T, c->oc_lds);
+    if (e != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); return 1; }
+    const long long fit = (long long)per_cu * c->n_cus / std::max(1, c->oc_G);
+    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(c->uz_lanes_cfg > 0 ? c->uz_lanes_cfg : 8, fit), launches));
+}
+
+// The lanes of uz_columns_on_lanes: stream, event and one slab of device memory each (set up at create for scenes with colliders, so
+// that the first touchdown does not pay for it).  0 ok.
+int uz_make_lanes(admm_hip_ctx *c, int L) {
+    typedef admm_hip_ctx::OcLane Lane;
+    if (!c->uz_fork && hipEventCreateWithFlags(&c->uz_fork, hipEventDisableTiming) != hipSuccess) return -1;
+    while ((int)c->uz_lanes.size() < L) {
+        c->uz_lanes.emplace_back();
+        Lane &ln = c->uz_lanes.back();
+        // the runtime keeps separate hardware queues per stream priority: lanes of different priority never share one
+        static const int prio_mode = [] { const char *e = getenv("ADMM_HIP_UZ_LANE_PRIO"); return e ? atoi(e) : 1; }();
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);      // (lowest, highest): numerically phi <= plo
+        const int idx = (int)c->uz_lanes.size() - 1, span = plo - phi + 1;
+        const int prio = (prio_mode && span > 1) ? phi + idx % span : 0;
+        if (hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) return -1;
+        size_t off = 0;
+        auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_ubuf = take(c->oc_ubuf.n * 8), o_part = take(c->oc_part.n * 8), o_cbuf = take(c->oc_cbuf.n * 8), o_bar = take(c->oc_bar.n * 4),
+                     o_flags = take(c->oc_flags.n * 8), o_scal = take(2 * sizeof(CgScal)), o_cnt = take(c->counters.n * 4),
+                     o_b = take(c->n3 * 8), o_x = take(c->n3 * 8), o_u = take(c->n3 * 8);
+        // (cleared ON the lane's stream: its first operation makes the runtime create the hardware queue behind it, ~5 ms each -- here, not in the first batch)
+        if (ln.slab.alloc(off) != hipSuccess || hipMemsetAsync(ln.slab.p, 0, off, ln.st) != hipSuccess || hipStreamSynchronize(ln.st) != hipSuccess) return -1;
+        char *p = ln.slab.p;
+        ln.ubuf = (double *)(p + o_ubuf); ln.part = (double *)(p + o_part); ln.cbuf = (double *)(p + o_cbuf); ln.bar = (unsigned *)(p + o_bar);
+        ln.flags = (unsigned long long *)(p + o_flags); ln.scal = (CgScal *)(p + o_scal); ln.counters = (int *)(p + o_cnt);
+        ln.b = (double *)(p + o_b); ln.x = (double *)(p + o_x); ln.u = (double *)(p + o_u);
+    }
+    return 0;
+}
+
+// The batch of uz_ensure_columns on L side streams.  *converged = solves that met their tolerance.  0 ok, -1 error.
+int uz_columns_on_lanes(admm_hip_ctx *c, const std::vector<int> &miss, const std::vector<int> &slots, int n_missing, int L, int max_iters,
+                        int *launched, int *converged) {
+    typedef admm_hip_ctx::OcLane Lane;
+    const int nv = c->nv;
+    if (uz_make_lanes(c, L)) return -1;
+
+    if (hipEventRecord(c->uz_fork, c->stream) != hipSuccess) return -1;
+    for (int l = 0; l < L; ++l) {
+        Lane &ln = c->uz_lanes[l];
+        if (hipStreamWaitEvent(ln.st, c->uz_fork, 0) != hipSuccess) return -1;
+        if (hipMemsetAsync(ln.counters, 0, c->counters.n * sizeof(int), ln.st) != hipSuccess || hipMemsetAsync(ln.bar, 0, c->oc_bar.n * sizeof(unsigned), ln.st) != hipSuccess) return -1;
+        // [75] the block smoother was given up, [76] the short-pass trust was revoked: the context's findings hold for the lanes too
+        if (hipMemcpyAsync(ln.counters + 75, c->counters.p + 75, 2 * sizeof(int), hipMemcpyDeviceToDevice, ln.st) != hipSuccess) return -1;
+    }
+    static const bool dbg = [] { const char *e = getenv("ADMM_HIP_UZ_LANES_DEBUG"); return e && e[0] == '1'; }();
+    const auto t_enq0 = std::chrono::steady_clock::now();
+    int n = 0;
+    for (int k = 0; k < n_missing; k += 3, ++n) {
+        Lane &ln = c->uz_lanes[n % L];
+        int v[3], sl[3];
+        for (int j = 0; j < 3; ++j) { v[j] = k + j < n_missing ? miss[k + j] : -1; sl[j] = v[j] >= 0 ? slots[k + j] : -1; }
+        hipLaunchKernelGGL(k_uz_unit_rhs_x0, dim3(blocks_for(c->n3)), dim3(256), 0, ln.st, (int)c->n3, v[0], v[1], v[2], ln.b, ln.x);
+        if (launch_pcg2(c, ln.b, ln.x, max_iters, OcRc(), &ln)) return -1;
+        hipLaunchKernelGGL(k_uz_store_cols, dim3(blocks_for(nv)), dim3(256), 0, ln.st, nv, ln.x, c->uzc_cols.p, sl[0], sl[1], sl[2]);
+        c->uzc_col_solves += 1;
+    }
+    *launched = n;
+    for (int l = 0; l < L; ++l) {
+        Lane &ln = c->uz_lanes[l];
+        if (hipEventRecord(ln.done, ln.st) != hipSuccess || hipStreamWaitEvent(c->stream, ln.done, 0) != hipSuccess) return -1;
+    }
+    const auto t_enq1 = std::chrono::steady_clock::now();
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    if (dbg) fprintf(stderr, "[uz_lanes] %d solves on %d streams: enqueued in %.2f ms, done after %.2f ms\n", n, L,
+                     std::chrono::duration<double, std::milli>(t_enq1 - t_enq0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count());
+    int conv = 0;
+    for (int l = 0; l < L; ++l) {
+        int v = 0;
+        if (hipMemcpy(&v, c->uz_lanes[l].counters + 4, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        conv += v;
+    }
+    *converged = conv;
+    c->uzc_lane_batches += 1;
+    return 0;
+}
+
 // Columns of K^-1 for the vertices listed in uzc_miss (n_missing of them): three per PCG launch (one per axis), at a tolerance two
 // orders below the context's.  1 = every active vertex now has its column, 0 = the cache is full (this solve uses the PCG), -1 error.
 int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
@@ -1094,13 +1217,17 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     int cnt0[8], tot0[3];
     if (hipMemcpy(cnt0, c->counters.p, sizeof(cnt0), hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(tot0, c->counters.p + 72, sizeof(tot0), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    int launched = 0;
+    int launched = 0, lane_conv = -1;
+    const int max_col_iters = c->uzc_test_iters > 0 ? c->uzc_test_iters : std::max(c->pcg_max_iters, 2000);
+    const int lanes = uz_lane_count(c, (n_missing + 2) / 3);
+    if (lanes >= 2) { if (uz_columns_on_lanes(c, miss, slots, n_missing, lanes, max_col_iters, &launched, &lane_conv)) rc = -1; }
+    else
     for (int k = 0; k < n_missing && rc == 1; k += 3) {
         int v[3], sl[3];
         for (int j = 0; j < 3; ++j) { v[j] = k + j < n_missing ? miss[k + j] : -1; sl[j] = v[j] >= 0 ? slots[k + j] : -1; }
         if (hipMemsetAsync(c->uz_q1.p, 0, c->n3 * sizeof(double), st) != hipSuccess || hipMemsetAsync(c->uz_q2.p, 0, c->n3 * sizeof(double), st) != hipSuccess) { rc = -1; break; }
         hipLaunchKernelGGL(k_uz_unit_rhs, dim3(1), dim3(1), 0, st, v[0], v[1], v[2], c->uz_q1.p);
-        if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, c->uzc_test_iters > 0 ? c->uzc_test_iters : std::max(c->pcg_max_iters, 2000))) { rc = -1; break; }
+        if (launch_pcg(c, c->uz_q1.p, c->uz_q2.p, max_col_iters)) { rc = -1; break; }
         hipLaunchKernelGGL(k_uz_store_cols, dim3(blocks_for(nv)), dim3(256), 0, st, nv, c->uz_q2.p, c->uzc_cols.p, sl[0], sl[1], sl[2]);
         c->uzc_col_solves += 1; ++launched;
     }
@@ -1110,7 +1237,8 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     // Did every column solve meet its tolerance?  A column that ran out of iterations would be a wrong Schur operator for every later
     // solve: the batch is then not committed and this solve applies A^-1 by inner PCG solves (rc 0), counted in uzc_unconverged.
     bool all_converged = true;
-    if (rc == 1 && !aborted) {
+    if (rc == 1 && !aborted && lane_conv >= 0) all_converged = lane_conv == launched;      // (the lanes count in their own counters: nothing to restore)
+    else if (rc == 1 && !aborted) {
         int cnt1[8];
         if (hipMemcpy(cnt1, c->counters.p, sizeof(cnt1), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
         else {
@@ -2259,6 +2387,11 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 { const char *pe = getenv("ADMM_HIP_UZ_PERSIST"); c->uzp_enabled = !(pe && pe[0] == '0'); }
                 { const char *lb = getenv("ADMM_HIP_UZ_LIST_BLOCKS"); if (lb) c->uzc_one_block_max = std::max(0, atoi(lb)); }
                 { const char *ta = getenv("ADMM_HIP_TEST_ABORT_SCHUR"); c->test_abort_uzp = ta ? atoi(ta) : 0; }
+                { const char *le = getenv("ADMM_HIP_UZ_LANES"); c->uz_lanes_cfg = le ? std::max(1, std::min(8, atoi(le))) : 0; }      // streams of a batch of column solves (uz_lane_count)
+                if (d->n_obstacles > 0) {      // a scene with colliders will need columns: the lanes are set up here, not inside its first touchdown
+                    const int L = uz_lane_count(c, 8);
+                    if (L >= 2 && uz_make_lanes(c, L)) return fail(ADMM_HIP_ERR_DEVICE, "create: streams / memory of the UzawaCG column lanes");
+                }
                 { const char *pr = getenv("ADMM_HIP_UZ_PERSIST_ROWS"); c->uzp_rows = (pr && (atoi(pr) == 8 || atoi(pr) == 16)) ? atoi(pr) : 0; }   // 0: two launches per Schur iteration (A/B, tests)   // 0: full-height column pass in every Schur iteration (A/B)
                 { const char *e1 = getenv("ADMM_HIP_UZ_ONE_MAX"), *e2 = getenv("ADMM_HIP_UZ_COMPACT_MAX");      // test hooks
                   if (e1) c->uzc_one_max = std::max(0, std::min(1024, atoi(e1))); if (e2) c->uzc_compact_max = std::max(0, atoi(e2)); }
@@ -3556,6 +3689,12 @@ int admm_hip_uzawa_cache_stats(admm_hip_ctx *c, int64_t *columns, int64_t *colum
     }
     if (schur_by_pcg) *schur_by_pcg = c->uzc_pcg_solves;
     if (evicted) *evicted = c->uzc_evictions;
+    return ADMM_HIP_OK;
+}
+int admm_hip_uzawa_column_lanes(admm_hip_ctx *c, int64_t *batches, int *lanes) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "uzawa_column_lanes: NULL context");
+    if (batches) *batches = c->uzc_lane_batches;
+    if (lanes) *lanes = (int)c->uz_lanes.size();
     return ADMM_HIP_OK;
 }
 int admm_hip_uzawa_unconverged_columns(admm_hip_ctx *c, int64_t *n) {

@@ -1997,6 +1997,13 @@ __global__ void k_uz_unit_rhs(int v0, int v1, int v2, double *__restrict__ rhs) 
     if (v1 >= 0) rhs[3 * (size_t)v1 + 1] = 1.0;
     if (v2 >= 0) rhs[3 * (size_t)v2 + 2] = 1.0;
 }
+// the same right-hand side and the zero start vector in ONE launch (the side-stream batches are bound by the host's launch rate)
+__global__ __launch_bounds__(256) void k_uz_unit_rhs_x0(int n3, int v0, int v1, int v2, double *__restrict__ rhs, double *__restrict__ x) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n3) return;
+    rhs[i] = (i == 3 * v0 || i == 3 * v1 + 1 || i == 3 * v2 + 2) ? 1.0 : 0.0;      // (v < 0: 3 v + j < 0 never matches)
+    x[i] = 0.0;
+}
 __global__ __launch_bounds__(256) void k_uz_store_cols(int nv, const double *__restrict__ sol, double *__restrict__ cols, int s0, int s1, int s2) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nv) return;

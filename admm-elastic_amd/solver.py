@@ -669,6 +669,9 @@ class Solver:
         u = C.c_int64(0)
         check(lib().admm_hip_uzawa_unconverged_columns(self._ctx, C.byref(u)))
         d["unconverged_columns"] = u.value
+        nb, nl = C.c_int64(0), C.c_int(0)
+        check(lib().admm_hip_uzawa_column_lanes(self._ctx, C.byref(nb), C.byref(nl)))
+        d["lane_batches"], d["lanes"] = nb.value, nl.value
         return d
 
     def tet_rest_mode(self):

@@ -422,6 +422,11 @@ int admm_hip_uzawa_cache_stats(admm_hip_ctx *ctx, int64_t *columns, int64_t *col
  * (an inexact column would be a wrong Schur operator for every later solve), the solve that asked for them applies A^-1 by inner PCG
  * solves instead.  0 in every healthy run. */
 int admm_hip_uzawa_unconverged_columns(admm_hip_ctx *ctx, int64_t *n);
+/* The column solves of a batch run side by side on up to 8 streams when several instances of the on-chip PCG kernel fit the chip at
+ * once (small bodies: the kernel of a 20 k-vertex body holds 77 of 256 CUs and is bound by its grid barrier's latency).  The count is
+ * the occupancy of the kernel, never more; ADMM_HIP_UZ_LANES=n (1..8) lowers it, 1 = the main stream only.  batches: batches solved on
+ * more than one stream since create; lanes: streams set up (at create for scenes with colliders, else by the first such batch). */
+int admm_hip_uzawa_column_lanes(admm_hip_ctx *ctx, int64_t *batches, int *lanes);
 /* A user-defined PassiveCollision on the device (src/Collider.hpp:66-83; the reference calls signed_distance per vertex inside
  * Collider::detect_passive, :137-150).  fn(user, x, out7) evaluates the object at x on a FRESH payload: out7 = signed distance, contact
  * point xyz, normal xyz.  Sampled at the nx x ny x nz nodes of the box [lo, hi] (each n >= 2) into meta10_out (node offset 0: the

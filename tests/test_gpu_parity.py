@@ -539,6 +539,37 @@ def test_global_solve_uzawa_collisions(what):
         assert np.abs(X[hv, 1] - sc.obstacles[0][1][0]).max() < 1e-6
 
 
+def test_uzawa_column_solves_side_by_side(monkeypatch):
+    """The columns of K^-1 of a batch are solved on several streams at once when several instances of the on-chip PCG kernel fit the
+    chip (admm_hip_uzawa_column_lanes): same columns, same Schur solve as on the main stream alone (ADMM_HIP_UZ_LANES=1), and the
+    solver's own counters do not see them."""
+    sc = scenes.cube_scene(12, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=8, linsolver=2, size=0.5)
+    sc.obstacles.append((0, [0.03, 0.0, 0.0, 0.0]))
+    rng = np.random.default_rng(3)
+    x = sc.x.copy(); x[:, 1] -= 0.02 + 0.03 * rng.random(len(x)); x = x.ravel()
+    o = sc.make_oracle(mode=1)
+    b = o.A @ (x + 0.001 * rng.standard_normal(x.size))
+    res = {}
+    for lanes in ("1", None, "3"):
+        if lanes: monkeypatch.setenv("ADMM_HIP_UZ_LANES", lanes)
+        s = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
+        if lanes: monkeypatch.delenv("ADMM_HIP_UZ_LANES")
+        xg, itg = s.global_solve(b, x)
+        st = s.uzawa_cache_stats()
+        assert st["unconverged_columns"] == 0 and st["schur_by_pcg"] == 0 and st["columns"] > 100, st
+        assert st["column_solves"] == (st["columns"] + 2) // 3, st
+        tot = s.solve_totals()
+        assert tot[0] < 0 or tot[0] <= 2, tot
+        res[lanes] = (xg, itg, st)
+    assert res["1"][2]["lanes"] == 0 and res["1"][2]["lane_batches"] == 0
+    assert res[None][2]["lanes"] >= 2 and res[None][2]["lane_batches"] >= 1, res[None][2]
+    assert res["3"][2]["lanes"] == 3, res["3"][2]
+    for k in (None, "3"):
+        assert np.abs(res[k][0] - res["1"][0]).max() < 1e-10 and abs(res[k][1] - res["1"][1]) <= 1, (k, np.abs(res[k][0] - res["1"][0]).max())
+    xo, _ = o.solve_uzawa(x, b, o.detect_passive(x))
+    assert np.abs(res[None][0] - xo).max() < 1e-7
+
+
 def test_uzawa_cached_columns_equal_inner_solves(monkeypatch):
     """The Schur iterations apply A^-1 through cached columns of K^-1 instead of one PCG solve each -- on the active vertices only
     (the active x active block of K^-1, x updated once after the loop), or as a full-height column pass per iteration
