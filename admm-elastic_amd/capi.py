@@ -115,7 +115,7 @@ SYMBOLS = [
     ("admm_hip_tet_rest_mode", C.c_int, [C.c_void_p]),
     ("admm_hip_uzawa_cache_stats", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 5),
     ("admm_hip_uzawa_unconverged_columns", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
-    ("admm_hip_uzawa_column_lanes", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ("admm_hip_uzawa_column_lanes", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("admm_host_sample_obstacle", C.c_int, [OBSTACLE_FN, C.c_void_p, c_double_p, c_double_p, c_int_p, c_double_p, c_double_p]),
     ("admm_host_bend_hinges", C.c_int32, [C.c_int32, C.c_int32, c_int_p, c_double_p, C.c_int32, c_int_p, c_double_p, c_double_p]),
     ("admm_host_tri_rest", C.c_int, [C.c_int32, c_int_p, c_double_p, c_double_p, c_double_p]),

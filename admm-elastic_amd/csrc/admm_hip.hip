@@ -296,6 +296,7 @@ struct admm_hip_ctx {
         double *ubuf = nullptr, *part = nullptr, *cbuf = nullptr, *b = nullptr, *x = nullptr, *u = nullptr;
         unsigned *bar = nullptr; unsigned long long *flags = nullptr; CgScal *scal = nullptr; int *counters = nullptr;
         void release() {
+            if (st) (void)hipStreamSynchronize(st);      // (look-ahead solves may still be in flight)
             slab.release();
             if (done) (void)hipEventDestroy(done);
             if (st) (void)hipStreamDestroy(st);
@@ -304,6 +305,10 @@ struct admm_hip_ctx {
     };
     std::vector<OcLane> uz_lanes; hipEvent_t uz_fork = nullptr; int uz_lanes_cfg = -1;   // uz_lanes_cfg: ADMM_HIP_UZ_LANES (1 = the main stream only; default: what fits, <= 8)
     long long uzc_lane_batches = 0;
+    // columns solved AHEAD of the contact (uz_ahead_launch): in flight on the lanes while the ADMM loop goes on, committed when they are done
+    bool pf_on = false, in_step = false; double pf_frames = 4.0; int uz_fit = -1;
+    DevBuf<int> pf_list; std::vector<int> pf_v, pf_slot; int pf_launched = 0, pf_lanes = 0;
+    long long pf_batches = 0, pf_columns = 0, pf_waits = 0;
     long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0, uzc_evictions = 0, uzc_unconverged = 0;
     bool uz_freeze = false, uz_detected = false;   // tests (ADMM_HIP_UZ_FREEZE=1): Collider::detect only in the first ADMM iteration of a step
     // GS: the whole solve (colours x sweeps + residual tests, ~500 tiny launches) is captured once into a
@@ -370,7 +375,7 @@ struct admm_hip_ctx {
         lk_ts.release(); lk_out.release();
         dyn.clear(); dyn_face.release(); surf_list.release(); dyn_bary.release(); dyn_n.release(); dyn_dx.release(); surf_mask.release();
         for (OcLane &ln : uz_lanes) ln.release();
-        uz_lanes.clear();
+        uz_lanes.clear(); pf_list.release();
         if (uz_fork) (void)hipEventDestroy(uz_fork);
         for (hipEvent_t e : ev_phase) (void)hipEventDestroy(e);
         for (hipEvent_t e : lt_ev) (void)hipEventDestroy(e);
@@ -1085,15 +1090,19 @@ int enqueue_dyn_detect(admm_hip_ctx *c, const double *x) {
 // queue serialise (measured, 243 launches on the 20 k-vertex cube: 231 ms on the main stream; equal priorities 116 / 84-152 / 116 / 91 ms
 // on 2 / 3 / 4 / 8 lanes depending on which lanes collide; cycled priorities 117 / 89 / 70 / 49 / 38 ms on 2 / 3 / 4 / 6 / 8 lanes --
 // profiles/r05_uzawa_column_lanes.txt).
-int uz_lane_count(admm_hip_ctx *c, int launches) {
-    if (!c->oc_enabled || c->dist_solve || c->oc_debug || c->oc_prof.p || launches < 2) return 1;
-    if (c->uz_lanes_cfg == 1) return 1;
+int uz_lane_fit(admm_hip_ctx *c) {      // instances of k_pcg2 the chip holds at once
+    if (c->uz_fit >= 0) return c->uz_fit;
     int per_cu = 0;
     const hipError_t e = c->oc_T <= 768 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<768>, c->oc_T, c->oc_lds)
                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg2<1024>, c->oc_T, c->oc_lds);
-    if (e != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); return 1; }
-    const long long fit = (long long)per_cu * c->n_cus / std::max(1, c->oc_G);
-    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(c->uz_lanes_cfg > 0 ? c->uz_lanes_cfg : 8, fit), launches));
+    if (e != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); per_cu = 1; }
+    c->uz_fit = (int)std::min<long long>(64, (long long)per_cu * c->n_cus / std::max(1, c->oc_G));
+    return c->uz_fit;
+}
+int uz_lane_count(admm_hip_ctx *c, int launches) {
+    if (!c->oc_enabled || c->dist_solve || c->oc_debug || c->oc_prof.p || launches < 2) return 1;
+    if (c->uz_lanes_cfg == 1) return 1;
+    return std::max(1, std::min(std::min(c->uz_lanes_cfg > 0 ? c->uz_lanes_cfg : 8, uz_lane_fit(c)), launches));
 }
 
 // The lanes of uz_columns_on_lanes: stream, event and one slab of device memory each (set up at create for scenes with colliders, so
@@ -1126,13 +1135,12 @@ int uz_make_lanes(admm_hip_ctx *c, int L) {
     return 0;
 }
 
-// The batch of uz_ensure_columns on L side streams.  *converged = solves that met their tolerance.  0 ok, -1 error.
-int uz_columns_on_lanes(admm_hip_ctx *c, const std::vector<int> &miss, const std::vector<int> &slots, int n_missing, int L, int max_iters,
-                        int *launched, int *converged) {
+// Column solves dealt round-robin onto L lanes: fork from the context's stream, three vertices per launch, one `done` event per lane.
+// Does NOT wait.  0 ok, -1 error.
+int uz_lanes_enqueue(admm_hip_ctx *c, const std::vector<int> &verts, const std::vector<int> &slots, int n_verts, int L, int max_iters, int *launched) {
     typedef admm_hip_ctx::OcLane Lane;
     const int nv = c->nv;
     if (uz_make_lanes(c, L)) return -1;
-
     if (hipEventRecord(c->uz_fork, c->stream) != hipSuccess) return -1;
     for (int l = 0; l < L; ++l) {
         Lane &ln = c->uz_lanes[l];
@@ -1141,28 +1149,22 @@ int uz_columns_on_lanes(admm_hip_ctx *c, const std::vector<int> &miss, const std
         // [75] the block smoother was given up, [76] the short-pass trust was revoked: the context's findings hold for the lanes too
         if (hipMemcpyAsync(ln.counters + 75, c->counters.p + 75, 2 * sizeof(int), hipMemcpyDeviceToDevice, ln.st) != hipSuccess) return -1;
     }
-    static const bool dbg = [] { const char *e = getenv("ADMM_HIP_UZ_LANES_DEBUG"); return e && e[0] == '1'; }();
-    const auto t_enq0 = std::chrono::steady_clock::now();
     int n = 0;
-    for (int k = 0; k < n_missing; k += 3, ++n) {
+    for (int k = 0; k < n_verts; k += 3, ++n) {
         Lane &ln = c->uz_lanes[n % L];
         int v[3], sl[3];
-        for (int j = 0; j < 3; ++j) { v[j] = k + j < n_missing ? miss[k + j] : -1; sl[j] = v[j] >= 0 ? slots[k + j] : -1; }
+        for (int j = 0; j < 3; ++j) { v[j] = k + j < n_verts ? verts[k + j] : -1; sl[j] = v[j] >= 0 ? slots[k + j] : -1; }
         hipLaunchKernelGGL(k_uz_unit_rhs_x0, dim3(blocks_for(c->n3)), dim3(256), 0, ln.st, (int)c->n3, v[0], v[1], v[2], ln.b, ln.x);
         if (launch_pcg2(c, ln.b, ln.x, max_iters, OcRc(), &ln)) return -1;
         hipLaunchKernelGGL(k_uz_store_cols, dim3(blocks_for(nv)), dim3(256), 0, ln.st, nv, ln.x, c->uzc_cols.p, sl[0], sl[1], sl[2]);
         c->uzc_col_solves += 1;
     }
     *launched = n;
-    for (int l = 0; l < L; ++l) {
-        Lane &ln = c->uz_lanes[l];
-        if (hipEventRecord(ln.done, ln.st) != hipSuccess || hipStreamWaitEvent(c->stream, ln.done, 0) != hipSuccess) return -1;
-    }
-    const auto t_enq1 = std::chrono::steady_clock::now();
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
-    if (dbg) fprintf(stderr, "[uz_lanes] %d solves on %d streams: enqueued in %.2f ms, done after %.2f ms\n", n, L,
-                     std::chrono::duration<double, std::milli>(t_enq1 - t_enq0).count(),
-                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count());
+    for (int l = 0; l < L; ++l)
+        if (hipEventRecord(c->uz_lanes[l].done, c->uz_lanes[l].st) != hipSuccess) return -1;
+    return 0;
+}
+int uz_lanes_converged(admm_hip_ctx *c, int L, int *converged) {      // (after the lanes are done) solves that met their tolerance
     int conv = 0;
     for (int l = 0; l < L; ++l) {
         int v = 0;
@@ -1170,7 +1172,107 @@ int uz_columns_on_lanes(admm_hip_ctx *c, const std::vector<int> &miss, const std
         conv += v;
     }
     *converged = conv;
+    return 0;
+}
+
+// The batch of uz_ensure_columns on L side streams.  *converged = solves that met their tolerance.  0 ok, -1 error.
+int uz_columns_on_lanes(admm_hip_ctx *c, const std::vector<int> &miss, const std::vector<int> &slots, int n_missing, int L, int max_iters,
+                        int *launched, int *converged) {
+    static const bool dbg = [] { const char *e = getenv("ADMM_HIP_UZ_LANES_DEBUG"); return e && e[0] == '1'; }();
+    const auto t_enq0 = std::chrono::steady_clock::now();
+    if (uz_lanes_enqueue(c, miss, slots, n_missing, L, max_iters, launched)) return -1;
+    for (int l = 0; l < L; ++l)
+        if (hipStreamWaitEvent(c->stream, c->uz_lanes[l].done, 0) != hipSuccess) return -1;
+    const auto t_enq1 = std::chrono::steady_clock::now();
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    if (dbg) fprintf(stderr, "[uz_lanes] ctx %p frame %d: %d solves on %d streams: enqueued in %.2f ms, done after %.2f ms\n", (void *)c, c->rc_frame, *launched, L,
+                     std::chrono::duration<double, std::milli>(t_enq1 - t_enq0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enq0).count());
+    if (uz_lanes_converged(c, L, converged)) return -1;
     c->uzc_lane_batches += 1;
+    return 0;
+}
+
+// Room for `top` columns in uzc_cols (doubling, at least 64 columns, never beyond the cap; the columns move once).  Must not be called
+// while lanes are writing columns.  1 ok, 0 no room, -1 error.
+int uz_grow_cols(admm_hip_ctx *c, size_t top) {
+    const int nv = c->nv;
+    if (top * (size_t)nv <= c->uzc_cols.n) return 1;
+    const size_t have = c->uzc_cols.n / (size_t)nv, cols = std::min(c->uzc_cap, std::max<size_t>(top, std::max<size_t>(64, 2 * have)));
+    if (cols < top) return 0;
+    DevBuf<double> nb;
+    if (nb.alloc(cols * (size_t)nv) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { nb.release(); return -1; }
+    if (c->uzc_n > 0 && hipMemcpy(nb.p, c->uzc_cols.p, sizeof(double) * (size_t)c->uzc_n * nv, hipMemcpyDeviceToDevice) != hipSuccess) { nb.release(); return -1; }
+    c->uzc_cols.release();
+    c->uzc_cols = nb;
+    return 1;
+}
+
+double uz_column_tol(const admm_hip_ctx *c) {      // a fraction of the solver's own (ADMM_HIP_UZ_COL_TOL=f, default 0.01), never looser than 1e-10
+    static const double col_factor = [] { const char *e = getenv("ADMM_HIP_UZ_COL_TOL"); const double f = e ? atof(e) : 0.01; return f > 0.0 && f <= 1.0 ? f : 0.01; }();
+    return std::min(col_factor * c->pcg_tol, 1e-10);
+}
+
+// LOOK-AHEAD.  The columns in flight are done (block: wait for them): commit their slots, or give the look-ahead up when a solve missed
+// its tolerance.  1 = nothing in flight any more, 0 = still running (block == false), -1 error.
+int uz_ahead_harvest(admm_hip_ctx *c, bool block) {
+    if (c->pf_v.empty()) return 1;
+    for (int l = 0; l < c->pf_lanes; ++l) {
+        const hipError_t e = block ? hipEventSynchronize(c->uz_lanes[l].done) : hipEventQuery(c->uz_lanes[l].done);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+        if (e != hipSuccess) return -1;
+    }
+    int conv = 0;
+    if (uz_lanes_converged(c, c->pf_lanes, &conv)) return -1;
+    const bool aborted = c->h_sig && c->h_sig[2];
+    { static const bool dbg = [] { const char *e = getenv("ADMM_HIP_UZ_LANES_DEBUG"); return e && e[0] == '1'; }();
+      if (dbg) fprintf(stderr, "[uz_ahead] ctx %p frame %d: harvest (%s) of %d columns: %d of %d launches converged%s\n", (void *)c, c->rc_frame, block ? "waited" : "polled",
+                       (int)c->pf_v.size(), conv, c->pf_launched, aborted ? ", ABORTED" : ""); }
+    if (!aborted && conv == c->pf_launched) {
+        for (size_t k = 0; k < c->pf_v.size(); ++k) c->uzc_slot_h[c->pf_v[k]] = c->pf_slot[k];
+        if (hipMemcpy(c->uzc_slot.p, c->uzc_slot_h.data(), sizeof(int) * (size_t)c->nv, hipMemcpyHostToDevice) != hipSuccess) return -1;
+        c->pf_columns += (long long)c->pf_v.size();
+    } else {      // (their slots stay unused; the vertices get columns the ordinary way when they touch)
+        c->pf_on = false;
+        if (!aborted) c->uzc_unconverged += c->pf_launched;
+    }
+    c->pf_v.clear(); c->pf_slot.clear(); c->pf_launched = 0;
+    return 1;
+}
+
+// Launch the column solves of the `count` vertices k_uz_near listed, on the lanes, WITHOUT waiting: they run beside the ADMM loop
+// (lanes + the loop's own k_pcg2 <= what the chip holds).  0 ok (also when there was nothing to do), -1 error.
+int uz_ahead_launch(admm_hip_ctx *c, int count) {
+    static const bool dbg = [] { const char *e = getenv("ADMM_HIP_UZ_LANES_DEBUG"); return e && e[0] == '1'; }();
+    if (count <= 0 || !c->pf_v.empty()) return 0;
+    // Fewer lanes than a batch the loop WAITS for: the loop's own persistent kernels (k_pcg2, the Schur CG with up to 100 KB of LDS per
+    // block) must find their CUs beside the lanes' blocks (ADMM_HIP_UZ_AHEAD_LANES=n, default 4).
+    static const int ahead_lanes = [] { const char *e = getenv("ADMM_HIP_UZ_AHEAD_LANES"); return e ? std::max(1, std::min(8, atoi(e))) : 4; }();
+    const int L = std::min(std::min(c->uz_lanes_cfg > 0 ? c->uz_lanes_cfg : 8, ahead_lanes), uz_lane_fit(c) - 1);
+    if (L < 1) { c->pf_on = false; return 0; }
+    std::vector<int> list(count);
+    if (hipMemcpy(list.data(), c->pf_list.p, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    std::sort(list.begin(), list.end());
+    list.erase(std::remove_if(list.begin(), list.end(), [c](int v) { return v < 0 || v >= c->nv || c->uzc_slot_h[v] >= 0; }), list.end());
+    const size_t room = c->uzc_cap - (size_t)c->uzc_n;
+    const size_t n = std::min(std::min(list.size(), room), (size_t)3 * 512);
+    if (n == 0) return 0;
+    list.resize(n);
+    const int g = uz_grow_cols(c, (size_t)c->uzc_n + n);
+    if (g <= 0) return g;       // no room: the look-ahead just does not happen
+    std::vector<int> slots(n);
+    for (size_t k = 0; k < n; ++k) slots[k] = c->uzc_n + (int)k;
+    const double keep_tol = c->pcg_tol;
+    c->pcg_tol = uz_column_tol(c);
+    int launched = 0;
+    const int rc = uz_lanes_enqueue(c, list, slots, (int)n, L, std::max(c->pcg_max_iters, 2000), &launched);
+    c->pcg_tol = keep_tol;
+    if (rc) return -1;
+    c->uzc_n += (int)n;      // (reserved: committed by uz_ahead_harvest)
+    c->pf_v = list; c->pf_slot = slots; c->pf_launched = launched; c->pf_lanes = L;
+    c->pf_batches += 1;
+    if (dbg) fprintf(stderr, "[uz_ahead] ctx %p frame %d: %d columns (%d launches) in flight on %d lanes\n", (void *)c, c->rc_frame, (int)n, launched, L);
     return 0;
 }
 
@@ -1180,6 +1282,18 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
     if (n_missing <= 0) return 1;
     hipStream_t st = c->stream;
     const int nv = c->nv;
+    std::vector<int> miss(n_missing);
+    if (hipMemcpy(miss.data(), c->uzc_miss.p, sizeof(int) * (size_t)n_missing, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (!c->pf_v.empty()) {      // columns in flight (look-ahead): wait for them -- some of the missing ones may be among them
+        c->pf_waits += 1;
+        if (uz_ahead_harvest(c, true) < 0) return -1;
+        if (c->h_sig && c->h_sig[2]) return -2;
+    }
+    if (c->pf_batches > 0) {     // (the list was made with the slot table of BEFORE this solve's harvest)
+        miss.erase(std::remove_if(miss.begin(), miss.end(), [c](int v) { return c->uzc_slot_h[v] >= 0; }), miss.end());
+        n_missing = (int)miss.size();
+        if (n_missing == 0) return 1;
+    }
     // slots for the new columns: fresh ones while the cache has room; a FULL cache gives up the columns of every vertex that is not
     // active in this solve (contacts that moved on -- a rolling or sliding body -- must not pin the cache for good)
     std::vector<int> slots;
@@ -1196,21 +1310,9 @@ int uz_ensure_columns(admm_hip_ctx *c, int n_missing) {
         if (slots.size() < (size_t)n_missing) return 0;      // the active set itself does not fit: this solve uses the PCG
     }
     const size_t top = (size_t)*std::max_element(slots.begin(), slots.end()) + 1;
-    if (top * (size_t)nv > c->uzc_cols.n) {     // grow (doubling, at least 64 columns, never beyond the cap); the columns move once
-        const size_t have = c->uzc_cols.n / (size_t)nv, cols = std::min(c->uzc_cap, std::max<size_t>(top, std::max<size_t>(64, 2 * have)));
-        DevBuf<double> nb;
-        if (nb.alloc(cols * (size_t)nv) != hipSuccess) { (void)hipGetLastError(); return 0; }      // no room: this solve uses the PCG
-        if (hipStreamSynchronize(st) != hipSuccess) { nb.release(); return -1; }
-        if (c->uzc_n > 0 && hipMemcpy(nb.p, c->uzc_cols.p, sizeof(double) * (size_t)c->uzc_n * nv, hipMemcpyDeviceToDevice) != hipSuccess) { nb.release(); return -1; }
-        c->uzc_cols.release();
-        c->uzc_cols = nb;
-    }
-    std::vector<int> miss(n_missing);
-    if (hipMemcpy(miss.data(), c->uzc_miss.p, sizeof(int) * (size_t)n_missing, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    { const int g = uz_grow_cols(c, top); if (g <= 0) return g; }      // no room: this solve uses the PCG
     const double keep_tol = c->pcg_tol;
-    // tolerance of a column: a fraction of the solver's own (ADMM_HIP_UZ_COL_TOL=f, default 0.01), never looser than 1e-10
-    static const double col_factor = [] { const char *e = getenv("ADMM_HIP_UZ_COL_TOL"); const double f = e ? atof(e) : 0.01; return f > 0.0 && f <= 1.0 ? f : 0.01; }();
-    c->pcg_tol = std::min(col_factor * keep_tol, 1e-10);
+    c->pcg_tol = uz_column_tol(c);
     int rc = 1;
     // the solver's counters before the batch: [4] solves of this step that met their tolerance -- every column solve must add one --
     // and [72..74] the totals admm_hip_solve_totals reports, which the column solves must not show up in (the caller's solves only)
@@ -1275,6 +1377,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
     const int *qlist = c->n_surf > 0 ? c->surf_list.p : nullptr;
     if (c->uz_freeze && c->uz_detected) nh = c->uz_last_hits;     // frozen active set: the rows of this step's first detect
     else if (c->obst.n > 0 || dyn) {
+        const bool first_detect = !c->uz_detected;
         c->uz_detected = true;
         // Collider::detect at the current iterate + ConstraintSet::make_matrix (ck = sqrt(constraint_w))
         const double ck = std::sqrt(std::max(0.0, c->constraint_w));
@@ -1323,13 +1426,26 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
                 }
             }
         } else if (hipMemcpyAsync(&nh, c->counters.p + 6, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+        // LOOK-AHEAD, once per step (its first detect), passive objects: which vertices will touch within pf_frames frames at their current
+        // speed and have no column of K^-1?  (c->v: the velocity after the explicit forces of this step.)  Their columns are solved on the
+        // lanes while the ADMM loop goes on, so that the touchdown finds them in the cache.
+        int pf_count = 0;
+        const bool pf_scan = c->uzc_on && c->pf_on && c->in_step && first_detect && c->obst.n > 0 && c->oc_enabled && c->pf_v.empty() && (size_t)c->uzc_n < c->uzc_cap;
+        if (pf_scan) {
+            if (hipMemsetAsync(c->pf_list.p + nv, 0, sizeof(int), st) != hipSuccess) return -1;
+            hipLaunchKernelGGL(k_uz_near, dim3(gv), dim3(256), 0, st, nv, x, c->v.p, c->obst, c->pf_frames * c->dt, c->uzc_slot.p,
+                               c->n_surf > 0 ? c->surf_mask.p : nullptr, c->pf_list.p, c->pf_list.p + nv);
+            if (hipMemcpyAsync(&pf_count, c->pf_list.p + nv, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+        }
         if (hipStreamSynchronize(st) != hipSuccess) return -1;
         if (c->h_sig && c->h_sig[2]) return -2;      // an earlier persistent launch (Schur CG, on-chip PCG) was given up: recovery path
+        if (c->uzc_on && first_detect && !c->pf_v.empty() && uz_ahead_harvest(c, false) < 0) return -1;      // (done by now? then commit; never waits here)
         if (c->uzc_on) nh = info[2];
         if (c->uzc_on) {
             c->uzc_n_act = info[0];
             c->uzc_usable = false;
             if (nh > 0) { const int rc = uz_ensure_columns(c, info[1]); if (rc < 0) return rc; c->uzc_usable = rc == 1; }
+            if (pf_scan && pf_count > 0 && uz_ahead_launch(c, pf_count) < 0) return -1;
         }
         if (c->timing) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->ev_coll0, c->ev_coll1) == hipSuccess) c->coll_ms_step += ms; }
     }
@@ -2391,6 +2507,11 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 if (d->n_obstacles > 0) {      // a scene with colliders will need columns: the lanes are set up here, not inside its first touchdown
                     const int L = uz_lane_count(c, 8);
                     if (L >= 2 && uz_make_lanes(c, L)) return fail(ADMM_HIP_ERR_DEVICE, "create: streams / memory of the UzawaCG column lanes");
+                    // look-ahead (ADMM_HIP_UZ_AHEAD=f: frames of travel, default 4; 0 = off): needs room for the lanes BESIDE the loop's own solve
+                    const char *ae = getenv("ADMM_HIP_UZ_AHEAD");
+                    c->pf_frames = ae ? atof(ae) : 4.0;
+                    c->pf_on = L >= 2 && c->pf_frames > 0.0 && uz_lane_fit(c) >= 2;
+                    if (c->pf_on) HIP_TRY(c->pf_list.alloc((size_t)nv + 1));
                 }
                 { const char *pr = getenv("ADMM_HIP_UZ_PERSIST_ROWS"); c->uzp_rows = (pr && (atoi(pr) == 8 || atoi(pr) == 16)) ? atoi(pr) : 0; }   // 0: two launches per Schur iteration (A/B, tests)   // 0: full-height column pass in every Schur iteration (A/B)
                 { const char *e1 = getenv("ADMM_HIP_UZ_ONE_MAX"), *e2 = getenv("ADMM_HIP_UZ_COMPACT_MAX");      // test hooks
@@ -2818,6 +2939,8 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     HIP_TRY(hipEventRecord(c->ev_step0, st));
     // counters[5] (closed chunks) must stay monotone across steps: only [0..4] are reset
     c->uz_iters_step = 0; c->uz_detected = false;
+    struct InStep { admm_hip_ctx *c; ~InStep() { c->in_step = false; } } in_step_guard{c};
+    c->in_step = true;
     c->rc_prev2_valid = c->rc_prev_valid; c->rc_prev_valid = c->rc_iter; c->rc_frame += 1; c->rc_iter = 0;   // this frame's pairs become "previous frame"
     // How many pairs a projection uses is decided ONCE per context, from the scene's own behaviour: four pairs cost ~4 us per solve
     // more than three (8.8 MB of reads, 20 block sums) and pay when solves need many iterations (Kuhn cube: 17.4 -> 13.9 per solve),
@@ -3691,10 +3814,12 @@ int admm_hip_uzawa_cache_stats(admm_hip_ctx *c, int64_t *columns, int64_t *colum
     if (evicted) *evicted = c->uzc_evictions;
     return ADMM_HIP_OK;
 }
-int admm_hip_uzawa_column_lanes(admm_hip_ctx *c, int64_t *batches, int *lanes) {
+int admm_hip_uzawa_column_lanes(admm_hip_ctx *c, int64_t *batches, int *lanes, int64_t *ahead_columns, int64_t *ahead_waits) {
     if (!c) return fail(ADMM_HIP_ERR_ARG, "uzawa_column_lanes: NULL context");
     if (batches) *batches = c->uzc_lane_batches;
     if (lanes) *lanes = (int)c->uz_lanes.size();
+    if (ahead_columns) *ahead_columns = c->pf_columns;
+    if (ahead_waits) *ahead_waits = c->pf_waits;
     return ADMM_HIP_OK;
 }
 int admm_hip_uzawa_unconverged_columns(admm_hip_ctx *c, int64_t *n) {

@@ -1756,6 +1756,20 @@ __global__ __launch_bounds__(256) void k_uz_detect(int nv, const double *__restr
     if (hit) atomicAdd(nhits, 1);
 }
 
+// Look-ahead of the UzawaCG column cache: the vertices that are not in contact yet, would reach a passive object within `ahead`
+// seconds at their current speed, and have no column of K^-1 (slot < 0).  Unordered (the host sorts the list).
+__global__ __launch_bounds__(256) void k_uz_near(int nv, const double *__restrict__ x, const double *__restrict__ vel, Obstacles ob, double ahead,
+                                                 const int *__restrict__ slot, const unsigned char *__restrict__ mask,
+                                                 int *__restrict__ list, int *__restrict__ count) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= nv || slot[v] >= 0 || (mask != nullptr && !mask[v])) return;
+    const double xv[3] = {x[3 * (size_t)v], x[3 * (size_t)v + 1], x[3 * (size_t)v + 2]};
+    double best = 1.7976931348623157e308, n[3] = {0, 0, 0}, p[3] = {0, 0, 0};
+    for (int j = 0; j < ob.n; ++j) obstacle_payload(ob, j, xv, best, n, p);
+    const double w[3] = {vel[3 * (size_t)v], vel[3 * (size_t)v + 1], vel[3 * (size_t)v + 2]};
+    if (best >= 0.0 && best < ahead * sqrt(dot3(w, w))) list[atomicAdd(count, 1)] = v;
+}
+
 // out = base - C^T y  (mode 0)   or   out = C^T y (mode 1)
 __global__ __launch_bounds__(256) void k_uz_ct(int nv, int mode, const double *__restrict__ base, const double *__restrict__ cn,
                                                const double *__restrict__ y, double *__restrict__ out) {

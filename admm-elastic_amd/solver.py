@@ -669,9 +669,9 @@ class Solver:
         u = C.c_int64(0)
         check(lib().admm_hip_uzawa_unconverged_columns(self._ctx, C.byref(u)))
         d["unconverged_columns"] = u.value
-        nb, nl = C.c_int64(0), C.c_int(0)
-        check(lib().admm_hip_uzawa_column_lanes(self._ctx, C.byref(nb), C.byref(nl)))
-        d["lane_batches"], d["lanes"] = nb.value, nl.value
+        nb, nl, na, nw = C.c_int64(0), C.c_int(0), C.c_int64(0), C.c_int64(0)
+        check(lib().admm_hip_uzawa_column_lanes(self._ctx, C.byref(nb), C.byref(nl), C.byref(na), C.byref(nw)))
+        d["lane_batches"], d["lanes"], d["ahead_columns"], d["ahead_waits"] = nb.value, nl.value, na.value, nw.value
         return d
 
     def tet_rest_mode(self):

@@ -530,7 +530,11 @@ def main():
         "uzawa": None if uz0 is None else {"cached_columns": uz1["columns"],
                                            "schur_iterations_from_columns": uz1["schur_from_columns"] - uz0["schur_from_columns"],
                                            "schur_iterations_by_pcg": uz1["schur_by_pcg"] - uz0["schur_by_pcg"],
-                                           "column_solves_in_timed_region": uz1["column_solves"] - uz0["column_solves"]},
+                                           "column_solves_in_timed_region": uz1["column_solves"] - uz0["column_solves"],
+                                           # ... of which look-ahead (solved on side streams beside the ADMM loop, before the vertex touches):
+                                           "columns_committed_ahead_of_contact": uz1.get("ahead_columns", 0) - uz0.get("ahead_columns", 0),
+                                           "solves_that_waited_for_a_column": uz1.get("ahead_waits", 0) - uz0.get("ahead_waits", 0),
+                                           "column_lanes": uz1.get("lanes", 0)},
         # mean time of one inner (PCG / GS) iteration incl. the per-solve overheads: (global - rhs) / inner iterations.
         # The PCG kernel keeps matrix and vectors on chip; its iteration is bound by one grid barrier, not by HBM.
         "us_per_inner_iter": 1e3 * (global_ms - rhs_ms) / max(inner, 1),
