@@ -621,6 +621,10 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     // the two-level preconditioner lets every thread handle two coarse unknowns (4 G <= 2 x 64 spb); small systems therefore
     // use fewer, larger blocks (which also makes their grid barrier cheaper)
     while (spb < 16 && (ns + spb - 1) / spb > 32 * spb) ++spb;
+    {   // ADMM_HIP_OC_SPB=n: slices (waves) per block forced (experiments: barrier cost against block-local work on small systems)
+        const char *se = getenv("ADMM_HIP_OC_SPB");
+        if (se && atoi(se) >= 1 && atoi(se) <= 16 && (ns + atoi(se) - 1) / atoi(se) <= cus) spb = atoi(se);
+    }
     G = (ns + spb - 1) / spb;
     const int T = 64 * spb;
     size_t lds_max = std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
