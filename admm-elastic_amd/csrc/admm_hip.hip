@@ -1122,7 +1122,12 @@ int uz_make_lanes(admm_hip_ctx *c, int L) {
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);      // (lowest, highest): numerically phi <= plo
         const int idx = (int)c->uz_lanes.size() - 1, span = plo - phi + 1;
-        const int prio = (prio_mode && span > 1) ? phi + idx % span : 0;
+        // (highest and lowest first, three lanes each, then the default priority: that class also carries the context's own stream and the
+        //  process's null stream -- a fourth lane in one class shares a hardware queue with another and the two serialise)
+        int prio = 0;
+        if (prio_mode == 2 && span > 1) prio = phi + idx % span;      // plain cycle (A/B)
+        else if (prio_mode && span > 2) { static const int cls[8] = {0, 1, 0, 1, 0, 1, 2, 2}; const int k = cls[idx & 7]; prio = k == 0 ? phi : k == 1 ? plo : (phi + plo) / 2; }
+        else if (prio_mode && span > 1) prio = (idx & 1) ? plo : phi;
         if (hipStreamCreateWithPriority(&ln.st, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) return -1;
         size_t off = 0;
         auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
