@@ -1093,7 +1093,7 @@ int enqueue_dyn_detect(admm_hip_ctx *c, const double *x) {
 // through the stream priorities: the runtime multiplexes streams of ONE priority on four hardware queues, where two lanes on the same
 // queue serialise (measured, 243 launches on the 20 k-vertex cube: 231 ms on the main stream; equal priorities 116 / 84-152 / 116 / 91 ms
 // on 2 / 3 / 4 / 8 lanes depending on which lanes collide; cycled priorities 117 / 89 / 70 / 49 / 38 ms on 2 / 3 / 4 / 6 / 8 lanes --
-// profiles/r05_uzawa_column_lanes.txt).
+// profiles/r05_uzawa_column_lanes.txt).  Final assignment of the priorities: uz_make_lanes.
 int uz_lane_fit(admm_hip_ctx *c) {      // instances of k_pcg2 the chip holds at once
     if (c->uz_fit >= 0) return c->uz_fit;
     int per_cu = 0;
