@@ -306,7 +306,7 @@ struct admm_hip_ctx {
     std::vector<OcLane> uz_lanes; hipEvent_t uz_fork = nullptr; int uz_lanes_cfg = -1;   // uz_lanes_cfg: ADMM_HIP_UZ_LANES (1 = the main stream only; default: what fits, <= 8)
     long long uzc_lane_batches = 0;
     // columns solved AHEAD of the contact (uz_ahead_launch): in flight on the lanes while the ADMM loop goes on, committed when they are done
-    bool pf_on = false, in_step = false; double pf_frames = 4.0; int uz_fit = -1;
+    bool pf_on = false, in_step = false; double pf_frames = 0.0; int uz_fit = -1;
     DevBuf<int> pf_list; std::vector<int> pf_v, pf_slot; int pf_launched = 0, pf_lanes = 0;
     long long pf_batches = 0, pf_columns = 0, pf_waits = 0;
     long long uzc_col_solves = 0, uzc_applies = 0, uzc_pcg_solves = 0, uzc_evictions = 0, uzc_unconverged = 0;
@@ -2516,9 +2516,12 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
                 if (d->n_obstacles > 0) {      // a scene with colliders will need columns: the lanes are set up here, not inside its first touchdown
                     const int L = uz_lane_count(c, 8);
                     if (L >= 2 && uz_make_lanes(c, L)) return fail(ADMM_HIP_ERR_DEVICE, "create: streams / memory of the UzawaCG column lanes");
-                    // look-ahead (ADMM_HIP_UZ_AHEAD=f: frames of travel, default 4; 0 = off): needs room for the lanes BESIDE the loop's own solve
+                    // look-ahead (ADMM_HIP_UZ_AHEAD=f: frames of travel; default 0 = OFF): needs room for the lanes BESIDE the loop's own solve.
+                    // Off by default since the batches take 39 ms: constant-velocity prediction lists layers that never touch (a landing body
+                    // decelerates) -- 200 frames of cube100k_uzawa_floor: 2 layers needed, 4-5 solved ahead, 1 277-1 300 against 1 311-1 329
+                    // ADMM it/s without (profiles/r05_uzawa_look_ahead.txt).  What it buys is the stall: no solve ever waits for a column.
                     const char *ae = getenv("ADMM_HIP_UZ_AHEAD");
-                    c->pf_frames = ae ? atof(ae) : 4.0;
+                    c->pf_frames = ae ? atof(ae) : 0.0;
                     c->pf_on = L >= 2 && c->pf_frames > 0.0 && uz_lane_fit(c) >= 2;
                     if (c->pf_on) HIP_TRY(c->pf_list.alloc((size_t)nv + 1));
                 }

@@ -426,11 +426,12 @@ int admm_hip_uzawa_unconverged_columns(admm_hip_ctx *ctx, int64_t *n);
  * once (small bodies: the kernel of a 20 k-vertex body holds 77 of 256 CUs and is bound by its grid barrier's latency).  The count is
  * the occupancy of the kernel, never more; ADMM_HIP_UZ_LANES=n (1..8) lowers it, 1 = the main stream only.  batches: batches solved on
  * more than one stream since create; lanes: streams set up (at create for scenes with colliders, else by the first such batch).
- * LOOK-AHEAD (admm_hip_step, passive objects, bodies that leave room for the lanes beside the loop's own solve): in the first solve of
- * a step the vertices that would reach an object within ADMM_HIP_UZ_AHEAD frames (default 4, 0 = off) at their current speed get their
+ * LOOK-AHEAD (opt-in: ADMM_HIP_UZ_AHEAD=frames, e.g. 4; default 0 = off; admm_hip_step, passive objects, bodies that leave room for the
+ * lanes beside the loop's own solve): in the first solve of a step the vertices that would reach an object within that many frames at their current speed get their
  * columns solved on the lanes WHILE the ADMM loop goes on; they are committed when done, a touchdown that needs one still in flight
  * waits for it.  ahead_columns: columns committed that way; ahead_waits: solves that had to wait.  Same columns to the tolerance of a
- * column (the three vertices of a launch share its iteration count), same active sets. */
+ * column (the three vertices of a launch share its iteration count), same active sets.  Trades throughput (columns of vertices that never
+ * touch: -2 % over 200 frames of the bench's contact scene) for the absence of a stall in the touchdown frame. */
 int admm_hip_uzawa_column_lanes(admm_hip_ctx *ctx, int64_t *batches, int *lanes, int64_t *ahead_columns, int64_t *ahead_waits);
 /* A user-defined PassiveCollision on the device (src/Collider.hpp:66-83; the reference calls signed_distance per vertex inside
  * Collider::detect_passive, :137-150).  fn(user, x, out7) evaluates the object at x on a FRESH payload: out7 = signed distance, contact
