@@ -222,7 +222,7 @@ struct admm_hip_ctx {
     // another persistent kernel, a second context or CU masking can break that).  The state at the last point known to be
     // good is kept, with the steps issued since; a timed-out barrier (detected at the next synchronisation) switches the
     // context to the launch-per-iteration PCG for good, restores that state and replays the steps.
-    DevBuf<double> bk_x, bk_v; std::vector<std::pair<int, double> > pending; bool oc_gave_up = false;
+    DevBuf<double> bk_x, bk_v, bk_y; int bk_prev_hits = -1, bk_prev_iters = 0; std::vector<std::pair<int, double> > pending; bool oc_gave_up = false;   // bk_y, bk_prev_*: UzawaCG's multipliers and the row count they belong to (kept across solves, UzawaCG.hpp:74)
     // WindForce on the device (admm_hip_set_wind): triangles, their vertex incidence, per-triangle forces
     int wind_n = 0; double wind_dir[3] = {0.0, 0.0, 0.0}; DevBuf<int> wind_tris; SellDev wind_inc; DevBuf<double> wind_force;
     DevBuf<unsigned long long> gs_proj; long long uz_rows_total = 0;   // admm_hip_contact_totals: rows projected inside the GS sweeps (device), rows of C over all UzawaCG solves (host)
@@ -358,7 +358,7 @@ struct admm_hip_ctx {
         cg_scal.release(); counters.release(); color_nodes.release(); gs_sell.release(); gs_slot_node.release(); gs_diag.release(); gs_xb.release(); gs_part2.release(); gs_low.release();
         oc_A.release(); oc_orig.release(); oc_ldsoff.release(); oc_wls.release(); oc_haloptr.release(); oc_halosrc.release(); oc_col16.release();
         oc_mdiag.release(); oc_ainv.release(); oc_cbuf.release(); oc_cwt.release();
-        bk_x.release(); bk_v.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
+        bk_x.release(); bk_v.release(); bk_y.release(); wind_tris.release(); wind_inc.release(); wind_force.release();
         oc_ubuf.release(); oc_part.release(); oc_rc_part.release(); oc_bar.release(); oc_prof.release(); oc_nbr.release(); oc_flags.release();
         gsp_hdr.release(); gsp_orig.release(); gsp_out.release(); gsp_hbox.release(); gsp_horig.release(); gsp_diag.release(); gsp_vals.release(); gsp_cols.release();
         obst_gmeta.release(); obst_gdata.release(); obst_dev.release();
@@ -3075,6 +3075,22 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     return ADMM_HIP_OK;
 }
 
+// The state a replay starts from: positions, velocities and -- UzawaCG -- the multipliers with the row count they belong to (an aborted
+// Schur launch leaves them half-updated; a replay that started from those would run its <= 20 Schur iterations from a different point
+// than the undisturbed run: 2.6e-6 instead of < 1e-7 in test_persistent_schur_hand_off_timeout_recovers, depending on how far the other
+// blocks got before they saw the abort).
+static hipError_t backup_state(admm_hip_ctx *c) {
+    hipError_t e;
+    if (!c->bk_x.p) { if ((e = c->bk_x.alloc(c->n3)) != hipSuccess) return e; if ((e = c->bk_v.alloc(c->n3)) != hipSuccess) return e; }
+    if ((e = hipMemcpyAsync(c->bk_x.p, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(c->bk_v.p, c->v.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream)) != hipSuccess) return e;
+    if (c->linsolver == 2 && c->uz_y.p) {
+        if (!c->bk_y.p && (e = c->bk_y.alloc(c->uz_y.n)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(c->bk_y.p, c->uz_y.p, c->uz_y.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream)) != hipSuccess) return e;
+        c->bk_prev_hits = c->uz_prev_hits; c->bk_prev_iters = c->uz_prev_iters;
+    }
+    return hipSuccess;
+}
 // A timed-out grid barrier was seen after a stream synchronisation: give up the persistent kernel, go back to the last
 // good state and replay.  Single-GPU contexts only (a replay on one rank would issue all-reduces the others do not).
 static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
@@ -3094,6 +3110,10 @@ static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
     if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
     HIP_TRY(hipMemcpyAsync(c->x.p, c->bk_x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->v.p, c->bk_v.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (c->bk_y.p && c->uz_y.p) {
+        HIP_TRY(hipMemcpyAsync(c->uz_y.p, c->bk_y.p, c->uz_y.n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        c->uz_prev_hits = c->bk_prev_hits; c->uz_prev_iters = c->bk_prev_iters;
+    }
     const std::vector<std::pair<int, double> > todo(c->pending);
     c->pending.clear();
     for (size_t i = 0; i < todo.size(); ++i) {
@@ -3116,16 +3136,11 @@ int admm_hip_step(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_
     if (admm_iters < 0) return fail(ADMM_HIP_ERR_ARG, "step: admm_iters < 0");
     HIP_TRY(hipSetDevice(c->device));
     if (((c->oc_enabled && c->linsolver != 1) || (c->gsp_enabled && c->linsolver == 1) || (c->uzp_enabled && c->linsolver == 2 && c->uzc_on)) && c->world == 1 && !c->comm && !c->ar_fn) {
-        if (c->pending.empty()) {   // the state every later replay starts from
-            if (!c->bk_x.p) { HIP_TRY(c->bk_x.alloc(c->n3)); HIP_TRY(c->bk_v.alloc(c->n3)); }
-            HIP_TRY(hipMemcpyAsync(c->bk_x.p, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->bk_v.p, c->v.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        }
+        if (c->pending.empty()) HIP_TRY(backup_state(c));   // the state every later replay starts from
         if (c->pending.size() >= 4096) {   // a long chain of unsynchronised steps: settle it
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (int rc = settle(c)) return rc;
-            HIP_TRY(hipMemcpyAsync(c->bk_x.p, c->x.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->bk_v.p, c->v.p, c->n3 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(backup_state(c));
         }
         c->pending.emplace_back(admm_iters, gravity);
     }
