@@ -2654,6 +2654,16 @@ static int set_pins_impl(admm_hip_ctx *c, int32_t n, const int32_t *vert, const 
             for (int j = 0; j < 3; ++j) p[3 * (size_t)vert[i] + j] = xyz[3 * (size_t)i + j];
         }
         c->gs_has_pins = n > 0;
+        if (c->has_slide) {      // a vertex that LEFT the pin set loses its slide normal: pinned again later it is an ordinary pin
+            bool any = false;
+            for (int v = 0; v < c->nv; ++v) {
+                double *q = c->pin_nrm_h.data() + 3 * (size_t)v;
+                if (!flag[v]) q[0] = q[1] = q[2] = 0.0;
+                any = any || q[0] != 0.0 || q[1] != 0.0 || q[2] != 0.0;
+            }
+            c->has_slide = any;
+            HIP_TRY(hipMemcpy(c->gs_pin_nrm.p, c->pin_nrm_h.data(), c->pin_nrm_h.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
         if (c->gs_exec) { (void)hipGraphExecDestroy(c->gs_exec); c->gs_exec = nullptr; } // pin pointer is baked into the graph
         HIP_TRY(hipMemcpy(c->gs_pin_flag.p, flag.data(), flag.size() * sizeof(int), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->gs_pin_xyz.p, p.data(), p.size() * sizeof(double), hipMemcpyHostToDevice));

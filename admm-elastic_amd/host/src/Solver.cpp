@@ -412,8 +412,14 @@ void Solver::set_slide_pins(const std::vector<int> &inds, const std::vector<Vec3
                 err << "**Solver::set_pins Error: Constraint for " << kv.first << " not found.\n";
                 throw std::runtime_error(err.str());
             }
+    std::vector<int32_t> left;      // a vertex that leaves the set must not keep its normal (it would slide again when pinned later)
+    for (auto &kv : m_constraints->slides) if (!fresh.count(kv.first)) left.push_back(kv.first);
     m_constraints->slides = fresh;
     if (!initialized) return;
+    if (!left.empty()) {
+        std::vector<double> zero(3 * left.size(), 0.0);
+        check(admm_hip_set_pin_normals((admm_hip_ctx *)m_ctx, (int32_t)left.size(), left.data(), zero.data()), "Solver::set_slide_pins");
+    }
     for (auto &se : m_slide_energies) se.second->set_active(false);
     for (auto &kv : fresh) {
         auto it = m_slide_energies.find(kv.first);

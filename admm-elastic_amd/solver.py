@@ -274,6 +274,9 @@ class Solver:
             if not l > 0.0:
                 raise AdmmHipError(-1, "set_slide_pins: zero normal")
             new[int(idx)] = (f64(points[i]).ravel().copy(), n / l)
+        left = [k for k in self._slides if k not in new]
+        if self.initialized and left:      # a vertex that leaves the set must not keep its normal (it would slide again when pinned later)
+            check(lib().admm_hip_set_pin_normals(self._ctx, len(left), iptr(i32(left)), dptr(np.zeros((len(left), 3)))))
         self._slides = new
         if self.initialized:
             self._push_pins()

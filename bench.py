@@ -378,13 +378,16 @@ def main():
     # statistics frames are the timed ones, as in round 1.
     local_ms = rhs_ms = global_ms = lk_ms = 0.0
     inner = unconv = 0
+    inner_timed = None
     # contact-free scenes on the on-chip PCG (linsolver 0, or UzawaCG without obstacles: one prefactored solve per ADMM iteration)
     contact_free = w["linsolver"] == 0 or (w["linsolver"] == 2 and not sc.obstacles and not sc.dynamic)
     tot0 = s.solve_totals() if contact_free else (-1, -1, -1)
     lean = tot0[0] >= 0
     lt_pairs, lt_ms = 0, 0.0       # the local-step launches of the TIMED region: event pairs, read after it
     if lean:
-        s.time_local_launches(2)   # a hipEvent pair attached to the dispatch of every local-step kernel of the timed region
+        # a hipEvent pair attached to the dispatch of every local-step kernel of the timed region (ADMM_BENCH_LOCAL_EVENTS=0 / 1: none /
+        # hipEventRecords around the launch -- same-box A/B of what the instrumentation costs, experiments/r06_a.sh)
+        s.time_local_launches(int(os.environ.get("ADMM_BENCH_LOCAL_EVENTS", "2")))
         s.local_launch_times()     # (clears what the warm-up recorded)
     uz0 = s.uzawa_cache_stats() if w["linsolver"] == 2 else None
     has_contact = bool(sc.obstacles or sc.dynamic) and w["linsolver"] != 0
@@ -410,6 +413,7 @@ def main():
         tot1 = s.solve_totals()
         unconv = (tot1[0] - tot0[0]) - (tot1[1] - tot0[1])
         assert tot1[0] - tot0[0] == iters * args.steps, (tot0, tot1)
+        inner_timed = tot1[2] - tot0[2]      # PCG iterations of the TIMED frames themselves (the solver's own device-side totals)
         t1s = time.perf_counter()
         for _ in range(args.steps):
             s.step_device(stats=True)
@@ -513,7 +517,10 @@ def main():
         "ms_per_frame": ms_per_step,
         "split_ms_per_admm_iter": {"local": local_ms / (iters * args.steps), "rhs": rhs_ms / (iters * args.steps),
                                    "global": global_ms / (iters * args.steps)},
-        "inner_iters_per_admm_iter": inner / (iters * args.steps), "unconverged_solves_in_timed_region": unconv,
+        # of the TIMED frames (admm_hip_solve_totals before / after them); the statistics frames that follow have their own count
+        "inner_iters_per_admm_iter": (inner_timed if inner_timed is not None else inner) / (iters * args.steps),
+        "inner_iters_per_admm_iter_statistics_frames": inner / (iters * args.steps) if lean else None,
+        "unconverged_solves_in_timed_region": unconv,
         "timed_region": ("frames issued without per-step statistics (one hipEvent pair around every local-step launch is the only instrumentation: "
                          "`roofline`); split / iteration counts from as many STATISTICS FRAMES right after, which take %.3f x the time of the timed ones "
                          "(`stats_frames_ms_per_step`)" % (stats_elapsed / elapsed)) if lean else "frames with per-step statistics",
@@ -577,12 +584,19 @@ def main():
             # is measured live on the same grid with the kernel's own primitives (admm_hip_probe_sync).
             a2a, xch, pst = s.probe_sync(200)
             n_solves = iters * args.steps
-            it_per_solve = inner / max(n_solves, 1)
-            solve_us = 1e3 * (global_ms - rhs_ms) / max(n_solves, 1)
+            it_stats = inner / max(n_solves, 1)
+            solve_us_stats = 1e3 * (global_ms - rhs_ms) / max(n_solves, 1)
+            # The TIMED frames carry no events between their kernels, so their solve time is what is left of a timed ADMM iteration after the
+            # local step and the right-hand side (statistics frames' durations; launch gaps stay inside: an upper bound), and the iteration
+            # count is the timed frames' own.  The statistics frames' pair of numbers rides along.
+            it_per_solve = (inner_timed if inner_timed is not None else inner) / max(n_solves, 1)
+            solve_us = 1e3 * ms_per_step / iters - 1e3 * (local_ms + rhs_ms) / max(n_solves, 1)
             us_it = solve_us / max(it_per_solve, 1e-9)
             out["roofline_global"] = {
                 "role": "TIME-DOMINANT kernel: %.0f %% of a statistics frame" % (100.0 * (global_ms - rhs_ms) / max(local_ms + global_ms, 1e-30)),
-                "measured_in": "statistics frames (event pairs between the phases), not the timed region",
+                "measured_in": "the TIMED frames: iterations from the solver's totals around them, `solve_us` = timed ADMM iteration - local step - right-hand side "
+                               "(launch gaps included); the statistics frames' event-pair figures in `statistics_frames`",
+                "statistics_frames": {"iterations_per_solve": it_stats, "solve_us": solve_us_stats},
                 "kernel": "k_pcg2 (whole two-level PCG solve, one persistent launch per ADMM iteration)",
                 "bound": "synchronisation latency (grid barrier + neighbour exchange); data on chip",
                 "iterations_per_solve": it_per_solve, "solve_us": solve_us, "us_per_iteration_incl_solve_overhead": us_it,

@@ -92,7 +92,11 @@ def lib():
 
 
 def ref_lib():
-    """The real-reference pieces (oracle/_ref/libadmm_ref.so) or None when not built."""
+    """The real-reference pieces (oracle/_ref/libadmm_ref.so) or None when not built.  Only used where the reference tree itself
+    exists (the build container): on a GPU box the golden vectors made from it (tests/golden/ref_vectors.npz) stand in, and a
+    prebuilt library that travelled with a snapshot is never mapped (ADMM_ORACLE_FORCE_REF=1 overrides, for a calibration run)."""
+    if not os.path.isdir("/root/reference") and os.environ.get("ADMM_ORACLE_FORCE_REF") != "1":
+        return None
     if not os.path.exists(_REF):
         try:
             build()

@@ -226,6 +226,44 @@ def test_slide_pins_vs_oracle(ls):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ls", [0, 1, 2])
+def test_slide_normal_does_not_outlive_its_constraint(ls):
+    """Slide, then drop the slide constraints, then set_pins on the same vertices: they must be HELD (an ordinary pin), not slide on in
+    the plane they once had (a stale normal kept by the context made them slide again).  A twin that keeps its slide constraints gives the
+    distance a sliding vertex covers in the same two frames."""
+    def make():
+        sc = scenes.cube_scene(4, pkg.TET_NEOHOOKEAN, pin_face=False, admm_iters=15, linsolver=ls)
+        verts = sc.x
+        for v in (int(i) for i in np.nonzero(verts[:, 0] < 1e-9)[0]):
+            if verts[v, 1] < 1e-9:
+                sc.pins[v] = verts[v].copy()
+            else:
+                sc.slides[v] = (verts[v].copy(), np.array([1.0, 0.0, 0.0]))
+        return sc, sc.make_solver(pcg_tol=1e-12, pcg_max_iters=1500)
+    sc, s = make()
+    _, twin = make()
+    for f in range(2):
+        s.step(); twin.step()
+    sl = list(sc.slides)
+    here = s.m_x.reshape(-1, 3)[sl].copy()
+    s.set_slide_pins([], [], [])
+    s.set_pins(list(sc.pins) + sl, [sc.pins[v] for v in sc.pins] + [here[i] for i in range(len(sl))])
+    for f in range(2):
+        s.step(); twin.step()
+    held = np.abs(s.m_x.reshape(-1, 3)[sl] - here).max()
+    slid = np.abs(twin.m_x.reshape(-1, 3)[sl] - here).max()
+    assert slid > 1e-4, slid
+    assert held < (1e-12 if ls == 1 else 0.05 * slid), (held, slid)
+    # and back: the same vertices slide again when the constraints return
+    s.set_pins(list(sc.pins), [sc.pins[v] for v in sc.pins])
+    s.set_slide_pins(sl, [sc.x[v] for v in sl], [np.array([1.0, 0.0, 0.0])] * len(sl))
+    for f in range(2):
+        s.step()
+    X = s.m_x.reshape(-1, 3)[sl]
+    assert np.abs(X - here).max() > 0.2 * slid and np.abs(X[:, 0]).max() < (1e-12 if ls == 1 else 2e-3)
+
+
+@pytest.mark.gpu
 def test_f3_terms_in_the_multi_rank_partitions():
     """Element-block partition (every rank its block of hinges, partial right-hand sides summed) and the component partition (sub-scenes
     carry their hinges and slide normals): rank contexts on one device reproduce the single context."""
