@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <array>
 #include <map>
 #include <memory>
 #include <numeric>
@@ -164,6 +165,11 @@ struct admm_hip_ctx {
     DevBuf<int> t_mat;
     DevBuf<Mat> mats; DevBuf<double> spl_tab;   // tabulated user splines (ADMM_TET_SPLINE_TABLE)
     SellDev t_inc; DevBuf<int> g_order;   // incidence lists, and the vertex every row of them gathers for
+    // the same record lists in the on-chip solver's internal row order: k_pcg2 sums the right-hand side of its own rows (Oc2Args::g_inc) and
+    // the k_gather_rhs launch of the ADMM loop goes away (fuse_rhs_ok: the plan has them; fuse_rhs: armed for the next on-chip solve)
+    DevBuf<double> big_agree;     // distributed solve: the ranks' agreement on the solver (launch_pcg)
+    bool defl_armed = false;      // launch_pcg2 armed the fused end projection for the solve just launched
+    SellDev oc_inc; std::vector<int32_t> rec_vertex_h; bool fuse_rhs_ok = false, fuse_rhs = false; long long fused_rhs_solves = 0;
     // tris
     int ntri = 0, ldr = 0;
     DevBuf<int4> r_idx;
@@ -268,7 +274,11 @@ struct admm_hip_ctx {
     // most recent pairs are worth more than any history (cube, history for all 20 solves: 556 -> 735 iterations per frame).
     int kRcHist = 5;      // (ADMM_HIP_RC_HIST_N)
     int rc_hist = 0, rc_prev2_valid = 0;
-    int rc_loc(int s, int frame) const { return (rc_hist && s < kRcHist) ? kRcAllSlots + ((frame % 3 + 3) % 3) * kRcHist + s : rc_slot(s); }
+    // rc_depth: frames the history keeps (this one included; ADMM_HIP_RC_DEPTH, default 3); rc_vb[d]: solves of frame - d whose pairs are valid;
+    // rc_order[s] (s = 0, 1; ADMM_HIP_RC_ORDER0 / 1, experiments): the basis of solve s as a list of tokens "oK" = this frame's solve s - K,
+    // "pQ.D" = solve s + Q of frame - D, in order of preference -- unset: the built-in order of launch_pcg_recycled_impl
+    int rc_depth = 3, rc_vb[8] = {0, 0, 0, 0, 0, 0, 0, 0}; std::vector<std::array<int, 3> > rc_order[2];
+    int rc_loc(int s, int frame) const { return (rc_hist && s < kRcHist) ? kRcAllSlots + ((frame % rc_depth + rc_depth) % rc_depth) * kRcHist + s : rc_slot(s); }
     double *rc_Ef(int s, int frame) { return rc_buf.p + ((size_t)rc_loc(s, frame) * 2 + 0) * (size_t)n3i; }
     double *rc_Rf(int s, int frame) { return rc_buf.p + ((size_t)rc_loc(s, frame) * 2 + 1) * (size_t)n3i; }
     // UzawaCG (per-vertex constraint rows)
@@ -580,8 +590,19 @@ int launch_pcg2(admm_hip_ctx *c, const double *b, double *x, int max_iters, cons
     a.skip = rc.skip;
     // (every 16th solve and a context's first 40 verify whatever the rule says: the sample that can revoke the trust, pcg_onchip2.hpp)
     a.trust_short = (c->oc_always_verify || c->oc_launches < 40 || (c->oc_launches & 15) == 0) ? 0 : 1;
-    if (rc.on && c->defl_fused && c->defl_k > 0 && c->defl_now) { a.defl_dbg = c->defl_dbg; a.defl_k = c->defl_k; a.defl_Z = c->defl_Zint.p; a.defl_Ginv = c->defl_Ginv.p; a.defl_rec = c->defl_rec.p; }      // (the ADMM loop's solves only: not the K^-1 columns of UzawaCG)
+    if (rc.on && c->defl_fused && c->defl_k > 0 && c->defl_now) { c->defl_armed = true; a.defl_dbg = c->defl_dbg; a.defl_k = c->defl_k; a.defl_Z = c->defl_Zint.p; a.defl_Ginv = c->defl_Ginv.p; a.defl_rec = c->defl_rec.p; }      // (the ADMM loop's solves only: not the K^-1 columns of UzawaCG)
     a.sm_ab = c->oc_sm_ab; a.sm_b = c->oc_sm_b; a.sm_c0 = c->oc_sm_c0; a.sm_k1 = c->oc_sm_k1; a.sm_k2 = c->oc_sm_k2;
+    if (c->fuse_rhs) {      // armed by step_impl for exactly this solve: the kernel sums its own right-hand side (no k_gather_rhs launch was made)
+        c->fuse_rhs = false;
+        if (ln || b != c->b.p || !c->fuse_rhs_ok) return -1;
+        a.g_ptr = c->oc_inc.ptr.p; a.g_w = c->oc_inc.w.p; a.g_inc = c->oc_inc.idx.p; a.g_pad = c->n_rec; a.g_rec = c->t_rec.p; a.g_Mxbar = c->Mxbar.p; a.g_b = c->b.p;
+        if (c->npin_terms > 0) {
+            a.g_pin_nrm = c->has_slide ? c->pin_nrm.p : nullptr;
+            a.g_vert_pin = c->vert_pin.p; a.g_pin_xyz = c->pin_xyz.p; a.g_pin_active = c->pin_active.p;
+            a.g_pin_u = c->pin_u.p; a.g_pin_z = c->pin_z.p; a.g_pin_sc = c->dt * c->dt * c->pin_weight * c->pin_weight;
+        }
+        c->fused_rhs_solves += 1;
+    }
     c->oc_launches += 1;
     if (ln) {      // a side-stream solve (UzawaCG's columns): the lane's own copies of everything the kernel writes, no diagnosis
         a.u_out = ln->u; a.ubuf = ln->ubuf; a.part = ln->part; a.bar = ln->bar; a.flags = c->oc_flags.p ? ln->flags : nullptr;
@@ -748,6 +769,14 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     }
     c->oc_enabled = true;
     { const char *ta = getenv("ADMM_HIP_TEST_ABORT_SOLVE"); c->test_abort_seq = ta ? atoi(ta) : 0; }
+    {   // the record lists in internal row order (tets only: triangles and hinges keep the gather launch); ADMM_HIP_FUSE_RHS=0: A/B
+        const char *fe = getenv("ADMM_HIP_FUSE_RHS");
+        if (!(fe && fe[0] == '0') && c->nt > 0 && c->ntri == 0 && c->nbend == 0 && c->world == 1 && !c->rec_vertex_h.empty()) {
+            std::vector<int32_t> rv(c->oc_orig_h.begin(), c->oc_orig_h.end());
+            if ((e = c->oc_inc.upload(admm_host::record_incidence(c->nv, c->n_rec, c->rec_vertex_h.data(), c->n_rec, rv.data(), c->oc_rows))) != hipSuccess) return e;
+            c->fuse_rhs_ok = true;
+        }
+    }
     return hipSuccess;
 }
 
@@ -939,6 +968,17 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
 
 int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters, const int *skip = nullptr) {
     if (c->dist_solve) {      // rows split over the ranks: the two-level PCG on the rank's aggregates (ADMM_HIP_BIG=0: the Jacobi PCG of round 4)
+        if (!c->big_tried) {
+            // Every rank must take the SAME branch (the two solvers issue different collectives: a rank whose plan failed -- an allocation, an
+            // upload -- would hang the others until the communicator times out): the first solve agrees on it with one sum all-reduce.
+            const bool mine = ensure_big_plan(c);
+            double v = mine ? 1.0 : 0.0;
+            if (!c->big_agree.p && c->big_agree.alloc(1) != hipSuccess) return -1;
+            if (hipMemcpyAsync(c->big_agree.p, &v, sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return -1;
+            if (int r = comm_allreduce(c, c->big_agree.p, 1)) return r < 0 ? -1 : r;
+            if (hipMemcpyAsync(&v, c->big_agree.p, sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+            c->big_enabled = mine && v > (double)c->world - 0.5;
+        }
         const int r = ensure_big_plan(c) ? launch_pcg_big(c, b, x, max_iters) : launch_pcg_dist(c, b, x, max_iters);
         return r ? -1 : 0;
     }
@@ -999,8 +1039,11 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     // 8.2 -> 5.4 iterations per solve over 200 frames, drift 3.9e-6 -> 3.2e-6 (profiles/r05_drift_start_projection.txt).  In front of the first
     // solve (mask 3) or the third (mask 6) it costs more than it saves.  Three small launches (k_defl_*), ~0.1 ms per frame.
     if (c->defl_start && !c->defl_start_hold && c->defl_k > 0 && c->defl_now && c->rc_iter < 31 && ((c->defl_start >> c->rc_iter) & 1)) launch_deflation(c, b, x);
+    c->defl_armed = false;
     const int rc = launch_pcg_recycled_impl(c, b, x);
-    if (rc == 0 && c->defl_k > 0 && c->defl_now && !(c->defl_fused && c->oc_enabled)) launch_deflation(c, b, x);      // (fused into k_pcg2's epilogue when the on-chip kernel runs)
+    // (fused into k_pcg2's epilogue when the on-chip kernel ran WITH it -- launch_pcg2 says so: a solve that went there without the recycled
+    // basis, ADMM_HIP_NO_RECYCLE=1, or down the launch path gets the separate kernels)
+    if (rc == 0 && c->defl_k > 0 && c->defl_now && !c->defl_armed) launch_deflation(c, b, x);
     return rc;
 }
 int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x) {
@@ -1017,6 +1060,12 @@ int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x) {
         // prev(s+1), own(s-3), prev2(s+1), own(s-4)
         auto add = [&](int q, int frame, bool valid) { if (valid && B.cnt < rc_pairs) { B.E[B.cnt] = c->rc_Ef(q, frame); B.R[B.cnt] = c->rc_Rf(q, frame); ++B.cnt; } };
         const int H = c->kRcHist;
+        if (s < 2 && !c->rc_order[s].empty()) {
+            for (auto &t : c->rc_order[s]) {
+                if (t[0] == 0) add(s - t[1], fr, t[1] >= 1 && s - t[1] >= 0);
+                else add(s + t[1], fr - t[2], s + t[1] >= 0 && s + t[1] < H && s + t[1] < c->rc_vb[t[2]]);
+            }
+        } else {
         add(s - 1, fr, s - 1 >= 0);
         add(s, fr - 1, s < H && s < c->rc_prev_valid);
         add(s, fr - 2, s < H && s < c->rc_prev2_valid);
@@ -1025,6 +1074,7 @@ int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x) {
         add(s - 3, fr, s - 3 >= 0);
         add(s + 1, fr - 2, s + 1 < H && s + 1 < c->rc_prev2_valid);
         add(s - 4, fr, s - 4 >= 0);
+        }
         OcRc rc; rc.on = true; rc.B = B; rc.Eslot = c->rc_Ef(s, fr); rc.Rslot = c->rc_Rf(s, fr);
         const int r = launch_pcg_onchip(c, b, x, c->pcg_max_iters, rc);
         c->rc_iter = s + 1;
@@ -2208,6 +2258,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         HIP_TRY(c->t_rec.alloc((size_t)4 * (ch.n_rec + 1))); HIP_TRY(c->t_rec.zero());     // record n_rec stays zero: the padding of the incidence lists
         HIP_TRY(c->t_inc.upload(admm_host::record_incidence(nv, ch.n_rec, ch.rec_vertex.data(), ch.n_rec, g_order.data())));
         c->n_rec = ch.n_rec;
+        c->rec_vertex_h = ch.rec_vertex;
     }
     // ---- tris ----
     c->ntri = re - rb; c->ldr = c->ntri + 1;
@@ -2403,7 +2454,20 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
         if (c->rc_enabled) {
             { const char *he = getenv("ADMM_HIP_RC_HIST"); c->rc_hist = (!(he && he[0] == '0') && c->oc_enabled && c->oc_plan) ? 1 : 0; }   // (=0: round 3's basis, A/B)
             { const char *hn = getenv("ADMM_HIP_RC_HIST_N"); if (hn) c->kRcHist = std::max(1, std::min(64, atoi(hn))); }
-            HIP_TRY(c->rc_buf.alloc((size_t)(admm_hip_ctx::kRcAllSlots + (c->rc_hist ? 3 * c->kRcHist : 0)) * 2 * c->n3i));
+            { const char *de = getenv("ADMM_HIP_RC_DEPTH"); if (de) c->rc_depth = std::max(3, std::min(8, atoi(de))); }
+            for (int q = 0; q < 2; ++q) {      // ADMM_HIP_RC_ORDER0="p0.1,p0.2,p0.3,p1.1": see rc_order
+                const char *oe = getenv(q == 0 ? "ADMM_HIP_RC_ORDER0" : "ADMM_HIP_RC_ORDER1");
+                if (!oe) continue;
+                std::string str(oe); size_t pos = 0;
+                while (pos < str.size()) {
+                    size_t e = str.find(',', pos); if (e == std::string::npos) e = str.size();
+                    const std::string tok = str.substr(pos, e - pos); pos = e + 1;
+                    int a1 = 0, a2 = 0;
+                    if (tok.size() >= 2 && tok[0] == 'o' && sscanf(tok.c_str() + 1, "%d", &a1) == 1) c->rc_order[q].push_back({0, a1, 0});
+                    else if (tok.size() >= 4 && tok[0] == 'p' && sscanf(tok.c_str() + 1, "%d.%d", &a1, &a2) == 2 && a2 >= 1 && a2 < c->rc_depth) c->rc_order[q].push_back({1, a1, a2});
+                }
+            }
+            HIP_TRY(c->rc_buf.alloc((size_t)(admm_hip_ctx::kRcAllSlots + (c->rc_hist ? c->rc_depth * c->kRcHist : 0)) * 2 * c->n3i));
             HIP_TRY(c->rc_r0.alloc(c->n3i)); HIP_TRY(c->rc_xs.alloc(c->n3i));
             HIP_TRY(c->rc_part.alloc((size_t)3 * kRcQ * c->NBR)); HIP_TRY(c->rc_coef.alloc(3 * kRc)); HIP_TRY(c->rc_coef.zero());
         }
@@ -2596,7 +2660,7 @@ static int set_state_impl(admm_hip_ctx *c, const double *x, const double *v) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->h_sig && c->h_sig[2]) {   // the steps before this call hit a barrier time-out; their result is overwritten anyway
         c->h_sig[2] = 0; c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false; c->uzp_enabled = false; c->rc_iter = 0;
-        c->rc_hist = 0; c->rc_prev_valid = 0; c->rc_prev2_valid = 0;   // (pairs half-written by the aborted solve, and in the on-chip row order)
+        c->rc_hist = 0; c->rc_prev_valid = 0; c->rc_prev2_valid = 0; for (int &v : c->rc_vb) v = 0;   // (pairs half-written by the aborted solve, and in the on-chip row order)
         if (c->oc_bar.p) HIP_TRY(c->oc_bar.zero());
         if (c->gsp_abort.p) HIP_TRY(c->gsp_abort.zero());
         if (c->uzp_abort.p) HIP_TRY(c->uzp_abort.zero());
@@ -2931,6 +2995,18 @@ static int launch_global(admm_hip_ctx *c, const double *b, double *x) {
     return launch_pcg_recycled(c, b, x);
 }
 
+// true: launch_global(c, c->b.p, c->curr.p) will reach launch_pcg2 with the recycled basis as the FIRST thing that reads b
+static bool fuse_rhs_route(const admm_hip_ctx *c) {
+    if (!c->fuse_rhs_ok || c->world > 1 || c->comm || c->ar_fn) return false;
+    if (c->linsolver == 1) return false;
+    if (c->linsolver == 2 && (c->obst.n > 0 || !c->dyn.empty() || c->uz_freeze)) return false;      // (contact-free: UzawaCG::solve is the prefactored solve)
+    if (!(c->rc_enabled && c->oc_enabled && c->oc_plan)) return false;
+    const bool defl_now = c->defl_every <= 1;      // (experiments with ADMM_HIP_DEFL_EVERY keep the launch)
+    if (!defl_now) return false;
+    if (c->defl_start && !c->defl_start_hold && c->defl_k > 0 && c->rc_iter < 31 && ((c->defl_start >> c->rc_iter) & 1)) return false;   // the start step reads b first
+    return true;
+}
+
 constexpr int kStepAborted = -100;   // step_impl: a grid barrier of the on-chip PCG timed out (seen at the final synchronisation)
 static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_hip_stats *stats) {
     hipStream_t st = c->stream;
@@ -2963,6 +3039,8 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
     c->uz_iters_step = 0; c->uz_detected = false;
     struct InStep { admm_hip_ctx *c; ~InStep() { c->in_step = false; } } in_step_guard{c};
     c->in_step = true;
+    for (int d = 7; d >= 2; --d) c->rc_vb[d] = c->rc_vb[d - 1];
+    c->rc_vb[1] = c->rc_iter;
     c->rc_prev2_valid = c->rc_prev_valid; c->rc_prev_valid = c->rc_iter; c->rc_frame += 1; c->rc_iter = 0;   // this frame's pairs become "previous frame"
     // How many pairs a projection uses is decided ONCE per context, from the scene's own behaviour: four pairs cost ~4 us per solve
     // more than three (8.8 MB of reads, 20 block sums) and pay when solves need many iterations (Kuhn cube: 17.4 -> 13.9 per solve),
@@ -3015,7 +3093,11 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         }
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 1], st));
         // passive collisions are resolved inside the GS sweeps (linsolver 1, Solver.cpp:76)
-        if (int rr = launch_rhs(c))             // Solver.cpp:98
+        // The contact-free on-chip solves of one GPU sum their own right-hand side (Oc2Args::g_inc): no gather launch.  Decided HERE, from
+        // exactly the conditions that lead launch_global to launch_pcg2 with the recycled basis; every other route gets the launch.
+        const bool fuse = fuse_rhs_route(c);
+        if (fuse) c->fuse_rhs = true;
+        else if (int rr = launch_rhs(c))             // Solver.cpp:98
             return fail(rr == -2 ? ADMM_HIP_ERR_STATE : ADMM_HIP_ERR_COMM, rr == -2 ? "step: world_size > 1 but neither admm_hip_comm_init nor admm_hip_set_rhs_allreduce was called" : "all-reduce of the right-hand side failed");
         if (timed) HIP_TRY(hipEventRecord(c->ev_phase[3 * s + 2], st));
         // experiments (ADMM_HIP_TOL_LAST=tol, ADMM_HIP_TOL_LAST_N=k): the last k solves of a step at another tolerance
@@ -3025,6 +3107,7 @@ static int step_impl(admm_hip_ctx *c, int32_t admm_iters, double gravity, admm_h
         c->defl_now = c->defl_every <= 1 || ((s + 1) % c->defl_every) == 0;
         const int grc = launch_global(c, c->b.p, c->curr.p);   // Solver.cpp:99
         c->pcg_tol = keep_tol;
+        if (c->fuse_rhs) { c->fuse_rhs = false; return fail(ADMM_HIP_ERR_STATE, "step: the solve that was to sum its right-hand side did not run (internal)"); }
         if (grc == -2) return kStepAborted;       // a grid barrier timed out in a column solve of UzawaCG: same recovery as any aborted on-chip solve
         if (grc) return fail(ADMM_HIP_ERR_DEVICE, "PCG: the device stopped signalling progress");
     }
@@ -3112,7 +3195,7 @@ static int recover_from_abort(admm_hip_ctx *c, admm_hip_stats *stats_of_last) {
         return fail(ADMM_HIP_ERR_DEVICE, "PCG: a grid barrier of the on-chip solve timed out (is another persistent kernel sharing the GPU?)");
     if (!c->oc_gave_up) fprintf(stderr, "[admm_hip] on-chip PCG: a grid barrier timed out (blocks not co-resident?) -- falling back to the launch-per-iteration PCG and replaying %d step(s)\n", (int)c->pending.size());
     c->oc_gave_up = true; c->oc_enabled = false; c->gsp_enabled = false; c->uzp_enabled = false;
-    c->rc_hist = 0; c->rc_prev_valid = 0; c->rc_prev2_valid = 0;   // the history slots may hold pairs half-written by the aborted solve, in the on-chip kernel's row order
+    c->rc_hist = 0; c->rc_prev_valid = 0; c->rc_prev2_valid = 0; for (int &v : c->rc_vb) v = 0;   // the history slots may hold pairs half-written by the aborted solve, in the on-chip kernel's row order
     c->defl_fused = false;      // (the end projection on the soft modes goes on as separate launches)
     if (c->gsp_abort.p) HIP_TRY(c->gsp_abort.zero());
     if (c->uzp_abort.p) HIP_TRY(c->uzp_abort.zero());
@@ -3708,8 +3791,9 @@ int admm_host_oc_plan(const admm_hip_desc *d, int32_t n_blocks, int32_t spb, int
     admm_host::lame(10000000.0, 0.499, &mu, &la, &k);
     const double pw = d->pin_weight > 0 ? d->pin_weight : std::sqrt(k * 2.0);
     const bool pins_as_terms = (d->linsolver == 0 || d->linsolver == 2);
-    const admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
+    admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
                                                       d->tri_idx, d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, pw);
+    if (d->n_bends > 0) A = admm_host::add_stencil_terms(A, dt, d->n_bends, d->bend_idx, d->bend_coef, d->bend_weight);      // (the matrix admm_hip_create plans for)
     const admm_host::OcPlan P = admm_host::build_oc_plan(A, d->masses, n_blocks, spb, lds_bytes, coarse_inv != nullptr, d->vert_xyz);
     if (!P.ok) return fail(ADMM_HIP_ERR_ARG, "oc_plan: a block does not fit its slots");
     if (row_vertex) std::copy(P.orig.begin(), P.orig.end(), row_vertex);
@@ -3737,8 +3821,9 @@ int admm_host_big_plan(const admm_hip_desc *d, int32_t max_aggregates, int32_t *
     admm_host::lame(10000000.0, 0.499, &mu, &la, &k);
     const double pw = d->pin_weight > 0 ? d->pin_weight : std::sqrt(k * 2.0);
     const bool pins_as_terms = (d->linsolver == 0 || d->linsolver == 2);
-    const admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
-                                                      d->tri_idx, d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, pw);
+    admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
+                                                d->tri_idx, d->tri_rest, d->tri_weight, pins_as_terms ? d->n_pins : 0, d->pin_vert, pw);
+    if (d->n_bends > 0) A = admm_host::add_stencil_terms(A, dt, d->n_bends, d->bend_idx, d->bend_coef, d->bend_weight);      // (the matrix admm_hip_create plans for)
     const admm_host::BigPlan P = admm_host::build_big_plan(A, d->masses, d->vert_xyz, max_aggregates > 0 ? max_aggregates : 1024);
     if (!P.ok) return fail(ADMM_HIP_ERR_ARG, "big_plan: no plan (masses differ between the axes of a vertex)");
     stats[0] = P.G; stats[1] = P.ra; stats[2] = P.n_rows; stats[3] = P.nc; stats[4] = P.ncp; stats[5] = P.A.n_slices;
@@ -3753,8 +3838,9 @@ int admm_host_gs_plan_sweeps(const admm_hip_desc *d, int32_t n_colors, const int
     if (rc) return rc;
     if (!color || !b || !x || sweeps < 0) return fail(ADMM_HIP_ERR_ARG, "gs_plan_sweeps: NULL argument");
     const double dt = d->dt > 0.0 ? d->dt : 1.0 / 24.0;
-    const admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
-                                                      d->tri_idx, d->tri_rest, d->tri_weight, 0, d->pin_vert, 0.0);
+    admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
+                                                d->tri_idx, d->tri_rest, d->tri_weight, 0, d->pin_vert, 0.0);
+    if (d->n_bends > 0) A = admm_host::add_stencil_terms(A, dt, d->n_bends, d->bend_idx, d->bend_coef, d->bend_weight);      // (the matrix admm_hip_create plans for)
     const admm_host::GsPlan P = admm_host::build_gs_plan(A, n_colors, color, max_blocks > 0 ? max_blocks : 256, rows_target > 0 ? rows_target : 384, 160 * 1024);
     if (!P.ok) return fail(ADMM_HIP_ERR_ARG, "gs_plan_sweeps: no plan (too many colours, or a block does not fit the LDS)");
     const int G = P.G, C = P.C, H = admm_host::kGspHdr;

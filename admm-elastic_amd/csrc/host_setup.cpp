@@ -204,7 +204,36 @@ TetChunks tet_chunks(int32_t n_tets, const int32_t *tet_idx, const int32_t kind_
     return C;
 }
 
-Sell record_incidence(int32_t n_verts, int32_t n_rec, const int32_t *rec_vertex, int32_t pad_code, const int32_t *row_vertex) {
+Sell record_incidence(int32_t n_verts, int32_t n_rec, const int32_t *rec_vertex, int32_t pad_code, const int32_t *row_vertex, int32_t n_rows) {
+    // n_rows >= 0: the lists of n_rows rows, row r gathering for vertex row_vertex[r] (< 0: a dummy row, empty list) -- the on-chip
+    // solver's internal row order (k_pcg2 sums the right-hand side of its own rows); n_rows < 0: one row per vertex
+    if (n_rows >= 0) {
+        std::vector<int32_t> cntv(n_verts + 1, 0);
+        for (int32_t i = 0; i < n_rec; ++i) cntv[rec_vertex[i] + 1]++;
+        for (int32_t i = 0; i < n_verts; ++i) cntv[i + 1] += cntv[i];
+        std::vector<int32_t> lst(cntv[n_verts]);
+        std::vector<int32_t> pos(cntv.begin(), cntv.end() - 1);
+        for (int32_t e = 0; e < n_rec; ++e) lst[pos[rec_vertex[e]]++] = e;
+        Sell S;
+        S.n_rows = n_rows;
+        S.n_slices = (n_rows + 63) / 64;
+        S.slice_ptr.assign(S.n_slices + 1, 0);
+        S.slice_width.assign(S.n_slices, 0);
+        auto len = [&](int32_t r) { const int32_t v = row_vertex[r]; return v < 0 ? 0 : cntv[v + 1] - cntv[v]; };
+        for (int32_t s = 0; s < S.n_slices; ++s) {
+            int32_t w = 0;
+            for (int32_t r = 64 * s; r < std::min(n_rows, 64 * s + 64); ++r) w = std::max(w, len(r));
+            w = std::max(4, (w + 3) / 4 * 4);
+            S.slice_width[s] = w;
+            S.slice_ptr[s + 1] = S.slice_ptr[s] + 64 * w;
+        }
+        S.idx.assign(S.slice_ptr[S.n_slices], pad_code);
+        for (int32_t r = 0; r < n_rows; ++r) {
+            const int32_t s = r / 64, l = r % 64, v = row_vertex[r];
+            for (int32_t k = 0; k < len(r); ++k) S.idx[(size_t)S.slice_ptr[s] + 64 * k + l] = lst[cntv[v] + k];
+        }
+        return S;
+    }
     std::vector<int32_t> cnt(n_verts + 1, 0);
     for (int32_t i = 0; i < n_rec; ++i) cnt[rec_vertex[i] + 1]++;
     for (int32_t i = 0; i < n_verts; ++i) cnt[i + 1] += cnt[i];

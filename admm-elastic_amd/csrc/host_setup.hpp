@@ -62,7 +62,7 @@ struct TetChunks {
 };
 TetChunks tet_chunks(int32_t n_tets, const int32_t *tet_idx, const int32_t kind_begin[6]);
 // vertex -> records incidence lists (row r gathers for vertex row_vertex[r]); widths are multiples of 4, padding = pad_code
-Sell record_incidence(int32_t n_verts, int32_t n_rec, const int32_t *rec_vertex, int32_t pad_code, const int32_t *row_vertex = nullptr);
+Sell record_incidence(int32_t n_verts, int32_t n_rec, const int32_t *rec_vertex, int32_t pad_code, const int32_t *row_vertex = nullptr, int32_t n_rows = -1);
 std::vector<int32_t> incidence_row_order(int32_t n_verts, int32_t n_tets, const int32_t *tet_idx, int32_t n_tris, const int32_t *tri_idx, int32_t window);
 
 int greedy_coloring(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t *color);

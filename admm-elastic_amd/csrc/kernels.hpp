@@ -694,6 +694,39 @@ __device__ __forceinline__ void gather_corners(const int *__restrict__ inc, int 
     for (int i = 0; i < R; ++i) { acc[0] += g[3 * i]; acc[1] += g[3 * i + 1]; acc[2] += g[3 * i + 2]; }
 }
 
+// The SpringPin term of vertex v (src/SpringEnergyTerm.hpp:31-73; EnergyTerm::update, src/EnergyTerm.hpp:130-140): z = pin point (or q with
+// the term inactive), u += D x - z, and its share dt^2 w^2 (z - u) of the right-hand side added to acc.  One thread per vertex, once per
+// ADMM iteration -- from k_gather_rhs or from the fill phase of k_pcg2 (pcg_onchip2.hpp: the solve that sums its own right-hand side).
+__device__ __forceinline__ void pin_term_update(const int *__restrict__ vert_pin, const double *__restrict__ pin_xyz, const int *__restrict__ pin_active,
+                                                double *__restrict__ pin_u, double *__restrict__ pin_z, double pin_sc, const double *__restrict__ pin_nrm,
+                                                const double *__restrict__ x, int v, bool add, double *acc) {
+    const int pi = vert_pin[v];
+    if (pi < 0) return;
+    const bool act = pin_active[pi] != 0;
+    // SLIDE pin (README.md:23-28 TODO of the reference; a SpringPin, src/SpringEnergyTerm.hpp:31-73, whose prox projects onto
+    // the plane through the pin's point instead of onto the point): z = q - n (n . (q - p)), q = D x + u
+    double sl = 0.0, nrm[3] = {0.0, 0.0, 0.0};
+    if (pin_nrm && act) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) nrm[j] = pin_nrm[3 * (size_t)pi + j];
+        if (nrm[0] != 0.0 || nrm[1] != 0.0 || nrm[2] != 0.0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sl = fma(nrm[j], x[3 * (size_t)v + j] + pin_u[3 * (size_t)pi + j] - pin_xyz[3 * (size_t)pi + j], sl);
+        }
+    }
+    const bool slide = nrm[0] != 0.0 || nrm[1] != 0.0 || nrm[2] != 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double Dix = x[3 * (size_t)v + j];
+        const double uo = pin_u[3 * (size_t)pi + j];
+        const double zi = !act ? (Dix + uo) : slide ? fma(-sl, nrm[j], Dix + uo) : pin_xyz[3 * (size_t)pi + j];
+        const double un = uo + (Dix - zi);
+        pin_u[3 * (size_t)pi + j] = un;
+        pin_z[3 * (size_t)pi + j] = zi;
+        if (add) acc[j] += pin_sc * (zi - un);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
     const int lane = threadIdx.x & 63;
     const int s = wave_slice();
@@ -706,34 +739,7 @@ __global__ __launch_bounds__(256) void k_gather_rhs(GatherArgs a) {
         if (a.r_inc) gather_corners<false>(a.r_inc + a.r_ptr[s] + lane, a.r_w[s], a.r_cf, a.r_ld, acc);
         if (a.h_inc) gather_corners<false>(a.h_inc + a.h_ptr[s] + lane, a.h_w[s], a.h_cf, a.h_ld, acc);
         if (v < a.nv) {
-            if (a.vert_pin) {
-                const int pi = a.vert_pin[v];
-                if (pi >= 0) {
-                    const bool act = a.pin_active[pi] != 0;
-                    // SLIDE pin (README.md:23-28 TODO of the reference; a SpringPin, src/SpringEnergyTerm.hpp:31-73, whose prox projects onto
-                    // the plane through the pin's point instead of onto the point): z = q - n (n . (q - p)), q = D x + u
-                    double sl = 0.0, nrm[3] = {0.0, 0.0, 0.0};
-                    if (a.pin_nrm && act) {
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) nrm[j] = a.pin_nrm[3 * (size_t)pi + j];
-                        if (nrm[0] != 0.0 || nrm[1] != 0.0 || nrm[2] != 0.0) {
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) sl = fma(nrm[j], a.x[3 * (size_t)v + j] + a.pin_u[3 * (size_t)pi + j] - a.pin_xyz[3 * (size_t)pi + j], sl);
-                        }
-                    }
-                    const bool slide = nrm[0] != 0.0 || nrm[1] != 0.0 || nrm[2] != 0.0;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const double Dix = a.x[3 * (size_t)v + j];
-                        const double uo = a.pin_u[3 * (size_t)pi + j];
-                        const double zi = !act ? (Dix + uo) : slide ? fma(-sl, nrm[j], Dix + uo) : a.pin_xyz[3 * (size_t)pi + j];
-                        const double un = uo + (Dix - zi);
-                        a.pin_u[3 * (size_t)pi + j] = un;
-                        a.pin_z[3 * (size_t)pi + j] = zi;
-                        if (a.add_mxbar) acc[j] += a.pin_sc * (zi - un);
-                    }
-                }
-            }
+            if (a.vert_pin) pin_term_update(a.vert_pin, a.pin_xyz, a.pin_active, a.pin_u, a.pin_z, a.pin_sc, a.pin_nrm, a.x, v, a.add_mxbar != 0, acc);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 double r = acc[j];

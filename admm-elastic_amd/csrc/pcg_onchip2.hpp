@@ -85,6 +85,12 @@ struct Oc2Args {
     int defl_dbg;      // (experiments: bit 0 no mode loads in the dots, bit 1 no own-row loads, bit 2 no G^-1 staging)
     int defl_k; const float *defl_Z; const double *defl_Ginv; double *defl_rec;      // defl_Z: SINGLE precision (the step stays an exact Galerkin step: G is formed
                                                                                      // from the rounded vectors); defl_rec: [2][3 kOc2DeflMax][G] block sums, by solve parity
+    // THE SOLVE SUMS ITS OWN RIGHT-HAND SIDE (g_inc != nullptr; the ADMM loop's contact-free solves on one GPU): what k_gather_rhs does as a
+    // launch of its own (kernels.hpp; src/Solver.cpp:98) -- b = M x_bar + the records of the local step + the pin terms -- is done by the
+    // thread that owns the row, in the shadow of the LDS fill: the record lists come in the plan's internal row order (one SELL slice per
+    // wave, like the matrix), b is also written to g_b (= b: later readers, the recovery path).  Same lists, same order: the same bits.
+    const int *g_ptr, *g_w, *g_inc; int g_pad; const double *g_rec, *g_Mxbar; double *g_b;      // g_pad: the all-zero record the lists are padded with
+    const int *g_vert_pin; const double *g_pin_xyz; const int *g_pin_active; double *g_pin_u, *g_pin_z; double g_pin_sc; const double *g_pin_nrm;
 };
 constexpr int kOc2DeflMax = 32;
 
@@ -172,13 +178,49 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     const unsigned long long *const cpg_w = (const unsigned long long *)(a.col16 + base);
     LdsD *const lv_w = lv_all + slab_off * 64;
     LdsU64 *const lc_w = lc_all + (slab_off >> 2) * 64;
-    {   // the thread's matrix row -> LDS, once per solve
+    // This row's right-hand side (see Oc2Args::g_inc): records of the local step + pin term + M x_bar, INTERLEAVED with the LDS fill -- as one
+    // dependent chain in front of it (index -> record -> sum: three round trips on 12 waves per CU) the fill phase took 24 us instead of 8
+    // (ADMM_HIP_OC_PROF, round 6), more than the launch it replaces.  Stage A: the first eight list entries; the slab's values; stage C: their
+    // records; the slab's columns; stage E: the sums, in list order (the order of k_gather_rhs: the same bits), longer lists in the plain loop.
+    const bool gon = a.g_inc != nullptr;
+    int ge[8]; const int *ginc = nullptr; int gw = 0;
+    if (gon) {
+        gw = __builtin_amdgcn_readfirstlane(a.g_w[s]);
+        ginc = a.g_inc + __builtin_amdgcn_readfirstlane(a.g_ptr[s]) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ge[i] = ginc[64 * i];
+#pragma unroll
+        for (int i = 4; i < 8; ++i) ge[i] = gw > 4 ? ginc[64 * i] : a.g_pad;
+    }
+    {   // the thread's matrix row -> LDS, once per solve: values
         LdsD *lvw = lv_w + lane;
-        LdsU64 *lcw = lc_w + lane;
         const double *vpg = vpg_w + lane;
-        const unsigned long long *cpg = cpg_w + lane;
         for (int k = 0; k < wl_s; ++k) lvw[64 * k] = vpg[64 * k];
+    }
+    union { double d[2]; bv4u v; } gr0[8]; union { double d; bv2u v; } gr1[8];
+    if (gon) {
+        const __amdgpu_buffer_rsrc_t rr = soa_rsrc(a.g_rec);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            gr0[i].v = __builtin_amdgcn_raw_buffer_load_b128(rr, ge[i] * 32, 0, 0);
+            gr1[i].v = __builtin_amdgcn_raw_buffer_load_b64(rr, ge[i] * 32 + 16, 0, 0);
+        }
+    }
+    {   // ... and its columns
+        LdsU64 *lcw = lc_w + lane;
+        const unsigned long long *cpg = cpg_w + lane;
         for (int k = 0; k < (wl_s >> 2); ++k) lcw[64 * k] = cpg[64 * k];
+    }
+    if (gon) {
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[0] += gr0[i].d[0]; acc[1] += gr0[i].d[1]; acc[2] += gr1[i].d; }
+        if (gw > 8) gather_records(ginc + 64 * 8, gw - 8, a.g_rec, acc);
+        if (live) {
+            if (a.g_vert_pin) pin_term_update(a.g_vert_pin, a.g_pin_xyz, a.g_pin_active, a.g_pin_u, a.g_pin_z, a.g_pin_sc, a.g_pin_nrm, a.x, vi, true, acc);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a.g_b[3 * (size_t)vi + j] = acc[j] + a.g_Mxbar[3 * (size_t)vi + j];
+        }
     }
     const int hp0 = a.halo_ptr[blockIdx.x], nh = a.halo_ptr[blockIdx.x + 1] - hp0;
     // the halo entries this thread fetches (two per thread cover nh <= 2 T; more are read from the list every time)

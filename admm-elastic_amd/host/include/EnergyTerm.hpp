@@ -6,6 +6,7 @@
 #ifndef ADMM_ENERGYTERM_HPP
 #define ADMM_ENERGYTERM_HPP 1
 
+#include <iostream>      // (the reference's EnergyTerm.hpp brings it to every user, src/EnergyTerm.hpp:26)
 #include <memory>
 #include <vector>
 #include "MiniLinAlg.hpp"

@@ -10,6 +10,35 @@
 #include <stdexcept>
 #include <vector>
 
+#if defined(ADMM_WITH_EIGEN)
+// Built against a real Eigen found at build time (-DADMM_WITH_EIGEN -I<eigen>; never copied into this tree): the value types of the public
+// API ARE the Eigen types the reference's headers show (src/Solver.hpp:66-68, src/EnergyTerm.hpp:68-107), so code written against the
+// reference -- its own samples/tests/test_lineartet.cpp -- compiles unchanged against this mirror (tests/cpp/build_reference_test.sh).
+#include <Eigen/Dense>
+#include <Eigen/Sparse>
+namespace admm {
+typedef Eigen::Vector3d Vec3;
+typedef Eigen::Vector3i Vec3i;
+typedef Eigen::Vector4i Vec4i;
+typedef Eigen::VectorXd VecX;
+typedef Eigen::Triplet<double> Triplet;
+typedef Eigen::SparseMatrix<double, Eigen::RowMajor> SparseMat;
+namespace la {      // the three things the mirror does with a sparse matrix beyond Eigen's own interface
+inline void get_csr(const SparseMat &M, std::vector<int> &rp, std::vector<int> &ci, std::vector<double> &va) {
+    SparseMat C = M; C.makeCompressed();
+    rp.assign(C.outerIndexPtr(), C.outerIndexPtr() + C.rows() + 1); ci.assign(C.innerIndexPtr(), C.innerIndexPtr() + C.nonZeros()); va.assign(C.valuePtr(), C.valuePtr() + C.nonZeros());
+}
+inline void set_csr(SparseMat &M, int n, const std::vector<int> &rp, const std::vector<int> &ci, const std::vector<double> &va) {
+    std::vector<Triplet> t; t.reserve(ci.size());
+    for (int i = 0; i < n; ++i) for (int k = rp[i]; k < rp[i + 1]; ++k) t.emplace_back(i, ci[k], va[k]);
+    M.resize(n, n); M.setFromTriplets(t.begin(), t.end());
+}
+inline void scale_columns(SparseMat &M, const VecX &s, double f) { M = (M * s.asDiagonal()).eval() * f; }      // M <- f M diag(s)
+inline VecX zeros(std::size_t n) { return VecX::Zero((Eigen::Index)n); }
+}
+}
+#else
+
 namespace admm {
 
 struct Vec3 {
@@ -133,5 +162,13 @@ private:
     std::vector<double> val_;
 };
 
+namespace la {
+inline void get_csr(const SparseMat &M, std::vector<int> &rp, std::vector<int> &ci, std::vector<double> &va) { rp = M.rowptr(); ci = M.colind(); va = M.values(); }
+inline void set_csr(SparseMat &M, int n, const std::vector<int> &rp, const std::vector<int> &ci, const std::vector<double> &va) { M.setCsr(n, rp, ci, va); }
+inline void scale_columns(SparseMat &M, const VecX &s, double f) { M.scaleColumns(s, f); }
+inline VecX zeros(std::size_t n) { return VecX::Zero(n); }
+}
+
 } // namespace admm
+#endif
 #endif

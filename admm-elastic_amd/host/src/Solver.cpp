@@ -485,7 +485,7 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
         VecX w2(n_row);
         for (int i = 0; i < n_row; ++i) w2[i] = weights[i] * weights[i];
         solver_Dt_Wt_W = m_Dt;
-        solver_Dt_Wt_W.scaleColumns(w2, m_settings.timestep_s * m_settings.timestep_s);
+        la::scale_columns(solver_Dt_Wt_W, w2, m_settings.timestep_s * m_settings.timestep_s);
     }
     switch (m_settings.linsolver) {
         default: if (!std::dynamic_pointer_cast<LDLTSolver>(m_linsolver)) m_linsolver = std::make_shared<LDLTSolver>(); break;
@@ -572,7 +572,7 @@ bool Solver::initialize(const Settings &settings_) { // src/Solver.cpp:167-261
     check(admm_hip_get_matrix(ctx, nullptr, nullptr, nullptr, &nnz), "Solver::initialize");
     std::vector<int32_t> rp(d.n_verts + 1), ci(nnz); std::vector<double> va(nnz);
     check(admm_hip_get_matrix(ctx, rp.data(), ci.data(), va.data(), &nnz), "Solver::initialize");
-    solver_termA.setCsr(d.n_verts, std::vector<int>(rp.begin(), rp.end()), std::vector<int>(ci.begin(), ci.end()), va);
+    la::set_csr(solver_termA, d.n_verts, std::vector<int>(rp.begin(), rp.end()), std::vector<int>(ci.begin(), ci.end()), va);
     m_linsolver->update_system(solver_termA);
     if (m_settings.verbose >= 1) printf("%d nodes, %d energy terms\n", (int)m_x.size() / 3, (int)energyterms.size());
     initialized = true;
@@ -599,9 +599,11 @@ void Solver::step() { // src/Solver.cpp:35-110
 void Solver::save_matrix(const std::string &filename) { // src/Solver.cpp:264-269 (Ahat; A = diag(m) + Ahat (x) I3)
     std::cout << "Saving matrix (" << solver_termA.rows() << "x" << solver_termA.cols() << ") to " << filename << std::endl;
     std::ofstream out(filename.c_str());
-    for (int i = 0; i < solver_termA.rows(); ++i)
-        for (int k = solver_termA.rowptr()[i]; k < solver_termA.rowptr()[i + 1]; ++k)
-            out << i << " " << solver_termA.colind()[k] << " " << solver_termA.values()[k] << "\n";
+    std::vector<int> rp, ci; std::vector<double> va;
+    la::get_csr(solver_termA, rp, ci, va);
+    for (int i = 0; i < (int)solver_termA.rows(); ++i)
+        for (int k = rp[i]; k < rp[i + 1]; ++k)
+            out << i << " " << ci[k] << " " << va[k] << "\n";
 }
 
 // The command-line switches of the reference's samples (src/Solver.cpp:273-307), as one table: switch, the field it sets, help text.

@@ -1,10 +1,12 @@
 """Parity at the BENCHMARKED settings and sizes (round-3 review, item 1): every workload bench.py quotes a number on has a twin
 here that runs it under a checker at the size, solver settings and frame count the driver times.
 
-  blob1m_mix            configs[2]  1 012 608 tets, bench.PCG_TOL, recycled warm start, unverified short passes:
-                                    25 frames (the driver's timed region is frames 5-14, its statistics frames 15-24) against the
-                                    same path at 1e-12 + verification, rel_err < 1e-5 at EVERY frame; the 52 k-tet twin against the
-                                    oracle's exact (SuperLU) solves for 25 frames
+  blob1m_mix            configs[2]  1 012 608 tets, bench.PCG_TOL + bench.SOFT_MODES, recycled warm start, unverified short passes:
+                                    two frames of the 1e-12 path against the ORACLE's exact solves at full size; 200 frames (the
+                                    driver's timed region is frames 5-24, its statistics frames 25-44) of the bench settings against
+                                    that 1e-12 path (kernel vs kernel), rel_err < 1e-5 at EVERY frame; the 52 k-tet twin at bench
+                                    settings against the oracle's exact (SuperLU) solves for 25 frames
+  cube1m_nh, cube1m_mix             998 250 tets, their own settings (bench.workload_settings): 200 frames like the blob
   cube100k_gs           configs[1]  105 456 tets, 30-sweep multi-colour GS: whole frames against the oracle, shared colouring
   cloth200k_gs_floor    configs[4]  199 712 triangles, limits, pins, floor inside the sweeps: whole frames against the oracle until
                                     the cloth lies on the floor
@@ -58,40 +60,56 @@ def test_blob1m_two_frames_vs_oracle_exact_solves():
     s.close()
 
 
-def test_blob1m_drift_200_frames_bench_tolerance_vs_tight_solve():
-    """The driver's workload with the driver's settings against the same path converged to 1e-12 with every pass verified, frame by
-    frame -- through the driver's whole run (warm-up + timed + statistics frames) and far beyond it: 200 frames (round-4 review, item
-    1(b): "nobody knows the error at frame 300"; ADMM_TEST_DRIFT_FRAMES overrides).  The per-frame record goes to
-    gpurun_out/drift_blob1m_frames.txt (committed under profiles/ per round)."""
-    n = int(os.environ.get("ADMM_TEST_BIG_BLOB_N", "118"))
-    sc, nt, nv = _bench_scene("blob1m_mix", n)
+def _drift_200_frames(workload, n=None):
+    """One quoted PCG workload with ITS OWN bench settings (bench.workload_settings: tolerance, soft modes, the library's default start step)
+    against the same path converged to 1e-12 with every pass verified, frame by frame -- through the driver's whole run (warm-up + timed +
+    statistics frames) and far beyond it: 200 frames (ADMM_TEST_DRIFT_FRAMES overrides).  NOTE what this is: kernel against kernel -- the
+    oracle enters the chain at 1 M tets for two frames (test_blob1m_two_frames_vs_oracle_exact_solves: the 1e-12 path vs exact solves,
+    ~1e-9) and at 52 k tets for 25 frames at bench settings (test_blob52k_drift_25_frames_bench_settings_vs_oracle).  The per-frame record
+    goes to gpurun_out/drift_<workload>_frames.txt (committed under profiles/ per round)."""
+    import bench
+    sc, nt, nv = _bench_scene(workload, n)
+    tol, soft = bench.workload_settings(workload)
     frames = int(os.environ.get("ADMM_TEST_DRIFT_FRAMES", "200"))
     os.environ["ADMM_HIP_OC_VERIFY"] = "1"
     try:
         tight = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=1500)
     finally:
         os.environ.pop("ADMM_HIP_OC_VERIFY", None)
-    import bench
-    loose = sc.make_solver(pcg_tol=bench.PCG_TOL, pcg_max_iters=600, soft_modes=bench.SOFT_MODES)        # bench.py's defaults
+    loose = sc.make_solver(pcg_tol=tol, pcg_max_iters=600, soft_modes=soft)        # what `python bench.py --workload <workload>` runs
     errs = []
     for f in range(frames):
         tight.step(); loose.step()
         assert tight.runtime_data().unconverged_solves == 0 and loose.runtime_data().unconverged_solves == 0, f
         errs.append(scenes.rel_err(loose.m_x, tight.m_x))
-    print("blob drift rel_err, %d frames at pcg_tol %g: max %.2e at frame %d; every 10th:" % (frames, bench.PCG_TOL, max(errs), int(np.argmax(errs))),
+    print("%s drift rel_err, %d frames at pcg_tol %g, %d soft modes: max %.2e at frame %d; every 10th:" % (workload, frames, tol, soft, max(errs), int(np.argmax(errs))),
           " ".join("%.2e" % e for e in errs[9::10]))
     try:
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "drift_blob1m_frames.txt"), "w") as fh:
-            fh.write("# blob1m_mix (%d tets), bench settings (pcg_tol %g, %s) vs the same path at 1e-12 verified: rel_err per frame\n" %
-                     (nt, bench.PCG_TOL, "soft modes %d" % bench.SOFT_MODES))
+        with open(os.path.join(out, "drift_%s_frames.txt" % workload), "w") as fh:
+            fh.write("# %s (%d tets), bench settings (pcg_tol %g, soft modes %d) vs the same path at 1e-12 verified: rel_err per frame\n" % (workload, nt, tol, soft))
             fh.write("\n".join("%d %.3e" % (i, e) for i, e in enumerate(errs)) + "\n")
     except OSError:
         pass
     assert max(errs) < 1e-5, errs
-    assert np.abs(tight.m_x - sc.x.ravel()).max() > 1e-3      # the body actually moves (it sways by ~0.3 % of its size)
+    assert np.abs(tight.m_x - sc.x.ravel()).max() > 1e-3      # the body actually moves
     tight.close(); loose.close()
+
+
+def test_blob1m_drift_200_frames_bench_tolerance_vs_tight_solve():
+    """configs[2], the driver's default workload (round-4 review, item 1(b): "nobody knows the error at frame 300")."""
+    n = int(os.environ.get("ADMM_TEST_BIG_BLOB_N", "118"))
+    _drift_200_frames("blob1m_mix", n)
+
+
+@pytest.mark.parametrize("workload", ["cube1m_nh", "cube1m_mix"])
+def test_cube1m_drift_200_frames_bench_settings_vs_tight_solve(workload):
+    """Round-5 review, weak item 1: the other two quoted 1 M-tet PCG workloads -- cube1m_nh is the north-star's own mesh -- had no drift record
+    at the settings bench.py runs them with.  They have their OWN settings now (bench.WORKLOADS: a looser tolerance, no soft-mode step: the
+    pinned-face cube has no soft global modes), asserted here like the blob's."""
+    n = int(os.environ.get("ADMM_TEST_BIG_N", "55"))
+    _drift_200_frames(workload, n)
 
 
 def test_blob52k_drift_25_frames_bench_settings_vs_oracle():
