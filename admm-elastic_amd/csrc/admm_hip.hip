@@ -769,9 +769,13 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
     }
     c->oc_enabled = true;
     { const char *ta = getenv("ADMM_HIP_TEST_ABORT_SOLVE"); c->test_abort_seq = ta ? atoi(ta) : 0; }
-    {   // the record lists in internal row order (tets only: triangles and hinges keep the gather launch); ADMM_HIP_FUSE_RHS=0: A/B
+    {   // the record lists in internal row order (tets only: triangles and hinges keep the gather launch).  OPT-IN (ADMM_HIP_FUSE_RHS=1): built
+        // and measured in round 6 (and, differently, in round 3) -- correct, bit-identical right-hand sides, and ~1 % SLOWER on the bench body:
+        // inside k_pcg2 the gather costs 16 us of the fill phase (8 -> 24 us, interleaved with the slab loads or not: a wave's 64 rows are a
+        // length-sorted sample of its block, their 32-byte records share no cache lines -- k_gather_rhs walks the records in vertex order on
+        // 32 waves per CU and takes 10.4 us) against the 10.4 us kernel + ~3 us launch gap it replaces (profiles/r06_fused_rhs_ab.txt).
         const char *fe = getenv("ADMM_HIP_FUSE_RHS");
-        if (!(fe && fe[0] == '0') && c->nt > 0 && c->ntri == 0 && c->nbend == 0 && c->world == 1 && !c->rec_vertex_h.empty()) {
+        if ((fe && fe[0] == '1') && c->nt > 0 && c->ntri == 0 && c->nbend == 0 && c->world == 1 && !c->rec_vertex_h.empty()) {
             std::vector<int32_t> rv(c->oc_orig_h.begin(), c->oc_orig_h.end());
             if ((e = c->oc_inc.upload(admm_host::record_incidence(c->nv, c->n_rec, c->rec_vertex_h.data(), c->n_rec, rv.data(), c->oc_rows))) != hipSuccess) return e;
             c->fuse_rhs_ok = true;
@@ -3401,7 +3405,8 @@ int admm_hip_get_solver_params(const admm_hip_ctx *c, int32_t kind, int32_t *max
 int admm_hip_set_soft_modes(admm_hip_ctx *c, int32_t k, const double *Z) {
     if (!c || k < 0 || k > kDeflMax || (k > 0 && !Z)) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: bad input (at most 64 modes)");
     if (c->linsolver == 1) return fail(ADMM_HIP_ERR_ARG, "set_soft_modes: this context runs no PCG");
-    if (c->dist_solve) return fail(ADMM_HIP_ERR_STATE, "set_soft_modes: not with the distributed solve (ADMM_HIP_DIST_SOLVE=1)");      // (see admm_hip_compute_soft_modes)
+    // (the distributed solve: every rank holds the whole x and the whole b after a solve -- x is assembled by the solve's last all-reduce, b by the
+    // right-hand side's -- and the whole matrix; the Galerkin step on the modes is then the SAME replicated computation on every rank, k_defl_*)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (int rc = settle(c)) return rc;
@@ -3477,9 +3482,10 @@ int admm_hip_compute_soft_modes(admm_hip_ctx *c, int32_t k, int32_t iters) {
     if (k == 0) return admm_hip_set_soft_modes(c, 0, nullptr);
     if (c->linsolver == 1) return fail(ADMM_HIP_ERR_ARG, "compute_soft_modes: this context runs no PCG");
     // multi-rank contexts: the element-block partition replicates the solve (every rank computes the same modes from the same matrix with the
-    // same deterministic code, no collective inside a solve), the component partition solves the rank's own bodies; the DISTRIBUTED solve is
-    // the one configuration whose modes would have to be assembled across ranks
-    if (c->dist_solve) return fail(ADMM_HIP_ERR_STATE, "compute_soft_modes: not with the distributed solve (ADMM_HIP_DIST_SOLVE=1)");
+    // same deterministic code, no collective inside a solve), the component partition solves the rank's own bodies.  The DISTRIBUTED solve
+    // (round 6): a COLLECTIVE call -- every rank runs the same inverse iteration on the same start vectors, each K^-1 X is one distributed solve
+    // whose result every rank receives whole (the solve's closing all-reduce), the Rayleigh-Ritz steps are the same host arithmetic everywhere:
+    // identical modes on every rank, no assembly step.
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (int rc = settle(c)) return rc;

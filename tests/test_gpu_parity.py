@@ -1374,3 +1374,27 @@ def test_wind_force_on_the_device():
     s.m_x = x0.copy(); s.m_v = v0.copy()
     s.step()
     assert np.abs(s.m_v - v0).max() <= 1e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ls", [0, 2])
+def test_solve_that_sums_its_own_right_hand_side_is_bit_identical(ls, monkeypatch):
+    """ADMM_HIP_FUSE_RHS=1 (opt-in, round 6: k_pcg2 sums the records of the local step, the pin terms and M x_bar for its own rows instead of a
+    k_gather_rhs launch, src/Solver.cpp:98): same lists in the same order, so the right-hand sides -- and with them whole frames -- have the
+    SAME BITS as the default path.  Unstructured body with pins, soft modes on (the start step in front of a frame's second solve keeps the
+    launch for that solve), slide pin on one foot."""
+    xs = []
+    for fuse in ("0", "1"):
+        sc = scenes.blob_scene(30, admm_iters=8, linsolver=ls)
+        v = next(iter(sc.pins))
+        sc.slides[v] = (sc.pins.pop(v), np.array([0.0, 1.0, 0.0]))
+        monkeypatch.setenv("ADMM_HIP_FUSE_RHS", fuse)
+        s = sc.make_solver(pcg_tol=1e-9, pcg_max_iters=600, soft_modes=8)
+        monkeypatch.delenv("ADMM_HIP_FUSE_RHS")
+        for _ in range(3):
+            s.step()
+            assert s.runtime_data().unconverged_solves == 0
+        xs.append(s.m_x.copy())
+        s.close()
+    assert np.abs(xs[0] - sc.x.ravel()).max() > 1e-4
+    assert np.array_equal(xs[0], xs[1]), np.abs(xs[0] - xs[1]).max()
