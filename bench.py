@@ -587,6 +587,19 @@ def main():
         out["expected_speedup"] = {"model": "t_N = (local + rhs) / N + solve + 0.04 ms all-reduce (4.4 MB over xGMI); the solve (one persistent on-chip launch, latency-bound) is replicated",
                                    "single_gpu_ms_per_admm_iter": {"local": loc, "rhs": rhs, "solve": glo - rhs},
                                    "vs_one_gpu": (loc + glo) / ((loc + rhs) / world + (glo - rhs) + 0.04)}
+    if world > 1 and not weak:
+        # The ONE-body configuration that can scale: N M tets on N GPUs, rows of the launch-path two-level PCG split over the ranks
+        # (ADMM_HIP_DIST_SOLVE=1).  No multi-GPU node has been available to this repository: the model below is arithmetic on single-GPU kernel
+        # times (profiles/r05_size_curve.txt, r04_dist_solve_cost.txt), stated so that the first real run can be CHECKED against it.
+        def _dist(n):
+            stream = 58.0 * (n / 2.0) / n            # k_big_spmv + k_big_vec, us per iteration: (33 + 25) at 2 M tets, by size / ranks
+            coarse = 36.0 / n                        # dense coarse rows of the rank's own aggregates (923 aggregates at 4-8 M tets)
+            coll = 3 * 13.0                          # three latency-bound all-reduces per iteration over xGMI (12-15 us each)
+            per_solve = 14.0 * (stream + coarse + coll) + 500.0      # ~14 iterations with the soft-mode steps + entry / recycling / soft-mode kernels
+            return 1e6 / (per_solve + 75.0 / 1.0 + 40.0)             # + local step and gather of 1 M tets per rank + the right-hand side's all-reduce
+        out["distributed_solve_model"] = {"what": "ONE body of N M tets on N GPUs, ADMM_HIP_DIST_SOLVE=1 (not what this line ran): expected ADMM it/s",
+                                          "admm_it_per_s": {"2": _dist(2), "4": _dist(4), "8": _dist(8)},
+                                          "single_gpu_measured": {"2 M tets": 537, "4 M tets": 293}}
     if weak and world > 1:
         out["expected_speedup"] = {"model": "N independent bodies, no exchange inside a step: N x the single-GPU rate of one body", "vs_one_gpu": float(world)}
     if rank == 0:
