@@ -564,18 +564,24 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                 }
                 if (cnt > 0) {
                     __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)a.rc_part, 0, 72 * a.G * 8, 0x00020000);
-                    // block totals of the 3 x kRcQ products, 24 at a time
+                    // Block totals of the products, 24 at a time.  Round 6: the Gram matrix E_i . R_j = E_i . A E_j is symmetric (the pairs are exact
+                    // to rounding, and rc_cholesky takes the symmetric part anyway), so only i <= j is summed: per axis 10 + kRc + 2 = 16 sums,
+                    // 48 in all -- two rounds of 24 instead of three, 48 instead of 66 sums to add up behind the barrier.
+                    constexpr int kRcS = kRc * (kRc + 1) / 2 + kRc + 2;      // 16: [0, 10) G_ij (i <= j, row by row), [10, 14) E_i . r0, 14 r0 . D^-1 r0, 15 b . D^-1 b
+                    static_assert(3 * kRcS == 48, "two rounds of 24 sums");
 #pragma unroll
-                    for (int g24 = 0; g24 < 3; ++g24) {
+                    for (int g24 = 0; g24 < 2; ++g24) {
                         double q24[24];
 #pragma unroll
                         for (int i = 0; i < 24; ++i) {
-                            const int f = 24 * g24 + i, ax = f / kRcQ, qi = f % kRcQ;     // compile-time after unrolling
-                            q24[i] = (f >= 3 * kRcQ) ? 0.0
-                                   : (qi < kRc * kRc) ? e[qi / kRc][ax < 3 ? ax : 0] * r[qi % kRc][ax < 3 ? ax : 0]
-                                   : (qi < kRc * kRc + kRc) ? e[(qi - kRc * kRc) % kRc][ax < 3 ? ax : 0] * ri[ax < 3 ? ax : 0]
-                                   : (qi == kRc * kRc + kRc) ? ri[ax < 3 ? ax : 0] * rd[ax < 3 ? ax : 0] * ri[ax < 3 ? ax : 0]
-                                   : bj[ax < 3 ? ax : 0] * rd[ax < 3 ? ax : 0] * bj[ax < 3 ? ax : 0];
+                            const int f = 24 * g24 + i, ax = f / kRcS, qi = f % kRcS;     // compile-time after unrolling
+                            int gi = 0, gj = 0;
+                            { int k = qi; for (int ii = 0; ii < kRc; ++ii) { if (k < kRc - ii) { gi = ii; gj = ii + k; break; } k -= kRc - ii; } }
+                            constexpr int NG_ = kRc * (kRc + 1) / 2;
+                            q24[i] = (qi < NG_) ? e[gi][ax] * r[gj][ax]
+                                   : (qi < NG_ + kRc) ? e[qi - NG_][ax] * ri[ax]
+                                   : (qi == NG_ + kRc) ? ri[ax] * rd[ax] * ri[ax]
+                                   : bj[ax] * rd[ax] * bj[ax];
                         }
                         block_sums24(q24);
                         if (tid < 24) oc_store_sc1(rs_r, ((24 * g24 + tid) * a.G + (int)blockIdx.x) * 8, res24[tid]);
@@ -584,30 +590,30 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                     ++be;
                     if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
                     if (prof) a.prof[62 * 8 + 2] = wall_clock64();
-                    double *sums = (double *)(smem + kOc2Scratch);   // [3 kRcQ + 2 + 3 kRc] in the (idle) local vector
+                    double *sums = (double *)(smem + kOc2Scratch);   // [3 kRcS + 3 kRc] in the (idle) local vector
                     {   // every block adds the G partials of every sum in the same order; wave wv takes sums wv, wv + nw, ...:
                         // all loads first, one round trip
-                        double v[6][4];
+                        double v[4][4];
 #pragma unroll
-                        for (int t = 0; t < 6; ++t) {
+                        for (int t = 0; t < 4; ++t) {
                             const int k = wv + nw * t;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const int g = lane + 64 * j;
-                                v[t][j] = (k < 3 * kRcQ && g < a.G) ? oc_load_sc1_f64(rs_r, (k * a.G + g) * 8) : 0.0;
+                                v[t][j] = (k < 3 * kRcS && g < a.G) ? oc_load_sc1_f64(rs_r, (k * a.G + g) * 8) : 0.0;
                             }
                         }
 #pragma unroll
-                        for (int t = 0; t < 6; ++t) {
+                        for (int t = 0; t < 4; ++t) {
                             const int k = wv + nw * t;
-                            if (k < 3 * kRcQ) {
+                            if (k < 3 * kRcS) {
                                 double sm = ((v[t][0] + v[t][1]) + v[t][2]) + v[t][3];
                                 for (int g = lane + 256; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_r, (k * a.G + g) * 8);
                                 sm = wave_sum(sm);
                                 if (lane == 0) sums[k] = sm;
                             }
                         }
-                        for (int k = wv + 6 * nw; k < 3 * kRcQ; k += nw) {   // blocks with fewer than 11 waves
+                        for (int k = wv + 4 * nw; k < 3 * kRcS; k += nw) {   // blocks with fewer than 12 waves
                             double sm = 0.0;
                             for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_r, (k * a.G + g) * 8);
                             sm = wave_sum(sm);
@@ -615,12 +621,24 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                         }
                     }
                     __syncthreads();
-                    double *coefL = sums + 3 * kRcQ + 2;   // [3][kRc]
+                    double *coefL = sums + 3 * kRcS;   // [3][kRc]
                     if (tid < 3) {
                         bool skip = true;    // r0 already meets the tolerance on every axis: the pairs must not perturb x
-                        for (int ax = 0; ax < 3; ++ax) skip = skip && (sums[ax * kRcQ + 20] <= a.tol2 * sums[ax * kRcQ + 21] + 1e-300);
+                        for (int ax = 0; ax < 3; ++ax) skip = skip && (sums[ax * kRcS + 14] <= a.tol2 * sums[ax * kRcS + 15] + 1e-300);
+                        // the layout rc_cholesky reads (G_ij at i kRc + j, E_i . r0 at kRc^2 + i), filled from the triangle
+                        double S[kRc * kRc + kRc];
+                        const double *sa = sums + kRcS * tid;
+                        {
+                            int k = 0;
+#pragma unroll
+                            for (int ii = 0; ii < kRc; ++ii)
+#pragma unroll
+                                for (int jj = ii; jj < kRc; ++jj) { S[ii * kRc + jj] = sa[k]; S[jj * kRc + ii] = sa[k]; ++k; }
+#pragma unroll
+                            for (int ii = 0; ii < kRc; ++ii) S[kRc * kRc + ii] = sa[kRc * (kRc + 1) / 2 + ii];
+                        }
                         double c[kRc];
-                        rc_cholesky(sums + kRcQ * tid, cnt, skip, c);
+                        rc_cholesky(S, cnt, skip, c);
 #pragma unroll
                         for (int i = 0; i < kRc; ++i) coefL[tid * kRc + i] = c[i];
                     }
