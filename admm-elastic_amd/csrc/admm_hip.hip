@@ -1748,7 +1748,7 @@ void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
     a.pin_flag = c->gs_has_pins ? c->gs_pin_flag.p : nullptr; a.pin_xyz = c->gs_pin_xyz.p; a.pin_nrm = c->gs_pin_nrm.p;
     a.omega = c->gs_omega; a.tol2 = c->gs_tol * c->gs_tol; a.max_sweeps = c->gs_max_iters; a.check = c->gs_tol > 0.0 ? 1 : 0;
     a.seq = (unsigned)++c->solve_seq;
-    a.box = (v4u *)c->gsp_box.p; a.part = (v4u *)c->gsp_part.p; a.meet = (v4u *)c->gsp_meet.p; a.abort_word = c->gsp_abort.p;
+    a.box = (v4u *)c->gsp_box.p; a.n_box = (int)std::max<int64_t>(c->gsp_stat[4], 1); a.part = (v4u *)c->gsp_part.p; a.meet = (v4u *)c->gsp_meet.p; a.abort_word = c->gsp_abort.p;
     a.done = c->counters.p + 1; a.sweeps = c->counters.p + 2; a.total = c->counters.p; a.sig = c->d_sig;
     a.prof = c->gsp_prof.p; a.prof_block = c->gsp_prof_block;
     a.ob = c->obst_dev.p; a.proj = c->gs_proj.p;
@@ -1757,12 +1757,14 @@ void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
     hipLaunchKernelGGL(k_gs_persist, dim3(c->gsp_G), dim3(kGspT), c->gsp_lds, st, a);
     c->gsp_launches += 1;
     if (c->gsp_prof.p && (c->solve_seq % 200) == 0) {     // diagnosis: one block's wall-clock split of the phases since the last print
-        unsigned long long h[8];
+        unsigned long long h[16];
         if (hipMemcpyAsync(h, c->gsp_prof.p, sizeof(h), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && h[4]) {
             const double k = 0.01 / (double)h[4];      // 100 MHz ticks -> us per phase
             fprintf(stderr, "[gsp_prof] block %d, %llu phases: halo poll %.2f  block barrier %.2f  rows + publish %.2f  verdict etc. %.2f us per phase\n",
                     c->gsp_prof_block, h[4], k * h[0], k * h[1], k * h[2], k * h[3]);
             if (h[6]) fprintf(stderr, "[gsp_prof] shader clock during the solves: %.0f MHz\n", 100.0 * (double)h[5] / (double)h[6]);
+            if (h[8]) fprintf(stderr, "[gsp_prof] rows + publish in detail (-DADMM_GSP_PROF_FINE): row sums %.2f  own row's data + residual before %.2f  pin / relax %.2f  stores + granules + residual after %.2f  "
+                                      "parked partial + judge %.2f  park %.2f us per phase\n", k * h[8], k * h[9], k * h[10], k * h[11], k * h[12], k * h[13]);
             (void)hipMemsetAsync(c->gsp_prof.p, 0, sizeof(h), st);
         }
     }
@@ -1806,7 +1808,7 @@ hipError_t plan_gs_persist(admm_hip_ctx *c) {
     if ((e = c->gsp_abort.alloc(16)) != hipSuccess) return e;
     if ((e = c->gsp_abort.zero()) != hipSuccess) return e;
     { const char *pe = getenv("ADMM_HIP_GSP_PROF"), *pb = getenv("ADMM_HIP_GSP_PROF_BLOCK");
-      if (pe && pe[0] == '1') { if ((e = c->gsp_prof.alloc(8)) != hipSuccess) return e; if ((e = c->gsp_prof.zero()) != hipSuccess) return e; c->gsp_prof_block = pb ? atoi(pb) : 0; } }
+      if (pe && pe[0] == '1') { if ((e = c->gsp_prof.alloc(16)) != hipSuccess) return e; if ((e = c->gsp_prof.zero()) != hipSuccess) return e; c->gsp_prof_block = pb ? atoi(pb) : 0; } }
     c->gsp_G = P.G; c->gsp_C = P.C; c->gsp_lds = (size_t)P.lds_bytes;
     c->gsp_stat[0] = P.G; c->gsp_stat[1] = P.max_rows; c->gsp_stat[2] = P.max_halo; c->gsp_stat[3] = P.max_nbr; c->gsp_stat[4] = P.ob_total; c->gsp_stat[5] = P.lds_bytes;
     if (getenv("ADMM_HIP_OC_DIAG"))
@@ -3637,7 +3639,10 @@ int admm_hip_probe_sync(admm_hip_ctx *c, int32_t n, double *us_all_to_all, doubl
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     double out[2] = {0.0, 0.0};
-    for (int mode = 0; mode < 2; ++mode) {
+    const char *pm = getenv("ADMM_HIP_PROBE_A2A_MODE");      // (experiments: another record layout in the all-to-all probe, pcg_onchip2.hpp)
+    const int a2a_mode = pm ? atoi(pm) : 0;
+    for (int slot = 0; slot < 2; ++slot) {
+        const int mode = slot == 0 ? a2a_mode : 1;
         Oc2Args a{};
         a.n_rows = c->oc_rows; a.halo_ptr = c->oc_haloptr.p; a.halo_src = c->oc_halosrc.p; a.vec_len = c->oc_veclen;
         a.ubuf = c->oc_ubuf.p; a.part = c->oc_part.p; a.bar = c->oc_bar.p; a.nbr = c->oc_nbr.p; a.flags = c->oc_flags.p;
@@ -3652,7 +3657,7 @@ int admm_hip_probe_sync(admm_hip_ctx *c, int32_t n, double *us_all_to_all, doubl
         }
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-        out[mode] = 1e3 * (double)ms / (double)n;
+        out[slot] = 1e3 * (double)ms / (double)n;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (c->h_sig && c->h_sig[2]) { c->h_sig[2] = 0; return fail(ADMM_HIP_ERR_DEVICE, "probe_sync: a grid barrier timed out"); }

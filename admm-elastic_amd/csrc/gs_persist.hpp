@@ -5,10 +5,20 @@
 // mesh (host plan: oc_plan.cpp build_gs_plan) for the whole solve -- its rows' matrix entries, right-hand side, its part of x and
 // the values of the neighbouring blocks' rows it references, all in LDS -- and a colour phase costs ONE neighbour hand-off:
 //
-//   * every block publishes the boundary rows of the colour it has just swept as TAGGED GRANULES, 16 bytes = {lo32(value), stamp,
-//     hi32(value), stamp}, written with one write-through (sc1) store: the two 8-byte halves are single-copy atomic, so a reader that
-//     sees the phase's stamp in both halves has the value -- no drain, no flag, no second round trip (experiments/sync_latency.hip:
-//     1.6-2.4 us per phase against 2.2-3.1 us for data + drain + flag + poll and ~5.2 us for a kernel launch inside a hipGraph);
+//   * every block publishes the boundary rows of the colour it has just swept as TAGGED GRANULES: 16-byte write-through (sc1) stores whose
+//     two 8-byte halves (each single-copy atomic) carry the phase's stamp next to their payload, so a reader that sees the stamp in every half
+//     has the value -- no drain, no flag, no second round trip (experiments/sync_latency.hip: 1.6-2.4 us per phase against 2.2-3.1 us for
+//     data + drain + flag + poll and ~5.2 us for a kernel launch inside a hipGraph);
+//   * ROUND 6 -- what a hand-off costs is how the granules fill SECTORS (profiles/r06_gs_granules_ab.txt).  Rounds 4-5 wrote one granule per
+//     value ({lo32, stamp, hi32, stamp}: 48 bytes per row) at [node][parity][axis]: every store instruction of a wave left one 16-byte half
+//     sector per row, 96 bytes apart, and the phase's hand-off took 1.4 us.  Now (a) a row's x | y | z travel as ONE 192-bit string in TWO
+//     granules = four 8-byte units of 48 payload bits + the low 16 bits of the stamp (gsp_pack3; enough to tell the phases of a solve and
+//     sixteen consecutive solves apart, and every slot is rewritten in every solve), and (b) the outbox is laid out [parity][granule][node]:
+//     the rows a wave publishes have consecutive outbox nodes (the plan numbers a block's boundary rows colour by colour), so one store
+//     instruction fills whole sectors and whole lines, and the consumer's lanes (halo lists sorted by source block and row) read them the
+//     same way.  Hand-off 1.4 -> 0.70 us per phase: cube100k_gs 4 330 -> 5 260, cloth200k_gs_floor 3 090 -> 3 300 ADMM it/s, same bits.
+//     (Measured and dropped in the same session: two or three polls of a granule in flight at a time -- the wait is the neighbours' stores
+//     draining, not the sampling instant: -1 % / -8 %; one granule per lane behind a block barrier -- 4 460 on the cube.)
 //   * a consumer polls exactly the granules of its halo entries of that colour (sc1 loads), with bounded spins: a hand-off that
 //     cannot complete aborts the solve (sig[2]) instead of hanging the GPU;
 //   * two outbox slots per node alternate between sweeps (a block can run at most one sweep ahead of a neighbour: it needs the
@@ -46,7 +56,8 @@ struct GspArgs {
     double omega, tol2;
     int max_sweeps, check;
     unsigned seq;                                             // solve number of the context (stamps)
-    v4u *box;                                                 // [outbox nodes][2 sweep parities][3 axes] granules
+    v4u *box;                                                 // [outbox nodes][2 sweep parities][3 axes] granules (gsp_box_off)
+    int n_box;                                                // outbox nodes of all blocks
     v4u *part;                                                // [G][4 sweep slots][2] granules: |r|^2, |b|^2 of the block
     v4u *meet;                                                // [G] granules: the blocks' rendez-vous before a replay
     unsigned *abort_word;                                     // raised by the first block that gives up
@@ -72,12 +83,49 @@ __device__ __forceinline__ void gsp_store(__amdgpu_buffer_rsrc_t rs, int byte_of
     __builtin_amdgcn_raw_buffer_store_b128(g, rs, byte_off, 0, 16 /* sc1: write-through */);
 }
 
-#ifndef ADMM_GSP_STAGGER
-#define ADMM_GSP_STAGGER -1
+#ifndef ADMM_GSP_PACK2
+#define ADMM_GSP_PACK2 1
 #endif
-constexpr int kGspStagger = ADMM_GSP_STAGGER;      // >= 0: a second poll that many s_sleep periods behind the first -- measured and OFF: 2 / 5 / 9 / 14
-                                                   // periods give 4 190 / 4 249 / 4 281 / 4 270 against 4 330-4 390 ADMM it/s (cube), 2 857 ... 2 927 against 3 107 (cloth):
-                                                   // the second poll's loads queue in front of everything the wave issues next (loads return in order)
+// ADMM_GSP_PACK2: the three values of a boundary row in TWO granules instead of three -- four 8-byte units (each single-copy atomic) of 48 payload
+// bits + the low 16 bits of the stamp: x | y | z as one 192-bit string cut into four.  16 bits tell the phases of one solve apart and sixteen
+// consecutive solves (stamp = solve x 4096 + 1 + phase, phase < 4048); every slot is rewritten in every solve.
+__device__ __forceinline__ void gsp_pack3(const double *v, unsigned stamp, v4u &ga, v4u &gb) {
+    union { double d; unsigned u[2]; } x, y, z; x.d = v[0]; y.d = v[1]; z.d = v[2];
+    const unsigned s = stamp << 16;
+    ga.x = x.u[0];                              ga.y = (x.u[1] & 0xffffu) | s;
+    ga.z = (x.u[1] >> 16) | (y.u[0] << 16);     ga.w = (y.u[0] >> 16) | s;
+    gb.x = y.u[1];                              gb.y = (z.u[0] & 0xffffu) | s;
+    gb.z = (z.u[0] >> 16) | (z.u[1] << 16);     gb.w = (z.u[1] >> 16) | s;
+}
+__device__ __forceinline__ bool gsp_ok3(v4u ga, v4u gb, unsigned stamp) {
+    const unsigned s = stamp & 0xffffu;
+    return (ga.y >> 16) == s && (ga.w >> 16) == s && (gb.y >> 16) == s && (gb.w >> 16) == s;
+}
+__device__ __forceinline__ void gsp_unpack3(v4u ga, v4u gb, double *v) {
+    union { double d; unsigned u[2]; } x, y, z;
+    x.u[0] = ga.x;                              x.u[1] = (ga.y & 0xffffu) | (ga.z << 16);
+    y.u[0] = (ga.z >> 16) | (ga.w << 16);       y.u[1] = gb.x;
+    z.u[0] = (gb.y & 0xffffu) | (gb.z << 16);   z.u[1] = (gb.z >> 16) | (gb.w << 16);
+    v[0] = x.d; v[1] = y.d; v[2] = z.d;
+}
+constexpr int kGspGran = ADMM_GSP_PACK2 ? 2 : 3;      // granules per (outbox node, sweep parity)
+#ifndef ADMM_GSP_SOA
+#define ADMM_GSP_SOA 1
+#endif
+// Byte offset of granule k of outbox node `node`, sweep parity `par`.  ADMM_GSP_SOA: [parity][granule][node] -- the rows a wave publishes have
+// consecutive outbox nodes (the plan numbers a block's boundary rows colour by colour), so ONE store instruction covers whole 32-byte sectors and
+// whole lines, and the consumer's lanes (halo lists sorted by source block and row) read them the same way; 0: [node][parity][granule], a wave's
+// store instruction touches one 16-byte half sector per row, 96 bytes apart (half-written sectors drain slowly: pcg_onchip2.hpp, publish()).
+__device__ __forceinline__ int gsp_box_off(int node, int par, int k, int n_nodes) {
+#if ADMM_GSP_SOA
+    return ((par * kGspGran + k) * n_nodes + node) * 16;
+#else
+    (void)n_nodes;
+    return ((node * 2 + par) * kGspGran + k) * 16;
+#endif
+}
+
+struct GspObstOne { int n; int kind[1]; double par[1][4]; const double *gmeta, *gdata; };      // Obstacles with room for one (k_gs_persist: in SGPRs)
 
 __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,6 +151,22 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     }
     __syncthreads();
     if (ctl[0]) return;
+    const bool has_ob = __builtin_amdgcn_readfirstlane(obl->n) > 0;      // (uniform, in an SGPR: no LDS round trip per row for scenes without obstacles)
+    // ONE obstacle (the usual scene: a floor): count, kind and parameters live in SGPRs -- read from the LDS copy they were three dependent round trips
+    // in front of every row's update.  gs_relax is a template on the obstacle container: the same arithmetic, the same bits.
+    GspObstOne ob1;
+    {
+        auto rfl_d = [](double v) -> double {
+            return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+        };
+        const bool one = __builtin_amdgcn_readfirstlane(obl->n) == 1;
+        ob1.n = one ? 1 : 0;
+        ob1.kind[0] = one ? __builtin_amdgcn_readfirstlane(obl->kind[0]) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ob1.par[0][q] = one ? rfl_d(obl->par[0][q]) : 0.0;
+        ob1.gmeta = a.ob->gmeta; ob1.gdata = a.ob->gdata;      // (kernel-argument memory: scalar loads, once)
+    }
+    const bool one_ob = ob1.n == 1;
     const int n_own = ih[0], n_halo = ih[1], row_base = ih[2], halo_base = ih[3], ent_base = ih[4], ob_base = ih[5], ent_count = ih[7];
     const int L = n_own + n_halo, C = a.C;
     LdsD *xl = (LdsD *)(smem + 1024);
@@ -174,23 +238,29 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     auto fetch_halo = [&](int cp, int par, unsigned want, bool keep_old) {
         const int h0 = ih[21 + cp], h1 = ih[21 + cp + 1];
         for (int hh = h0 + t; hh < h1; hh += kGspT) {
-            const int off = ((hl[hh] * 2 + par) * 3) * 16;
+            const int off = gsp_box_off(hl[hh], par, 0, a.n_box), off1 = gsp_box_off(hl[hh], par, 1, a.n_box), off2 = gsp_box_off(hl[hh], par, kGspGran - 1, a.n_box);
             v4u g0, g1, g2;
             unsigned spins = 0;
+#if ADMM_GSP_PACK2
             while (true) {
-                // (kGspStagger >= 0, an experiment: TWO polls under way, the second a fraction of a round trip behind the first)
-                g0 = gsp_load(rbox, off); g1 = gsp_load(rbox, off + 16); g2 = gsp_load(rbox, off + 32);
-                if constexpr (kGspStagger >= 0) {
-                    __builtin_amdgcn_s_sleep(kGspStagger);
-                    const v4u h0 = gsp_load(rbox, off), h1 = gsp_load(rbox, off + 16), h2 = gsp_load(rbox, off + 32);
-                    if (gsp_ok(g0, want) && gsp_ok(g1, want) && gsp_ok(g2, want)) break;
-                    if (gsp_ok(h0, want) && gsp_ok(h1, want) && gsp_ok(h2, want)) { g0 = h0; g1 = h1; g2 = h2; break; }
-                } else if (gsp_ok(g0, want) && gsp_ok(g1, want) && gsp_ok(g2, want)) break;
+                g0 = gsp_load(rbox, off); g1 = gsp_load(rbox, off1);
+                if (gsp_ok3(g0, g1, want)) break;
                 if (poll_failed(spins)) break;
             }
+#else
+            while (true) {
+                g0 = gsp_load(rbox, off); g1 = gsp_load(rbox, off1); g2 = gsp_load(rbox, off2);
+                if (gsp_ok(g0, want) && gsp_ok(g1, want) && gsp_ok(g2, want)) break;
+                if (poll_failed(spins)) break;
+            }
+#endif
             const int j = 3 * (n_own + hh);
             if (keep_old) { xo[j] = xl[j]; xo[j + 1] = xl[j + 1]; xo[j + 2] = xl[j + 2]; }
+#if ADMM_GSP_PACK2
+            { double v3[3]; gsp_unpack3(g0, g1, v3); xl[j] = v3[0]; xl[j + 1] = v3[1]; xl[j + 2] = v3[2]; }
+#else
             xl[j] = gsp_val(g0); xl[j + 1] = gsp_val(g1); xl[j + 2] = gsp_val(g2);
+#endif
         }
     };
     // cur = sum_k Ahat(row, k) x_k of row i of colour c (entries in CSR order: the sums of k_gs_color).  BOTH: also old = the same sum
@@ -246,27 +316,42 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     // row's residual of the PREVIOUS sweep before it moves (first colour: nothing has moved yet; middle colours: the neighbours that
     // have, by their parked values); 2 POST -- the residual of THIS sweep right after the update (last colour: every neighbour is
     // final).  Returns the thread's sum of squared residuals.
+#ifdef ADMM_GSP_PROF_FINE      // (experiments: where the time of "rows + publish" goes -- thread 0 of the profiled block, 100 MHz wall clock)
+    const bool proff = a.prof != nullptr && b == a.prof_block && t == 0;
+    unsigned long long pf[6] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull}, tf = 0ull;
+#define GSP_FLAP0() do { if (proff) tf = wall_clock64(); } while (0)
+#define GSP_FLAP(k) do { if (proff) { const unsigned long long now_ = wall_clock64(); pf[k] += now_ - tf; tf = now_; } } while (0)
+#else
+#define GSP_FLAP0()
+#define GSP_FLAP(k)
+#endif
     auto sweep_colour = [&](int c, int par, unsigned stamp, int role, bool keep_old, bool first_sweep) -> double {
         const int r0 = ih[8 + c], n_c = ih[8 + c + 1] - r0;
         const bool both = role == 1 && c > 0;
         double rs = 0.0;
         for (int i = t; i < n_c; i += kGspT) {
             double LUx[3], LUo[3];
-            row_sum(c, i, LUx, LUo, both);
+            GSP_FLAP0();
+            // (everything the update needs besides the row sum is asked for FIRST: LDS answers in order, so these arrive under the row sum's round trips
+            // instead of forming three more of their own behind it)
             const int li = r0 + i;
+            const int pflag = pl[li], o = ol[li];
             const double bi[3] = {bl[3 * li], bl[3 * li + 1], bl[3 * li + 2]};
             const double aii[3] = {al[3 * li], al[3 * li + 1], al[3 * li + 2]};
             const double iaii[3] = {il[3 * li], il[3 * li + 1], il[3 * li + 2]};
             const double cx[3] = {xl[3 * li], xl[3 * li + 1], xl[3 * li + 2]};
+            row_sum(c, i, LUx, LUo, both);
+            GSP_FLAP(0);
             double nx[3];
             if (role == 1) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { const double r = bi[q] - fma(aii[q], cx[q], both ? LUo[q] : LUx[q]); rs = fma(r, r, rs); }
             }
-            if (pl[li] == 2) {      // slide pin (normal-only constraint): the unrelaxed value projected onto the pin's plane, every sweep
+            GSP_FLAP(1);
+            if (pflag == 2) {      // slide pin (normal-only constraint): the unrelaxed value projected onto the pin's plane, every sweep
                 const int v = a.orig[row_base + li];
                 gs_pin_value(2, a.pin_xyz + 3 * (size_t)v, a.pin_nrm + 3 * (size_t)v, bi, LUx, iaii, nx);
-            } else if (pl[li]) { // :111-117
+            } else if (pflag) { // :111-117
 #ifdef ADMM_GSP_OB_GLOBAL
                 if (true) {
 #else
@@ -283,19 +368,29 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
 #ifdef ADMM_GSP_OB_GLOBAL      // (same-box A/B only: the obstacles through the argument pointer, as before round 4's second session)
             else if (gs_relax(*a.ob, a.omega, bi, LUx, iaii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
+            else if (!has_ob) {      // no passive obstacle in the scene (uniform): :210 alone
+#pragma unroll
+                for (int q = 0; q < 3; ++q) nx[q] = fma(a.omega, (bi[q] - LUx[q]) * iaii[q], (1.0 - a.omega) * cx[q]);
+            }
+            else if (one_ob) { if (gs_relax(ob1, a.omega, bi, LUx, iaii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
             else if (gs_relax(*obl, a.omega, bi, LUx, iaii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS add: rows projected, counted below)
 #endif
+            GSP_FLAP(2);
+            if (o >= 0) {      // the neighbours wait for these: out first, the block's own copies after
+                const int off = gsp_box_off(ob_base + o, par, 0, a.n_box), off1 = gsp_box_off(ob_base + o, par, 1, a.n_box);
+#if ADMM_GSP_PACK2
+                { v4u ga, gb; gsp_pack3(nx, stamp, ga, gb); gsp_store(rbox, off, ga); gsp_store(rbox, off1, gb); }
+#else
+                gsp_store(rbox, off, gsp_pack(nx[0], stamp)); gsp_store(rbox, off1, gsp_pack(nx[1], stamp)); gsp_store(rbox, gsp_box_off(ob_base + o, par, 2, a.n_box), gsp_pack(nx[2], stamp));
+#endif
+            }
             if (keep_old) { xo[3 * li] = cx[0]; xo[3 * li + 1] = cx[1]; xo[3 * li + 2] = cx[2]; }
             xl[3 * li] = nx[0]; xl[3 * li + 1] = nx[1]; xl[3 * li + 2] = nx[2];
-            const int o = ol[li];
-            if (o >= 0) {
-                const int off = (((ob_base + o) * 2 + par) * 3) * 16;
-                gsp_store(rbox, off, gsp_pack(nx[0], stamp)); gsp_store(rbox, off + 16, gsp_pack(nx[1], stamp)); gsp_store(rbox, off + 32, gsp_pack(nx[2], stamp));
-            }
             if (role == 2) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) { const double r = bi[q] - fma(aii[q], nx[q], LUx[q]); rs = fma(r, r, rs); }
             }
+            GSP_FLAP(3);
         }
         return rs;
     };
@@ -407,15 +502,22 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                 lap(1);
                 if (block_failed()) return -2;
                 if (tests && ctl[4 + 2 * ((p + 1) & 1)] != 0) return ctl[5 + 2 * ((p + 1) & 1)];   // the verdict of the PREVIOUS phase: that sweep met the tolerance
-                if (parked >= 0) { publish_parked(parked, stamp0 + (unsigned)parked); parked = -1; }
+                GSP_FLAP0();
+                // (the parked partial is not needed before the verdict two sweeps on: with C >= 2 thread 0 sends it AFTER its row of this phase -- the next
+                // park is a barrier away -- instead of in front of it, where the whole block's phase waited for it)
+                if (C < 2 && parked >= 0) { publish_parked(parked, stamp0 + (unsigned)parked); parked = -1; }
                 if (judge) verdict_wave(sweep - 2, stamp0 + (unsigned)(sweep - 2), pre, p & 1);
+                GSP_FLAP(4);
                 int role = 0;
                 if (tests) {
                     if (C >= 2 && c == C - 1) role = 2;
                     else if (sweep > 0) role = 1;
                 }
                 racc += sweep_colour(c, sweep & 1, stamp0 + (unsigned)p, role, keep_old, sweep == 0);
+                GSP_FLAP0();
+                if (parked >= 0) { publish_parked(parked, stamp0 + (unsigned)parked); parked = -1; }
                 if (tests && sweep > 0 && c == c_pub) { park(racc); parked = sweep - 1; racc = 0.0; }
+                GSP_FLAP(5);
                 lap(2);
             }
         }
@@ -481,6 +583,9 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     }
     __syncthreads();
     if (t == 0 && a.proj && ctl[10] > 0) atomicAdd(a.proj, (unsigned long long)ctl[10]);
+#ifdef ADMM_GSP_PROF_FINE
+    if (proff) { for (int k = 0; k < 6; ++k) a.prof[8 + k] += pf[k]; }
+#endif
     if (b == 0 && t == 0) {
         *a.done = conv_flag; *a.sweeps = failed_tests;      // (stored, not accumulated: the launch needs no memset in front of it)
         atomicAdd(a.total, failed_tests);

@@ -1217,6 +1217,34 @@ __global__ __launch_bounds__(MAXT) void k_sync_probe(Oc2Args a, int n, int mode,
             }
             __syncthreads();
             acc = acc * 0.5 + bc[0] * 1e-300;
+        } else if (mode >= 2) {
+            // (experiments, ADMM_HIP_PROBE_A2A_MODE: the block's 7 sums as ONE 64-byte chunk [parity][block][8] -- whole sectors of its own -- instead of
+            // [parity][sum][block], where four blocks share a sector.  2: read sum by sum (64-byte stride); 3: read chunk-wise, one 16-byte load per thread;
+            // 4: as 3, stored with four 16-byte stores)
+            ++be;
+            const int par = (int)(be & 1u);
+            if (mode == 4) { if (tid < 4) oc_store_sc1(rs_p, ((par * a.G + (int)blockIdx.x) * 8 + 2 * tid) * 8, acc, acc); }
+            else if (tid < 8) oc_store_sc1(rs_p, ((par * a.G + (int)blockIdx.x) * 8 + tid) * 8, acc);
+            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) break;
+            if (mode == 2) {
+                if (wv < 7) {
+                    double sm = 0.0;
+                    for (int g = lane; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_p, ((par * a.G + g) * 8 + wv) * 8);
+                    sm = wave_sum(sm);
+                    if (lane == 0) bc[wv] = sm;
+                }
+            } else {
+                double sm = 0.0;
+                for (int o = tid; o < 4 * a.G; o += T) {
+                    union { double d[2]; v4u v; } g;
+                    g.v = __builtin_amdgcn_raw_buffer_load_b128(rs_p, par * a.G * 64 + o * 16, 0, 16);
+                    sm += g.d[0] + g.d[1];
+                }
+                sm = wave_sum(sm);
+                if (lane == 0 && wv < 7) bc[wv] = sm;
+            }
+            __syncthreads();
+            acc = acc * 0.5 + bc[0] * 1e-300;
         } else {
             ++ph;
             LdsD *o = vec + wv * 64;
