@@ -1765,6 +1765,8 @@ void launch_gs_persist(admm_hip_ctx *c, const double *b, double *x) {
             if (h[6]) fprintf(stderr, "[gsp_prof] shader clock during the solves: %.0f MHz\n", 100.0 * (double)h[5] / (double)h[6]);
             if (h[8]) fprintf(stderr, "[gsp_prof] rows + publish in detail (-DADMM_GSP_PROF_FINE): row sums %.2f  own row's data + residual before %.2f  pin / relax %.2f  stores + granules + residual after %.2f  "
                                       "parked partial + judge %.2f  park %.2f us per phase\n", k * h[8], k * h[9], k * h[10], k * h[11], k * h[12], k * h[13]);
+            if (h[14]) { const double ps = k * (double)c->gs_max_iters * (double)c->gsp_C;     // per solve of max_iters sweeps
+                         fprintf(stderr, "[gsp_prof] per solve: fill %.2f  phases %.2f  end of the last sweep + verdicts + write-back %.2f us\n", ps * h[14], ps * h[6], ps * ((double)h[15] - (double)h[6])); }
             (void)hipMemsetAsync(c->gsp_prof.p, 0, sizeof(h), st);
         }
     }

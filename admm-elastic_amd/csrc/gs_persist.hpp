@@ -125,11 +125,34 @@ __device__ __forceinline__ int gsp_box_off(int node, int par, int k, int n_nodes
 #endif
 }
 
-struct GspObstOne { int n; int kind[1]; double par[1][4]; const double *gmeta, *gdata; };      // Obstacles with room for one (k_gs_persist: in SGPRs)
+#ifndef ADMM_GSP_PIPE
+#define ADMM_GSP_PIPE 0
+#endif
+#ifndef ADMM_GSP_PIPE_D
+#define ADMM_GSP_PIPE_D 6
+#endif
+#ifndef ADMM_GSP_PIPE_D0
+#define ADMM_GSP_PIPE_D0 0
+#endif
+constexpr int kGspPipeD = ADMM_GSP_PIPE_D, kGspPipeD0 = ADMM_GSP_PIPE_D0, kGspPipeChain = 10;      // (s_sleep periods of 64 clocks; checks in the chain)
+struct GspSet2 { v4u g[2]; };
+__device__ __forceinline__ void gsp_poll2(__amdgpu_buffer_rsrc_t rs, int off, int off1, GspSet2 &p) { p.g[0] = gsp_load(rs, off); p.g[1] = gsp_load(rs, off1); }
+template <int K> __device__ __forceinline__ bool gsp_chain2(__amdgpu_buffer_rsrc_t rs, int off, int off1, unsigned want, const GspSet2 &pa, const GspSet2 &pb, GspSet2 &out) {
+    if (gsp_ok3(pa.g[0], pa.g[1], want)) { out = pa; return true; }
+    if constexpr (K == 0) { out = pa; return false; }
+    else {
+        GspSet2 pn;
+        gsp_poll2(rs, off, off1, pn);
+        return gsp_chain2<K - 1>(rs, off, off1, want, pb, pn, out);
+    }
+}
 
 __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = (int)blockIdx.x, t = (int)threadIdx.x;
+#ifdef ADMM_GSP_PROF_FINE
+    const unsigned long long tk0 = wall_clock64();
+#endif
     // ---- LDS: scratch | x [L][3] | x of the previous sweep [L][3] | b [n_own][3] | a_ii [n_own][3] | values | columns | outbox node per
     //      row | halo source | pin flags | 1 / a_ii [n_own][3]   (host_setup.hpp: gsp_lds_bytes computes the same offsets)
     LdsD *scr = (LdsD *)smem;                       // [0..3] wave sums of the residual partial, [8] |b|^2 of the block
@@ -152,21 +175,6 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     __syncthreads();
     if (ctl[0]) return;
     const bool has_ob = __builtin_amdgcn_readfirstlane(obl->n) > 0;      // (uniform, in an SGPR: no LDS round trip per row for scenes without obstacles)
-    // ONE obstacle (the usual scene: a floor): count, kind and parameters live in SGPRs -- read from the LDS copy they were three dependent round trips
-    // in front of every row's update.  gs_relax is a template on the obstacle container: the same arithmetic, the same bits.
-    GspObstOne ob1;
-    {
-        auto rfl_d = [](double v) -> double {
-            return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-        };
-        const bool one = __builtin_amdgcn_readfirstlane(obl->n) == 1;
-        ob1.n = one ? 1 : 0;
-        ob1.kind[0] = one ? __builtin_amdgcn_readfirstlane(obl->kind[0]) : 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ob1.par[0][q] = one ? rfl_d(obl->par[0][q]) : 0.0;
-        ob1.gmeta = a.ob->gmeta; ob1.gdata = a.ob->gdata;      // (kernel-argument memory: scalar loads, once)
-    }
-    const bool one_ob = ob1.n == 1;
     const int n_own = ih[0], n_halo = ih[1], row_base = ih[2], halo_base = ih[3], ent_base = ih[4], ob_base = ih[5], ent_count = ih[7];
     const int L = n_own + n_halo, C = a.C;
     LdsD *xl = (LdsD *)(smem + 1024);
@@ -241,7 +249,25 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
             const int off = gsp_box_off(hl[hh], par, 0, a.n_box), off1 = gsp_box_off(hl[hh], par, 1, a.n_box), off2 = gsp_box_off(hl[hh], par, kGspGran - 1, a.n_box);
             v4u g0, g1, g2;
             unsigned spins = 0;
-#if ADMM_GSP_PACK2
+#if ADMM_GSP_PACK2 && ADMM_GSP_PIPE >= 2
+            // (experiment, OFF: ADMM_GSP_PIPE polls in flight, the oldest checked and re-issued -- a CHAIN of checks, not a loop: register sets carried
+            // around a back edge are copied there, and the copy waits for every poll in flight.  profiles/r06_gs_granules_ab.txt)
+            bool have = false;
+            {
+                GspSet2 p0, p1, out;
+                if (kGspPipeD0 > 0) __builtin_amdgcn_s_sleep(kGspPipeD0);
+                gsp_poll2(rbox, off, off1, p0);
+                __builtin_amdgcn_s_sleep(kGspPipeD);
+                gsp_poll2(rbox, off, off1, p1);
+                have = gsp_chain2<kGspPipeChain>(rbox, off, off1, want, p0, p1, out);
+                g0 = out.g[0]; g1 = out.g[1];
+            }
+            while (!have) {
+                g0 = gsp_load(rbox, off); g1 = gsp_load(rbox, off1);
+                if (gsp_ok3(g0, g1, want)) break;
+                if (poll_failed(spins)) break;
+            }
+#elif ADMM_GSP_PACK2
             while (true) {
                 g0 = gsp_load(rbox, off); g1 = gsp_load(rbox, off1);
                 if (gsp_ok3(g0, g1, want)) break;
@@ -332,16 +358,14 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
         for (int i = t; i < n_c; i += kGspT) {
             double LUx[3], LUo[3];
             GSP_FLAP0();
-            // (everything the update needs besides the row sum is asked for FIRST: LDS answers in order, so these arrive under the row sum's round trips
-            // instead of forming three more of their own behind it)
+            row_sum(c, i, LUx, LUo, both);
+            GSP_FLAP(0);
             const int li = r0 + i;
             const int pflag = pl[li], o = ol[li];
             const double bi[3] = {bl[3 * li], bl[3 * li + 1], bl[3 * li + 2]};
             const double aii[3] = {al[3 * li], al[3 * li + 1], al[3 * li + 2]};
             const double iaii[3] = {il[3 * li], il[3 * li + 1], il[3 * li + 2]};
             const double cx[3] = {xl[3 * li], xl[3 * li + 1], xl[3 * li + 2]};
-            row_sum(c, i, LUx, LUo, both);
-            GSP_FLAP(0);
             double nx[3];
             if (role == 1) {
 #pragma unroll
@@ -372,7 +396,6 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) nx[q] = fma(a.omega, (bi[q] - LUx[q]) * iaii[q], (1.0 - a.omega) * cx[q]);
             }
-            else if (one_ob) { if (gs_relax(ob1, a.omega, bi, LUx, iaii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
             else if (gs_relax(*obl, a.omega, bi, LUx, iaii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS add: rows projected, counted below)
 #endif
             GSP_FLAP(2);
@@ -503,9 +526,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                 if (block_failed()) return -2;
                 if (tests && ctl[4 + 2 * ((p + 1) & 1)] != 0) return ctl[5 + 2 * ((p + 1) & 1)];   // the verdict of the PREVIOUS phase: that sweep met the tolerance
                 GSP_FLAP0();
-                // (the parked partial is not needed before the verdict two sweeps on: with C >= 2 thread 0 sends it AFTER its row of this phase -- the next
-                // park is a barrier away -- instead of in front of it, where the whole block's phase waited for it)
-                if (C < 2 && parked >= 0) { publish_parked(parked, stamp0 + (unsigned)parked); parked = -1; }
+                if (parked >= 0) { publish_parked(parked, stamp0 + (unsigned)parked); parked = -1; }
                 if (judge) verdict_wave(sweep - 2, stamp0 + (unsigned)(sweep - 2), pre, p & 1);
                 GSP_FLAP(4);
                 int role = 0;
@@ -515,7 +536,6 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                 }
                 racc += sweep_colour(c, sweep & 1, stamp0 + (unsigned)p, role, keep_old, sweep == 0);
                 GSP_FLAP0();
-                if (parked >= 0) { publish_parked(parked, stamp0 + (unsigned)parked); parked = -1; }
                 if (tests && sweep > 0 && c == c_pub) { park(racc); parked = sweep - 1; racc = 0.0; }
                 GSP_FLAP(5);
                 lap(2);
@@ -550,6 +570,9 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     const unsigned stamp0 = a.seq * 4096u + 1u;         // phases (and partials) of the first run: stamp0 + p; of a replay: stamp0 + 2048 + p
     const int n = a.max_sweeps;
     int failed_tests = n, conv_flag = 0;                // what the counters get: sweeps whose test failed, done
+#ifdef ADMM_GSP_PROF_FINE
+    const unsigned long long tk1 = wall_clock64();
+#endif
     const int first = run(n, a.check != 0, stamp0);
     if (first == -2) return;
     if (first >= 0) { failed_tests = first; conv_flag = 1; }
@@ -584,7 +607,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     __syncthreads();
     if (t == 0 && a.proj && ctl[10] > 0) atomicAdd(a.proj, (unsigned long long)ctl[10]);
 #ifdef ADMM_GSP_PROF_FINE
-    if (proff) { for (int k = 0; k < 6; ++k) a.prof[8 + k] += pf[k]; }
+    if (proff) { for (int k = 0; k < 6; ++k) a.prof[8 + k] += pf[k]; a.prof[14] += tk1 - tk0; a.prof[15] += wall_clock64() - tk1; }
 #endif
     if (b == 0 && t == 0) {
         *a.done = conv_flag; *a.sweeps = failed_tests;      // (stored, not accumulated: the launch needs no memset in front of it)

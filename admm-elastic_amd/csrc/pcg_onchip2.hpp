@@ -101,6 +101,9 @@ constexpr int kOc2DeflMax = 32;
 #define ADMM_OC2_LB(t) (t)          // (ISA experiments: another register budget)
 #endif
 constexpr int kOc2Scratch = 4096;
+#ifndef ADMM_OC2_REC_CHUNK
+#define ADMM_OC2_REC_CHUNK 1        // 1: a block's seven sums are ONE 64-byte chunk of the record buffer ([parity][block][8]: two sectors of its own), read
+#endif                              // chunk-wise; 0 (rounds 2-5): [parity][sum][block] -- four blocks on four XCDs share every sector, a wave per sum reads it back
 #ifndef ADMM_OC2_TRUST_SAMPLE
 #define ADMM_OC2_TRUST_SAMPLE 1      // the trust rule checked on a sample of solves, revoked when a check fails
 #endif
@@ -428,14 +431,60 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
             }
         }, std::integral_constant<int, 3>());
         const int tid = otid();
+#if ADMM_OC2_REC_CHUNK
+        if (tid < 8) oc_store_sc1(rs_p, ((par * a.G + (int)blockIdx.x) * 8 + tid) * 8, res24[tid]);      // (res24[7] = 0: the chunk is written whole)
+#else
         if (tid < 7) oc_store_sc1(rs_p, ((par * 8 + tid) * a.G + (int)blockIdx.x) * 8, res24[tid]);
+#endif
         else if (with_v && tid >= 8 && tid < 8 + 3 * kOcSubK) {
             const int ag = (tid - 8) / 3, j = (tid - 8) - 3 * ag;
             oc_store_sc1(rs_c, ((par * 3 + j) * a.ncp + (int)blockIdx.x * kOcSubK + ag) * 8, res24[tid]);
         }
     };
     // after the grid barrier: bc[0..nsum) = the global sums of the records of parity par
+#if ADMM_OC2_REC_CHUNK
+    // The records of all blocks, chunk-wise (round 6): the buffer of one parity is 4 G units of 16 bytes (unit o = sums 2 (o & 3), 2 (o & 3) + 1 of block
+    // o >> 2); thread tid takes the units tid, tid + T, ... -- T is a multiple of four, so all of them carry the SAME pair of sums -- one or two
+    // 16-byte loads per thread instead of four 8-byte loads per lane of seven waves, every sector asked for once per block.  rec_reduce then adds
+    // up the pairs: over the lanes of equal lane & 3 inside each row of sixteen (two DPP shifts), over the four rows (two lane exchanges), over the
+    // waves (LDS, the idle local vector).  The same order in every block: the same bits, the same decisions.
+    union RecUnit { double d[2]; v4u v; };
+    auto rec_issue = [&](int par, RecUnit &g0, RecUnit &g1) {
+        const int tid = otid(), n16 = 4 * a.G;
+        g0.d[0] = 0.0; g0.d[1] = 0.0; g1.d[0] = 0.0; g1.d[1] = 0.0;
+        if (tid < n16) g0.v = __builtin_amdgcn_raw_buffer_load_b128(rs_p, par * a.G * 64 + tid * 16, 0, 16);
+        if (tid + T < n16) g1.v = __builtin_amdgcn_raw_buffer_load_b128(rs_p, par * a.G * 64 + (tid + T) * 16, 0, 16);
+    };
+    auto rec_reduce = [&](int par, int nsum, const RecUnit &g0, const RecUnit &g1) {      // -> bc[0..nsum), valid after the NEXT block barrier
+        double sa = g0.d[0] + g1.d[0], sb = g0.d[1] + g1.d[1];
+        const int tid = otid(), n16 = 4 * a.G;
+        for (int o = tid + 2 * T; o < n16; o += T) {      // (blocks of few waves)
+            RecUnit g; g.v = __builtin_amdgcn_raw_buffer_load_b128(rs_p, par * a.G * 64 + o * 16, 0, 16);
+            sa += g.d[0]; sb += g.d[1];
+        }
+        sa += dpp_f64<0x114>(sa); sb += dpp_f64<0x114>(sb);      // row_shr:4 (lanes without a source add 0)
+        sa += dpp_f64<0x118>(sa); sb += dpp_f64<0x118>(sb);      // row_shr:8 -> lanes 12..15 of a row: the row's total of their pair
+        sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64);
+        sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64);
+        double *red2 = (double *)(smem + kOc2Scratch);      // [waves][8], in the idle local vector
+        const int lane = tid & 63;
+        if (lane >= 12 && lane < 16) { red2[(tid >> 6) * 8 + 2 * (lane & 3)] = sa; red2[(tid >> 6) * 8 + 2 * (lane & 3) + 1] = sb; }
+        __syncthreads();
+        if (tid < nsum) {
+            double sm = 0.0;
+            for (int k = 0; k < nw; ++k) sm += red2[k * 8 + tid];
+            bc[tid] = sm;
+        }
+    };
+#endif
     auto reduce_records = [&](int par, int nsum) {
+#if ADMM_OC2_REC_CHUNK
+        RecUnit g0, g1;
+        rec_issue(par, g0, g1);
+        rec_reduce(par, nsum, g0, g1);
+        __syncthreads();
+        return;
+#endif
         const int tid = otid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         for (int k = wv; k < nsum; k += nw) {
             double rec[4];
@@ -465,16 +514,25 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
     auto reduce_and_coarse = [&](int par, int nsum, const AinvRows &ar) {
         double rec[4] = {0.0, 0.0, 0.0, 0.0}, cn[2][3];
         const int tid = otid(), lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if ADMM_OC2_REC_CHUNK
+        RecUnit g0, g1;
+        if (nsum > 0) rec_issue(par, g0, g1);
+#else
         if (wv < nsum) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { const int g = lane + 64 * i; rec[i] = g < a.G ? oc_load_sc1_f64(rs_p, ((par * 8 + wv) * a.G + g) * 8) : 0.0; }
         }
+#endif
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int c = tid + it * T;
 #pragma unroll
             for (int j = 0; j < 3; ++j) cn[it][j] = c < a.nc ? oc_load_sc1_f64(rs_c, ((par * 3 + j) * a.ncp + c) * 8) : 0.0;
         }
+#if ADMM_OC2_REC_CHUNK
+        if (nsum > 0) rec_reduce(par, nsum, g0, g1);      // (bc is read behind the block barriers of the coarse rows below)
+        (void)rec; (void)lane; (void)wv;
+#else
         if (wv < nsum) {
             double sm = (rec[0] + rec[1]) + (rec[2] + rec[3]);
             for (int g = lane + 256; g < a.G; g += 64) sm += oc_load_sc1_f64(rs_p, ((par * 8 + wv) * a.G + g) * 8);
@@ -487,6 +545,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
             sm = wave_sum(sm);
             if (lane == 0) bc[k] = sm;
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);     // (the record sums are done and their registers free before the coarse rows start)
         block_sums_gen([&](int h, double *q8) {
 #pragma unroll
@@ -1207,6 +1266,26 @@ __global__ __launch_bounds__(MAXT) void k_sync_probe(Oc2Args a, int n, int mode,
         if (mode == 0) {
             ++be;
             const int par = (int)(be & 1u);
+#if ADMM_OC2_REC_CHUNK      // (as k_pcg2: publish_record, rec_issue, rec_reduce)
+            if (tid < 8) oc_store_sc1(rs_p, ((par * a.G + (int)blockIdx.x) * 8 + tid) * 8, acc);
+            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) break;
+            {
+                double sa = 0.0, sb = 0.0;
+                for (int o = tid; o < 4 * a.G; o += T) {
+                    union { double d[2]; v4u v; } g;
+                    g.v = __builtin_amdgcn_raw_buffer_load_b128(rs_p, par * a.G * 64 + o * 16, 0, 16);
+                    sa += g.d[0]; sb += g.d[1];
+                }
+                sa += dpp_f64<0x114>(sa); sb += dpp_f64<0x114>(sb);
+                sa += dpp_f64<0x118>(sa); sb += dpp_f64<0x118>(sb);
+                sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64);
+                sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64);
+                double *red2 = (double *)(smem + kOc2Scratch);
+                if (lane >= 12 && lane < 16) { red2[wv * 8 + 2 * (lane & 3)] = sa; red2[wv * 8 + 2 * (lane & 3) + 1] = sb; }
+                __syncthreads();
+                if (tid < 7) { double sm = 0.0; for (int k = 0; k < nw; ++k) sm += red2[k * 8 + tid]; bc[tid] = sm; }
+            }
+#else
             if (tid < 7) oc_store_sc1(rs_p, ((par * 8 + tid) * a.G + (int)blockIdx.x) * 8, acc);
             if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) break;
             if (wv < 7) {
@@ -1215,6 +1294,7 @@ __global__ __launch_bounds__(MAXT) void k_sync_probe(Oc2Args a, int n, int mode,
                 sm = wave_sum(sm);
                 if (lane == 0) bc[wv] = sm;
             }
+#endif
             __syncthreads();
             acc = acc * 0.5 + bc[0] * 1e-300;
         } else if (mode >= 2) {
