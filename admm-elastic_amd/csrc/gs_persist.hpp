@@ -129,7 +129,7 @@ __device__ __forceinline__ int gsp_box_off(int node, int par, int k, int n_nodes
 #define ADMM_GSP_PIPE 0
 #endif
 #ifndef ADMM_GSP_PIPE_D
-#define ADMM_GSP_PIPE_D 6
+#define ADMM_GSP_PIPE_D 3
 #endif
 #ifndef ADMM_GSP_PIPE_D0
 #define ADMM_GSP_PIPE_D0 0
@@ -146,6 +146,12 @@ template <int K> __device__ __forceinline__ bool gsp_chain2(__amdgpu_buffer_rsrc
         return gsp_chain2<K - 1>(rs, off, off1, want, pb, pn, out);
     }
 }
+
+struct GspObstOne {      // Obstacles with exactly one entry (k_gs_persist: in SGPRs; kernels.hpp: ObstSingle)
+    static constexpr bool kSingle = true;
+    static constexpr int n = 1;
+    int kind[1]; double par[1][4]; const double *gmeta, *gdata;
+};
 
 __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,6 +181,19 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     __syncthreads();
     if (ctl[0]) return;
     const bool has_ob = __builtin_amdgcn_readfirstlane(obl->n) > 0;      // (uniform, in an SGPR: no LDS round trip per row for scenes without obstacles)
+    // ONE obstacle (the usual scene: a floor): kind and parameters in SGPRs -- read from the LDS copy they are three dependent round trips in front of
+    // every row's update.  gs_relax is a template on the obstacle container: the same arithmetic, the same bits.
+    GspObstOne ob1;
+    const bool one_ob = __builtin_amdgcn_readfirstlane(obl->n) == 1;
+    {
+        auto rfl_d = [](double v) -> double {
+            return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+        };
+        ob1.kind[0] = one_ob ? __builtin_amdgcn_readfirstlane(obl->kind[0]) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ob1.par[0][q] = one_ob ? rfl_d(obl->par[0][q]) : 0.0;
+        ob1.gmeta = a.ob->gmeta; ob1.gdata = a.ob->gdata;      // (kernel-argument memory: scalar loads, once)
+    }
     const int n_own = ih[0], n_halo = ih[1], row_base = ih[2], halo_base = ih[3], ent_base = ih[4], ob_base = ih[5], ent_count = ih[7];
     const int L = n_own + n_halo, C = a.C;
     LdsD *xl = (LdsD *)(smem + 1024);
@@ -191,10 +210,57 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
     const int lane = t & 63, wv = t >> 6;
 
     // ---- fill: matrix, right-hand side, diagonal, lists (once), x (again before a replay) ----
-    for (int i = t; i < ent_count; i += kGspT) { vl[i] = a.vals[(size_t)ent_base + i]; cl[i] = a.cols[(size_t)ent_base + i]; }
+    // Round 6: BATCHED.  The lists are two levels deep (row -> vertex -> b, m, x, pin) and the fill of 52-77 blocks is pure latency: written as
+    // plain loops it was one dependent round trip after the other (6-8 us per solve, ADMM_GSP_PROF_FINE).  Now every thread first asks for the
+    // first level of its rows and halo entries t, t + 256, streams the matrix through registers eight entries at a time while that is under way,
+    // then asks for the whole second level at once.  Rows / entries beyond 512 per block take the plain loops (same order of the |b|^2 sum).
     {
+        constexpr int NS = 2;
+        int vo[NS], oi[NS], vh[NS], hb[NS]; double dg[NS]; bool ok_o[NS], ok_h[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int i = t + kGspT * u;
+            ok_o[u] = i < n_own; ok_h[u] = i < n_halo;
+            vo[u] = ok_o[u] ? a.orig[row_base + i] : 0; dg[u] = ok_o[u] ? a.diag[row_base + i] : 0.0; oi[u] = ok_o[u] ? a.out_idx[row_base + i] : -1;
+            vh[u] = ok_h[u] ? a.halo_orig[halo_base + i] : 0; hb[u] = ok_h[u] ? a.halo_box[halo_base + i] : 0;
+        }
+        for (int i0 = t; i0 < ent_count; i0 += 8 * kGspT) {
+            double v8[8]; unsigned short c8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + kGspT * u; const bool ok = i < ent_count; v8[u] = ok ? a.vals[(size_t)ent_base + i] : 0.0; c8[u] = ok ? a.cols[(size_t)ent_base + i] : (unsigned short)0; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + kGspT * u; if (i < ent_count) { vl[i] = v8[u]; cl[i] = c8[u]; } }
+        }
+        double bq[NS][3], mq[NS][3], xq[NS][3], xh[NS][3]; int pf[NS];
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            pf[u] = (ok_o[u] && a.pin_flag) ? a.pin_flag[vo[u]] : 0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                bq[u][q] = ok_o[u] ? a.b[3 * (size_t)vo[u] + q] : 0.0; mq[u][q] = ok_o[u] ? a.m[3 * (size_t)vo[u] + q] : 1.0; xq[u][q] = ok_o[u] ? a.x[3 * (size_t)vo[u] + q] : 0.0;
+                xh[u][q] = ok_h[u] ? a.x[3 * (size_t)vh[u] + q] : 0.0;
+            }
+        }
         double bb = 0.0;
-        for (int i = t; i < n_own; i += kGspT) {
+#pragma unroll
+        for (int u = 0; u < NS; ++u) {
+            const int i = t + kGspT * u;
+            if (ok_o[u]) {
+                ol[i] = oi[u]; pl[i] = (unsigned char)pf[u];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double bi = bq[u][q], aq = dg[u] + mq[u][q];
+                    bl[3 * i + q] = bi; al[3 * i + q] = aq; il[3 * i + q] = 1.0 / aq; xl[3 * i + q] = xq[u][q];
+                    bb = fma(bi, bi, bb);
+                }
+            }
+            if (ok_h[u]) {
+                hl[i] = hb[u];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) xl[3 * (n_own + i) + q] = xh[u][q];
+            }
+        }
+        for (int i = t + NS * kGspT; i < n_own; i += kGspT) {
             const int v = a.orig[row_base + i];
             const double d = a.diag[row_base + i];
             ol[i] = a.out_idx[row_base + i];
@@ -203,14 +269,19 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
             for (int q = 0; q < 3; ++q) {
                 const double bi = a.b[3 * (size_t)v + q];
                 const double aq = d + a.m[3 * (size_t)v + q];
-                bl[3 * i + q] = bi; al[3 * i + q] = aq; il[3 * i + q] = 1.0 / aq;
+                bl[3 * i + q] = bi; al[3 * i + q] = aq; il[3 * i + q] = 1.0 / aq; xl[3 * i + q] = a.x[3 * (size_t)v + q];
                 bb = fma(bi, bi, bb);
             }
+        }
+        for (int i = t + NS * kGspT; i < n_halo; i += kGspT) {
+            hl[i] = a.halo_box[halo_base + i];
+            const int v = a.halo_orig[halo_base + i];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xl[3 * (n_own + i) + q] = a.x[3 * (size_t)v + q];
         }
         bb = wave_sum(bb);
         if (lane == 0) scr[4 + wv] = bb;
     }
-    for (int i = t; i < n_halo; i += kGspT) hl[i] = a.halo_box[halo_base + i];
     auto load_x = [&]() {
         for (int i = t; i < n_own; i += kGspT) {
             const int v = a.orig[row_base + i];
@@ -223,8 +294,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
             for (int q = 0; q < 3; ++q) xl[3 * (n_own + i) + q] = a.x[3 * (size_t)v + q];
         }
     };
-    load_x();
-    __syncthreads();
+    __syncthreads();      // (x came with the fill; load_x: before a replay)
     if (t == 0) scr[8] = scr[4] + scr[5] + scr[6] + scr[7];     // |b|^2 of the block's rows (constant during the solve)
 
     auto give_up = [&]() {      // (one thread) tell everybody, and the host
@@ -396,6 +466,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
 #pragma unroll
                 for (int q = 0; q < 3; ++q) nx[q] = fma(a.omega, (bi[q] - LUx[q]) * iaii[q], (1.0 - a.omega) * cx[q]);
             }
+            else if (one_ob) { if (gs_relax(ob1, a.omega, bi, LUx, iaii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
             else if (gs_relax(*obl, a.omega, bi, LUx, iaii, cx, nx)) __hip_atomic_fetch_add(&ctl[10], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS add: rows projected, counted below)
 #endif
             GSP_FLAP(2);

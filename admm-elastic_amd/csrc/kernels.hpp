@@ -1289,9 +1289,17 @@ __device__ __forceinline__ void obstacle_payload(const OB &ob, int j, const doub
         }
     }
 }
+// (a container that holds exactly ONE obstacle says so -- `static constexpr bool kSingle = true` -- and is read with a constant index: its count, kind
+// and parameters then stay in (scalar) registers; indexed by the loop variable they would live in scratch memory)
+template <class OB, class = void> struct ObstSingle { static constexpr bool value = false; };
+template <class OB> struct ObstSingle<OB, decltype((void)OB::kSingle)> { static constexpr bool value = OB::kSingle; };
 template <class OB>
 __device__ __forceinline__ bool passive_hit(const OB &ob, const double *x, double *n, double *p) {
     double best = 1.7976931348623157e308; // Payload ctor (src/Collider.hpp:73)
+    if constexpr (ObstSingle<OB>::value) {
+        obstacle_payload(ob, 0, x, best, n, p);
+        return best < 0.0;
+    }
     for (int j = 0; j < ob.n; ++j) {
         obstacle_payload(ob, j, x, best, n, p);
         if (best < 0.0) return true; // src/Collider.hpp:143-148: first object with dx < 0 wins
