@@ -1785,7 +1785,10 @@ hipError_t plan_gs_persist(admm_hip_ctx *c) {
     const int cus = prop.multiProcessorCount;
     const int lds_max = (int)std::min<size_t>(prop.sharedMemPerBlock, 160 * 1024);
     const char *rt = getenv("ADMM_HIP_GS_ROWS");
-    const int rows_target = rt ? std::max(32, atoi(rt)) : 384;
+    // (rows per block: 384 through round 5; with the two-granule / whole-sector hand-off of round 6 a phase no longer pays per granule and smaller
+    // blocks -- fewer granules to wait for, a shorter fill -- win: cube100k_gs 96 / 128 / 192 / 256 / 320 / 384 / 448 rows = 5 407 / 5 584 / 5 858 /
+    // 5 773 / 5 702 / 5 298 / 5 142 ADMM it/s, profiles/r06_gs_rows_per_block.txt; bodies beyond 49 k vertices fill all CUs either way)
+    const int rows_target = rt ? std::max(32, atoi(rt)) : kGspRowsTarget;
     std::vector<int32_t> col32(c->color_h.begin(), c->color_h.end());
     admm_host::GsPlan P = admm_host::build_gs_plan(c->Ahat, c->n_colors, col32.data(), cus, rows_target, lds_max);
     if (!P.ok) return hipSuccess;
@@ -3862,7 +3865,7 @@ int admm_host_gs_plan_sweeps(const admm_hip_desc *d, int32_t n_colors, const int
     admm_host::Csr A = admm_host::assemble_Ahat(d->n_verts, dt, d->n_tets, d->tet_idx, d->tet_Binv, d->tet_weight, d->n_tris,
                                                 d->tri_idx, d->tri_rest, d->tri_weight, 0, d->pin_vert, 0.0);
     if (d->n_bends > 0) A = admm_host::add_stencil_terms(A, dt, d->n_bends, d->bend_idx, d->bend_coef, d->bend_weight);      // (the matrix admm_hip_create plans for)
-    const admm_host::GsPlan P = admm_host::build_gs_plan(A, n_colors, color, max_blocks > 0 ? max_blocks : 256, rows_target > 0 ? rows_target : 384, 160 * 1024);
+    const admm_host::GsPlan P = admm_host::build_gs_plan(A, n_colors, color, max_blocks > 0 ? max_blocks : 256, rows_target > 0 ? rows_target : kGspRowsTarget, 160 * 1024);
     if (!P.ok) return fail(ADMM_HIP_ERR_ARG, "gs_plan_sweeps: no plan (too many colours, or a block does not fit the LDS)");
     const int G = P.G, C = P.C, H = admm_host::kGspHdr;
     if (stats) { stats[0] = G; stats[1] = C; stats[2] = P.lds_bytes; stats[3] = P.max_halo; stats[4] = P.max_nbr; stats[5] = P.max_rows; }

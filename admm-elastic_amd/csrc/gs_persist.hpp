@@ -38,7 +38,7 @@
 
 namespace admm_k {
 
-constexpr int kGspMaxCK = 12, kGspHdrK = 64, kGspT = 256;
+constexpr int kGspMaxCK = 12, kGspHdrK = 64, kGspT = 256, kGspRowsTarget = 192;
 constexpr unsigned kGspSpin = 3000000u;
 typedef __attribute__((address_space(3))) unsigned short LdsU16;
 typedef __attribute__((address_space(3))) int LdsI32;
