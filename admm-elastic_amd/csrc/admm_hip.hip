@@ -1790,12 +1790,23 @@ hipError_t plan_gs_persist(admm_hip_ctx *c) {
     // 5 773 / 5 702 / 5 298 / 5 142 ADMM it/s, profiles/r06_gs_rows_per_block.txt; bodies beyond 49 k vertices fill all CUs either way)
     const int rows_target = rt ? std::max(32, atoi(rt)) : kGspRowsTarget;
     std::vector<int32_t> col32(c->color_h.begin(), c->color_h.end());
-    admm_host::GsPlan P = admm_host::build_gs_plan(c->Ahat, c->n_colors, col32.data(), cus, rows_target, lds_max);
-    if (!P.ok) return hipSuccess;
-    if ((e = hipFuncSetAttribute((const void *)k_gs_persist, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes)) != hipSuccess) return e;
+    // Blocks: one per CU.  (ADMM_HIP_GS_BLOCKS_PER_CU=2, an experiment of round 6: two per CU for bodies with more than cus x rows_target rows -- the
+    // 200 k-triangle cloth as 512 blocks of 197 rows instead of 256 of 393.  Measured: 3 452 -> 2 850 ADMM it/s; two waves per SIMD stretch every
+    // row's chain and the block barrier (0.03 -> 0.27 us).  Every block of a persistent kernel must be resident at once: the occupancy query decides,
+    // a plan that does not fit two per CU is rebuilt for one.  profiles/r06_gs_rows_per_block.txt)
+    const char *bpc = getenv("ADMM_HIP_GS_BLOCKS_PER_CU");
+    int want_per_cu = bpc ? std::max(1, std::min(2, atoi(bpc))) : 1;
+    admm_host::GsPlan P;
     int per_cu = 0;
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gs_persist, kGspT, P.lds_bytes)) != hipSuccess) return e;
-    if (per_cu < 1 || P.G > cus) return hipSuccess;      // every block must be resident at once
+    for (;;) {
+        P = admm_host::build_gs_plan(c->Ahat, c->n_colors, col32.data(), cus * want_per_cu, rows_target, lds_max);
+        if (!P.ok) { if (want_per_cu > 1) { want_per_cu = 1; continue; } return hipSuccess; }
+        if ((e = hipFuncSetAttribute((const void *)k_gs_persist, hipFuncAttributeMaxDynamicSharedMemorySize, P.lds_bytes)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gs_persist, kGspT, P.lds_bytes)) != hipSuccess) return e;
+        if (per_cu >= 1 && P.G <= cus * std::min(per_cu, want_per_cu)) break;
+        if (want_per_cu > 1) { want_per_cu = 1; continue; }
+        return hipSuccess;      // every block must be resident at once
+    }
     if ((e = c->gsp_hdr.upload(std::vector<int>(P.hdr.begin(), P.hdr.end()))) != hipSuccess) return e;
     if ((e = c->gsp_orig.upload(std::vector<int>(P.orig.begin(), P.orig.end()))) != hipSuccess) return e;
     if ((e = c->gsp_out.upload(std::vector<int>(P.out_idx.begin(), P.out_idx.end()))) != hipSuccess) return e;

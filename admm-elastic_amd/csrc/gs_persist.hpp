@@ -512,7 +512,7 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
         }
     };
     // The residual test of sweep k from all blocks' partials; every block adds the same numbers in the same order: identical
-    // verdicts.  Wave 0: lane l takes blocks l, l + 64, l + 128, l + 192.  `pre`: granules loaded earlier (their latency hidden behind
+    // verdicts.  Wave 0: lane l takes blocks l, l + 64, l + 128, l + 192 (, ...).  `pre`: granules loaded earlier (their latency hidden behind
     // the halo hand-off); whatever has not arrived yet is polled.  All threads call; one block barrier.
     auto verdict = [&](int k, unsigned sp, v4u (*pre)[2], bool have_pre) -> bool {
         if (t < 64) {
@@ -532,6 +532,17 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                     }
                     r2 += gsp_val(g0); b2 += gsp_val(g1);
                 }
+            }
+            for (int j = t + 256; j < a.G; j += 64) {      // (more than 256 blocks: two per CU)
+                const int off = ((j * 4 + (k & 3)) * 2) * 16;
+                v4u g0, g1;
+                unsigned spins = 0;
+                while (true) {
+                    g0 = gsp_load(rpart, off); g1 = gsp_load(rpart, off + 16);
+                    if (gsp_ok(g0, sp) && gsp_ok(g1, sp)) break;
+                    if (poll_failed(spins)) break;
+                }
+                r2 += gsp_val(g0); b2 += gsp_val(g1);
             }
             r2 = wave_sum(r2); b2 = wave_sum(b2);
             if (t == 0) ctl[1] = (r2 / b2 < a.tol2) ? 1 : 0;
@@ -559,6 +570,17 @@ __global__ __launch_bounds__(kGspT) void k_gs_persist(GspArgs a) {
                 }
                 r2 += gsp_val(g0); b2 += gsp_val(g1);
             }
+        }
+        for (int j = (t & 63) + 256; j < a.G; j += 64) {      // (more than 256 blocks: not loaded ahead)
+            const int off = ((j * 4 + (k & 3)) * 2) * 16;
+            v4u g0, g1;
+            unsigned spins = 0;
+            while (true) {
+                g0 = gsp_load(rpart, off); g1 = gsp_load(rpart, off + 16);
+                if (gsp_ok(g0, sp) && gsp_ok(g1, sp)) break;
+                if (poll_failed(spins)) break;
+            }
+            r2 += gsp_val(g0); b2 += gsp_val(g1);
         }
         r2 = wave_sum(r2); b2 = wave_sum(b2);
         if ((t & 63) == 0 && r2 / b2 < a.tol2) { ctl[5 + 2 * q] = k; ctl[4 + 2 * q] = 1; }
