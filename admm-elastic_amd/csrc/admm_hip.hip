@@ -238,6 +238,9 @@ struct admm_hip_ctx {
     SellDev big_A; DevBuf<int> big_orig; DevBuf<float> big_ainv;
     DevBuf<double> big_mass, big_dinv, big_cwt, big_xi, big_r, big_u, big_w, big_p, big_s, big_part, big_cvec, big_rho, big_dots; DevBuf<int> big_tick;
     long long big_solves = 0;
+    bool defl_use_resid = true;    // launch_deflation after a launch-path solve: the solve's own final residual (ADMM_HIP_DEFL_RESID=0 at create: b - A x again)
+    bool big_rfin_valid = false;   // c->cg_u holds D^-1 (final residual) of the launch-path solve that has just returned (launch_deflation)
+    int big_its_hist[32] = {};    // iterations the launch-path solve at position s of the previous frame needed (first chunk of the next one)
     int big_row_lo = 0, big_row_hi = 0x7fffffff, big_nif = 0; DevBuf<int> big_if_rows; DevBuf<double> big_ifbuf;      // distributed solve: owned internal rows, interface rows
     // end projection of every PCG solve on soft modes (admm_hip_set_soft_modes; kernels.hpp: k_defl_*)
     int defl_k = 0, defl_every = 1; bool defl_now = true, defl_fused = false; DevBuf<double> defl_Z, defl_Ginv, defl_part, defl_y, defl_rec; DevBuf<float> defl_Zint;
@@ -943,6 +946,7 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
         if (int r = comm_allreduce(c, c->cg_u.p, (size_t)c->n3)) return r;
         c->last_launched_iters = launched;
         c->big_solves += 1;
+        c->big_rfin_valid = true;      // (cg_u = D^-1 r_final, assembled over the ranks)
         return 0;
     }
     hipLaunchKernelGGL(k_big_gather, dim3(nbr), dim3(256), 0, st, a);
@@ -951,9 +955,18 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
     hipLaunchKernelGGL(k_big_coarse, dim3(c->big_G), dim3(kBigVecT), 0, st, a, -1);
     volatile int *sig = c->h_sig;
     int launched = 0, chunks = 0;
-    const int chunk = 8;      // (iterations launched behind a converged one are no-ops, but 3 launches each)
+    // Iterations launched behind a converged one are no-ops, but three launches each, and the host learns of convergence one chunk late.  Fixed
+    // chunks of 8 cost a late solve of an ADMM frame (1-5 iterations) 11-15 idle iterations = 33-45 empty launches.  Since round 6 the FIRST chunk
+    // is what the solve at the same position of the previous frame needed (+ 1: the iteration that reports convergence), the chunks behind it
+    // are short (an iteration is >= 70 us of kernels at these sizes; the host needs ~ 20 us to see a mark and launch the next chunk).
+    // ADMM_HIP_BIG_CHUNK=8: the fixed chunks of round 5 (A/B).
+    static const int fixed_chunk = [] { const char *e = getenv("ADMM_HIP_BIG_CHUNK"); return e ? std::max(1, atoi(e)) : 0; }();
+    static const int tail_chunk = [] { const char *e = getenv("ADMM_HIP_BIG_TAIL"); return e ? std::max(1, atoi(e)) : 2; }();
+    const int pos = std::min(std::max(c->rc_iter, 0), (int)(sizeof(c->big_its_hist) / sizeof(c->big_its_hist[0])) - 1);
+    const int first = fixed_chunk ? fixed_chunk : (c->big_its_hist[pos] > 0 ? c->big_its_hist[pos] + 1 : 8);
+    bool seen = false;
     while (launched < max_iters) {
-        const int n = std::min(chunk, max_iters - launched);
+        const int n = std::min(fixed_chunk ? fixed_chunk : (chunks == 0 ? first : tail_chunk), max_iters - launched);
         for (int it = launched; it < launched + n; ++it) {
             hipLaunchKernelGGL(k_big_spmv, dim3(c->big_NBt), dim3(256), 0, st, a, it);
             hipLaunchKernelGGL(k_big_vec, dim3(c->big_G), dim3(kBigVecT), 0, st, a, it, (it == launched + n - 1) ? 1 : 0);
@@ -966,12 +979,15 @@ int launch_pcg_big(admm_hip_ctx *c, const double *b, double *x, int max_iters) {
             const int need = c->marks_expected - 1;
             long spins = 0;
             while (sig[1] < need) { if (++spins > 2000000000L) return -1; }
-            if (sig[0] == a.seq) break;
+            if (sig[0] == a.seq) { seen = true; break; }
         }
     }
+    if (seen) c->big_its_hist[pos] = std::max(1, (int)sig[3]);      // (the iteration the device converged at: written in front of sig[0])
+    else if (launched >= max_iters) c->big_its_hist[pos] = 0;       // (ran to the cap: nothing learnt)
     hipLaunchKernelGGL(k_big_scatter, dim3(nbr), dim3(256), 0, st, a, launched & 1);
     c->last_launched_iters = launched;
     c->big_solves += 1;
+    c->big_rfin_valid = true;          // (cg_u = D^-1 r_final: launch_deflation)
     return 0;
 }
 
@@ -1030,9 +1046,18 @@ int launch_pcg(admm_hip_ctx *c, const double *b, double *x, int max_iters, const
 }
 
 // End projection of a finished solve on the soft modes (kernels.hpp: k_defl_*)
-void launch_deflation(admm_hip_ctx *c, const double *b, double *x) {
+// have_resid: x is the iterate a launch-path solve has just returned and c->cg_u still holds D^-1 times ITS final residual (k_big_scatter): the
+// projection takes the residual from there instead of forming b - A x again (ADMM_HIP_DEFL_RESID=0: always the product -- A/B, tests).
+void launch_deflation(admm_hip_ctx *c, const double *b, double *x, bool have_resid = false) {
     hipStream_t st = c->stream;
     const int NB = c->NB, k = c->defl_k;
+    if (have_resid && c->defl_use_resid) {
+        const int NBd = (c->nv + 256 * kDeflRV - 1) / (256 * kDeflRV);
+        hipLaunchKernelGGL(k_defl_dots_r, dim3(NBd), dim3(256), 0, st, c->nv, c->cg_u.p, c->dinv.p, k, c->defl_Z.p, c->defl_part.p, NBd);
+        hipLaunchKernelGGL(k_defl_solve, dim3(1), dim3(1024), 0, st, k, c->defl_part.p, NBd, c->defl_Ginv.p, c->defl_y.p);
+        hipLaunchKernelGGL(k_defl_apply, dim3(blocks_for(c->nv)), dim3(256), 0, st, c->nv, k, c->defl_Z.p, c->defl_y.p, x);
+        return;
+    }
     hipLaunchKernelGGL(k_defl_dots, dim3(NB), dim3(256), 0, st, sell_arg(c->A), c->m.p, b, x, k, c->defl_Z.p, c->nv, c->defl_part.p, NB);
     hipLaunchKernelGGL(k_defl_solve, dim3(1), dim3(1024), 0, st, k, c->defl_part.p, NB, c->defl_Ginv.p, c->defl_y.p);
     hipLaunchKernelGGL(k_defl_apply, dim3(blocks_for(c->nv)), dim3(256), 0, st, c->nv, k, c->defl_Z.p, c->defl_y.p, x);
@@ -1049,10 +1074,11 @@ int launch_pcg_recycled(admm_hip_ctx *c, const double *b, double *x) {
     // solve (mask 3) or the third (mask 6) it costs more than it saves.  Three small launches (k_defl_*), ~0.1 ms per frame.
     if (c->defl_start && !c->defl_start_hold && c->defl_k > 0 && c->defl_now && c->rc_iter < 31 && ((c->defl_start >> c->rc_iter) & 1)) launch_deflation(c, b, x);
     c->defl_armed = false;
+    c->big_rfin_valid = false;
     const int rc = launch_pcg_recycled_impl(c, b, x);
     // (fused into k_pcg2's epilogue when the on-chip kernel ran WITH it -- launch_pcg2 says so: a solve that went there without the recycled
     // basis, ADMM_HIP_NO_RECYCLE=1, or down the launch path gets the separate kernels)
-    if (rc == 0 && c->defl_k > 0 && c->defl_now && !c->defl_armed) launch_deflation(c, b, x);
+    if (rc == 0 && c->defl_k > 0 && c->defl_now && !c->defl_armed) launch_deflation(c, b, x, c->big_rfin_valid);
     return rc;
 }
 int launch_pcg_recycled_impl(admm_hip_ctx *c, const double *b, double *x) {
@@ -2453,6 +2479,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     c->create_xyz = d->vert_xyz;
     { const char *e = getenv("ADMM_HIP_BIG"); c->big_allowed = !(e && e[0] == '0'); }
     { const char *e = getenv("ADMM_HIP_DEFL_START"); if (e) c->defl_start = atoi(e); }
+    { const char *e = getenv("ADMM_HIP_DEFL_RESID"); c->defl_use_resid = !(e && e[0] == '0'); }
     { const char *e = getenv("ADMM_HIP_DEFL_DBG"); if (e) c->defl_dbg = atoi(e); }      // (experiments; bit 3 = the recycled pair carries the soft step: 9.28 -> 8.93 iterations per solve, +1 % ADMM it/s, 200-frame drift 3.9e-6 -> 6.1e-6: off)
     if (d->vert_xyz && d->linsolver != 1) c->xyz_h.assign(d->vert_xyz, d->vert_xyz + c->n3);      // (the launch-path two-level PCG plans lazily)
     {   // distributed solve of ONE body (ADMM_HIP_DIST_SOLVE=1, element-block partition): contiguous vertex rows per rank, 64-aligned

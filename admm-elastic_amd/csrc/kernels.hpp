@@ -1189,13 +1189,60 @@ __global__ __launch_bounds__(256) void k_defl_dots(SellA A, const double *__rest
     __syncthreads();
     for (int o = threadIdx.x; o < 3 * k; o += 256) part[(size_t)o * NB + blockIdx.x] = (lds[0][o] + lds[1][o]) + (lds[2][o] + lds[3][o]);
 }
+// The same partial sums from a residual the caller ALREADY HAS (round 6): after a launch-path solve the PCG's own final residual is in memory as
+// u = D^-1 r (k_big_scatter; what k_rc_record builds the recycled pair from), so the end projection needs no matrix-vector product of its own --
+// at 2 M tets k_defl_dots is 79 us, 45 of them the product (profiles/r06_launch_path_fixed_costs.txt).  Four vertices per thread, the loads
+// of eight modes x four vertices in flight, one wave sum per mode and axis; a quarter of the partials for k_defl_solve to add up.
+constexpr int kDeflRV = 4;
+__global__ __launch_bounds__(256) void k_defl_dots_r(int nv, const double *__restrict__ u, const double *__restrict__ dinv, int k, const double *__restrict__ Z,
+                                                     double *__restrict__ part, int NBd) {
+    __shared__ double lds[4][3 * kDeflMax];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int v0 = blockIdx.x * (256 * kDeflRV) + threadIdx.x;
+    double r[kDeflRV][3];
+#pragma unroll
+    for (int i = 0; i < kDeflRV; ++i) {
+        const int v = v0 + 256 * i;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r[i][j] = v < nv ? u[3 * (size_t)v + j] / dinv[3 * (size_t)v + j] : 0.0;
+    }
+    for (int q0 = 0; q0 < k; q0 += 8) {
+        double z[kDeflRV][8];
+#pragma unroll
+        for (int i = 0; i < kDeflRV; ++i) {
+            const int v = v0 + 256 * i;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) z[i][m] = (v < nv && q0 + m < k) ? Z[(size_t)(q0 + m) * nv + v] : 0.0;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (q0 + m < k) {
+                double t[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < kDeflRV; ++i) { t[0] = fma(z[i][m], r[i][0], t[0]); t[1] = fma(z[i][m], r[i][1], t[1]); t[2] = fma(z[i][m], r[i][2], t[2]); }
+                const double t0 = wave_sum(t[0]), t1 = wave_sum(t[1]), t2 = wave_sum(t[2]);
+                if (lane == 0) { lds[wv][3 * (q0 + m)] = t0; lds[wv][3 * (q0 + m) + 1] = t1; lds[wv][3 * (q0 + m) + 2] = t2; }
+            }
+        }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 3 * k; o += 256) part[(size_t)o * NBd + blockIdx.x] = (lds[0][o] + lds[1][o]) + (lds[2][o] + lds[3][o]);
+}
 // one block of 1024 threads: wave w adds up the quantities w, w + 16, ... over the blocks (lanes stride the blocks: fixed order), then y = G^-1 d
+// (round 6: eight partials of a lane in flight at a time -- as a plain loop every load waited for the one before it: 22 round trips per
+// quantity at 2 M tets, 35 us for a 24 x 24 solve; the order of the additions is unchanged)
 __global__ __launch_bounds__(1024) void k_defl_solve(int k, const double *__restrict__ part, int NB, const double *__restrict__ Ginv, double *__restrict__ y) {
     __shared__ double d[3 * kDeflMax];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);
     for (int q = wv; q < 3 * k; q += nw) {
         double t = 0.0;
-        for (int i = lane; i < NB; i += 64) t += part[(size_t)q * NB + i];
+        for (int i0 = lane; i0 < NB; i0 += 64 * 8) {
+            double v[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { const int i = i0 + 64 * w; v[w] = i < NB ? part[(size_t)q * NB + i] : 0.0; }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { const int i = i0 + 64 * w; if (i < NB) t += v[w]; }
+        }
         t = wave_sum(t);
         if (lane == 0) d[q] = t;
     }

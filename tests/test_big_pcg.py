@@ -87,6 +87,37 @@ def test_big_pcg_is_the_fall_back_after_a_barrier_time_out(monkeypatch):
     assert s.runtime_data().inner_iters < 4 * max(ref.runtime_data().inner_iters, 60)
 
 
+def test_launch_path_end_projection_takes_the_solves_own_residual(monkeypatch):
+    """Round 6: after a launch-path solve the soft-mode Galerkin step forms Z^T r from the PCG's own final residual (k_big_scatter leaves D^-1 r
+    in memory) instead of a second matrix-vector product.  Same step: the residual of the returned iterate is orthogonal to the modes, and the
+    iterate equals the one of the product form (ADMM_HIP_DEFL_RESID=0 at create) to the solver's round-off; whole frames agree too."""
+    sc = scenes.blob_scene(16, admm_iters=8, linsolver=0)
+    s = _solver(sc, monkeypatch, pcg_tol=1e-6, pcg_max_iters=2000, soft_modes=16)
+    monkeypatch.setenv("ADMM_HIP_DEFL_RESID", "0")
+    p = _solver(sc, monkeypatch, pcg_tol=1e-6, pcg_max_iters=2000, soft_modes=16)
+    monkeypatch.delenv("ADMM_HIP_DEFL_RESID")
+    plain = _solver(sc, monkeypatch, pcg_tol=1e-6, pcg_max_iters=2000)
+    rp, ci, va = s.system_matrix()
+    nv = len(sc.x)
+    K = (sp.csr_matrix((va, ci, rp), shape=(nv, nv)) + sp.diags(sc.m)).tocsr()
+    Z = s.get_soft_modes()
+    rng = np.random.default_rng(4)
+    xs = rng.standard_normal((nv, 3)) + 30.0 * (Z[:3].T @ rng.standard_normal((3, 3)))
+    b = K @ xs
+    x, _ = s.global_solve(b.ravel(), np.zeros(b.size))
+    xp, _ = p.global_solve(b.ravel(), np.zeros(b.size))
+    x0, _ = plain.global_solve(b.ravel(), np.zeros(b.size))
+    proj = np.abs(Z @ (b - K @ x.reshape(-1, 3))).max(); proj_plain = np.abs(Z @ (b - K @ x0.reshape(-1, 3))).max()
+    assert proj < 1e-6 * max(proj_plain, 1e-300) or proj < 1e-9 * np.abs(b).max(), (proj, proj_plain)
+    assert np.abs(x - xp).max() < 1e-9 * np.abs(xs).max(), np.abs(x - xp).max()
+    assert np.abs(x.reshape(-1, 3) - xs).max() < np.abs(x0.reshape(-1, 3) - xs).max()
+    for f in range(3):
+        s.step(); p.step()
+        assert s.runtime_data().unconverged_solves == 0
+    assert scenes.rel_err(s.m_x, p.m_x) < 1e-7, scenes.rel_err(s.m_x, p.m_x)
+    assert s.persistent_launches()["pcg"] == 0
+
+
 def test_body_beyond_the_chip_runs_the_two_level_launch_path():
     """A single body of ~1.6 M tets (more than 262 144 vertices): no on-chip plan exists; the launch-path two-level PCG serves it.  Two frames
     at the bench tolerance against the same path at 1e-12 (bar 1e-5, as for every workload), every solve converged."""
