@@ -96,6 +96,7 @@ SYMBOLS = [
     ("admm_hip_get_soft_modes", C.c_int, [C.c_void_p, c_int_p, c_double_p]),
     ("admm_hip_contact_totals", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("admm_hip_persistent_launches", C.c_int, [C.c_void_p] + [C.POINTER(C.c_int64)] * 3),
+    ("admm_hip_pcg_findings", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     ("admm_hip_probe_sync", C.c_int, [C.c_void_p, C.c_int32, c_double_p, c_double_p, C.POINTER(C.c_int64)]),
     ("admm_hip_time_local_launches", C.c_int, [C.c_void_p, C.c_int32]),
     ("admm_hip_local_launch_times", C.c_int, [C.c_void_p, C.POINTER(C.c_int64), c_double_p]),

@@ -238,6 +238,7 @@ struct admm_hip_ctx {
     SellDev big_A; DevBuf<int> big_orig; DevBuf<float> big_ainv;
     DevBuf<double> big_mass, big_dinv, big_cwt, big_xi, big_r, big_u, big_w, big_p, big_s, big_part, big_cvec, big_rho, big_dots; DevBuf<int> big_tick;
     long long big_solves = 0;
+    int oc_dbg_sm_off = -1;        // ADMM_HIP_OC_DEBUG: last seen state of counters[75] (block smoother switched off for the context)
     bool defl_use_resid = true;    // launch_deflation after a launch-path solve: the solve's own final residual (ADMM_HIP_DEFL_RESID=0 at create: b - A x again)
     bool big_rfin_valid = false;   // c->cg_u holds D^-1 (final residual) of the launch-path solve that has just returned (launch_deflation)
     int big_its_hist[32] = {};    // iterations the launch-path solve at position s of the previous frame needed (first chunk of the next one)
@@ -528,6 +529,9 @@ int oc_diagnostics(admm_hip_ctx *c, int seq) {
     if (c->oc_debug) {
         CgScal h;
         if (hipMemcpyAsync(&h, c->cg_scal.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        int sm_off[2] = {0, 0};
+        if (hipMemcpyAsync(sm_off, c->counters.p + 75, sizeof(sm_off), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return -1;
+        if (sm_off[0] != c->oc_dbg_sm_off) { c->oc_dbg_sm_off = sm_off[0]; fprintf(stderr, "[oc] seq %d: block smoother switched %s for the context (counters[75]), sm_b %.3g, trust revoked %d\n", h.seq, sm_off[0] ? "OFF" : "on", c->oc_sm_b, sm_off[1]); }
         fprintf(stderr, "[oc] seq %d iters %d (pipelined %d) verifications %d (last: true gamma / (tol^2 gamma_b) = %.2f) phases %d conv %d gamma %.3e %.3e %.3e gb %.3e %.3e %.3e\n", h.seq, h.iters, h.pad_,
                 (int)h.alpha[0], h.alpha[2], (int)h.alpha[1], h.converged, h.gamma[0], h.gamma[1], h.gamma[2], h.gamma_b[0], h.gamma_b[1], h.gamma_b[2]);
     }
@@ -1627,7 +1631,7 @@ int launch_uzawa(admm_hip_ctx *c, const double *b, double *x, int *iters) {
             ua.dbox = (v4u *)c->uzp_dbox.p; ua.sbox = (v4u *)c->uzp_sbox.p;
             ua.stamp0 = (++c->uzp_seq) * 1024u;      // (four stamps per iteration, < 250 iterations)
             ua.abort_word = c->uzp_abort.p; ua.sig = c->d_sig;
-            ua.iters_step = c->counters.p + 7; ua.applies_total = c->counters.p + 76;
+            ua.iters_step = c->counters.p + 7; ua.applies_total = c->counters.p + 78;      // ([76] is k_pcg2's "trust revoked" word: until round 6 the two shared it -- every Schur launch revoked the trust, a revocation reset the count)
             if (c->test_abort_uzp > 0 && (int)c->uzp_seq == c->test_abort_uzp)      // test hook: this launch finds its hand-off given up
                 (void)hipMemsetAsync(c->uzp_abort.p, 1, sizeof(unsigned), st);
             hipLaunchKernelGGL(k_uz_persist, dim3(NB), dim3(kUzpT), lds, st, ua);
@@ -2475,7 +2479,7 @@ static int create_impl(const admm_hip_desc *d, admm_hip_ctx **out) {
     HIP_TRY(c->cg_p.zero()); HIP_TRY(c->cg_s.zero());
     HIP_TRY(c->part.alloc(6 * (size_t)c->NB)); HIP_TRY(c->part_b.alloc(3 * (size_t)c->NB));
     HIP_TRY(c->cg_scal.alloc(2)); HIP_TRY(c->cg_scal.zero());
-    HIP_TRY(c->counters.alloc(8 + 64 + 8)); HIP_TRY(c->counters.zero());   // [72..74]: totals since create (on-chip PCG)
+    HIP_TRY(c->counters.alloc(8 + 64 + 8)); HIP_TRY(c->counters.zero());   // [72..74]: totals since create (on-chip PCG); [75] block smoother given up, [76] short-pass trust revoked, [77] failed sample checks (k_pcg2); [78] Schur products (k_uz_persist)
     c->create_xyz = d->vert_xyz;
     { const char *e = getenv("ADMM_HIP_BIG"); c->big_allowed = !(e && e[0] == '0'); }
     { const char *e = getenv("ADMM_HIP_DEFL_START"); if (e) c->defl_start = atoi(e); }
@@ -3575,6 +3579,13 @@ int admm_hip_compute_soft_modes(admm_hip_ctx *c, int32_t k, int32_t iters) {
     DevBuf<double> db, dx;
     HIP_TRY(db.alloc(c->n3)); HIP_TRY(dx.alloc(c->n3));
     int rcode = ADMM_HIP_OK;
+    // The solves below are not the scene's: from the second round on their right-hand sides are (nearly) eigenvectors, CG ends after one or two steps
+    // and runs on into rounding noise, where the recurrences' r . u can turn negative -- which k_pcg2 reads as "the preconditioner is not positive
+    // definite" and answers by giving up its block smoother FOR THE CONTEXT (counters[75]).  Until round 6 that is what happened to every context
+    // that computed its modes here: the bench body ran its ADMM loop with S = D^-1 (ADMM_HIP_OC_CHEB=0 and =2 gave the same 8.675 iterations per
+    // solve).  What these solves find out about the context (smoother given up, short-pass trust revoked) is put back afterwards.
+    int found0[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(found0, c->counters.p + 75, sizeof(found0), hipMemcpyDeviceToHost));
     for (int it = 0; it < iters && rcode == ADMM_HIP_OK; ++it) {
         if (!mgs(X)) { rcode = fail(ADMM_HIP_ERR_DEVICE, "compute_soft_modes: the subspace collapsed"); break; }
         for (int c0 = 0; c0 < k3 && rcode == ADMM_HIP_OK; c0 += 3) {      // Y = K^-1 X, three columns = the three axes of one solve
@@ -3631,6 +3642,8 @@ int admm_hip_compute_soft_modes(admm_hip_ctx *c, int32_t k, int32_t iters) {
         }
     }
     db.release(); dx.release();
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(c->counters.p + 75, found0, sizeof(found0), hipMemcpyHostToDevice));
     if (rcode != ADMM_HIP_OK) return rcode;
     c->rc_iter = 0; c->rc_prev_valid = 0; c->rc_prev2_valid = 0;      // (the recycled basis of the ADMM loop starts clean)
     return admm_hip_set_soft_modes(c, k, X.data());
@@ -3670,6 +3683,17 @@ int admm_hip_persistent_launches(const admm_hip_ctx *c, int64_t *pcg, int64_t *g
     return ADMM_HIP_OK;
 }
 
+int admm_hip_pcg_findings(admm_hip_ctx *c, int32_t *smoother_given_up, int32_t *trust_revoked, int64_t *failed_checks) {
+    if (!c) return fail(ADMM_HIP_ERR_ARG, "pcg_findings: NULL context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int h[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(h, c->counters.p + 75, sizeof(h), hipMemcpyDeviceToHost));
+    if (smoother_given_up) *smoother_given_up = h[0] != 0;
+    if (trust_revoked) *trust_revoked = h[1] != 0;
+    if (failed_checks) *failed_checks = h[2];
+    return ADMM_HIP_OK;
+}
 int admm_hip_probe_sync(admm_hip_ctx *c, int32_t n, double *us_all_to_all, double *us_exchange, int64_t *plan_stats) {
     if (!c || n < 1) return fail(ADMM_HIP_ERR_ARG, "probe_sync: bad input");
     if (us_all_to_all) *us_all_to_all = 0.0;
@@ -3992,7 +4016,7 @@ int admm_hip_uzawa_cache_stats(admm_hip_ctx *c, int64_t *columns, int64_t *colum
         int dev = 0;      // the persistent Schur launches count on the device
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMemcpy(&dev, c->counters.p + 76, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&dev, c->counters.p + 78, sizeof(int), hipMemcpyDeviceToHost));
         *schur_from_columns = c->uzc_applies + dev;
     }
     if (schur_by_pcg) *schur_by_pcg = c->uzc_pcg_solves;

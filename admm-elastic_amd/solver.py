@@ -642,6 +642,13 @@ class Solver:
         check(lib().admm_hip_persistent_launches(self._ctx, *[C.byref(x) for x in a]))
         return dict(zip(("pcg", "gs", "schur"), (x.value for x in a)))
 
+    def pcg_findings(self):
+        """admm_hip_pcg_findings: dict(smoother_given_up, trust_revoked, failed_checks) -- what the on-chip PCG holds against this context."""
+        self._need_ctx()
+        a = C.c_int32(0); b = C.c_int32(0); n = C.c_int64(0)
+        check(lib().admm_hip_pcg_findings(self._ctx, C.byref(a), C.byref(b), C.byref(n)))
+        return dict(smoother_given_up=bool(a.value), trust_revoked=bool(b.value), failed_checks=n.value)
+
     def probe_sync(self, n=200):
         """admm_hip_probe_sync: (us per all-to-all, us per vector exchange, plan statistics dict) of the on-chip PCG."""
         self._need_ctx()

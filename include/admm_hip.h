@@ -320,6 +320,14 @@ int admm_hip_contact_totals(admm_hip_ctx *ctx, int64_t *rows);
  * the context falls back to the launch-per-iteration kernels for good: the counts then stop growing (tests). */
 int admm_hip_persistent_launches(const admm_hip_ctx *ctx, int64_t *pcg, int64_t *gs, int64_t *schur);
 
+/* What the on-chip PCG (k_pcg2) has found out about this context since admm_hip_create and acts on for good (no reference counterpart; diagnostics,
+ * tests): *smoother_given_up -- a pipelined pass broke off with negative or non-finite sums far from convergence, later solves run with the Jacobi
+ * smoother instead of the block-local Chebyshev polynomial (slower, as exact); *trust_revoked -- a sampled verification of a short first pass
+ * failed, every later solve verifies its residual; *failed_checks -- how many such checks failed.  Any pointer may be NULL.  The solves of
+ * admm_hip_compute_soft_modes (right-hand sides that are nearly eigenvectors) do not count: their findings are put back (round 6: until then
+ * they switched the smoother off for every context that computed its modes).  Synchronises the stream. */
+int admm_hip_pcg_findings(admm_hip_ctx *ctx, int32_t *smoother_given_up, int32_t *trust_revoked, int64_t *failed_checks);
+
 /* Diagnostics of the on-chip PCG (linsolver 0 / 2; no reference counterpart): the latency floor of the two
  * synchronisations one CG iteration consists of, measured on this context's grid with the kernel's own primitives and
  * payloads but no arithmetic, as microseconds per repetition over n repetitions: the all-to-all (block record -> grid barrier

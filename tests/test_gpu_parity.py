@@ -616,6 +616,10 @@ def test_uzawa_cached_columns_equal_inner_solves(monkeypatch):
     assert st["schur_from_columns"] >= itg - 1 > 0 and st["schur_by_pcg"] == 0, (st, itg)    # (launched; those behind the stop are no-ops)
     xg2, _ = s.global_solve(b, x)                      # same active set: no new columns
     assert s.uzawa_cache_stats()["column_solves"] == st["column_solves"]
+    # (round 6: the persistent Schur kernel counted its products in the word k_pcg2 reads as "short-pass trust revoked" -- every contact scene
+    # verified every solve, and a real revocation reset the count)
+    f = s.pcg_findings()
+    assert s.persistent_launches()["schur"] > 0 and not f["trust_revoked"] and f["failed_checks"] == 0 and not f["smoother_given_up"], f
     monkeypatch.setenv("ADMM_HIP_UZ_CACHE", "0")
     s0 = sc.make_solver(pcg_tol=1e-12, pcg_max_iters=400)
     monkeypatch.delenv("ADMM_HIP_UZ_CACHE")

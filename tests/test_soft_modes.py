@@ -3,6 +3,8 @@ csrc/pcg_onchip2.hpp: the epilogue of k_pcg2, csrc/kernels.hpp: k_defl_* as sepa
 (src/LinearSolver.hpp:87-90); a PCG stopped on a residual norm leaves its error where the eigenvalues are small, and that error is what
 drifts over hundreds of frames (profiles/r05_drift_*).  The projection x += Z (Z^T K Z)^-1 Z^T (b - A x) is an exact Galerkin step:
 afterwards the residual is orthogonal to the modes whatever their accuracy."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -87,6 +89,32 @@ def test_fused_and_separate_projection_agree_over_frames_and_help_the_drift(monk
     print("12 frames at pcg_tol 1e-7: rel_err %.2e with the end projection, %.2e without" % (e_f, e_p))
     assert e_f < 0.5 * e_p
     assert fused.runtime_data().unconverged_solves == 0
+
+
+def test_block_smoother_survives_the_mode_computation(monkeypatch):
+    """Round 6: from their second round on the solves of admm_hip_compute_soft_modes have (nearly) eigenvectors as right-hand sides -- CG is done
+    after a step or two and runs on into rounding noise, where r . u of the recurrences can turn negative; k_pcg2 reads that as a preconditioner
+    that is not positive definite and gives up its block smoother for the context.  That is what every context with library-computed modes ran
+    with until round 6 (the bench body: 8.7 instead of 6.7 iterations per solve).  The findings of those solves are put back now: the smoother
+    is alive afterwards (admm_hip_pcg_findings), and at work (fewer iterations than with ADMM_HIP_OC_CHEB=0)."""
+    import bench
+    sc, nt, nv = bench.build_scene(bench.WORKLOADS["blob1m_mix"], int(os.environ.get("ADMM_TEST_SMOOTHER_N", "118")))
+    s = sc.make_solver(pcg_tol=7e-10, pcg_max_iters=1500, soft_modes=24)
+    assert s.persistent_launches()["pcg"] > 0
+    f = s.pcg_findings()
+    assert not f["smoother_given_up"] and not f["trust_revoked"], f
+    monkeypatch.setenv("ADMM_HIP_OC_CHEB", "0")
+    j = sc.make_solver(pcg_tol=7e-10, pcg_max_iters=1500, soft_modes=24)
+    monkeypatch.delenv("ADMM_HIP_OC_CHEB")
+    t0s, t0j = s.solve_totals(), j.solve_totals()
+    for _ in range(4):
+        s.step(); j.step()
+    its_s, its_j = s.solve_totals()[2] - t0s[2], j.solve_totals()[2] - t0j[2]
+    print("%d tets: %d PCG iterations in 4 frames with the block smoother, %d with S = D^-1" % (nt, its_s, its_j))
+    assert its_s < 0.93 * its_j, (its_s, its_j)
+    assert not s.pcg_findings()["smoother_given_up"]
+    assert scenes.rel_err(s.m_x, j.m_x) < 1e-6
+    s.close(); j.close()
 
 
 def test_soft_modes_argument_checks():
