@@ -710,7 +710,7 @@ hipError_t plan_pcg_onchip(admm_hip_ctx *c) {
                     const char *ch = getenv("ADMM_HIP_OC_CHEB"), *cr = getenv("ADMM_HIP_OC_CHEB_RATIO");
                     c->oc_sm_ab = 0.0; c->oc_sm_b = 0.0; c->oc_lam_bb = plan.lam_bb;
                     if (!(ch && ch[0] == '0') && plan.lam_bb > 0.0) {
-                        const double ratio = cr ? std::max(1.5, atof(cr)) : 16.0;
+                        const double ratio = cr ? std::max(1.5, atof(cr)) : 400.0;      // (16 until round 6's last session: with the wider interval 1-2.5 % fewer iterations on the 1 M-tet bodies, 200-frame drift unchanged -- profiles/r06_block_smoother_fix.txt)
                         // upper end of the interval: the plan's estimate of lambda_max(D^-1 A_bb) (power iterations from three
                         // starts, run until they stagnate) + 10 %, never above the plan's rigorous Gershgorin bound; the polynomial
                         // stays positive up to 1.125 x this value
