@@ -572,6 +572,23 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         for (int j = 0; j < 3; ++j) y[j] = prolong(ycur, j);                     // (start of a pass only)
         return true;
     };
+    // ... with the block smoother applied to the same vector BEHIND the barrier's latency (round 6: at the start of a solve S r sat in front of
+    // the coarse all-to-all, ~3 us on the critical path of every solve since the smoother is alive in every context)
+    auto coarse_apply_smooth = [&](const double *v, double *y, double *sv) -> bool {
+        ++be;
+        const int par = (int)(be & 1u);
+        const double z7[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        publish_record(z7, v, true, par);
+        AinvRows ar;
+        ainv_prefetch(ar);
+        oc2_barrier_arrive(bar);
+        smooth(v, sv);
+        if (!oc_barrier_wait(bar, be, a.G, ok_lds, a.sig)) return false;
+        reduce_and_coarse(par, 0, ar);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) y[j] = prolong(ycur, j);
+        return true;
+    };
     int iters = 0, pipe_iters = 0;
     bool conv = false, aborted = false;
     auto action = [&]() -> int { __syncthreads(); return __builtin_amdgcn_readfirstlane(ictl[2]); };
@@ -723,13 +740,12 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
             if (prof) a.prof[62 * 8 + 3] = wall_clock64();
 #pragma unroll
             for (int j = 0; j < 3; ++j) rr[j] = live ? ru[j] * fast_rcp(rd[j]) : 0.0;
-            smooth(rr, ru);
             if (two_level) {
                 double y[3];
-                if (!coarse_apply(rr, y)) { aborted = true; break; }
+                if (!coarse_apply_smooth(rr, y, ru)) { aborted = true; break; }
 #pragma unroll
                 for (int j = 0; j < 3; ++j) ru[j] += y[j];
-            }
+            } else smooth(rr, ru);
             // u to the neighbours (hand-off, no barrier), w = A u, then ONE record: the stop-test sums and P^T w
             if (prof) a.prof[62 * 8 + 4] = wall_clock64();
             ++ph; publish(ru);
@@ -744,7 +760,10 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
         {
             AinvRows ar0;
             if (two_level) ainv_prefetch(ar0);
-            if (!oc_barrier(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
+            // (S w for the first pass behind this barrier's latency, like S n in the iterations: start_pass(have_uw = true) finds it done)
+            oc2_barrier_arrive(bar);
+            smooth(rw, sw);
+            if (!oc_barrier_wait(bar, be, a.G, ok_lds, a.sig)) { aborted = true; break; }
             if (two_level) {
                 reduce_and_coarse((int)(be & 1u), 6, ar0);      // ... and y_w = Ac^-1 P^T w for the first pass
                 if (tid < 3 * kOcSubK) { yw[ywp + tid] = ycur[tid]; yz[tid] = 0.0; }
@@ -838,7 +857,7 @@ __global__ __launch_bounds__(ADMM_OC2_LB(MAXT)) ADMM_OC2_ATTR void k_pcg2(Oc2Arg
                     if (tid < 3 * kOcSubK) { yw[ywp + tid] = ycur[tid]; yz[tid] = 0.0; }
                     __syncthreads();
                 }
-                smooth(rw, sw);
+                if (!have_uw) smooth(rw, sw);      // (have_uw: formed behind the start phase's last barrier)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) sz[j] = 0.0;
                 return true;
