@@ -538,6 +538,9 @@ def main():
         "inner_iters_per_admm_iter": (inner_timed if inner_timed is not None else inner) / (iters * args.steps),
         "inner_iters_per_admm_iter_statistics_frames": inner / (iters * args.steps) if lean else None,
         "unconverged_solves_in_timed_region": unconv,
+        # what the on-chip PCG holds against this context (admm_hip_pcg_findings): until round 6's last session the soft-mode computation left every
+        # context that used it with `smoother_given_up` -- the headline ran with a Jacobi smoother.  All false / 0 is the healthy state.
+        "pcg_findings": (s.pcg_findings() if w["linsolver"] != 1 else None),
         "timed_region": ("frames issued without per-step statistics (one hipEvent pair around every local-step launch is the only instrumentation: "
                          "`roofline`); split / iteration counts from as many STATISTICS FRAMES right after, which take %.3f x the time of the timed ones "
                          "(`stats_frames_ms_per_step`)" % (stats_elapsed / elapsed)) if lean else "frames with per-step statistics",
